@@ -1,0 +1,162 @@
+"""CPU: pins the oracle (oracle/vpf_oracle.c + oracle/torch_oracle.py) against the
+fixtures captured from the imported reference (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+from oracle import torch_oracle as O
+
+PRE = ["u1024", "u2048", "d1024", "g1024", "c6_1000", "u256", "u512"]
+
+
+@pytest.mark.parametrize("tag", PRE)
+def test_preproc_bit_exact(tag):
+    g = Hh.golden(f"preproc_{tag}.npz")
+    seed, B, N, C, G, K = [int(v) for v in g["meta"]]
+    mode = {"d": "dups", "g": "grid"}.get(tag[0], "uniform")
+    pts = Hh.synth_points(seed, B, N, C, mode)
+    start = Hh.synth_start(seed, B, N)
+    idx = O.fps_indices(pts, start, G)
+    assert np.array_equal(idx.numpy(), g["fps_idx"])                      # FPS: bit-exact indices
+    nb, ct, kidx = O.divide_patches(pts, idx, K, True)
+    assert np.array_equal(ct.numpy(), g["centers"])
+    d = O.square_distance(ct, pts).numpy().view(np.uint32)
+    gb = g["sqdist_bits"]
+    assert np.array_equal(d[:, :gb.shape[1], :], gb)                      # distances: bitwise
+    assert np.array_equal(kidx.numpy(), g["knn_canonical"])               # canonical order
+    if bool(g["tie_free"]):                                               # vs raw topk: same SET
+        assert np.array_equal(np.sort(kidx.numpy(), -1), g["knn_raw_sorted"])
+    assert np.array_equal(nb.numpy(), g["neighbors"])                     # incl. the :36 axis quirk
+    # quirk sanity: members 0..2 centred, the rest absolute
+    raw = torch.gather(pts.unsqueeze(1).expand(B, G, N, C), 2, kidx.unsqueeze(-1).expand(B, G, K, C))
+    assert torch.equal(nb[:, :, 3:], raw[:, :, 3:]) and torch.equal(nb[:, :, :3], raw[:, :, :3] - ct.unsqueeze(2))
+
+
+def _arch(name, drops=(0.0, 0.0)):
+    a = Hh.ARCHS[name]
+    return O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"],
+                  atten_drop=drops[0], mlp_drop=drops[1]), a
+
+
+def _close(x, ref, rtol=2e-5, atol=2e-5):
+    x = x.detach().numpy() if torch.is_tensor(x) else x
+    np.testing.assert_allclose(x, ref, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1"])
+def test_models_vs_reference(name):
+    arch, a = _arch(name)
+    g = Hh.golden(f"model_{name}.npz")
+    B = 2
+    pc = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100)
+    im = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200)
+    pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
+    imgs = Hh.synth_images(400, B, a["img"], a["img"])
+    with torch.no_grad():
+        f, bb = O.pc_forward(pc, pts, start, arch, False)
+        fi, bbi = O.img_forward(im, imgs, arch, False)
+    _close(f, g["pc_eval_feats"]); _close(bb, g["pc_eval_backbone"])
+    _close(fi, g["img_eval_feats"]); _close(bbi, g["img_eval_backbone"])
+    # train mode (dropout 0) + loss + grads
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_{name}.json")))
+    pcp = {k: pc[k].clone().requires_grad_() for k in names["pc"]}
+    imp = {k: im[k].clone().requires_grad_() for k in names["img"]}
+    pc_sd = dict(pc); pc_sd.update(pcp)
+    im_sd = dict(im); im_sd.update(imp)
+    for k in list(pc_sd):
+        if "cross_attn_1." in k:
+            pc_sd[k] = pc_sd[k.replace("cross_attn_1.", "cross_attn_n.")]
+    for k in list(im_sd):
+        if "cross_attn_1." in k:
+            im_sd[k] = im_sd[k.replace("cross_attn_1.", "cross_attn_n.")]
+    bufs = {}
+    loss, l_im, l_cm = O.pretrain_losses(pc_sd, im_sd, pts[:B], pts[B:], imgs, start, arch, True,
+                                         O.Masks("off"), O.Masks("off"), bufs, {})
+    _close(np.array([loss.item(), l_im.item(), l_cm.item()]), g["loss"], 1e-5, 1e-5)
+    loss.backward()
+    for which, params, key in (("pc", pcp, "pc_grad"), ("img", imp, "img_grad")):
+        norms = np.array([params[k].grad.double().norm().item() for k in names[which]])
+        np.testing.assert_allclose(norms, g[key + "_norms"], rtol=2e-3, atol=1e-6)
+        heads = np.stack([torch.cat([params[k].grad.reshape(-1)[:8], torch.zeros(max(0, 8 - params[k].numel()))]).numpy()
+                          for k in names[which]])
+        np.testing.assert_allclose(heads, g[key + "_heads"], rtol=5e-3, atol=2e-5)
+    for k in ("latent_head.0.running_mean", "latent_head.0.running_var", "group2emb.first_conv.1.running_var"):
+        _close(bufs[k], g["pc_buf." + k])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1"])
+def test_stages_vs_reference(name):
+    arch, a = _arch(name)
+    g = Hh.golden(f"stages_{name}.npz")
+    B = 2
+    sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100)
+    pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
+    nb, ct, _ = O.divide_patches(pts, O.fps_indices(pts, start, arch.G), arch.K)
+    pre = "group2emb."
+    wk = [k for k in sd if k.startswith(pre) and not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    p = {k: sd[k].clone().requires_grad_() for k in wk}
+    s2 = dict(sd); s2.update(p)
+    bufs = {}
+    y = O.group2emb(s2, pre, nb, True, bufs)
+    R = Hh.synth_like(500, y.shape)
+    (y * R).sum().backward()
+    c1 = name == "c1"
+    _close(y[:, :8] if c1 else y, g["g2e_train"], 1e-4, 1e-4)
+    _close(bufs[pre + "first_conv.1.running_mean"], g["g2e_rm1"]); _close(bufs[pre + "first_conv.1.running_var"], g["g2e_rv1"])
+    _close(bufs[pre + "second_conv.1.running_mean"], g["g2e_rm2"]); _close(bufs[pre + "second_conv.1.running_var"], g["g2e_rv2"])
+    for k in wk:
+        ref = g["g2e_grad." + k[len(pre):]]
+        got = p[k].grad.reshape(-1)[:ref.size].reshape(ref.shape) if c1 and p[k].numel() > 4096 else p[k].grad
+        np.testing.assert_allclose(got.numpy(), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()))
+    with torch.no_grad():
+        ye = O.group2emb(sd, pre, nb, False)
+        _close(ye[:, :8] if c1 else ye, g["g2e_eval"], 1e-4, 1e-4)
+        _close(O.adapter(sd, "input_adapter.", pts)[:, :32], g["adapter"], 1e-4, 1e-5)
+        ps = O.pos_mlp(sd, "position_emb.", ct)
+        _close(ps[:, :8] if c1 else ps, g["pos"], 1e-4, 1e-5)
+    # CA / SA layers fwd + input grads
+    x = Hh.synth_like(600, (2 * B, arch.G, arch.D)).requires_grad_()
+    kv = Hh.synth_like(601, (2 * B, a["N"], arch.D)).requires_grad_()
+    m = O.Masks("off")
+    yca = O.ca_layer(sd, "encoder.cross_attn_1.", x, kv, arch, m, "ca")
+    Rl = Hh.synth_like(602, yca.shape)
+    (yca * Rl).sum().backward()
+    sl = (slice(None), slice(0, 8)) if c1 else (slice(None),)
+    _close(yca[sl], g["ca_out"], 1e-4, 1e-4); _close(x.grad[sl], g["ca_dx"], 1e-3, 1e-4)
+    _close(kv.grad[:, :32], g["ca_dkv"], 1e-3, 1e-4)
+    x2 = Hh.synth_like(603, (2 * B, arch.G, arch.D)).requires_grad_()
+    ysa = O.sa_layer(sd, "encoder.sa_layers.0.", x2, arch, m, "sa0")
+    (ysa * Rl).sum().backward()
+    _close(ysa[sl], g["sa_out"], 1e-4, 1e-4); _close(x2.grad[sl], g["sa_dx"], 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2"])
+def test_dropout_placement_vs_reference(name):
+    """Train mode with the real probabilities: the oracle draws its masks from torch's
+    RNG in the reference's call order, so equal seeds must give equal outputs.  Pins
+    WHERE each dropout sits and with which p (partseg.py:165-166,186-187)."""
+    arch, a = _arch(name, (0.1, 0.5))
+    g = Hh.golden(f"dropout_{name}.npz")
+    B = 2
+    pc = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100)
+    im = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200)
+    pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
+    imgs = Hh.synth_images(400, B, a["img"], a["img"])
+    with torch.no_grad():
+        torch.manual_seed(77)
+        f, bb = O.pc_forward(pc, pts, start, arch, True, O.Masks("torch"), {})
+        torch.manual_seed(78)
+        fi, bbi = O.img_forward(im, imgs, arch, True, O.Masks("torch"), {})
+    _close(f, g["pc_feats"], 1e-4, 1e-4); _close(bb, g["pc_backbone"], 1e-4, 1e-4)
+    _close(fi, g["img_feats"], 1e-4, 1e-4); _close(bbi, g["img_backbone"], 1e-4, 1e-4)
+
+
+def test_param_counts_match_paper_tables():
+    """assets/tab1.png / tab2.png: 5.1 M and 16.7 M parameters."""
+    c = json.load(open(os.path.join(Hh.GOLDEN_DIR, "param_counts.json")))
+    assert c["c1"]["pc_params"] == 4074368 and c["c3"]["pc_params"] == 5127040 and c["c4"]["pc_params"] == 16654336
+    assert c["c1"]["pc_state"] == 148 and c["c1"]["img_state"] == 123 and c["c3"]["pc_state"] == 174
