@@ -1,0 +1,69 @@
+"""In-tree build of libvipformer_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    python -m vipformer_amd.build          # incremental
+    python -m vipformer_amd.build --force
+
+One object per .hip file (rebuilt when the source or a header is newer), linked into
+vipformer_amd/libvipformer_hip.so.  The .so is git-ignored but travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+LIB = os.path.join(HERE, "libvipformer_hip.so")
+ARCH = "gfx950"
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# bit-exact fp32 index kernels: no implicit FMA contraction
+PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
+
+
+def _newest_header() -> float:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "vipformer_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hdr = _newest_header()
+    jobs = []
+    for f in srcs:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr):
+            jobs.append((["hipcc"] + COMMON + PER_FILE.get(f, []) + ["-c", src, "-o", obj], f))
+
+    def run(job):
+        cmd, name = job
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {name}:\n{r.stderr[-6000:]}")
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr[-2000:])
+        return name
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for name in ex.map(run, jobs):
+                if verbose:
+                    print("compiled", name)
+    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in srcs]
+    if jobs or not os.path.exists(LIB) or force:
+        r = subprocess.run(["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        if verbose:
+            print("linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

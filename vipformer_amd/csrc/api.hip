@@ -1,0 +1,17 @@
+// api.hip -- version / error strings of the C ABI.
+#include "vpf_common.h"
+
+extern "C" int vpf_version(void) { return 100; }  // 0.1.0
+
+extern "C" const char* vpf_strerror(int code)
+{
+    switch (code) {
+        case VPF_OK: return "ok";
+        case VPF_ERR_BADSHAPE: return "bad shape / size out of the supported range";
+        case VPF_ERR_BADALIGN: return "pointer or leading dimension not aligned as required";
+        case VPF_ERR_UNSUPPORTED: return "unsupported configuration";
+        case VPF_ERR_HIP: return "HIP launch error";
+        case VPF_ERR_NULL: return "null pointer for a required argument";
+        default: return "unknown error";
+    }
+}

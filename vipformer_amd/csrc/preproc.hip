@@ -1,0 +1,281 @@
+// preproc.hip -- farthest-point sampling, kNN grouping, index_points, square_distance.
+// Replaces the aten compositions of vipformer/model/pointcloud/utils.py:6-141 (reference).
+// Bit-exact contract: fp32, fixed evaluation order, the ONLY fused multiply-adds are the
+// explicit fmaf() calls (this file is compiled with -ffp-contract=off, and the pragma below
+// keeps that true if the flag is ever dropped).
+#pragma clang fp contract(off)
+#include "vpf_common.h"
+
+// =============================================================================== FPS
+// One workgroup per cloud.  The cloud's xyz is staged once into LDS (SoA, coalesced HBM read:
+// the whole cloud is 12 KB at N=1024) for the centroid broadcast; every thread keeps PPT points
+// and their running min-distance in registers.  Per iteration: PPT distance updates, a
+// wavefront arg-max (64-bit key = distance bits : ~index, so max == farthest, ties -> lowest
+// index), one LDS slot per wave, ONE barrier (slots are double-buffered by iteration parity).
+template <int NT, int PPT>
+__global__ void __launch_bounds__(NT) fps_kernel(const float* __restrict__ pts, int N, int C,
+                                                const int64_t* __restrict__ start_idx, int G,
+                                                int64_t* __restrict__ out_idx)
+{
+    extern __shared__ float smem[];
+    constexpr int NW = NT / 64;
+    float* sx = smem;
+    float* sy = sx + N;
+    float* sz = sy + N;
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(sz + N + ((N & 1) ? 1 : 0));  // [2][NW], 8B aligned
+
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* p = pts + (size_t)b * N * C;
+
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = t + j * NT;
+        if (i < N) {
+            px[j] = p[(size_t)i * C + 0]; py[j] = p[(size_t)i * C + 1]; pz[j] = p[(size_t)i * C + 2];
+            sx[i] = px[j]; sy[i] = py[j]; sz[i] = pz[j];
+            dist[j] = 1e10f;
+        } else {
+            px[j] = py[j] = pz[j] = 0.f;
+            dist[j] = -1.f;   // padding: never updated, never selected
+        }
+    }
+    int far = (int)start_idx[b];
+    __syncthreads();
+
+    for (int g = 0; g < G; ++g) {
+        if (t == 0) out_idx[(size_t)b * G + g] = far;
+        if (g + 1 == G) break;
+        const float cx = sx[far], cy = sy[far], cz = sz[far];
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+            float d = dx * dx;
+            d = d + dy * dy;
+            d = d + dz * dz;
+            const int i = t + j * NT;
+            if (i < N) {
+                dist[j] = fminf(dist[j], d);
+                // distances are >= +0: float order == unsigned bit order
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)(~(unsigned)i);
+                best = key > best ? key : best;
+            }
+        }
+        best = wave_max_u64(best);
+        unsigned long long* s = slot + (g & 1) * NW;
+        if (lane == 0) s[wave] = best;
+        __syncthreads();
+        unsigned long long m = s[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { const unsigned long long v = s[w]; m = v > m ? v : m; }
+        far = (int)(~(unsigned)(m & 0xffffffffull));
+    }
+}
+
+template <int NT, int PPT>
+static int launch_fps(const float* pts, int B, int N, int C, const int64_t* start, int G, int64_t* out, hipStream_t st)
+{
+    const size_t lds = sizeof(float) * (3 * (size_t)N + 1) + sizeof(unsigned long long) * 2 * (NT / 64) + 8;
+    hipLaunchKernelGGL((fps_kernel<NT, PPT>), dim3(B), dim3(NT), lds, st, pts, N, C, start, G, out);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+extern "C" int vpf_fps_f32(const float* pts, int B, int N, int C, const int64_t* start_idx, int G,
+                           int64_t* out_idx, void* stream)
+{
+    if (!pts || !start_idx || !out_idx) return VPF_ERR_NULL;
+    if (B < 0 || N <= 0 || C < 3 || G < 0 || N > 4096) return VPF_ERR_BADSHAPE;
+    if (B == 0 || G == 0) return VPF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 256) return launch_fps<256, 1>(pts, B, N, C, start_idx, G, out_idx, st);
+    if (N <= 512) return launch_fps<256, 2>(pts, B, N, C, start_idx, G, out_idx, st);
+    if (N <= 1024) return launch_fps<256, 4>(pts, B, N, C, start_idx, G, out_idx, st);
+    if (N <= 2048) return launch_fps<512, 4>(pts, B, N, C, start_idx, G, out_idx, st);
+    return launch_fps<512, 8>(pts, B, N, C, start_idx, G, out_idx, st);
+}
+
+// =============================================================================== index_points
+__global__ void index_points_kernel(const float* __restrict__ points, int N, int C, const int64_t* __restrict__ idx,
+                                    int S, float* __restrict__ out, long total)
+{
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long r = e / C;            // b*S + s
+        const long b = r / S;
+        const long j = idx[r];
+        out[e] = points[((size_t)b * N + j) * C + c];
+    }
+}
+extern "C" int vpf_index_points_f32(const float* points, int B, int N, int C, const int64_t* idx, int S,
+                                    float* out, void* stream)
+{
+    if (!points || !idx || !out) return VPF_ERR_NULL;
+    if (B < 0 || N <= 0 || C <= 0 || S < 0) return VPF_ERR_BADSHAPE;
+    const long total = (long)B * S * C;
+    if (total == 0) return VPF_OK;
+    int grid = vpf_cdiv(total, 256); if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(index_points_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, points, N, C, idx, S, out, total);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== square_distance
+__device__ __forceinline__ float sq3(float x, float y, float z)
+{
+    float s = x * x;
+    s = s + y * y;
+    s = s + z * z;
+    return s;
+}
+__device__ __forceinline__ float sqdist3(float s0, float s1, float s2, float sn, float d0, float d1, float d2, float dn)
+{
+    float m = s0 * d0;
+    m = fmaf(s1, d1, m);
+    m = fmaf(s2, d2, m);
+    float r = -2.0f * m;
+    r = r + sn;
+    r = r + dn;
+    return r;
+}
+__global__ void square_distance_kernel(const float* __restrict__ src, int Cs, const float* __restrict__ dst, int Cd,
+                                       int Ns, int Nd, float* __restrict__ out)
+{
+    const int b = blockIdx.z, i = blockIdx.y;
+    const float* s = src + ((size_t)b * Ns + i) * Cs;
+    const float s0 = s[0], s1 = s[1], s2 = s[2];
+    const float sn = sq3(s0, s1, s2);
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < Nd; j += gridDim.x * blockDim.x) {
+        const float* d = dst + ((size_t)b * Nd + j) * Cd;
+        const float d0 = d[0], d1 = d[1], d2 = d[2];
+        out[((size_t)b * Ns + i) * Nd + j] = sqdist3(s0, s1, s2, sn, d0, d1, d2, sq3(d0, d1, d2));
+    }
+}
+extern "C" int vpf_square_distance_f32(const float* src, int Cs, const float* dst, int Cd, int B, int Ns, int Nd,
+                                       float* out, void* stream)
+{
+    if (!src || !dst || !out) return VPF_ERR_NULL;
+    if (B < 0 || Ns < 0 || Nd < 0 || Cs < 3 || Cd < 3 || B > 65535 || Ns > 65535) return VPF_ERR_BADSHAPE;
+    if (B == 0 || Ns == 0 || Nd == 0) return VPF_OK;
+    int gx = vpf_cdiv(Nd, 256); if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(square_distance_kernel, dim3(gx, Ns, B), dim3(256), 0, (hipStream_t)stream, src, Cs, dst, Cd, Ns, Nd, out);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== kNN + group
+// One workgroup (4 waves) per (cloud, slice of centres).  The cloud is staged once into LDS as
+// SoA x/y/z/|p|^2 (coalesced HBM read, conflict-free LDS reads: lane l owns points l, l+64, ...).
+// Each wave owns one centre at a time: PPL exact-recipe distances per lane as 64-bit keys
+// (order-preserving distance bits : index), then K wave-wide min extractions -> ascending
+// distance, ties -> lower index.  Lane k keeps the k-th winner and writes idx / dist / gathered
+// neighbour row (with the utils.py:36 member-axis centre subtraction).
+__device__ __forceinline__ uint32_t f32_sortable(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float sortable_f32(uint32_t s)
+{
+    const uint32_t u = s ^ ((s >> 31) ? 0x80000000u : 0xffffffffu);
+    return __uint_as_float(u);
+}
+
+template <int PPL>
+__global__ void __launch_bounds__(256) knn_group_kernel(const float* __restrict__ xyz, int N, int C,
+                                                       const float* __restrict__ centers, int Cc, int G, int K,
+                                                       int quirk, int centres_per_wg, int64_t* __restrict__ knn_idx,
+                                                       float* __restrict__ knn_dist, float* __restrict__ neighbors)
+{
+    extern __shared__ float smem[];
+    float* sx = smem;
+    float* sy = sx + N;
+    float* sz = sy + N;
+    float* sn = sz + N;
+    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* p = xyz + (size_t)b * N * C;
+    for (int i = t; i < N; i += 256) {
+        const float x = p[(size_t)i * C + 0], y = p[(size_t)i * C + 1], z = p[(size_t)i * C + 2];
+        sx[i] = x; sy[i] = y; sz[i] = z; sn[i] = sq3(x, y, z);
+    }
+    __syncthreads();
+
+    const int g0 = blockIdx.x * centres_per_wg;
+    const int g1 = min(G, g0 + centres_per_wg);
+    for (int g = g0 + wave; g < g1; g += 4) {
+        const float* c = centers + ((size_t)b * G + g) * Cc;
+        const float c0 = c[0], c1 = c[1], c2 = c[2];
+        const float cn = sq3(c0, c1, c2);
+        unsigned long long key[PPL];
+        unsigned long long lmin = ~0ull;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int i = lane + j * 64;
+            if (i < N) {
+                const float d = sqdist3(c0, c1, c2, cn, sx[i], sy[i], sz[i], sn[i]);
+                key[j] = ((unsigned long long)f32_sortable(d) << 32) | (unsigned)i;
+            } else {
+                key[j] = ~0ull;
+            }
+            lmin = key[j] < lmin ? key[j] : lmin;
+        }
+        unsigned long long mine = ~0ull;
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long w = wave_min_u64(lmin);
+            if (lane == k) mine = w;
+            // the owner retires the winner and refreshes its local minimum
+            unsigned long long nm = ~0ull;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) {
+                key[j] = (key[j] == w) ? ~0ull : key[j];
+                nm = key[j] < nm ? key[j] : nm;
+            }
+            lmin = nm;
+        }
+        if (lane < K) {
+            const int j = (int)(mine & 0xffffffffull);
+            const size_t o = ((size_t)b * G + g) * K + lane;
+            if (knn_idx) knn_idx[o] = (int64_t)j;
+            if (knn_dist) knn_dist[o] = sortable_f32((uint32_t)(mine >> 32));
+            if (neighbors) {
+                const bool sub = quirk && lane < 3;
+                float* dstp = neighbors + o * C;
+                const float* srcp = p + (size_t)j * C;
+                for (int ch = 0; ch < C; ++ch) {
+                    const float v = srcp[ch];
+                    dstp[ch] = sub ? (v - c[ch]) : v;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int vpf_knn_group_f32(const float* xyz, int B, int N, int C, const float* centers, int Cc, int G, int K,
+                                 int apply_ref_axis_quirk, int64_t* knn_idx, float* knn_dist, float* neighbors,
+                                 void* stream)
+{
+    if (!xyz || !centers) return VPF_ERR_NULL;
+    if (B < 0 || N <= 0 || C < 3 || Cc < 3 || G < 0 || K <= 0 || K > 64 || K > N || N > 4096 || B > 65535)
+        return VPF_ERR_BADSHAPE;
+    if (neighbors && Cc != C) return VPF_ERR_BADSHAPE;
+    if (B == 0 || G == 0) return VPF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // aim for >= ~1024 workgroups, each re-staging the cloud at most G/4 times
+    int cpw = 4;
+    while ((long)B * vpf_cdiv(G, cpw) > 2048 && cpw < G) cpw *= 2;
+    dim3 grid(vpf_cdiv(G, cpw), B);
+    const size_t lds = sizeof(float) * 4 * (size_t)N;
+#define VPF_KNN_LAUNCH(PPL)                                                                                      \
+    hipLaunchKernelGGL((knn_group_kernel<PPL>), grid, dim3(256), lds, st, xyz, N, C, centers, Cc, G, K,            \
+                       apply_ref_axis_quirk, cpw, knn_idx, knn_dist, neighbors)
+    if (N <= 256) VPF_KNN_LAUNCH(4);
+    else if (N <= 512) VPF_KNN_LAUNCH(8);
+    else if (N <= 1024) VPF_KNN_LAUNCH(16);
+    else if (N <= 2048) VPF_KNN_LAUNCH(32);
+    else VPF_KNN_LAUNCH(64);
+#undef VPF_KNN_LAUNCH
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
