@@ -1,0 +1,301 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against plain torch fp32
+references of the same op on the same bf16-rounded operands.  Tolerances are stated per test."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def rnd(seed, *shape, scale=1.0):
+    return (Hh.synth_like(seed, shape) * scale).cuda()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("a_tr,b_tr", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 64, 32), (64, 64, 64), (200, 72, 40), (1000, 256, 256), (96, 136, 520), (8, 8, 8)])
+def test_gemm_layouts_exact_integers(a_tr, b_tr, M, N, K):
+    """Exact small-integer data, ASYMMETRIC operands: catches any row/col or k-order mix-up of the
+    MFMA fragment maps and of the transposing LDS reads (results must be bit-exact)."""
+    from vipformer_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    A[0, 0], A[M - 1, K - 1], B[0, K - 1], B[N - 1, 0] = 5, -7, 6, -5
+    ref = A @ B.t()
+    Ad = bf(A.t().contiguous() if a_tr else A).cuda()
+    Bd = bf(B.t().contiguous() if b_tr else B).cuda()
+    C = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm(Ad, a_tr, M if a_tr else K, Bd, b_tr, N if b_tr else K, M, N, K, C, N, c_f32=True)
+    assert torch.equal(C.cpu(), ref), f"max abs diff {(C.cpu() - ref).abs().max()}"
+
+
+def test_gemm_epilogues_and_splitk():
+    from vipformer_amd import ops
+    M, N, K = 520, 264, 136
+    A, W, bias = rnd(1, M, K), rnd(2, N, K, scale=0.1), rnd(3, N)
+    A16, W16 = bf(A), bf(W)
+    ref = A16.float() @ W16.float().t() + bias
+    y = ops.linear_fwd(A16, W16, N, K, bias)
+    assert rel(y.float(), ref) < 4e-3          # bf16 output rounding
+    y32 = ops.linear_fwd(A16, W16, N, K, bias, out_f32=True)
+    assert rel(y32, ref) < 1e-5                # fp32 accumulate, only summation order differs
+    # GELU epilogue (+ pre-activation), GELU' dgrad epilogue
+    u = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    h = ops.linear_fwd(A16, W16, N, K, bias, mode=ops.EPI_GELU, C2=u, ldc2=N)
+    assert rel(u.float(), ref) < 4e-3
+    assert rel(h.float(), torch.nn.functional.gelu(u.float())) < 4e-3
+    dY = bf(rnd(4, M, N))
+    dx = ops.linear_dgrad(dY, W16, N, K, out_f32=True)
+    assert rel(dx, dY.float() @ W16.float()) < 1e-5
+    Wk = bf(rnd(5, K, N, scale=0.1))           # dgrad through a [K_out=N... shape check with GELU'
+    du = ops.linear_dgrad(bf(rnd(6, M, K)), Wk, K, N, mode=ops.EPI_GELU_BWD, aux=u, ldaux=N)
+    uu = u.float().requires_grad_()
+    torch.nn.functional.gelu(uu).backward(bf(rnd(6, M, K)).float() @ Wk.float())
+    assert rel(du.float(), uu.grad) < 5e-3
+    # wgrad: split-K atomics accumulate INTO the buffer
+    dW = torch.ones(N, K, dtype=torch.float32, device="cuda")
+    ops.linear_wgrad(dY, A16, N, K, dW)
+    assert rel(dW, 1.0 + dY.float().t() @ A16.float()) < 1e-5
+    # dropout + residual epilogue against the exported mask
+    res = rnd(7, M, N)
+    site, p = 12345, 0.3
+    out = ops.linear_fwd(A16, W16, N, K, bias, out_f32=True, mode=ops.EPI_DROP_RES, res=res, ldres=N, site=site, p=p)
+    keep = ops.dropout_keep_mask(site, p, (M, N), "cuda").float()
+    assert abs(keep.mean().item() - (1 - p)) < 0.01
+    assert rel(out, res + ref * keep / (1 - p)) < 1e-5
+    # group bias + batched
+    gb = rnd(8, M // 8, N)
+    yg = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm(A16, 0, K, W16, 0, K, M, N, K, yg, N, c_f32=True, mode=ops.EPI_GROUPBIAS, gbias=gb, group=8)
+    assert rel(yg, A16.float() @ W16.float().t() + gb.repeat_interleave(8, 0)) < 1e-5
+    Ab = bf(rnd(9, 3, 64, 40)); Bb = bf(rnd(10, 3, 48, 40))
+    Cb = torch.empty(3, 64, 48, dtype=torch.float32, device="cuda")
+    ops.gemm(Ab, 0, 40, Bb, 0, 40, 64, 48, 40, Cb, 48, c_f32=True, batch=3, sAb=64 * 40, sBb=48 * 40, sCb=64 * 48)
+    assert rel(Cb, torch.bmm(Ab.float(), Bb.float().transpose(1, 2))) < 1e-5
+
+
+def test_gemm_bad_alignment_is_loud():
+    from vipformer_amd import _lib, ops
+    A, B = bf(rnd(1, 16, 12)), bf(rnd(2, 16, 12))
+    with pytest.raises(_lib.VpfError):
+        ops.gemm(A, 0, 12, B, 0, 12, 16, 16, 12, torch.empty(16, 16, device="cuda"), 16, c_f32=True)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm / dropout
+@pytest.mark.parametrize("rows,D", [(1000, 256), (37, 64), (513, 384), (64, 128)])
+def test_layernorm_fwd_bwd(rows, D):
+    from vipformer_amd import ops
+    x, pos = rnd(1, rows, D, scale=2.0), rnd(2, rows, D)
+    gamma = torch.nn.Parameter(rnd(3, D) * 0.2 + 1.0); beta = torch.nn.Parameter(rnd(4, D) * 0.1)
+    y, mean, rstd, xsum = ops.layernorm_fwd(x, gamma.data, beta.data, pos=pos, want_sum=True)
+    xr = (x + pos).requires_grad_()
+    g2, b2 = gamma.detach().clone().requires_grad_(), beta.detach().clone().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (D,), g2, b2, 1e-5)
+    assert torch.equal(xsum, x + pos) and rel(y.float(), yr) < 4e-3
+    dy = bf(rnd(5, rows, D)); dres = rnd(6, rows, D)
+    dx = ops.layernorm_bwd(dy, xsum, mean, rstd, gamma, beta, dres)
+    yr.backward(dy.float())
+    assert rel(dx, xr.grad + dres) < 1e-4 and rel(gamma.grad, g2.grad) < 1e-4 and rel(beta.grad, b2.grad) < 1e-4
+    # broadcast pos ([T,D] over the batch) and bf16 input
+    T = rows // 4 if rows % 4 == 0 else rows
+    y2, _, _, xs2 = ops.layernorm_fwd(x, gamma.data, beta.data, pos=pos[:T].contiguous(), want_sum=True)
+    assert torch.equal(xs2, x + pos[:T].repeat(rows // T, 1))
+    y3, m3, r3, _ = ops.layernorm_fwd(bf(x), gamma.data, beta.data)
+    assert rel(y3.float(), torch.nn.functional.layer_norm(bf(x).float(), (D,), gamma.data, beta.data, 1e-5)) < 4e-3
+
+
+def test_dropout_add_and_mask_statistics():
+    from vipformer_amd import ops
+    n = 1 << 20
+    y, res = bf(rnd(1, n)), rnd(2, n)
+    for p in (0.1, 0.5):
+        site = ops.new_site()
+        out = ops.DropoutAddFn.apply(y, res, p, site)
+        keep = ops.dropout_keep_mask(site, p, (n,), "cuda").float()
+        assert abs(keep.mean().item() - (1 - p)) < 3e-3                    # ~3 sigma at n = 1M is 1.5e-3
+        assert torch.allclose(out, res + y.float() * keep / (1 - p), rtol=1e-6, atol=1e-6)
+        # different sites / steps decorrelate
+        k2 = ops.dropout_keep_mask(site + 1, p, (n,), "cuda").float()
+        assert abs(((keep - keep.mean()) * (k2 - k2.mean())).mean().item()) < 2e-3
+    ops.rng.advance("cuda")
+    k3 = ops.dropout_keep_mask(site, 0.5, (n,), "cuda").float()
+    assert (k3 != keep).float().mean().item() > 0.4
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(q, k, v, scale, keep, p):
+    """q [B,H,Lq,64] etc. fp32; keep [B,H,Lq,Lkv] or None."""
+    s = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    a = s.softmax(-1)
+    if keep is not None:
+        a = a * keep / (1 - p)
+    return torch.einsum("bhij,bhjd->bhid", a, v), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,H,Lq,Lkv,p", [(2, 2, 96, 1024, 0.0), (2, 4, 196, 196, 0.0), (1, 1, 16, 8, 0.0), (2, 1, 33, 70, 0.0),
+                                          (2, 2, 96, 96, 0.1), (1, 2, 128, 1024, 0.1), (2, 4, 196, 196, 0.1), (3, 1, 50, 200, 0.5)])
+def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    D = 64 * H
+    q, k, v = rnd(1, B, Lq, D), rnd(2, B, Lkv, D), rnd(3, B, Lkv, D)
+    do = rnd(4, B, Lq, D)
+    q16, k16, v16, do16 = bf(q), bf(k), bf(v), bf(do)
+    site = ops.new_site()
+    scale = 64 ** -0.5
+    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
+    st = ops.rng.state("cuda")
+    L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse)
+    keep = ops.dropout_keep_mask(site, p, (B, H, Lq, Lkv), "cuda").float() if p > 0 else None
+    split = lambda t, Lx: t.float().view(B, Lx, H, 64).permute(0, 2, 1, 3).contiguous().requires_grad_()
+    qr, kr, vr = split(q16, Lq), split(k16, Lkv), split(v16, Lkv)
+    oref, lref = attn_ref(qr, kr, vr, scale, keep, p)
+    og = o.float().view(B, Lq, H, 64).permute(0, 2, 1, 3)
+    assert rel(og, oref) < 8e-3, f"fwd rel {rel(og, oref)}"            # bf16 P and bf16 output
+    assert torch.allclose(lse.view(B, H, Lq), lref, rtol=1e-4, atol=1e-4)
+    dq = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    dk = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+    dv = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+    L.call("vpf_attention_bwd", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
+           dq, D, dk, D, dv, D)
+    oref.backward(do16.float().view(B, Lq, H, 64).permute(0, 2, 1, 3))
+    unsplit = lambda t, Lx: t.permute(0, 2, 1, 3).reshape(B * Lx, D)
+    for name, got, ref in (("dq", dq, unsplit(qr.grad, Lq)), ("dk", dk, unsplit(kr.grad, Lkv)), ("dv", dv, unsplit(vr.grad, Lkv))):
+        r = rel(got.float(), ref)
+        assert r < 1.5e-2, f"{name} rel {r}"                                 # bf16 P/dS operands + bf16 outputs
+
+
+def test_attention_strided_qkv_views():
+    """q/k/v as column slices of one [M,3D] buffer (how the fused QKV projection hands them over)."""
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    B, H, Lq = 2, 2, 96
+    D = 128
+    qkv = bf(rnd(1, B * Lq, 3 * D))
+    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
+    L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, 64, 0.125, 0.0,
+           ops.rng.state("cuda"), 1, o, D, lse)
+    sp = lambda t: t.float().reshape(B, Lq, H, 64).permute(0, 2, 1, 3)
+    oref, _ = attn_ref(sp(qkv[:, :D]), sp(qkv[:, D:2 * D]), sp(qkv[:, 2 * D:]), 0.125, None, 0.0)
+    assert rel(o.float().view(B, Lq, H, 64).permute(0, 2, 1, 3), oref) < 8e-3
+
+
+# ------------------------------------------------------------------------------------------ BN / pooling / small kernels
+def test_batchnorm_pieces():
+    from vipformer_amd import ops
+    M, C = 4096, 256
+    x = rnd(1, M, C, scale=2.0) + 0.3
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    bn.weight.data = rnd(2, C) * 0.2 + 1; bn.bias.data = rnd(3, C) * 0.1
+    ref = torch.nn.BatchNorm1d(C).cuda()
+    ref.load_state_dict(bn.state_dict())
+    x16 = bf(x)
+    stat = ops._bn_stat(x16, C, bn, True)
+    y = ops._bn_act(x16, C, stat, bn, True, False)
+    xr = x16.float().requires_grad_()
+    yr = torch.relu(ref(xr))
+    assert rel(y, yr) < 1e-4
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5) and torch.allclose(bn.running_var, ref.running_var, rtol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+    dy = bf(rnd(4, M, C))
+    dx = ops._bn_bwd(dy, x16, C, stat, bn, True, True, False)
+    yr.backward(dy.float())
+    assert rel(dx, xr.grad) < 2e-4 and rel(bn.weight.grad, ref.weight.grad) < 2e-4 and rel(bn.bias.grad, ref.bias.grad) < 2e-4
+    # eval mode uses the running statistics
+    bn.eval(); ref.eval()
+    se = ops._bn_stat(x16, C, bn, False)
+    assert rel(ops._bn_act(x16, C, se, bn, False, False), ref(x16.float())) < 1e-5
+
+
+def test_group_max_concat_pool():
+    from vipformer_amd import _lib as L
+    NG, K, C = 50, 32, 128
+    h = bf(rnd(1, NG * K, C))
+    out = torch.empty(NG, C, dtype=torch.float32, device="cuda"); arg = torch.empty(NG, C, dtype=torch.uint8, device="cuda")
+    L.call("vpf_group_max_fwd", h, NG, K, C, out, 0, arg)
+    mv, mi = h.float().view(NG, K, C).max(1)
+    assert torch.equal(out, mv)
+    assert torch.equal(torch.gather(h.float().view(NG, K, C), 1, arg.long().unsqueeze(1)).squeeze(1), mv)
+    dout = rnd(2, NG, C)
+    dh = torch.empty(NG * K, C, dtype=torch.bfloat16, device="cuda")
+    L.call("vpf_group_max_bwd", dout, 0, arg, NG, K, C, dh)
+    ref = torch.zeros(NG, K, C, device="cuda").scatter_(1, arg.long().unsqueeze(1), bf(dout).float().unsqueeze(1))
+    assert torch.equal(dh.float().view(NG, K, C), ref)
+    g16 = bf(out)
+    feat = torch.empty(NG * K, 2 * C, dtype=torch.bfloat16, device="cuda")
+    L.call("vpf_g2e_concat_fwd", g16, h, NG * K, K, C, feat)
+    assert torch.equal(feat.view(NG, K, 2 * C)[:, :, :C], g16.unsqueeze(1).expand(NG, K, C)) and torch.equal(feat[:, C:], h)
+    dfeat = bf(rnd(3, NG * K, 2 * C))
+    dh2 = torch.empty(NG * K, C, dtype=torch.bfloat16, device="cuda")
+    L.call("vpf_g2e_concat_bwd", dfeat, arg, NG, K, C, dh2)
+    dfv = dfeat.float().view(NG, K, 2 * C)
+    ref2 = dfv[:, :, C:] + torch.zeros(NG, K, C, device="cuda").scatter_(1, arg.long().unsqueeze(1), dfv[:, :, :C].sum(1, keepdim=True))
+    assert rel(dh2.float().view(NG, K, C), ref2) < 4e-3
+    # token pooling
+    from vipformer_amd import ops
+    x = rnd(4, 6, 96, 64).requires_grad_()
+    o = ops.PoolFn.apply(x)
+    r = torch.cat([x.max(1)[0], x.mean(1)], 1)
+    assert torch.allclose(o, r, atol=1e-6)
+    gsel = rnd(5, 6, 128)
+    (gx,) = torch.autograd.grad((o * gsel).sum(), x)
+    (gr,) = torch.autograd.grad((r * gsel).sum(), x)
+    assert torch.allclose(gx, gr, atol=1e-6)
+
+
+def test_ntxent_fwd_bwd_vs_oracle():
+    from oracle import torch_oracle as O
+    from vipformer_amd import ops
+    for b, D in ((64, 256), (4, 64), (33, 384)):
+        z0, z1 = rnd(1, b, D).requires_grad_(), rnd(2, b, D).requires_grad_()
+        loss = ops.ntxent_loss(z0, z1, 0.1)
+        (loss * 1.7).backward()
+        c0, c1 = z0.detach().cpu().requires_grad_(), z1.detach().cpu().requires_grad_()
+        lr = O.ntxent(c0, c1, 0.1)
+        (lr * 1.7).backward()
+        assert abs(loss.item() - lr.item()) < 1e-4 * max(1, abs(lr.item()))
+        assert rel(z0.grad.cpu(), c0.grad) < 1e-4 and rel(z1.grad.cpu(), c1.grad) < 1e-4
+
+
+def test_adamw_matches_torch():
+    from vipformer_amd import _lib as L
+    n = 100003
+    p0, g = rnd(1, n), rnd(2, n, scale=0.01)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sh = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0.0, 0.0], device="cuda")
+    for it in range(3):
+        gi = g * (it + 1)
+        ref.grad = gi.clone(); opt.step()
+        L.call("vpf_adamw_step", p, gi, m, v, sh, n, hyper, 1)
+    assert torch.allclose(p, ref.data, rtol=1e-5, atol=1e-7) and hyper[6].item() == 3.0
+    assert torch.equal(sh, p.to(torch.bfloat16))
+
+
+def test_patchify_on_permuted_nchw_view():
+    from oracle import torch_oracle as O
+    from vipformer_amd import _lib as L
+    imgs = Hh.synth_images(3, 2, 32, 48).cuda()                     # [B,H,W,3] view of NCHW
+    assert not imgs.is_contiguous()
+    out = torch.empty(2 * (32 // 8) * (48 // 8), 8 * 8 * 3, dtype=torch.bfloat16, device="cuda")
+    sb, sh, sw, sc = imgs.stride()
+    L.call("vpf_patchify", imgs, sb, sh, sw, sc, 2, 32, 48, 3, 8, out)
+    assert torch.equal(out.view(2, -1, 192), bf(O.patchify(imgs.cpu(), 8)).cuda())

@@ -57,3 +57,74 @@ def need_cuda(*ts) -> None:
     for t in ts:
         if t is not None and not t.is_cuda:
             raise VpfError("vipformer_amd ops run on an MI355X only (got a CPU tensor); there is no CPU fallback")
+
+
+# --------------------------------------------------------------------------- signatures
+L_ = ctypes.c_long
+U32 = ctypes.c_uint32
+SIGS = {
+    "vpf_fps_f32": [VP, I, I, I, VP, I, VP, VP],
+    "vpf_index_points_f32": [VP, I, I, I, VP, I, VP, VP],
+    "vpf_square_distance_f32": [VP, I, VP, I, I, I, I, VP, VP],
+    "vpf_knn_group_f32": [VP, I, I, I, VP, I, I, I, I, VP, VP, VP, VP],
+    "vpf_gemm_bf16": [VP, I, L_, VP, I, L_, I, I, I, I, L_, L_, L_, VP, L_, I, I, VP, VP, L_, VP, L_, VP, L_, VP, I, VP, U32, F, I, VP],
+    "vpf_cast_f32_bf16": [VP, VP, L_, VP],
+    "vpf_cast_bf16_f32": [VP, VP, L_, VP],
+    "vpf_layernorm_fwd": [VP, I, VP, I, VP, VP, VP, VP, VP, VP, L_, I, F, VP],
+    "vpf_layernorm_bwd": [VP, VP, I, VP, VP, VP, VP, VP, I, VP, VP, L_, I, VP],
+    "vpf_dropout_add_fwd": [VP, VP, VP, L_, VP, U32, F, VP],
+    "vpf_dropout_bwd": [VP, VP, L_, VP, U32, F, VP],
+    "vpf_dropout_mask": [VP, L_, VP, U32, F, VP],
+    "vpf_rng_advance": [VP, VP],
+    "vpf_colsum": [VP, I, L_, I, VP, VP, VP],
+    "vpf_bn_finalize": [VP, VP, L_, I, F, F, I, VP, VP, VP, VP, VP],
+    "vpf_bn_act_fwd": [VP, I, VP, VP, VP, VP, I, L_, I, I, VP],
+    "vpf_bn_bwd": [VP, I, VP, I, VP, VP, VP, L_, I, I, I, VP, VP, I, VP, VP, VP],
+    "vpf_group_max_fwd": [VP, L_, I, I, VP, I, VP, VP],
+    "vpf_group_max_bwd": [VP, I, VP, L_, I, I, VP, VP],
+    "vpf_g2e_concat_fwd": [VP, VP, L_, I, I, VP, VP],
+    "vpf_g2e_concat_bwd": [VP, VP, L_, I, I, VP, VP],
+    "vpf_pool_fwd": [VP, I, I, I, VP, VP, VP],
+    "vpf_pool_bwd": [VP, VP, I, I, I, VP, VP],
+    "vpf_axpy_f32": [VP, VP, L_, F, VP],
+    "vpf_rowsum_mod_f32": [VP, L_, I, I, VP, VP],
+    "vpf_attention_fwd": [VP, L_, VP, L_, VP, L_, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, VP],
+    "vpf_attention_bwd": [VP, L_, VP, L_, VP, L_, VP, L_, VP, L_, VP, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, L_, VP, L_, VP],
+    "vpf_adapter_front_fwd": [VP, L_, I, VP, VP, VP, VP, VP, VP],
+    "vpf_adapter_front_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP],
+    "vpf_smallk_fwd": [VP, L_, I, VP, VP, I, I, VP, VP],
+    "vpf_smallk_bwd": [VP, VP, L_, I, VP, VP, I, I, VP, VP, VP],
+    "vpf_g2e_conv1_stats": [VP, L_, I, VP, VP, VP, VP, VP],
+    "vpf_g2e_conv1_apply": [VP, L_, I, VP, VP, VP, VP, VP, VP, VP],
+    "vpf_g2e_conv1_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP],
+    "vpf_patchify": [VP, L_, L_, L_, L_, I, I, I, I, I, VP, VP],
+    "vpf_ntxent_fwd": [VP, VP, I, I, F, VP, VP, VP, VP, VP, VP],
+    "vpf_ntxent_bwd": [VP, VP, VP, I, I, F, VP, VP, VP, VP],
+    "vpf_adamw_step": [VP, VP, VP, VP, VP, L_, VP, I, VP],
+}
+_bound = {}
+
+
+def call(name: str, *args) -> None:
+    """Invoke a C-ABI entry point on torch's current stream (appended as the last argument);
+    tensors are passed by data_ptr; raises VpfError on a non-zero return."""
+    fn = _bound.get(name)
+    if fn is None:
+        fn = getattr(lib(), name)
+        fn.argtypes = SIGS[name]
+        fn.restype = I
+        _bound[name] = fn
+    conv = []
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif isinstance(a, torch.Tensor):
+            if not a.is_cuda:
+                raise VpfError(f"{name}: got a CPU tensor; vipformer_amd runs on an MI355X only (no CPU fallback)")
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    conv.append(torch.cuda.current_stream().cuda_stream)
+    rc = fn(*conv)
+    if rc != 0:
+        raise VpfError(f"{name} failed: {lib().vpf_strerror(rc).decode()} (rc={rc})")

@@ -1,0 +1,565 @@
+// elementwise.hip -- normalisation, dropout/residual, reductions, pooling, BatchNorm pieces.
+// Replaces the aten layer_norm / batch_norm / dropout / add / max / mean / cat calls (and their
+// autograd backward) of vipformer/model/pointcloud/partseg.py:100-116,191-213,519-525,547 and
+// utils.py:156,163,179-189.  All kernels are HBM-bound streaming kernels: coalesced rows,
+// wavefront (64-lane) reductions, fp32 statistics.
+#include "vpf_common.h"
+
+template <typename T> __device__ __forceinline__ float ld_f(const T* p, size_t i);
+template <> __device__ __forceinline__ float ld_f<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ld_f<bf16_t>(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
+template <typename T> __device__ __forceinline__ void st_f(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void st_f<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void st_f<bf16_t>(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16(v); }
+
+static inline int grid_for(long n, int per_block, int cap = 4096)
+{
+    long g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// =============================================================================== cast
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n)
+{
+    const long n4 = n / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        reinterpret_cast<uint2*>(y)[i] = o;
+    }
+    for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        y[i] = f32_to_bf16(x[i]);
+}
+extern "C" int vpf_cast_f32_bf16(const float* x, void* y, long n, void* stream)
+{
+    if (!x || !y) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return VPF_ERR_BADALIGN;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = bf16_to_f32(x[i]);
+}
+extern "C" int vpf_cast_bf16_f32(const void* x, float* y, long n, void* stream)
+{
+    if (!x || !y) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== LayerNorm
+// One wavefront per row, D <= 512 values in registers (lane owns columns lane + 64 i).
+#define LN_MAXI 8
+template <typename TIN>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ pos, int pos_rows,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          bf16_t* __restrict__ y, float* __restrict__ xsum,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, long rows, int D, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long r = wave0; r < rows; r += nw) {
+        float v[LN_MAXI];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = 0.f;
+            if (c < D) {
+                v[i] = ld_f<TIN>(x, (size_t)r * D + c);
+                if (pos) v[i] += pos[(size_t)(r % pos_rows) * D + c];
+                if (xsum) xsum[(size_t)r * D + c] = v[i];
+                s += v[i];
+            }
+        }
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; ++i) { const int c = lane + 64 * i; if (c < D) { const float d = v[i] - mu; q += d * d; } }
+        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) y[(size_t)r * D + c] = f32_to_bf16((v[i] - mu) * rs * gamma[c] + beta[c]);
+        }
+        if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+    }
+}
+extern "C" int vpf_layernorm_fwd(const void* x, int x_is_bf16, const float* pos, int pos_rows, const float* gamma,
+                                 const float* beta, void* y_bf16, float* xsum, float* mean, float* rstd, long rows, int D,
+                                 float eps, void* stream)
+{
+    if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd) return VPF_ERR_NULL;
+    if (rows < 0 || D <= 0 || D > 64 * LN_MAXI || (pos && pos_rows <= 0)) return VPF_ERR_BADSHAPE;
+    if (rows == 0) return VPF_OK;
+    const int grid = grid_for(rows, 4);
+    if (x_is_bf16)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, pos, pos_rows,
+                           gamma, beta, (bf16_t*)y_bf16, xsum, mean, rstd, rows, D, eps);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, pos, pos_rows,
+                           gamma, beta, (bf16_t*)y_bf16, xsum, mean, rstd, rows, D, eps);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// dx = (dres ? dres : 0) + rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)); dgamma += dy*xhat; dbeta += dy
+template <typename TX, typename TDX>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const TX* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                          TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          long rows, int D)
+{
+    __shared__ float red[2][4][64 * LN_MAXI];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float ag[LN_MAXI], ab[LN_MAXI], gm[LN_MAXI];
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) { ag[i] = ab[i] = 0.f; const int c = lane + 64 * i; gm[i] = c < D ? gamma[c] : 0.f; }
+    for (long r = wave0; r < rows; r += nw) {
+        const float mu = mean[r], rs = rstd[r];
+        float xh[LN_MAXI], g[LN_MAXI];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; ++i) {
+            const int c = lane + 64 * i;
+            xh[i] = g[i] = 0.f;
+            if (c < D) {
+                const float d = bf16_to_f32(dy[(size_t)r * D + c]);
+                xh[i] = (ld_f<TX>(x, (size_t)r * D + c) - mu) * rs;
+                ag[i] += d * xh[i]; ab[i] += d;
+                g[i] = d * gm[i];
+                s1 += g[i]; s2 += g[i] * xh[i];
+            }
+        }
+        s1 = wave_sum(s1) / (float)D; s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXI; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                float v = rs * (g[i] - s1 - xh[i] * s2);
+                if (dres) v += dres[(size_t)r * D + c];
+                st_f<TDX>(dx, (size_t)r * D + c, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXI; ++i) { red[0][wv][lane + 64 * i] = ag[i]; red[1][wv][lane + 64 * i] = ab[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b);
+    }
+}
+extern "C" int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf16, const float* mean, const float* rstd,
+                                 const float* gamma, const float* dres, void* dx, int dx_is_bf16, float* dgamma, float* dbeta,
+                                 long rows, int D, void* stream)
+{
+    if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return VPF_ERR_NULL;
+    if (rows < 0 || D <= 0 || D > 64 * LN_MAXI) return VPF_ERR_BADSHAPE;
+    if (rows == 0) return VPF_OK;
+    const int grid = grid_for(rows, 64, 512);
+    hipStream_t st = (hipStream_t)stream;
+#define LNB(TX, TDX) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDX>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy_bf16, (const TX*)x, \
+                                        mean, rstd, gamma, dres, (TDX*)dx, dgamma, dbeta, rows, D)
+    if (x_is_bf16 && dx_is_bf16) LNB(bf16_t, bf16_t);
+    else if (x_is_bf16) LNB(bf16_t, float);
+    else if (dx_is_bf16) LNB(float, bf16_t);
+    else LNB(float, float);
+#undef LNB
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== dropout (+ residual)
+__global__ void dropout_add_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ res, float* __restrict__ out,
+                                       long n, const uint32_t* __restrict__ rng_state, uint32_t site, float p)
+{
+    const VpfRng rng = vpf_rng_init(rng_state, site, p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = bf16_to_f32(y[i]);
+        out[i] = (res ? res[i] : 0.f) + (vpf_keep(rng, (uint64_t)i) ? v * rng.scale : 0.f);
+    }
+}
+extern "C" int vpf_dropout_add_fwd(const void* y_bf16, const float* res, float* out, long n, const uint32_t* rng_state,
+                                   uint32_t site, float p, void* stream)
+{
+    if (!y_bf16 || !out || !rng_state) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(dropout_add_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y_bf16, res, out, n,
+                       rng_state, site, p);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// dy(bf16) = keep ? dout * scale : 0
+__global__ void dropout_bwd_kernel(const float* __restrict__ dout, bf16_t* __restrict__ dy, long n,
+                                   const uint32_t* __restrict__ rng_state, uint32_t site, float p)
+{
+    const VpfRng rng = vpf_rng_init(rng_state, site, p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dy[i] = f32_to_bf16(vpf_keep(rng, (uint64_t)i) ? dout[i] * rng.scale : 0.f);
+}
+extern "C" int vpf_dropout_bwd(const float* dout, void* dy_bf16, long n, const uint32_t* rng_state, uint32_t site, float p,
+                               void* stream)
+{
+    if (!dout || !dy_bf16 || !rng_state) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, (bf16_t*)dy_bf16, n, rng_state, site, p);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// keep-mask export (tests feed it to the oracle): out[i] = 1 if element i of `site` is kept
+__global__ void dropout_mask_kernel(uint8_t* __restrict__ out, long n, const uint32_t* __restrict__ rng_state, uint32_t site, float p)
+{
+    const VpfRng rng = vpf_rng_init(rng_state, site, p);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = vpf_keep(rng, (uint64_t)i) ? 1 : 0;
+}
+extern "C" int vpf_dropout_mask(uint8_t* out, long n, const uint32_t* rng_state, uint32_t site, float p, void* stream)
+{
+    if (!out || !rng_state) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, rng_state, site, p);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+__global__ void rng_advance_kernel(uint32_t* st) { if (threadIdx.x == 0 && blockIdx.x == 0) st[2] += 1u; }
+extern "C" int vpf_rng_advance(uint32_t* rng_state, void* stream)
+{
+    if (!rng_state) return VPF_ERR_NULL;
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng_state);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== column sums (bias grads, BN stats)
+// x [M,C] -> acc[c] += sum_m x ; acc2[c] += sum_m x^2 (optional).  thread = column, block = 128-row slab.
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ acc, float* __restrict__ acc2, int rows_per_block)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f, q = 0.f;
+    for (long r = r0; r < r1; ++r) { const float v = ld_f<T>(x, (size_t)r * C + c); s += v; q += v * v; }
+    atomicAdd(acc + c, s);
+    if (acc2) atomicAdd(acc2 + c, q);
+}
+extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* acc, float* acc2, void* stream)
+{
+    if (!x || !acc) return VPF_ERR_NULL;
+    if (M < 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    if (M == 0) return VPF_OK;
+    int rpb = 128;
+    while ((M + rpb - 1) / rpb > 16384) rpb *= 2;
+    dim3 grid(vpf_cdiv(C, 256), (unsigned)((M + rpb - 1) / rpb));
+    if (x_is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, C, acc, acc2, rpb);
+    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, M, C, acc, acc2, rpb);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== BatchNorm (channels-last [M,C])
+// stat layout: [mean(C) | rstd(C)].  training: from batch sums, updates running stats
+// (momentum 0.1, unbiased variance) like nn.BatchNorm1d; eval: from running stats.
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ sumsq, long M, int C, float eps, float momentum,
+                                   int training, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ num_batches, float* __restrict__ stat)
+{
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        if (training) {
+            const float mu = sums[c] / (float)M;
+            float var = sumsq[c] / (float)M - mu * mu;
+            var = var < 0.f ? 0.f : var;
+            stat[c] = mu; stat[C + c] = rsqrtf(var + eps);
+            if (running_mean) {
+                const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+            }
+        } else {
+            stat[c] = running_mean[c]; stat[C + c] = rsqrtf(running_var[c] + eps);
+        }
+    }
+    if (training && num_batches && blockIdx.x == 0 && threadIdx.x == 0) *num_batches += 1;
+}
+extern "C" int vpf_bn_finalize(const float* sums, const float* sumsq, long M, int C, float eps, float momentum, int training,
+                               float* running_mean, float* running_var, long long* num_batches, float* stat, void* stream)
+{
+    if (!stat || (training && (!sums || !sumsq)) || (!training && (!running_mean || !running_var))) return VPF_ERR_NULL;
+    if (C <= 0 || M <= 0) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(vpf_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, sumsq, M, C, eps, momentum,
+                       training, running_mean, running_var, num_batches, stat);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+template <typename TIN, typename TOUT>
+__global__ void bn_act_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ stat, const float* __restrict__ gamma,
+                                  const float* __restrict__ beta, TOUT* __restrict__ y, long total, int C, int relu)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = (ld_f<TIN>(x, i) - stat[c]) * stat[C + c] * gamma[c] + beta[c];
+        if (relu) v = fmaxf(v, 0.f);
+        st_f<TOUT>(y, i, v);
+    }
+}
+extern "C" int vpf_bn_act_fwd(const void* x, int x_is_bf16, const float* stat, const float* gamma, const float* beta, void* y,
+                              int y_is_bf16, long M, int C, int relu, void* stream)
+{
+    if (!x || !stat || !gamma || !beta || !y) return VPF_ERR_NULL;
+    if (M < 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    const long total = M * C;
+    if (total == 0) return VPF_OK;
+    const int grid = grid_for(total, 256);
+    hipStream_t st = (hipStream_t)stream;
+#define BNF(TI, TO) hipLaunchKernelGGL((bn_act_fwd_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)x, stat, gamma, beta, (TO*)y, total, C, relu)
+    if (x_is_bf16 && y_is_bf16) BNF(bf16_t, bf16_t);
+    else if (x_is_bf16) BNF(bf16_t, float);
+    else if (y_is_bf16) BNF(float, bf16_t);
+    else BNF(float, float);
+#undef BNF
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// backward pass 1: tmp[c] += sum g ; tmp[C+c] += sum g*xhat   with g = dy * relu'(y)
+template <typename TX, typename TDY>
+__global__ void bn_bwd_reduce_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ stat,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, long M, int C, int relu,
+                                     float* __restrict__ tmp, int rows_per_block)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = stat[c], rs = stat[C + c], ga = gamma[c], be = beta[c];
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s = 0.f, q = 0.f;
+    for (long r = r0; r < r1; ++r) {
+        const float xh = (ld_f<TX>(x, (size_t)r * C + c) - mu) * rs;
+        float g = ld_f<TDY>(dy, (size_t)r * C + c);
+        if (relu && (xh * ga + be) <= 0.f) g = 0.f;
+        s += g; q += g * xh;
+    }
+    atomicAdd(tmp + c, s); atomicAdd(tmp + C + c, q);
+}
+// backward pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gxh/M); block 0 also does dgamma += sum_gxh, dbeta += sum_g
+template <typename TX, typename TDY, typename TDX>
+__global__ void bn_bwd_apply_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float* __restrict__ stat,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ tmp,
+                                    long M, int C, int relu, int training, TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const long total = M * C;
+    const float invM = 1.f / (float)M;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float rs = stat[C + c], ga = gamma[c];
+        const float xh = (ld_f<TX>(x, i) - stat[c]) * rs;
+        float g = ld_f<TDY>(dy, i);
+        if (relu && (xh * ga + beta[c]) <= 0.f) g = 0.f;
+        const float v = training ? ga * rs * (g - tmp[c] * invM - xh * tmp[C + c] * invM) : ga * rs * g;
+        if (dx) st_f<TDX>(dx, i, v);
+    }
+    if (blockIdx.x == 0 && dgamma)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(dgamma + c, tmp[C + c]); atomicAdd(dbeta + c, tmp[c]); }
+}
+extern "C" int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* stat, const float* gamma,
+                          const float* beta, long M, int C, int relu, int training, float* tmp2C_zeroed, void* dx, int dx_is_bf16,
+                          float* dgamma, float* dbeta, void* stream)
+{
+    if (!dy || !x || !stat || !gamma || !beta || !tmp2C_zeroed) return VPF_ERR_NULL;
+    if (M <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    int rpb = 128;
+    while ((M + rpb - 1) / rpb > 16384) rpb *= 2;
+    dim3 g1(vpf_cdiv(C, 256), (unsigned)((M + rpb - 1) / rpb));
+    const int g2 = grid_for(M * C, 256);
+#define BNR(TX, TDY) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TX, TDY>), g1, dim3(256), 0, st, (const TDY*)dy, (const TX*)x, stat, gamma, beta, M, C, relu, tmp2C_zeroed, rpb)
+#define BNA(TX, TDY, TDX) hipLaunchKernelGGL((bn_bwd_apply_kernel<TX, TDY, TDX>), dim3(g2), dim3(256), 0, st, (const TDY*)dy, (const TX*)x, stat, gamma, beta, tmp2C_zeroed, M, C, relu, training, (TDX*)dx, dgamma, dbeta)
+    if (x_is_bf16 && dy_is_bf16) { BNR(bf16_t, bf16_t); if (dx_is_bf16) BNA(bf16_t, bf16_t, bf16_t); else BNA(bf16_t, bf16_t, float); }
+    else if (x_is_bf16 && !dy_is_bf16) { BNR(bf16_t, float); if (dx_is_bf16) BNA(bf16_t, float, bf16_t); else BNA(bf16_t, float, float); }
+    else if (!x_is_bf16 && dy_is_bf16) { BNR(float, bf16_t); if (dx_is_bf16) BNA(float, bf16_t, bf16_t); else BNA(float, bf16_t, float); }
+    else { BNR(float, float); if (dx_is_bf16) BNA(float, float, bf16_t); else BNA(float, float, float); }
+#undef BNR
+#undef BNA
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== max over group members
+// h [NG, K, C] bf16 -> out [NG, C] (f32 or bf16), arg [NG, C] (uint8, first max)
+template <typename TOUT>
+__global__ void group_max_fwd_kernel(const bf16_t* __restrict__ h, long NG, int K, int C, TOUT* __restrict__ out, uint8_t* __restrict__ arg)
+{
+    const long total = NG * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / C; const int c = (int)(i % C);
+        float best = -INFINITY; int bi = 0;
+        for (int k = 0; k < K; ++k) { const float v = bf16_to_f32(h[((size_t)g * K + k) * C + c]); if (v > best) { best = v; bi = k; } }
+        st_f<TOUT>(out, i, best);
+        if (arg) arg[i] = (uint8_t)bi;
+    }
+}
+extern "C" int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream)
+{
+    if (!h_bf16 || !out) return VPF_ERR_NULL;
+    if (NG < 0 || K <= 0 || K > 255 || C <= 0) return VPF_ERR_BADSHAPE;
+    if (NG == 0) return VPF_OK;
+    const int grid = grid_for(NG * C, 256);
+    if (out_is_bf16) hipLaunchKernelGGL(group_max_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, NG, K, C, (bf16_t*)out, arg);
+    else hipLaunchKernelGGL(group_max_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, NG, K, C, (float*)out, arg);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// dh [NG,K,C] bf16 = (k == arg) ? dout : 0
+template <typename TIN>
+__global__ void group_max_bwd_kernel(const TIN* __restrict__ dout, const uint8_t* __restrict__ arg, long NG, int K, int C, bf16_t* __restrict__ dh)
+{
+    const long total = NG * K * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); const long gk = i / C; const int k = (int)(gk % K); const long g = gk / K;
+        dh[i] = (arg[g * C + c] == k) ? f32_to_bf16(ld_f<TIN>(dout, (size_t)g * C + c)) : (bf16_t)0;
+    }
+}
+extern "C" int vpf_group_max_bwd(const void* dout, int dout_is_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
+{
+    if (!dout || !arg || !dh_bf16) return VPF_ERR_NULL;
+    if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    if (NG == 0) return VPF_OK;
+    const int grid = grid_for(NG * K * C, 256);
+    if (dout_is_bf16) hipLaunchKernelGGL(group_max_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, arg, NG, K, C, (bf16_t*)dh_bf16);
+    else hipLaunchKernelGGL(group_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dout, arg, NG, K, C, (bf16_t*)dh_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// Group2Emb concat (utils.py:183): feat[m, 0:C] = gmax[m / K, :], feat[m, C:2C] = h[m, :]
+__global__ void g2e_concat_fwd_kernel(const bf16_t* __restrict__ gmax, const bf16_t* __restrict__ h, long M, int K, int C, bf16_t* __restrict__ feat)
+{
+    const long total = M * 2 * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (2 * C)); const long m = i / (2 * C);
+        feat[i] = c < C ? gmax[(m / K) * C + c] : h[m * C + (c - C)];
+    }
+}
+extern "C" int vpf_g2e_concat_fwd(const void* gmax_bf16, const void* h_bf16, long M, int K, int C, void* feat_bf16, void* stream)
+{
+    if (!gmax_bf16 || !h_bf16 || !feat_bf16) return VPF_ERR_NULL;
+    if (M < 0 || K <= 0 || C <= 0 || (M % K)) return VPF_ERR_BADSHAPE;
+    if (M == 0) return VPF_OK;
+    hipLaunchKernelGGL(g2e_concat_fwd_kernel, dim3(grid_for(M * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gmax_bf16,
+                       (const bf16_t*)h_bf16, M, K, C, (bf16_t*)feat_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// dh[m,c] = dfeat[m, C+c] + (k == arg[g,c] ? sum_k' dfeat[(g,k'), c] : 0)
+__global__ void g2e_concat_bwd_kernel(const bf16_t* __restrict__ dfeat, const uint8_t* __restrict__ arg, long NG, int K, int C, bf16_t* __restrict__ dh)
+{
+    const long total = NG * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / C; const int c = (int)(i % C);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += bf16_to_f32(dfeat[((size_t)g * K + k) * 2 * C + c]);
+        const int a = arg[i];
+        for (int k = 0; k < K; ++k) {
+            const float v = bf16_to_f32(dfeat[((size_t)g * K + k) * 2 * C + C + c]) + (k == a ? s : 0.f);
+            dh[((size_t)g * K + k) * C + c] = f32_to_bf16(v);
+        }
+    }
+}
+extern "C" int vpf_g2e_concat_bwd(const void* dfeat_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
+{
+    if (!dfeat_bf16 || !arg || !dh_bf16) return VPF_ERR_NULL;
+    if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    if (NG == 0) return VPF_OK;
+    hipLaunchKernelGGL(g2e_concat_bwd_kernel, dim3(grid_for(NG * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dfeat_bf16, arg, NG, K, C, (bf16_t*)dh_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== token pooling  partseg.py:547
+// x f32 [B,L,D] -> out f32 [B,2D] = [max over L | mean over L], arg int32 [B,D]
+__global__ void pool_fwd_kernel(const float* __restrict__ x, int B, int L, int D, float* __restrict__ out, int* __restrict__ arg)
+{
+    const long total = (long)B * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / D), d = (int)(i % D);
+        float best = -INFINITY, s = 0.f; int bi = 0;
+        for (int l = 0; l < L; ++l) { const float v = x[((size_t)b * L + l) * D + d]; s += v; if (v > best) { best = v; bi = l; } }
+        out[(size_t)b * 2 * D + d] = best; out[(size_t)b * 2 * D + D + d] = s / (float)L;
+        if (arg) arg[i] = bi;
+    }
+}
+extern "C" int vpf_pool_fwd(const float* x, int B, int L, int D, float* out, int* arg, void* stream)
+{
+    if (!x || !out) return VPF_ERR_NULL;
+    if (B < 0 || L <= 0 || D <= 0) return VPF_ERR_BADSHAPE;
+    if (B == 0) return VPF_OK;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for((long)B * D, 64)), dim3(64), 0, (hipStream_t)stream, x, B, L, D, out, arg);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+__global__ void pool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg, int B, int L, int D, float* __restrict__ dx)
+{
+    const long total = (long)B * L * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D); const long bl = i / D; const int l = (int)(bl % L); const int b = (int)(bl / L);
+        float v = dout[(size_t)b * 2 * D + D + d] / (float)L;
+        if (arg[(size_t)b * D + d] == l) v += dout[(size_t)b * 2 * D + d];
+        dx[i] = v;
+    }
+}
+extern "C" int vpf_pool_bwd(const float* dout, const int* arg, int B, int L, int D, float* dx, void* stream)
+{
+    if (!dout || !arg || !dx) return VPF_ERR_NULL;
+    if (B < 0 || L <= 0 || D <= 0) return VPF_ERR_BADSHAPE;
+    if (B == 0) return VPF_OK;
+    hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for((long)B * L * D, 256)), dim3(256), 0, (hipStream_t)stream, dout, arg, B, L, D, dx);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== misc
+// y += a * x   (fp32)
+__global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a)
+{
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] += a * x[i];
+}
+extern "C" int vpf_axpy_f32(const float* x, float* y, long n, float a, void* stream)
+{
+    if (!x || !y) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// acc[r % period, :] += x[r, :]  (positional-embedding gradient: sum over the batch), fp32
+__global__ void rowsum_mod_kernel(const float* __restrict__ x, long rows, int D, int period, float* __restrict__ acc)
+{
+    const long total = (long)period * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % D); const long t = i / D;
+        float s = 0.f;
+        for (long r = t; r < rows; r += period) s += x[(size_t)r * D + d];
+        acc[i] += s;
+    }
+}
+extern "C" int vpf_rowsum_mod_f32(const float* x, long rows, int D, int period, float* acc, void* stream)
+{
+    if (!x || !acc) return VPF_ERR_NULL;
+    if (rows < 0 || D <= 0 || period <= 0) return VPF_ERR_BADSHAPE;
+    if (rows == 0) return VPF_OK;
+    hipLaunchKernelGGL(rowsum_mod_kernel, dim3(grid_for((long)period * D, 256)), dim3(256), 0, (hipStream_t)stream, x, rows, D, period, acc);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}

@@ -1,0 +1,312 @@
+// gemm.hip -- bf16 MFMA GEMM family for gfx950:  C[m,n] (+)= sum_k A(m,k) * B(n,k)
+//
+// Replaces the aten linear / conv1d(k=1) / mm / bmm calls of the reference's encoder, MLP,
+// projections and Group2Emb (vipformer/model/pointcloud/partseg.py:48-51,67-86,191-198;
+// utils.py:153-165) and their autograd backward (dgrad / wgrad).
+//
+// One kernel template covers forward (A=[M,K], B=W[N,K]), dgrad (B = W read "k-strided") and
+// wgrad (both operands k-strided, split-K with fp32 atomics into the gradient buffer):
+//   * operands are bf16 in HBM; an operand is either K-MAJOR (contraction index contiguous)
+//     or K-STRIDED (stored [K][rows]).  Tiles are staged in LDS in their natural HBM
+//     orientation with 16-byte coalesced loads; K-major fragments are read with ds_read_b128,
+//     K-strided fragments with the gfx950 transposing read ds_read_b64_tr_b16, so no operand
+//     is ever transposed in memory.
+//   * 64-lane wavefronts, v_mfma_f32_32x32x16_bf16, fp32 accumulate; 256 threads = 4 waves per
+//     workgroup, wave tile = TM x TN MFMA tiles; LDS double-buffered with register prefetch
+//     (global loads of tile t+1 are in flight while tile t is on the matrix cores).
+//   * fused epilogues: bias, GELU (+ pre-activation for backward), dropout + residual add,
+//     GELU' multiply (dgrad), ReLU, per-row-group bias, fp32 atomic accumulate.
+#include "vpf_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define GEMM_BK 32
+#define LDS_PAD 8   // bf16 elements (16 B) of row padding
+
+enum {
+    EPI_STORE = 0,       // C = acc (+bias)            -> bf16 or f32
+    EPI_GELU = 1,        // u = acc + bias; C2 = u (bf16, pre-activation), C = gelu(u) (bf16)
+    EPI_DROP_RES = 2,    // C(f32) = res(f32) + dropout(acc + bias)
+    EPI_GELU_BWD = 3,    // C(bf16) = acc * gelu'(aux_u(bf16))
+    EPI_ATOMIC = 4,      // C(f32) += acc   (split-K)
+    EPI_RELU = 5,        // C = relu(acc + bias)
+    EPI_GROUPBIAS = 6,   // C = acc + gbias[(m / group) * N + n]   (f32 row-group bias), bf16/f32 out
+};
+
+struct GemmArgs {
+    const bf16_t* A; const bf16_t* B;
+    long lda, ldb;              // leading dimension (elements) of the stored matrices
+    long sAb, sBb, sCb;         // batch strides (elements); 0 = shared
+    int M, N, K;
+    int splitk;                 // >1: blockIdx.z = k-slice (EPI_ATOMIC), else blockIdx.z = batch
+    int mode;
+    void* C; long ldc; int c_f32;
+    void* C2; long ldc2;        // EPI_GELU: pre-activation (bf16)
+    const float* bias;          // [N] or null
+    const float* res; long ldres;      // EPI_DROP_RES
+    const bf16_t* aux; long ldaux;     // EPI_GELU_BWD: u
+    const float* gbias; int group;     // EPI_GROUPBIAS
+    const uint32_t* rng; uint32_t site; float p;   // dropout
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x)
+{
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ------------------------------------------------------------------ tile staging
+// K-major operand tile: LDS [ROWS][BK + pad]; K-strided operand tile: LDS [BK][ROWS + pad].
+template <int ROWS, bool TR>
+struct TileCfg {
+    static constexpr int LD = TR ? (ROWS + LDS_PAD) : (GEMM_BK + LDS_PAD);
+    static constexpr int ELEMS = TR ? GEMM_BK * LD : ROWS * LD;
+    static constexpr int CHUNKS = ROWS * GEMM_BK / 8;          // 16-byte chunks per tile
+    static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
+};
+
+template <int ROWS, bool TR>
+__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld, int R, int K, int r0, int k0, int kend,
+                                          uint4 (&regs)[TileCfg<ROWS, TR>::PER_THREAD])
+{
+    using Cfg = TileCfg<ROWS, TR>;
+#pragma unroll
+    for (int i = 0; i < Cfg::PER_THREAD; ++i) {
+        const int c = threadIdx.x + i * 256;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (c < Cfg::CHUNKS) {
+            if (!TR) {
+                const int row = c / (GEMM_BK / 8), kc = c % (GEMM_BK / 8);
+                const int gr = r0 + row, gk = k0 + kc * 8;
+                if (gr < R && gk < kend) v = *reinterpret_cast<const uint4*>(G + (size_t)gr * ld + gk);
+            } else {
+                const int krow = c / (ROWS / 8), rc = c % (ROWS / 8);
+                const int gk = k0 + krow, gr = r0 + rc * 8;
+                if (gk < kend && gr < R) v = *reinterpret_cast<const uint4*>(G + (size_t)gk * ld + gr);
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+template <int ROWS, bool TR>
+__device__ __forceinline__ void tile_store(bf16_t* __restrict__ S, const uint4 (&regs)[TileCfg<ROWS, TR>::PER_THREAD])
+{
+    using Cfg = TileCfg<ROWS, TR>;
+#pragma unroll
+    for (int i = 0; i < Cfg::PER_THREAD; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < Cfg::CHUNKS) {
+            int off;
+            if (!TR) { const int row = c / (GEMM_BK / 8), kc = c % (GEMM_BK / 8); off = row * Cfg::LD + kc * 8; }
+            else { const int krow = c / (ROWS / 8), rc = c % (ROWS / 8); off = krow * Cfg::LD + rc * 8; }
+            *reinterpret_cast<uint4*>(S + off) = regs[i];
+        }
+    }
+}
+
+// fragment for one 32x32x16 MFMA: rows [row0, row0+32), k-step s (16 wide) of the BK=32 tile
+template <int ROWS, bool TR>
+__device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int row0, int s)
+{
+    using Cfg = TileCfg<ROWS, TR>;
+    const int lane = threadIdx.x & 63;
+    if (!TR) {
+        const int r = lane & 31, h = lane >> 5;
+        const uint4 v = *reinterpret_cast<const uint4*>(S + (row0 + r) * Cfg::LD + s * 16 + 8 * h);
+        return __builtin_bit_cast(bf16x8_t, v);
+    } else {
+        // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p addresses row q,
+        // columns 4p..4p+3; lane i receives column i of the 4 rows.
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const int h = g >> 1, roff = 16 * (g & 1);
+        const bf16_t* a0 = S + (s * 16 + 8 * h + q) * Cfg::LD + row0 + roff + 4 * p;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * Cfg::LD));
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        s16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8_t, v);
+    }
+}
+
+// ------------------------------------------------------------------ kernel
+template <int TM, int TN, int WM, int WN, bool ATR, bool BTR>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    using ACfg = TileCfg<BM, ATR>;
+    using BCfg = TileCfg<BN, BTR>;
+    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (ACfg::ELEMS + BCfg::ELEMS)];
+    constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    int kbeg = 0, kend = g.K;
+    const bf16_t* A = g.A; const bf16_t* B = g.B;
+    long cb = 0;
+    if (g.splitk > 1) {
+        const int per = ((g.K + g.splitk - 1) / g.splitk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+        kbeg = blockIdx.z * per; kend = min(g.K, kbeg + per);
+        if (kbeg >= kend) return;
+    } else {
+        A += (size_t)blockIdx.z * g.sAb; B += (size_t)blockIdx.z * g.sBb; cb = (long)blockIdx.z * g.sCb;
+    }
+
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[ACfg::PER_THREAD], rb[BCfg::PER_THREAD];
+    tile_load<BM, ATR>(A, g.lda, g.M, g.K, m0, kbeg, kend, ra);
+    tile_load<BN, BTR>(B, g.ldb, g.N, g.K, n0, kbeg, kend, rb);
+    tile_store<BM, ATR>(lds, ra);
+    tile_store<BN, BTR>(lds + ACfg::ELEMS, rb);
+    __syncthreads();
+
+    const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bf16_t* cA = lds + cur * STAGE;
+        const bf16_t* cB = cA + ACfg::ELEMS;
+        bf16_t* nA = lds + (cur ^ 1) * STAGE;
+        bf16_t* nB = nA + ACfg::ELEMS;
+        if (kt + 1 < nk) {
+            tile_load<BM, ATR>(A, g.lda, g.M, g.K, m0, kbeg + (kt + 1) * GEMM_BK, kend, ra);
+            tile_load<BN, BTR>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + 1) * GEMM_BK, kend, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR>(cA, (wm * TM + i) * 32, s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR>(cB, (wn * TN + j) * 32, s);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            tile_store<BM, ATR>(nA, ra);
+            tile_store<BN, BTR>(nB, rb);
+        }
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+    VpfRng rng;
+    if (g.mode == EPI_DROP_RES) rng = vpf_rng_init(g.rng, g.site, g.p);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + col_l;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rsub;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bv;
+                const size_t co = (size_t)cb + (size_t)m * g.ldc + n;
+                switch (g.mode) {
+                    case EPI_STORE: break;
+                    case EPI_GELU:
+                        reinterpret_cast<bf16_t*>(g.C2)[(size_t)m * g.ldc2 + n] = f32_to_bf16(v);
+                        v = gelu_f(bf16_to_f32(f32_to_bf16(v)));
+                        break;
+                    case EPI_DROP_RES: {
+                        const bool keep = vpf_keep(rng, (uint64_t)m * (uint64_t)g.N + (uint64_t)n);
+                        v = g.res[(size_t)m * g.ldres + n] + (keep ? v * rng.scale : 0.f);
+                        break;
+                    }
+                    case EPI_GELU_BWD: v = v * gelu_grad_f(bf16_to_f32(g.aux[(size_t)m * g.ldaux + n])); break;
+                    case EPI_ATOMIC: atomicAdd(reinterpret_cast<float*>(g.C) + co, v); continue;
+                    case EPI_RELU: v = fmaxf(v, 0.f); break;
+                    case EPI_GROUPBIAS: v += g.gbias[(size_t)(m / g.group) * g.N + n]; break;
+                }
+                if (g.c_f32) reinterpret_cast<float*>(g.C)[co] = v;
+                else reinterpret_cast<bf16_t*>(g.C)[co] = f32_to_bf16(v);
+            }
+        }
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_cfg(const GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t st)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    dim3 grid(vpf_cdiv(g.N, BN), vpf_cdiv(g.M, BM), g.splitk > 1 ? g.splitk : batch);
+    if (!a_tr && !b_tr) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, false, false>), grid, dim3(256), 0, st, g);
+    else if (!a_tr && b_tr) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, false, true>), grid, dim3(256), 0, st, g);
+    else if (a_tr && !b_tr) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, true, false>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, true, true>), grid, dim3(256), 0, st, g);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t st)
+{
+    if (!g.A || !g.B || !g.C) return VPF_ERR_NULL;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || batch <= 0) return VPF_ERR_BADSHAPE;
+    // 16-byte vector loads along the contiguous dimension of each operand
+    const int acont = a_tr ? g.M : g.K, bcont = b_tr ? g.N : g.K;
+    if ((acont % 8) || (bcont % 8) || (g.lda % 8) || (g.ldb % 8) || (g.sAb % 8) || (g.sBb % 8)) return VPF_ERR_BADALIGN;
+    if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return VPF_ERR_BADALIGN;
+    if (g.mode == EPI_ATOMIC) {
+        if (!g.c_f32) return VPF_ERR_UNSUPPORTED;
+        if (g.splitk <= 0) {
+            // fill ~512 workgroups of 64x64 tiles
+            const long tiles = (long)vpf_cdiv(g.M, 64) * vpf_cdiv(g.N, 64);
+            long s = 512 / (tiles > 0 ? tiles : 1);
+            const long maxs = vpf_cdiv(g.K, 4 * GEMM_BK);
+            if (s > maxs) s = maxs;
+            if (s < 1) s = 1;
+            g.splitk = (int)s;
+        }
+        if (g.splitk == 1) g.splitk = 0, batch = 1;
+        if (batch != 1 && g.splitk > 1) return VPF_ERR_UNSUPPORTED;
+        return launch_cfg<1, 1, 2, 2>(g, a_tr, b_tr, batch, st);
+    }
+    g.splitk = 0;
+    const long wg_128x64 = (long)vpf_cdiv(g.M, 128) * vpf_cdiv(g.N, 64) * batch;
+    if (wg_128x64 >= 2048 && g.N >= 128) return launch_cfg<2, 2, 2, 2>(g, a_tr, b_tr, batch, st);   // 128x128
+    if (wg_128x64 >= 512) return launch_cfg<1, 2, 4, 1>(g, a_tr, b_tr, batch, st);                   // 128x64
+    return launch_cfg<1, 1, 2, 2>(g, a_tr, b_tr, batch, st);                                         // 64x64
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void* B, int b_kstrided, long ldb,
+                             int M, int N, int K, int batch, long sAb, long sBb, long sCb,
+                             void* C, long ldc, int c_is_f32, int mode, const float* bias,
+                             void* C2, long ldc2, const float* res, long ldres, const void* aux, long ldaux,
+                             const float* gbias, int group, const uint32_t* rng_state, uint32_t site, float p,
+                             int splitk, void* stream)
+{
+    GemmArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb;
+    g.sAb = sAb; g.sBb = sBb; g.sCb = sCb; g.M = M; g.N = N; g.K = K; g.splitk = splitk; g.mode = mode;
+    g.C = C; g.ldc = ldc; g.c_f32 = c_is_f32; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
+    g.aux = (const bf16_t*)aux; g.ldaux = ldaux; g.gbias = gbias; g.group = group > 0 ? group : 1;
+    g.rng = rng_state; g.site = site; g.p = p;
+    if (mode < 0 || mode > EPI_GROUPBIAS) return VPF_ERR_UNSUPPORTED;
+    if (mode == EPI_GELU && !C2) return VPF_ERR_NULL;
+    if (mode == EPI_DROP_RES && (!res || !rng_state || !c_is_f32)) return VPF_ERR_NULL;
+    if (mode == EPI_GELU_BWD && !aux) return VPF_ERR_NULL;
+    if (mode == EPI_GROUPBIAS && !gbias) return VPF_ERR_NULL;
+    return gemm_dispatch(g, a_kstrided, b_kstrided, batch, (hipStream_t)stream);
+}

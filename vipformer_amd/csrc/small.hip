@@ -1,0 +1,457 @@
+// small.hip -- the K=3 front-ends (per-point adapter MLP, centre position MLP, Group2Emb's first
+// conv + BatchNorm), image patchify, NT-Xent and the fused AdamW step.
+// Replaces: classifier.py:31-36 (PointCloudInputAdapter.point_mlp[0:3]); partseg.py:498-501
+// (position_emb[0:2]); utils.py:153-157 (first_conv[0:3]); partseg.py:632 (Rearrange);
+// lightly NTXentLoss (pretrain.py:155,196,202); torch.optim.AdamW (pretrain.py:121-124,210).
+#include "vpf_common.h"
+
+static inline int grid_for(long n, int per_block, int cap = 4096)
+{
+    long g = (n + per_block - 1) / per_block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x)
+{
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// =============================================================================== adapter front: Linear(C,64) -> LN(64) -> ReLU
+// wave per row (grid-stride), lane = channel.  out bf16 [M,64] feeds the 64->D MFMA GEMM.
+#define AD_MAXC 8
+__global__ void __launch_bounds__(256) adapter_front_fwd_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W,
+                                                              const float* __restrict__ b, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, bf16_t* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float w[AD_MAXC];
+#pragma unroll
+    for (int j = 0; j < AD_MAXC; ++j) w[j] = j < C ? W[lane * C + j] : 0.f;
+    const float bb = b[lane], ga = gamma[lane], be = beta[lane];
+    for (long r = wave0; r < M; r += nw) {
+        float h = bb;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) if (j < C) h += w[j] * x[(size_t)r * C + j];
+        const float mu = wave_sum(h) * (1.f / 64.f);
+        const float d = h - mu;
+        const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + 1e-5f);
+        out[(size_t)r * 64 + lane] = f32_to_bf16(fmaxf(d * rs * ga + be, 0.f));
+    }
+}
+extern "C" int vpf_adapter_front_fwd(const float* x, long M, int C, const float* W, const float* b, const float* gamma,
+                                     const float* beta, void* out_bf16, void* stream)
+{
+    if (!x || !W || !b || !gamma || !beta || !out_bf16) return VPF_ERR_NULL;
+    if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
+    if (M == 0) return VPF_OK;
+    hipLaunchKernelGGL(adapter_front_fwd_kernel, dim3(grid_for(M, 32, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, gamma, beta, (bf16_t*)out_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// da (bf16 [M,64]) -> dW[64,C] += , db[64] +=, dgamma[64] +=, dbeta[64] +=   (input needs no grad)
+__global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
+                                                              const float* __restrict__ W, const float* __restrict__ b,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float w[AD_MAXC], aw[AD_MAXC];
+#pragma unroll
+    for (int j = 0; j < AD_MAXC; ++j) { w[j] = j < C ? W[lane * C + j] : 0.f; aw[j] = 0.f; }
+    const float bb = b[lane], ga = gamma[lane], be = beta[lane];
+    float adb = 0.f, adg = 0.f, adbe = 0.f;
+    for (long r = wave0; r < M; r += nw) {
+        float xv[AD_MAXC];
+        float h = bb;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) { xv[j] = j < C ? x[(size_t)r * C + j] : 0.f; h += w[j] * xv[j]; }
+        const float mu = wave_sum(h) * (1.f / 64.f);
+        const float d = h - mu;
+        const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + 1e-5f);
+        const float xh = d * rs;
+        float g = bf16_to_f32(da[(size_t)r * 64 + lane]);
+        if (xh * ga + be <= 0.f) g = 0.f;
+        adg += g * xh; adbe += g;
+        const float gx = g * ga;
+        const float m1 = wave_sum(gx) * (1.f / 64.f), m2 = wave_sum(gx * xh) * (1.f / 64.f);
+        const float dh = rs * (gx - m1 - xh * m2);
+        adb += dh;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[j];
+    }
+    atomicAdd(db + lane, adb); atomicAdd(dgamma + lane, adg); atomicAdd(dbeta + lane, adbe);
+#pragma unroll
+    for (int j = 0; j < AD_MAXC; ++j) if (j < C) atomicAdd(dW + lane * C + j, aw[j]);
+}
+extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b,
+                                     const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta,
+                                     void* stream)
+{
+    if (!x || !da_bf16 || !W || !b || !gamma || !beta || !dW || !db || !dgamma || !dbeta) return VPF_ERR_NULL;
+    if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
+    if (M == 0) return VPF_OK;
+    hipLaunchKernelGGL(adapter_front_bwd_kernel, dim3(grid_for(M, 256, 512)), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C,
+                       W, b, gamma, beta, dW, db, dgamma, dbeta);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== generic tiny-K front: y = act(x W^T + b), x f32 [M,C<=8], W [N,C]
+// act 0 = none, 1 = GELU.  out bf16 [M,N].  (position_emb[0:2]: C=3, N=128, GELU)
+__global__ void smallk_fwd_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W, const float* __restrict__ b,
+                                  int N, int act, bf16_t* __restrict__ out)
+{
+    const long total = M * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N); const long m = i / N;
+        float u = b[n];
+        for (int j = 0; j < C; ++j) u += W[n * C + j] * x[(size_t)m * C + j];
+        out[i] = f32_to_bf16(act == 1 ? gelu_f(u) : u);
+    }
+}
+extern "C" int vpf_smallk_fwd(const float* x, long M, int C, const float* W, const float* b, int N, int act, void* out_bf16, void* stream)
+{
+    if (!x || !W || !b || !out_bf16) return VPF_ERR_NULL;
+    if (M < 0 || C <= 0 || C > 8 || N <= 0) return VPF_ERR_BADSHAPE;
+    if (M == 0) return VPF_OK;
+    hipLaunchKernelGGL(smallk_fwd_kernel, dim3(grid_for(M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, N, act, (bf16_t*)out_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// dy bf16 [M,N] -> dW[N,C] +=, db[N] +=.   thread = output channel n, block = row slab
+__global__ void smallk_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, long M, int C, const float* __restrict__ W,
+                                  const float* __restrict__ b, int N, int act, float* __restrict__ dW, float* __restrict__ db, int rows_per_block)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float w[8], aw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w[j] = j < C ? W[n * C + j] : 0.f; aw[j] = 0.f; }
+    const float bb = b[n];
+    float ab = 0.f;
+    const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (long r = r0; r < r1; ++r) {
+        float xv[8];
+        float u = bb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { xv[j] = j < C ? x[(size_t)r * C + j] : 0.f; u += w[j] * xv[j]; }
+        float g = bf16_to_f32(dy[(size_t)r * N + n]);
+        if (act == 1) g *= gelu_grad_f(u);
+        ab += g;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) aw[j] += g * xv[j];
+    }
+    atomicAdd(db + n, ab);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < C) atomicAdd(dW + n * C + j, aw[j]);
+}
+extern "C" int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C, const float* W, const float* b, int N, int act,
+                              float* dW, float* db, void* stream)
+{
+    if (!x || !dy_bf16 || !W || !b || !dW || !db) return VPF_ERR_NULL;
+    if (M < 0 || C <= 0 || C > 8 || N <= 0) return VPF_ERR_BADSHAPE;
+    if (M == 0) return VPF_OK;
+    int rpb = 64;
+    while ((M + rpb - 1) / rpb > 8192) rpb *= 2;
+    const int bx = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    dim3 grid(vpf_cdiv(N, bx), (unsigned)((M + rpb - 1) / rpb));
+    hipLaunchKernelGGL(smallk_bwd_kernel, grid, dim3(bx), 0, (hipStream_t)stream, x, (const bf16_t*)dy_bf16, M, C, W, b, N, act, dW, db, rpb);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== Group2Emb first conv (C -> 64) + BatchNorm(64) + ReLU
+// h1 = x W^T + b is never stored: statistics pass, then normalise pass (both recompute it from the 12-byte row).
+__global__ void __launch_bounds__(256) g2e_conv1_stats_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W,
+                                                            const float* __restrict__ b, float* __restrict__ sums, float* __restrict__ sumsq)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float w[AD_MAXC];
+#pragma unroll
+    for (int j = 0; j < AD_MAXC; ++j) w[j] = j < C ? W[lane * C + j] : 0.f;
+    const float bb = b[lane];
+    float s = 0.f, q = 0.f;
+    for (long r = wave0; r < M; r += nw) {
+        float h = bb;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) if (j < C) h += w[j] * x[(size_t)r * C + j];
+        s += h; q += h * h;
+    }
+    atomicAdd(sums + lane, s); atomicAdd(sumsq + lane, q);
+}
+extern "C" int vpf_g2e_conv1_stats(const float* x, long M, int C, const float* W, const float* b, float* sums, float* sumsq, void* stream)
+{
+    if (!x || !W || !b || !sums || !sumsq) return VPF_ERR_NULL;
+    if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(g2e_conv1_stats_kernel, dim3(grid_for(M, 512, 1024)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, sums, sumsq);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+__global__ void __launch_bounds__(256) g2e_conv1_apply_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W,
+                                                            const float* __restrict__ b, const float* __restrict__ stat,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float w[AD_MAXC];
+#pragma unroll
+    for (int j = 0; j < AD_MAXC; ++j) w[j] = j < C ? W[lane * C + j] : 0.f;
+    const float bb = b[lane], mu = stat[lane], rs = stat[64 + lane], ga = gamma[lane], be = beta[lane];
+    for (long r = wave0; r < M; r += nw) {
+        float h = bb;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) if (j < C) h += w[j] * x[(size_t)r * C + j];
+        out[(size_t)r * 64 + lane] = f32_to_bf16(fmaxf((h - mu) * rs * ga + be, 0.f));
+    }
+}
+extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
+                                   const float* beta, void* out_bf16, void* stream)
+{
+    if (!x || !W || !b || !stat || !gamma || !beta || !out_bf16) return VPF_ERR_NULL;
+    if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(g2e_conv1_apply_kernel, dim3(grid_for(M, 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, stat, gamma, beta, (bf16_t*)out_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// backward: pass 1 (reduce) tmp[c] += sum g, tmp[64+c] += sum g*xhat ; pass 2 dW/db (and dgamma/dbeta from tmp)
+__global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
+                                                          const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ stat,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int training,
+                                                          float* __restrict__ tmp, int pass, float* __restrict__ dW, float* __restrict__ db,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+    float w[AD_MAXC], aw[AD_MAXC];
+#pragma unroll
+    for (int j = 0; j < AD_MAXC; ++j) { w[j] = j < C ? W[lane * C + j] : 0.f; aw[j] = 0.f; }
+    const float bb = b[lane], mu = stat[lane], rs = stat[64 + lane], ga = gamma[lane], be = beta[lane];
+    const float invM = 1.f / (float)M;
+    const float sg = pass ? tmp[lane] * invM : 0.f, sgx = pass ? tmp[64 + lane] * invM : 0.f;
+    float a0 = 0.f, a1 = 0.f;
+    for (long r = wave0; r < M; r += nw) {
+        float xv[AD_MAXC];
+        float h = bb;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) { xv[j] = j < C ? x[(size_t)r * C + j] : 0.f; h += w[j] * xv[j]; }
+        const float xh = (h - mu) * rs;
+        float g = bf16_to_f32(da[(size_t)r * 64 + lane]);
+        if (xh * ga + be <= 0.f) g = 0.f;
+        if (!pass) { a0 += g; a1 += g * xh; }
+        else {
+            const float dh = training ? ga * rs * (g - sg - xh * sgx) : ga * rs * g;
+            a0 += dh;
+#pragma unroll
+            for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[j];
+        }
+    }
+    if (!pass) { atomicAdd(tmp + lane, a0); atomicAdd(tmp + 64 + lane, a1); }
+    else {
+        atomicAdd(db + lane, a0);
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) if (j < C) atomicAdd(dW + lane * C + j, aw[j]);
+        if (blockIdx.x == 0 && threadIdx.x < 64) { atomicAdd(dgamma + lane, tmp[64 + lane]); atomicAdd(dbeta + lane, tmp[lane]); }
+    }
+}
+extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
+                                 const float* gamma, const float* beta, int training, float* tmp128_zeroed, float* dW, float* db,
+                                 float* dgamma, float* dbeta, void* stream)
+{
+    if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !tmp128_zeroed || !dW || !db || !dgamma || !dbeta) return VPF_ERR_NULL;
+    if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
+    const int grid = grid_for(M, 512, 1024);
+    for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma,
+                           beta, training, tmp128_zeroed, pass, dW, db, dgamma, dbeta);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== patchify  'b (h p1) (w p2) c -> b (h w) (p1 p2 c)'
+// imgs is an arbitrary-stride [B,H,W,3] view (pretrain.py:179 hands a permuted NCHW tensor); out bf16 [B*T, p*p*3]
+__global__ void patchify_kernel(const float* __restrict__ img, long sb, long sh, long sw, long sc, int B, int Hh, int Ww, int Cc, int p,
+                                bf16_t* __restrict__ out)
+{
+    const int wp = Ww / p, hp = Hh / p, pd = p * p * Cc;
+    const long total = (long)B * hp * wp * pd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % pd); const long tok = i / pd;
+        const int c = e % Cc, p2 = (e / Cc) % p, p1 = e / (Cc * p);
+        const int tw = (int)(tok % wp), th = (int)((tok / wp) % hp); const long b = tok / ((long)wp * hp);
+        out[i] = f32_to_bf16(img[b * sb + (long)(th * p + p1) * sh + (long)(tw * p + p2) * sw + c * sc]);
+    }
+}
+extern "C" int vpf_patchify(const float* img, long sb, long sh, long sw, long sc, int B, int H, int W, int C, int p, void* out_bf16, void* stream)
+{
+    if (!img || !out_bf16) return VPF_ERR_NULL;
+    if (B < 0 || H <= 0 || W <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p)) return VPF_ERR_BADSHAPE;
+    if (B == 0) return VPF_OK;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, img, sb, sh, sw, sc, B, H, W, C, p, (bf16_t*)out_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== NT-Xent (lightly 1.1.21 formulation, memory bank 0)
+// z0,z1 f32 [b,D].  n = 2b rows.  fwd: zn (normalised rows) [n,D], inv norms [n], P [n,n] softmax over j != i of zn_i.zn_j/T,
+// loss = mean_i -log P[i, pos(i)], pos(i) = (i + b) mod n.  bwd: dz from dloss.
+__global__ void __launch_bounds__(256) ntxent_norm_kernel(const float* __restrict__ z0, const float* __restrict__ z1, int b, int D,
+                                                        float* __restrict__ zn, float* __restrict__ inv)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= 2 * b) return;
+    const float* src = r < b ? z0 + (size_t)r * D : z1 + (size_t)(r - b) * D;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += src[c] * src[c];
+    s = wave_sum(s);
+    const float iv = 1.f / fmaxf(sqrtf(s), 1e-12f);     // F.normalize eps
+    for (int c = lane; c < D; c += 64) zn[(size_t)r * D + c] = src[c] * iv;
+    if (lane == 0) inv[r] = iv;
+}
+// one workgroup per row i
+__global__ void __launch_bounds__(256) ntxent_row_kernel(const float* __restrict__ zn, int b, int D, float invT, float* __restrict__ P,
+                                                       float* __restrict__ loss_rows)
+{
+    extern __shared__ float sm[];      // zi[D] + logits[n]
+    const int n = 2 * b, i = blockIdx.x;
+    float* zi = sm; float* lg = sm + D;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) zi[c] = zn[(size_t)i * D + c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int j = wv; j < n; j += nwv) {
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += zi[c] * zn[(size_t)j * D + c];
+        s = wave_sum(s);
+        if (lane == 0) lg[j] = (j == i) ? -INFINITY : s * invT;
+    }
+    __syncthreads();
+    __shared__ float red[8];
+    float mx = -INFINITY;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) mx = fmaxf(mx, lg[j]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wv] = mx;
+    __syncthreads();
+    mx = red[0];
+    for (int w = 1; w < nwv; ++w) mx = fmaxf(mx, red[w]);
+    __syncthreads();
+    float se = 0.f;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) se += __expf(lg[j] - mx);
+    se = wave_sum(se);
+    if (lane == 0) red[wv] = se;
+    __syncthreads();
+    se = 0.f;
+    for (int w = 0; w < nwv; ++w) se += red[w];
+    const float lse = mx + logf(se);
+    for (int j = threadIdx.x; j < n; j += blockDim.x) P[(size_t)i * n + j] = (j == i) ? 0.f : __expf(lg[j] - lse);
+    if (threadIdx.x == 0) loss_rows[i] = lse - lg[(i + b) % n];
+}
+__global__ void ntxent_mean_kernel(const float* __restrict__ loss_rows, int n, float* __restrict__ loss)
+{
+    float s = 0.f;
+    for (int j = threadIdx.x; j < n; j += 64) s += loss_rows[j];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) *loss = s / (float)n;
+}
+extern "C" int vpf_ntxent_fwd(const float* z0, const float* z1, int b, int D, float temperature, float* zn, float* inv_norm, float* P,
+                              float* loss_rows, float* loss, void* stream)
+{
+    if (!z0 || !z1 || !zn || !inv_norm || !P || !loss_rows || !loss) return VPF_ERR_NULL;
+    if (b <= 0 || D <= 0 || 2 * b > 8192) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = 2 * b;
+    hipLaunchKernelGGL(ntxent_norm_kernel, dim3(vpf_cdiv(n, 4)), dim3(256), 0, st, z0, z1, b, D, zn, inv_norm);
+    hipLaunchKernelGGL(ntxent_row_kernel, dim3(n), dim3(256), sizeof(float) * (D + n), st, zn, b, D, 1.f / temperature, P, loss_rows);
+    hipLaunchKernelGGL(ntxent_mean_kernel, dim3(1), dim3(64), 0, st, loss_rows, n, loss);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// dzn_i = (dL/n/T) * sum_j (G[i,j] + G[j,i]) zn_j,  G = P - onehot(pos);  dz = inv * (dzn - zn (zn . dzn))
+__global__ void __launch_bounds__(256) ntxent_bwd_kernel(const float* __restrict__ zn, const float* __restrict__ inv, const float* __restrict__ P,
+                                                       int b, int D, float invT, const float* __restrict__ dloss, float* __restrict__ dz0,
+                                                       float* __restrict__ dz1)
+{
+    extern __shared__ float sm[];      // coef[n] + dzn[D]
+    const int n = 2 * b, i = blockIdx.x;
+    float* coef = sm; float* dzn = sm + n;
+    const float gs = dloss[0] * invT / (float)n;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        float g = P[(size_t)i * n + j] + P[(size_t)j * n + i];
+        if (j == (i + b) % n) g -= 1.f;
+        if (i == (j + b) % n) g -= 1.f;
+        coef[j] = (j == i) ? 0.f : g * gs;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) s += coef[j] * zn[(size_t)j * D + c];
+        dzn[c] = s;
+    }
+    __syncthreads();
+    __shared__ float red[8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    float dot = 0.f;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) dot += dzn[c] * zn[(size_t)i * D + c];
+    dot = wave_sum(dot);
+    if (lane == 0) red[wv] = dot;
+    __syncthreads();
+    dot = 0.f;
+    for (int w = 0; w < nwv; ++w) dot += red[w];
+    float* dst = i < b ? dz0 + (size_t)i * D : dz1 + (size_t)(i - b) * D;
+    const float iv = inv[i];
+    for (int c = threadIdx.x; c < D; c += blockDim.x) dst[c] = iv * (dzn[c] - zn[(size_t)i * D + c] * dot);
+}
+extern "C" int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b, int D, float temperature, const float* dloss,
+                              float* dz0, float* dz1, void* stream)
+{
+    if (!zn || !inv_norm || !P || !dloss || !dz0 || !dz1) return VPF_ERR_NULL;
+    if (b <= 0 || D <= 0 || 2 * b > 8192) return VPF_ERR_BADSHAPE;
+    const int n = 2 * b;
+    hipLaunchKernelGGL(ntxent_bwd_kernel, dim3(n), dim3(256), sizeof(float) * (n + D), (hipStream_t)stream, zn, inv_norm, P, b, D, 1.f / temperature, dloss, dz0, dz1);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// =============================================================================== fused AdamW over a flat buffer (+ bf16 shadow)
+// torch.optim.AdamW semantics (decoupled weight decay, bias correction).  hyper (device, 8 floats):
+// {lr, beta1, beta2, eps, weight_decay, grad_scale, step (float, incremented here), skip_flag}
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16_t* __restrict__ shadow, long n, const float* __restrict__ hyper)
+{
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gs = hyper[5], step = hyper[6] + 1.f;
+    const bool skip = hyper[7] != 0.f;
+    const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float pv = p[i];
+        if (!skip) {
+            const float gv = g[i] * gs;
+            const float mv = b1 * m[i] + (1.f - b1) * gv;
+            const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+            m[i] = mv; v[i] = vv;
+            pv = pv * (1.f - lr * wd);
+            pv -= step_size * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
+            p[i] = pv;
+        }
+        if (shadow) shadow[i] = f32_to_bf16(pv);
+    }
+}
+__global__ void adamw_step_kernel(float* hyper) { if (threadIdx.x == 0 && hyper[7] == 0.f) hyper[6] += 1.f; }
+extern "C" int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev, int advance_step,
+                              void* stream)
+{
+    if (!p || !g || !m || !v || !hyper_dev) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow_bf16, n, hyper_dev);
+    if (advance_step) hipLaunchKernelGGL(adamw_step_kernel, dim3(1), dim3(64), 0, st, hyper_dev);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}

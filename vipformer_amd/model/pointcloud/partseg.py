@@ -1,0 +1,341 @@
+"""MI355X mirror of the pre-training part of ``vipformer.model.pointcloud.partseg``
+(reference partseg.py:14-342, 473-550, 608-680): same class names, constructor
+arguments, forward contracts and state-dict keys; every forward is a short sequence
+of C-ABI calls into libvipformer_hip.so (see vipformer_amd/ops.py).
+
+Supported configuration of the fused kernels: head dim 64 (every shipped architecture:
+H4D256, H6D384), q/kv/latent/output channels all equal, no pad/attn masks (never used on
+the pre-training path, partseg.py:326-335 passes pad_mask=None).  Anything else raises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import _lib as L
+from ... import ops
+from .utils import Group2Emb, Sequential, divide_patches
+
+
+def _ln_params(*mods):
+    out = []
+    for m in mods:
+        if m is not None:
+            out += list(m.parameters())
+    return out
+
+
+class MultiHeadAttention(nn.Module):
+    """partseg.py:14-86.  q/k/v projections without bias, o_proj with bias, dropout on the
+    attention probabilities.  Returns fp32 [B, Lq, D]."""
+
+    def __init__(self, num_heads: int, num_q_input_channels: int, num_kv_input_channels: int, num_latent_channels: int,
+                 num_output_channels: Optional[int] = None, dropout: float = 0.0):
+        super().__init__()
+        if num_output_channels is None:
+            num_output_channels = num_q_input_channels
+        if num_latent_channels % num_heads != 0:
+            raise ValueError("num_latent_channels must be divisible by num_heads")
+        per_head = num_latent_channels // num_heads
+        self.dp_scale = per_head ** -0.5
+        self.num_heads = num_heads
+        self.q_proj = nn.Linear(num_q_input_channels, num_latent_channels, bias=False)
+        self.k_proj = nn.Linear(num_kv_input_channels, num_latent_channels, bias=False)
+        self.v_proj = nn.Linear(num_kv_input_channels, num_latent_channels, bias=False)
+        self.o_proj = nn.Linear(num_latent_channels, num_latent_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.site_attn = ops.new_site()
+        self._dims = (num_q_input_channels, num_kv_input_channels, num_latent_channels, num_output_channels, per_head)
+
+    def _check(self, pad_mask, attn_mask):
+        if attn_mask is not None:
+            raise NotImplementedError("attention masks not supported yet")
+        if pad_mask is not None:
+            raise L.VpfError("pad_mask is not supported by the fused attention kernel (unused on the pre-training path)")
+        qi, ki, lat, out, ph = self._dims
+        if not (qi == ki == lat == out) or ph != 64:
+            raise L.VpfError("fused attention needs equal q/kv/latent/output channels and head dim 64")
+
+    def _run(self, x_q, x_kv, pos, ln_q, ln_kv, residual, p_res, site_res):
+        cfg = dict(ln_q=ln_q, ln_kv=ln_kv, residual=residual, p_res=p_res, site_res=site_res, training=self.training)
+        return ops.AttnBlockFn.apply(x_q, pos, x_kv, self, cfg, *(list(self.parameters()) + _ln_params(ln_q, ln_kv)))
+
+    def forward(self, x_q, x_kv, pad_mask=None, attn_mask=None):
+        self._check(pad_mask, attn_mask)
+        return self._run(x_q, None if x_kv is x_q else x_kv, None, None, None, False, 0.0, 0)
+
+
+class CrossAttention(nn.Module):
+    """partseg.py:89-116: LayerNorm(q), LayerNorm(kv) (separate affine) then MultiHeadAttention."""
+
+    def __init__(self, num_heads: int, num_q_input_channels: int, num_kv_input_channels: int, num_latent_channels: int,
+                 dropout: float = 0.0):
+        super().__init__()
+        self.q_norm = nn.LayerNorm(num_q_input_channels)
+        self.kv_norm = nn.LayerNorm(num_kv_input_channels)
+        self.attention = MultiHeadAttention(num_heads=num_heads, num_q_input_channels=num_q_input_channels,
+                                            num_kv_input_channels=num_kv_input_channels,
+                                            num_latent_channels=num_latent_channels,
+                                            num_output_channels=num_latent_channels, dropout=dropout)
+
+    def _fused(self, args, pos, residual, p_res, site_res):
+        x_q, x_kv = args[0], args[1]
+        pad_mask = args[2] if len(args) > 2 else None
+        self.attention._check(pad_mask, None)
+        return self.attention._run(x_q, x_kv, pos, self.q_norm, self.kv_norm, residual, p_res, site_res)
+
+    def forward(self, x_q, x_kv, pad_mask=None, attn_mask=None):
+        self.attention._check(pad_mask, attn_mask)
+        return self.attention._run(x_q, x_kv, None, self.q_norm, self.kv_norm, False, 0.0, 0)
+
+
+class SelfAttention(nn.Module):
+    """partseg.py:119-141: one LayerNorm then MultiHeadAttention(x, x)."""
+
+    def __init__(self, num_heads: int, num_latent_channels: int, dropout: float = 0.0):
+        super().__init__()
+        self.norm = nn.LayerNorm(num_latent_channels)
+        self.attention = MultiHeadAttention(num_heads=num_heads, num_q_input_channels=num_latent_channels,
+                                            num_kv_input_channels=num_latent_channels,
+                                            num_latent_channels=num_latent_channels,
+                                            num_output_channels=num_latent_channels, dropout=dropout)
+
+    def _fused(self, args, pos, residual, p_res, site_res):
+        pad_mask = args[1] if len(args) > 1 else None
+        self.attention._check(pad_mask, None)
+        return self.attention._run(args[0], None, pos, self.norm, None, residual, p_res, site_res)
+
+    def forward(self, x, pad_mask=None, attn_mask=None):
+        self.attention._check(pad_mask, attn_mask)
+        return self.attention._run(x, None, None, self.norm, None, False, 0.0, 0)
+
+
+class MLP(Sequential):
+    """partseg.py:191-198: LayerNorm -> Linear(D, w*D) -> GELU(erf) -> Linear(w*D, D)."""
+
+    def __init__(self, num_channels: int, widening_factor: int):
+        super().__init__(nn.LayerNorm(num_channels), nn.Linear(num_channels, widening_factor * num_channels), nn.GELU(),
+                         nn.Linear(widening_factor * num_channels, num_channels))
+
+    def _fused(self, args, pos, residual, p_res, site_res):
+        if pos is not None:
+            raise L.VpfError("pos is only fused into attention blocks")
+        cfg = dict(residual=residual, p_res=p_res, site_res=site_res, training=self.training)
+        return ops.MLPBlockFn.apply(args[0], self, cfg, *self.parameters())
+
+    def forward(self, *x):
+        return self._fused(x, None, False, 0.0, 0)
+
+
+class DropPath(nn.Module):
+    """Stochastic depth (timm.models.layers.DropPath in the reference).  Identity on the
+    pre-training path (max_dpr = 0 on every shipped script, partseg.py:206)."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class Residual(nn.Module):
+    """partseg.py:201-213: drop_path(dropout(module(*args)) + args[0]).  For the attention and
+    MLP blocks the dropout + residual add run inside the producing GEMM's epilogue."""
+
+    def __init__(self, module: nn.Module, dropout: float, drop_path_rate: float):
+        super().__init__()
+        self.module = module
+        self.dropout = nn.Dropout(p=dropout)
+        self.drop_path = DropPath(drop_path_rate) if drop_path_rate > .0 else nn.Identity()
+        self.site = ops.new_site()
+
+    def forward(self, *args, pos=None, **kwargs):
+        fused = isinstance(self.module, (CrossAttention, SelfAttention, MLP)) and not kwargs \
+            and isinstance(self.drop_path, nn.Identity)
+        if fused:
+            return self.module._fused(args, pos, True, self.dropout.p, self.site)
+        base = args[0] if pos is None else args[0] + pos
+        y = self.module(base, *args[1:], **kwargs)
+        p = self.dropout.p if self.training else 0.0
+        return self.drop_path(ops.DropoutAddFn.apply(y, base, p, self.site))
+
+
+class _Layer(Sequential):
+    """Two Residual blocks; ``pos`` (added to the input, part of the residual base,
+    partseg.py:326,335) is folded into the first block's LayerNorm kernel."""
+
+    def forward(self, *x, pos=None):
+        x = self[0](*x, pos=pos)
+        return self[1](x)
+
+
+class CrossAttentionLayer(_Layer):
+    """partseg.py:144-167.  Residual dropout: attention branch atten_drop, MLP branch mlp_drop."""
+
+    def __init__(self, num_heads: int, num_q_input_channels: int, num_kv_input_channels: int, num_latent_channels: int,
+                 widening_factor: int = 1, drop_path_rate: float = 0.0, atten_drop: float = 0.0, mlp_drop: float = 0.0,
+                 attention_residual: bool = True):
+        cross_attn = CrossAttention(num_heads=num_heads, num_q_input_channels=num_q_input_channels,
+                                    num_kv_input_channels=num_kv_input_channels,
+                                    num_latent_channels=num_latent_channels, dropout=atten_drop)
+        self.attention_residual = attention_residual
+        super().__init__(Residual(cross_attn, atten_drop, drop_path_rate) if attention_residual else cross_attn,
+                         Residual(MLP(num_q_input_channels, widening_factor), mlp_drop, drop_path_rate))
+
+    def forward(self, *x, pos=None):
+        if not self.attention_residual:
+            base = x[0] if pos is None else x[0] + pos
+            return self[1](self[0](base, *x[1:]))
+        return super().forward(*x, pos=pos)
+
+
+class SelfAttentionLayer(_Layer):
+    """partseg.py:170-188.  BOTH residual dropouts use mlp_drop (:186-187)."""
+
+    def __init__(self, num_heads: int, num_latent_channels: int, widening_factor: int = 1, drop_path_rate: float = 0.0,
+                 atten_drop: float = 0.0, mlp_drop: float = 0.0):
+        self_attn = SelfAttention(num_heads=num_heads, num_latent_channels=num_latent_channels, dropout=atten_drop)
+        super().__init__(Residual(self_attn, mlp_drop, drop_path_rate),
+                         Residual(MLP(num_latent_channels, widening_factor), mlp_drop, drop_path_rate))
+
+
+class Encoder(nn.Module):
+    """partseg.py:233-342: one cross-attention layer (query = tokens + pos, key/value = the
+    per-point / per-patch embeddings) followed by ``num_self_attention_layers`` self-attention
+    layers; ``pos`` is re-added before every layer.  ``cross_attn_1 is cross_attn_n`` when
+    there is a single cross-attention layer (one parameter set, two state-dict prefixes)."""
+
+    def __init__(self, num_latent_channels: int, num_cross_attention_layers: int = 1, num_cross_attention_heads: int = 4,
+                 cross_attention_widening_factor: int = 1, first_cross_attention_layer_shared: bool = False,
+                 num_self_attention_layers: int = 6, num_self_attention_heads: int = 4,
+                 self_attention_widening_factor: int = 1, dpr_list: list = [], atten_drop: float = 0.0,
+                 mlp_drop: float = 0.0, activation_checkpointing: bool = False, modal_prior: bool = False):
+        super().__init__()
+        if num_cross_attention_layers <= 0:
+            raise ValueError("num_cross_attention_layers must be > 0")
+        if activation_checkpointing:
+            raise L.VpfError("activation checkpointing is never enabled by the reference's factories (utils.py:120-132)")
+        self.num_cross_attention_layers = num_cross_attention_layers
+
+        def cross_attn():
+            return CrossAttentionLayer(num_heads=num_cross_attention_heads, num_q_input_channels=num_latent_channels,
+                                       num_kv_input_channels=num_latent_channels, num_latent_channels=num_latent_channels,
+                                       widening_factor=cross_attention_widening_factor, atten_drop=atten_drop,
+                                       mlp_drop=mlp_drop)
+
+        self.cross_attn_n = cross_attn()
+        if first_cross_attention_layer_shared or num_cross_attention_layers == 1:
+            self.cross_attn_1 = self.cross_attn_n
+        else:
+            self.cross_attn_1 = cross_attn()
+        self.sa_layers = nn.ModuleList()
+        for i in range(num_self_attention_layers):
+            self.sa_layers.append(SelfAttentionLayer(num_heads=num_self_attention_heads,
+                                                     num_latent_channels=num_latent_channels,
+                                                     widening_factor=self_attention_widening_factor,
+                                                     drop_path_rate=dpr_list[i], atten_drop=atten_drop,
+                                                     mlp_drop=mlp_drop))
+        self.modal_prior = modal_prior
+
+    def forward(self, group_embs, pos_embs, pts_embs, layer_idx=[], pad_mask=None):
+        x = self.cross_attn_1(group_embs, pts_embs, pad_mask, pos=pos_embs)
+        feats = []
+        for i, sa in enumerate(self.sa_layers):
+            if i + 1 < self.num_cross_attention_layers:
+                x = self.cross_attn_n(x, pts_embs, pad_mask, pos=pos_embs)
+            x = sa(x, pos=pos_embs)
+            if i + 1 in layer_idx:
+                feats.append(x)
+        return x if self.modal_prior else feats
+
+
+class _Patchify(nn.Module):
+    """Stands in for einops' Rearrange('b (h p1) (w p2) c -> b (h w) (p1 p2 c)') at index 0 of
+    ``patch2emb`` (keeps the Linear at ``patch2emb.1``); the gather itself is vpf_patchify."""
+
+    def __init__(self, patch_size: int):
+        super().__init__()
+        self.patch_size = patch_size
+
+    def forward(self, x):
+        raise L.VpfError("patch2emb is executed as one fused op by CrossFormer_img_mp.forward")
+
+
+def _latent_head(D):
+    return nn.Sequential(nn.BatchNorm1d(2 * D), nn.ReLU(), nn.Linear(2 * D, D, bias=False), nn.BatchNorm1d(D), nn.ReLU(),
+                         nn.Linear(D, D, bias=False))
+
+
+def _encoder(D, n_ca, h_ca, n_sa, h_sa, mr, max_dpr, atten_drop, mlp_drop, modal_prior):
+    dpr_list = [x.item() for x in torch.linspace(0, max_dpr, n_sa)]
+    return Encoder(num_latent_channels=D, num_cross_attention_layers=n_ca, num_cross_attention_heads=h_ca,
+                   cross_attention_widening_factor=mr, num_self_attention_layers=n_sa, num_self_attention_heads=h_sa,
+                   self_attention_widening_factor=mr, dpr_list=dpr_list, atten_drop=atten_drop, mlp_drop=mlp_drop,
+                   modal_prior=modal_prior)
+
+
+class CrossFormer_pc_mp(nn.Module):
+    """partseg.py:473-550: point-cloud branch of --mp pre-training.
+    forward(pts [B,N,3]) -> (feats [B,D], backbone [B,2D])."""
+
+    def __init__(self, input_adapter=None, num_latents=128, num_latent_channels=384, group_size=32,
+                 num_cross_attention_layers=1, num_cross_attention_heads=6, num_self_attention_layers=6,
+                 num_self_attention_heads=6, mlp_widen_factor=4, max_dpr=.0, atten_drop=0.1, mlp_drop=.5, modal_prior=True):
+        super().__init__()
+        self.num_groups = num_latents
+        self.group_size = group_size
+        self.group2emb = Group2Emb(num_latent_channels)
+        self.position_emb = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, num_latent_channels))
+        self.input_adapter = input_adapter
+        self.encoder = _encoder(num_latent_channels, num_cross_attention_layers, num_cross_attention_heads,
+                                num_self_attention_layers, num_self_attention_heads, mlp_widen_factor, max_dpr, atten_drop,
+                                mlp_drop, modal_prior)
+        self.latent_head = _latent_head(num_latent_channels)
+
+    def backbone(self, pts):
+        pts_embs = self.input_adapter(pts)
+        neighborhood, center = divide_patches(pts, self.num_groups, self.group_size)
+        group_embs = self.group2emb(neighborhood)
+        pos_embs = ops.PosMLPFn.apply(center, self.position_emb, *self.position_emb.parameters())
+        x = self.encoder(group_embs, pos_embs, pts_embs)
+        return ops.PoolFn.apply(x)
+
+    def forward(self, pts):
+        backbone_feats = self.backbone(pts)
+        feats = ops.HeadFn.apply(backbone_feats, self.latent_head, self.training, *self.latent_head.parameters())
+        return feats, backbone_feats
+
+
+class CrossFormer_img_mp(nn.Module):
+    """partseg.py:608-680: image branch.  forward(imgs [B,H,W,3]) -> (feats [B,D], backbone [B,2D]).
+    ``imgs`` may be the permuted NCHW view pretrain.py:179 hands over (strides are honoured)."""
+
+    def __init__(self, img_height=144, img_width=144, patch_size=12, num_latent_channels=384,
+                 num_cross_attention_layers=1, num_cross_attention_heads=6, num_self_attention_layers=6,
+                 num_self_attention_heads=6, mlp_widen_factor=4, max_dpr=.0, atten_drop=0.1, mlp_drop=.5, modal_prior=True):
+        super().__init__()
+        num_patches = (img_height // patch_size) * (img_width // patch_size)
+        self.patch_size = patch_size
+        self.patch2emb = nn.Sequential(_Patchify(patch_size), nn.Linear(patch_size * patch_size * 3, num_latent_channels))
+        self.position_emb = nn.Parameter(torch.randn(1, num_patches, num_latent_channels))
+        self.encoder = _encoder(num_latent_channels, num_cross_attention_layers, num_cross_attention_heads,
+                                num_self_attention_layers, num_self_attention_heads, mlp_widen_factor, max_dpr, atten_drop,
+                                mlp_drop, modal_prior)
+        self.latent_head = _latent_head(num_latent_channels)
+
+    def forward(self, imgs):
+        lin = self.patch2emb[1]
+        patch_embs = ops.PatchEmbedFn.apply(imgs, lin, self.patch_size, *lin.parameters())
+        if patch_embs.shape[1] != self.position_emb.shape[1]:
+            raise ValueError(f"image gives {patch_embs.shape[1]} patches, position_emb has {self.position_emb.shape[1]}")
+        x = self.encoder(patch_embs, self.position_emb, patch_embs)
+        backbone_feats = ops.PoolFn.apply(x)
+        feats = ops.HeadFn.apply(backbone_feats, self.latent_head, self.training, *self.latent_head.parameters())
+        return feats, backbone_feats

@@ -96,3 +96,39 @@ def divide_patches(points: torch.Tensor, num_groups: int, group_size: int):
     centers = fps(points, num_groups)
     _, _, nb = _knn_group(points, centers, group_size, True, False, False, True)
     return nb, centers
+
+
+# ----------------------------------------------------------------------------------------- modules
+class Group2Emb(nn.Module):
+    """utils.py:144-189: per-group mini-PointNet  [B,G,K,C] -> [B,G,dim_model].
+
+    Same sub-module names as the reference (``first_conv.{0,1,3}``, ``second_conv.{0,1,3}``;
+    conv weights are [out,in,1]) so checkpoints interchange; forward is one fused HIP
+    sequence (K=3 front in VALU, 64->128 / 256->256 / 256->D on MFMA, BatchNorm batch
+    statistics in fp32, both max-pools)."""
+
+    def __init__(self, dim_model, point_channels=3):
+        super().__init__()
+        self.dim_model = dim_model
+        self.point_channels = point_channels
+        self.first_conv = nn.Sequential(nn.Conv1d(point_channels, 64, 1), nn.BatchNorm1d(64), nn.ReLU(inplace=True),
+                                        nn.Conv1d(64, 128, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(256, 256, 1), nn.BatchNorm1d(256), nn.ReLU(inplace=True),
+                                         nn.Conv1d(256, self.dim_model, 1))
+
+    def forward(self, point_groups):
+        from ... import ops
+        if point_groups.shape[-1] != self.point_channels:
+            raise ValueError(f"expected {self.point_channels} point channels, got {point_groups.shape[-1]}")
+        if self.dim_model % 8:
+            raise L.VpfError("dim_model must be a multiple of 8")
+        return ops.Group2EmbFn.apply(point_groups, self, self.training, *self.parameters())
+
+
+class Sequential(nn.Sequential):
+    """utils.py:245-252: nn.Sequential whose forward splats tuples into the next module."""
+
+    def forward(self, *x):
+        for layer in self:
+            x = layer(*x) if type(x) == tuple else layer(x)
+        return x

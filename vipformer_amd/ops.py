@@ -1,0 +1,747 @@
+"""Host-side glue between the mirrored nn.Modules and the C ABI (libvipformer_hip.so).
+
+Everything numerical happens in the HIP kernels; this file owns buffers, autograd wiring
+(torch.autograd.Function with hand-written backward sequences) and the small amount of
+parameter bookkeeping the fused kernels need:
+
+  * bf16 "shadow" copies of fp32 master weights (MFMA operands), refreshed when the
+    parameter changes, or owned by the trainer's fused AdamW (which writes them directly);
+  * packed q/k/v weights and gradients (one [3D,D] GEMM instead of three);
+  * weight gradients are accumulated by the wgrad kernels straight into ``param.grad``
+    (fp32 atomics, split over the token dimension), so the Functions return ``None`` for
+    parameters and nothing is re-added by autograd.
+
+Precision contract: fp32 master weights, fp32 residual stream, bf16 MFMA operands with fp32
+accumulation, bf16 activations between fused ops, fp32 statistics (LayerNorm/BatchNorm/softmax).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+EPI_STORE, EPI_GELU, EPI_DROP_RES, EPI_GELU_BWD, EPI_ATOMIC, EPI_RELU, EPI_GROUPBIAS = range(7)
+
+
+# --------------------------------------------------------------------------- RNG state
+class _Rng:
+    """Device-resident dropout state {seed_lo, seed_hi, step, 0}; ``step`` is bumped on the
+    device (vpf_rng_advance) so a captured hipGraph draws fresh masks on every replay."""
+
+    def __init__(self):
+        self.states = {}
+        self.seed_value = 0x1234ABCD5678EF01
+
+    def state(self, device) -> torch.Tensor:
+        key = torch.device(device).index or 0
+        st = self.states.get(key)
+        if st is None:
+            lo, hi = self.seed_value & 0xFFFFFFFF, (self.seed_value >> 32) & 0xFFFFFFFF
+            to_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
+            st = torch.tensor([to_i32(lo), to_i32(hi), 0, 0], dtype=torch.int32, device=f"cuda:{key}")
+            self.states[key] = st
+        return st
+
+    def seed(self, seed: int) -> None:
+        self.seed_value = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.states.clear()
+
+    def advance(self, device) -> None:
+        L.call("vpf_rng_advance", self.state(device))
+
+
+rng = _Rng()
+_site_counter = [0]
+
+
+def new_site() -> int:
+    _site_counter[0] += 1
+    return _site_counter[0]
+
+
+def dropout_keep_mask(site: int, p: float, shape, device) -> torch.Tensor:
+    """The keep mask (uint8) the kernels use for ``site`` at the current rng state (tests)."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    L.call("vpf_dropout_mask", out, n, rng.state(device), site, float(p))
+    return out.view(*shape)
+
+
+# --------------------------------------------------------------------------- parameter packing / shadows
+_managed_shadow: List[Tuple[int, int, torch.Tensor, torch.Tensor]] = []   # (ptr_begin, ptr_end, flat_f32, flat_bf16)
+_shadow_cache = {}
+
+
+def register_managed_shadow(flat_f32: torch.Tensor, flat_bf16: torch.Tensor) -> None:
+    """The trainer's flat fp32 parameter buffer and its bf16 shadow (kept fresh by vpf_adamw_step)."""
+    _managed_shadow.append((flat_f32.data_ptr(), flat_f32.data_ptr() + flat_f32.numel() * 4, flat_f32, flat_bf16))
+
+
+def clear_managed_shadows() -> None:
+    _managed_shadow.clear()
+    _shadow_cache.clear()
+
+
+def _adjacent(ts: Sequence[torch.Tensor]) -> bool:
+    for a, b in zip(ts[:-1], ts[1:]):
+        if not a.is_contiguous() or not b.is_contiguous() or a.data_ptr() + a.numel() * a.element_size() != b.data_ptr():
+            return False
+        if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+            return False
+    return True
+
+
+def pack_params(params: Sequence[torch.nn.Parameter]) -> None:
+    """Make the fp32 storage of ``params`` adjacent (in order) so they can be used as one matrix."""
+    if len(params) == 1 or _adjacent([p.data for p in params]):
+        return
+    flat = torch.cat([p.data.reshape(-1) for p in params])
+    off = 0
+    for p in params:
+        p.data = flat[off:off + p.numel()].view_as(p.data)
+        off += p.numel()
+
+
+def packed_grad(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
+    """fp32 gradient buffer covering ``params`` contiguously (views installed as p.grad)."""
+    grads = [p.grad for p in params]
+    if all(g is not None for g in grads) and _adjacent(grads):
+        n = sum(p.numel() for p in params)
+        g0 = grads[0]
+        return torch.as_strided(g0, (n,), (1,), g0.storage_offset()) if len(params) > 1 else g0.view(-1)
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=F32, device=params[0].device)
+    off = 0
+    for p, g in zip(params, grads):
+        v = flat[off:off + p.numel()].view_as(p.data)
+        if g is not None:
+            v.copy_(g)
+        p.grad = v
+        off += p.numel()
+    return flat
+
+
+def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data)
+    return p.grad
+
+
+def shadow(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
+    """bf16 copy of the (adjacent) parameters as one flat tensor."""
+    p0 = params[0]
+    n = sum(p.numel() for p in params)
+    ptr = p0.data_ptr()
+    for (b, e, f32, b16) in _managed_shadow:
+        if b <= ptr and ptr + n * 4 <= e:
+            off = (ptr - b) // 4
+            return b16[off:off + n]
+    key = (ptr, n)
+    ver = tuple(p._version for p in params)
+    hit = _shadow_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    src = torch.as_strided(p0.data, (n,), (1,), p0.data.storage_offset()) if len(params) > 1 else p0.data.reshape(-1)
+    out = hit[1] if hit is not None else torch.empty(n, dtype=BF16, device=p0.device)
+    if (src.data_ptr() & 15) == 0:
+        L.call("vpf_cast_f32_bf16", src, out, n)
+    else:   # unaligned view: stage through an aligned copy
+        L.call("vpf_cast_f32_bf16", src.clone(), out, n)
+    _shadow_cache[key] = (ver, out)
+    return out
+
+
+# --------------------------------------------------------------------------- thin kernel wrappers
+def to_bf16(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == BF16:
+        return x.contiguous()
+    x = x.contiguous().float()
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    if x.numel():
+        L.call("vpf_cast_f32_bf16", x, out, x.numel())
+    return out
+
+
+def to_f32(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == F32:
+        return x.contiguous()
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=F32, device=x.device)
+    if x.numel():
+        L.call("vpf_cast_bf16_f32", x, out, x.numel())
+    return out
+
+
+def gemm(A, a_tr, lda, Bm, b_tr, ldb, M, N, K, C, ldc, *, c_f32, mode=EPI_STORE, bias=None, C2=None, ldc2=0, res=None,
+         ldres=0, aux=None, ldaux=0, gbias=None, group=1, site=0, p=0.0, splitk=0, batch=1, sAb=0, sBb=0, sCb=0):
+    st = rng.state(C.device) if mode == EPI_DROP_RES else None
+    L.call("vpf_gemm_bf16", A, int(a_tr), lda, Bm, int(b_tr), ldb, M, N, K, batch, sAb, sBb, sCb, C, ldc, int(c_f32), mode,
+           bias, C2, ldc2, res, ldres, aux, ldaux, gbias, group, st, site, float(p), splitk)
+
+
+def linear_fwd(x16, w16, N, K, bias=None, *, out_f32=False, mode=EPI_STORE, **kw):
+    """y[M,N] = x16[M,K] @ w16[N,K]^T (+bias, epilogue)."""
+    M = x16.numel() // K
+    y = torch.empty(M, N, dtype=F32 if out_f32 else BF16, device=x16.device)
+    gemm(x16, 0, K, w16, 0, K, M, N, K, y, N, c_f32=out_f32, mode=mode, bias=bias, **kw)
+    return y
+
+
+def linear_dgrad(dy16, w16, N, K, *, out_f32=False, mode=EPI_STORE, **kw):
+    """dx[M,K] = dy16[M,N] @ w16[N,K]   (W read k-strided: no transposed copy)."""
+    M = dy16.numel() // N
+    dx = torch.empty(M, K, dtype=F32 if out_f32 else BF16, device=dy16.device)
+    gemm(dy16, 0, N, w16, 1, K, M, K, N, dx, K, c_f32=out_f32, mode=mode, **kw)
+    return dx
+
+
+def linear_wgrad(dy16, x16, N, K, dW):
+    """dW[N,K] += dy16[M,N]^T @ x16[M,K]   (both operands k-strided, split over M, fp32 atomics)."""
+    M = dy16.numel() // N
+    gemm(dy16, 1, N, x16, 1, K, N, K, M, dW, K, c_f32=True, mode=EPI_ATOMIC)
+
+
+def colsum(x, C, acc, acc2=None):
+    M = x.numel() // C
+    L.call("vpf_colsum", x, int(x.dtype == BF16), M, C, acc, acc2)
+
+
+def layernorm_fwd(x, gamma, beta, pos=None, want_sum=False):
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    mean = torch.empty(rows, dtype=F32, device=x.device)
+    rstd = torch.empty(rows, dtype=F32, device=x.device)
+    xsum = torch.empty(x.shape, dtype=F32, device=x.device) if (pos is not None and want_sum) else None
+    pos_rows = (pos.numel() // D) if pos is not None else 0
+    L.call("vpf_layernorm_fwd", x, int(x.dtype == BF16), pos, pos_rows, gamma, beta, y, xsum, mean, rstd, rows, D, 1e-5)
+    return y, mean, rstd, xsum
+
+
+def layernorm_bwd(dy16, x, mean, rstd, gamma_p, beta_p, dres=None, out_bf16=False):
+    D = x.shape[-1]
+    rows = x.numel() // D
+    dx = torch.empty(x.shape, dtype=BF16 if out_bf16 else F32, device=x.device)
+    L.call("vpf_layernorm_bwd", dy16, x, int(x.dtype == BF16), mean, rstd, gamma_p.data, dres, dx, int(out_bf16),
+           grad_buf(gamma_p), grad_buf(beta_p), rows, D)
+    return dx
+
+
+# --------------------------------------------------------------------------- attention residual block
+class AttnBlockFn(torch.autograd.Function):
+    """[pos-add] -> LN(q) [, LN(kv)] -> q/k/v projections -> fused attention -> o_proj [-> dropout + residual].
+
+    Covers MultiHeadAttention, CrossAttention, SelfAttention and Residual(attention) of
+    partseg.py:14-141,201-213 depending on the flags in ``cfg``."""
+
+    @staticmethod
+    def forward(ctx, xq, pos, xkv, mod, cfg, *params):
+        ctx.nparams = len(params)
+        # mod: the MultiHeadAttention module (weights); cfg: dict(ln_q, ln_kv (modules or None), residual, p_res, site_res, training)
+        B, Lq, D = xq.shape
+        H = mod.num_heads
+        dev = xq.device
+        training = cfg["training"]
+        is_self = xkv is None
+        lnq, lnkv = cfg["ln_q"], cfg["ln_kv"]
+        xq = xq.contiguous()
+        base = xq
+        mq = rq = None
+        if lnq is not None:
+            nq, mq, rq, xsum = layernorm_fwd(xq, lnq.weight.data, lnq.bias.data, pos=pos, want_sum=True)
+            if xsum is not None:
+                base = xsum
+        else:
+            if pos is not None:
+                raise L.VpfError("pos requires a query LayerNorm")
+            nq = to_bf16(xq)
+        mk = rk = None
+        if is_self:
+            nk, Lkv = nq, Lq
+        else:
+            xkv = xkv.contiguous()
+            Lkv = xkv.shape[1]
+            if lnkv is not None:
+                nk, mk, rk, _ = layernorm_fwd(xkv, lnkv.weight.data, lnkv.bias.data)
+            else:
+                nk = to_bf16(xkv)
+        qkvw = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
+        pack_params(qkvw)
+        w16 = shadow(qkvw)                      # [3D, D] bf16
+        Mq, Mk = B * Lq, B * Lkv
+        if is_self:
+            qkv = linear_fwd(nq, w16, 3 * D, D)                                  # [Mq, 3D]
+            q, k, v, ldq, ldk, ldv = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D
+            kv = None
+        else:
+            qkv = linear_fwd(nq, w16[:D * D], D, D)                              # [Mq, D]
+            kv = linear_fwd(nk, w16[D * D:], 2 * D, D)                           # [Mk, 2D]
+            q, k, v, ldq, ldk, ldv = qkv, kv, kv[:, D:], D, 2 * D, 2 * D
+        o = torch.empty(Mq, D, dtype=BF16, device=dev)
+        lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
+        p_att = mod.dropout.p if training else 0.0
+        L.call("vpf_attention_fwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lkv, D // H, float(mod.dp_scale), float(p_att),
+               rng.state(dev), mod.site_attn, o, D, lse)
+        wo16 = shadow([mod.o_proj.weight])
+        residual = cfg["residual"]
+        p_res = cfg["p_res"] if training else 0.0
+        if residual:
+            out = linear_fwd(o, wo16, D, D, mod.o_proj.bias.data, out_f32=True, mode=EPI_DROP_RES, res=base, ldres=D,
+                             site=cfg["site_res"], p=p_res)
+        else:
+            out = linear_fwd(o, wo16, D, D, mod.o_proj.bias.data, out_f32=True)
+        ctx.mod, ctx.cfg = mod, cfg
+        ctx.dims = (B, Lq, Lkv, D, H, is_self, p_att, p_res)
+        ctx.has_pos = pos is not None
+        ctx.pos_shape = tuple(pos.shape) if pos is not None else None
+        ctx.xkv_dtype = None if is_self else xkv.dtype
+        ctx.save_for_backward(base, mq, rq, nq, None if is_self else xkv, mk, rk, None if is_self else nk, qkv, kv, o, lse)
+        return out.view(B, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        base, mq, rq, nq, xkv, mk, rk, nk, qkv, kv, o, lse = ctx.saved_tensors
+        mod, cfg = ctx.mod, ctx.cfg
+        B, Lq, Lkv, D, H, is_self, p_att, p_res = ctx.dims
+        dev = dout.device
+        dout = dout.contiguous().float()
+        Mq, Mk = B * Lq, B * Lkv
+        residual = cfg["residual"]
+        if residual and p_res > 0.0:
+            dz = torch.empty(Mq, D, dtype=BF16, device=dev)
+            L.call("vpf_dropout_bwd", dout, dz, dout.numel(), rng.state(dev), cfg["site_res"], float(p_res))
+        else:
+            dz = to_bf16(dout).view(Mq, D)
+        colsum(dz, D, grad_buf(mod.o_proj.bias))
+        linear_wgrad(dz, o, D, D, grad_buf(mod.o_proj.weight))
+        do = linear_dgrad(dz, shadow([mod.o_proj.weight]), D, D)
+        qkvw = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
+        w16 = shadow(qkvw)
+        gW = packed_grad(qkvw)
+        if is_self:
+            dqkv = torch.empty(Mq, 3 * D, dtype=BF16, device=dev)
+            q, k, v, ldq, ldk, ldv = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D
+            dq, dk, dv, lddq, lddk, lddv = dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D
+        else:
+            dq = torch.empty(Mq, D, dtype=BF16, device=dev)
+            dkv = torch.empty(Mk, 2 * D, dtype=BF16, device=dev)
+            q, k, v, ldq, ldk, ldv = qkv, kv, kv[:, D:], D, 2 * D, 2 * D
+            dk, dv, lddq, lddk, lddv = dkv, dkv[:, D:], D, 2 * D, 2 * D
+        L.call("vpf_attention_bwd", q, ldq, k, ldk, v, ldv, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(mod.dp_scale),
+               float(p_att), rng.state(dev), mod.site_attn, dq, lddq, dk, lddk, dv, lddv)
+        dxkv = None
+        if is_self:
+            linear_wgrad(dqkv, nq, 3 * D, D, gW)
+            dnq = linear_dgrad(dqkv, w16, 3 * D, D)
+        else:
+            linear_wgrad(dq, nq, D, D, gW[:D * D])
+            dnq = linear_dgrad(dq, w16[:D * D], D, D)
+            linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
+            if ctx.needs_input_grad[2]:
+                dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
+                lnkv = cfg["ln_kv"]
+                if lnkv is not None:
+                    dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16))
+                    dxkv = dxkv.view(B, Lkv, D)
+                else:
+                    dxkv = (dnk if ctx.xkv_dtype == BF16 else to_f32(dnk)).view(B, Lkv, D)
+            elif cfg["ln_kv"] is not None:
+                # kv input needs no grad but the kv LayerNorm affine does
+                dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
+                lnkv = cfg["ln_kv"]
+                layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
+        lnq = cfg["ln_q"]
+        if lnq is not None:
+            dbase = layernorm_bwd(dnq, base, mq, rq, lnq.weight, lnq.bias, dout if residual else None)
+        else:
+            dbase = to_f32(dnq)
+            if residual:
+                dbase = dbase.view_as(dout) + dout
+        dbase = dbase.view(B, Lq, D)
+        dpos = None
+        if ctx.has_pos and ctx.needs_input_grad[1]:
+            if ctx.pos_shape[0] == B or B == 1:
+                dpos = dbase.view(ctx.pos_shape)
+            else:
+                dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dev)
+                L.call("vpf_rowsum_mod_f32", dbase, Mq, D, Lq, dpos)
+        return (dbase, dpos, dxkv, None, None) + (None,) * ctx.nparams
+
+
+# --------------------------------------------------------------------------- MLP residual block
+class MLPBlockFn(torch.autograd.Function):
+    """LN -> Linear -> GELU -> Linear [-> dropout + residual]   (partseg.py:191-213)."""
+
+    @staticmethod
+    def forward(ctx, x, mod, cfg, *params):
+        ctx.nparams = len(params)
+        shp = x.shape
+        D = shp[-1]
+        x = x.contiguous().float()
+        ln, fc1, fc2 = mod[0], mod[1], mod[3]
+        Hd = fc1.weight.shape[0]
+        n, mean, rstd, _ = layernorm_fwd(x, ln.weight.data, ln.bias.data)
+        M = x.numel() // D
+        u = torch.empty(M, Hd, dtype=BF16, device=x.device)
+        h = linear_fwd(n, shadow([fc1.weight]), Hd, D, fc1.bias.data, mode=EPI_GELU, C2=u, ldc2=Hd)
+        training, residual = cfg["training"], cfg["residual"]
+        p_res = cfg["p_res"] if training else 0.0
+        if residual:
+            out = linear_fwd(h, shadow([fc2.weight]), D, Hd, fc2.bias.data, out_f32=True, mode=EPI_DROP_RES, res=x, ldres=D,
+                             site=cfg["site_res"], p=p_res)
+        else:
+            out = linear_fwd(h, shadow([fc2.weight]), D, Hd, fc2.bias.data, out_f32=True)
+        ctx.mod, ctx.cfg, ctx.p_res = mod, cfg, p_res
+        ctx.save_for_backward(x, mean, rstd, n, u, h)
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, mean, rstd, n, u, h = ctx.saved_tensors
+        mod, cfg, p_res = ctx.mod, ctx.cfg, ctx.p_res
+        ln, fc1, fc2 = mod[0], mod[1], mod[3]
+        D = x.shape[-1]
+        Hd = fc1.weight.shape[0]
+        M = x.numel() // D
+        dout = dout.contiguous().float()
+        residual = cfg["residual"]
+        if residual and p_res > 0.0:
+            dz = torch.empty(M, D, dtype=BF16, device=x.device)
+            L.call("vpf_dropout_bwd", dout, dz, dout.numel(), rng.state(x.device), cfg["site_res"], float(p_res))
+        else:
+            dz = to_bf16(dout).view(M, D)
+        colsum(dz, D, grad_buf(fc2.bias))
+        linear_wgrad(dz, h, D, Hd, grad_buf(fc2.weight))
+        du = linear_dgrad(dz, shadow([fc2.weight]), D, Hd, mode=EPI_GELU_BWD, aux=u, ldaux=Hd)
+        colsum(du, Hd, grad_buf(fc1.bias))
+        linear_wgrad(du, n, Hd, D, grad_buf(fc1.weight))
+        dn = linear_dgrad(du, shadow([fc1.weight]), Hd, D)
+        dx = layernorm_bwd(dn, x, mean, rstd, ln.weight, ln.bias, dout if residual else None)
+        return (dx.view_as(dout), None, None) + (None,) * ctx.nparams
+
+
+# --------------------------------------------------------------------------- generic dropout + residual (Residual fallback)
+class DropoutAddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, res, p, site):
+        y16 = to_bf16(y)
+        res = res.contiguous().float()
+        out = torch.empty(res.shape, dtype=F32, device=res.device)
+        L.call("vpf_dropout_add_fwd", y16, res, out, out.numel(), rng.state(res.device), site, float(p))
+        ctx.p, ctx.site, ctx.ydt = p, site, y.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous().float()
+        dy = torch.empty(dout.shape, dtype=BF16, device=dout.device)
+        L.call("vpf_dropout_bwd", dout, dy, dout.numel(), rng.state(dout.device), ctx.site, float(ctx.p))
+        return (dy if ctx.ydt == BF16 else to_f32(dy)), dout, None, None
+
+
+# --------------------------------------------------------------------------- BatchNorm helper (channels-last [M,C])
+def _bn_stat(x, C, bn, training):
+    """Returns stat [2C] = mean | rstd (batch statistics + running update when training)."""
+    M = x.numel() // C
+    dev = x.device
+    stat = torch.empty(2 * C, dtype=F32, device=dev)
+    if training:
+        sums = torch.zeros(2 * C, dtype=F32, device=dev)
+        colsum(x, C, sums[:C], sums[C:])
+        L.call("vpf_bn_finalize", sums[:C], sums[C:], M, C, float(bn.eps), float(bn.momentum), 1, bn.running_mean,
+               bn.running_var, bn.num_batches_tracked, stat)
+    else:
+        L.call("vpf_bn_finalize", None, None, M, C, float(bn.eps), float(bn.momentum), 0, bn.running_mean, bn.running_var,
+               None, stat)
+    return stat
+
+
+def _bn_act(x, C, stat, bn, relu, out_bf16):
+    M = x.numel() // C
+    y = torch.empty(M, C, dtype=BF16 if out_bf16 else F32, device=x.device)
+    L.call("vpf_bn_act_fwd", x, int(x.dtype == BF16), stat, bn.weight.data, bn.bias.data, y, int(out_bf16), M, C, int(relu))
+    return y
+
+
+def _bn_bwd(dy, x, C, stat, bn, relu, training, out_bf16, want_dx=True):
+    M = x.numel() // C
+    tmp = torch.zeros(2 * C, dtype=F32, device=x.device)
+    dx = torch.empty(M, C, dtype=BF16 if out_bf16 else F32, device=x.device) if want_dx else None
+    L.call("vpf_bn_bwd", dy, int(dy.dtype == BF16), x, int(x.dtype == BF16), stat, bn.weight.data, bn.bias.data, M, C,
+           int(relu), int(training), tmp, dx, int(out_bf16), grad_buf(bn.weight), grad_buf(bn.bias))
+    return dx
+
+
+# --------------------------------------------------------------------------- Group2Emb (utils.py:144-189)
+class Group2EmbFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, groups, mod, training, *params):
+        ctx.nparams = len(params)
+        Bq, G, K, C = groups.shape
+        dev = groups.device
+        x = groups.contiguous().float().view(-1, C)
+        M, NG = x.shape[0], Bq * G
+        c1, bn1, c2 = mod.first_conv[0], mod.first_conv[1], mod.first_conv[3]
+        c3, bn2, c4 = mod.second_conv[0], mod.second_conv[1], mod.second_conv[3]
+        Dm = c4.weight.shape[0]
+        w1 = c1.weight.data.view(64, C)
+        stat1 = torch.empty(128, dtype=F32, device=dev)
+        if training:
+            sums = torch.zeros(128, dtype=F32, device=dev)
+            L.call("vpf_g2e_conv1_stats", x, M, C, w1, c1.bias.data, sums[:64], sums[64:])
+            L.call("vpf_bn_finalize", sums[:64], sums[64:], M, 64, float(bn1.eps), float(bn1.momentum), 1, bn1.running_mean,
+                   bn1.running_var, bn1.num_batches_tracked, stat1)
+        else:
+            L.call("vpf_bn_finalize", None, None, M, 64, float(bn1.eps), float(bn1.momentum), 0, bn1.running_mean,
+                   bn1.running_var, None, stat1)
+        a1 = torch.empty(M, 64, dtype=BF16, device=dev)
+        L.call("vpf_g2e_conv1_apply", x, M, C, w1, c1.bias.data, stat1, bn1.weight.data, bn1.bias.data, a1)
+        h2 = linear_fwd(a1, shadow([c2.weight]), 128, 64, c2.bias.data)                      # [M,128]
+        gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
+        arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
+        L.call("vpf_group_max_fwd", h2, NG, K, 128, gmax, 1, arg2)
+        feat = torch.empty(M, 256, dtype=BF16, device=dev)
+        L.call("vpf_g2e_concat_fwd", gmax, h2, M, K, 128, feat)
+        h3 = linear_fwd(feat, shadow([c3.weight]), 256, 256, c3.bias.data)                    # [M,256]
+        stat2 = _bn_stat(h3, 256, bn2, training)
+        a3 = _bn_act(h3, 256, stat2, bn2, True, True)
+        h4 = linear_fwd(a3, shadow([c4.weight]), Dm, 256, c4.bias.data)                       # [M,Dm]
+        out = torch.empty(NG, Dm, dtype=F32, device=dev)
+        arg4 = torch.empty(NG, Dm, dtype=torch.uint8, device=dev)
+        L.call("vpf_group_max_fwd", h4, NG, K, Dm, out, 0, arg4)
+        ctx.mod, ctx.training, ctx.dims = mod, training, (Bq, G, K, C, Dm)
+        ctx.save_for_backward(x, stat1, a1, arg2, feat, h3, stat2, a3, arg4)
+        return out.view(Bq, G, Dm)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, stat1, a1, arg2, feat, h3, stat2, a3, arg4 = ctx.saved_tensors
+        mod, training = ctx.mod, ctx.training
+        Bq, G, K, C, Dm = ctx.dims
+        dev = dout.device
+        M, NG = x.shape[0], Bq * G
+        c1, bn1, c2 = mod.first_conv[0], mod.first_conv[1], mod.first_conv[3]
+        c3, bn2, c4 = mod.second_conv[0], mod.second_conv[1], mod.second_conv[3]
+        dout = dout.contiguous().float()
+        dh4 = torch.empty(M, Dm, dtype=BF16, device=dev)
+        L.call("vpf_group_max_bwd", dout, 0, arg4, NG, K, Dm, dh4)
+        colsum(dh4, Dm, grad_buf(c4.bias))
+        linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight))
+        da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
+        dh3 = _bn_bwd(da3, h3, 256, stat2, bn2, True, training, True)
+        colsum(dh3, 256, grad_buf(c3.bias))
+        linear_wgrad(dh3, feat, 256, 256, grad_buf(c3.weight))
+        dfeat = linear_dgrad(dh3, shadow([c3.weight]), 256, 256)
+        dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
+        L.call("vpf_g2e_concat_bwd", dfeat, arg2, NG, K, 128, dh2)
+        colsum(dh2, 128, grad_buf(c2.bias))
+        linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight))
+        da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
+        tmp = torch.zeros(128, dtype=F32, device=dev)
+        L.call("vpf_g2e_conv1_bwd", x, da1, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
+               int(training), tmp, grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight), grad_buf(bn1.bias))
+        return (None, None, None) + (None,) * ctx.nparams
+
+
+# --------------------------------------------------------------------------- adapter / position MLP / patch embedding
+class AdapterFn(torch.autograd.Function):
+    """PointCloudInputAdapter.point_mlp (classifier.py:31-36): Linear(C,64) LN ReLU Linear(64,D) -> bf16 [B,N,D]."""
+
+    @staticmethod
+    def forward(ctx, pts, mod, *params):
+        ctx.nparams = len(params)
+        B, N, C = pts.shape
+        x = pts.contiguous().float().view(-1, C)
+        M = x.shape[0]
+        l0, ln, l3 = mod.point_mlp[0], mod.point_mlp[1], mod.point_mlp[3]
+        D = l3.weight.shape[0]
+        a = torch.empty(M, 64, dtype=BF16, device=x.device)
+        L.call("vpf_adapter_front_fwd", x, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data, a)
+        y = linear_fwd(a, shadow([l3.weight]), D, 64, l3.bias.data)
+        ctx.mod = mod
+        ctx.save_for_backward(x, a)
+        return y.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        mod = ctx.mod
+        l0, ln, l3 = mod.point_mlp[0], mod.point_mlp[1], mod.point_mlp[3]
+        D = l3.weight.shape[0]
+        M, C = x.shape
+        dy16 = to_bf16(dy).view(M, D)
+        colsum(dy16, D, grad_buf(l3.bias))
+        linear_wgrad(dy16, a, D, 64, grad_buf(l3.weight))
+        da = linear_dgrad(dy16, shadow([l3.weight]), D, 64)
+        L.call("vpf_adapter_front_bwd", x, da, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data,
+               grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias))
+        return (None, None) + (None,) * ctx.nparams
+
+
+class PosMLPFn(torch.autograd.Function):
+    """position_emb (partseg.py:498-501): Linear(3,128) GELU Linear(128,D) -> f32 [B,G,D]."""
+
+    @staticmethod
+    def forward(ctx, centers, seq, *params):
+        ctx.nparams = len(params)
+        B, G, C = centers.shape
+        x = centers.contiguous().float().view(-1, C)
+        M = x.shape[0]
+        l0, l2 = seq[0], seq[2]
+        Hd, D = l0.weight.shape[0], l2.weight.shape[0]
+        g = torch.empty(M, Hd, dtype=BF16, device=x.device)
+        L.call("vpf_smallk_fwd", x, M, C, l0.weight.data, l0.bias.data, Hd, 1, g)
+        y = linear_fwd(g, shadow([l2.weight]), D, Hd, l2.bias.data, out_f32=True)
+        ctx.seq = seq
+        ctx.save_for_backward(x, g)
+        return y.view(B, G, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        l0, l2 = ctx.seq[0], ctx.seq[2]
+        Hd, D = l0.weight.shape[0], l2.weight.shape[0]
+        M, C = x.shape
+        dy16 = to_bf16(dy).view(M, D)
+        colsum(dy16, D, grad_buf(l2.bias))
+        linear_wgrad(dy16, g, D, Hd, grad_buf(l2.weight))
+        dg = linear_dgrad(dy16, shadow([l2.weight]), D, Hd)
+        L.call("vpf_smallk_bwd", x, dg, M, C, l0.weight.data, l0.bias.data, Hd, 1, grad_buf(l0.weight), grad_buf(l0.bias))
+        return (None, None) + (None,) * ctx.nparams
+
+
+class PatchEmbedFn(torch.autograd.Function):
+    """patch2emb (partseg.py:631-634): 'b (h p1)(w p2) c -> b (h w)(p1 p2 c)' + Linear(3p^2, D) -> f32 [B,T,D]."""
+
+    @staticmethod
+    def forward(ctx, imgs, lin, p, *params):
+        ctx.nparams = len(params)
+        B, Hh, Ww, C = imgs.shape
+        if imgs.dtype != F32:
+            imgs = imgs.float()
+        T, pd = (Hh // p) * (Ww // p), p * p * C
+        if Hh % p or Ww % p:
+            raise L.VpfError(f"image {Hh}x{Ww} is not divisible by patch_size {p}")
+        patches = torch.empty(B * T, pd, dtype=BF16, device=imgs.device)
+        sb, sh, sw, sc = imgs.stride()
+        L.call("vpf_patchify", imgs, sb, sh, sw, sc, B, Hh, Ww, C, p, patches)
+        D = lin.weight.shape[0]
+        y = linear_fwd(patches, shadow([lin.weight]), D, pd, lin.bias.data, out_f32=True)
+        ctx.lin = lin
+        ctx.save_for_backward(patches)
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (patches,) = ctx.saved_tensors
+        lin = ctx.lin
+        D, pd = lin.weight.shape
+        dy16 = to_bf16(dy).view(-1, D)
+        colsum(dy16, D, grad_buf(lin.bias))
+        linear_wgrad(dy16, patches, D, pd, grad_buf(lin.weight))
+        return (None, None, None) + (None,) * ctx.nparams
+
+
+# --------------------------------------------------------------------------- pooling + projection head
+class PoolFn(torch.autograd.Function):
+    """cat[max over tokens, mean over tokens]  (partseg.py:547)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, Lt, D = x.shape
+        x = x.contiguous().float()
+        out = torch.empty(B, 2 * D, dtype=F32, device=x.device)
+        arg = torch.empty(B, D, dtype=torch.int32, device=x.device)
+        L.call("vpf_pool_fwd", x, B, Lt, D, out, arg)
+        ctx.dims = (B, Lt, D)
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        B, Lt, D = ctx.dims
+        dx = torch.empty(B, Lt, D, dtype=F32, device=dout.device)
+        L.call("vpf_pool_bwd", dout.contiguous().float(), arg, B, Lt, D, dx)
+        return dx
+
+
+class HeadFn(torch.autograd.Function):
+    """latent_head (partseg.py:519-525): BN1d ReLU Linear(no bias) BN1d ReLU Linear(no bias), fp32 in/out."""
+
+    @staticmethod
+    def forward(ctx, x, seq, training, *params):
+        ctx.nparams = len(params)
+        bn1, l1, bn2, l2 = seq[0], seq[2], seq[3], seq[5]
+        Bn, C1 = x.shape
+        C2, C3 = l1.weight.shape[0], l2.weight.shape[0]
+        x = x.contiguous().float()
+        s1 = _bn_stat(x, C1, bn1, training)
+        a1 = _bn_act(x, C1, s1, bn1, True, True)
+        h = linear_fwd(a1, shadow([l1.weight]), C2, C1, l1.bias.data if l1.bias is not None else None, out_f32=True)
+        s2 = _bn_stat(h, C2, bn2, training)
+        a2 = _bn_act(h, C2, s2, bn2, True, True)
+        y = linear_fwd(a2, shadow([l2.weight]), C3, C2, l2.bias.data if l2.bias is not None else None, out_f32=True)
+        ctx.seq, ctx.training = seq, training
+        ctx.save_for_backward(x, s1, a1, h, s2, a2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s1, a1, h, s2, a2 = ctx.saved_tensors
+        seq, training = ctx.seq, ctx.training
+        bn1, l1, bn2, l2 = seq[0], seq[2], seq[3], seq[5]
+        C1 = x.shape[1]
+        C2, C3 = l1.weight.shape[0], l2.weight.shape[0]
+        dy16 = to_bf16(dy)
+        if l2.bias is not None:
+            colsum(dy16, C3, grad_buf(l2.bias))
+        linear_wgrad(dy16, a2, C3, C2, grad_buf(l2.weight))
+        da2 = linear_dgrad(dy16, shadow([l2.weight]), C3, C2, out_f32=True)
+        dh = _bn_bwd(da2, h, C2, s2, bn2, True, training, True)
+        if l1.bias is not None:
+            colsum(dh, C2, grad_buf(l1.bias))
+        linear_wgrad(dh, a1, C2, C1, grad_buf(l1.weight))
+        da1 = linear_dgrad(dh, shadow([l1.weight]), C2, C1, out_f32=True)
+        dx = _bn_bwd(da1, x, C1, s1, bn1, True, training, False)
+        return (dx, None, None) + (None,) * ctx.nparams
+
+
+# --------------------------------------------------------------------------- NT-Xent
+class NTXentFn(torch.autograd.Function):
+    """lightly==1.1.21 NTXentLoss(temperature, memory_bank_size=0) -- pretrain.py:155,196,202."""
+
+    @staticmethod
+    def forward(ctx, z0, z1, temperature):
+        b, D = z0.shape
+        z0, z1 = z0.contiguous().float(), z1.contiguous().float()
+        dev = z0.device
+        n = 2 * b
+        zn = torch.empty(n, D, dtype=F32, device=dev)
+        inv = torch.empty(n, dtype=F32, device=dev)
+        P = torch.empty(n, n, dtype=F32, device=dev)
+        rows = torch.empty(n, dtype=F32, device=dev)
+        loss = torch.empty((), dtype=F32, device=dev)
+        L.call("vpf_ntxent_fwd", z0, z1, b, D, float(temperature), zn, inv, P, rows, loss)
+        ctx.t, ctx.dims = temperature, (b, D)
+        ctx.save_for_backward(zn, inv, P)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        zn, inv, P = ctx.saved_tensors
+        b, D = ctx.dims
+        dz0 = torch.empty(b, D, dtype=F32, device=zn.device)
+        dz1 = torch.empty(b, D, dtype=F32, device=zn.device)
+        L.call("vpf_ntxent_bwd", zn, inv, P, b, D, float(ctx.t), dloss.contiguous().float().reshape(1), dz0, dz1)
+        return dz0, dz1, None
+
+
+def ntxent_loss(z0, z1, temperature=0.1):
+    return NTXentFn.apply(z0, z1, temperature)
