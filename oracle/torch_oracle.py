@@ -144,13 +144,48 @@ class Masks:
         return x * keep * (1.0 / (1.0 - p))
 
 
+# --------------------------------------------------------------------------- precision emulation
+class _RoundBF16(torch.autograd.Function):
+    """Round-to-nearest-even to bf16 and back, straight-through gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+_EMULATE = [False]
+
+
+class emulate_bf16:
+    """Context manager: while active, the float stages round to bf16 at exactly the points where the HIP
+    path stores bf16 (GEMM operand weights, LayerNorm / activation / projection outputs, attention
+    probabilities and outputs).  Off (the default) the oracle is the plain fp32 restatement that the
+    golden fixtures pin against the reference.  On, it predicts the HIP path to ~1e-3 -- in particular
+    the same max-pool winners -- which separates kernel logic errors from bf16 precision effects."""
+
+    def __enter__(self):
+        self.prev = _EMULATE[0]
+        _EMULATE[0] = True
+
+    def __exit__(self, *a):
+        _EMULATE[0] = self.prev
+
+
+def Q(x):
+    return _RoundBF16.apply(x) if _EMULATE[0] else x
+
+
 # --------------------------------------------------------------------------- float stages
 def adapter(sd, pre: str, pts):
     """classifier.py:31-36,48: Linear(C,64) -> LayerNorm(64) -> ReLU -> Linear(64,D)."""
     h = F.linear(pts, sd[pre + "point_mlp.0.weight"], sd[pre + "point_mlp.0.bias"])
     h = F.layer_norm(h, (64,), sd[pre + "point_mlp.1.weight"], sd[pre + "point_mlp.1.bias"], 1e-5)
-    h = F.relu(h)
-    return F.linear(h, sd[pre + "point_mlp.3.weight"], sd[pre + "point_mlp.3.bias"])
+    h = Q(F.relu(h))
+    return Q(F.linear(h, Q(sd[pre + "point_mlp.3.weight"]), sd[pre + "point_mlp.3.bias"]))
 
 
 def _bn(sd, pre, x, train, buffers):
@@ -172,20 +207,20 @@ def group2emb(sd, pre: str, neighbors, train: bool, buffers=None):
     B, G, K, C = neighbors.shape
     x = neighbors.reshape(B * G, K, C).transpose(2, 1)                       # [BG, C, K]
     h = F.conv1d(x, sd[pre + "first_conv.0.weight"], sd[pre + "first_conv.0.bias"])
-    h = F.relu(_bn(sd, pre + "first_conv.1.", h, train, buffers))
-    h = F.conv1d(h, sd[pre + "first_conv.3.weight"], sd[pre + "first_conv.3.bias"])   # [BG,128,K]
+    h = Q(F.relu(_bn(sd, pre + "first_conv.1.", h, train, buffers)))
+    h = Q(F.conv1d(h, Q(sd[pre + "first_conv.3.weight"]), sd[pre + "first_conv.3.bias"]))   # [BG,128,K]
     g = h.max(dim=2, keepdim=True)[0]
     h = torch.cat([g.expand(-1, -1, K), h], dim=1)                            # [BG,256,K]
-    h = F.conv1d(h, sd[pre + "second_conv.0.weight"], sd[pre + "second_conv.0.bias"])
-    h = F.relu(_bn(sd, pre + "second_conv.1.", h, train, buffers))
-    h = F.conv1d(h, sd[pre + "second_conv.3.weight"], sd[pre + "second_conv.3.bias"])
+    h = Q(F.conv1d(h, Q(sd[pre + "second_conv.0.weight"]), sd[pre + "second_conv.0.bias"]))
+    h = Q(F.relu(_bn(sd, pre + "second_conv.1.", h, train, buffers)))
+    h = Q(F.conv1d(h, Q(sd[pre + "second_conv.3.weight"]), sd[pre + "second_conv.3.bias"]))
     return h.max(dim=2)[0].reshape(B, G, -1)
 
 
 def pos_mlp(sd, pre: str, centers):
     """partseg.py:498-501: Linear(3,128) -> GELU(erf) -> Linear(128,D)."""
-    h = F.gelu(F.linear(centers, sd[pre + "0.weight"], sd[pre + "0.bias"]))
-    return F.linear(h, sd[pre + "2.weight"], sd[pre + "2.bias"])
+    h = Q(F.gelu(F.linear(centers, sd[pre + "0.weight"], sd[pre + "0.bias"])))
+    return F.linear(h, Q(sd[pre + "2.weight"]), sd[pre + "2.bias"])
 
 
 def mha(sd, pre: str, xq, xkv, H: int, p: float, masks: Masks, site: str):
@@ -193,22 +228,23 @@ def mha(sd, pre: str, xq, xkv, H: int, p: float, masks: Masks, site: str):
     B, Lq, D = xq.shape
     Lk = xkv.shape[1]
     dh = D // H
-    q = F.linear(xq, sd[pre + "q_proj.weight"]).reshape(B, Lq, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lq, dh)
-    k = F.linear(xkv, sd[pre + "k_proj.weight"]).reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
-    v = F.linear(xkv, sd[pre + "v_proj.weight"]).reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
+    xq, xkv = Q(xq), Q(xkv)
+    q = Q(F.linear(xq, Q(sd[pre + "q_proj.weight"]))).reshape(B, Lq, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lq, dh)
+    k = Q(F.linear(xkv, Q(sd[pre + "k_proj.weight"]))).reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
+    v = Q(F.linear(xkv, Q(sd[pre + "v_proj.weight"]))).reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
     a = torch.bmm(q, k.transpose(1, 2)) * (dh ** -0.5)
     a = a.softmax(dim=-1)
-    a = masks.apply(a, site, p)
-    o = torch.bmm(a, v).reshape(B, H, Lq, dh).permute(0, 2, 1, 3).reshape(B, Lq, D)
-    return F.linear(o, sd[pre + "o_proj.weight"], sd[pre + "o_proj.bias"])
+    a = Q(masks.apply(a, site, p))
+    o = Q(torch.bmm(a, v)).reshape(B, H, Lq, dh).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    return F.linear(o, Q(sd[pre + "o_proj.weight"]), sd[pre + "o_proj.bias"])
 
 
 def mlp(sd, pre: str, x):
     """partseg.py:191-198: LN -> Linear -> GELU -> Linear."""
     D = x.shape[-1]
-    h = F.layer_norm(x, (D,), sd[pre + "0.weight"], sd[pre + "0.bias"], 1e-5)
-    h = F.gelu(F.linear(h, sd[pre + "1.weight"], sd[pre + "1.bias"]))
-    return F.linear(h, sd[pre + "3.weight"], sd[pre + "3.bias"])
+    h = Q(F.layer_norm(x, (D,), sd[pre + "0.weight"], sd[pre + "0.bias"], 1e-5))
+    h = Q(F.gelu(Q(F.linear(h, Q(sd[pre + "1.weight"]), sd[pre + "1.bias"]))))
+    return F.linear(h, Q(sd[pre + "3.weight"]), sd[pre + "3.bias"])
 
 
 def ca_layer(sd, pre: str, xq, xkv, a: Arch, masks: Masks, tag: str):
@@ -251,10 +287,10 @@ def encoder(sd, pre: str, tokens, pos, kv, a: Arch, masks: Masks, taps=()):
 
 def latent_head(sd, pre: str, x, train: bool, buffers=None):
     """partseg.py:519-525: BN1d(2D) ReLU Linear(2D,D,no bias) BN1d(D) ReLU Linear(D,D,no bias)."""
-    h = F.relu(_bn(sd, pre + "0.", x, train, buffers))
-    h = F.linear(h, sd[pre + "2.weight"])
-    h = F.relu(_bn(sd, pre + "3.", h, train, buffers))
-    return F.linear(h, sd[pre + "5.weight"])
+    h = Q(F.relu(_bn(sd, pre + "0.", x, train, buffers)))
+    h = F.linear(h, Q(sd[pre + "2.weight"]))
+    h = Q(F.relu(_bn(sd, pre + "3.", h, train, buffers)))
+    return F.linear(h, Q(sd[pre + "5.weight"]))
 
 
 def pool(x):
@@ -285,7 +321,7 @@ def patchify(imgs, p: int):
 def img_forward(sd, imgs, a: Arch, train: bool, masks: Optional[Masks] = None, buffers=None):
     """CrossFormer_img_mp.forward, partseg.py:661-680.  imgs [B,H,W,3]."""
     masks = masks or Masks("off")
-    tok = F.linear(patchify(imgs, a.patch), sd["patch2emb.1.weight"], sd["patch2emb.1.bias"])
+    tok = F.linear(Q(patchify(imgs, a.patch)), Q(sd["patch2emb.1.weight"]), sd["patch2emb.1.bias"])
     x, _ = encoder(sd, "encoder.", tok, sd["position_emb"], tok, a, masks)
     bb = pool(x)
     return latent_head(sd, "latent_head.", bb, train, buffers), bb

@@ -215,7 +215,12 @@ def main():
             out["pos"] = out["pos"][:, :8].clone()
         save(f"stages_{name}.npz", **out)
 
-        # ---- full models: eval, train (dropout 0) + grads
+        # ---- full models: eval, train (dropout 0) + grads.  More pairs than the stage fixtures: the projection
+        #      head's BatchNorm normalises over the batch, and 4 samples make it needlessly ill-conditioned.
+        B = Hh.MODEL_BATCH[name]
+        pts = Hh.synth_points(300, 2 * B, a["N"], 3, "uniform")
+        start = Hh.synth_start(300, 2 * B, a["N"])
+        imgs = Hh.synth_images(400, B, a["img"], a["img"])
         res = {}
         pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100))
         pc.eval(); im.eval()
@@ -231,12 +236,15 @@ def main():
         fi, bbi = im(imgs)
         res["pc_train_feats"], res["pc_train_backbone"] = f, bb
         res["img_train_feats"], res["img_train_backbone"] = fi, bbi
-        # the pretrain.py:189-207 loss with the (unpinned) NT-Xent restatement
+        # the pretrain.py:189-207 loss VALUE with the (unpinned) NT-Xent restatement
         f1, f2 = f[:B], f[B:]
         l_im = O.ntxent(f1, f2); l_cm = O.ntxent((f1 + f2) / 2, fi)
-        loss = l_im + l_cm
-        loss.backward()
-        res["loss"] = np.array([loss.item(), l_im.item(), l_cm.item()])
+        res["loss"] = np.array([(l_im + l_cm).item(), l_im.item(), l_cm.item()])
+        # gradients of a loss that is LINEAR in the backbone features (well-conditioned: the projection head's
+        # BatchNorm over a handful of samples and the temperature-0.1 softmax amplify any forward difference,
+        # which would make a gradient comparison measure the forward error instead of the backward kernels)
+        (bb * Hh.synth_like(700, bb.shape)).sum().backward()
+        (bbi * Hh.synth_like(701, bbi.shape)).sum().backward()
         n, norms, heads = grad_summary(pc)
         res["pc_grad_norms"], res["pc_grad_heads"] = norms, heads
         n2, norms2, heads2 = grad_summary(im)

@@ -111,3 +111,6 @@ ARCHS = {
     "c3": dict(D=256, H=4, G=128, K=32, S=8, MR=2, N=1024, img=224, patch=16),
     "c4": dict(D=384, H=6, G=128, K=32, S=8, MR=4, N=2048, img=224, patch=16),
 }
+
+# pairs per batch used by the model_* / dropout-step fixtures and tests
+MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4}

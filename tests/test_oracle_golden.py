@@ -51,7 +51,7 @@ def _close(x, ref, rtol=2e-5, atol=2e-5):
 def test_models_vs_reference(name):
     arch, a = _arch(name)
     g = Hh.golden(f"model_{name}.npz")
-    B = 2
+    B = Hh.MODEL_BATCH[name]
     pc = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100)
     im = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200)
     pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
@@ -74,14 +74,18 @@ def test_models_vs_reference(name):
         if "cross_attn_1." in k:
             im_sd[k] = im_sd[k.replace("cross_attn_1.", "cross_attn_n.")]
     bufs = {}
-    loss, l_im, l_cm = O.pretrain_losses(pc_sd, im_sd, pts[:B], pts[B:], imgs, start, arch, True,
-                                         O.Masks("off"), O.Masks("off"), bufs, {})
-    _close(np.array([loss.item(), l_im.item(), l_cm.item()]), g["loss"], 1e-5, 1e-5)
-    loss.backward()
+    f, bb = O.pc_forward(pc_sd, pts, start, arch, True, O.Masks("off"), bufs)
+    fi, bbi = O.img_forward(im_sd, imgs, arch, True, O.Masks("off"), {})
+    l_im = O.ntxent(f[:B], f[B:]); l_cm = O.ntxent((f[:B] + f[B:]) / 2, fi)
+    _close(np.array([(l_im + l_cm).item(), l_im.item(), l_cm.item()]), g["loss"], 1e-5, 1e-5)
+    _close(f, g["pc_train_feats"], 1e-4, 1e-4); _close(fi, g["img_train_feats"], 1e-4, 1e-4)
+    (bb * Hh.synth_like(700, bb.shape)).sum().backward()
+    (bbi * Hh.synth_like(701, bbi.shape)).sum().backward()
+    zero = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)
     for which, params, key in (("pc", pcp, "pc_grad"), ("img", imp, "img_grad")):
-        norms = np.array([params[k].grad.double().norm().item() for k in names[which]])
-        np.testing.assert_allclose(norms, g[key + "_norms"], rtol=2e-3, atol=1e-6)
-        heads = np.stack([torch.cat([params[k].grad.reshape(-1)[:8], torch.zeros(max(0, 8 - params[k].numel()))]).numpy()
+        norms = np.array([zero(params[k]).double().norm().item() for k in names[which]])
+        np.testing.assert_allclose(norms, g[key + "_norms"], rtol=2e-3, atol=1e-5)
+        heads = np.stack([torch.cat([zero(params[k]).reshape(-1)[:8], torch.zeros(max(0, 8 - params[k].numel()))]).numpy()
                           for k in names[which]])
         np.testing.assert_allclose(heads, g[key + "_heads"], rtol=5e-3, atol=2e-5)
     for k in ("latent_head.0.running_mean", "latent_head.0.running_var", "group2emb.first_conv.1.running_var"):
@@ -141,7 +145,7 @@ def test_dropout_placement_vs_reference(name):
     WHERE each dropout sits and with which p (partseg.py:165-166,186-187)."""
     arch, a = _arch(name, (0.1, 0.5))
     g = Hh.golden(f"dropout_{name}.npz")
-    B = 2
+    B = Hh.MODEL_BATCH[name]
     pc = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100)
     im = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200)
     pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])

@@ -76,7 +76,6 @@ def dropout_keep_mask(site: int, p: float, shape, device) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- parameter packing / shadows
 _managed_shadow: List[Tuple[int, int, torch.Tensor, torch.Tensor]] = []   # (ptr_begin, ptr_end, flat_f32, flat_bf16)
-_shadow_cache = {}
 
 
 def register_managed_shadow(flat_f32: torch.Tensor, flat_bf16: torch.Tensor) -> None:
@@ -86,7 +85,6 @@ def register_managed_shadow(flat_f32: torch.Tensor, flat_bf16: torch.Tensor) -> 
 
 def clear_managed_shadows() -> None:
     _managed_shadow.clear()
-    _shadow_cache.clear()
 
 
 def _adjacent(ts: Sequence[torch.Tensor]) -> bool:
@@ -142,18 +140,18 @@ def shadow(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
         if b <= ptr and ptr + n * 4 <= e:
             off = (ptr - b) // 4
             return b16[off:off + n]
-    key = (ptr, n)
-    ver = tuple(p._version for p in params)
-    hit = _shadow_cache.get(key)
-    if hit is not None and hit[0] == ver:
+    # cached on the first parameter OBJECT (dies with it; a (pointer, size) key could alias a freed model)
+    ver = tuple((p._version, p.data_ptr()) for p in params)
+    hit = getattr(p0, "_vpf_shadow", None)
+    if hit is not None and hit[0] == ver and hit[1].numel() == n:
         return hit[1]
     src = torch.as_strided(p0.data, (n,), (1,), p0.data.storage_offset()) if len(params) > 1 else p0.data.reshape(-1)
-    out = hit[1] if hit is not None else torch.empty(n, dtype=BF16, device=p0.device)
+    out = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == p0.device) else torch.empty(n, dtype=BF16, device=p0.device)
     if (src.data_ptr() & 15) == 0:
         L.call("vpf_cast_f32_bf16", src, out, n)
     else:   # unaligned view: stage through an aligned copy
         L.call("vpf_cast_f32_bf16", src.clone(), out, n)
-    _shadow_cache[key] = (ver, out)
+    p0._vpf_shadow = (ver, out)
     return out
 
 
