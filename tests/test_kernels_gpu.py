@@ -147,7 +147,7 @@ def attn_ref(q, k, v, scale, keep, p):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lkv,p", [(2, 2, 96, 1024, 0.0), (2, 4, 196, 196, 0.0), (1, 1, 16, 8, 0.0), (2, 1, 33, 70, 0.0),
-                                          (2, 2, 96, 96, 0.1), (1, 2, 128, 1024, 0.1), (2, 4, 196, 196, 0.1), (3, 1, 50, 200, 0.5)])
+                                          (2, 2, 96, 96, 0.1), (1, 2, 128, 1024, 0.1), (2, 4, 196, 196, 0.1), (3, 1, 50, 200, 0.5), (1, 2, 300, 520, 0.1), (2, 1, 160, 96, 0.0)])
 def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
     from vipformer_amd import _lib as L
     from vipformer_amd import ops
@@ -172,7 +172,7 @@ def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
     dk = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
     dv = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
     L.call("vpf_attention_bwd", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
-           dq, D, dk, D, dv, D)
+           dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"))
     oref.backward(do16.float().view(B, Lq, H, 64).permute(0, 2, 1, 3))
     unsplit = lambda t, Lx: t.permute(0, 2, 1, 3).reshape(B * Lx, D)
     for name, got, ref in (("dq", dq, unsplit(qr.grad, Lq)), ("dk", dk, unsplit(kr.grad, Lkv)), ("dv", dv, unsplit(vr.grad, Lkv))):

@@ -371,7 +371,7 @@ def test_training_step_with_dropout_vs_oracle(name):
     ((bbe * Rb).sum() + (bbie * Rbi).sum()).backward(retain_graph=True)
     # residual differences: bf16 rounding of the backward activations, and max-pool winners (token pooling,
     # group pooling) that flip between near-tied candidates -- a discontinuous re-routing of the gradient
-    compare("emulated, linear loss", lambda p: lin_grads.get(id(p)), 0.995, 0.995, 0.98)
+    compare("emulated, linear loss", lambda p: lin_grads.get(id(p)), 0.99, 0.99, 0.97)
     for r in (pcp, imp):
         for v in r.values():
             v.grad = None

@@ -29,6 +29,38 @@ def preproc():
               f"knn+group {t_knn:.1f} us ({knn_bytes/t_knn/1e3:.2f} GB/s)")
 
 
+
+
+def attn():
+    from vipformer_amd import _lib as L, ops
+    st = ops.rng.state("cuda")
+    for (B, H, Lq, Lkv, p, tag) in [(64, 4, 196, 196, 0.1, "img"), (128, 4, 96, 96, 0.1, "pc-SA"), (128, 4, 96, 1024, 0.1, "pc-CA")]:
+        D = 64 * H
+        q = torch.randn(B * Lq, D, device="cuda").bfloat16(); k = torch.randn(B * Lkv, D, device="cuda").bfloat16()
+        v = torch.randn(B * Lkv, D, device="cuda").bfloat16(); do = torch.randn(B * Lq, D, device="cuda").bfloat16()
+        o = torch.empty_like(q); lse = torch.empty(B * H * Lq, device="cuda")
+        dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
+        f = lambda: L.call("vpf_attention_fwd", q, D, k, D, v, D, B, H, Lq, Lkv, 64, 0.125, p, st, 7, o, D, lse)
+        b = lambda: L.call("vpf_attention_bwd", q, D, k, D, v, D, o, D, do, D, lse, B, H, Lq, Lkv, 64, 0.125, p, st, 7, dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"))
+        tf, tb = timeit(f, 20, 3), timeit(b, 20, 3)
+        fl = 4.0 * B * H * Lq * Lkv * 64
+        print(f"attn {tag} B={B} H={H} Lq={Lq} Lkv={Lkv}: fwd {tf:.1f} us ({fl/tf/1e6:.1f} TF/s)  bwd {tb:.1f} us ({2.5*fl/tb/1e6:.1f} TF/s)")
+
+
+def gemm():
+    from vipformer_amd import ops
+    for (M, N, K, tag) in [(393216, 256, 256, "g2e conv3"), (393216, 128, 64, "g2e conv2"), (131072, 512, 256, "CA kv proj"),
+                           (12288, 768, 256, "SA qkv"), (12288, 512, 256, "fc1"), (12288, 256, 512, "fc2"), (12544, 256, 768, "patch")]:
+        A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+        dY = torch.randn(M, N, device="cuda").bfloat16(); dW = torch.zeros(N, K, device="cuda")
+        bias = torch.zeros(N, device="cuda")
+        t1 = timeit(lambda: ops.linear_fwd(A, W, N, K, bias), 20, 3)
+        t2 = timeit(lambda: ops.linear_dgrad(dY, W, N, K), 20, 3)
+        t3 = timeit(lambda: ops.linear_wgrad(dY, A, N, K, dW), 20, 3)
+        fl = 2.0 * M * N * K
+        print(f"gemm {tag} M={M} N={N} K={K}: fwd {t1:.1f} us ({fl/t1/1e6:.0f} TF/s) dgrad {t2:.1f} us ({fl/t2/1e6:.0f} TF/s) wgrad {t3:.1f} us ({fl/t3/1e6:.0f} TF/s)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["preproc"]
     for w in which:

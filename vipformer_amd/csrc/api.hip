@@ -1,7 +1,10 @@
 // api.hip -- version / error strings of the C ABI.
 #include "vpf_common.h"
 
-extern "C" int vpf_version(void) { return 100; }  // 0.1.0
+extern "C" int vpf_version(void)
+{
+    return 100;   // 0.1.0
+}
 
 extern "C" const char* vpf_strerror(int code)
 {

@@ -246,6 +246,7 @@ extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ld
                                  int Lq, int Lkv, int head_dim, float scale, float dropout_p, const uint32_t* rng_state,
                                  uint32_t site, void* out, long ldo, float* lse, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (head_dim != DH) return VPF_ERR_UNSUPPORTED;
     AttnArgs a = {};
     a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -268,36 +269,29 @@ extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ld
 }
 
 // =============================================================================== backward
-// One workgroup = one (batch, head) with ALL its query rows (one wave per 32 rows), looping over
-// 32-row K/V tiles.  Per tile and wave: S^T and dP^T as in forward; dS^T accumulators feed
-// dQ^T += K^T . dS^T directly; P and dS cross LDS once ([q][kv] scratch) so that
-// dV[kv,d] = sum_q P[q,kv] dO[q,d] and dK[kv,d] = sum_q dS[q,kv] Q[q,d] contract over the query index with
-// transposing reads.  The waves' dK/dV partial tiles meet in an fp32 LDS accumulator (ds_add_f32), which
-// is flushed to HBM as bf16 once per tile -- no global atomics, no cross-workgroup reduction.
+// Two kernels, neither of which reduces anything across waves (no LDS / global atomics, no flush phase):
+//   attn_bwd_dq_kernel   wave = 32 query rows, loops over K/V tiles exactly like forward:
+//                        S^T, dP^T (swapped products), dS^T accumulators feed dQ^T += K^T . dS^T directly.
+//                        Also writes delta[q] = rowsum(dO * O) for the second kernel.
+//   attn_bwd_dkv_kernel  wave = 32 key rows (K and V fragments live in registers), loops over Q/dO tiles:
+//                        S[q,kv], dP[q,kv] with the KEY on the lane, so the P and dS accumulators are already
+//                        the B operands of dV^T += dO^T . P and dK^T += Q^T . dS (Q^T / dO^T by transposing reads).
+// Recomputing S and dP in both costs 8 extra MFMAs per 32x32 (q,kv) pair; it buys the absence of any
+// cross-wave reduction, which dominated an earlier single-kernel version (LDS float atomics).
 #define BWD_KT 32
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float* __restrict__ delta_out)
 {
     constexpr int NT = NW * 64;
     constexpr int MAXC = (BWD_KT * 8 + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    bf16_t* sKV = reinterpret_cast<bf16_t*>(smem_raw);                          // [2 buf][K,V][32][KLD]
-    float* sAcc = reinterpret_cast<float*>(sKV + 2 * 2 * BWD_KT * KLD);          // [2 buf][dK,dV][32][64]
-    bf16_t* sW = reinterpret_cast<bf16_t*>(sAcc + 2 * 2 * BWD_KT * DH);          // per wave: Q[32][KLD], dO[32][KLD], P[32][TLD], dS[32][TLD]
-    constexpr int WSZ = 2 * 32 * KLD + 2 * 32 * TLD;
+    __shared__ __attribute__((aligned(16))) bf16_t sKV[2 * 2 * BWD_KT * KLD];     // [2 buf][K,V][32][KLD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, ql = lane & 31;
-    bf16_t* sQ = sW + wave * WSZ;
-    bf16_t* sdO = sQ + 32 * KLD;
-    bf16_t* sP = sdO + 32 * KLD;
-    bf16_t* sdS = sP + 32 * TLD;
-
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
-    const int q = wave * 32 + ql;
+    const int q = (blockIdx.y * NW + wave) * 32 + ql;
     const bool qok = q < a.Lq;
     const bf16_t* Kg = a.K + (size_t)b * a.Lkv * a.ldk + hd * DH;
     const bf16_t* Vg = a.V + (size_t)b * a.Lkv * a.ldv + hd * DH;
 
-    // ---- per-wave prologue: Q / dO fragments (registers + natural LDS image), delta = rowsum(dO * O)
     bf16x8_t qf[4], dof[4];
     float delta = 0.f;
     {
@@ -309,8 +303,6 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
         for (int ks = 0; ks < 4; ++ks) {
             const uint4 uq = ld16_or_zero(qp + ks * 16, qok), ud = ld16_or_zero(dp + ks * 16, qok), uo = ld16_or_zero(op + ks * 16, qok);
             qf[ks] = __builtin_bit_cast(bf16x8_t, uq); dof[ks] = __builtin_bit_cast(bf16x8_t, ud);
-            *reinterpret_cast<uint4*>(sQ + ql * KLD + ks * 16 + 8 * hl) = uq;
-            *reinterpret_cast<uint4*>(sdO + ql * KLD + ks * 16 + 8 * hl) = ud;
             const uint32_t dw[4] = {ud.x, ud.y, ud.z, ud.w}, ow[4] = {uo.x, uo.y, uo.z, uo.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -320,6 +312,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
         }
     }
     delta += __shfl_xor(delta, 32, 64);
+    if (qok && hl == 0) delta_out[(size_t)bh * a.Lq + q] = delta;
     const float lse2 = qok ? a.LSE[(size_t)bh * a.Lq + q] * LOG2E : 0.f;
     const float c = a.scale * LOG2E;
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
@@ -330,7 +323,6 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
 
-    for (int i = threadIdx.x; i < 2 * 2 * BWD_KT * DH; i += NT) sAcc[i] = 0.f;
     uint4 rk[MAXC], rv[MAXC];
     const int nt = (a.Lkv + BWD_KT - 1) / BWD_KT;
     kv_load<BWD_KT, MAXC>(Kg, a.ldk, a.Lkv, 0, rk, NT);
@@ -342,14 +334,11 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
     for (int t = 0; t < nt; ++t) {
         const bf16_t* sK = sKV + (t & 1) * 2 * BWD_KT * KLD;
         const bf16_t* sV = sK + BWD_KT * KLD;
-        float* accK = sAcc + (t & 1) * 2 * BWD_KT * DH;
-        float* accV = accK + BWD_KT * DH;
         const int kv0 = t * BWD_KT;
         if (t + 1 < nt) {
             kv_load<BWD_KT, MAXC>(Kg, a.ldk, a.Lkv, (t + 1) * BWD_KT, rk, NT);
             kv_load<BWD_KT, MAXC>(Vg, a.ldv, a.Lkv, (t + 1) * BWD_KT, rv, NT);
         }
-        // S^T and dP^T
         f32x16_t s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -358,7 +347,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, 0, ks * 16), qf[ks], s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sV, KLD, 0, ks * 16), dof[ks], dp, 0, 0, 0);
         }
-        float pd[16], ds[16];
+        float ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -366,10 +355,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
             const float pr = ok ? exp2f(s[r] * c - lse2) : 0.f;
             float keep = 1.f;
             if (drop) keep = vpf_keep(rng, rbase + (uint64_t)kv) ? rng.scale : 0.f;
-            pd[r] = pr * keep;
             ds[r] = pr * (dp[r] * keep - delta) * a.scale;
         }
-        // dQ^T += K^T . dS^T   (dS accumulators as the B operand, K^T by transposing reads)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const bf16x8_t dsf = pack8(ds + 8 * s2);
@@ -377,59 +364,12 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
             for (int dt = 0; dt < 2; ++dt)
                 dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, 16 * s2, dt * 32), dsf, dq[dt], 0, 0, 0);
         }
-        // P, dS -> per-wave LDS scratch [q][kv]
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            uint2 u, w;
-            u.x = pack_bf16x2(pd[4 * gq + 0], pd[4 * gq + 1]); u.y = pack_bf16x2(pd[4 * gq + 2], pd[4 * gq + 3]);
-            w.x = pack_bf16x2(ds[4 * gq + 0], ds[4 * gq + 1]); w.y = pack_bf16x2(ds[4 * gq + 2], ds[4 * gq + 3]);
-            *reinterpret_cast<uint2*>(sP + ql * TLD + 8 * gq + 4 * hl) = u;
-            *reinterpret_cast<uint2*>(sdS + ql * TLD + 8 * gq + 4 * hl) = w;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // dV[kv,d] += P^T dO ; dK[kv,d] += dS^T Q   (contract over this wave's 32 query rows)
-        f32x16_t dv[2], dk[2];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { dv[0][r] = dv[1][r] = dk[0][r] = dk[1][r] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8_t pf = frag_tr_nat(sP, TLD, 16 * ks, 0);
-            const bf16x8_t sf = frag_tr_nat(sdS, TLD, 16 * ks, 0);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_tr_nat(sdO, KLD, 16 * ks, dt * 32), dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sf, frag_tr_nat(sQ, KLD, 16 * ks, dt * 32), dk[dt], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kvl = (r & 3) + 8 * (r >> 2) + 4 * hl;
-                atomicAdd(accV + kvl * DH + dt * 32 + ql, dv[dt][r]);
-                atomicAdd(accK + kvl * DH + dt * 32 + ql, dk[dt][r]);
-            }
         if (t + 1 < nt) {
             bf16_t* nK = sKV + ((t + 1) & 1) * 2 * BWD_KT * KLD;
             kv_store<BWD_KT, MAXC>(nK, rk, NT);
             kv_store<BWD_KT, MAXC>(nK + BWD_KT * KLD, rv, NT);
         }
         __syncthreads();
-        // flush this tile's dK / dV (bf16) and clear the accumulator for tile t+2
-        for (int e = threadIdx.x; e < 2 * BWD_KT * DH / 4; e += NT) {
-            const int which = e / (BWD_KT * DH / 4), r4 = e % (BWD_KT * DH / 4);
-            const int kvl = r4 / (DH / 4), d4 = (r4 % (DH / 4)) * 4;
-            float* src = accK + which * BWD_KT * DH + kvl * DH + d4;
-            const float4 v = *reinterpret_cast<float4*>(src);
-            *reinterpret_cast<float4*>(src) = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kv0 + kvl < a.Lkv) {
-                uint2 u; u.x = pack_bf16x2(v.x, v.y); u.y = pack_bf16x2(v.z, v.w);
-                bf16_t* dst = which ? a.dV + ((size_t)b * a.Lkv + kv0 + kvl) * a.lddv + hd * DH + d4
-                                    : a.dK + ((size_t)b * a.Lkv + kv0 + kvl) * a.lddk + hd * DH + d4;
-                *reinterpret_cast<uint2*>(dst) = u;
-            }
-        }
     }
     if (qok) {
         bf16_t* op = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + hd * DH;
@@ -446,26 +386,150 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_kernel(AttnArgs a)
 }
 
 template <int NW>
-static int launch_bwd(const AttnArgs& a, hipStream_t st)
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const float* __restrict__ delta_in)
 {
-    const size_t lds = sizeof(bf16_t) * (2 * 2 * BWD_KT * KLD) + sizeof(float) * (2 * 2 * BWD_KT * DH) +
-                       sizeof(bf16_t) * (size_t)NW * (2 * 32 * KLD + 2 * 32 * TLD);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return VPF_ERR_HIP;
-        attr_set = true;
+    constexpr int NT = NW * 64;
+    constexpr int MAXC = (BWD_KT * 8 + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) bf16_t sQD[2 * 2 * BWD_KT * KLD];     // [2 buf][Q,dO][32][KLD]
+    __shared__ float sStat[2 * 2 * BWD_KT];                                        // [2 buf][lse*log2e, delta][32]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, kl = lane & 31;
+    const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+    const int kv = (blockIdx.y * NW + wave) * 32 + kl;
+    const bool kvok = kv < a.Lkv;
+    const bf16_t* Qg = a.Q + (size_t)b * a.Lq * a.ldq + hd * DH;
+    const bf16_t* Dg = a.dO + (size_t)b * a.Lq * a.lddo + hd * DH;
+    const float* lseg = a.LSE + (size_t)bh * a.Lq;
+    const float* delg = delta_in + (size_t)bh * a.Lq;
+
+    bf16x8_t kf[4], vf[4];
+    {
+        const size_t row = (size_t)b * a.Lkv + (kvok ? kv : 0);
+        const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+        const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, kvok));
+            vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, kvok));
+        }
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<NW>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a);
+    const float c = a.scale * LOG2E;
+    const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
+    const bool drop = a.p > 0.f;
+
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
+
+    uint4 rq[MAXC], rd[MAXC];
+    float st0 = 0.f;
+    const int nt = (a.Lq + BWD_KT - 1) / BWD_KT;
+    auto stat_load = [&](int q0) {
+        // threads 0..31: lse * log2e of row q0 + t ; threads 32..63: delta
+        float v = 0.f;
+        if (threadIdx.x < 64) {
+            const int qq = q0 + (threadIdx.x & 31);
+            if (qq < a.Lq) v = threadIdx.x < 32 ? lseg[qq] * LOG2E : delg[qq];
+        }
+        return v;
+    };
+    kv_load<BWD_KT, MAXC>(Qg, a.ldq, a.Lq, 0, rq, NT);
+    kv_load<BWD_KT, MAXC>(Dg, a.lddo, a.Lq, 0, rd, NT);
+    st0 = stat_load(0);
+    kv_store<BWD_KT, MAXC>(sQD, rq, NT);
+    kv_store<BWD_KT, MAXC>(sQD + BWD_KT * KLD, rd, NT);
+    if (threadIdx.x < 64) sStat[threadIdx.x] = st0;
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const bf16_t* sQ = sQD + (t & 1) * 2 * BWD_KT * KLD;
+        const bf16_t* sD = sQ + BWD_KT * KLD;
+        const float* sL = sStat + (t & 1) * 2 * BWD_KT;
+        const int q0 = t * BWD_KT;
+        if (t + 1 < nt) {
+            kv_load<BWD_KT, MAXC>(Qg, a.ldq, a.Lq, (t + 1) * BWD_KT, rq, NT);
+            kv_load<BWD_KT, MAXC>(Dg, a.lddo, a.Lq, (t + 1) * BWD_KT, rd, NT);
+            st0 = stat_load((t + 1) * BWD_KT);
+        }
+        // S[q,kv] and dP[q,kv]: A = Q / dO rows (LDS), B = K / V fragments (registers); key on the lane
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, 0, ks * 16), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, 0, ks * 16), vf[ks], dp, 0, 0, 0);
+        }
+        float pd[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = (r & 3) + 8 * (r >> 2) + 4 * hl;
+            const int q = q0 + qr;
+            const bool ok = kvok && q < a.Lq;
+            const float pr = ok ? exp2f(s[r] * c - sL[qr]) : 0.f;
+            float keep = 1.f;
+            if (drop) keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)q) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
+            pd[r] = pr * keep;
+            ds[r] = pr * (dp[r] * keep - sL[BWD_KT + qr]) * a.scale;
+        }
+        // dV^T[d,kv] += dO^T[d,q] . P[q,kv] ; dK^T[d,kv] += Q^T[d,q] . dS[q,kv]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+            }
+        }
+        if (t + 1 < nt) {
+            bf16_t* nQ = sQD + ((t + 1) & 1) * 2 * BWD_KT * KLD;
+            kv_store<BWD_KT, MAXC>(nQ, rq, NT);
+            kv_store<BWD_KT, MAXC>(nQ + BWD_KT * KLD, rd, NT);
+            if (threadIdx.x < 64) sStat[((t + 1) & 1) * 2 * BWD_KT + threadIdx.x] = st0;
+        }
+        __syncthreads();
+    }
+    if (kvok) {
+        bf16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
+        bf16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 u, w;
+                u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
+                *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
+            }
+    }
+}
+
+template <int NWQ, int NWK>
+static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
+{
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), 0, st, a, delta);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<NWK>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
+}
+template <int NWQ>
+static int launch_bwd_k(const AttnArgs& a, float* delta, hipStream_t st)
+{
+    const int nkb = vpf_cdiv(a.Lkv, 32);
+    if (nkb <= 1) return launch_bwd<NWQ, 1>(a, delta, st);
+    if (nkb <= 2) return launch_bwd<NWQ, 2>(a, delta, st);
+    if (nkb == 3 || nkb == 6 || nkb == 9) return launch_bwd<NWQ, 3>(a, delta, st);
+    if (nkb == 7) return launch_bwd<NWQ, 7>(a, delta, st);
+    return launch_bwd<NWQ, 4>(a, delta, st);
 }
 
 extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* out,
                                  long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
                                  int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
-                                 void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, void* stream)
+                                 void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (head_dim != DH) return VPF_ERR_UNSUPPORTED;
     AttnArgs a = {};
     a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
@@ -475,19 +539,14 @@ extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ld
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     int rc = check_common(a);
     if (rc) return rc;
-    if (!out || !dout || !lse || !dq || !dk || !dv) return VPF_ERR_NULL;
+    if (!out || !dout || !lse || !dq || !dk || !dv || !delta_ws) return VPF_ERR_NULL;
     if ((ldo % 8) || (lddo % 8) || (lddq % 4) || (lddk % 4) || (lddv % 4)) return VPF_ERR_BADALIGN;
     if (((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7) || ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7)) return VPF_ERR_BADALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int nqb = vpf_cdiv(Lq, 32);
-    switch (nqb) {
-        case 1: return launch_bwd<1>(a, st);
-        case 2: return launch_bwd<2>(a, st);
-        case 3: return launch_bwd<3>(a, st);
-        case 4: return launch_bwd<4>(a, st);
-        case 5: return launch_bwd<5>(a, st);
-        case 6: return launch_bwd<6>(a, st);
-        case 7: return launch_bwd<7>(a, st);
-        default: return VPF_ERR_UNSUPPORTED;   // Lq > 224: not on the pre-training path (G <= 128, T = 196)
-    }
+    if (nqb <= 1) return launch_bwd_k<1>(a, delta_ws, st);
+    if (nqb <= 2) return launch_bwd_k<2>(a, delta_ws, st);
+    if (nqb == 3 || nqb == 6 || nqb == 9) return launch_bwd_k<3>(a, delta_ws, st);
+    if (nqb == 7) return launch_bwd_k<7>(a, delta_ws, st);
+    return launch_bwd_k<4>(a, delta_ws, st);
 }

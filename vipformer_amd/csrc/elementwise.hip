@@ -34,6 +34,7 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __rest
 }
 extern "C" int vpf_cast_f32_bf16(const float* x, void* y, long n, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !y) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return VPF_ERR_BADALIGN;
@@ -48,6 +49,7 @@ __global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __rest
 }
 extern "C" int vpf_cast_bf16_f32(const void* x, float* y, long n, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !y) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
@@ -97,6 +99,7 @@ extern "C" int vpf_layernorm_fwd(const void* x, int x_is_bf16, const float* pos,
                                  const float* beta, void* y_bf16, float* xsum, float* mean, float* rstd, long rows, int D,
                                  float eps, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd) return VPF_ERR_NULL;
     if (rows < 0 || D <= 0 || D > 64 * LN_MAXI || (pos && pos_rows <= 0)) return VPF_ERR_BADSHAPE;
     if (rows == 0) return VPF_OK;
@@ -165,10 +168,11 @@ extern "C" int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf
                                  const float* gamma, const float* dres, void* dx, int dx_is_bf16, float* dgamma, float* dbeta,
                                  long rows, int D, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return VPF_ERR_NULL;
     if (rows < 0 || D <= 0 || D > 64 * LN_MAXI) return VPF_ERR_BADSHAPE;
     if (rows == 0) return VPF_OK;
-    const int grid = grid_for(rows, 64, 512);
+    const int grid = grid_for(rows, 16, 1024);
     hipStream_t st = (hipStream_t)stream;
 #define LNB(TX, TDX) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDX>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy_bf16, (const TX*)x, \
                                         mean, rstd, gamma, dres, (TDX*)dx, dgamma, dbeta, rows, D)
@@ -194,6 +198,7 @@ __global__ void dropout_add_fwd_kernel(const bf16_t* __restrict__ y, const float
 extern "C" int vpf_dropout_add_fwd(const void* y_bf16, const float* res, float* out, long n, const uint32_t* rng_state,
                                    uint32_t site, float p, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!y_bf16 || !out || !rng_state) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(dropout_add_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y_bf16, res, out, n,
@@ -212,6 +217,7 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dout, bf16_t* __res
 extern "C" int vpf_dropout_bwd(const float* dout, void* dy_bf16, long n, const uint32_t* rng_state, uint32_t site, float p,
                                void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dout || !dy_bf16 || !rng_state) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, (bf16_t*)dy_bf16, n, rng_state, site, p);
@@ -227,6 +233,7 @@ __global__ void dropout_mask_kernel(uint8_t* __restrict__ out, long n, const uin
 }
 extern "C" int vpf_dropout_mask(uint8_t* out, long n, const uint32_t* rng_state, uint32_t site, float p, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!out || !rng_state) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, out, n, rng_state, site, p);
@@ -236,6 +243,7 @@ extern "C" int vpf_dropout_mask(uint8_t* out, long n, const uint32_t* rng_state,
 __global__ void rng_advance_kernel(uint32_t* st) { if (threadIdx.x == 0 && blockIdx.x == 0) st[2] += 1u; }
 extern "C" int vpf_rng_advance(uint32_t* rng_state, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!rng_state) return VPF_ERR_NULL;
     hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rng_state);
     VPF_CHECK_LAUNCH();
@@ -243,9 +251,60 @@ extern "C" int vpf_rng_advance(uint32_t* rng_state, void* stream)
 }
 
 // =============================================================================== column sums (bias grads, BN stats)
-// x [M,C] -> acc[c] += sum_m x ; acc2[c] += sum_m x^2 (optional).  thread = column, block = 128-row slab.
+// x [M,C] -> acc[c] += sum_m x ; acc2[c] += sum_m x^2 (optional).  A block owns a slab of rows; every thread
+// streams 8 consecutive columns (16-byte loads for bf16) of one row per step; the block's row-lanes meet in
+// LDS and ONE fp32 atomic per column and block leaves the CU.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ acc, float* __restrict__ acc2, int rows_per_block)
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ acc, float* __restrict__ acc2,
+                                                   int rows_per_block)
+{
+    __shared__ float red[2][256][9];
+    const int c8 = C / 8;                       // column groups (C % 8 == 0 on this path)
+    const int gpr = c8 < 256 ? c8 : 256;        // groups handled per row by the block at a time
+    const int rlanes = 256 / gpr;               // rows in flight
+    const int t = threadIdx.x, cg0 = t % gpr, rl = t / gpr;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int cgb = 0; cgb < c8; cgb += gpr) {
+        const int cg = cgb + cg0;
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+        if (cg < c8 && rl < rlanes) {
+            for (long r = r0 + rl; r < r1; r += rlanes) {
+                float v[8];
+                if (sizeof(T) == 2) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + (size_t)r * C + cg * 8);
+                    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+                } else {
+                    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + cg * 8);
+                    const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + cg * 8 + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[0][t][j] = s[j]; red[1][t][j] = q[j]; }
+        __syncthreads();
+        // thread (cg0, rl==0 .. ) : fold the row lanes; spread the 8 columns over the row-lane threads
+        for (int e = t; e < gpr * 8; e += 256) {
+            const int g = e / 8, j = e % 8;
+            if (cgb + g < c8) {
+                float a = 0.f, b = 0.f;
+                for (int k = 0; k < rlanes; ++k) { a += red[0][k * gpr + g][j]; b += red[1][k * gpr + g][j]; }
+                atomicAdd(acc + (cgb + g) * 8 + j, a);
+                if (acc2) atomicAdd(acc2 + (cgb + g) * 8 + j, b);
+            }
+        }
+        __syncthreads();
+    }
+}
+// generic fallback (C % 8 != 0): thread = column
+template <typename T>
+__global__ void colsum_generic_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ acc, float* __restrict__ acc2, int rows_per_block)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -257,14 +316,24 @@ __global__ void colsum_kernel(const T* __restrict__ x, long M, int C, float* __r
 }
 extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* acc, float* acc2, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !acc) return VPF_ERR_NULL;
     if (M < 0 || C <= 0) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
-    int rpb = 128;
-    while ((M + rpb - 1) / rpb > 16384) rpb *= 2;
-    dim3 grid(vpf_cdiv(C, 256), (unsigned)((M + rpb - 1) / rpb));
-    if (x_is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, M, C, acc, acc2, rpb);
-    else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, M, C, acc, acc2, rpb);
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 8 == 0 && (((uintptr_t)x & 15) == 0)) {
+        int rpb = 32;
+        while ((M + rpb - 1) / rpb > 512) rpb *= 2;      // <= 512 blocks -> <= 512 atomics per column
+        const int grid = (int)((M + rpb - 1) / rpb);
+        if (x_is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2, rpb);
+        else hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, M, C, acc, acc2, rpb);
+    } else {
+        int rpb = 128;
+        while ((M + rpb - 1) / rpb > 16384) rpb *= 2;
+        dim3 grid(vpf_cdiv(C, 256), (unsigned)((M + rpb - 1) / rpb));
+        if (x_is_bf16) hipLaunchKernelGGL(colsum_generic_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2, rpb);
+        else hipLaunchKernelGGL(colsum_generic_kernel<float>, grid, dim3(256), 0, st, (const float*)x, M, C, acc, acc2, rpb);
+    }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -296,6 +365,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
 extern "C" int vpf_bn_finalize(const float* sums, const float* sumsq, long M, int C, float eps, float momentum, int training,
                                float* running_mean, float* running_var, long long* num_batches, float* stat, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!stat || (training && (!sums || !sumsq)) || (!training && (!running_mean || !running_var))) return VPF_ERR_NULL;
     if (C <= 0 || M <= 0) return VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(vpf_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, sumsq, M, C, eps, momentum,
@@ -318,6 +388,7 @@ __global__ void bn_act_fwd_kernel(const TIN* __restrict__ x, const float* __rest
 extern "C" int vpf_bn_act_fwd(const void* x, int x_is_bf16, const float* stat, const float* gamma, const float* beta, void* y,
                               int y_is_bf16, long M, int C, int relu, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !stat || !gamma || !beta || !y) return VPF_ERR_NULL;
     if (M < 0 || C <= 0) return VPF_ERR_BADSHAPE;
     const long total = M * C;
@@ -377,6 +448,7 @@ extern "C" int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_i
                           const float* beta, long M, int C, int relu, int training, float* tmp2C_zeroed, void* dx, int dx_is_bf16,
                           float* dgamma, float* dbeta, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dy || !x || !stat || !gamma || !beta || !tmp2C_zeroed) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -412,6 +484,7 @@ __global__ void group_max_fwd_kernel(const bf16_t* __restrict__ h, long NG, int 
 }
 extern "C" int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!h_bf16 || !out) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || K > 255 || C <= 0) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
@@ -433,6 +506,7 @@ __global__ void group_max_bwd_kernel(const TIN* __restrict__ dout, const uint8_t
 }
 extern "C" int vpf_group_max_bwd(const void* dout, int dout_is_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dout || !arg || !dh_bf16) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
@@ -454,6 +528,7 @@ __global__ void g2e_concat_fwd_kernel(const bf16_t* __restrict__ gmax, const bf1
 }
 extern "C" int vpf_g2e_concat_fwd(const void* gmax_bf16, const void* h_bf16, long M, int K, int C, void* feat_bf16, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!gmax_bf16 || !h_bf16 || !feat_bf16) return VPF_ERR_NULL;
     if (M < 0 || K <= 0 || C <= 0 || (M % K)) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
@@ -479,6 +554,7 @@ __global__ void g2e_concat_bwd_kernel(const bf16_t* __restrict__ dfeat, const ui
 }
 extern "C" int vpf_g2e_concat_bwd(const void* dfeat_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dfeat_bf16 || !arg || !dh_bf16) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
@@ -502,6 +578,7 @@ __global__ void pool_fwd_kernel(const float* __restrict__ x, int B, int L, int D
 }
 extern "C" int vpf_pool_fwd(const float* x, int B, int L, int D, float* out, int* arg, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !out) return VPF_ERR_NULL;
     if (B < 0 || L <= 0 || D <= 0) return VPF_ERR_BADSHAPE;
     if (B == 0) return VPF_OK;
@@ -521,6 +598,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dout, const int* __res
 }
 extern "C" int vpf_pool_bwd(const float* dout, const int* arg, int B, int L, int D, float* dx, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dout || !arg || !dx) return VPF_ERR_NULL;
     if (B < 0 || L <= 0 || D <= 0) return VPF_ERR_BADSHAPE;
     if (B == 0) return VPF_OK;
@@ -537,6 +615,7 @@ __global__ void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, 
 }
 extern "C" int vpf_axpy_f32(const float* x, float* y, long n, float a, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !y) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, a);
@@ -556,6 +635,7 @@ __global__ void rowsum_mod_kernel(const float* __restrict__ x, long rows, int D,
 }
 extern "C" int vpf_rowsum_mod_f32(const float* x, long rows, int D, int period, float* acc, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !acc) return VPF_ERR_NULL;
     if (rows < 0 || D <= 0 || period <= 0) return VPF_ERR_BADSHAPE;
     if (rows == 0) return VPF_OK;

@@ -207,43 +207,100 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
     }
 
     // ---------------------------------------------------------------- epilogue
-    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+    if (g.mode == EPI_ATOMIC) {
+        // split-K partial sums: fp32 atomics straight from the accumulators (128-byte row segments)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + col_l;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rsub;
+                    if (n < g.N && m < g.M) atomicAdd(reinterpret_cast<float*>(g.C) + (size_t)cb + (size_t)m * g.ldc + n, acc[i][j][r]);
+                }
+            }
+        return;
+    }
+    // Every other mode: one (i,j) sub-tile of every wave at a time is parked in LDS as fp32 (the operand
+    // buffers are dead), then each thread finishes 4 consecutive columns of a row: bias / GELU / GELU' /
+    // dropout+residual / group bias with 16-byte loads of the side inputs and 8- or 16-byte stores.
+    constexpr int SR = WM * 32, SC = WN * 32, SLD = SC + 4;
+    static_assert(SR * SLD * 4 <= 2 * STAGE * 2, "staging tile must fit in the operand buffers");
+    float* sf = reinterpret_cast<float*>(lds);
     VpfRng rng;
     if (g.mode == EPI_DROP_RES) rng = vpf_rng_init(g.rng, g.site, g.p);
+    const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (((uintptr_t)g.C & 15) == 0) && (g.sCb % 4 == 0) &&
+                     (g.mode != EPI_GELU || ((g.ldc2 % 4 == 0) && (((uintptr_t)g.C2 & 7) == 0))) &&
+                     (g.mode != EPI_DROP_RES || ((g.ldres % 4 == 0) && (((uintptr_t)g.res & 15) == 0))) &&
+                     (g.mode != EPI_GELU_BWD || ((g.ldaux % 4 == 0) && (((uintptr_t)g.aux & 7) == 0))) &&
+                     (g.mode != EPI_GROUPBIAS || (((uintptr_t)g.gbias & 15) == 0));
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 32 + col_l;
-            if (n >= g.N) continue;
-            const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rsub;
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                const size_t co = (size_t)cb + (size_t)m * g.ldc + n;
-                switch (g.mode) {
-                    case EPI_STORE: break;
-                    case EPI_GELU:
-                        reinterpret_cast<bf16_t*>(g.C2)[(size_t)m * g.ldc2 + n] = f32_to_bf16(v);
-                        v = gelu_f(bf16_to_f32(f32_to_bf16(v)));
-                        break;
-                    case EPI_DROP_RES: {
-                        const bool keep = vpf_keep(rng, (uint64_t)m * (uint64_t)g.N + (uint64_t)n);
-                        v = g.res[(size_t)m * g.ldres + n] + (keep ? v * rng.scale : 0.f);
-                        break;
-                    }
-                    case EPI_GELU_BWD: v = v * gelu_grad_f(bf16_to_f32(g.aux[(size_t)m * g.ldaux + n])); break;
-                    case EPI_ATOMIC: atomicAdd(reinterpret_cast<float*>(g.C) + co, v); continue;
-                    case EPI_RELU: v = fmaxf(v, 0.f); break;
-                    case EPI_GROUPBIAS: v += g.gbias[(size_t)(m / g.group) * g.N + n]; break;
+            for (int r = 0; r < 16; ++r)
+                sf[(wm * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SLD + wn * 32 + col_l] = acc[i][j][r];
+            __syncthreads();
+            for (int e = threadIdx.x; e < SR * (SC / 4); e += 256) {
+                const int sr = e / (SC / 4), sc = (e % (SC / 4)) * 4;
+                const int m = m0 + ((sr >> 5) * TM + i) * 32 + (sr & 31);
+                const int n = n0 + ((sc >> 5) * TN + j) * 32 + (sc & 31);
+                if (m >= g.M || n >= g.N) continue;
+                const float4 a4 = *reinterpret_cast<const float4*>(sf + sr * SLD + sc);
+                float v[4] = {a4.x, a4.y, a4.z, a4.w};
+                const int nv = min(4, g.N - n);
+                if (g.bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q < nv) v[q] += g.bias[n + q];
                 }
-                if (g.c_f32) reinterpret_cast<float*>(g.C)[co] = v;
-                else reinterpret_cast<bf16_t*>(g.C)[co] = f32_to_bf16(v);
+                const size_t co = (size_t)cb + (size_t)m * g.ldc + n;
+                if (g.mode == EPI_GELU) {
+                    bf16_t ub[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { ub[q] = f32_to_bf16(v[q]); v[q] = gelu_f(bf16_to_f32(ub[q])); }
+                    bf16_t* u = reinterpret_cast<bf16_t*>(g.C2) + (size_t)m * g.ldc2 + n;
+                    if (vec) { uint2 w; w.x = ub[0] | ((uint32_t)ub[1] << 16); w.y = ub[2] | ((uint32_t)ub[3] << 16); *reinterpret_cast<uint2*>(u) = w; }
+                    else { for (int q = 0; q < nv; ++q) u[q] = ub[q]; }
+                } else if (g.mode == EPI_DROP_RES) {
+                    const float* rp = g.res + (size_t)m * g.ldres + n;
+                    float rr[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (vec) { const float4 t = *reinterpret_cast<const float4*>(rp); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
+                    else { for (int q = 0; q < nv; ++q) rr[q] = rp[q]; }
+                    const uint64_t base = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = rr[q] + (vpf_keep(rng, base + q) ? v[q] * rng.scale : 0.f);
+                } else if (g.mode == EPI_GELU_BWD) {
+                    const bf16_t* ap = g.aux + (size_t)m * g.ldaux + n;
+                    bf16_t ab[4] = {0, 0, 0, 0};
+                    if (vec) { const uint2 t = *reinterpret_cast<const uint2*>(ap); ab[0] = t.x & 0xffff; ab[1] = t.x >> 16; ab[2] = t.y & 0xffff; ab[3] = t.y >> 16; }
+                    else { for (int q = 0; q < nv; ++q) ab[q] = ap[q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= gelu_grad_f(bf16_to_f32(ab[q]));
+                } else if (g.mode == EPI_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                } else if (g.mode == EPI_GROUPBIAS) {
+                    const float* gp = g.gbias + (size_t)(m / g.group) * g.N + n;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q < nv) v[q] += gp[q];
+                }
+                if (g.c_f32) {
+                    float* o = reinterpret_cast<float*>(g.C) + co;
+                    if (vec) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    else { for (int q = 0; q < nv; ++q) o[q] = v[q]; }
+                } else {
+                    bf16_t* o = reinterpret_cast<bf16_t*>(g.C) + co;
+                    if (vec) { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *reinterpret_cast<uint2*>(o) = w; }
+                    else { for (int q = 0; q < nv; ++q) o[q] = f32_to_bf16(v[q]); }
+                }
             }
+            __syncthreads();
         }
+    }
 }
 
 template <int TM, int TN, int WM, int WN>
@@ -297,6 +354,7 @@ extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void
                              const float* gbias, int group, const uint32_t* rng_state, uint32_t site, float p,
                              int splitk, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     GemmArgs g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb;
     g.sAb = sAb; g.sBb = sBb; g.sCb = sCb; g.M = M; g.N = N; g.K = K; g.splitk = splitk; g.mode = mode;

@@ -86,6 +86,7 @@ static int launch_fps(const float* pts, int B, int N, int C, const int64_t* star
 extern "C" int vpf_fps_f32(const float* pts, int B, int N, int C, const int64_t* start_idx, int G,
                            int64_t* out_idx, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!pts || !start_idx || !out_idx) return VPF_ERR_NULL;
     if (B < 0 || N <= 0 || C < 3 || G < 0 || N > 4096) return VPF_ERR_BADSHAPE;
     if (B == 0 || G == 0) return VPF_OK;
@@ -112,6 +113,7 @@ __global__ void index_points_kernel(const float* __restrict__ points, int N, int
 extern "C" int vpf_index_points_f32(const float* points, int B, int N, int C, const int64_t* idx, int S,
                                     float* out, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!points || !idx || !out) return VPF_ERR_NULL;
     if (B < 0 || N <= 0 || C <= 0 || S < 0) return VPF_ERR_BADSHAPE;
     const long total = (long)B * S * C;
@@ -156,6 +158,7 @@ __global__ void square_distance_kernel(const float* __restrict__ src, int Cs, co
 extern "C" int vpf_square_distance_f32(const float* src, int Cs, const float* dst, int Cd, int B, int Ns, int Nd,
                                        float* out, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!src || !dst || !out) return VPF_ERR_NULL;
     if (B < 0 || Ns < 0 || Nd < 0 || Cs < 3 || Cd < 3 || B > 65535 || Ns > 65535) return VPF_ERR_BADSHAPE;
     if (B == 0 || Ns == 0 || Nd == 0) return VPF_OK;
@@ -256,6 +259,7 @@ extern "C" int vpf_knn_group_f32(const float* xyz, int B, int N, int C, const fl
                                  int apply_ref_axis_quirk, int64_t* knn_idx, float* knn_dist, float* neighbors,
                                  void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!xyz || !centers) return VPF_ERR_NULL;
     if (B < 0 || N <= 0 || C < 3 || Cc < 3 || G < 0 || K <= 0 || K > 64 || K > N || N > 4096 || B > 65535)
         return VPF_ERR_BADSHAPE;

@@ -46,6 +46,7 @@ __global__ void __launch_bounds__(256) adapter_front_fwd_kernel(const float* __r
 extern "C" int vpf_adapter_front_fwd(const float* x, long M, int C, const float* W, const float* b, const float* gamma,
                                      const float* beta, void* out_bf16, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !W || !b || !gamma || !beta || !out_bf16) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
@@ -94,6 +95,7 @@ extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M
                                      const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta,
                                      void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !da_bf16 || !W || !b || !gamma || !beta || !dW || !db || !dgamma || !dbeta) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
@@ -118,6 +120,7 @@ __global__ void smallk_fwd_kernel(const float* __restrict__ x, long M, int C, co
 }
 extern "C" int vpf_smallk_fwd(const float* x, long M, int C, const float* W, const float* b, int N, int act, void* out_bf16, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !W || !b || !out_bf16) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > 8 || N <= 0) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
@@ -155,6 +158,7 @@ __global__ void smallk_bwd_kernel(const float* __restrict__ x, const bf16_t* __r
 extern "C" int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C, const float* W, const float* b, int N, int act,
                               float* dW, float* db, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !dy_bf16 || !W || !b || !dW || !db) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > 8 || N <= 0) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
@@ -189,6 +193,7 @@ __global__ void __launch_bounds__(256) g2e_conv1_stats_kernel(const float* __res
 }
 extern "C" int vpf_g2e_conv1_stats(const float* x, long M, int C, const float* W, const float* b, float* sums, float* sumsq, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !W || !b || !sums || !sumsq) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(g2e_conv1_stats_kernel, dim3(grid_for(M, 512, 1024)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, sums, sumsq);
@@ -215,6 +220,7 @@ __global__ void __launch_bounds__(256) g2e_conv1_apply_kernel(const float* __res
 extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
                                    const float* beta, void* out_bf16, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !W || !b || !stat || !gamma || !beta || !out_bf16) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(g2e_conv1_apply_kernel, dim3(grid_for(M, 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, stat, gamma, beta, (bf16_t*)out_bf16);
@@ -265,6 +271,7 @@ extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, in
                                  const float* gamma, const float* beta, int training, float* tmp128_zeroed, float* dW, float* db,
                                  float* dgamma, float* dbeta, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !tmp128_zeroed || !dW || !db || !dgamma || !dbeta) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     const int grid = grid_for(M, 512, 1024);
@@ -291,6 +298,7 @@ __global__ void patchify_kernel(const float* __restrict__ img, long sb, long sh,
 }
 extern "C" int vpf_patchify(const float* img, long sb, long sh, long sw, long sc, int B, int H, int W, int C, int p, void* out_bf16, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!img || !out_bf16) return VPF_ERR_NULL;
     if (B < 0 || H <= 0 || W <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p)) return VPF_ERR_BADSHAPE;
     if (B == 0) return VPF_OK;
@@ -363,6 +371,7 @@ __global__ void ntxent_mean_kernel(const float* __restrict__ loss_rows, int n, f
 extern "C" int vpf_ntxent_fwd(const float* z0, const float* z1, int b, int D, float temperature, float* zn, float* inv_norm, float* P,
                               float* loss_rows, float* loss, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!z0 || !z1 || !zn || !inv_norm || !P || !loss_rows || !loss) return VPF_ERR_NULL;
     if (b <= 0 || D <= 0 || 2 * b > 8192) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
@@ -411,6 +420,7 @@ __global__ void __launch_bounds__(256) ntxent_bwd_kernel(const float* __restrict
 extern "C" int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b, int D, float temperature, const float* dloss,
                               float* dz0, float* dz1, void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!zn || !inv_norm || !P || !dloss || !dz0 || !dz1) return VPF_ERR_NULL;
     if (b <= 0 || D <= 0 || 2 * b > 8192) return VPF_ERR_BADSHAPE;
     const int n = 2 * b;
@@ -447,6 +457,7 @@ __global__ void adamw_step_kernel(float* hyper) { if (threadIdx.x == 0 && hyper[
 extern "C" int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev, int advance_step,
                               void* stream)
 {
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!p || !g || !m || !v || !hyper_dev) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;

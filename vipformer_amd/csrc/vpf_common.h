@@ -32,36 +32,70 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
 }
 
 // ------------------------------------------------------------------ wave-level reductions (64 lanes)
+// DPP (data-parallel primitives) cross-lane moves stay in the VALU: quad permutes, row (16-lane) mirrors,
+// then row_bcast15 / row_bcast31 fold the four rows; the total lands in lane 63 and is read back as a
+// wave-uniform scalar.  ~6 dependent VALU ops instead of 6 LDS round trips (ds_bpermute).
+#define VPF_DPP_QUAD_1032 0xB1
+#define VPF_DPP_QUAD_2301 0x4E
+#define VPF_DPP_ROW_HALF_MIRROR 0x141
+#define VPF_DPP_ROW_MIRROR 0x140
+#define VPF_DPP_ROW_BCAST15 0x142
+#define VPF_DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f<VPF_DPP_QUAD_1032, 0xF>(0.f, v);
+    v += dpp_f<VPF_DPP_QUAD_2301, 0xF>(0.f, v);
+    v += dpp_f<VPF_DPP_ROW_HALF_MIRROR, 0xF>(0.f, v);
+    v += dpp_f<VPF_DPP_ROW_MIRROR, 0xF>(0.f, v);
+    v += dpp_f<VPF_DPP_ROW_BCAST15, 0xA>(0.f, v);
+    v += dpp_f<VPF_DPP_ROW_BCAST31, 0xC>(0.f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<VPF_DPP_QUAD_1032, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<VPF_DPP_QUAD_2301, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<VPF_DPP_ROW_HALF_MIRROR, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<VPF_DPP_ROW_MIRROR, 0xF>(v, v));
+    v = fmaxf(v, dpp_f<VPF_DPP_ROW_BCAST15, 0xA>(v, v));
+    v = fmaxf(v, dpp_f<VPF_DPP_ROW_BCAST31, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+// 64-bit keys as (hi, lo) pairs
+template <int CTRL, int ROW_MASK, bool MAXOP>
+__device__ __forceinline__ void dpp_step_u64(uint32_t& hi, uint32_t& lo)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_xor(v, o, 64);
-        v = t > v ? t : v;
-    }
-    return v;
+    const uint32_t th = dpp_u<CTRL, ROW_MASK>(hi, hi), tl = dpp_u<CTRL, ROW_MASK>(lo, lo);
+    const bool take = MAXOP ? (th > hi || (th == hi && tl > lo)) : (th < hi || (th == hi && tl < lo));
+    hi = take ? th : hi; lo = take ? tl : lo;
 }
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+template <bool MAXOP>
+__device__ __forceinline__ unsigned long long wave_reduce_u64(unsigned long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        unsigned long long t = __shfl_xor(v, o, 64);
-        v = t < v ? t : v;
-    }
-    return v;
+    uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+    dpp_step_u64<VPF_DPP_QUAD_1032, 0xF, MAXOP>(hi, lo);
+    dpp_step_u64<VPF_DPP_QUAD_2301, 0xF, MAXOP>(hi, lo);
+    dpp_step_u64<VPF_DPP_ROW_HALF_MIRROR, 0xF, MAXOP>(hi, lo);
+    dpp_step_u64<VPF_DPP_ROW_MIRROR, 0xF, MAXOP>(hi, lo);
+    dpp_step_u64<VPF_DPP_ROW_BCAST15, 0xA, MAXOP>(hi, lo);
+    dpp_step_u64<VPF_DPP_ROW_BCAST31, 0xC, MAXOP>(hi, lo);
+    hi = (uint32_t)__builtin_amdgcn_readlane((int)hi, 63);
+    lo = (uint32_t)__builtin_amdgcn_readlane((int)lo, 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) { return wave_reduce_u64<true>(v); }
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) { return wave_reduce_u64<false>(v); }
 
 // ------------------------------------------------------------------ counter-based dropout RNG
 // rng_state (device memory, 4 x uint32): {seed_lo, seed_hi, step, reserved}.  A keep decision is a

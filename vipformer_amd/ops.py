@@ -332,7 +332,8 @@ class AttnBlockFn(torch.autograd.Function):
             q, k, v, ldq, ldk, ldv = qkv, kv, kv[:, D:], D, 2 * D, 2 * D
             dk, dv, lddq, lddk, lddv = dkv, dkv[:, D:], D, 2 * D, 2 * D
         L.call("vpf_attention_bwd", q, ldq, k, ldk, v, ldv, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(mod.dp_scale),
-               float(p_att), rng.state(dev), mod.site_attn, dq, lddq, dk, lddk, dv, lddv)
+               float(p_att), rng.state(dev), mod.site_attn, dq, lddq, dk, lddk, dv, lddv,
+               torch.empty(B * H * Lq, dtype=F32, device=dev))
         dxkv = None
         if is_self:
             linear_wgrad(dqkv, nq, 3 * D, D, gW)

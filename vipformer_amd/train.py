@@ -1,0 +1,179 @@
+"""The --mp pre-training step of the reference (pretrain.py:173-211) on MI355X.
+
+    zero_grad -> pc forward on cat(view1, view2) -> NT-Xent(view1, view2)  (IMC)
+              -> img forward -> NT-Xent(mean(view1, view2), img)          (CMC)
+              -> backward -> gradient all-reduce (data parallel) -> AdamW
+
+What is specific to this implementation:
+  * all parameters of both models live in ONE flat fp32 buffer (q/k/v weights adjacent so the
+    fused [3D,D] projection needs no copy); gradients in one flat fp32 buffer that the wgrad
+    kernels accumulate into directly; Adam moments flat; a flat bf16 shadow of the weights is
+    rewritten by the fused AdamW kernel (vpf_adamw_step) and is what the MFMA kernels read.
+  * data parallelism = one process per GPU; the only collective is ONE all-reduce of the flat
+    gradient buffer over RCCL/xGMI (the reference's two DDP reducers with 25 MB buckets become a
+    single 33 MB message); NT-Xent negatives and BatchNorm statistics stay rank-local exactly
+    like the reference (lightly 1.1.21 has no gather; no SyncBatchNorm).  The mean over ranks is
+    folded into the AdamW kernel's gradient scale.
+  * bf16 operands need no loss scaling, so the reference's GradScaler (fp16 autocast,
+    pretrain.py:154,209-211) has no counterpart; the AdamW kernel still takes a gradient scale
+    and a skip flag so a scaler can be put in front of it.
+  * the whole step (forward, backward, AdamW, dropout-state advance) can be captured into one
+    hipGraph (``capture=True``): a few hundred short kernels per step are launch-bound from Python.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+
+
+class FlatParams:
+    """Flat fp32 parameters / gradients / Adam moments + bf16 shadow for a list of modules."""
+
+    def __init__(self, modules: Sequence[torch.nn.Module]):
+        seen, params = set(), []
+        for m in modules:
+            for p in m.parameters():
+                if id(p) not in seen:
+                    seen.add(id(p))
+                    params.append(p)
+        self.params: List[torch.nn.Parameter] = params
+        dev = params[0].device
+        offs, n = [], 0
+        for p in params:
+            n = (n + 7) // 8 * 8            # 16-byte aligned bf16 shadow / 32-byte aligned fp32
+            offs.append(n)
+            n += p.numel()
+        n = (n + 7) // 8 * 8
+        self.numel = n
+        self.p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.s = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        for p, o in zip(params, offs):
+            self.p[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + p.numel()].view_as(p.data)
+            p.grad = self.g[o:o + p.numel()].view_as(p.data)
+        self.offsets = offs
+        self.refresh_shadow()
+        ops.register_managed_shadow(self.p, self.s)
+
+    def refresh_shadow(self) -> None:
+        L.call("vpf_cast_f32_bf16", self.p, self.s, self.numel)
+
+    def attach_grads(self) -> None:
+        """Re-install the flat views (after an optimizer.zero_grad(set_to_none=True))."""
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.g[o:o + p.numel()].view_as(p.data)
+
+
+class Pretrainer:
+    """One object = the reference's models + AdamW + NT-Xent loop state for one rank."""
+
+    def __init__(self, pc_model, img_model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, temperature=0.1,
+                 cmid_weight=1.0, process_group=None, world_size: Optional[int] = None):
+        self.pc_model, self.img_model = pc_model, img_model
+        self.temperature, self.cmid_weight = temperature, cmid_weight
+        self.flat = FlatParams([pc_model, img_model])
+        self.group = process_group
+        if world_size is None:
+            world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.world = world_size
+        dev = self.flat.p.device
+        # {lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip}
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / world_size, 0.0, 0.0],
+                                  dtype=torch.float32, device=dev)
+        self.device = dev
+        self._graph = None
+        self._static = None
+        self.losses = None
+
+    # ------------------------------------------------------------------ pieces
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """DDP constructor semantics (pretrain.py:104-105): rank 0's parameters and buffers everywhere."""
+        if self.world > 1:
+            dist.broadcast(self.flat.p, src, group=self.group)
+            for m in (self.pc_model, self.img_model):
+                for b in m.buffers():
+                    dist.broadcast(b, src, group=self.group)
+            self.flat.refresh_shadow()
+
+    def forward_backward(self, pc_t1, pc_t2, imgs):
+        """pretrain.py:174-209 (modality 'both').  imgs: [b,3,H,W] as the loader yields it."""
+        self.flat.g.zero_()
+        imgs = imgs.permute(0, 2, 3, 1)                     # pretrain.py:179 (a view; strides go to the kernel)
+        b = pc_t1.shape[0]
+        pc = torch.cat([pc_t1, pc_t2], dim=0)               # pretrain.py:183
+        feats = self.pc_model(pc)[0]
+        f1, f2 = feats[:b], feats[b:]
+        loss_imid = ops.ntxent_loss(f1, f2, self.temperature)
+        img_feats = self.img_model(imgs)[0]
+        loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, self.temperature)
+        total = loss_imid + self.cmid_weight * loss_cmid
+        total.backward()
+        return total.detach(), loss_imid.detach(), loss_cmid.detach()
+
+    def allreduce_gradients(self) -> None:
+        """The step's single collective: SUM of the flat gradient over ranks (mean folded into AdamW)."""
+        if self.world > 1:
+            dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def optimizer_step(self) -> None:
+        f = self.flat
+        L.call("vpf_adamw_step", f.p, f.g, f.m, f.v, f.s, f.numel, self.hyper, 1)
+        ops.rng.advance(self.device)
+
+    # ------------------------------------------------------------------ whole step
+    def step(self, pc_t1, pc_t2, imgs):
+        losses = self.forward_backward(pc_t1, pc_t2, imgs)
+        self.allreduce_gradients()
+        self.optimizer_step()
+        self.losses = losses
+        return losses
+
+    def capture(self, pc_t1, pc_t2, imgs, warmup: int = 3):
+        """Capture forward+backward (+AdamW when single-rank) into a hipGraph on static input buffers.
+        Returns the static (pc_t1, pc_t2, imgs) tensors to copy new batches into."""
+        self._static = (pc_t1.clone(), pc_t2.clone(), imgs.clone())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.step(*self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.losses = self.forward_backward(*self._static)
+            if self.world == 1:
+                self.optimizer_step()
+        return self._static
+
+    def replay(self):
+        """One captured step (inputs are whatever the static buffers hold)."""
+        self._graph.replay()
+        if self.world > 1:
+            self.allreduce_gradients()
+            self.optimizer_step()
+        return self.losses
+
+
+def build_models(D=256, H=4, G=96, K=32, S=6, MR=2, N=1024, img=224, patch=16, atten_drop=0.1, mlp_drop=0.5, n_ca=1,
+                 point_channels=3, device="cuda"):
+    """utils.py:119-149 (build_model, --mp branch) with the architecture flags spelled out."""
+    from .model.pointcloud import CrossFormer_img_mp, CrossFormer_pc_mp, PointCloudInputAdapter
+    adapter = PointCloudInputAdapter(pointcloud_shape=(N, point_channels), num_input_channels=D)
+    pc = CrossFormer_pc_mp(input_adapter=adapter, num_latents=G, num_latent_channels=D, group_size=K,
+                           num_cross_attention_layers=n_ca, num_cross_attention_heads=H, num_self_attention_layers=S,
+                           num_self_attention_heads=H, mlp_widen_factor=MR, max_dpr=0.0, atten_drop=atten_drop,
+                           mlp_drop=mlp_drop, modal_prior=True)
+    im = CrossFormer_img_mp(img_height=img, img_width=img, patch_size=patch, num_latent_channels=D,
+                            num_cross_attention_layers=n_ca, num_cross_attention_heads=H, num_self_attention_layers=S,
+                            num_self_attention_heads=H, mlp_widen_factor=MR, max_dpr=0.0, atten_drop=atten_drop,
+                            mlp_drop=mlp_drop, modal_prior=True)
+    return pc.to(device), im.to(device)
