@@ -76,6 +76,140 @@ int vpf_knn_group_f32(const float* xyz, int B, int N, int C, const float* center
                       int K, int apply_ref_axis_quirk, int64_t* knn_idx, float* knn_dist,
                       float* neighbors, void* stream);
 
+
+/* ------------------------------------------------------------------ bf16 MFMA GEMM family
+ * C[m,n] (+)= sum_k A(m,k) * B(n,k), bf16 operands, fp32 accumulate (v_mfma_f32_32x32x16_bf16).
+ * Replaces every aten linear / conv1d(k=1) / mm of the path and its autograd backward:
+ * q/k/v/o projections partseg.py:48-51,67-69,86; MLP partseg.py:191-198; Group2Emb convs
+ * utils.py:153-165; adapter / position / patch linears classifier.py:35, partseg.py:500,633;
+ * latent_head partseg.py:522,524.
+ *   a_kstrided / b_kstrided: 0 = operand stored [rows][K] (K contiguous); 1 = stored [K][rows]
+ *     (forward: 0,0 with B = W[N,K];  dgrad dX = dY W: A = dY (0), B = W (1);
+ *      wgrad dW = dY^T X: A = dY (1), B = X (1), mode VPF_EPI_ATOMIC, split over K = tokens).
+ *   contiguous dimension of each operand and lda/ldb must be multiples of 8, bases 16-byte aligned.
+ *   batch > 1: blockIdx.z strides sAb/sBb/sCb (elements).  splitk: 0 = auto (atomic mode only).
+ *   mode (epilogue): 0 store (+bias) | 1 bias+GELU, C2 = pre-activation (bf16) | 2 C(f32) = res +
+ *     dropout(acc+bias) keyed by (rng_state, site, m*N+n) | 3 C = acc * gelu'(aux) | 4 C(f32) += acc
+ *     (atomics) | 5 bias+ReLU | 6 acc + gbias[(m/group)*N + n].
+ *   dbias (nullable; wgrad only): dbias[m] += sum_k A(m,k), the bias gradient, fused into the same pass. */
+#define VPF_EPI_STORE 0
+#define VPF_EPI_GELU 1
+#define VPF_EPI_DROP_RES 2
+#define VPF_EPI_GELU_BWD 3
+#define VPF_EPI_ATOMIC 4
+#define VPF_EPI_RELU 5
+#define VPF_EPI_GROUPBIAS 6
+int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void* B, int b_kstrided, long ldb,
+                  int M, int N, int K, int batch, long sAb, long sBb, long sCb,
+                  void* C, long ldc, int c_is_f32, int mode, const float* bias,
+                  void* C2, long ldc2, const float* res, long ldres, const void* aux, long ldaux,
+                  const float* gbias, int group, const uint32_t* rng_state, uint32_t site, float p,
+                  int splitk, float* dbias, void* stream);
+
+/* ------------------------------------------------------------------ fused attention (head dim 64)
+ * MultiHeadAttention.forward partseg.py:67-86: softmax(q k^T * scale) -> dropout(p) -> . v, without the
+ * [b*h, Lq, Lkv] matrix in HBM.  q/k/v/out are bf16 [B, L, H*64] views with row strides ld* (elements),
+ * head h at column h*64 (so column slices of a fused [M,3D] projection buffer are valid operands).
+ * lse f32 [B,H,Lq] = log-sum-exp of the scaled scores.  Dropout keep decisions are a pure function of
+ * (rng_state, site, (b*H+h, q, kv)); backward regenerates them. */
+int vpf_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, int B, int H,
+                      int Lq, int Lkv, int head_dim, float scale, float dropout_p, const uint32_t* rng_state,
+                      uint32_t site, void* out, long ldo, float* lse, void* stream);
+/* autograd backward of the above: dq/dk/dv bf16, same layouts.  delta_ws: f32 workspace [B*H*Lq]. */
+int vpf_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* out,
+                      long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
+                      int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                      void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm / dropout / residual
+ * nn.LayerNorm of CrossAttention.q_norm/kv_norm, SelfAttention.norm, MLP[0] (partseg.py:100-101,
+ * 131,193), eps 1e-5.  y(bf16) = LN(x [+ pos[row % pos_rows]]); xsum (nullable) receives x + pos (the
+ * residual base of partseg.py:326,335); mean/rstd f32 [rows] are kept for backward.  D <= 512. */
+int vpf_layernorm_fwd(const void* x, int x_is_bf16, const float* pos, int pos_rows, const float* gamma,
+                      const float* beta, void* y_bf16, float* xsum, float* mean, float* rstd, long rows, int D,
+                      float eps, void* stream);
+/* dx = (dres ? dres : 0) + LN'(dy); dgamma/dbeta += (fp32).  ws (nullable, >= 2*1024*D floats): per-block
+ * partial sums instead of contended atomics. */
+int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf16, const float* mean, const float* rstd,
+                      const float* gamma, const float* dres, void* dx, int dx_is_bf16, float* dgamma, float* dbeta,
+                      float* ws, long ws_floats, long rows, int D, void* stream);
+/* Residual.forward partseg.py:208-212: out = res + dropout(y) (generic path; the attention / MLP blocks
+ * fuse this into the producing GEMM, mode 2). */
+int vpf_dropout_add_fwd(const void* y_bf16, const float* res, float* out, long n, const uint32_t* rng_state,
+                        uint32_t site, float p, void* stream);
+int vpf_dropout_bwd(const float* dout, void* dy_bf16, long n, const uint32_t* rng_state, uint32_t site, float p,
+                    void* stream);
+/* the keep mask (1/0 bytes) the kernels use for `site` at the current state (test hook) */
+int vpf_dropout_mask(uint8_t* out, long n, const uint32_t* rng_state, uint32_t site, float p, void* stream);
+/* rng_state = {seed_lo, seed_hi, step, 0}: step += 1 on the device (fresh masks per hipGraph replay) */
+int vpf_rng_advance(uint32_t* rng_state, void* stream);
+int vpf_cast_f32_bf16(const float* x, void* y_bf16, long n, void* stream);
+int vpf_cast_bf16_f32(const void* x_bf16, float* y, long n, void* stream);
+/* acc[c] += sum_m x[m,c]; acc2[c] += sum_m x^2 (nullable): bias gradients and BatchNorm statistics */
+int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* acc, float* acc2, void* stream);
+int vpf_axpy_f32(const float* x, float* y, long n, float a, void* stream);
+/* acc[r % period, :] += x[r, :]: gradient of CrossFormer_img_mp.position_emb [1,T,D] (partseg.py:637) */
+int vpf_rowsum_mod_f32(const float* x, long rows, int D, int period, float* acc, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm1d (channels-last [M,C])
+ * utils.py:156,163 and partseg.py:520,523, momentum 0.1, eps 1e-5.  stat = [mean(C) | rstd(C)]:
+ * training -> from batch sums (vpf_colsum), updates running_mean/var (unbiased) and num_batches_tracked;
+ * eval -> from the running statistics. */
+int vpf_bn_finalize(const float* sums, const float* sumsq, long M, int C, float eps, float momentum, int training,
+                    float* running_mean, float* running_var, long long* num_batches, float* stat, void* stream);
+int vpf_bn_act_fwd(const void* x, int x_is_bf16, const float* stat, const float* gamma, const float* beta, void* y,
+                   int y_is_bf16, long M, int C, int relu, void* stream);
+/* dx (nullable) = BN'(relu'(dy)); dgamma/dbeta +=.  tmp2C_zeroed: f32 [2C] scratch, zero on entry. */
+int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* stat, const float* gamma,
+               const float* beta, long M, int C, int relu, int training, float* tmp2C_zeroed, void* dx, int dx_is_bf16,
+               float* dgamma, float* dbeta, void* stream);
+
+/* ------------------------------------------------------------------ Group2Emb pieces (utils.py:168-189)
+ * first conv (C->64) + BatchNorm(64) + ReLU without materialising the conv output: statistics pass,
+ * apply pass (out bf16 [M,64]), two-pass backward (weight/bias/BN-affine gradients; the input needs none). */
+int vpf_g2e_conv1_stats(const float* x, long M, int C, const float* W, const float* b, float* sums, float* sumsq, void* stream);
+int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
+                        const float* beta, void* out_bf16, void* stream);
+int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
+                      const float* gamma, const float* beta, int training, float* tmp128_zeroed, float* dW, float* db,
+                      float* dgamma, float* dbeta, void* stream);
+/* torch.max over the K group members (utils.py:180,188): h bf16 [NG,K,C] -> out [NG,C], arg uint8 (first max) */
+int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream);
+int vpf_group_max_bwd(const void* dout, int dout_is_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream);
+/* torch.cat([global.expand, local]) (utils.py:183) and its backward */
+int vpf_g2e_concat_fwd(const void* gmax_bf16, const void* h_bf16, long M, int K, int C, void* feat_bf16, void* stream);
+int vpf_g2e_concat_bwd(const void* dfeat_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream);
+
+/* ------------------------------------------------------------------ K=3 front-ends, patchify, pooling
+ * PointCloudInputAdapter.point_mlp[0:3] (classifier.py:31-34): Linear(C,64) LayerNorm(64) ReLU -> bf16 [M,64] */
+int vpf_adapter_front_fwd(const float* x, long M, int C, const float* W, const float* b, const float* gamma,
+                          const float* beta, void* out_bf16, void* stream);
+int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b,
+                          const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta, void* stream);
+/* y = act(x W^T + b), x f32 [M,C<=8] -> bf16 [M,N]; act 1 = GELU(erf): position_emb[0:2] (partseg.py:498-500) */
+int vpf_smallk_fwd(const float* x, long M, int C, const float* W, const float* b, int N, int act, void* out_bf16, void* stream);
+int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C, const float* W, const float* b, int N, int act,
+                   float* dW, float* db, void* stream);
+/* Rearrange('b (h p1) (w p2) c -> b (h w) (p1 p2 c)') (partseg.py:632) on an arbitrary-stride [B,H,W,C] view
+ * (pretrain.py:179 hands a permuted NCHW tensor): out bf16 [B*T, p*p*C] */
+int vpf_patchify(const float* img, long sb, long sh, long sw, long sc, int B, int H, int W, int C, int p, void* out_bf16, void* stream);
+/* cat[x.max(1)[0], x.mean(1)] (partseg.py:547): x f32 [B,L,D] -> out f32 [B,2D], arg int32 [B,D] */
+int vpf_pool_fwd(const float* x, int B, int L, int D, float* out, int* arg, void* stream);
+int vpf_pool_bwd(const float* dout, const int* arg, int B, int L, int D, float* dx, void* stream);
+
+/* ------------------------------------------------------------------ loss and optimizer
+ * lightly==1.1.21 NTXentLoss(temperature, memory_bank_size=0) (pretrain.py:155,196,202; third party, absent
+ * from the reference tree): z0,z1 f32 [b,D]; workspaces zn [2b,D], inv_norm [2b], P [2b,2b], loss_rows [2b];
+ * loss = scalar.  bwd: dz0/dz1 from dloss (device scalar). */
+int vpf_ntxent_fwd(const float* z0, const float* z1, int b, int D, float temperature, float* zn, float* inv_norm, float* P,
+                   float* loss_rows, float* loss, void* stream);
+int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b, int D, float temperature, const float* dloss,
+                   float* dz0, float* dz1, void* stream);
+/* torch.optim.AdamW (pretrain.py:121-124,210) over a flat fp32 buffer, also rewriting the bf16 shadow the MFMA
+ * kernels read.  hyper_dev (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip}. */
+int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev,
+                   int advance_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

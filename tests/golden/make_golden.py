@@ -126,6 +126,15 @@ def main():
                             pc_named=[k for k, _ in pc.named_parameters()],
                             img_named=[k for k, _ in im.named_parameters()])
     json.dump(counts, open(os.path.join(HERE, "param_counts.json"), "w"))
+    # default-initialisation fingerprint: torch.manual_seed(1) (parser.py:17) then build_model order (utils.py:115-149)
+    init = {}
+    for name in ("tiny", "c1"):
+        a = Hh.ARCHS[name]
+        torch.manual_seed(1)
+        pc, im = build_ref(a)
+        init[name] = dict(pc={k: float(v.double().sum()) for k, v in pc.state_dict().items()},
+                          img={k: float(v.double().sum()) for k, v in im.state_dict().items()})
+    json.dump(init, open(os.path.join(HERE, "init_checksums.json"), "w"))
     print({k: (v["pc_params"], v["img_params"], v["pc_state"], v["img_state"]) for k, v in counts.items()})
 
     # ------------------------------------------------------------ FPS / sqdist / kNN / divide_patches

@@ -1,0 +1,177 @@
+"""CPU (no GPU): the C-ABI library loads and exports every declared symbol, the ctypes table matches
+the header, the mirrored modules reproduce the reference's state-dict keys / shapes / parameter counts /
+default initialisation, error behaviour, and the data-parallel gradient exchange over gloo (world size 2)."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from tests import helpers as Hh
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    hdr = open(os.path.join(ROOT, "include", "vipformer_hip.h")).read()
+    return {m.group(1): m.group(2) for m in re.finditer(r"\b(?:int|const char\*) (vpf_[a-z0-9_]+)\((.*?)\);", hdr, re.S)}
+
+
+def test_library_exports_every_declared_symbol():
+    from vipformer_amd import _lib, build
+    build.build(verbose=False)
+    lib = _lib.lib()
+    fns = _header_functions()
+    assert len(fns) >= 40
+    for name in fns:
+        assert hasattr(lib, name), f"{name} declared in include/vipformer_hip.h but not exported"
+    assert lib.vpf_version() >= 100
+    assert _lib.lib().vpf_strerror(-3).decode().startswith("unsupported")
+
+
+def test_ctypes_table_matches_header():
+    from vipformer_amd import _lib
+    fns = _header_functions()
+    kind = {_lib.VP: "p", _lib.I: "i", _lib.L_: "l", _lib.F: "f", _lib.U32: "u"}
+    for name, sig in _lib.SIGS.items():
+        params = [p.strip() for p in fns[name].replace("\n", " ").split(",")]
+        want = []
+        for p in params:
+            if "*" in p:
+                want.append("p")
+            else:
+                t = p.split()[1] if p.startswith("const") else p.split()[0]
+                want.append({"int": "i", "long": "l", "float": "f", "uint32_t": "u"}[t])
+        assert [kind[t] for t in sig] == want, name
+    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror"}
+
+
+def _build(name):
+    from vipformer_amd.train import build_models
+    a = Hh.ARCHS[name]
+    return build_models(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], N=a["N"], img=a["img"], patch=a["patch"],
+                        device="cpu")
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4"])
+def test_state_dict_keys_shapes_and_counts_match_reference(name):
+    pc, im = _build(name)
+    assert [(k, tuple(v.shape)) for k, v in pc.state_dict().items()] == Hh.load_keyshapes(f"keys_pc_{name}.json")
+    assert [(k, tuple(v.shape)) for k, v in im.state_dict().items()] == Hh.load_keyshapes(f"keys_img_{name}.json")
+    c = json.load(open(os.path.join(Hh.GOLDEN_DIR, "param_counts.json")))[name]
+    assert sum(p.numel() for p in pc.parameters()) == c["pc_params"]
+    assert sum(p.numel() for p in im.parameters()) == c["img_params"]
+    assert [k for k, _ in pc.named_parameters()] == c["pc_named"] and [k for k, _ in im.named_parameters()] == c["img_named"]
+    # cross_attn_1 IS cross_attn_n (partseg.py:297-298): one parameter set under two prefixes
+    assert pc.encoder.cross_attn_1 is pc.encoder.cross_attn_n
+    sd = pc.state_dict()
+    assert sd["encoder.cross_attn_1.0.module.q_norm.weight"].data_ptr() == sd["encoder.cross_attn_n.0.module.q_norm.weight"].data_ptr()
+    # reference checkpoints load strictly
+    pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 1), strict=True)
+    im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 2), strict=True)
+
+
+def test_paper_parameter_counts():
+    """assets/tab1.png / tab2.png: 5.1 M (E1CL8SL-H4D256-L128-MR2) and 16.7 M (E1CL8SL-H6D384-L128-MR4)."""
+    assert sum(p.numel() for p in _build("c3")[0].parameters()) == 5127040
+    assert sum(p.numel() for p in _build("c4")[0].parameters()) == 16654336
+    assert sum(p.numel() for p in _build("c1")[0].parameters()) == 4074368
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1"])
+def test_default_initialisation_matches_reference_construction_order(name):
+    """Same seed -> same parameters as the reference's build_model (modules are created in the same order
+    with the same initialisers), so a run is reproducible against the reference from torch.manual_seed alone."""
+    ref = json.load(open(os.path.join(Hh.GOLDEN_DIR, "init_checksums.json")))[name]
+    torch.manual_seed(1)
+    pc, im = _build(name)
+    for model, want in ((pc, ref["pc"]), (im, ref["img"])):
+        got = {k: float(v.double().sum()) for k, v in model.state_dict().items()}
+        assert got.keys() == want.keys()
+        for k in want:
+            assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), k
+
+
+def test_error_behaviour_matches_reference_and_no_cpu_fallback():
+    from vipformer_amd import _lib
+    from vipformer_amd.model.pointcloud import partseg as P
+    from vipformer_amd.model.pointcloud import utils as U
+    with pytest.raises(ValueError):
+        P.MultiHeadAttention(3, 64, 64, 64)                       # partseg.py:39-40
+    with pytest.raises(ValueError):
+        P.Encoder(64, num_cross_attention_layers=0, dpr_list=[0.0] * 6)   # partseg.py:279-280
+    mha = P.MultiHeadAttention(1, 64, 64, 64)
+    x = torch.zeros(1, 4, 64)
+    with pytest.raises(NotImplementedError):
+        mha(x, x, attn_mask=torch.zeros(1))                       # partseg.py:64-65
+    with pytest.raises(_lib.VpfError):
+        mha(x, x)                                                 # CPU tensors: there is no eager fallback
+    with pytest.raises(_lib.VpfError):
+        U.divide_patches(torch.zeros(1, 64, 3), 4, 4)
+    with pytest.raises(_lib.VpfError):
+        U.Group2Emb(64)(torch.zeros(1, 2, 4, 3))
+
+
+def test_install_as_vipformer_aliases():
+    import sys
+    import vipformer_amd
+    saved = {k: v for k, v in sys.modules.items() if k == "vipformer" or k.startswith("vipformer.")}
+    try:
+        vipformer_amd.install_as_vipformer()
+        from vipformer.model.pointcloud import CrossFormer_img_mp, CrossFormer_pc_mp, PointCloudInputAdapter  # noqa: F401
+        from vipformer.model.pointcloud.utils import Group2Emb, divide_patches, farthest_point_sample, knn_point  # noqa: F401
+        from vipformer.preproc import fps  # noqa: F401
+        assert CrossFormer_pc_mp.__module__.startswith("vipformer_amd")
+    finally:
+        for k in [k for k in sys.modules if k == "vipformer" or k.startswith("vipformer.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+# ------------------------------------------------------------------------------------------ data parallel over gloo
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from oracle import torch_oracle as O
+    from vipformer_amd.train import Pretrainer
+    dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+
+    class Flat:          # the flat buffers Pretrainer.allreduce_gradients works on (CPU stand-in)
+        pass
+    tr = Pretrainer.__new__(Pretrainer)
+    tr.world, tr.group, tr.flat = world, None, Flat()
+    n = 1000
+    g = torch.Generator().manual_seed(10 + rank)
+    tr.flat.g = torch.randn(n, generator=g)
+    mine = tr.flat.g.clone()
+    tr.allreduce_gradients()                                     # the step's single collective
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    ok_sum = torch.allclose(tr.flat.g, sum(gathered), atol=1e-6)
+    # AdamW with grad_scale = 1/world on the SUM == AdamW on the mean of the per-rank gradients
+    p0 = torch.linspace(-1, 1, n)
+    pa, pb = {"w": p0.clone()}, {"w": p0.clone()}
+    O.adamw_step(pa, {"w": tr.flat.g / world}, {}, 1)
+    O.adamw_step(pb, {"w": sum(gathered) / world}, {}, 1)
+    ok_step = torch.equal(pa["w"], pb["w"])
+    # every rank ends with identical parameters
+    allp = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(allp, pa["w"])
+    ok_same = all(torch.equal(allp[0], t) for t in allp)
+    q.put((rank, ok_sum, ok_step, ok_same))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[0] for r in res) == [0, 1]
+    assert all(r[1] and r[2] and r[3] for r in res), res

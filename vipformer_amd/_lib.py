@@ -67,11 +67,11 @@ SIGS = {
     "vpf_index_points_f32": [VP, I, I, I, VP, I, VP, VP],
     "vpf_square_distance_f32": [VP, I, VP, I, I, I, I, VP, VP],
     "vpf_knn_group_f32": [VP, I, I, I, VP, I, I, I, I, VP, VP, VP, VP],
-    "vpf_gemm_bf16": [VP, I, L_, VP, I, L_, I, I, I, I, L_, L_, L_, VP, L_, I, I, VP, VP, L_, VP, L_, VP, L_, VP, I, VP, U32, F, I, VP],
+    "vpf_gemm_bf16": [VP, I, L_, VP, I, L_, I, I, I, I, L_, L_, L_, VP, L_, I, I, VP, VP, L_, VP, L_, VP, L_, VP, I, VP, U32, F, I, VP, VP],
     "vpf_cast_f32_bf16": [VP, VP, L_, VP],
     "vpf_cast_bf16_f32": [VP, VP, L_, VP],
     "vpf_layernorm_fwd": [VP, I, VP, I, VP, VP, VP, VP, VP, VP, L_, I, F, VP],
-    "vpf_layernorm_bwd": [VP, VP, I, VP, VP, VP, VP, VP, I, VP, VP, L_, I, VP],
+    "vpf_layernorm_bwd": [VP, VP, I, VP, VP, VP, VP, VP, I, VP, VP, VP, L_, L_, I, VP],
     "vpf_dropout_add_fwd": [VP, VP, VP, L_, VP, U32, F, VP],
     "vpf_dropout_bwd": [VP, VP, L_, VP, U32, F, VP],
     "vpf_dropout_mask": [VP, L_, VP, U32, F, VP],

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const bf16_t* __rest
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ dres,
                                                           TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                          long rows, int D)
+                                                          float* __restrict__ ws, long rows, int D)
 {
     __shared__ float red[2][4][64 * LN_MAXI];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -161,26 +161,44 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const bf16_t* __rest
     for (int c = threadIdx.x; c < D; c += 256) {
         const float a = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float b = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b);
+        if (ws) {   // per-block partials, folded by layernorm_bwd_finish_kernel (no contended atomics)
+            ws[(size_t)blockIdx.x * D + c] = a;
+            ws[((size_t)gridDim.x + blockIdx.x) * D + c] = b;
+        } else { atomicAdd(dgamma + c, a); atomicAdd(dbeta + c, b); }
     }
+}
+__global__ void layernorm_bwd_finish_kernel(const float* __restrict__ ws, int nblk, int D, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;      // column in [0, 2D)
+    if (c >= 2 * D) return;
+    const int which = c / D, cc = c % D;
+    const int per = (nblk + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(nblk, r0 + per);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += ws[((size_t)which * nblk + r) * D + cc];
+    atomicAdd((which ? dbeta : dgamma) + cc, s);
 }
 extern "C" int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf16, const float* mean, const float* rstd,
                                  const float* gamma, const float* dres, void* dx, int dx_is_bf16, float* dgamma, float* dbeta,
-                                 long rows, int D, void* stream)
+                                 float* ws, long ws_floats, long rows, int D, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return VPF_ERR_NULL;
     if (rows < 0 || D <= 0 || D > 64 * LN_MAXI) return VPF_ERR_BADSHAPE;
     if (rows == 0) return VPF_OK;
-    const int grid = grid_for(rows, 16, 1024);
+    int grid = grid_for(rows, 16, 1024);
     hipStream_t st = (hipStream_t)stream;
+    // workspace of 2 * grid * D floats -> per-block partial sums + a finishing pass; without it: fp32 atomics
+    float* wsp = (ws && ws_floats >= 2L * grid * D && grid > 8) ? ws : nullptr;
+    if (!wsp && grid > 64) grid = 64;            // atomic fallback: keep the contention on the 2D addresses low
 #define LNB(TX, TDX) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDX>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy_bf16, (const TX*)x, \
-                                        mean, rstd, gamma, dres, (TDX*)dx, dgamma, dbeta, rows, D)
+                                        mean, rstd, gamma, dres, (TDX*)dx, dgamma, dbeta, wsp, rows, D)
     if (x_is_bf16 && dx_is_bf16) LNB(bf16_t, bf16_t);
     else if (x_is_bf16) LNB(bf16_t, float);
     else if (dx_is_bf16) LNB(float, bf16_t);
     else LNB(float, float);
 #undef LNB
+    if (wsp) hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(vpf_cdiv(2 * D, 256), 32), dim3(256), 0, st, wsp, grid, D, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

@@ -22,7 +22,6 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-#define GEMM_BK 32
 #define LDS_PAD 8   // bf16 elements (16 B) of row padding
 
 enum {
@@ -49,6 +48,7 @@ struct GemmArgs {
     const bf16_t* aux; long ldaux;     // EPI_GELU_BWD: u
     const float* gbias; int group;     // EPI_GROUPBIAS
     const uint32_t* rng; uint32_t site; float p;   // dropout
+    float* dbias;                                   // EPI_ATOMIC with a k-strided A: dbias[m] += sum_k A(m,k)
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -61,26 +61,26 @@ __device__ __forceinline__ float gelu_grad_f(float x)
 
 // ------------------------------------------------------------------ tile staging
 // K-major operand tile: LDS [ROWS][BK + pad]; K-strided operand tile: LDS [BK][ROWS + pad].
-template <int ROWS, bool TR>
+template <int ROWS, bool TR, int BK>
 struct TileCfg {
-    static constexpr int LD = TR ? (ROWS + LDS_PAD) : (GEMM_BK + LDS_PAD);
-    static constexpr int ELEMS = TR ? GEMM_BK * LD : ROWS * LD;
-    static constexpr int CHUNKS = ROWS * GEMM_BK / 8;          // 16-byte chunks per tile
+    static constexpr int LD = TR ? (ROWS + LDS_PAD) : (BK + LDS_PAD);
+    static constexpr int ELEMS = TR ? BK * LD : ROWS * LD;
+    static constexpr int CHUNKS = ROWS * BK / 8;          // 16-byte chunks per tile
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
 };
 
-template <int ROWS, bool TR>
+template <int ROWS, bool TR, int BK>
 __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld, int R, int K, int r0, int k0, int kend,
-                                          uint4 (&regs)[TileCfg<ROWS, TR>::PER_THREAD])
+                                          uint4 (&regs)[TileCfg<ROWS, TR, BK>::PER_THREAD])
 {
-    using Cfg = TileCfg<ROWS, TR>;
+    using Cfg = TileCfg<ROWS, TR, BK>;
 #pragma unroll
     for (int i = 0; i < Cfg::PER_THREAD; ++i) {
         const int c = threadIdx.x + i * 256;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (c < Cfg::CHUNKS) {
             if (!TR) {
-                const int row = c / (GEMM_BK / 8), kc = c % (GEMM_BK / 8);
+                const int row = c / (BK / 8), kc = c % (BK / 8);
                 const int gr = r0 + row, gk = k0 + kc * 8;
                 if (gr < R && gk < kend) v = *reinterpret_cast<const uint4*>(G + (size_t)gr * ld + gk);
             } else {
@@ -93,27 +93,27 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld,
     }
 }
 
-template <int ROWS, bool TR>
-__device__ __forceinline__ void tile_store(bf16_t* __restrict__ S, const uint4 (&regs)[TileCfg<ROWS, TR>::PER_THREAD])
+template <int ROWS, bool TR, int BK>
+__device__ __forceinline__ void tile_store(bf16_t* __restrict__ S, const uint4 (&regs)[TileCfg<ROWS, TR, BK>::PER_THREAD])
 {
-    using Cfg = TileCfg<ROWS, TR>;
+    using Cfg = TileCfg<ROWS, TR, BK>;
 #pragma unroll
     for (int i = 0; i < Cfg::PER_THREAD; ++i) {
         const int c = threadIdx.x + i * 256;
         if (c < Cfg::CHUNKS) {
             int off;
-            if (!TR) { const int row = c / (GEMM_BK / 8), kc = c % (GEMM_BK / 8); off = row * Cfg::LD + kc * 8; }
+            if (!TR) { const int row = c / (BK / 8), kc = c % (BK / 8); off = row * Cfg::LD + kc * 8; }
             else { const int krow = c / (ROWS / 8), rc = c % (ROWS / 8); off = krow * Cfg::LD + rc * 8; }
             *reinterpret_cast<uint4*>(S + off) = regs[i];
         }
     }
 }
 
-// fragment for one 32x32x16 MFMA: rows [row0, row0+32), k-step s (16 wide) of the BK=32 tile
-template <int ROWS, bool TR>
+// fragment for one 32x32x16 MFMA: rows [row0, row0+32), k-step s (16 wide) of the BK-deep tile
+template <int ROWS, bool TR, int BK>
 __device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int row0, int s)
 {
-    using Cfg = TileCfg<ROWS, TR>;
+    using Cfg = TileCfg<ROWS, TR, BK>;
     const int lane = threadIdx.x & 63;
     if (!TR) {
         const int r = lane & 31, h = lane >> 5;
@@ -136,13 +136,13 @@ __device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int 
 }
 
 // ------------------------------------------------------------------ kernel
-template <int TM, int TN, int WM, int WN, bool ATR, bool BTR>
+template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    using ACfg = TileCfg<BM, ATR>;
-    using BCfg = TileCfg<BN, BTR>;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (ACfg::ELEMS + BCfg::ELEMS)];
+    using ACfg = TileCfg<BM, ATR, BK>;
+    using BCfg = TileCfg<BN, BTR, BK>;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];      // 2 * (ACfg::ELEMS + BCfg::ELEMS)
     constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
     const bf16_t* A = g.A; const bf16_t* B = g.B;
     long cb = 0;
     if (g.splitk > 1) {
-        const int per = ((g.K + g.splitk - 1) / g.splitk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
+        const int per = ((g.K + g.splitk - 1) / g.splitk + BK - 1) / BK * BK;
         kbeg = blockIdx.z * per; kend = min(g.K, kbeg + per);
         if (kbeg >= kend) return;
     } else {
@@ -169,13 +169,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     uint4 ra[ACfg::PER_THREAD], rb[BCfg::PER_THREAD];
-    tile_load<BM, ATR>(A, g.lda, g.M, g.K, m0, kbeg, kend, ra);
-    tile_load<BN, BTR>(B, g.ldb, g.N, g.K, n0, kbeg, kend, rb);
-    tile_store<BM, ATR>(lds, ra);
-    tile_store<BN, BTR>(lds + ACfg::ELEMS, rb);
+    tile_load<BM, ATR, BK>(A, g.lda, g.M, g.K, m0, kbeg, kend, ra);
+    tile_load<BN, BTR, BK>(B, g.ldb, g.N, g.K, n0, kbeg, kend, rb);
+    tile_store<BM, ATR, BK>(lds, ra);
+    tile_store<BN, BTR, BK>(lds + ACfg::ELEMS, rb);
     __syncthreads();
 
-    const int nk = (kend - kbeg + GEMM_BK - 1) / GEMM_BK;
+    // fused bias gradient (wgrad): the first column of workgroups also sums its dY tiles over the tokens
+    const bool do_bias = ATR && g.dbias != nullptr && blockIdx.x == 0;
+    float bsum = 0.f;
+    const int nk = (kend - kbeg + BK - 1) / BK;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bf16_t* cA = lds + cur * STAGE;
@@ -183,16 +186,22 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
         bf16_t* nA = lds + (cur ^ 1) * STAGE;
         bf16_t* nB = nA + ACfg::ELEMS;
         if (kt + 1 < nk) {
-            tile_load<BM, ATR>(A, g.lda, g.M, g.K, m0, kbeg + (kt + 1) * GEMM_BK, kend, ra);
-            tile_load<BN, BTR>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + 1) * GEMM_BK, kend, rb);
+            tile_load<BM, ATR, BK>(A, g.lda, g.M, g.K, m0, kbeg + (kt + 1) * BK, kend, ra);
+            tile_load<BN, BTR, BK>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + 1) * BK, kend, rb);
+        }
+        if (ATR && do_bias) {
+            constexpr int RG = 256 / BM > 0 ? 256 / BM : 1;                 // row groups (BM <= 256)
+            const int c = threadIdx.x % BM, rg = threadIdx.x / BM;
+            if (rg < RG)
+                for (int r = rg; r < BK; r += RG) bsum += bf16_to_f32(cA[r * ACfg::LD + c]);
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < BK / 16; ++s) {
             bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR>(cA, (wm * TM + i) * 32, s);
+            for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, s);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR>(cB, (wn * TN + j) * 32, s);
+            for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR, BK>(cB, (wn * TN + j) * 32, s);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -200,8 +209,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            tile_store<BM, ATR>(nA, ra);
-            tile_store<BN, BTR>(nB, rb);
+            tile_store<BM, ATR, BK>(nA, ra);
+            tile_store<BN, BTR, BK>(nB, rb);
         }
         __syncthreads();
     }
@@ -209,6 +218,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
     // ---------------------------------------------------------------- epilogue
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+    if (ATR && do_bias) {
+        const int c = threadIdx.x % BM;
+        if (threadIdx.x / BM < (256 / BM > 0 ? 256 / BM : 1) && m0 + c < g.M) atomicAdd(g.dbias + m0 + c, bsum);
+    }
     if (g.mode == EPI_ATOMIC) {
         // split-K partial sums: fp32 atomics straight from the accumulators (128-byte row segments)
 #pragma unroll
@@ -303,17 +316,30 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
     }
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR>
+static int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, ATR, BK>::ELEMS + TileCfg<BN, BTR, BK>::ELEMS);
+    static bool attr = false;
+    if (!attr) {
+        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR>), grid, dim3(256), lds, st, g);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+template <int TM, int TN, int WM, int WN, int BK>
 static int launch_cfg(const GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     dim3 grid(vpf_cdiv(g.N, BN), vpf_cdiv(g.M, BM), g.splitk > 1 ? g.splitk : batch);
-    if (!a_tr && !b_tr) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, false, false>), grid, dim3(256), 0, st, g);
-    else if (!a_tr && b_tr) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, false, true>), grid, dim3(256), 0, st, g);
-    else if (a_tr && !b_tr) hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, true, false>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, true, true>), grid, dim3(256), 0, st, g);
-    VPF_CHECK_LAUNCH();
-    return VPF_OK;
+    if (!a_tr && !b_tr) return launch_one<TM, TN, WM, WN, BK, false, false>(g, grid, st);
+    if (!a_tr && b_tr) return launch_one<TM, TN, WM, WN, BK, false, true>(g, grid, st);
+    if (a_tr && !b_tr) return launch_one<TM, TN, WM, WN, BK, true, false>(g, grid, st);
+    return launch_one<TM, TN, WM, WN, BK, true, true>(g, grid, st);
 }
 
 static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t st)
@@ -330,20 +356,20 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
             // fill ~512 workgroups of 64x64 tiles
             const long tiles = (long)vpf_cdiv(g.M, 64) * vpf_cdiv(g.N, 64);
             long s = 512 / (tiles > 0 ? tiles : 1);
-            const long maxs = vpf_cdiv(g.K, 4 * GEMM_BK);
+            const long maxs = vpf_cdiv(g.K, 256);
             if (s > maxs) s = maxs;
             if (s < 1) s = 1;
             g.splitk = (int)s;
         }
         if (g.splitk == 1) g.splitk = 0, batch = 1;
         if (batch != 1 && g.splitk > 1) return VPF_ERR_UNSUPPORTED;
-        return launch_cfg<1, 1, 2, 2>(g, a_tr, b_tr, batch, st);
+        return launch_cfg<1, 1, 2, 2, 128>(g, a_tr, b_tr, batch, st);
     }
     g.splitk = 0;
     const long wg_128x64 = (long)vpf_cdiv(g.M, 128) * vpf_cdiv(g.N, 64) * batch;
-    if (wg_128x64 >= 2048 && g.N >= 128) return launch_cfg<2, 2, 2, 2>(g, a_tr, b_tr, batch, st);   // 128x128
-    if (wg_128x64 >= 512) return launch_cfg<1, 2, 4, 1>(g, a_tr, b_tr, batch, st);                   // 128x64
-    return launch_cfg<1, 1, 2, 2>(g, a_tr, b_tr, batch, st);                                         // 64x64
+    if (wg_128x64 >= 2048 && g.N >= 128) return launch_cfg<2, 2, 2, 2, 64>(g, a_tr, b_tr, batch, st);   // 128x128
+    if (wg_128x64 >= 512) return launch_cfg<1, 2, 4, 1, 64>(g, a_tr, b_tr, batch, st);                   // 128x64
+    return launch_cfg<1, 1, 2, 2, 128>(g, a_tr, b_tr, batch, st);                                        // 64x64
 }
 
 // ------------------------------------------------------------------ C ABI
@@ -352,7 +378,7 @@ extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void
                              void* C, long ldc, int c_is_f32, int mode, const float* bias,
                              void* C2, long ldc2, const float* res, long ldres, const void* aux, long ldaux,
                              const float* gbias, int group, const uint32_t* rng_state, uint32_t site, float p,
-                             int splitk, void* stream)
+                             int splitk, float* dbias, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     GemmArgs g;
@@ -360,7 +386,8 @@ extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void
     g.sAb = sAb; g.sBb = sBb; g.sCb = sCb; g.M = M; g.N = N; g.K = K; g.splitk = splitk; g.mode = mode;
     g.C = C; g.ldc = ldc; g.c_f32 = c_is_f32; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16_t*)aux; g.ldaux = ldaux; g.gbias = gbias; g.group = group > 0 ? group : 1;
-    g.rng = rng_state; g.site = site; g.p = p;
+    g.rng = rng_state; g.site = site; g.p = p; g.dbias = dbias;
+    if (dbias && !(mode == EPI_ATOMIC && a_kstrided)) return VPF_ERR_UNSUPPORTED;
     if (mode < 0 || mode > EPI_GROUPBIAS) return VPF_ERR_UNSUPPORTED;
     if (mode == EPI_GELU && !C2) return VPF_ERR_NULL;
     if (mode == EPI_DROP_RES && (!res || !rng_state || !c_is_f32)) return VPF_ERR_NULL;

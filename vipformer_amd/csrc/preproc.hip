@@ -197,7 +197,19 @@ __global__ void __launch_bounds__(256) knn_group_kernel(const float* __restrict_
     float* sy = sx + N;
     float* sz = sy + N;
     float* sn = sz + N;
-    const int b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so the
+    // parts of ONE cloud are given to block ids that are congruent mod 8 -> one L2 fetches the cloud once.
+    // (placement is a speed matter only: any mapping is correct.)
+    const int parts = gridDim.x, nclouds = gridDim.y;
+    int b, part;
+    {
+        const int L = blockIdx.y * parts + blockIdx.x;                 // linear id
+        const int full = (nclouds / 8) * 8;                            // clouds covered by complete groups of 8
+        const int slot = L / 8, xcd = L % 8;
+        if (L < full * parts) { b = (slot / parts) * 8 + xcd; part = slot % parts; }
+        else { const int r = L - full * parts; b = full + r / parts; part = r % parts; }
+    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* p = xyz + (size_t)b * N * C;
     for (int i = t; i < N; i += 256) {
         const float x = p[(size_t)i * C + 0], y = p[(size_t)i * C + 1], z = p[(size_t)i * C + 2];
@@ -205,7 +217,7 @@ __global__ void __launch_bounds__(256) knn_group_kernel(const float* __restrict_
     }
     __syncthreads();
 
-    const int g0 = blockIdx.x * centres_per_wg;
+    const int g0 = part * centres_per_wg;
     const int g1 = min(G, g0 + centres_per_wg);
     for (int g = g0 + wave; g < g1; g += 4) {
         const float* c = centers + ((size_t)b * G + g) * Cc;

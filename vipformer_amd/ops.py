@@ -177,10 +177,10 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(A, a_tr, lda, Bm, b_tr, ldb, M, N, K, C, ldc, *, c_f32, mode=EPI_STORE, bias=None, C2=None, ldc2=0, res=None,
-         ldres=0, aux=None, ldaux=0, gbias=None, group=1, site=0, p=0.0, splitk=0, batch=1, sAb=0, sBb=0, sCb=0):
+         ldres=0, aux=None, ldaux=0, gbias=None, group=1, site=0, p=0.0, splitk=0, batch=1, sAb=0, sBb=0, sCb=0, dbias=None):
     st = rng.state(C.device) if mode == EPI_DROP_RES else None
     L.call("vpf_gemm_bf16", A, int(a_tr), lda, Bm, int(b_tr), ldb, M, N, K, batch, sAb, sBb, sCb, C, ldc, int(c_f32), mode,
-           bias, C2, ldc2, res, ldres, aux, ldaux, gbias, group, st, site, float(p), splitk)
+           bias, C2, ldc2, res, ldres, aux, ldaux, gbias, group, st, site, float(p), splitk, dbias)
 
 
 def linear_fwd(x16, w16, N, K, bias=None, *, out_f32=False, mode=EPI_STORE, **kw):
@@ -199,10 +199,11 @@ def linear_dgrad(dy16, w16, N, K, *, out_f32=False, mode=EPI_STORE, **kw):
     return dx
 
 
-def linear_wgrad(dy16, x16, N, K, dW):
-    """dW[N,K] += dy16[M,N]^T @ x16[M,K]   (both operands k-strided, split over M, fp32 atomics)."""
+def linear_wgrad(dy16, x16, N, K, dW, dbias=None):
+    """dW[N,K] += dy16[M,N]^T @ x16[M,K]   (both operands k-strided, split over M, fp32 atomics);
+    dbias[N] += column sums of dy16 in the same pass."""
     M = dy16.numel() // N
-    gemm(dy16, 1, N, x16, 1, K, N, K, M, dW, K, c_f32=True, mode=EPI_ATOMIC)
+    gemm(dy16, 1, N, x16, 1, K, N, K, M, dW, K, c_f32=True, mode=EPI_ATOMIC, dbias=dbias)
 
 
 def colsum(x, C, acc, acc2=None):
@@ -226,8 +227,9 @@ def layernorm_bwd(dy16, x, mean, rstd, gamma_p, beta_p, dres=None, out_bf16=Fals
     D = x.shape[-1]
     rows = x.numel() // D
     dx = torch.empty(x.shape, dtype=BF16 if out_bf16 else F32, device=x.device)
+    ws = torch.empty(2 * 1024 * D, dtype=F32, device=x.device)      # per-block dgamma/dbeta partials
     L.call("vpf_layernorm_bwd", dy16, x, int(x.dtype == BF16), mean, rstd, gamma_p.data, dres, dx, int(out_bf16),
-           grad_buf(gamma_p), grad_buf(beta_p), rows, D)
+           grad_buf(gamma_p), grad_buf(beta_p), ws, ws.numel(), rows, D)
     return dx
 
 
@@ -316,8 +318,7 @@ class AttnBlockFn(torch.autograd.Function):
             L.call("vpf_dropout_bwd", dout, dz, dout.numel(), rng.state(dev), cfg["site_res"], float(p_res))
         else:
             dz = to_bf16(dout).view(Mq, D)
-        colsum(dz, D, grad_buf(mod.o_proj.bias))
-        linear_wgrad(dz, o, D, D, grad_buf(mod.o_proj.weight))
+        linear_wgrad(dz, o, D, D, grad_buf(mod.o_proj.weight), grad_buf(mod.o_proj.bias))
         do = linear_dgrad(dz, shadow([mod.o_proj.weight]), D, D)
         qkvw = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
         w16 = shadow(qkvw)
@@ -415,11 +416,9 @@ class MLPBlockFn(torch.autograd.Function):
             L.call("vpf_dropout_bwd", dout, dz, dout.numel(), rng.state(x.device), cfg["site_res"], float(p_res))
         else:
             dz = to_bf16(dout).view(M, D)
-        colsum(dz, D, grad_buf(fc2.bias))
-        linear_wgrad(dz, h, D, Hd, grad_buf(fc2.weight))
+        linear_wgrad(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
         du = linear_dgrad(dz, shadow([fc2.weight]), D, Hd, mode=EPI_GELU_BWD, aux=u, ldaux=Hd)
-        colsum(du, Hd, grad_buf(fc1.bias))
-        linear_wgrad(du, n, Hd, D, grad_buf(fc1.weight))
+        linear_wgrad(du, n, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
         dn = linear_dgrad(du, shadow([fc1.weight]), Hd, D)
         dx = layernorm_bwd(dn, x, mean, rstd, ln.weight, ln.bias, dout if residual else None)
         return (dx.view_as(dout), None, None) + (None,) * ctx.nparams
@@ -530,17 +529,14 @@ class Group2EmbFn(torch.autograd.Function):
         dout = dout.contiguous().float()
         dh4 = torch.empty(M, Dm, dtype=BF16, device=dev)
         L.call("vpf_group_max_bwd", dout, 0, arg4, NG, K, Dm, dh4)
-        colsum(dh4, Dm, grad_buf(c4.bias))
-        linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight))
+        linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight), grad_buf(c4.bias))
         da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
         dh3 = _bn_bwd(da3, h3, 256, stat2, bn2, True, training, True)
-        colsum(dh3, 256, grad_buf(c3.bias))
-        linear_wgrad(dh3, feat, 256, 256, grad_buf(c3.weight))
+        linear_wgrad(dh3, feat, 256, 256, grad_buf(c3.weight), grad_buf(c3.bias))
         dfeat = linear_dgrad(dh3, shadow([c3.weight]), 256, 256)
         dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
         L.call("vpf_g2e_concat_bwd", dfeat, arg2, NG, K, 128, dh2)
-        colsum(dh2, 128, grad_buf(c2.bias))
-        linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight))
+        linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
         da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
         tmp = torch.zeros(128, dtype=F32, device=dev)
         L.call("vpf_g2e_conv1_bwd", x, da1, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
@@ -575,8 +571,7 @@ class AdapterFn(torch.autograd.Function):
         D = l3.weight.shape[0]
         M, C = x.shape
         dy16 = to_bf16(dy).view(M, D)
-        colsum(dy16, D, grad_buf(l3.bias))
-        linear_wgrad(dy16, a, D, 64, grad_buf(l3.weight))
+        linear_wgrad(dy16, a, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
         da = linear_dgrad(dy16, shadow([l3.weight]), D, 64)
         L.call("vpf_adapter_front_bwd", x, da, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data,
                grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias))
@@ -608,8 +603,7 @@ class PosMLPFn(torch.autograd.Function):
         Hd, D = l0.weight.shape[0], l2.weight.shape[0]
         M, C = x.shape
         dy16 = to_bf16(dy).view(M, D)
-        colsum(dy16, D, grad_buf(l2.bias))
-        linear_wgrad(dy16, g, D, Hd, grad_buf(l2.weight))
+        linear_wgrad(dy16, g, D, Hd, grad_buf(l2.weight), grad_buf(l2.bias))
         dg = linear_dgrad(dy16, shadow([l2.weight]), D, Hd)
         L.call("vpf_smallk_bwd", x, dg, M, C, l0.weight.data, l0.bias.data, Hd, 1, grad_buf(l0.weight), grad_buf(l0.bias))
         return (None, None) + (None,) * ctx.nparams
@@ -642,8 +636,7 @@ class PatchEmbedFn(torch.autograd.Function):
         lin = ctx.lin
         D, pd = lin.weight.shape
         dy16 = to_bf16(dy).view(-1, D)
-        colsum(dy16, D, grad_buf(lin.bias))
-        linear_wgrad(dy16, patches, D, pd, grad_buf(lin.weight))
+        linear_wgrad(dy16, patches, D, pd, grad_buf(lin.weight), grad_buf(lin.bias))
         return (None, None, None) + (None,) * ctx.nparams
 
 
