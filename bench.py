@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the image branch on the same stream as the point-cloud branch")
     ap.add_argument("--pairs", type=int, default=PER_GPU_PAIRS, help="pairs per GPU (default = BASELINE configs[1])")
     args = ap.parse_args()
 
@@ -144,6 +145,7 @@ def main():
     pc, im = build_models(**ARCH, device=device)
     pc.train(); im.train()
     tr = Pretrainer(pc, im, world_size=world)
+    tr.overlap = not args.no_overlap
     tr.broadcast_parameters(0)
     torch.manual_seed(100 + rank)                          # FPS start indices differ per rank
     t1, t2, imgs = synth_batch(args.pairs, ARCH["N"], ARCH["img"], seed=rank, device=device)
@@ -191,7 +193,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "E1CL6SL-H4D256-L96-MR2, per-GPU batch %d pairs (2x1024-pt clouds + 224x224 img, patch 16), "
                                    "fwd+bwd+AdamW, NT-Xent IMC+CMC, dropout 0.1/0.5" % args.pairs,
-                       "global_batch": args.pairs * world, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                       "global_batch": args.pairs * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "two_stream_overlap": tr.overlap,
                        "last_losses": losses, "losses_finite": finite,
                        "step_tflops_algorithmic": round(value * GFLOP_PER_PAIR / 1e3, 2),
                        "step_mfma_frac": round(value * GFLOP_PER_PAIR / 1e3 / (PEAK_BF16_TFLOPS * world), 4),

@@ -168,6 +168,9 @@ int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, con
  * first conv (C->64) + BatchNorm(64) + ReLU without materialising the conv output: statistics pass,
  * apply pass (out bf16 [M,64]), two-pass backward (weight/bias/BN-affine gradients; the input needs none). */
 int vpf_g2e_conv1_stats(const float* x, long M, int C, const float* W, const float* b, float* sums, float* sumsq, void* stream);
+/* the same statistics from the C x C second-moment matrix of the inputs (h1 is affine in x): mom72_zeroed = f32 [72] scratch */
+int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, const float* b, float* mom72_zeroed,
+                                float* sums, float* sumsq, void* stream);
 int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
                         const float* beta, void* out_bf16, void* stream);
 int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
@@ -176,6 +179,9 @@ int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const 
 /* torch.max over the K group members (utils.py:180,188): h bf16 [NG,K,C] -> out [NG,C], arg uint8 (first max) */
 int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream);
 int vpf_group_max_bwd(const void* dout, int dout_is_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream);
+/* sum over the K members (gradient of the broadcast global feature) and max-pool backward added in place */
+int vpf_group_sum(const void* x_bf16, long NG, int K, int C, float* out, void* stream);
+int vpf_group_max_scatter_add(const void* dg_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream);
 /* torch.cat([global.expand, local]) (utils.py:183) and its backward */
 int vpf_g2e_concat_fwd(const void* gmax_bf16, const void* h_bf16, long M, int K, int C, void* feat_bf16, void* stream);
 int vpf_g2e_concat_bwd(const void* dfeat_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream);

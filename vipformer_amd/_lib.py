@@ -95,6 +95,9 @@ SIGS = {
     "vpf_smallk_fwd": [VP, L_, I, VP, VP, I, I, VP, VP],
     "vpf_smallk_bwd": [VP, VP, L_, I, VP, VP, I, I, VP, VP, VP],
     "vpf_g2e_conv1_stats": [VP, L_, I, VP, VP, VP, VP, VP],
+    "vpf_g2e_conv1_stats_moments": [VP, L_, I, VP, VP, VP, VP, VP, VP],
+    "vpf_group_sum": [VP, L_, I, I, VP, VP],
+    "vpf_group_max_scatter_add": [VP, VP, L_, I, I, VP, VP],
     "vpf_g2e_conv1_apply": [VP, L_, I, VP, VP, VP, VP, VP, VP, VP],
     "vpf_g2e_conv1_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP],
     "vpf_patchify": [VP, L_, L_, L_, L_, I, I, I, I, I, VP, VP],

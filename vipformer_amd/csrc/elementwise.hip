@@ -581,6 +581,51 @@ extern "C" int vpf_g2e_concat_bwd(const void* dfeat_bf16, const uint8_t* arg, lo
     return VPF_OK;
 }
 
+// sum over the K group members: x bf16 [NG,K,C] -> out f32 [NG,C]   (gradient of the broadcast "global" feature, utils.py:183)
+__global__ void group_sum_kernel(const bf16_t* __restrict__ x, long NG, int K, int C, float* __restrict__ out)
+{
+    const long total = NG * (C / 2);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / (C / 2); const int c2 = (int)(i % (C / 2));
+        float s0 = 0.f, s1 = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const uint32_t u = *reinterpret_cast<const uint32_t*>(x + ((size_t)g * K + k) * C + 2 * c2);
+            s0 += __uint_as_float(u << 16); s1 += __uint_as_float(u & 0xffff0000u);
+        }
+        out[g * C + 2 * c2] = s0; out[g * C + 2 * c2 + 1] = s1;
+    }
+}
+extern "C" int vpf_group_sum(const void* x_bf16, long NG, int K, int C, float* out, void* stream)
+{
+    (void)hipGetLastError();
+    if (!x_bf16 || !out) return VPF_ERR_NULL;
+    if (NG < 0 || K <= 0 || C <= 0 || (C & 1)) return VPF_ERR_BADSHAPE;
+    if (NG == 0) return VPF_OK;
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(NG * (C / 2), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, NG, K, C, out);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// dh[g, arg[g,c], c] += dg[g,c]   (max-pool backward added onto an existing gradient; one writer per element)
+__global__ void group_max_scatter_add_kernel(const bf16_t* __restrict__ dg, const uint8_t* __restrict__ arg, long NG, int K, int C, bf16_t* __restrict__ dh)
+{
+    const long total = NG * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long g = i / C; const int c = (int)(i % C);
+        const size_t o = ((size_t)g * K + arg[i]) * C + c;
+        dh[o] = f32_to_bf16(bf16_to_f32(dh[o]) + bf16_to_f32(dg[i]));
+    }
+}
+extern "C" int vpf_group_max_scatter_add(const void* dg_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
+{
+    (void)hipGetLastError();
+    if (!dg_bf16 || !arg || !dh_bf16) return VPF_ERR_NULL;
+    if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    if (NG == 0) return VPF_OK;
+    hipLaunchKernelGGL(group_max_scatter_add_kernel, dim3(grid_for(NG * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dg_bf16, arg, NG, K, C, (bf16_t*)dh_bf16);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 // =============================================================================== token pooling  partseg.py:547
 // x f32 [B,L,D] -> out f32 [B,2D] = [max over L | mean over L], arg int32 [B,D]
 __global__ void pool_fwd_kernel(const float* __restrict__ x, int B, int L, int D, float* __restrict__ out, int* __restrict__ arg)

@@ -200,6 +200,68 @@ extern "C" int vpf_g2e_conv1_stats(const float* x, long M, int C, const float* W
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
+// Batch statistics of h1 = x W^T + b WITHOUT touching the M x 64 matrix: h1 is affine in the C<=8 inputs, so
+//   sum_m h1_c   = W_c . S1 + M b_c                     S1 = sum_m x        (C)
+//   sum_m h1_c^2 = W_c S2 W_c^T + 2 b_c W_c . S1 + M b_c^2   S2 = sum_m x x^T   (C x C)
+// mom (f32, zeroed): [S1 (8) | S2 (64)]
+__global__ void __launch_bounds__(256) g2e_moments_kernel(const float* __restrict__ x, long M, int C, float* __restrict__ mom)
+{
+    __shared__ float red[4][72];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float s1[AD_MAXC], s2[AD_MAXC][AD_MAXC];
+#pragma unroll
+    for (int i = 0; i < AD_MAXC; ++i) { s1[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) s2[i][j] = 0.f; }
+    for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < M; r += (long)gridDim.x * blockDim.x) {
+        float v[AD_MAXC];
+#pragma unroll
+        for (int i = 0; i < AD_MAXC; ++i) v[i] = i < C ? x[(size_t)r * C + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < AD_MAXC; ++i) if (i < C) { s1[i] += v[i];
+#pragma unroll
+            for (int j = 0; j < AD_MAXC; ++j) if (j <= i) s2[i][j] += v[i] * v[j]; }
+    }
+#pragma unroll
+    for (int i = 0; i < AD_MAXC; ++i) if (i < C) {
+        const float a = wave_sum(s1[i]);
+        if (lane == 0) red[wv][i] = a;
+#pragma unroll
+        for (int j = 0; j < AD_MAXC; ++j) if (j <= i) { const float b = wave_sum(s2[i][j]); if (lane == 0) red[wv][8 + i * 8 + j] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 72) {
+        const int e = threadIdx.x, i = e < 8 ? e : (e - 8) / 8, j = e < 8 ? 0 : (e - 8) % 8;
+        if (i < C && (e < 8 || j <= i)) atomicAdd(mom + e, red[0][e] + red[1][e] + red[2][e] + red[3][e]);
+    }
+}
+__global__ void g2e_moments_to_sums_kernel(const float* __restrict__ mom, long M, int C, const float* __restrict__ W, const float* __restrict__ b,
+                                           float* __restrict__ sums, float* __restrict__ sumsq)
+{
+    const int c = threadIdx.x;          // 64 channels
+    if (c >= 64) return;
+    float ws1 = 0.f, q = 0.f;
+    for (int i = 0; i < C; ++i) {
+        ws1 += W[c * C + i] * mom[i];
+        for (int j = 0; j < C; ++j) { const float s2 = j <= i ? mom[8 + i * 8 + j] : mom[8 + j * 8 + i]; q += W[c * C + i] * W[c * C + j] * s2; }
+    }
+    const float bb = b[c];
+    sums[c] = ws1 + (float)M * bb;
+    sumsq[c] = q + 2.f * bb * ws1 + (float)M * bb * bb;
+}
+extern "C" int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, const float* b, float* mom72_zeroed,
+                                           float* sums, float* sumsq, void* stream)
+{
+    (void)hipGetLastError();
+    if (!x || !W || !b || !mom72_zeroed || !sums || !sumsq) return VPF_ERR_NULL;
+    if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(g2e_moments_kernel, dim3(grid_for(M, 256 * 4, 512)), dim3(256), 0, st, x, M, C, mom72_zeroed);
+    hipLaunchKernelGGL(g2e_moments_to_sums_kernel, dim3(1), dim3(64), 0, st, (const float*)mom72_zeroed, M, C, W, b, sums, sumsq);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 __global__ void __launch_bounds__(256) g2e_conv1_apply_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W,
                                                             const float* __restrict__ b, const float* __restrict__ stat,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ out)

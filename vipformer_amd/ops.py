@@ -478,6 +478,12 @@ def _bn_bwd(dy, x, C, stat, bn, relu, training, out_bf16, want_dx=True):
 
 # --------------------------------------------------------------------------- Group2Emb (utils.py:144-189)
 class Group2EmbFn(torch.autograd.Function):
+    """conv(C,64) BN ReLU conv(64,128) -> max over K -> cat[global, local] -> conv(256,256) BN ReLU conv(256,D) -> max over K.
+
+    The concatenation is never formed: conv(256,256) on [global | local] = local . W[:,128:]^T + a per-group
+    bias (global . W[:,:128]^T + b), which also removes a quarter of the block's MACs.  BatchNorm-1 statistics
+    come from the 3x3 second-moment matrix of the inputs (the first conv is affine in x)."""
+
     @staticmethod
     def forward(ctx, groups, mod, training, *params):
         ctx.nparams = len(params)
@@ -491,8 +497,9 @@ class Group2EmbFn(torch.autograd.Function):
         w1 = c1.weight.data.view(64, C)
         stat1 = torch.empty(128, dtype=F32, device=dev)
         if training:
-            sums = torch.zeros(128, dtype=F32, device=dev)
-            L.call("vpf_g2e_conv1_stats", x, M, C, w1, c1.bias.data, sums[:64], sums[64:])
+            scratch = torch.zeros(72 + 128, dtype=F32, device=dev)
+            sums = scratch[72:]
+            L.call("vpf_g2e_conv1_stats_moments", x, M, C, w1, c1.bias.data, scratch, sums[:64], sums[64:])
             L.call("vpf_bn_finalize", sums[:64], sums[64:], M, 64, float(bn1.eps), float(bn1.momentum), 1, bn1.running_mean,
                    bn1.running_var, bn1.num_batches_tracked, stat1)
         else:
@@ -504,9 +511,11 @@ class Group2EmbFn(torch.autograd.Function):
         gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
         arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
         L.call("vpf_group_max_fwd", h2, NG, K, 128, gmax, 1, arg2)
-        feat = torch.empty(M, 256, dtype=BF16, device=dev)
-        L.call("vpf_g2e_concat_fwd", gmax, h2, M, K, 128, feat)
-        h3 = linear_fwd(feat, shadow([c3.weight]), 256, 256, c3.bias.data)                    # [M,256]
+        w3 = shadow([c3.weight])                                                              # [256, 256] = [global | local]
+        gb = torch.empty(NG, 256, dtype=F32, device=dev)
+        gemm(gmax, 0, 128, w3, 0, 256, NG, 256, 128, gb, 256, c_f32=True, bias=c3.bias.data)  # global . W[:, :128]^T + b
+        h3 = torch.empty(M, 256, dtype=BF16, device=dev)
+        gemm(h2, 0, 128, w3[128:], 0, 256, M, 256, 128, h3, 256, c_f32=False, mode=EPI_GROUPBIAS, gbias=gb, group=K)
         stat2 = _bn_stat(h3, 256, bn2, training)
         a3 = _bn_act(h3, 256, stat2, bn2, True, True)
         h4 = linear_fwd(a3, shadow([c4.weight]), Dm, 256, c4.bias.data)                       # [M,Dm]
@@ -514,12 +523,12 @@ class Group2EmbFn(torch.autograd.Function):
         arg4 = torch.empty(NG, Dm, dtype=torch.uint8, device=dev)
         L.call("vpf_group_max_fwd", h4, NG, K, Dm, out, 0, arg4)
         ctx.mod, ctx.training, ctx.dims = mod, training, (Bq, G, K, C, Dm)
-        ctx.save_for_backward(x, stat1, a1, arg2, feat, h3, stat2, a3, arg4)
+        ctx.save_for_backward(x, stat1, a1, arg2, h2, gmax, h3, stat2, a3, arg4)
         return out.view(Bq, G, Dm)
 
     @staticmethod
     def backward(ctx, dout):
-        x, stat1, a1, arg2, feat, h3, stat2, a3, arg4 = ctx.saved_tensors
+        x, stat1, a1, arg2, h2, gmax, h3, stat2, a3, arg4 = ctx.saved_tensors
         mod, training = ctx.mod, ctx.training
         Bq, G, K, C, Dm = ctx.dims
         dev = dout.device
@@ -532,10 +541,20 @@ class Group2EmbFn(torch.autograd.Function):
         linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight), grad_buf(c4.bias))
         da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
         dh3 = _bn_bwd(da3, h3, 256, stat2, bn2, True, training, True)
-        linear_wgrad(dh3, feat, 256, 256, grad_buf(c3.weight), grad_buf(c3.bias))
-        dfeat = linear_dgrad(dh3, shadow([c3.weight]), 256, 256)
+        # conv(256,256) on [global | local]: per-group part and per-point part
+        w3 = shadow([c3.weight])
+        gW3 = grad_buf(c3.weight).view(256, 256)
+        dgb = torch.empty(NG, 256, dtype=F32, device=dev)
+        L.call("vpf_group_sum", dh3, NG, K, 256, dgb)                                        # d(per-group bias)
+        colsum(dgb, 256, grad_buf(c3.bias))
+        dgb16 = to_bf16(dgb)
+        gemm(dgb16, 1, 256, gmax, 1, 128, 256, 128, NG, gW3, 256, c_f32=True, mode=EPI_ATOMIC)            # dW[:, :128]
+        gemm(dh3, 1, 256, h2, 1, 128, 256, 128, M, gW3[:, 128:], 256, c_f32=True, mode=EPI_ATOMIC)        # dW[:, 128:]
+        dgmax = torch.empty(NG, 128, dtype=BF16, device=dev)
+        gemm(dgb16, 0, 256, w3, 1, 256, NG, 128, 256, dgmax, 128, c_f32=False)                             # dglobal
         dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
-        L.call("vpf_g2e_concat_bwd", dfeat, arg2, NG, K, 128, dh2)
+        gemm(dh3, 0, 256, w3[128:], 1, 256, M, 128, 256, dh2, 128, c_f32=False)                            # dlocal
+        L.call("vpf_group_max_scatter_add", dgmax, arg2, NG, K, 128, dh2)
         linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
         da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
         tmp = torch.zeros(128, dtype=F32, device=dev)

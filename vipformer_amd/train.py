@@ -89,6 +89,10 @@ class Pretrainer:
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / world_size, 0.0, 0.0],
                                   dtype=torch.float32, device=dev)
         self.device = dev
+        # the image branch is independent of the point-cloud branch until the CMC loss: it runs on its own
+        # stream so its kernels fill the CUs that FPS / kNN / the small GEMMs of the pc branch leave idle
+        self.overlap = True
+        self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._graph = None
         self._static = None
         self.losses = None
@@ -109,10 +113,21 @@ class Pretrainer:
         imgs = imgs.permute(0, 2, 3, 1)                     # pretrain.py:179 (a view; strides go to the kernel)
         b = pc_t1.shape[0]
         pc = torch.cat([pc_t1, pc_t2], dim=0)               # pretrain.py:183
-        feats = self.pc_model(pc)[0]
-        f1, f2 = feats[:b], feats[b:]
-        loss_imid = ops.ntxent_loss(f1, f2, self.temperature)
-        img_feats = self.img_model(imgs)[0]
+        if self.overlap and self._side is not None:
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                img_feats = self.img_model(imgs)[0]
+            feats = self.pc_model(pc)[0]
+            f1, f2 = feats[:b], feats[b:]
+            loss_imid = ops.ntxent_loss(f1, f2, self.temperature)
+            main.wait_stream(self._side)
+            img_feats.record_stream(main)
+        else:
+            feats = self.pc_model(pc)[0]
+            f1, f2 = feats[:b], feats[b:]
+            loss_imid = ops.ntxent_loss(f1, f2, self.temperature)
+            img_feats = self.img_model(imgs)[0]
         loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, self.temperature)
         total = loss_imid + self.cmid_weight * loss_cmid
         total.backward()
