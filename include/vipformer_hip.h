@@ -106,6 +106,19 @@ int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void* B, int b_
                   const float* gbias, int group, const uint32_t* rng_state, uint32_t site, float p,
                   int splitk, float* dbias, void* stream);
 
+/* The same GEMM with operand prologues and a max-pool epilogue (Group2Emb's last conv utils.py:163-165,188 and its
+ * backward): a_kind / b_kind 1 = relu(scale[c]*x + shift[c]) applied while the operand is staged (BatchNorm + ReLU,
+ * the normalised activation never reaches HBM); a_kind 2 = the A operand is the VIRTUAL gradient of a max over
+ * a_group consecutive rows, rebuilt from (a_dout f32 [rows/a_group, a_ncols], a_arg uint8) -- A is ignored.
+ * mode 0 store | 4 atomic (+dbias) | 7 group max: C f32 [M/group, N] = max over each group of `group` rows of
+ * bf16(acc + bias), C2 uint8 = first arg-max (group must divide 32). */
+#define VPF_EPI_GROUPMAX 7
+int vpf_gemm_bf16_fused(const void* A, int a_kstrided, long lda, int a_kind, const float* a_scale, const float* a_shift,
+                        const float* a_dout, const uint8_t* a_arg, int a_group, long a_ncols,
+                        const void* B, int b_kstrided, long ldb, int b_kind, const float* b_scale, const float* b_shift,
+                        int M, int N, int K, void* C, long ldc, int c_is_f32, int mode, const float* bias,
+                        void* C2, long ldc2, int group, int splitk, float* dbias, void* stream);
+
 /* ------------------------------------------------------------------ fused attention (head dim 64)
  * MultiHeadAttention.forward partseg.py:67-86: softmax(q k^T * scale) -> dropout(p) -> . v, without the
  * [b*h, Lq, Lkv] matrix in HBM.  q/k/v/out are bf16 [B, L, H*64] views with row strides ld* (elements),
@@ -157,6 +170,8 @@ int vpf_rowsum_mod_f32(const float* x, long rows, int D, int period, float* acc,
  * eval -> from the running statistics. */
 int vpf_bn_finalize(const float* sums, const float* sumsq, long M, int C, float eps, float momentum, int training,
                     float* running_mean, float* running_var, long long* num_batches, float* stat, void* stream);
+/* ab = [rstd*gamma | beta - mean*rstd*gamma]: BatchNorm as a per-channel affine (operand prologue of vpf_gemm_bf16_fused) */
+int vpf_bn_affine(const float* stat, const float* gamma, const float* beta, int C, float* ab, void* stream);
 int vpf_bn_act_fwd(const void* x, int x_is_bf16, const float* stat, const float* gamma, const float* beta, void* y,
                    int y_is_bf16, long M, int C, int relu, void* stream);
 /* dx (nullable) = BN'(relu'(dy)); dgamma/dbeta +=.  tmp2C_zeroed: f32 [2C] scratch, zero on entry. */

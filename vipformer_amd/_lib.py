@@ -68,6 +68,7 @@ SIGS = {
     "vpf_square_distance_f32": [VP, I, VP, I, I, I, I, VP, VP],
     "vpf_knn_group_f32": [VP, I, I, I, VP, I, I, I, I, VP, VP, VP, VP],
     "vpf_gemm_bf16": [VP, I, L_, VP, I, L_, I, I, I, I, L_, L_, L_, VP, L_, I, I, VP, VP, L_, VP, L_, VP, L_, VP, I, VP, U32, F, I, VP, VP],
+    "vpf_gemm_bf16_fused": [VP, I, L_, I, VP, VP, VP, VP, I, L_, VP, I, L_, I, VP, VP, I, I, I, VP, L_, I, I, VP, VP, L_, I, I, VP, VP],
     "vpf_cast_f32_bf16": [VP, VP, L_, VP],
     "vpf_cast_bf16_f32": [VP, VP, L_, VP],
     "vpf_layernorm_fwd": [VP, I, VP, I, VP, VP, VP, VP, VP, VP, L_, I, F, VP],
@@ -78,6 +79,7 @@ SIGS = {
     "vpf_rng_advance": [VP, VP],
     "vpf_colsum": [VP, I, L_, I, VP, VP, VP],
     "vpf_bn_finalize": [VP, VP, L_, I, F, F, I, VP, VP, VP, VP, VP],
+    "vpf_bn_affine": [VP, VP, VP, I, VP, VP],
     "vpf_bn_act_fwd": [VP, I, VP, VP, VP, VP, I, L_, I, I, VP],
     "vpf_bn_bwd": [VP, I, VP, I, VP, VP, VP, L_, I, I, I, VP, VP, I, VP, VP, VP],
     "vpf_group_max_fwd": [VP, L_, I, I, VP, I, VP, VP],

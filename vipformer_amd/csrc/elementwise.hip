@@ -392,6 +392,22 @@ extern "C" int vpf_bn_finalize(const float* sums, const float* sumsq, long M, in
     return VPF_OK;
 }
 
+// fold BatchNorm into y = a[c]*x + b[c]:  a = rstd*gamma, b = beta - mean*rstd*gamma   (ab = [a(C) | b(C)])
+__global__ void bn_affine_kernel(const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ beta, int C, float* __restrict__ ab)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { const float a = stat[C + c] * gamma[c]; ab[c] = a; ab[C + c] = beta[c] - stat[c] * a; }
+}
+extern "C" int vpf_bn_affine(const float* stat, const float* gamma, const float* beta, int C, float* ab, void* stream)
+{
+    (void)hipGetLastError();
+    if (!stat || !gamma || !beta || !ab) return VPF_ERR_NULL;
+    if (C <= 0) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(bn_affine_kernel, dim3(vpf_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stat, gamma, beta, C, ab);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 template <typename TIN, typename TOUT>
 __global__ void bn_act_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ stat, const float* __restrict__ gamma,
                                   const float* __restrict__ beta, TOUT* __restrict__ y, long total, int C, int relu)

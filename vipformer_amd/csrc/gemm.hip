@@ -32,6 +32,18 @@ enum {
     EPI_ATOMIC = 4,      // C(f32) += acc   (split-K)
     EPI_RELU = 5,        // C = relu(acc + bias)
     EPI_GROUPBIAS = 6,   // C = acc + gbias[(m / group) * N + n]   (f32 row-group bias), bf16/f32 out
+    EPI_GROUPMAX = 7,    // C(f32)[m / group, n] = max over the group's rows of bf16(acc + bias); C2(u8) = first arg-max
+};
+
+// Operand prologue: what a 16-byte chunk (8 values along the operand's contiguous dimension = channel axis) becomes
+// while it is staged into LDS.  kind 1: y = relu(a[c] * x + b[c]) (BatchNorm + ReLU folded into an affine, the
+// normalised activation is never materialised).  kind 2: the operand is VIRTUAL -- the gradient of a max over `group`
+// consecutive rows: value(token, c) = (arg[(token/group)*ncols + c] == token % group) ? dout[(token/group)*ncols + c] : 0.
+struct OpXform {
+    int kind;
+    const float* a; const float* b;          // kind 1
+    const float* dout; const uint8_t* arg;   // kind 2
+    int group; long ncols;
 };
 
 struct GemmArgs {
@@ -49,6 +61,7 @@ struct GemmArgs {
     const float* gbias; int group;     // EPI_GROUPBIAS
     const uint32_t* rng; uint32_t site; float p;   // dropout
     float* dbias;                                   // EPI_ATOMIC with a k-strided A: dbias[m] += sum_k A(m,k)
+    OpXform xa, xb;                                 // operand prologues (kind 0 = none)
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -69,9 +82,42 @@ struct TileCfg {
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
 };
 
-template <int ROWS, bool TR, int BK>
+template <int XK>
+__device__ __forceinline__ uint4 xform_chunk(const OpXform& xf, uint4 v, int token, int ch)
+{
+    if constexpr (XK == 1) {
+        const float4 a0 = *reinterpret_cast<const float4*>(xf.a + ch), a1 = *reinterpret_cast<const float4*>(xf.a + ch + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(xf.b + ch), b1 = *reinterpret_cast<const float4*>(xf.b + ch + 4);
+        const float aa[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = fmaxf(fmaf(aa[2 * j], __uint_as_float(w[j] << 16), bb[2 * j]), 0.f);
+            const float hi = fmaxf(fmaf(aa[2 * j + 1], __uint_as_float(w[j] & 0xffff0000u), bb[2 * j + 1]), 0.f);
+            w[j] = pack_bf16x2(lo, hi);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    // kind 2 (group is a power of two: it divides 32)
+    const int sh = 31 - __clz(xf.group);
+    const int g = token >> sh, k = token & (xf.group - 1);
+    const size_t o = (size_t)g * xf.ncols + ch;
+    const uint2 ar = *reinterpret_cast<const uint2*>(xf.arg + o);
+    const float4 d0 = *reinterpret_cast<const float4*>(xf.dout + o), d1 = *reinterpret_cast<const float4*>(xf.dout + o + 4);
+    const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+    const uint32_t aw[2] = {ar.x, ar.y};
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e0 = (aw[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xff, e1 = (aw[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xff;
+        w[j] = pack_bf16x2(e0 == k ? dd[2 * j] : 0.f, e1 == k ? dd[2 * j + 1] : 0.f);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int ROWS, bool TR, int BK, int XK>
 __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld, int R, int K, int r0, int k0, int kend,
-                                          uint4 (&regs)[TileCfg<ROWS, TR, BK>::PER_THREAD])
+                                          uint4 (&regs)[TileCfg<ROWS, TR, BK>::PER_THREAD], const OpXform& xf)
 {
     using Cfg = TileCfg<ROWS, TR, BK>;
 #pragma unroll
@@ -82,11 +128,17 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld,
             if (!TR) {
                 const int row = c / (BK / 8), kc = c % (BK / 8);
                 const int gr = r0 + row, gk = k0 + kc * 8;
-                if (gr < R && gk < kend) v = *reinterpret_cast<const uint4*>(G + (size_t)gr * ld + gk);
+                if (gr < R && gk < kend) {
+                    if constexpr (XK != 2) v = *reinterpret_cast<const uint4*>(G + (size_t)gr * ld + gk);
+                    if constexpr (XK != 0) v = xform_chunk<XK>(xf, v, gr, gk);
+                }
             } else {
                 const int krow = c / (ROWS / 8), rc = c % (ROWS / 8);
                 const int gk = k0 + krow, gr = r0 + rc * 8;
-                if (gk < kend && gr < R) v = *reinterpret_cast<const uint4*>(G + (size_t)gk * ld + gr);
+                if (gk < kend && gr < R) {
+                    if constexpr (XK != 2) v = *reinterpret_cast<const uint4*>(G + (size_t)gk * ld + gr);
+                    if constexpr (XK != 0) v = xform_chunk<XK>(xf, v, gk, gr);
+                }
             }
         }
         regs[i] = v;
@@ -136,7 +188,7 @@ __device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int 
 }
 
 // ------------------------------------------------------------------ kernel
-template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR>
+template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -169,8 +221,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     uint4 ra[ACfg::PER_THREAD], rb[BCfg::PER_THREAD];
-    tile_load<BM, ATR, BK>(A, g.lda, g.M, g.K, m0, kbeg, kend, ra);
-    tile_load<BN, BTR, BK>(B, g.ldb, g.N, g.K, n0, kbeg, kend, rb);
+    tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg, kend, ra, g.xa);
+    tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg, kend, rb, g.xb);
     tile_store<BM, ATR, BK>(lds, ra);
     tile_store<BN, BTR, BK>(lds + ACfg::ELEMS, rb);
     __syncthreads();
@@ -186,8 +238,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
         bf16_t* nA = lds + (cur ^ 1) * STAGE;
         bf16_t* nB = nA + ACfg::ELEMS;
         if (kt + 1 < nk) {
-            tile_load<BM, ATR, BK>(A, g.lda, g.M, g.K, m0, kbeg + (kt + 1) * BK, kend, ra);
-            tile_load<BN, BTR, BK>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + 1) * BK, kend, rb);
+            tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg + (kt + 1) * BK, kend, ra, g.xa);
+            tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + 1) * BK, kend, rb, g.xb);
         }
         if (ATR && do_bias) {
             constexpr int RG = 256 / BM > 0 ? 256 / BM : 1;                 // row groups (BM <= 256)
@@ -258,6 +310,36 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
             for (int r = 0; r < 16; ++r)
                 sf[(wm * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SLD + wn * 32 + col_l] = acc[i][j][r];
             __syncthreads();
+            if (g.mode == EPI_GROUPMAX) {
+                // max over the `group` consecutive rows of every group inside this 32-row-aligned sub-tile
+                const int gpb = SR / g.group;                                  // groups per staged sub-tile
+                for (int e = threadIdx.x; e < gpb * (SC / 4); e += 256) {
+                    const int gi = e / (SC / 4), sc = (e % (SC / 4)) * 4;
+                    const int sr0 = gi * g.group;
+                    const int m = m0 + ((sr0 >> 5) * TM + i) * 32 + (sr0 & 31);
+                    const int n = n0 + ((sc >> 5) * TN + j) * 32 + (sc & 31);
+                    if (m >= g.M || n >= g.N) continue;
+                    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    int bi[4] = {0, 0, 0, 0};
+                    float bvv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (g.bias) { bvv[0] = g.bias[n]; bvv[1] = g.bias[n + 1]; bvv[2] = g.bias[n + 2]; bvv[3] = g.bias[n + 3]; }
+                    for (int k = 0; k < g.group; ++k) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(sf + (sr0 + k) * SLD + sc);
+                        const float vv[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float t = bf16_to_f32(f32_to_bf16(vv[q] + bvv[q]));
+                            if (t > best[q]) { best[q] = t; bi[q] = k; }
+                        }
+                    }
+                    const size_t go = (size_t)(m / g.group) * g.ldc + n;
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + go) = make_float4(best[0], best[1], best[2], best[3]);
+                    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g.C2) + (size_t)(m / g.group) * g.ldc2 + n) =
+                        (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+                }
+                __syncthreads();
+                continue;
+            }
             for (int e = threadIdx.x; e < SR * (SC / 4); e += 256) {
                 const int sr = e / (SC / 4), sc = (e % (SC / 4)) * 4;
                 const int m = m0 + ((sr >> 5) * TM + i) * 32 + (sr & 31);
@@ -316,18 +398,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
     }
 }
 
-template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR>
+template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
 static int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, ATR, BK>::ELEMS + TileCfg<BN, BTR, BK>::ELEMS);
     static bool attr = false;
     if (!attr) {
-        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR>,
+        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>), grid, dim3(256), lds, st, g);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -336,10 +418,18 @@ static int launch_cfg(const GemmArgs& g, int a_tr, int b_tr, int batch, hipStrea
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     dim3 grid(vpf_cdiv(g.N, BN), vpf_cdiv(g.M, BM), g.splitk > 1 ? g.splitk : batch);
-    if (!a_tr && !b_tr) return launch_one<TM, TN, WM, WN, BK, false, false>(g, grid, st);
-    if (!a_tr && b_tr) return launch_one<TM, TN, WM, WN, BK, false, true>(g, grid, st);
-    if (a_tr && !b_tr) return launch_one<TM, TN, WM, WN, BK, true, false>(g, grid, st);
-    return launch_one<TM, TN, WM, WN, BK, true, true>(g, grid, st);
+    const int ax = g.xa.kind, bx = g.xb.kind;
+    if (ax == 0 && bx == 0) {
+        if (!a_tr && !b_tr) return launch_one<TM, TN, WM, WN, BK, false, false, 0, 0>(g, grid, st);
+        if (!a_tr && b_tr) return launch_one<TM, TN, WM, WN, BK, false, true, 0, 0>(g, grid, st);
+        if (a_tr && !b_tr) return launch_one<TM, TN, WM, WN, BK, true, false, 0, 0>(g, grid, st);
+        return launch_one<TM, TN, WM, WN, BK, true, true, 0, 0>(g, grid, st);
+    }
+    // operand prologues: only the combinations the Group2Emb tail uses are instantiated
+    if (ax == 1 && bx == 0 && !a_tr && !b_tr) return launch_one<TM, TN, WM, WN, BK, false, false, 1, 0>(g, grid, st);   // fwd: relu(bn(h3)) . W^T
+    if (ax == 2 && bx == 0 && !a_tr && b_tr) return launch_one<TM, TN, WM, WN, BK, false, true, 2, 0>(g, grid, st);     // dgrad: dmax . W
+    if (ax == 2 && bx == 1 && a_tr && b_tr) return launch_one<TM, TN, WM, WN, BK, true, true, 2, 1>(g, grid, st);       // wgrad: dmax^T . relu(bn(h3))
+    return VPF_ERR_UNSUPPORTED;
 }
 
 static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t st)
@@ -387,11 +477,42 @@ extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void
     g.C = C; g.ldc = ldc; g.c_f32 = c_is_f32; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16_t*)aux; g.ldaux = ldaux; g.gbias = gbias; g.group = group > 0 ? group : 1;
     g.rng = rng_state; g.site = site; g.p = p; g.dbias = dbias;
+    g.xa.kind = 0; g.xb.kind = 0;
     if (dbias && !(mode == EPI_ATOMIC && a_kstrided)) return VPF_ERR_UNSUPPORTED;
-    if (mode < 0 || mode > EPI_GROUPBIAS) return VPF_ERR_UNSUPPORTED;
+    if (mode < 0 || mode > EPI_GROUPBIAS) return VPF_ERR_UNSUPPORTED;   // EPI_GROUPMAX: vpf_gemm_bf16_fused
     if (mode == EPI_GELU && !C2) return VPF_ERR_NULL;
     if (mode == EPI_DROP_RES && (!res || !rng_state || !c_is_f32)) return VPF_ERR_NULL;
     if (mode == EPI_GELU_BWD && !aux) return VPF_ERR_NULL;
     if (mode == EPI_GROUPBIAS && !gbias) return VPF_ERR_NULL;
     return gemm_dispatch(g, a_kstrided, b_kstrided, batch, (hipStream_t)stream);
+}
+
+// GEMM with operand prologues and the max-pool epilogue (Group2Emb's last conv and its backward):
+//   a_kind / b_kind: 0 none | 1 relu(a[c]*x + b[c]) on the fly (xa = a, xb = b: f32 [channels]) |
+//                    2 (A only) virtual max-pool gradient from (dout f32 [tokens/group, ncols], arg u8), A pointer ignored
+//   mode: VPF_EPI_STORE / VPF_EPI_ATOMIC (+dbias) / 7 = group max: C f32 [M/group, N] (ldc), C2 u8 arg (ldc2)
+extern "C" int vpf_gemm_bf16_fused(const void* A, int a_kstrided, long lda, int a_kind, const float* a_scale, const float* a_shift,
+                                   const float* a_dout, const uint8_t* a_arg, int a_group, long a_ncols,
+                                   const void* B, int b_kstrided, long ldb, int b_kind, const float* b_scale, const float* b_shift,
+                                   int M, int N, int K, void* C, long ldc, int c_is_f32, int mode, const float* bias,
+                                   void* C2, long ldc2, int group, int splitk, float* dbias, void* stream)
+{
+    (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
+    GemmArgs g = {};
+    g.A = (const bf16_t*)(a_kind == 2 ? (const void*)a_dout : A); g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.splitk = splitk; g.mode = mode; g.C = C; g.ldc = ldc; g.c_f32 = c_is_f32; g.C2 = C2; g.ldc2 = ldc2;
+    g.bias = bias; g.group = group > 0 ? group : 1; g.dbias = dbias;
+    g.xa.kind = a_kind; g.xa.a = a_scale; g.xa.b = a_shift; g.xa.dout = a_dout; g.xa.arg = a_arg; g.xa.group = a_group > 0 ? a_group : 1; g.xa.ncols = a_ncols;
+    g.xb.kind = b_kind; g.xb.a = b_scale; g.xb.b = b_shift; g.xb.group = 1;
+    if (!(mode == EPI_STORE || mode == EPI_ATOMIC || mode == EPI_GROUPMAX)) return VPF_ERR_UNSUPPORTED;
+    if (a_kind < 0 || a_kind > 2 || b_kind < 0 || b_kind > 1) return VPF_ERR_UNSUPPORTED;
+    if ((a_kind == 1 && (!a_scale || !a_shift)) || (b_kind == 1 && (!b_scale || !b_shift)) || (a_kind == 2 && (!a_dout || !a_arg))) return VPF_ERR_NULL;
+    if (a_kind == 2 && ((a_ncols % 8) || ((uintptr_t)a_dout & 15) || ((uintptr_t)a_arg & 7))) return VPF_ERR_BADALIGN;
+    if (dbias && !(mode == EPI_ATOMIC && a_kstrided)) return VPF_ERR_UNSUPPORTED;
+    if (mode == EPI_GROUPMAX) {
+        if (!C2 || !c_is_f32) return VPF_ERR_NULL;
+        if (g.group > 32 || (32 % g.group) || (M % g.group) || (N % 4) || (ldc % 4) || (ldc2 % 4) || ((uintptr_t)C & 15) || ((uintptr_t)C2 & 3))
+            return VPF_ERR_UNSUPPORTED;
+    }
+    return gemm_dispatch(g, a_kstrided, b_kstrided, 1, (hipStream_t)stream);
 }

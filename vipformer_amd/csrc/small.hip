@@ -33,14 +33,23 @@ __global__ void __launch_bounds__(256) adapter_front_fwd_kernel(const float* __r
 #pragma unroll
     for (int j = 0; j < AD_MAXC; ++j) w[j] = j < C ? W[lane * C + j] : 0.f;
     const float bb = b[lane], ga = gamma[lane], be = beta[lane];
-    for (long r = wave0; r < M; r += nw) {
-        float h = bb;
+    constexpr int U = 4;                 // rows in flight per wave (the loop is latency-bound otherwise)
+    for (long r0 = wave0 * U; r0 < M; r0 += nw * U) {
+        float h[U];
 #pragma unroll
-        for (int j = 0; j < AD_MAXC; ++j) if (j < C) h += w[j] * x[(size_t)r * C + j];
-        const float mu = wave_sum(h) * (1.f / 64.f);
-        const float d = h - mu;
-        const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + 1e-5f);
-        out[(size_t)r * 64 + lane] = f32_to_bf16(fmaxf(d * rs * ga + be, 0.f));
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u < M ? r0 + u : M - 1;
+            h[u] = bb;
+#pragma unroll
+            for (int j = 0; j < AD_MAXC; ++j) if (j < C) h[u] += w[j] * x[(size_t)r * C + j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float mu = wave_sum(h[u]) * (1.f / 64.f);
+            const float d = h[u] - mu;
+            const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + 1e-5f);
+            if (r0 + u < M) out[(size_t)(r0 + u) * 64 + lane] = f32_to_bf16(fmaxf(d * rs * ga + be, 0.f));
+        }
     }
 }
 extern "C" int vpf_adapter_front_fwd(const float* x, long M, int C, const float* W, const float* b, const float* gamma,
@@ -50,7 +59,7 @@ extern "C" int vpf_adapter_front_fwd(const float* x, long M, int C, const float*
     if (!x || !W || !b || !gamma || !beta || !out_bf16) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
-    hipLaunchKernelGGL(adapter_front_fwd_kernel, dim3(grid_for(M, 32, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, gamma, beta, (bf16_t*)out_bf16);
+    hipLaunchKernelGGL(adapter_front_fwd_kernel, dim3(grid_for(M, 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, gamma, beta, (bf16_t*)out_bf16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -68,24 +77,34 @@ __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __r
     for (int j = 0; j < AD_MAXC; ++j) { w[j] = j < C ? W[lane * C + j] : 0.f; aw[j] = 0.f; }
     const float bb = b[lane], ga = gamma[lane], be = beta[lane];
     float adb = 0.f, adg = 0.f, adbe = 0.f;
-    for (long r = wave0; r < M; r += nw) {
-        float xv[AD_MAXC];
-        float h = bb;
+    constexpr int U = 4;
+    for (long r0 = wave0 * U; r0 < M; r0 += nw * U) {
+        float xv[U][AD_MAXC], h[U], gin[U];
 #pragma unroll
-        for (int j = 0; j < AD_MAXC; ++j) { xv[j] = j < C ? x[(size_t)r * C + j] : 0.f; h += w[j] * xv[j]; }
-        const float mu = wave_sum(h) * (1.f / 64.f);
-        const float d = h - mu;
-        const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + 1e-5f);
-        const float xh = d * rs;
-        float g = bf16_to_f32(da[(size_t)r * 64 + lane]);
-        if (xh * ga + be <= 0.f) g = 0.f;
-        adg += g * xh; adbe += g;
-        const float gx = g * ga;
-        const float m1 = wave_sum(gx) * (1.f / 64.f), m2 = wave_sum(gx * xh) * (1.f / 64.f);
-        const float dh = rs * (gx - m1 - xh * m2);
-        adb += dh;
+        for (int u = 0; u < U; ++u) {
+            const bool ok = r0 + u < M;
+            const long r = ok ? r0 + u : M - 1;
+            h[u] = bb;
 #pragma unroll
-        for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[j];
+            for (int j = 0; j < AD_MAXC; ++j) { xv[u][j] = (j < C && ok) ? x[(size_t)r * C + j] : 0.f; h[u] += w[j] * xv[u][j]; }
+            gin[u] = ok ? bf16_to_f32(da[(size_t)r * 64 + lane]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float mu = wave_sum(h[u]) * (1.f / 64.f);
+            const float d = h[u] - mu;
+            const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + 1e-5f);
+            const float xh = d * rs;
+            float g = gin[u];
+            if (xh * ga + be <= 0.f) g = 0.f;
+            adg += g * xh; adbe += g;
+            const float gx = g * ga;
+            const float m1 = wave_sum(gx) * (1.f / 64.f), m2 = wave_sum(gx * xh) * (1.f / 64.f);
+            const float dh = (r0 + u < M) ? rs * (gx - m1 - xh * m2) : 0.f;
+            adb += dh;
+#pragma unroll
+            for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[u][j];
+        }
     }
     atomicAdd(db + lane, adb); atomicAdd(dgamma + lane, adg); atomicAdd(dbeta + lane, adbe);
 #pragma unroll
@@ -272,11 +291,19 @@ __global__ void __launch_bounds__(256) g2e_conv1_apply_kernel(const float* __res
 #pragma unroll
     for (int j = 0; j < AD_MAXC; ++j) w[j] = j < C ? W[lane * C + j] : 0.f;
     const float bb = b[lane], mu = stat[lane], rs = stat[64 + lane], ga = gamma[lane], be = beta[lane];
-    for (long r = wave0; r < M; r += nw) {
-        float h = bb;
+    constexpr int U = 8;
+    for (long r0 = wave0 * U; r0 < M; r0 += nw * U) {
+        float h[U];
 #pragma unroll
-        for (int j = 0; j < AD_MAXC; ++j) if (j < C) h += w[j] * x[(size_t)r * C + j];
-        out[(size_t)r * 64 + lane] = f32_to_bf16(fmaxf((h - mu) * rs * ga + be, 0.f));
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u < M ? r0 + u : M - 1;
+            h[u] = bb;
+#pragma unroll
+            for (int j = 0; j < AD_MAXC; ++j) if (j < C) h[u] += w[j] * x[(size_t)r * C + j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (r0 + u < M) out[(size_t)(r0 + u) * 64 + lane] = f32_to_bf16(fmaxf((h[u] - mu) * rs * ga + be, 0.f));
     }
 }
 extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
@@ -305,20 +332,32 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restr
     const float invM = 1.f / (float)M;
     const float sg = pass ? tmp[lane] * invM : 0.f, sgx = pass ? tmp[64 + lane] * invM : 0.f;
     float a0 = 0.f, a1 = 0.f;
-    for (long r = wave0; r < M; r += nw) {
-        float xv[AD_MAXC];
-        float h = bb;
+    constexpr int U = 8;
+    for (long r0 = wave0 * U; r0 < M; r0 += nw * U) {
+        float xv[U][AD_MAXC], gin[U];
 #pragma unroll
-        for (int j = 0; j < AD_MAXC; ++j) { xv[j] = j < C ? x[(size_t)r * C + j] : 0.f; h += w[j] * xv[j]; }
-        const float xh = (h - mu) * rs;
-        float g = bf16_to_f32(da[(size_t)r * 64 + lane]);
-        if (xh * ga + be <= 0.f) g = 0.f;
-        if (!pass) { a0 += g; a1 += g * xh; }
-        else {
-            const float dh = training ? ga * rs * (g - sg - xh * sgx) : ga * rs * g;
-            a0 += dh;
+        for (int u = 0; u < U; ++u) {
+            const bool ok = r0 + u < M;
+            const long r = ok ? r0 + u : M - 1;
 #pragma unroll
-            for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[j];
+            for (int j = 0; j < AD_MAXC; ++j) xv[u][j] = (j < C && ok) ? x[(size_t)r * C + j] : 0.f;
+            gin[u] = ok ? bf16_to_f32(da[(size_t)r * 64 + lane]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float h = bb;
+#pragma unroll
+            for (int j = 0; j < AD_MAXC; ++j) h += w[j] * xv[u][j];
+            const float xh = (h - mu) * rs;
+            float g = gin[u];
+            if (xh * ga + be <= 0.f) g = 0.f;
+            if (!pass) { a0 += g; a1 += g * xh; }
+            else {
+                const float dh = (r0 + u < M) ? (training ? ga * rs * (g - sg - xh * sgx) : ga * rs * g) : 0.f;
+                a0 += dh;
+#pragma unroll
+                for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[u][j];
+            }
         }
     }
     if (!pass) { atomicAdd(tmp + lane, a0); atomicAdd(tmp + 64 + lane, a1); }

@@ -183,6 +183,19 @@ def gemm(A, a_tr, lda, Bm, b_tr, ldb, M, N, K, C, ldc, *, c_f32, mode=EPI_STORE,
            bias, C2, ldc2, res, ldres, aux, ldaux, gbias, group, st, site, float(p), splitk, dbias)
 
 
+def gemm_fused(A, a_tr, lda, Bm, b_tr, ldb, M, N, K, C, ldc, *, c_f32, mode=EPI_STORE, a_kind=0, a_ab=None, a_dout=None, a_arg=None,
+               a_group=1, a_ncols=0, b_kind=0, b_ab=None, bias=None, C2=None, ldc2=0, group=1, splitk=0, dbias=None):
+    """vpf_gemm_bf16_fused: operand prologues (BatchNorm+ReLU affine / virtual max-pool gradient) + group-max epilogue."""
+    nch_a = a_ab.numel() // 2 if a_ab is not None else 0
+    nch_b = b_ab.numel() // 2 if b_ab is not None else 0
+    L.call("vpf_gemm_bf16_fused", A, int(a_tr), lda, a_kind, a_ab, a_ab[nch_a:] if a_ab is not None else None, a_dout, a_arg,
+           a_group, a_ncols, Bm, int(b_tr), ldb, b_kind, b_ab, b_ab[nch_b:] if b_ab is not None else None, M, N, K, C, ldc,
+           int(c_f32), mode, bias, C2, ldc2, group, splitk, dbias)
+
+
+EPI_GROUPMAX = 7
+
+
 def linear_fwd(x16, w16, N, K, bias=None, *, out_f32=False, mode=EPI_STORE, **kw):
     """y[M,N] = x16[M,K] @ w16[N,K]^T (+bias, epilogue)."""
     M = x16.numel() // K
@@ -517,18 +530,27 @@ class Group2EmbFn(torch.autograd.Function):
         h3 = torch.empty(M, 256, dtype=BF16, device=dev)
         gemm(h2, 0, 128, w3[128:], 0, 256, M, 256, 128, h3, 256, c_f32=False, mode=EPI_GROUPBIAS, gbias=gb, group=K)
         stat2 = _bn_stat(h3, 256, bn2, training)
-        a3 = _bn_act(h3, 256, stat2, bn2, True, True)
-        h4 = linear_fwd(a3, shadow([c4.weight]), Dm, 256, c4.bias.data)                       # [M,Dm]
+        ab2 = torch.empty(512, dtype=F32, device=dev)
+        L.call("vpf_bn_affine", stat2, bn2.weight.data, bn2.bias.data, 256, ab2)
         out = torch.empty(NG, Dm, dtype=F32, device=dev)
         arg4 = torch.empty(NG, Dm, dtype=torch.uint8, device=dev)
-        L.call("vpf_group_max_fwd", h4, NG, K, Dm, out, 0, arg4)
-        ctx.mod, ctx.training, ctx.dims = mod, training, (Bq, G, K, C, Dm)
-        ctx.save_for_backward(x, stat1, a1, arg2, h2, gmax, h3, stat2, a3, arg4)
+        fused = (32 % K == 0) and (Dm % 8 == 0)
+        if fused:
+            # BatchNorm+ReLU applied while h3 is staged, max over the K members in the epilogue: neither the
+            # normalised activation nor the [M, Dm] conv output exists in HBM
+            gemm_fused(h3, 0, 256, shadow([c4.weight]), 0, 256, M, Dm, 256, out, Dm, c_f32=True, mode=EPI_GROUPMAX, a_kind=1,
+                       a_ab=ab2, bias=c4.bias.data, C2=arg4, ldc2=Dm, group=K)
+        else:
+            a3 = _bn_act(h3, 256, stat2, bn2, True, True)
+            h4 = linear_fwd(a3, shadow([c4.weight]), Dm, 256, c4.bias.data)
+            L.call("vpf_group_max_fwd", h4, NG, K, Dm, out, 0, arg4)
+        ctx.mod, ctx.training, ctx.dims, ctx.fused = mod, training, (Bq, G, K, C, Dm), fused
+        ctx.save_for_backward(x, stat1, a1, arg2, h2, gmax, h3, stat2, ab2, arg4)
         return out.view(Bq, G, Dm)
 
     @staticmethod
     def backward(ctx, dout):
-        x, stat1, a1, arg2, h2, gmax, h3, stat2, a3, arg4 = ctx.saved_tensors
+        x, stat1, a1, arg2, h2, gmax, h3, stat2, ab2, arg4 = ctx.saved_tensors
         mod, training = ctx.mod, ctx.training
         Bq, G, K, C, Dm = ctx.dims
         dev = dout.device
@@ -536,10 +558,20 @@ class Group2EmbFn(torch.autograd.Function):
         c1, bn1, c2 = mod.first_conv[0], mod.first_conv[1], mod.first_conv[3]
         c3, bn2, c4 = mod.second_conv[0], mod.second_conv[1], mod.second_conv[3]
         dout = dout.contiguous().float()
-        dh4 = torch.empty(M, Dm, dtype=BF16, device=dev)
-        L.call("vpf_group_max_bwd", dout, 0, arg4, NG, K, Dm, dh4)
-        linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight), grad_buf(c4.bias))
-        da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
+        if ctx.fused:
+            # d(conv output) = max-pool gradient: rebuilt on the fly from (dout, arg4) inside both GEMMs' A-operand
+            # loads; relu(bn(h3)) rebuilt inside the wgrad's B-operand load
+            gemm_fused(dout, 1, Dm, h3, 1, 256, Dm, 256, M, grad_buf(c4.weight), 256, c_f32=True, mode=EPI_ATOMIC, a_kind=2,
+                       a_dout=dout, a_arg=arg4, a_group=K, a_ncols=Dm, b_kind=1, b_ab=ab2, dbias=grad_buf(c4.bias))
+            da3 = torch.empty(M, 256, dtype=BF16, device=dev)
+            gemm_fused(dout, 0, Dm, shadow([c4.weight]), 1, 256, M, 256, Dm, da3, 256, c_f32=False, a_kind=2, a_dout=dout,
+                       a_arg=arg4, a_group=K, a_ncols=Dm)
+        else:
+            a3 = _bn_act(h3, 256, stat2, bn2, True, True)
+            dh4 = torch.empty(M, Dm, dtype=BF16, device=dev)
+            L.call("vpf_group_max_bwd", dout, 0, arg4, NG, K, Dm, dh4)
+            linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight), grad_buf(c4.bias))
+            da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
         dh3 = _bn_bwd(da3, h3, 256, stat2, bn2, True, training, True)
         # conv(256,256) on [global | local]: per-group part and per-point part
         w3 = shadow([c3.weight])
