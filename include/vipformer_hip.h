@@ -191,6 +191,17 @@ int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const flo
 int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
                       const float* gamma, const float* beta, int training, float* tmp128_zeroed, float* dW, float* db,
                       float* dgamma, float* dbeta, void* stream);
+/* Group2Emb forward for group_size == 32 as two persistent weight-stationary kernels (conv weights held in registers as
+ * MFMA fragments, activations of a pair of groups in LDS; only the pre-BN2 activation h3 and what backward needs reach HBM):
+ *   vpf_g2e_fold_bn1: BatchNorm-1 folded into the first conv (ab1 from vpf_bn_affine)
+ *   vpf_g2e_fwd_a:    x -> a1, h2, gmax/arg2 (max over members), h3 = conv3([gmax | h2]) ; sums512 += column sum | sum^2 of h3
+ *   vpf_g2e_fwd_b:    h3 -> BN2+ReLU -> conv4 -> max over members: out f32 [NG,Dm], arg4 */
+int vpf_g2e_fold_bn1(const float* W1, const float* b1, const float* ab1, int C, float* w1e, float* b1e, void* stream);
+int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, const float* b1e, const void* w2_bf16, const float* b2,
+                  const void* w3_bf16, const float* b3, void* a1, void* h2, void* gmax, uint8_t* arg2, void* h3,
+                  float* sums512_zeroed, void* stream);
+int vpf_g2e_fwd_b(const void* h3_bf16, long NG, const float* ab2, const void* w4_bf16, const float* b4, int Dm, float* out,
+                  uint8_t* arg4, void* stream);
 /* torch.max over the K group members (utils.py:180,188): h bf16 [NG,K,C] -> out [NG,C], arg uint8 (first max) */
 int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream);
 int vpf_group_max_bwd(const void* dout, int dout_is_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream);

@@ -518,32 +518,58 @@ class Group2EmbFn(torch.autograd.Function):
         else:
             L.call("vpf_bn_finalize", None, None, M, 64, float(bn1.eps), float(bn1.momentum), 0, bn1.running_mean,
                    bn1.running_var, None, stat1)
-        a1 = torch.empty(M, 64, dtype=BF16, device=dev)
-        L.call("vpf_g2e_conv1_apply", x, M, C, w1, c1.bias.data, stat1, bn1.weight.data, bn1.bias.data, a1)
-        h2 = linear_fwd(a1, shadow([c2.weight]), 128, 64, c2.bias.data)                      # [M,128]
-        gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
-        arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
-        L.call("vpf_group_max_fwd", h2, NG, K, 128, gmax, 1, arg2)
-        w3 = shadow([c3.weight])                                                              # [256, 256] = [global | local]
-        gb = torch.empty(NG, 256, dtype=F32, device=dev)
-        gemm(gmax, 0, 128, w3, 0, 256, NG, 256, 128, gb, 256, c_f32=True, bias=c3.bias.data)  # global . W[:, :128]^T + b
-        h3 = torch.empty(M, 256, dtype=BF16, device=dev)
-        gemm(h2, 0, 128, w3[128:], 0, 256, M, 256, 128, h3, 256, c_f32=False, mode=EPI_GROUPBIAS, gbias=gb, group=K)
-        stat2 = _bn_stat(h3, 256, bn2, training)
-        ab2 = torch.empty(512, dtype=F32, device=dev)
-        L.call("vpf_bn_affine", stat2, bn2.weight.data, bn2.bias.data, 256, ab2)
-        out = torch.empty(NG, Dm, dtype=F32, device=dev)
-        arg4 = torch.empty(NG, Dm, dtype=torch.uint8, device=dev)
-        fused = (32 % K == 0) and (Dm % 8 == 0)
-        if fused:
-            # BatchNorm+ReLU applied while h3 is staged, max over the K members in the epilogue: neither the
-            # normalised activation nor the [M, Dm] conv output exists in HBM
-            gemm_fused(h3, 0, 256, shadow([c4.weight]), 0, 256, M, Dm, 256, out, Dm, c_f32=True, mode=EPI_GROUPMAX, a_kind=1,
-                       a_ab=ab2, bias=c4.bias.data, C2=arg4, ldc2=Dm, group=K)
+        if K == 32 and C == 3 and Dm % 32 == 0 and Dm <= 512:
+            # two persistent weight-stationary kernels: activations of a pair of groups never leave the CU except h3
+            ab1 = torch.empty(128, dtype=F32, device=dev)
+            L.call("vpf_bn_affine", stat1, bn1.weight.data, bn1.bias.data, 64, ab1)
+            w1e = torch.empty(64 * C + 64, dtype=F32, device=dev)
+            L.call("vpf_g2e_fold_bn1", w1, c1.bias.data, ab1, C, w1e, w1e[64 * C:])
+            a1 = torch.empty(M, 64, dtype=BF16, device=dev)
+            h2 = torch.empty(M, 128, dtype=BF16, device=dev)
+            gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
+            arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
+            h3 = torch.empty(M, 256, dtype=BF16, device=dev)
+            sums2 = torch.zeros(512, dtype=F32, device=dev)
+            L.call("vpf_g2e_fwd_a", x, NG, C, w1e, w1e[64 * C:], shadow([c2.weight]), c2.bias.data, shadow([c3.weight]), c3.bias.data,
+                   a1, h2, gmax, arg2, h3, sums2)
+            stat2 = torch.empty(512, dtype=F32, device=dev)
+            if training:
+                L.call("vpf_bn_finalize", sums2[:256], sums2[256:], M, 256, float(bn2.eps), float(bn2.momentum), 1, bn2.running_mean,
+                       bn2.running_var, bn2.num_batches_tracked, stat2)
+            else:
+                L.call("vpf_bn_finalize", None, None, M, 256, float(bn2.eps), float(bn2.momentum), 0, bn2.running_mean,
+                       bn2.running_var, None, stat2)
+            ab2 = torch.empty(512, dtype=F32, device=dev)
+            L.call("vpf_bn_affine", stat2, bn2.weight.data, bn2.bias.data, 256, ab2)
+            out = torch.empty(NG, Dm, dtype=F32, device=dev)
+            arg4 = torch.empty(NG, Dm, dtype=torch.uint8, device=dev)
+            L.call("vpf_g2e_fwd_b", h3, NG, ab2, shadow([c4.weight]), c4.bias.data, Dm, out, arg4)
+            fused = True
         else:
-            a3 = _bn_act(h3, 256, stat2, bn2, True, True)
-            h4 = linear_fwd(a3, shadow([c4.weight]), Dm, 256, c4.bias.data)
-            L.call("vpf_group_max_fwd", h4, NG, K, Dm, out, 0, arg4)
+            a1 = torch.empty(M, 64, dtype=BF16, device=dev)
+            L.call("vpf_g2e_conv1_apply", x, M, C, w1, c1.bias.data, stat1, bn1.weight.data, bn1.bias.data, a1)
+            h2 = linear_fwd(a1, shadow([c2.weight]), 128, 64, c2.bias.data)                      # [M,128]
+            gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
+            arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
+            L.call("vpf_group_max_fwd", h2, NG, K, 128, gmax, 1, arg2)
+            w3 = shadow([c3.weight])                                                              # [256, 256] = [global | local]
+            gb = torch.empty(NG, 256, dtype=F32, device=dev)
+            gemm(gmax, 0, 128, w3, 0, 256, NG, 256, 128, gb, 256, c_f32=True, bias=c3.bias.data)  # global . W[:, :128]^T + b
+            h3 = torch.empty(M, 256, dtype=BF16, device=dev)
+            gemm(h2, 0, 128, w3[128:], 0, 256, M, 256, 128, h3, 256, c_f32=False, mode=EPI_GROUPBIAS, gbias=gb, group=K)
+            stat2 = _bn_stat(h3, 256, bn2, training)
+            ab2 = torch.empty(512, dtype=F32, device=dev)
+            L.call("vpf_bn_affine", stat2, bn2.weight.data, bn2.bias.data, 256, ab2)
+            out = torch.empty(NG, Dm, dtype=F32, device=dev)
+            arg4 = torch.empty(NG, Dm, dtype=torch.uint8, device=dev)
+            fused = (32 % K == 0) and (Dm % 8 == 0)
+            if fused:
+                gemm_fused(h3, 0, 256, shadow([c4.weight]), 0, 256, M, Dm, 256, out, Dm, c_f32=True, mode=EPI_GROUPMAX, a_kind=1,
+                           a_ab=ab2, bias=c4.bias.data, C2=arg4, ldc2=Dm, group=K)
+            else:
+                a3 = _bn_act(h3, 256, stat2, bn2, True, True)
+                h4 = linear_fwd(a3, shadow([c4.weight]), Dm, 256, c4.bias.data)
+                L.call("vpf_group_max_fwd", h4, NG, K, Dm, out, 0, arg4)
         ctx.mod, ctx.training, ctx.dims, ctx.fused = mod, training, (Bq, G, K, C, Dm), fused
         ctx.save_for_backward(x, stat1, a1, arg2, h2, gmax, h3, stat2, ab2, arg4)
         return out.view(Bq, G, Dm)
