@@ -202,6 +202,17 @@ int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, const float*
                   float* sums512_zeroed, void* stream);
 int vpf_g2e_fwd_b(const void* h3_bf16, long NG, const float* ab2, const void* w4_bf16, const float* b4, int Dm, float* out,
                   uint8_t* arg4, void* stream);
+/* Group2Emb backward, group_size == 32:
+ *   vpf_g2e_wgrad4: dW4 / db4 from the max-pool gradient (ONE non-zero per (group, column): 32x less work than a dense wgrad)
+ *   vpf_g2e_bwd (Dm <= 256): conv4 dgrad on MFMA from the rebuilt gradient tile, BatchNorm-2 backward (two passes), dh3, the
+ *                per-group sums dgb and dh2 = dh3 . W3[:,128:]  (w4t = W4^T [256,Dm], w3bt = W3[:,128:]^T [128,256], bf16)
+ *   vpf_transpose_bf16: dst[c][r] = src[r][c] */
+int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, const float* dout, const uint8_t* arg4, int Dm,
+                   float* dW4, float* db4, void* stream);
+int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_bf16, const float* stat2,
+                const float* gamma2, const float* beta2, const void* w4t_bf16, const void* w3bt_bf16, int training,
+                float* tmp512_zeroed, void* dh3_bf16, float* dgb, void* dh2_bf16, float* dgamma2, float* dbeta2, void* stream);
+int vpf_transpose_bf16(const void* src, long ld, int R, int C, void* dst, void* stream);
 /* torch.max over the K group members (utils.py:180,188): h bf16 [NG,K,C] -> out [NG,C], arg uint8 (first max) */
 int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream);
 int vpf_group_max_bwd(const void* dout, int dout_is_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream);

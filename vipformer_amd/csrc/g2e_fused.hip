@@ -286,3 +286,288 @@ extern "C" int vpf_g2e_fwd_b(const void* h3_bf16, long NG, const float* ab2, con
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
+
+// =============================================================================== backward (group_size == 32)
+// dW4[n,:] += sum_g dout[g,n] * a3[(g, arg4[g,n]), :]   and   db4[n] += sum_g dout[g,n]
+// The gradient of the last conv's output is the max-pool gradient: ONE non-zero per (group, column).  A dense wgrad
+// over all 32*NG rows does 32x the necessary work; here each thread owns 128 entries of one row of dW4 in registers
+// and walks the groups, fetching the winning row of a3 = relu(bn(h3)) from an LDS tile.
+struct G2eW4 {
+    const bf16_t* h3; long NG; const float* ab2;
+    const float* dout; const uint8_t* arg4; int Dm;
+    float* dW4; float* db4;                     // [Dm,256], [Dm]
+};
+__global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t sA3[2][32 * H3LD];
+    __shared__ float sD[2][256];
+    __shared__ uint8_t sR[2][256];
+    const int t = threadIdx.x, nl = t & 255, kh = t >> 8;
+    const int n = blockIdx.y * 256 + nl;
+    float aa[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { aa[j] = p.ab2[(t & 31) * 8 + j]; bb[j] = p.ab2[256 + (t & 31) * 8 + j]; }
+    float acc[128];
+#pragma unroll
+    for (int j = 0; j < 128; ++j) acc[j] = 0.f;
+    float accb = 0.f;
+
+    auto stage = [&](long g, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + i * 512, row = c >> 5, ch = c & 31;
+            uint4 v = *reinterpret_cast<const uint4*>(p.h3 + ((size_t)g * 32 + row) * 256 + ch * 8);
+            uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = pack_bf16x2(fmaxf(fmaf(aa[2 * j], __uint_as_float(u[j] << 16), bb[2 * j]), 0.f),
+                                   fmaxf(fmaf(aa[2 * j + 1], __uint_as_float(u[j] & 0xffff0000u), bb[2 * j + 1]), 0.f));
+            *reinterpret_cast<uint4*>(&sA3[buf][row * H3LD + ch * 8]) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
+        if (t < 256) {
+            const bool ok = n < p.Dm;
+            sD[buf][t] = ok ? p.dout[(size_t)g * p.Dm + n] : 0.f;
+            sR[buf][t] = ok ? p.arg4[(size_t)g * p.Dm + n] : 0;
+        }
+    };
+    long g = blockIdx.x;
+    int buf = 0;
+    if (g < p.NG) stage(g, 0);
+    __syncthreads();
+    for (; g < p.NG; g += gridDim.x) {
+        const long gn = g + gridDim.x;
+        if (gn < p.NG) stage(gn, buf ^ 1);
+        const float d = sD[buf][nl];
+        const bf16_t* row = &sA3[buf][(int)sR[buf][nl] * H3LD + kh * 128];
+        if (kh == 0) accb += d;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + q * 8);
+            const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[q * 8 + 2 * j] = fmaf(d, __uint_as_float(u[j] << 16), acc[q * 8 + 2 * j]);
+                acc[q * 8 + 2 * j + 1] = fmaf(d, __uint_as_float(u[j] & 0xffff0000u), acc[q * 8 + 2 * j + 1]);
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (n < p.Dm) {
+        float* dst = p.dW4 + (size_t)n * 256 + kh * 128;
+#pragma unroll
+        for (int j = 0; j < 128; ++j) atomicAdd(dst + j, acc[j]);
+        if (kh == 0) atomicAdd(p.db4 + n, accb);
+    }
+}
+extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, const float* dout, const uint8_t* arg4, int Dm,
+                              float* dW4, float* db4, void* stream)
+{
+    (void)hipGetLastError();
+    if (!h3_bf16 || !ab2 || !dout || !arg4 || !dW4 || !db4) return VPF_ERR_NULL;
+    if (NG <= 0 || Dm <= 0) return VPF_ERR_BADSHAPE;
+    G2eW4 p = {(const bf16_t*)h3_bf16, NG, ab2, dout, arg4, Dm, dW4, db4};
+    long gx = NG < 128 ? NG : 128;
+    hipLaunchKernelGGL(g2e_wgrad4_kernel, dim3((unsigned)gx, vpf_cdiv(Dm, 256)), dim3(512), 0, (hipStream_t)stream, p);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// dst[c][r] = src[r][c]  (bf16; k-strided weight operands of the persistent backward kernels are read from a transposed shadow)
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, long lds_, int R, int C, bf16_t* __restrict__ dst)
+{
+    __shared__ bf16_t tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) { const int r = r0 + i, c = c0 + threadIdx.x; tile[i][threadIdx.x] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : (bf16_t)0; }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) { const int c = c0 + i, r = r0 + threadIdx.x; if (c < C && r < R) dst[(size_t)c * R + r] = tile[threadIdx.x][i]; }
+}
+extern "C" int vpf_transpose_bf16(const void* src, long ld, int R, int C, void* dst, void* stream)
+{
+    (void)hipGetLastError();
+    if (!src || !dst) return VPF_ERR_NULL;
+    if (R <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(vpf_cdiv(C, 32), vpf_cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, (const bf16_t*)src, ld, R, C, (bf16_t*)dst);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// g2e_bwd kernels (Dm <= 256): per pair of groups the max-pool gradient tile dh4 [64 x Dm] is rebuilt in LDS from
+// (dout, arg4), da3 = dh4 . W4 runs on MFMA with W4^T fragments held in registers, and BatchNorm-2's backward is
+// applied in the accumulator layout (column = lane, so the per-channel statistics are per-lane scalars):
+//   PASS 0: tmp[c] += sum g, tmp[256+c] += sum g*xhat          (g = da3 * relu'(bn(h3)))
+//   PASS 1: dh3 = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M) -> HBM (bf16), dgb[g,:] = sum over the 32 members of dh3,
+//           dh2 = dh3 . W3[:,128:]  (W3b^T fragments in registers) -> HBM (bf16), without the max-pool term of the
+//           global feature (added afterwards by vpf_group_max_scatter_add)
+struct G2eBwd {
+    const float* dout; const uint8_t* arg4; int Dm; long NG;
+    const bf16_t* h3; const float* stat2; const float* gamma2; const float* beta2;
+    const bf16_t* w4t;            // [256][Dm]  (W4 transposed)
+    const bf16_t* w3bt;           // [128][256] (W3[:,128:] transposed)
+    float* tmp;                   // [512]
+    float invM; int training;
+    bf16_t* dh3; float* dgb; bf16_t* dh2;
+};
+
+template <int PASS>
+__global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
+{
+    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
+    bf16_t* sD4 = smem;                         // [64][H3LD]  dh4 tile (Dm <= 256), later dh2 staging
+    bf16_t* sH3 = smem + 64 * H3LD;             // [64][H3LD]  h3, overwritten by dh3
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, hl = lane >> 5, l31 = lane & 31;
+    const int KS4 = p.Dm / 16;                  // k-steps of the dh4 . W4 product (<= 16)
+    bf16x8_t w4f[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+        w4f[ks] = ks < KS4 ? ldfrag(p.w4t + (size_t)(w * 32 + l31) * p.Dm + ks * 16 + 8 * hl) : __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+    const int col = w * 32 + l31;
+    const float mean = p.stat2[col], rstd = p.stat2[256 + col], ga = p.gamma2[col], be = p.beta2[col];
+    float sg = 0.f, sgx = 0.f;
+    if (PASS == 1 && p.training) { sg = p.tmp[col] * p.invM; sgx = p.tmp[256 + col] * p.invM; }
+    // dh2 = dh3 . W3b : wave -> row tile rt2 = w >> 2, column tile ct2 = w & 3 of [64 x 128]
+    const int rt2 = w >> 2, ct2 = w & 3;
+    float a0 = 0.f, a1 = 0.f;
+
+    const long npairs = (p.NG + 1) / 2;
+    for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
+        const long row0 = pr * 64;
+        const long nrows = min((long)64, p.NG * 32 - row0);
+        // ---- stage dh4 (virtual) : thread = (group gi, 8-channel chunk ch, slice of 4 members)
+        {
+            const int gi = t >> 8, ch = (t >> 3) & 31, sl = t & 7;
+            const long g = pr * 2 + gi;
+            if (ch * 8 < p.Dm) {
+                uint32_t aw[2] = {0xffffffffu, 0xffffffffu};
+                float dd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (g < p.NG) {
+                    const size_t o = (size_t)g * p.Dm + ch * 8;
+                    const uint2 ar = *reinterpret_cast<const uint2*>(p.arg4 + o);
+                    aw[0] = ar.x; aw[1] = ar.y;
+                    const float4 d0 = *reinterpret_cast<const float4*>(p.dout + o), d1 = *reinterpret_cast<const float4*>(p.dout + o + 4);
+                    dd[0] = d0.x; dd[1] = d0.y; dd[2] = d0.z; dd[3] = d0.w; dd[4] = d1.x; dd[5] = d1.y; dd[6] = d1.z; dd[7] = d1.w;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = sl * 4 + i;
+                    uint32_t u[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e0 = (aw[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xff, e1 = (aw[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xff;
+                        u[j] = pack_bf16x2(e0 == k ? dd[2 * j] : 0.f, e1 == k ? dd[2 * j + 1] : 0.f);
+                    }
+                    *reinterpret_cast<uint4*>(sD4 + (gi * 32 + k) * H3LD + ch * 8) = make_uint4(u[0], u[1], u[2], u[3]);
+                }
+            }
+        }
+        // ---- stage h3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + i * 512, row = c >> 5, ch = c & 31;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < nrows) v = *reinterpret_cast<const uint4*>(p.h3 + (size_t)(row0 + row) * 256 + ch * 8);
+            *reinterpret_cast<uint4*>(sH3 + row * H3LD + ch * 8) = v;
+        }
+        __syncthreads();
+        // ---- da3 tile (columns w*32.., both row tiles)
+        f32x16_t acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+            if (ks < KS4) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sD4 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[ks], acc[rt], 0, 0, 0);
+            }
+        float gsum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                const float xh = (bf16_to_f32(sH3[row * H3LD + col]) - mean) * rstd;
+                float g = bf16_to_f32(f32_to_bf16(acc[rt][r]));            // da3 is a bf16 tensor in the unfused path
+                if (xh * ga + be <= 0.f || row >= nrows) g = 0.f;
+                if (PASS == 0) { a0 += g; a1 += g * xh; }
+                else {
+                    const float dv = p.training ? ga * rstd * (g - sg - xh * sgx) : ga * rstd * g;
+                    const bf16_t db = (row < nrows) ? f32_to_bf16(dv) : (bf16_t)0;
+                    sH3[row * H3LD + col] = db;
+                    gsum[rt] += bf16_to_f32(db);
+                }
+            }
+        if (PASS == 1) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float s = gsum[rt] + __shfl_xor(gsum[rt], 32, 64);
+                const long g = pr * 2 + rt;
+                if (hl == 0 && g < p.NG) p.dgb[(size_t)g * 256 + col] = s;
+            }
+            __syncthreads();                                       // dh3 tile complete; dh4 tile no longer needed
+            for (int c = t; c < 64 * 32; c += 512) {
+                const int row = c >> 5, ch = c & 31;
+                if (row < nrows) *reinterpret_cast<uint4*>(p.dh3 + (size_t)(row0 + row) * 256 + ch * 8) = *reinterpret_cast<const uint4*>(sH3 + row * H3LD + ch * 8);
+            }
+            f32x16_t a2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+            // W3b^T fragments come from L2 every pair (64 more live registers would spill); the pointer is laundered so the
+            // loads are not hoisted out of the persistent loop
+            const bf16_t* wp = p.w3bt + (size_t)(ct2 * 32 + l31) * 256 + 8 * hl;
+            asm volatile("" : "+v"(wp));
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sH3 + (rt2 * 32 + l31) * H3LD + ks * 16 + 8 * hl), ldfrag(wp + ks * 16), a2, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                sD4[row * H2LD + ct2 * 32 + l31] = f32_to_bf16(a2[r]);
+            }
+            __syncthreads();
+            for (int c = t; c < 64 * 16; c += 512) {
+                const int row = c >> 4, ch = c & 15;
+                if (row < nrows) *reinterpret_cast<uint4*>(p.dh2 + (size_t)(row0 + row) * 128 + ch * 8) = *reinterpret_cast<const uint4*>(sD4 + row * H2LD + ch * 8);
+            }
+        }
+        __syncthreads();
+    }
+    if (PASS == 0) {
+        a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
+        if (hl == 0) { atomicAdd(p.tmp + col, a0); atomicAdd(p.tmp + 256 + col, a1); }
+    }
+}
+
+// Group2Emb backward through conv4 / BatchNorm-2 / conv3's per-point half for group_size 32, Dm <= 256 (see above).
+// tmp512_zeroed: f32 scratch.  Also accumulates dgamma2 / dbeta2.
+__global__ void g2e_bn2_param_grad_kernel(const float* __restrict__ tmp, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int c = threadIdx.x;
+    if (c < 256) { atomicAdd(dgamma + c, tmp[256 + c]); atomicAdd(dbeta + c, tmp[c]); }
+}
+extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_bf16, const float* stat2,
+                           const float* gamma2, const float* beta2, const void* w4t_bf16, const void* w3bt_bf16, int training,
+                           float* tmp512_zeroed, void* dh3_bf16, float* dgb, void* dh2_bf16, float* dgamma2, float* dbeta2, void* stream)
+{
+    (void)hipGetLastError();
+    if (!dout || !arg4 || !h3_bf16 || !stat2 || !gamma2 || !beta2 || !w4t_bf16 || !w3bt_bf16 || !tmp512_zeroed || !dh3_bf16 || !dgb || !dh2_bf16 ||
+        !dgamma2 || !dbeta2) return VPF_ERR_NULL;
+    if (NG <= 0 || Dm <= 0 || Dm > 256 || (Dm % 16)) return VPF_ERR_BADSHAPE;
+    G2eBwd p = {dout, arg4, Dm, NG, (const bf16_t*)h3_bf16, stat2, gamma2, beta2, (const bf16_t*)w4t_bf16, (const bf16_t*)w3bt_bf16, tmp512_zeroed,
+                1.0f / (float)(NG * 32), training, (bf16_t*)dh3_bf16, dgb, (bf16_t*)dh2_bf16};
+    const size_t lds = sizeof(bf16_t) * 2 * 64 * H3LD;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    long grid = (NG + 1) / 2; if (grid > 256) grid = 256;
+    hipStream_t st = (hipStream_t)stream;
+    if (training) hipLaunchKernelGGL(g2e_bwd_kernel<0>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(g2e_bwd_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    if (training) hipLaunchKernelGGL(g2e_bn2_param_grad_kernel, dim3(1), dim3(256), 0, st, (const float*)tmp512_zeroed, dgamma2, dbeta2);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}

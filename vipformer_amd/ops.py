@@ -584,34 +584,49 @@ class Group2EmbFn(torch.autograd.Function):
         c1, bn1, c2 = mod.first_conv[0], mod.first_conv[1], mod.first_conv[3]
         c3, bn2, c4 = mod.second_conv[0], mod.second_conv[1], mod.second_conv[3]
         dout = dout.contiguous().float()
-        if ctx.fused:
-            # d(conv output) = max-pool gradient: rebuilt on the fly from (dout, arg4) inside both GEMMs' A-operand
-            # loads; relu(bn(h3)) rebuilt inside the wgrad's B-operand load
-            gemm_fused(dout, 1, Dm, h3, 1, 256, Dm, 256, M, grad_buf(c4.weight), 256, c_f32=True, mode=EPI_ATOMIC, a_kind=2,
-                       a_dout=dout, a_arg=arg4, a_group=K, a_ncols=Dm, b_kind=1, b_ab=ab2, dbias=grad_buf(c4.bias))
-            da3 = torch.empty(M, 256, dtype=BF16, device=dev)
-            gemm_fused(dout, 0, Dm, shadow([c4.weight]), 1, 256, M, 256, Dm, da3, 256, c_f32=False, a_kind=2, a_dout=dout,
-                       a_arg=arg4, a_group=K, a_ncols=Dm)
-        else:
-            a3 = _bn_act(h3, 256, stat2, bn2, True, True)
-            dh4 = torch.empty(M, Dm, dtype=BF16, device=dev)
-            L.call("vpf_group_max_bwd", dout, 0, arg4, NG, K, Dm, dh4)
-            linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight), grad_buf(c4.bias))
-            da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
-        dh3 = _bn_bwd(da3, h3, 256, stat2, bn2, True, training, True)
-        # conv(256,256) on [global | local]: per-group part and per-point part
         w3 = shadow([c3.weight])
         gW3 = grad_buf(c3.weight).view(256, 256)
-        dgb = torch.empty(NG, 256, dtype=F32, device=dev)
-        L.call("vpf_group_sum", dh3, NG, K, 256, dgb)                                        # d(per-group bias)
+        if ctx.fused and K == 32 and C == 3 and Dm <= 256 and Dm % 16 == 0:
+            # persistent fused path: sparse wgrad of the last conv, then dgrad + BatchNorm-2 backward + conv3 dgrad on MFMA
+            # with transposed weight fragments in registers; only dh3 / dh2 reach HBM
+            w4t = torch.empty(256 * Dm, dtype=BF16, device=dev)
+            L.call("vpf_transpose_bf16", shadow([c4.weight]), 256, Dm, 256, w4t)
+            w3bt = torch.empty(128 * 256, dtype=BF16, device=dev)
+            L.call("vpf_transpose_bf16", w3[128:], 256, 256, 128, w3bt)
+            L.call("vpf_g2e_wgrad4", h3, NG, ab2, dout, arg4, Dm, grad_buf(c4.weight), grad_buf(c4.bias))
+            tmp2 = torch.zeros(512, dtype=F32, device=dev)
+            dh3 = torch.empty(M, 256, dtype=BF16, device=dev)
+            dgb = torch.empty(NG, 256, dtype=F32, device=dev)
+            dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
+            L.call("vpf_g2e_bwd", dout, arg4, Dm, NG, h3, stat2, bn2.weight.data, bn2.bias.data, w4t, w3bt, int(training), tmp2, dh3,
+                   dgb, dh2, grad_buf(bn2.weight), grad_buf(bn2.bias))
+        else:
+            if ctx.fused:
+                # d(conv output) = max-pool gradient: rebuilt on the fly from (dout, arg4) inside both GEMMs' A-operand
+                # loads; relu(bn(h3)) rebuilt inside the wgrad's B-operand load
+                gemm_fused(dout, 1, Dm, h3, 1, 256, Dm, 256, M, grad_buf(c4.weight), 256, c_f32=True, mode=EPI_ATOMIC, a_kind=2,
+                           a_dout=dout, a_arg=arg4, a_group=K, a_ncols=Dm, b_kind=1, b_ab=ab2, dbias=grad_buf(c4.bias))
+                da3 = torch.empty(M, 256, dtype=BF16, device=dev)
+                gemm_fused(dout, 0, Dm, shadow([c4.weight]), 1, 256, M, 256, Dm, da3, 256, c_f32=False, a_kind=2, a_dout=dout,
+                           a_arg=arg4, a_group=K, a_ncols=Dm)
+            else:
+                a3 = _bn_act(h3, 256, stat2, bn2, True, True)
+                dh4 = torch.empty(M, Dm, dtype=BF16, device=dev)
+                L.call("vpf_group_max_bwd", dout, 0, arg4, NG, K, Dm, dh4)
+                linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight), grad_buf(c4.bias))
+                da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
+            dh3 = _bn_bwd(da3, h3, 256, stat2, bn2, True, training, True)
+            # conv(256,256) on [global | local]: per-group part and per-point part
+            dgb = torch.empty(NG, 256, dtype=F32, device=dev)
+            L.call("vpf_group_sum", dh3, NG, K, 256, dgb)                                        # d(per-group bias)
+            dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
+            gemm(dh3, 0, 256, w3[128:], 1, 256, M, 128, 256, dh2, 128, c_f32=False)                            # dlocal
         colsum(dgb, 256, grad_buf(c3.bias))
         dgb16 = to_bf16(dgb)
         gemm(dgb16, 1, 256, gmax, 1, 128, 256, 128, NG, gW3, 256, c_f32=True, mode=EPI_ATOMIC)            # dW[:, :128]
         gemm(dh3, 1, 256, h2, 1, 128, 256, 128, M, gW3[:, 128:], 256, c_f32=True, mode=EPI_ATOMIC)        # dW[:, 128:]
         dgmax = torch.empty(NG, 128, dtype=BF16, device=dev)
         gemm(dgb16, 0, 256, w3, 1, 256, NG, 128, 256, dgmax, 128, c_f32=False)                             # dglobal
-        dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
-        gemm(dh3, 0, 256, w3[128:], 1, 256, M, 128, 256, dh2, 128, c_f32=False)                            # dlocal
         L.call("vpf_group_max_scatter_add", dgmax, arg2, NG, K, 128, dh2)
         linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
         da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
