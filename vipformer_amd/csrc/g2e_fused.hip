@@ -353,11 +353,22 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
         __syncthreads();
         buf ^= 1;
     }
-    if (n < p.Dm) {
-        float* dst = p.dW4 + (size_t)n * 256 + kh * 128;
+    // flush: a wave-wide atomic must cover contiguous bytes (64 lanes in 64 different rows run ~17x slower), so the
+    // per-thread rows are transposed through LDS 64 rows of dW4 at a time and added as 256-byte row segments
+    float* tile = reinterpret_cast<float*>(&sA3[0][0]);            // 32 x 256 fp32 = 32 KB <= 2 x 32 x H3LD x 2 B
+    static_assert(sizeof(bf16_t) * 2 * 32 * H3LD >= 32 * 256 * 4, "flush tile must fit in the staging buffers");
+    if (kh == 0 && n < p.Dm) atomicAdd(p.db4 + n, accb);
+    for (int rr = 0; rr < 8; ++rr) {
+        __syncthreads();
+        if ((nl >> 5) == rr) {
 #pragma unroll
-        for (int j = 0; j < 128; ++j) atomicAdd(dst + j, acc[j]);
-        if (kh == 0) atomicAdd(p.db4 + n, accb);
+            for (int j = 0; j < 128; ++j) tile[(nl & 31) * 256 + kh * 128 + j] = acc[j];
+        }
+        __syncthreads();
+        for (int e = t; e < 32 * 256; e += 512) {
+            const int nn = blockIdx.y * 256 + rr * 32 + (e >> 8);
+            if (nn < p.Dm) atomicAdd(p.dW4 + (size_t)nn * 256 + (e & 255), tile[e]);
+        }
     }
 }
 extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, const float* dout, const uint8_t* arg4, int Dm,

@@ -316,57 +316,63 @@ extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-// backward: pass 1 (reduce) tmp[c] += sum g, tmp[64+c] += sum g*xhat ; pass 2 dW/db (and dgamma/dbeta from tmp)
-__global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
+// backward: pass 0 tmp[c] += sum g, tmp[64+c] += sum g*xhat ; pass 1 dW/db (and dgamma/dbeta from tmp).
+// thread = (row, 8 channels): 16-byte loads of the incoming gradient, per-thread partial sums, LDS fold per block.
+__global__ void __launch_bounds__(512) g2e_conv1_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
                                                           const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ stat,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int training,
                                                           float* __restrict__ tmp, int pass, float* __restrict__ dW, float* __restrict__ db,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta)
 {
-    const int lane = threadIdx.x & 63;
-    const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
-    float w[AD_MAXC], aw[AD_MAXC];
+    __shared__ float red[64][8][5];              // [row lane][channel in group][value]  (per 8-channel group pass)
+    const int t = threadIdx.x, rl = t >> 3, cg = (t & 7) * 8;
+    float w[8][3], bb[8], mu[8], rs[8], ga[8], be[8], sg[8], sgx[8];
 #pragma unroll
-    for (int j = 0; j < AD_MAXC; ++j) { w[j] = j < C ? W[lane * C + j] : 0.f; aw[j] = 0.f; }
-    const float bb = b[lane], mu = stat[lane], rs = stat[64 + lane], ga = gamma[lane], be = beta[lane];
-    const float invM = 1.f / (float)M;
-    const float sg = pass ? tmp[lane] * invM : 0.f, sgx = pass ? tmp[64 + lane] * invM : 0.f;
-    float a0 = 0.f, a1 = 0.f;
-    constexpr int U = 8;
-    for (long r0 = wave0 * U; r0 < M; r0 += nw * U) {
-        float xv[U][AD_MAXC], gin[U];
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg + j;
+        bb[j] = b[c]; mu[j] = stat[c]; rs[j] = stat[64 + c]; ga[j] = gamma[c]; be[j] = beta[c];
+        sg[j] = pass ? tmp[c] / (float)M : 0.f; sgx[j] = pass ? tmp[64 + c] / (float)M : 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool ok = r0 + u < M;
-            const long r = ok ? r0 + u : M - 1;
+        for (int i = 0; i < 3; ++i) w[j][i] = i < C ? W[c * C + i] : 0.f;
+    }
+    float a0[8], a1[8], aw[8][3];
 #pragma unroll
-            for (int j = 0; j < AD_MAXC; ++j) xv[u][j] = (j < C && ok) ? x[(size_t)r * C + j] : 0.f;
-            gin[u] = ok ? bf16_to_f32(da[(size_t)r * 64 + lane]) : 0.f;
-        }
+    for (int j = 0; j < 8; ++j) { a0[j] = a1[j] = 0.f; aw[j][0] = aw[j][1] = aw[j][2] = 0.f; }
+    for (long r = (long)blockIdx.x * 64 + rl; r < M; r += (long)gridDim.x * 64) {
+        const uint4 dv = *reinterpret_cast<const uint4*>(da + (size_t)r * 64 + cg);
+        const float x0 = x[(size_t)r * C], x1 = C > 1 ? x[(size_t)r * C + 1] : 0.f, x2 = C > 2 ? x[(size_t)r * C + 2] : 0.f;
+        const uint32_t u[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float h = bb;
-#pragma unroll
-            for (int j = 0; j < AD_MAXC; ++j) h += w[j] * xv[u][j];
-            const float xh = (h - mu) * rs;
-            float g = gin[u];
-            if (xh * ga + be <= 0.f) g = 0.f;
-            if (!pass) { a0 += g; a1 += g * xh; }
+        for (int j = 0; j < 8; ++j) {
+            const float h = w[j][0] * x0 + w[j][1] * x1 + w[j][2] * x2 + bb[j];
+            const float xh = (h - mu[j]) * rs[j];
+            float g = (j & 1) ? __uint_as_float(u[j >> 1] & 0xffff0000u) : __uint_as_float(u[j >> 1] << 16);
+            if (xh * ga[j] + be[j] <= 0.f) g = 0.f;
+            if (!pass) { a0[j] += g; a1[j] += g * xh; }
             else {
-                const float dh = (r0 + u < M) ? (training ? ga * rs * (g - sg - xh * sgx) : ga * rs * g) : 0.f;
-                a0 += dh;
-#pragma unroll
-                for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[u][j];
+                const float dh = training ? ga[j] * rs[j] * (g - sg[j] - xh * sgx[j]) : ga[j] * rs[j] * g;
+                a0[j] += dh; aw[j][0] += dh * x0; aw[j][1] += dh * x1; aw[j][2] += dh * x2;
             }
         }
     }
-    if (!pass) { atomicAdd(tmp + lane, a0); atomicAdd(tmp + 64 + lane, a1); }
-    else {
-        atomicAdd(db + lane, a0);
+    // fold the 64 row-lanes of every channel; one atomic per (block, value)
+    for (int grp = 0; grp < 8; ++grp) {
+        __syncthreads();
+        if ((t & 7) == grp) {
 #pragma unroll
-        for (int j = 0; j < AD_MAXC; ++j) if (j < C) atomicAdd(dW + lane * C + j, aw[j]);
-        if (blockIdx.x == 0 && threadIdx.x < 64) { atomicAdd(dgamma + lane, tmp[64 + lane]); atomicAdd(dbeta + lane, tmp[lane]); }
+            for (int j = 0; j < 8; ++j) { red[rl][j][0] = a0[j]; red[rl][j][1] = a1[j]; red[rl][j][2] = aw[j][0]; red[rl][j][3] = aw[j][1]; red[rl][j][4] = aw[j][2]; }
+        }
+        __syncthreads();
+        if (t < 40) {
+            const int j = t / 5, v = t % 5;
+            float s = 0.f;
+            for (int k = 0; k < 64; ++k) s += red[k][j][v];
+            const int c = grp * 8 + j;
+            if (!pass) { if (v == 0) atomicAdd(tmp + c, s); else if (v == 1) atomicAdd(tmp + 64 + c, s); }
+            else { if (v == 0) atomicAdd(db + c, s); else if (v >= 2 && v - 2 < C) atomicAdd(dW + c * C + (v - 2), s); }
+        }
     }
+    if (pass && blockIdx.x == 0 && t < 64) { atomicAdd(dgamma + t, tmp[64 + t]); atomicAdd(dbeta + t, tmp[t]); }
 }
 extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
                                  const float* gamma, const float* beta, int training, float* tmp128_zeroed, float* dW, float* db,
@@ -374,10 +380,10 @@ extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, in
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !tmp128_zeroed || !dW || !db || !dgamma || !dbeta) return VPF_ERR_NULL;
-    if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
-    const int grid = grid_for(M, 512, 1024);
+    if (M <= 0 || C <= 0 || C > 3) return VPF_ERR_BADSHAPE;
+    const int grid = grid_for(M, 64 * 8, 1024);
     for (int pass = 0; pass < 2; ++pass)
-        hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma,
+        hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma,
                            beta, training, tmp128_zeroed, pass, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
