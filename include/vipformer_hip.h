@@ -211,7 +211,8 @@ int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, const float* 
                    float* dW4, float* db4, void* stream);
 int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_bf16, const float* stat2,
                 const float* gamma2, const float* beta2, const void* w4t_bf16, const void* w3bt_bf16, int training,
-                float* tmp512_zeroed, void* dh3_bf16, float* dgb, void* dh2_bf16, float* dgamma2, float* dbeta2, void* stream);
+                float* tmp512_zeroed, void* dh3_bf16, float* dgb, void* dh2_bf16, float* dgamma2, float* dbeta2,
+                long long* dbg_cycles /* nullable diagnostic: [256*2*6] per-phase cycle sums */, void* stream);
 int vpf_transpose_bf16(const void* src, long ld, int R, int C, void* dst, void* stream);
 /* torch.max over the K group members (utils.py:180,188): h bf16 [NG,K,C] -> out [NG,C], arg uint8 (first max) */
 int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream);

@@ -61,6 +61,30 @@ def gemm():
         print(f"gemm {tag} M={M} N={N} K={K}: fwd {t1:.1f} us ({fl/t1/1e6:.0f} TF/s) dgrad {t2:.1f} us ({fl/t2/1e6:.0f} TF/s) wgrad {t3:.1f} us ({fl/t3/1e6:.0f} TF/s)")
 
 
+def g2e():
+    """Group2Emb forward/backward at the benchmark size + per-phase cycle stamps of the fused backward."""
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.utils import Group2Emb
+    torch.manual_seed(0)
+    m = Group2Emb(256).cuda().train()
+    x = torch.randn(128, 96, 32, 3, device="cuda")
+    y = m(x); g = torch.randn_like(y)
+    def step():
+        y = m(x); y.backward(g)
+    for _ in range(3): step()
+    torch.cuda.synchronize()
+    print("g2e fwd+bwd %.1f us" % timeit(step, 10, 2))
+    dbg = torch.zeros(256 * 2 * 6, dtype=torch.int64, device="cuda")
+    ops.G2E_DEBUG["dbg"] = dbg
+    step(); torch.cuda.synchronize()
+    d = dbg.view(256, 2, 6).double().mean(0)
+    names = ["stage+barrier", "mfma da3", "bn epilogue+barrier", "dh3 store", "mfma dh2 + stage + barrier", "dh2 store + barrier"]
+    for ps in range(2):
+        tot = d[ps].sum().item()
+        print("pass", ps, "cycles/WG %.0f:" % tot, ", ".join(f"{n} {v/tot*100:.0f}%" for n, v in zip(names, d[ps].tolist())))
+    ops.G2E_DEBUG.clear()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["preproc"]
     for w in which:

@@ -419,6 +419,7 @@ struct G2eBwd {
     float* tmp;                   // [512]
     float invM; int training;
     bf16_t* dh3; float* dgb; bf16_t* dh2;
+    long long* dbg;               // diagnostic: per-phase cycle sums of wave 0 of every workgroup (nullable)
 };
 
 template <int PASS>
@@ -442,6 +443,19 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     float a0 = 0.f, a1 = 0.f;
 
     const long npairs = (p.NG + 1) / 2;
+    uint4 rh[4];
+    auto load_h3 = [&](long pr) {
+        const long r0 = pr * 64, nr = min((long)64, p.NG * 32 - r0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + i * 512, row = c >> 5, ch = c & 31;
+            rh[i] = (pr < npairs && row < nr) ? *reinterpret_cast<const uint4*>(p.h3 + (size_t)(r0 + row) * 256 + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    load_h3(blockIdx.x);
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
+#define STAMP(i) do { if (p.dbg) { t1 = clock64(); ph[i] += t1 - t0; t0 = t1; } } while (0)
+    if (p.dbg) t0 = clock64();
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long row0 = pr * 64;
         const long nrows = min((long)64, p.NG * 32 - row0);
@@ -459,28 +473,31 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                     const float4 d0 = *reinterpret_cast<const float4*>(p.dout + o), d1 = *reinterpret_cast<const float4*>(p.dout + o + 4);
                     dd[0] = d0.x; dd[1] = d0.y; dd[2] = d0.z; dd[3] = d0.w; dd[4] = d1.x; dd[5] = d1.y; dd[6] = d1.z; dd[7] = d1.w;
                 }
+                // the 8 gradients as bf16 pairs once; every member row then keeps a pair element iff it won the max
+                uint32_t dp[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dp[j] = pack_bf16x2(dd[2 * j], dd[2 * j + 1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int k = sl * 4 + i;
+                    const uint32_t k = (uint32_t)(sl * 4 + i);
                     uint32_t u[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int e0 = (aw[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xff, e1 = (aw[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xff;
-                        u[j] = pack_bf16x2(e0 == k ? dd[2 * j] : 0.f, e1 == k ? dd[2 * j + 1] : 0.f);
+                        const uint32_t e0 = (aw[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xffu, e1 = (aw[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xffu;
+                        u[j] = (e0 == k ? (dp[j] & 0x0000ffffu) : 0u) | (e1 == k ? (dp[j] & 0xffff0000u) : 0u);
                     }
                     *reinterpret_cast<uint4*>(sD4 + (gi * 32 + k) * H3LD + ch * 8) = make_uint4(u[0], u[1], u[2], u[3]);
                 }
             }
         }
-        // ---- stage h3
+        // ---- stage h3 (requested at the end of the previous iteration, ahead of that iteration's stores)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = t + i * 512, row = c >> 5, ch = c & 31;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < nrows) v = *reinterpret_cast<const uint4*>(p.h3 + (size_t)(row0 + row) * 256 + ch * 8);
-            *reinterpret_cast<uint4*>(sH3 + row * H3LD + ch * 8) = v;
+            *reinterpret_cast<uint4*>(sH3 + row * H3LD + ch * 8) = rh[i];
         }
         __syncthreads();
+        STAMP(0);
         // ---- da3 tile (columns w*32.., both row tiles)
         f32x16_t acc[2];
 #pragma unroll
@@ -492,23 +509,38 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                 for (int rt = 0; rt < 2; ++rt)
                     acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sD4 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[ks], acc[rt], 0, 0, 0);
             }
+        STAMP(1);
+        if (PASS == 0) load_h3(pr + gridDim.x);
         float gsum[2] = {0.f, 0.f};
+        // all 32 h3 values of this lane first (independent LDS reads in flight together), then the math, then the stores
+        bf16_t hraw[2][16];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hraw[rt][r] = sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col];
+        bf16_t dres[2][16];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                const float xh = (bf16_to_f32(sH3[row * H3LD + col]) - mean) * rstd;
+                const float xh = (bf16_to_f32(hraw[rt][r]) - mean) * rstd;
                 float g = bf16_to_f32(f32_to_bf16(acc[rt][r]));            // da3 is a bf16 tensor in the unfused path
                 if (xh * ga + be <= 0.f || row >= nrows) g = 0.f;
                 if (PASS == 0) { a0 += g; a1 += g * xh; }
                 else {
                     const float dv = p.training ? ga * rstd * (g - sg - xh * sgx) : ga * rstd * g;
                     const bf16_t db = (row < nrows) ? f32_to_bf16(dv) : (bf16_t)0;
-                    sH3[row * H3LD + col] = db;
+                    dres[rt][r] = db;
                     gsum[rt] += bf16_to_f32(db);
                 }
             }
+        if (PASS == 1) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col] = dres[rt][r];
+        }
         if (PASS == 1) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
@@ -517,10 +549,13 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                 if (hl == 0 && g < p.NG) p.dgb[(size_t)g * 256 + col] = s;
             }
             __syncthreads();                                       // dh3 tile complete; dh4 tile no longer needed
+            STAMP(2);
+            load_h3(pr + gridDim.x);
             for (int c = t; c < 64 * 32; c += 512) {
                 const int row = c >> 5, ch = c & 31;
                 if (row < nrows) *reinterpret_cast<uint4*>(p.dh3 + (size_t)(row0 + row) * 256 + ch * 8) = *reinterpret_cast<const uint4*>(sH3 + row * H3LD + ch * 8);
             }
+            STAMP(3);
             f32x16_t a2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a2[r] = 0.f;
@@ -537,13 +572,17 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                 sD4[row * H2LD + ct2 * 32 + l31] = f32_to_bf16(a2[r]);
             }
             __syncthreads();
+            STAMP(4);
             for (int c = t; c < 64 * 16; c += 512) {
                 const int row = c >> 4, ch = c & 15;
                 if (row < nrows) *reinterpret_cast<uint4*>(p.dh2 + (size_t)(row0 + row) * 128 + ch * 8) = *reinterpret_cast<const uint4*>(sD4 + row * H2LD + ch * 8);
             }
         }
         __syncthreads();
+        STAMP(5);
     }
+    if (p.dbg && t == 0) { for (int i = 0; i < 6; ++i) p.dbg[(size_t)(blockIdx.x * 2 + PASS) * 6 + i] = ph[i]; }
+#undef STAMP
     if (PASS == 0) {
         a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
         if (hl == 0) { atomicAdd(p.tmp + col, a0); atomicAdd(p.tmp + 256 + col, a1); }
@@ -559,14 +598,15 @@ __global__ void g2e_bn2_param_grad_kernel(const float* __restrict__ tmp, float* 
 }
 extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_bf16, const float* stat2,
                            const float* gamma2, const float* beta2, const void* w4t_bf16, const void* w3bt_bf16, int training,
-                           float* tmp512_zeroed, void* dh3_bf16, float* dgb, void* dh2_bf16, float* dgamma2, float* dbeta2, void* stream)
+                           float* tmp512_zeroed, void* dh3_bf16, float* dgb, void* dh2_bf16, float* dgamma2, float* dbeta2, long long* dbg,
+                           void* stream)
 {
     (void)hipGetLastError();
     if (!dout || !arg4 || !h3_bf16 || !stat2 || !gamma2 || !beta2 || !w4t_bf16 || !w3bt_bf16 || !tmp512_zeroed || !dh3_bf16 || !dgb || !dh2_bf16 ||
         !dgamma2 || !dbeta2) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0 || Dm > 256 || (Dm % 16)) return VPF_ERR_BADSHAPE;
     G2eBwd p = {dout, arg4, Dm, NG, (const bf16_t*)h3_bf16, stat2, gamma2, beta2, (const bf16_t*)w4t_bf16, (const bf16_t*)w3bt_bf16, tmp512_zeroed,
-                1.0f / (float)(NG * 32), training, (bf16_t*)dh3_bf16, dgb, (bf16_t*)dh2_bf16};
+                1.0f / (float)(NG * 32), training, (bf16_t*)dh3_bf16, dgb, (bf16_t*)dh2_bf16, dbg};
     const size_t lds = sizeof(bf16_t) * 2 * 64 * H3LD;
     static bool attr = false;
     if (!attr) {

@@ -490,6 +490,9 @@ def _bn_bwd(dy, x, C, stat, bn, relu, training, out_bf16, want_dx=True):
 
 
 # --------------------------------------------------------------------------- Group2Emb (utils.py:144-189)
+G2E_DEBUG = {}      # {"dbg": int64 tensor [256*2*6]} -> per-phase cycle stamps of vpf_g2e_bwd (diagnostic)
+
+
 class Group2EmbFn(torch.autograd.Function):
     """conv(C,64) BN ReLU conv(64,128) -> max over K -> cat[global, local] -> conv(256,256) BN ReLU conv(256,D) -> max over K.
 
@@ -599,7 +602,7 @@ class Group2EmbFn(torch.autograd.Function):
             dgb = torch.empty(NG, 256, dtype=F32, device=dev)
             dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
             L.call("vpf_g2e_bwd", dout, arg4, Dm, NG, h3, stat2, bn2.weight.data, bn2.bias.data, w4t, w3bt, int(training), tmp2, dh3,
-                   dgb, dh2, grad_buf(bn2.weight), grad_buf(bn2.bias))
+                   dgb, dh2, grad_buf(bn2.weight), grad_buf(bn2.bias), G2E_DEBUG.get("dbg"))
         else:
             if ctx.fused:
                 # d(conv output) = max-pool gradient: rebuilt on the fly from (dout, arg4) inside both GEMMs' A-operand
