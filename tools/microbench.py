@@ -85,6 +85,21 @@ def g2e():
     ops.G2E_DEBUG.clear()
 
 
+def gemmk():
+    """Sensitivity of the small GEMM to K (fixed M=12288, N=256) and to the output type: separates the fixed
+    (launch + prologue + epilogue) cost from the per-k-step cost."""
+    from vipformer_amd import ops
+    M, N = 12288, 256
+    for K in (32, 64, 128, 256, 512, 1024, 2048):
+        A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+        y16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); y32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        t1 = timeit(lambda: ops.gemm(A, 0, K, W, 0, K, M, N, K, y16, N, c_f32=False), 30, 5)
+        t2 = timeit(lambda: ops.gemm(A, 0, K, W, 0, K, M, N, K, y32, N, c_f32=True), 30, 5)
+        print(f"gemmk K={K}: bf16-out {t1:.1f} us  f32-out {t2:.1f} us")
+    e = torch.empty(8, device="cuda")
+    print("empty launch (cast of 8 elems): %.1f us" % timeit(lambda: ops.to_bf16(e), 50, 5))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["preproc"]
     for w in which:

@@ -17,6 +17,7 @@
 //   * fused epilogues: bias, GELU (+ pre-activation for backward), dropout + residual add,
 //     GELU' multiply (dgrad), ReLU, per-row-group bias, fp32 atomic accumulate.
 #include "vpf_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -289,11 +290,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
             }
         return;
     }
-    // Every other mode: one (i,j) sub-tile of every wave at a time is parked in LDS as fp32 (the operand
-    // buffers are dead), then each thread finishes 4 consecutive columns of a row: bias / GELU / GELU' /
-    // dropout+residual / group bias with 16-byte loads of the side inputs and 8- or 16-byte stores.
-    constexpr int SR = WM * 32, SC = WN * 32, SLD = SC + 4;
-    static_assert(SR * SLD * 4 <= 2 * STAGE * 2, "staging tile must fit in the operand buffers");
+    // Every other mode: the whole BM x BN accumulator tile is parked in LDS as fp32 (+bias; the operand buffers are dead),
+    // ONE barrier, then each thread finishes 4 consecutive columns of a row: GELU / GELU' / dropout+residual / group bias /
+    // group max with 16-byte loads of the side inputs and 8- or 16-byte stores.
+    constexpr int SLD = BN + 4;
+    static_assert(BM * SLD * 4 <= 2 * STAGE * 2, "accumulator tile must fit in the operand buffers");
     float* sf = reinterpret_cast<float*>(lds);
     VpfRng rng;
     if (g.mode == EPI_DROP_RES) rng = vpf_rng_init(g.rng, g.site, g.p);
@@ -303,97 +304,87 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
                      (g.mode != EPI_GELU_BWD || ((g.ldaux % 4 == 0) && (((uintptr_t)g.aux & 7) == 0))) &&
                      (g.mode != EPI_GROUPBIAS || (((uintptr_t)g.gbias & 15) == 0));
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+            const int nl = (wn * TN + j) * 32 + col_l;
+            const float bv = (g.bias && n0 + nl < g.N) ? g.bias[n0 + nl] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                sf[(wm * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SLD + wn * 32 + col_l] = acc[i][j][r];
-            __syncthreads();
-            if (g.mode == EPI_GROUPMAX) {
-                // max over the `group` consecutive rows of every group inside this 32-row-aligned sub-tile
-                const int gpb = SR / g.group;                                  // groups per staged sub-tile
-                for (int e = threadIdx.x; e < gpb * (SC / 4); e += 256) {
-                    const int gi = e / (SC / 4), sc = (e % (SC / 4)) * 4;
-                    const int sr0 = gi * g.group;
-                    const int m = m0 + ((sr0 >> 5) * TM + i) * 32 + (sr0 & 31);
-                    const int n = n0 + ((sc >> 5) * TN + j) * 32 + (sc & 31);
-                    if (m >= g.M || n >= g.N) continue;
-                    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                    int bi[4] = {0, 0, 0, 0};
-                    float bvv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (g.bias) { bvv[0] = g.bias[n]; bvv[1] = g.bias[n + 1]; bvv[2] = g.bias[n + 2]; bvv[3] = g.bias[n + 3]; }
-                    for (int k = 0; k < g.group; ++k) {
-                        const float4 a4 = *reinterpret_cast<const float4*>(sf + (sr0 + k) * SLD + sc);
-                        const float vv[4] = {a4.x, a4.y, a4.z, a4.w};
+                sf[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rsub) * SLD + nl] = acc[i][j][r] + bv;
+        }
+    __syncthreads();
+    if (g.mode == EPI_GROUPMAX) {
+        // max over the `group` consecutive rows (group divides 32, tiles are 32-row aligned)
+        const int gpb = BM / g.group;
+        for (int e = threadIdx.x; e < gpb * (BN / 4); e += 256) {
+            const int gi = e / (BN / 4), sc = (e % (BN / 4)) * 4;
+            const int m = m0 + gi * g.group, n = n0 + sc;
+            if (m >= g.M || n >= g.N) continue;
+            float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int bi[4] = {0, 0, 0, 0};
+            for (int k = 0; k < g.group; ++k) {
+                const float4 a4 = *reinterpret_cast<const float4*>(sf + (gi * g.group + k) * SLD + sc);
+                const float vv[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float t = bf16_to_f32(f32_to_bf16(vv[q] + bvv[q]));
-                            if (t > best[q]) { best[q] = t; bi[q] = k; }
-                        }
-                    }
-                    const size_t go = (size_t)(m / g.group) * g.ldc + n;
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + go) = make_float4(best[0], best[1], best[2], best[3]);
-                    *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g.C2) + (size_t)(m / g.group) * g.ldc2 + n) =
-                        (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
-                }
-                __syncthreads();
-                continue;
-            }
-            for (int e = threadIdx.x; e < SR * (SC / 4); e += 256) {
-                const int sr = e / (SC / 4), sc = (e % (SC / 4)) * 4;
-                const int m = m0 + ((sr >> 5) * TM + i) * 32 + (sr & 31);
-                const int n = n0 + ((sc >> 5) * TN + j) * 32 + (sc & 31);
-                if (m >= g.M || n >= g.N) continue;
-                const float4 a4 = *reinterpret_cast<const float4*>(sf + sr * SLD + sc);
-                float v[4] = {a4.x, a4.y, a4.z, a4.w};
-                const int nv = min(4, g.N - n);
-                if (g.bias) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (q < nv) v[q] += g.bias[n + q];
-                }
-                const size_t co = (size_t)cb + (size_t)m * g.ldc + n;
-                if (g.mode == EPI_GELU) {
-                    bf16_t ub[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { ub[q] = f32_to_bf16(v[q]); v[q] = gelu_f(bf16_to_f32(ub[q])); }
-                    bf16_t* u = reinterpret_cast<bf16_t*>(g.C2) + (size_t)m * g.ldc2 + n;
-                    if (vec) { uint2 w; w.x = ub[0] | ((uint32_t)ub[1] << 16); w.y = ub[2] | ((uint32_t)ub[3] << 16); *reinterpret_cast<uint2*>(u) = w; }
-                    else { for (int q = 0; q < nv; ++q) u[q] = ub[q]; }
-                } else if (g.mode == EPI_DROP_RES) {
-                    const float* rp = g.res + (size_t)m * g.ldres + n;
-                    float rr[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (vec) { const float4 t = *reinterpret_cast<const float4*>(rp); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
-                    else { for (int q = 0; q < nv; ++q) rr[q] = rp[q]; }
-                    const uint64_t base = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = rr[q] + (vpf_keep(rng, base + q) ? v[q] * rng.scale : 0.f);
-                } else if (g.mode == EPI_GELU_BWD) {
-                    const bf16_t* ap = g.aux + (size_t)m * g.ldaux + n;
-                    bf16_t ab[4] = {0, 0, 0, 0};
-                    if (vec) { const uint2 t = *reinterpret_cast<const uint2*>(ap); ab[0] = t.x & 0xffff; ab[1] = t.x >> 16; ab[2] = t.y & 0xffff; ab[3] = t.y >> 16; }
-                    else { for (int q = 0; q < nv; ++q) ab[q] = ap[q]; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] *= gelu_grad_f(bf16_to_f32(ab[q]));
-                } else if (g.mode == EPI_RELU) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-                } else if (g.mode == EPI_GROUPBIAS) {
-                    const float* gp = g.gbias + (size_t)(m / g.group) * g.N + n;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) if (q < nv) v[q] += gp[q];
-                }
-                if (g.c_f32) {
-                    float* o = reinterpret_cast<float*>(g.C) + co;
-                    if (vec) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                    else { for (int q = 0; q < nv; ++q) o[q] = v[q]; }
-                } else {
-                    bf16_t* o = reinterpret_cast<bf16_t*>(g.C) + co;
-                    if (vec) { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *reinterpret_cast<uint2*>(o) = w; }
-                    else { for (int q = 0; q < nv; ++q) o[q] = f32_to_bf16(v[q]); }
+                for (int q = 0; q < 4; ++q) {
+                    const float t = bf16_to_f32(f32_to_bf16(vv[q]));
+                    if (t > best[q]) { best[q] = t; bi[q] = k; }
                 }
             }
-            __syncthreads();
+            const size_t go = (size_t)(m / g.group) * g.ldc + n;
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(g.C) + go) = make_float4(best[0], best[1], best[2], best[3]);
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(g.C2) + (size_t)(m / g.group) * g.ldc2 + n) =
+                (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+        }
+        return;
+    }
+    for (int e = threadIdx.x; e < BM * (BN / 4); e += 256) {
+        const int sr = e / (BN / 4), sc = (e % (BN / 4)) * 4;
+        const int m = m0 + sr, n = n0 + sc;
+        if (m >= g.M || n >= g.N) continue;
+        const float4 a4 = *reinterpret_cast<const float4*>(sf + sr * SLD + sc);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        const int nv = min(4, g.N - n);
+        const size_t co = (size_t)cb + (size_t)m * g.ldc + n;
+        if (g.mode == EPI_GELU) {
+            bf16_t ub[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ub[q] = f32_to_bf16(v[q]); v[q] = gelu_f(bf16_to_f32(ub[q])); }
+            bf16_t* u = reinterpret_cast<bf16_t*>(g.C2) + (size_t)m * g.ldc2 + n;
+            if (vec) { uint2 w; w.x = ub[0] | ((uint32_t)ub[1] << 16); w.y = ub[2] | ((uint32_t)ub[3] << 16); *reinterpret_cast<uint2*>(u) = w; }
+            else { for (int q = 0; q < nv; ++q) u[q] = ub[q]; }
+        } else if (g.mode == EPI_DROP_RES) {
+            const float* rp = g.res + (size_t)m * g.ldres + n;
+            float rr[4] = {0.f, 0.f, 0.f, 0.f};
+            if (vec) { const float4 t = *reinterpret_cast<const float4*>(rp); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
+            else { for (int q = 0; q < nv; ++q) rr[q] = rp[q]; }
+            const uint64_t base = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = rr[q] + (vpf_keep(rng, base + q) ? v[q] * rng.scale : 0.f);
+        } else if (g.mode == EPI_GELU_BWD) {
+            const bf16_t* ap = g.aux + (size_t)m * g.ldaux + n;
+            bf16_t ab[4] = {0, 0, 0, 0};
+            if (vec) { const uint2 t = *reinterpret_cast<const uint2*>(ap); ab[0] = t.x & 0xffff; ab[1] = t.x >> 16; ab[2] = t.y & 0xffff; ab[3] = t.y >> 16; }
+            else { for (int q = 0; q < nv; ++q) ab[q] = ap[q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] *= gelu_grad_f(bf16_to_f32(ab[q]));
+        } else if (g.mode == EPI_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        } else if (g.mode == EPI_GROUPBIAS) {
+            const float* gp = g.gbias + (size_t)(m / g.group) * g.N + n;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (q < nv) v[q] += gp[q];
+        }
+        if (g.c_f32) {
+            float* o = reinterpret_cast<float*>(g.C) + co;
+            if (vec) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            else { for (int q = 0; q < nv; ++q) o[q] = v[q]; }
+        } else {
+            bf16_t* o = reinterpret_cast<bf16_t*>(g.C) + co;
+            if (vec) { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *reinterpret_cast<uint2*>(o) = w; }
+            else { for (int q = 0; q < nv; ++q) o[q] = f32_to_bf16(v[q]); }
         }
     }
 }
@@ -456,10 +447,17 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
         return launch_cfg<1, 1, 2, 2, 128>(g, a_tr, b_tr, batch, st);
     }
     g.splitk = 0;
+    // Tile choice.  These GEMMs are small (M ~ 12 k tokens, N, K in 256..768) and bound by the bytes each CU has to pull
+    // (A re-read once per column tile, W once per row tile), so the largest tile that still gives every CU a workgroup wins.
+    static int forced = -2;
+    if (forced == -2) { const char* e = getenv("VPF_GEMM_CFG"); forced = e ? atoi(e) : -1; }
+    const long wg128 = (long)vpf_cdiv(g.M, 128) * vpf_cdiv(g.N, 128) * batch;
     const long wg_128x64 = (long)vpf_cdiv(g.M, 128) * vpf_cdiv(g.N, 64) * batch;
-    if (wg_128x64 >= 2048 && g.N >= 128) return launch_cfg<2, 2, 2, 2, 64>(g, a_tr, b_tr, batch, st);   // 128x128
-    if (wg_128x64 >= 512) return launch_cfg<1, 2, 4, 1, 64>(g, a_tr, b_tr, batch, st);                   // 128x64
-    return launch_cfg<1, 1, 2, 2, 128>(g, a_tr, b_tr, batch, st);                                        // 64x64
+    int cfg = (wg128 >= 160 && g.N >= 128) ? 2 : (wg_128x64 >= 192 ? 1 : 0);
+    if (forced >= 0) cfg = forced;
+    if (cfg == 2) return launch_cfg<2, 2, 2, 2, 64>(g, a_tr, b_tr, batch, st);    // 128x128
+    if (cfg == 1) return launch_cfg<1, 2, 4, 1, 64>(g, a_tr, b_tr, batch, st);    // 128x64
+    return launch_cfg<1, 1, 2, 2, 128>(g, a_tr, b_tr, batch, st);                 // 64x64
 }
 
 // ------------------------------------------------------------------ C ABI
