@@ -160,6 +160,8 @@ int vpf_cast_f32_bf16(const float* x, void* y_bf16, long n, void* stream);
 int vpf_cast_bf16_f32(const void* x_bf16, float* y, long n, void* stream);
 /* acc[c] += sum_m x[m,c]; acc2[c] += sum_m x^2 (nullable): bias gradients and BatchNorm statistics */
 int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* acc, float* acc2, void* stream);
+/* out[c] = sum_r x[r,c] with r ascending (deterministic) */
+int vpf_sum_rows_f32(const float* x, int R, int C, float* out, void* stream);
 int vpf_axpy_f32(const float* x, float* y, long n, float a, void* stream);
 /* acc[r % period, :] += x[r, :]: gradient of CrossFormer_img_mp.position_emb [1,T,D] (partseg.py:637) */
 int vpf_rowsum_mod_f32(const float* x, long rows, int D, int period, float* acc, void* stream);
@@ -183,8 +185,9 @@ int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, con
  * first conv (C->64) + BatchNorm(64) + ReLU without materialising the conv output: statistics pass,
  * apply pass (out bf16 [M,64]), two-pass backward (weight/bias/BN-affine gradients; the input needs none). */
 int vpf_g2e_conv1_stats(const float* x, long M, int C, const float* W, const float* b, float* sums, float* sumsq, void* stream);
-/* the same statistics from the C x C second-moment matrix of the inputs (h1 is affine in x): mom72_zeroed = f32 [72] scratch */
-int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, const float* b, float* mom72_zeroed,
+/* the same statistics from the C x C second-moment matrix of the inputs (h1 is affine in x); scratch = f32 [72 + 512*72];
+ * per-block partials folded in a fixed order (deterministic) */
+int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, const float* b, float* scratch,
                                 float* sums, float* sumsq, void* stream);
 int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
                         const float* beta, void* out_bf16, void* stream);
@@ -194,12 +197,13 @@ int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const 
 /* Group2Emb forward for group_size == 32 as two persistent weight-stationary kernels (conv weights held in registers as
  * MFMA fragments, activations of a pair of groups in LDS; only the pre-BN2 activation h3 and what backward needs reach HBM):
  *   vpf_g2e_fold_bn1: BatchNorm-1 folded into the first conv (ab1 from vpf_bn_affine)
- *   vpf_g2e_fwd_a:    x -> a1, h2, gmax/arg2 (max over members), h3 = conv3([gmax | h2]) ; sums512 += column sum | sum^2 of h3
+ *   vpf_g2e_fwd_a:    x -> a1, h2, gmax/arg2 (max over members), h3 = conv3([gmax | h2]) ; partials[wg][512] = column sum | sum^2
+ *                     of h3 per workgroup (*nrows_out rows; fold with vpf_sum_rows_f32: deterministic BatchNorm statistics)
  *   vpf_g2e_fwd_b:    h3 -> BN2+ReLU -> conv4 -> max over members: out f32 [NG,Dm], arg4 */
 int vpf_g2e_fold_bn1(const float* W1, const float* b1, const float* ab1, int C, float* w1e, float* b1e, void* stream);
 int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, const float* b1e, const void* w2_bf16, const float* b2,
                   const void* w3_bf16, const float* b3, void* a1, void* h2, void* gmax, uint8_t* arg2, void* h3,
-                  float* sums512_zeroed, void* stream);
+                  float* partials_256x512, int* nrows_out /* host */, void* stream);
 int vpf_g2e_fwd_b(const void* h3_bf16, long NG, const float* ab2, const void* w4_bf16, const float* b4, int Dm, float* out,
                   uint8_t* arg4, void* stream);
 /* Group2Emb backward, group_size == 32:

@@ -380,3 +380,47 @@ def test_training_step_with_dropout_vs_oracle(name):
     # forward difference of the projected features into a visibly different dL/dfeats: reported, loosely bounded
     compare("emulated, NT-Xent loss", lambda p: p.grad, 0.85, 0.90, 0.65)
     ck.done()
+
+
+def test_trainer_stream_and_graph_variants_agree():
+    """The step must not depend on HOW it is issued: single stream vs two-stream branch overlap vs side-stream weight
+    gradients vs hipGraph replay give the same loss and the same gradients (up to fp32 atomic ordering)."""
+    from vipformer_amd import ops
+    from vipformer_amd.train import Pretrainer, build_models
+    a = Hh.ARCHS["c1"]
+    B = 4
+    t1 = Hh.synth_points(1, B, a["N"]).cuda(); t2 = Hh.synth_points(2, B, a["N"]).cuda()
+    imgs = Hh.synth_images(3, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
+    start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
+    results = []
+    for overlap, wasync, graph in ((False, False, False), (True, False, False), (True, True, False), (True, True, True)):
+        ops.clear_managed_shadows()
+        ops.rng.seed(99)
+        ops._site_counter[0] = 5000                        # same dropout sites (hence masks) for every variant
+        torch.manual_seed(5)
+        pc, im = build_models(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], N=a["N"], img=a["img"], patch=a["patch"])
+        pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c1.json"), 100))
+        im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_img_c1.json"), 200))
+        pc.train(); im.train()
+        tr = Pretrainer(pc, im)
+        tr.overlap = overlap
+        ops.WGRAD_ASYNC[0] = wasync
+        with forced_start(start):
+            if graph:
+                tr.hyper[0] = 0.0; tr.hyper[4] = 0.0            # lr = wd = 0: the warm-up steps of capture() leave the weights alone
+                tr.capture(t1, t2, imgs, warmup=1)
+                ops.rng.state("cuda")[2] = 0                # same dropout step as the eager variants (the graph holds this tensor)
+                losses = tr.replay()
+            else:
+                losses = tr.forward_backward(t1, t2, imgs)
+        torch.cuda.synchronize()
+        # exact-zero gradients (a conv bias ahead of a BatchNorm) hold only atomic-order noise: leave them out
+        zero_grad = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias")
+        g = torch.cat([p.grad.reshape(-1) for m in (pc, im) for k, p in m.named_parameters() if k not in zero_grad])
+        results.append((float(losses[0]), g.clone()))
+    ops.WGRAD_ASYNC[0] = False
+    ops.clear_managed_shadows()
+    l0, g0 = results[0]
+    for (l, g), tag in zip(results[1:], ("two-stream", "two-stream + async wgrad", "hipGraph")):
+        assert abs(l - l0) < 1e-6 * abs(l0), (tag, l, l0)          # the forward pass is deterministic (no atomics in it)
+        assert cosine(g, g0) > 0.999999, (tag, cosine(g, g0))      # gradients: fp32 atomic ordering only

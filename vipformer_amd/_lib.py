@@ -83,7 +83,7 @@ SIGS = {
     "vpf_bn_act_fwd": [VP, I, VP, VP, VP, VP, I, L_, I, I, VP],
     "vpf_bn_bwd": [VP, I, VP, I, VP, VP, VP, L_, I, I, I, VP, VP, I, VP, VP, VP],
     "vpf_g2e_fold_bn1": [VP, VP, VP, I, VP, VP, VP],
-    "vpf_g2e_fwd_a": [VP, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP],
+    "vpf_g2e_fwd_a": [VP, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP],
     "vpf_g2e_fwd_b": [VP, L_, VP, VP, VP, I, VP, VP, VP],
     "vpf_g2e_wgrad4": [VP, L_, VP, VP, VP, I, VP, VP, VP],
     "vpf_g2e_bwd": [VP, VP, I, L_, VP, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, VP, VP],
@@ -94,6 +94,7 @@ SIGS = {
     "vpf_g2e_concat_bwd": [VP, VP, L_, I, I, VP, VP],
     "vpf_pool_fwd": [VP, I, I, I, VP, VP, VP],
     "vpf_pool_bwd": [VP, VP, I, I, I, VP, VP],
+    "vpf_sum_rows_f32": [VP, I, I, VP, VP],
     "vpf_axpy_f32": [VP, VP, L_, F, VP],
     "vpf_rowsum_mod_f32": [VP, L_, I, I, VP, VP],
     "vpf_attention_fwd": [VP, L_, VP, L_, VP, L_, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, VP],

@@ -341,6 +341,7 @@ extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* ac
     hipStream_t st = (hipStream_t)stream;
     if (C % 8 == 0 && (((uintptr_t)x & 15) == 0)) {
         int rpb = 32;
+        if (M <= 2048) rpb = (int)M;                        // one block: a deterministic sum (BatchNorm over a batch of samples)
         while ((M + rpb - 1) / rpb > 512) rpb *= 2;      // <= 512 blocks -> <= 512 atomics per column
         const int grid = (int)((M + rpb - 1) / rpb);
         if (x_is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2, rpb);
@@ -352,6 +353,25 @@ extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* ac
         if (x_is_bf16) hipLaunchKernelGGL(colsum_generic_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2, rpb);
         else hipLaunchKernelGGL(colsum_generic_kernel<float>, grid, dim3(256), 0, st, (const float*)x, M, C, acc, acc2, rpb);
     }
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// out[c] = sum_r x[r, c] in a FIXED order (r ascending): deterministic fold of per-workgroup partial statistics
+__global__ void sum_rows_kernel(const float* __restrict__ x, int R, int C, float* __restrict__ out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[(size_t)r * C + c];
+    out[c] = s;
+}
+extern "C" int vpf_sum_rows_f32(const float* x, int R, int C, float* out, void* stream)
+{
+    (void)hipGetLastError();
+    if (!x || !out) return VPF_ERR_NULL;
+    if (R <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(vpf_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, x, R, C, out);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

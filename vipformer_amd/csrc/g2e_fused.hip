@@ -30,7 +30,7 @@ struct G2eA {
     const bf16_t* w2; const float* b2;               // [128,64] bf16, [128]
     const bf16_t* w3; const float* b3;               // [256,256] bf16 ([global | local] columns), [256]
     bf16_t* a1; bf16_t* h2; bf16_t* gmax; uint8_t* arg2; bf16_t* h3;   // outputs
-    float* sums;                                     // [512] = sum | sumsq of h3 per column (atomics)
+    float* sums;                                     // [gridDim.x][512] = per-workgroup sum | sumsq of h3 per column
 };
 
 __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
         // sA1 / sH2 / sG are rewritten only after the next iteration's first barrier pair; sH3 after its third: safe
     }
     ssum += __shfl_xor(ssum, 32, 64); ssq += __shfl_xor(ssq, 32, 64);
-    if (hl == 0) { atomicAdd(p.sums + w * 32 + l31, ssum); atomicAdd(p.sums + 256 + w * 32 + l31, ssq); }
+    if (hl == 0) { p.sums[(size_t)blockIdx.x * 512 + w * 32 + l31] = ssum; p.sums[(size_t)blockIdx.x * 512 + 256 + w * 32 + l31] = ssq; }
 }
 
 struct G2eB {
@@ -253,19 +253,20 @@ extern "C" int vpf_g2e_fold_bn1(const float* W1, const float* b1, const float* a
     return VPF_OK;
 }
 
-// x [NG*32, C] -> a1 [M,64], h2 [M,128], gmax [NG,128], arg2 [NG,128], h3 [M,256] (all bf16 / u8), sums512 (zeroed) += column
-// sum | sum^2 of h3.  w1e/b1e: first conv with BatchNorm-1 folded in (fp32); w2 [128,64], w3 [256,256] bf16.
+// x [NG*32, C] -> a1 [M,64], h2 [M,128], gmax [NG,128], arg2 [NG,128], h3 [M,256] (all bf16 / u8); partials [256][512] receives one
+// row of column sum | sum^2 of h3 per workgroup (rows >= *nrows_out are not written): fold with vpf_sum_rows_f32 (deterministic).  w1e/b1e: first conv with BatchNorm-1 folded in (fp32); w2 [128,64], w3 [256,256] bf16.
 extern "C" int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, const float* b1e, const void* w2_bf16, const float* b2,
                              const void* w3_bf16, const float* b3, void* a1, void* h2, void* gmax, uint8_t* arg2, void* h3,
-                             float* sums512_zeroed, void* stream)
+                             float* partials_256x512, int* nrows_out, void* stream)
 {
     (void)hipGetLastError();
-    if (!x || !w1e || !b1e || !w2_bf16 || !b2 || !w3_bf16 || !b3 || !a1 || !h2 || !gmax || !arg2 || !h3 || !sums512_zeroed) return VPF_ERR_NULL;
+    if (!x || !w1e || !b1e || !w2_bf16 || !b2 || !w3_bf16 || !b3 || !a1 || !h2 || !gmax || !arg2 || !h3 || !partials_256x512 || !nrows_out) return VPF_ERR_NULL;
     if (NG <= 0 || C < 3 || C > 3) return VPF_ERR_BADSHAPE;       // xyz groups only (the pre-training path)
     if (((uintptr_t)w2_bf16 & 15) || ((uintptr_t)w3_bf16 & 15) || ((uintptr_t)a1 & 15) || ((uintptr_t)h2 & 15) || ((uintptr_t)h3 & 15)) return VPF_ERR_BADALIGN;
     G2eA p = {x, NG, C, w1e, b1e, (const bf16_t*)w2_bf16, b2, (const bf16_t*)w3_bf16, b3, (bf16_t*)a1, (bf16_t*)h2, (bf16_t*)gmax, arg2,
-              (bf16_t*)h3, sums512_zeroed};
+              (bf16_t*)h3, partials_256x512};
     long grid = (NG + 1) / 2; if (grid > 256) grid = 256;
+    *nrows_out = (int)grid;
     hipLaunchKernelGGL(g2e_fwd_a_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
     VPF_CHECK_LAUNCH();
     return VPF_OK;

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256) g2e_moments_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x < 72) {
         const int e = threadIdx.x, i = e < 8 ? e : (e - 8) / 8, j = e < 8 ? 0 : (e - 8) % 8;
-        if (i < C && (e < 8 || j <= i)) atomicAdd(mom + e, red[0][e] + red[1][e] + red[2][e] + red[3][e]);
+        mom[(size_t)blockIdx.x * 72 + e] = (i < C && (e < 8 || j <= i)) ? red[0][e] + red[1][e] + red[2][e] + red[3][e] : 0.f;
     }
 }
 __global__ void g2e_moments_to_sums_kernel(const float* __restrict__ mom, long M, int C, const float* __restrict__ W, const float* __restrict__ b,
@@ -268,15 +268,26 @@ __global__ void g2e_moments_to_sums_kernel(const float* __restrict__ mom, long M
     sums[c] = ws1 + (float)M * bb;
     sumsq[c] = q + 2.f * bb * ws1 + (float)M * bb * bb;
 }
-extern "C" int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, const float* b, float* mom72_zeroed,
+__global__ void g2e_moments_fold_kernel(const float* __restrict__ part, int nblk, float* __restrict__ mom)
+{
+    const int e = threadIdx.x;
+    if (e >= 72) return;
+    float s = 0.f;
+    for (int r = 0; r < nblk; ++r) s += part[(size_t)r * 72 + e];      // fixed order: deterministic statistics
+    mom[e] = s;
+}
+// scratch: f32 [72 + 512*72]
+extern "C" int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, const float* b, float* scratch,
                                            float* sums, float* sumsq, void* stream)
 {
     (void)hipGetLastError();
-    if (!x || !W || !b || !mom72_zeroed || !sums || !sumsq) return VPF_ERR_NULL;
+    if (!x || !W || !b || !scratch || !sums || !sumsq) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(g2e_moments_kernel, dim3(grid_for(M, 256 * 4, 512)), dim3(256), 0, st, x, M, C, mom72_zeroed);
-    hipLaunchKernelGGL(g2e_moments_to_sums_kernel, dim3(1), dim3(64), 0, st, (const float*)mom72_zeroed, M, C, W, b, sums, sumsq);
+    const int nblk = grid_for(M, 256 * 4, 512);
+    hipLaunchKernelGGL(g2e_moments_kernel, dim3(nblk), dim3(256), 0, st, x, M, C, scratch + 72);
+    hipLaunchKernelGGL(g2e_moments_fold_kernel, dim3(1), dim3(128), 0, st, (const float*)(scratch + 72), nblk, scratch);
+    hipLaunchKernelGGL(g2e_moments_to_sums_kernel, dim3(1), dim3(64), 0, st, (const float*)scratch, M, C, W, b, sums, sumsq);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

@@ -16,6 +16,7 @@ accumulation, bf16 activations between fused ops, fp32 statistics (LayerNorm/Bat
 """
 from __future__ import annotations
 
+import ctypes
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -212,11 +213,41 @@ def linear_dgrad(dy16, w16, N, K, *, out_f32=False, mode=EPI_STORE, **kw):
     return dx
 
 
+# Weight gradients are off the backward critical path (nothing downstream reads them before the optimizer), so they CAN be
+# issued on a side stream per compute stream (dgrad chain on the main stream, wgrad GEMMs on idle CUs).  Optional:
+WGRAD_ASYNC = [False]     # measured slower on MI355X at these kernel sizes (cross-stream event cost > overlap gain)
+_wgrad_streams = {}
+
+
+def _wgrad_side():
+    cur = torch.cuda.current_stream()
+    side = _wgrad_streams.get(cur.cuda_stream)
+    if side is None:
+        side = torch.cuda.Stream(device=cur.device)
+        _wgrad_streams[cur.cuda_stream] = side
+    return cur, side
+
+
+def join_wgrad_streams() -> None:
+    """Make the current stream wait for every outstanding side-stream weight gradient (call before the optimizer)."""
+    cur = torch.cuda.current_stream()
+    for side in _wgrad_streams.values():
+        cur.wait_stream(side)
+
+
 def linear_wgrad(dy16, x16, N, K, dW, dbias=None):
     """dW[N,K] += dy16[M,N]^T @ x16[M,K]   (both operands k-strided, split over M, fp32 atomics);
     dbias[N] += column sums of dy16 in the same pass."""
     M = dy16.numel() // N
-    gemm(dy16, 1, N, x16, 1, K, N, K, M, dW, K, c_f32=True, mode=EPI_ATOMIC, dbias=dbias)
+    if not WGRAD_ASYNC[0]:
+        gemm(dy16, 1, N, x16, 1, K, N, K, M, dW, K, c_f32=True, mode=EPI_ATOMIC, dbias=dbias)
+        return
+    cur, side = _wgrad_side()
+    side.wait_stream(cur)                                   # dy16 / x16 are produced on the compute stream
+    with torch.cuda.stream(side):
+        gemm(dy16, 1, N, x16, 1, K, N, K, M, dW, K, c_f32=True, mode=EPI_ATOMIC, dbias=dbias)
+    dy16.record_stream(side)
+    x16.record_stream(side)
 
 
 def colsum(x, C, acc, acc2=None):
@@ -513,8 +544,8 @@ class Group2EmbFn(torch.autograd.Function):
         w1 = c1.weight.data.view(64, C)
         stat1 = torch.empty(128, dtype=F32, device=dev)
         if training:
-            scratch = torch.zeros(72 + 128, dtype=F32, device=dev)
-            sums = scratch[72:]
+            scratch = torch.empty(72 + 512 * 72, dtype=F32, device=dev)
+            sums = torch.empty(128, dtype=F32, device=dev)
             L.call("vpf_g2e_conv1_stats_moments", x, M, C, w1, c1.bias.data, scratch, sums[:64], sums[64:])
             L.call("vpf_bn_finalize", sums[:64], sums[64:], M, 64, float(bn1.eps), float(bn1.momentum), 1, bn1.running_mean,
                    bn1.running_var, bn1.num_batches_tracked, stat1)
@@ -532,9 +563,12 @@ class Group2EmbFn(torch.autograd.Function):
             gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
             arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
             h3 = torch.empty(M, 256, dtype=BF16, device=dev)
-            sums2 = torch.zeros(512, dtype=F32, device=dev)
+            part = torch.empty(256 * 512, dtype=F32, device=dev)
+            nwg = ctypes.c_int(0)
             L.call("vpf_g2e_fwd_a", x, NG, C, w1e, w1e[64 * C:], shadow([c2.weight]), c2.bias.data, shadow([c3.weight]), c3.bias.data,
-                   a1, h2, gmax, arg2, h3, sums2)
+                   a1, h2, gmax, arg2, h3, part, ctypes.addressof(nwg))
+            sums2 = torch.empty(512, dtype=F32, device=dev)
+            L.call("vpf_sum_rows_f32", part, nwg.value, 512, sums2)          # fixed order: deterministic BatchNorm-2 statistics
             stat2 = torch.empty(512, dtype=F32, device=dev)
             if training:
                 L.call("vpf_bn_finalize", sums2[:256], sums2[256:], M, 256, float(bn2.eps), float(bn2.momentum), 1, bn2.running_mean,

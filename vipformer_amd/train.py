@@ -131,6 +131,11 @@ class Pretrainer:
         loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, self.temperature)
         total = loss_imid + self.cmid_weight * loss_cmid
         total.backward()
+        if self.overlap and self._side is not None:
+            # the kernels write weight gradients themselves (autograd sees no leaf accumulation on the side stream and
+            # therefore does not join it): the image branch's backward must land before anything reads the gradients
+            torch.cuda.current_stream().wait_stream(self._side)
+        ops.join_wgrad_streams()                             # side-stream weight gradients land before anything reads them
         return total.detach(), loss_imid.detach(), loss_cmid.detach()
 
     def allreduce_gradients(self) -> None:
