@@ -61,6 +61,17 @@ def gemm():
         print(f"gemm {tag} M={M} N={N} K={K}: fwd {t1:.1f} us ({fl/t1/1e6:.0f} TF/s) dgrad {t2:.1f} us ({fl/t2/1e6:.0f} TF/s) wgrad {t3:.1f} us ({fl/t3/1e6:.0f} TF/s)")
 
 
+def wgrad():
+    from vipformer_amd import ops
+    for (M, N, K, tag) in [(12288, 256, 512, "fc2"), (12288, 512, 256, "fc1"), (12288, 256, 256, "proj"), (12288, 768, 256, "qkv"),
+                           (131072, 512, 256, "CA kv")]:
+        A = torch.randn(M, K, device="cuda").bfloat16()
+        dY = torch.randn(M, N, device="cuda").bfloat16(); dW = torch.zeros(N, K, device="cuda")
+        t3 = timeit(lambda: ops.linear_wgrad(dY, A, N, K, dW), 300, 10)
+        fl = 2.0 * M * N * K
+        print(f"wgrad {tag} M={M} N={N} K={K}: {t3:.1f} us ({fl/t3/1e6:.0f} TF/s)")
+
+
 def g2e():
     """Group2Emb forward/backward at the benchmark size + per-phase cycle stamps of the fused backward."""
     from vipformer_amd import ops

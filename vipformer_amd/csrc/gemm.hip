@@ -433,10 +433,13 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return VPF_ERR_BADALIGN;
     if (g.mode == EPI_ATOMIC) {
         if (!g.c_f32) return VPF_ERR_UNSUPPORTED;
+        static int wcfg = -1, wtarget = 512;
+        if (wcfg < 0) { const char* e = getenv("VPF_WGRAD_CFG"); wcfg = e ? atoi(e) : 0; const char* t = getenv("VPF_WGRAD_WGS"); if (t) wtarget = atoi(t); }
+        const int tm = wcfg == 0 ? 64 : 128, tn = wcfg == 2 ? 128 : 64;
         if (g.splitk <= 0) {
             // fill ~512 workgroups of 64x64 tiles
-            const long tiles = (long)vpf_cdiv(g.M, 64) * vpf_cdiv(g.N, 64);
-            long s = 512 / (tiles > 0 ? tiles : 1);
+            const long tiles = (long)vpf_cdiv(g.M, tm) * vpf_cdiv(g.N, tn);
+            long s = wtarget / (tiles > 0 ? tiles : 1);
             const long maxs = vpf_cdiv(g.K, 256);
             if (s > maxs) s = maxs;
             if (s < 1) s = 1;
@@ -444,6 +447,8 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
         }
         if (g.splitk == 1) g.splitk = 0, batch = 1;
         if (batch != 1 && g.splitk > 1) return VPF_ERR_UNSUPPORTED;
+        if (wcfg == 2) return launch_cfg<2, 2, 2, 2, 64>(g, a_tr, b_tr, batch, st);
+        if (wcfg == 1) return launch_cfg<1, 2, 4, 1, 64>(g, a_tr, b_tr, batch, st);
         return launch_cfg<1, 1, 2, 2, 128>(g, a_tr, b_tr, batch, st);
     }
     g.splitk = 0;

@@ -12,17 +12,21 @@
 // and their running min-distance in registers.  Per iteration: PPT distance updates, a
 // wavefront arg-max (64-bit key = distance bits : ~index, so max == farthest, ties -> lowest
 // index), one LDS slot per wave, ONE barrier (slots are double-buffered by iteration parity).
+#ifndef FPS_STAMP
+#define FPS_STAMP(i)
+#define FPS_STAMP_INIT
+#define FPS_STAMP_FINI
+#endif
 template <int NT, int PPT>
 __global__ void __launch_bounds__(NT) fps_kernel(const float* __restrict__ pts, int N, int C,
                                                 const int64_t* __restrict__ start_idx, int G,
                                                 int64_t* __restrict__ out_idx)
 {
-    extern __shared__ float smem[];
+    extern __shared__ float4 smem4[];
     constexpr int NW = NT / 64;
-    float* sx = smem;
-    float* sy = sx + N;
-    float* sz = sy + N;
-    unsigned long long* slot = reinterpret_cast<unsigned long long*>(sz + N + ((N & 1) ? 1 : 0));  // [2][NW], 8B aligned
+    float4* sp = smem4;                                         // [N] xyz_ : one ds_read_b128 fetches the new centroid
+    uint2* slot2 = reinterpret_cast<uint2*>(sp + N);            // [2][NW] per-wave (max distance bits, lowest index)
+    int* sel = reinterpret_cast<int*>(slot2 + 2 * NW);          // [G] the selection, written out once at the end
 
     const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const float* p = pts + (size_t)b * N * C;
@@ -30,54 +34,73 @@ __global__ void __launch_bounds__(NT) fps_kernel(const float* __restrict__ pts, 
     float px[PPT], py[PPT], pz[PPT], dist[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
-        const int i = t + j * NT;
+        const int i = t * PPT + j;      // a thread owns PPT consecutive points: index order == (wave, lane, j) order
         if (i < N) {
             px[j] = p[(size_t)i * C + 0]; py[j] = p[(size_t)i * C + 1]; pz[j] = p[(size_t)i * C + 2];
-            sx[i] = px[j]; sy[i] = py[j]; sz[i] = pz[j];
+            sp[i] = make_float4(px[j], py[j], pz[j], 0.f);
             dist[j] = 1e10f;
         } else {
             px[j] = py[j] = pz[j] = 0.f;
-            dist[j] = -1.f;   // padding: never updated, never selected
+            dist[j] = -1.f;   // padding: min(-1, d >= 0) stays -1 and never beats a real point
         }
     }
     int far = (int)start_idx[b];
+    int zero = 0;
+    asm volatile("" : "+v"(zero));      // an opaque 0: keeps the slot reads below vector reads (no readfirstlane + scalar branch chain)
     __syncthreads();
 
+    // No global store inside the loop (a barrier would wait for its acknowledgement) and no divergent branch:
+    // the loop-carried chain is centroid read -> PPT distance updates -> two DPP reductions -> slot -> barrier -> slot reads.
+    FPS_STAMP_INIT
     for (int g = 0; g < G; ++g) {
-        if (t == 0) out_idx[(size_t)b * G + g] = far;
+        if (t == 0) sel[g] = far;
         if (g + 1 == G) break;
-        const float cx = sx[far], cy = sy[far], cz = sz[far];
-        unsigned long long best = 0ull;
+        FPS_STAMP(0);
+        const float4 c = sp[far];
+        float bd = -1.f; uint32_t bi = 0xffffffffu;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+            const float dx = px[j] - c.x, dy = py[j] - c.y, dz = pz[j] - c.z;
             float d = dx * dx;
             d = d + dy * dy;
             d = d + dz * dz;
-            const int i = t + j * NT;
-            if (i < N) {
-                dist[j] = fminf(dist[j], d);
-                // distances are >= +0: float order == unsigned bit order
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(dist[j]) << 32) | (unsigned)(~(unsigned)i);
-                best = key > best ? key : best;
-            }
+            const float nd = d < dist[j] ? d : dist[j];
+            dist[j] = nd;
+            const bool gt = nd > bd;                              // strict >: the lowest index of this thread wins ties
+            bd = gt ? nd : bd;
+            bi = gt ? (uint32_t)(t * PPT + j) : bi;
         }
-        best = wave_max_u64(best);
-        unsigned long long* s = slot + (g & 1) * NW;
-        if (lane == 0) s[wave] = best;
+        FPS_STAMP(1);
+        // wavefront arg-max: the maximum distance, then the lowest lane attaining it (== the lowest index, see the layout)
+        const float wm = wave_max_f32_asm(bd);
+        const unsigned long long tied = __ballot(bd == wm);
+        const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)bi, __builtin_ctzll(tied));
+        FPS_STAMP(2);
+        uint2* s = slot2 + (g & 1) * NW;
+        if (lane == 0) s[wave] = wm < 0.f ? make_uint2(0u, 0xffffffffu) : make_uint2(__float_as_uint(wm), wi);   // wave of padding only
         __syncthreads();
-        unsigned long long m = s[0];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) { const unsigned long long v = s[w]; m = v > m ? v : m; }
-        far = (int)(~(unsigned)(m & 0xffffffffull));
+        FPS_STAMP(3);
+        // cross-wave merge without a serial chain: lane l takes slot l mod NW, a DPP max over aligned groups of NW lanes,
+        // then the lowest tied lane (slots are in wave == index order) hands over its index
+        const uint2 v = s[(lane & (NW - 1)) + zero];
+        const float gm = row_max_f32_asm<NW>(__uint_as_float(v.x));     // distances are >= +0
+        const unsigned long long tied2 = __ballot(__uint_as_float(v.x) == gm);
+        far = __builtin_amdgcn_readlane((int)v.y, __builtin_ctzll(tied2));
+        FPS_STAMP(4);
     }
+    FPS_STAMP_FINI
+    __syncthreads();
+    for (int g = t; g < G; g += NT) out_idx[(size_t)b * G + g] = sel[g];
 }
 
 template <int NT, int PPT>
 static int launch_fps(const float* pts, int B, int N, int C, const int64_t* start, int G, int64_t* out, hipStream_t st)
 {
-    const size_t lds = sizeof(float) * (3 * (size_t)N + 1) + sizeof(unsigned long long) * 2 * (NT / 64) + 8;
+    const size_t lds = sizeof(float4) * (size_t)N + sizeof(uint2) * 2 * (NT / 64) + sizeof(int) * (size_t)G;
+    if (lds > 160 * 1024) return VPF_ERR_BADSHAPE;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)fps_kernel<NT, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return VPF_ERR_HIP;
     hipLaunchKernelGGL((fps_kernel<NT, PPT>), dim3(B), dim3(NT), lds, st, pts, N, C, start, G, out);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
@@ -93,9 +116,10 @@ extern "C" int vpf_fps_f32(const float* pts, int B, int N, int C, const int64_t*
     hipStream_t st = (hipStream_t)stream;
     if (N <= 256) return launch_fps<256, 1>(pts, B, N, C, start_idx, G, out_idx, st);
     if (N <= 512) return launch_fps<256, 2>(pts, B, N, C, start_idx, G, out_idx, st);
+    // measured (tools/microbench.py preproc): 4 points per thread beats more waves per cloud, the barrier grows with the wave count
     if (N <= 1024) return launch_fps<256, 4>(pts, B, N, C, start_idx, G, out_idx, st);
     if (N <= 2048) return launch_fps<512, 4>(pts, B, N, C, start_idx, G, out_idx, st);
-    return launch_fps<512, 8>(pts, B, N, C, start_idx, G, out_idx, st);
+    return launch_fps<1024, 4>(pts, B, N, C, start_idx, G, out_idx, st);
 }
 
 // =============================================================================== index_points

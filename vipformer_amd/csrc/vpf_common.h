@@ -75,6 +75,48 @@ __device__ __forceinline__ float wave_max(float v)
     v = fmaxf(v, dpp_f<VPF_DPP_ROW_BCAST31, 0xC>(v, v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = min(v, dpp_u<VPF_DPP_QUAD_1032, 0xF>(v, v));
+    v = min(v, dpp_u<VPF_DPP_QUAD_2301, 0xF>(v, v));
+    v = min(v, dpp_u<VPF_DPP_ROW_HALF_MIRROR, 0xF>(v, v));
+    v = min(v, dpp_u<VPF_DPP_ROW_MIRROR, 0xF>(v, v));
+    v = min(v, dpp_u<VPF_DPP_ROW_BCAST15, 0xA>(v, v));
+    v = min(v, dpp_u<VPF_DPP_ROW_BCAST31, 0xC>(v, v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Single-instruction DPP reduction steps (v_max_f32_dpp / v_min_u32_dpp): the compiler's update_dpp lowering spends a
+// copy + a DPP move + the op per step, and these reductions sit on the loop-carried chain of the FPS iteration.
+// s_nop covers the VALU-write -> DPP-read (2 wait states) and EXEC-write -> DPP (5) hazards, which the assembler
+// does not insert inside inline asm.  The result is valid in lane 63 and read from there.
+#define VPF_DPP_REDUCE_ASM(op)                                                                  \
+    "s_nop 4\n\t" op " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"          \
+    "s_nop 1\n\t" op " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"          \
+    "s_nop 1\n\t" op " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"              \
+    "s_nop 1\n\t" op " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"                   \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"                 \
+    "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"                 \
+    "s_nop 1"
+// max over aligned groups of W lanes (W = 4, 8 or 16), result in every lane of the group
+template <int W>
+__device__ __forceinline__ float row_max_f32_asm(float v)
+{
+    asm volatile("s_nop 4\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    if (W >= 8) asm volatile("v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    if (W >= 16) asm volatile("v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f32_asm(float v)
+{
+    asm volatile(VPF_DPP_REDUCE_ASM("v_max_f32_dpp") : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u32_asm(uint32_t v)
+{
+    asm volatile(VPF_DPP_REDUCE_ASM("v_min_u32_dpp") : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // 64-bit keys as (hi, lo) pairs
 template <int CTRL, int ROW_MASK, bool MAXOP>
 __device__ __forceinline__ void dpp_step_u64(uint32_t& hi, uint32_t& lo)
