@@ -258,6 +258,49 @@ int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b
 int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev,
                    int advance_step, void* stream);
 
+/* ------------------------------------------------------------------ fused self-attention layer
+ * SelfAttentionLayer.forward (partseg.py:170-188; Residual :201-213, MultiHeadAttention :14-86, MLP :191-198) for
+ * D = 256, 4 heads of 64, hidden 512, as ONE kernel per layer: attention -> o_proj + dropout + residual -> LayerNorm
+ * -> fc1 + GELU -> fc2 + dropout + residual, and -- when qkv_next is set -- the NEXT layer's (+pos) -> LayerNorm ->
+ * q/k/v projection (Encoder.forward re-adds pos before every layer, partseg.py:326-335).  One workgroup owns
+ * chunk_rows tokens of one sequence (L <= 96: the whole sequence; L <= 224: chunk_rows <= 128); with attention_done
+ * the attention itself is left to vpf_attention_fwd and a workgroup owns any 64 consecutive rows.
+ * Weights are read in the MFMA fragment order produced by vpf_pack_wfrag from the natural bf16 [N,K] matrices.
+ * Everything the backward needs is written as the unfused ops write it. */
+typedef struct VpfPackJob { const void* src; void* dst; int N, K; } VpfPackJob;
+#define VPF_PACK_MAX_JOBS 32
+/* natural bf16 W[N][K] -> fragment order: ((cb*(K/16) + ks)*64 + lane)*8 + j  <-  W[cb*32 + (lane&31)][ks*16 + 8*(lane>>5) + j].
+ * jobs is a HOST array (copied into the kernel arguments: capturable). */
+int vpf_pack_wfrag(const VpfPackJob* host_jobs, int njobs, void* stream);
+
+typedef struct VpfSaLayerFwd {
+    int B, L, chunk_rows, D, H, hidden;
+    const void* qkv;            /* bf16 [B*L, 3D]: q | k | v of THIS layer */
+    const float* base;          /* f32 [B*L, D]: residual base of this layer (x + pos) */
+    const uint32_t* rng;        /* dropout state (vpf_dropout_*) */
+    float scale, p_att; uint32_t site_att;
+    const void* Wo; const float* bo;               /* packed [D,D], f32 [D] */
+    float p_res1; uint32_t site_res1;
+    const float* ln2_g; const float* ln2_b;
+    const void* W1; const float* b1;               /* packed [hidden,D] */
+    const void* W2; const float* b2;               /* packed [D,hidden] */
+    float p_res2; uint32_t site_res2;
+    /* saved for backward */
+    void* o; float* lse;                            /* bf16 [M,D], f32 [B,H,L] */
+    float* x1; float* mean2; float* rstd2; void* n2;   /* f32 [M,D], [M], [M], bf16 [M,D] */
+    void* u; void* h;                               /* bf16 [M,hidden]: fc1 pre-activation, GELU output */
+    float* out;                                     /* f32 [M,D]: x2 (+ pos when pos != NULL) */
+    /* next layer's head (all NULL after the last layer) */
+    const float* pos; int pos_rows;                 /* f32 [pos_rows, D], row m uses pos[m % pos_rows] */
+    const float* ln1n_g; const float* ln1n_b; const void* Wqkv_next;   /* packed [3D,D] */
+    float* mean1n; float* rstd1n; void* n1n; void* qkv_next;
+    int attention_done;                             /* 1: o / lse were produced by vpf_attention_fwd (o is an INPUT; any L) */
+    long long* dbg;                                 /* optional: 8 phase cycle counters of workgroup 0 (profiling aid) */
+} VpfSaLayerFwd;
+int vpf_sa_layer_fwd(const VpfSaLayerFwd* host_args, void* stream);
+/* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1): lets a binding verify its struct layout */
+int vpf_abi_sizeof(int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -424,3 +424,48 @@ def test_trainer_stream_and_graph_variants_agree():
     for (l, g), tag in zip(results[1:], ("two-stream", "two-stream + async wgrad", "hipGraph")):
         assert abs(l - l0) < 1e-6 * abs(l0), (tag, l, l0)          # the forward pass is deterministic (no atomics in it)
         assert cosine(g, g0) > 0.999999, (tag, cosine(g, g0))      # gradients: fp32 atomic ordering only
+
+
+def test_fused_sa_stack_matches_unfused_blocks():
+    """vpf_sa_layer_fwd (one kernel per self-attention layer) against the block-by-block kernels it replaces: same
+    dropout masks (same sites / state), so the loss and the gradients agree up to bf16 rounding of intermediates."""
+    from vipformer_amd import ops
+    from vipformer_amd.train import Pretrainer, build_models
+    a = Hh.ARCHS["c1"]
+    B = 4
+    t1 = Hh.synth_points(1, B, a["N"]).cuda(); t2 = Hh.synth_points(2, B, a["N"]).cuda()
+    imgs = Hh.synth_images(3, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
+    start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
+    results = []
+    for fused in (False, True):
+        ops.clear_managed_shadows()
+        ops.rng.seed(99)
+        ops._site_counter[0] = 5000
+        torch.manual_seed(5)
+        pc, im = build_models(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], N=a["N"], img=a["img"], patch=a["patch"])
+        pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c1.json"), 100))
+        im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_img_c1.json"), 200))
+        pc.train(); im.train()
+        tr = Pretrainer(pc, im)
+        tr.overlap = False
+        ops.SA_FUSED[0] = fused
+        with forced_start(start):
+            feats_pc = pc(torch.cat([t1, t2]))[1].detach().clone()        # backbone features (before the BatchNorm head)
+            ops.rng.state("cuda")[2] = 0
+            losses = tr.forward_backward(t1, t2, imgs)
+        torch.cuda.synchronize()
+        zero_grad = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias")
+        g = {("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters() if k not in zero_grad}
+        results.append((float(losses[0]), feats_pc, g))
+    ops.SA_FUSED[0] = True
+    ops.clear_managed_shadows()
+    (l0, f0, g0), (l1, f1, g1) = results
+    C = Checks("fused_sa_stack")
+    C.lt("pc backbone feats rel", rel(f1, f0), 2e-2)
+    C.lt("loss rel", abs(l1 - l0) / abs(l0), 2e-2)
+    allg0 = torch.cat([v.reshape(-1) for v in g0.values()]); allg1 = torch.cat([g1[k].reshape(-1) for k in g0])
+    C.gt("all grads cos", cosine(allg1, allg0), 0.98)
+    worst = min((cosine(g1[k], g0[k]), k) for k in g0 if "sa_layers" in k and g0[k].numel() > 256)
+    report(f"fused_sa_stack worst sa grad: {worst}")
+    C.gt("worst sa-layer grad cos", worst[0], 0.9)
+    C.done()

@@ -72,6 +72,38 @@ def wgrad():
         print(f"wgrad {tag} M={M} N={N} K={K}: {t3:.1f} us ({fl/t3/1e6:.0f} TF/s)")
 
 
+def sa():
+    """fused self-attention layer forward: time per layer + phase cycles, pc (L=96) and img (L=196) shapes"""
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    import torch.nn as nn
+    for (B, Lq, tag) in [(128, 96, "pc"), (64, 196, "img")]:
+        layers = nn.ModuleList([SelfAttentionLayer(4, 256, 2, 0.0, 0.1, 0.5) for _ in range(6)]).cuda()
+        layers.train()
+        x = torch.randn(B, Lq, 256, device="cuda"); pos = torch.randn(B if tag == "pc" else 1, Lq, 256, device="cuda")
+        params = [p for l in layers for p in l.parameters()]
+        dbg = torch.zeros(8, dtype=torch.int64, device="cuda")
+        for fused, split in ((False, None), (True, False), (True, True)):
+            ops.SA_FUSED[0] = fused
+            ops.SA_SPLIT_ATTN[0] = split
+            def run():
+                with torch.no_grad():
+                    if fused:
+                        return ops.SAStackFn.apply(x, pos, layers, True, *params)
+                    y = x
+                    for l in layers: y = l(y, pos=pos)
+                    return y
+            t = timeit(run, 20, 3)
+            print(f"sa stack fwd {tag} B={B} L={Lq} fused={fused} split_attn={split}: {t:.1f} us / 6 layers = {t/6:.1f} us per layer")
+        ops.SA_DEBUG.append(dbg)
+        run(); torch.cuda.synchronize()
+        ops.SA_DEBUG.clear()
+        names = ["attention", "o_proj mfma", "drop+res epi", "LN2+store", "MLP", "final epi", "next LN1", "next qkv"]
+        print("   phase cycles (wg 0, layer 4): " + "  ".join(f"{n} {int(c)}" for n, c in zip(names, dbg.tolist())))
+    ops.SA_FUSED[0] = True
+    ops.SA_SPLIT_ATTN[0] = None
+
+
 def g2e():
     """Group2Emb forward/backward at the benchmark size + per-phase cycle stamps of the fused backward."""
     from vipformer_amd import ops

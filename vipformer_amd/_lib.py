@@ -113,7 +113,47 @@ SIGS = {
     "vpf_ntxent_fwd": [VP, VP, I, I, F, VP, VP, VP, VP, VP, VP],
     "vpf_ntxent_bwd": [VP, VP, VP, I, I, F, VP, VP, VP, VP],
     "vpf_adamw_step": [VP, VP, VP, VP, VP, L_, VP, I, VP],
+    "vpf_pack_wfrag": [VP, I, VP],
+    "vpf_sa_layer_fwd": [VP, VP],
+    "vpf_abi_sizeof": [I],
 }
+
+
+class PackJob(ctypes.Structure):
+    """struct VpfPackJob (include/vipformer_hip.h)."""
+    _fields_ = [("src", VP), ("dst", VP), ("N", I), ("K", I)]
+
+
+class SaLayerFwd(ctypes.Structure):
+    """struct VpfSaLayerFwd (include/vipformer_hip.h) -- same field order."""
+    _fields_ = [("B", I), ("L", I), ("chunk_rows", I), ("D", I), ("H", I), ("hidden", I),
+                ("qkv", VP), ("base", VP), ("rng", VP),
+                ("scale", F), ("p_att", F), ("site_att", U32),
+                ("Wo", VP), ("bo", VP),
+                ("p_res1", F), ("site_res1", U32),
+                ("ln2_g", VP), ("ln2_b", VP),
+                ("W1", VP), ("b1", VP), ("W2", VP), ("b2", VP),
+                ("p_res2", F), ("site_res2", U32),
+                ("o", VP), ("lse", VP),
+                ("x1", VP), ("mean2", VP), ("rstd2", VP), ("n2", VP),
+                ("u", VP), ("h", VP),
+                ("out", VP),
+                ("pos", VP), ("pos_rows", I),
+                ("ln1n_g", VP), ("ln1n_b", VP), ("Wqkv_next", VP),
+                ("mean1n", VP), ("rstd1n", VP), ("n1n", VP), ("qkv_next", VP), ("attention_done", I), ("dbg", VP)]
+
+
+def call_struct(name: str, struct, *extra) -> None:
+    """Entry points that take a pointer to a host-side argument struct (copied into the kernel arguments)."""
+    fn = _bound.get(name)
+    if fn is None:
+        fn = getattr(lib(), name)
+        fn.argtypes = SIGS[name]
+        fn.restype = I
+        _bound[name] = fn
+    rc = fn(ctypes.addressof(struct), *extra, torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise VpfError(f"{name} failed: {lib().vpf_strerror(rc).decode()} (rc={rc})")
 _bound = {}
 
 

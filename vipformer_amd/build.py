@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libvipformer_hip.so")
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # bit-exact fp32 index kernels: no implicit FMA contraction
 PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
 

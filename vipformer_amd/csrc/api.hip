@@ -1,5 +1,6 @@
 // api.hip -- version / error strings of the C ABI.
 #include "vpf_common.h"
+#include "vipformer_hip.h"
 
 extern "C" int vpf_version(void)
 {
@@ -16,5 +17,15 @@ extern "C" const char* vpf_strerror(int code)
         case VPF_ERR_HIP: return "HIP launch error";
         case VPF_ERR_NULL: return "null pointer for a required argument";
         default: return "unknown error";
+    }
+}
+
+// sizeof of the argument structs of the ABI (a binding checks its own layout against the library's)
+extern "C" int vpf_abi_sizeof(int which)
+{
+    switch (which) {
+        case 0: return (int)sizeof(VpfPackJob);
+        case 1: return (int)sizeof(VpfSaLayerFwd);
+        default: return -1;
     }
 }

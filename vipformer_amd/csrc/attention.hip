@@ -87,6 +87,13 @@ __device__ __forceinline__ uint4 ld16_or_zero(const bf16_t* p, bool ok)
     return ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
 }
 
+// every lane reads quad lane E's value (DPP quad_perm broadcast)
+template <int E>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, E | (E << 2) | (E << 4) | (E << 6), 0xF, 0xF, true);
+}
+
 // cooperative stage of a [ROWS x 64] bf16 tile (rows r0.. of a [L, ld] matrix, head column offset applied by caller)
 template <int ROWS, int MAXC>
 __device__ __forceinline__ void kv_load(const bf16_t* __restrict__ G, long ld, int L, int r0, uint4 (&regs)[MAXC], int nthreads)
@@ -179,15 +186,15 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
             float ps = 0.f;
             float pv[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pr = exp2f(s[r] - mn);
-                ps += pr;
-                float pd = pr;
-                if (drop) {
-                    const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                    pd = vpf_keep(rng, rbase + (uint64_t)kv) ? pr * rng.scale : 0.f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint32_t keep = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;   // keys kv0 + 8 g4 + 4 hl + 0..3
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const float pr = exp2f(s[r] - mn);
+                    ps += pr;
+                    pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
                 }
-                pv[r] = pd;
             }
             l = l * alpha + ps;
 #pragma unroll
@@ -349,13 +356,17 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
         }
         float ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-            const bool ok = qok && kv < a.Lkv;
-            const float pr = ok ? exp2f(s[r] * c - lse2) : 0.f;
-            float keep = 1.f;
-            if (drop) keep = vpf_keep(rng, rbase + (uint64_t)kv) ? rng.scale : 0.f;
-            ds[r] = pr * (dp[r] * keep - delta) * a.scale;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const uint32_t kbits = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                const int kv = kv0 + e + 8 * g4 + 4 * hl;
+                const bool ok = qok && kv < a.Lkv;
+                const float pr = ok ? exp2f(s[r] * c - lse2) : 0.f;
+                const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
+                ds[r] = pr * (dp[r] * keep - delta) * a.scale;
+            }
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -461,15 +472,42 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
         }
         float pd[16], ds[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = (r & 3) + 8 * (r >> 2) + 4 * hl;
-            const int q = q0 + qr;
-            const bool ok = kvok && q < a.Lq;
-            const float pr = ok ? exp2f(s[r] * c - sL[qr]) : 0.f;
-            float keep = 1.f;
-            if (drop) keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)q) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
-            pd[r] = pr * keep;
-            ds[r] = pr * (dp[r] * keep - sL[BWD_KT + qr]) * a.scale;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            // Dropout groups run along the key axis, which is the LANE axis here: the 4 lanes of a quad share one group per
+            // query.  Each quad lane hashes the group of a different query of this register quad and the results are
+            // exchanged with DPP quad broadcasts: one hash per 4 elements instead of one per element.
+            uint2 grp = make_uint2(0u, 0u);
+            const bool quad_ok = (a.Lkv & 3) == 0;
+            if (drop && quad_ok) {
+                const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
+                grp = vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
+            }
+            uint32_t gw[4];
+            {
+                const uint32_t mine = (lane & 2) ? 1u : 0u;      // which 32-bit word holds this lane's key (kv & 3)
+                const uint32_t x0 = quad_bcast<0>(grp.x), x1 = quad_bcast<1>(grp.x), x2 = quad_bcast<2>(grp.x), x3 = quad_bcast<3>(grp.x);
+                const uint32_t y0 = quad_bcast<0>(grp.y), y1 = quad_bcast<1>(grp.y), y2 = quad_bcast<2>(grp.y), y3 = quad_bcast<3>(grp.y);
+                gw[0] = mine ? y0 : x0; gw[1] = mine ? y1 : x1; gw[2] = mine ? y2 : x2; gw[3] = mine ? y3 : x3;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                const int qr = e + 8 * g4 + 4 * hl;
+                const int q = q0 + qr;
+                const bool ok = kvok && q < a.Lq;
+                const float pr = ok ? exp2f(s[r] * c - sL[qr]) : 0.f;
+                float keep = 1.f;
+                if (drop) {
+                    if (quad_ok) {
+                        const uint32_t word = gw[e];                                 // this lane's half of quad lane e's group
+                        keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                    } else {
+                        keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)q) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
+                    }
+                }
+                pd[r] = pr * keep;
+                ds[r] = pr * (dp[r] * keep - sL[BWD_KT + qr]) * a.scale;
+            }
         }
         // dV^T[d,kv] += dO^T[d,q] . P[q,kv] ; dK^T[d,kv] += Q^T[d,q] . dS[q,kv]
 #pragma unroll

@@ -208,9 +208,13 @@ __global__ void dropout_add_fwd_kernel(const bf16_t* __restrict__ y, const float
                                        long n, const uint32_t* __restrict__ rng_state, uint32_t site, float p)
 {
     const VpfRng rng = vpf_rng_init(rng_state, site, p);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float v = bf16_to_f32(y[i]);
-        out[i] = (res ? res[i] : 0.f) + (vpf_keep(rng, (uint64_t)i) ? v * rng.scale : 0.f);
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g * 4 < n; g += (long)gridDim.x * blockDim.x) {
+        const uint32_t keep = vpf_keep4(rng, (uint64_t)g);
+        for (int e = 0; e < 4 && g * 4 + e < n; ++e) {
+            const long i = g * 4 + e;
+            const float v = bf16_to_f32(y[i]);
+            out[i] = (res ? res[i] : 0.f) + (((keep >> e) & 1u) ? v * rng.scale : 0.f);
+        }
     }
 }
 extern "C" int vpf_dropout_add_fwd(const void* y_bf16, const float* res, float* out, long n, const uint32_t* rng_state,
@@ -229,8 +233,20 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dout, bf16_t* __res
                                    const uint32_t* __restrict__ rng_state, uint32_t site, float p)
 {
     const VpfRng rng = vpf_rng_init(rng_state, site, p);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        dy[i] = f32_to_bf16(vpf_keep(rng, (uint64_t)i) ? dout[i] * rng.scale : 0.f);
+    const bool vec = (n % 4 == 0) && (((uintptr_t)dout & 15) == 0) && (((uintptr_t)dy & 7) == 0);
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g * 4 < n; g += (long)gridDim.x * blockDim.x) {
+        const uint32_t keep = vpf_keep4(rng, (uint64_t)g);
+        if (vec) {
+            const float4 d = *reinterpret_cast<const float4*>(dout + g * 4);
+            uint2 w;
+            w.x = pack_bf16x2((keep & 1u) ? d.x * rng.scale : 0.f, (keep & 2u) ? d.y * rng.scale : 0.f);
+            w.y = pack_bf16x2((keep & 4u) ? d.z * rng.scale : 0.f, (keep & 8u) ? d.w * rng.scale : 0.f);
+            *reinterpret_cast<uint2*>(dy + g * 4) = w;
+        } else {
+            for (int e = 0; e < 4 && g * 4 + e < n; ++e)
+                dy[g * 4 + e] = f32_to_bf16(((keep >> e) & 1u) ? dout[g * 4 + e] * rng.scale : 0.f);
+        }
+    }
 }
 extern "C" int vpf_dropout_bwd(const float* dout, void* dy_bf16, long n, const uint32_t* rng_state, uint32_t site, float p,
                                void* stream)
@@ -246,8 +262,10 @@ extern "C" int vpf_dropout_bwd(const float* dout, void* dy_bf16, long n, const u
 __global__ void dropout_mask_kernel(uint8_t* __restrict__ out, long n, const uint32_t* __restrict__ rng_state, uint32_t site, float p)
 {
     const VpfRng rng = vpf_rng_init(rng_state, site, p);
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        out[i] = vpf_keep(rng, (uint64_t)i) ? 1 : 0;
+    for (long g = blockIdx.x * (long)blockDim.x + threadIdx.x; g * 4 < n; g += (long)gridDim.x * blockDim.x) {
+        const uint32_t keep = vpf_keep4(rng, (uint64_t)g);
+        for (int e = 0; e < 4 && g * 4 + e < n; ++e) out[g * 4 + e] = (keep >> e) & 1u;
+    }
 }
 extern "C" int vpf_dropout_mask(uint8_t* out, long n, const uint32_t* rng_state, uint32_t site, float p, void* stream)
 {

@@ -65,13 +65,8 @@ struct GemmArgs {
     OpXform xa, xb;                                 // operand prologues (kind 0 = none)
 };
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x)
-{
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
-}
+__device__ __forceinline__ float gelu_f(float x) { return vpf_gelu(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return vpf_gelu_grad(x); }
 
 // ------------------------------------------------------------------ tile staging
 // K-major operand tile: LDS [ROWS][BK + pad]; K-strided operand tile: LDS [BK][ROWS + pad].
@@ -360,8 +355,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
             if (vec) { const float4 t = *reinterpret_cast<const float4*>(rp); rr[0] = t.x; rr[1] = t.y; rr[2] = t.z; rr[3] = t.w; }
             else { for (int q = 0; q < nv; ++q) rr[q] = rp[q]; }
             const uint64_t base = (uint64_t)m * (uint64_t)g.N + (uint64_t)n;
+            const uint32_t keep = vpf_keep4_at(rng, base);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = rr[q] + (vpf_keep(rng, base + q) ? v[q] * rng.scale : 0.f);
+            for (int q = 0; q < 4; ++q) v[q] = rr[q] + (((keep >> q) & 1u) ? v[q] * rng.scale : 0.f);
         } else if (g.mode == EPI_GELU_BWD) {
             const bf16_t* ap = g.aux + (size_t)m * g.ldaux + n;
             bf16_t ab[4] = {0, 0, 0, 0};

@@ -1,0 +1,670 @@
+// sa_layer.hip -- one self-attention encoder layer (forward) as ONE kernel for gfx950.
+//
+// Replaces, for SelfAttentionLayer.forward (vipformer/model/pointcloud/partseg.py:170-188 with the
+// Residual / MultiHeadAttention / MLP pieces of :14-141,191-213), the chain
+//     attention -> o_proj + dropout + residual -> LayerNorm -> fc1 + GELU -> fc2 + dropout + residual
+// and, when a next layer follows, that layer's  (+pos) -> LayerNorm -> q/k/v projection  head, so that a stack of
+// self-attention layers is one launch per layer instead of nine.  At the reference's sizes (96 or 196 tokens x 256
+// channels per sequence, ~12 k tokens per batch) every separate kernel is dominated by its ramp-up and by writing
+// and re-reading small activations; here one workgroup owns one sequence chunk and keeps the activations in LDS.
+//
+// Workgroup = 256 threads (4 waves) = one chunk of a sequence (pc: the 96 tokens; img: 98 of the 196), RB blocks of
+// 32 tokens.  All matrix products are "swapped":  C^T[channel, token] = W[channel, :] . X[token, :]
+//   A operand = weight fragments, read from HBM/L2 in a PRE-PACKED fragment order (vpf_pack_wfrag: one coalesced
+//               1 KB load per 32x16 fragment),
+//   B operand = activation rows from LDS (ds_read_b128),
+// so a lane owns ONE token (lane & 31) and its registers run over channels: bias / LayerNorm / GELU / dropout /
+// residual epilogues are per-lane, LayerNorm statistics are in-register sums + one cross-wave LDS exchange.
+// Wave w owns channels [64 w, 64 w + 64) of every 256-channel output chunk.
+// Everything the existing backward needs is written exactly as the unfused path writes it (o, lse, x1, LN stats,
+// n2, u, h, next base / n1 / qkv), so forward and backward can be fused independently.
+#include "vpf_common.h"
+#include "vipformer_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+#define SA_D 256
+#define SA_HID 512
+#define SA_H 4
+#define SA_DH 64
+#define ALD 264         // LDS row stride (bf16) of a [tokens][256] activation tile (256 + 8 pad)
+#define KLD 72          // LDS row stride (bf16) of a [tokens][64] K / V tile
+#define LOG2E 1.4426950408889634f
+#define LN2F 0.6931471805599453f
+
+__device__ __forceinline__ s16x4_t sa_lds_tr16(const bf16_t* p)
+{
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
+}
+// see attention.hip: A-operand fragment of V^T with the k slots in accumulator order
+__device__ __forceinline__ bf16x8_t sa_frag_tr_perm(const bf16_t* S, int ld, int kbase, int c0)
+{
+    const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int h = g >> 1, coff = 16 * (g & 1);
+    const bf16_t* a = S + (kbase + 4 * h + q) * ld + c0 + coff + 4 * p;
+    const s16x4_t lo = sa_lds_tr16(a), hi = sa_lds_tr16(a + 8 * ld);
+    s16x8_t v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t sa_frag_row(const bf16_t* S, int ld, int row0, int kbase)
+{
+    const int lane = threadIdx.x & 63;
+    const uint4 v = *reinterpret_cast<const uint4*>(S + (row0 + (lane & 31)) * ld + kbase + 8 * (lane >> 5));
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+__device__ __forceinline__ bf16x8_t sa_pack8(const float* f)
+{
+    uint4 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]); u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ float sa_gelu(float x) { return vpf_gelu(x); }
+
+// ------------------------------------------------------------------------------------------------ weight packing
+// natural W[N][K] (bf16, row-major)  ->  fragment order: frag(cb, ks) = 64 lanes x 8 values,
+//   lane l holds W[cb*32 + (l & 31)][ks*16 + 8*(l >> 5) + 0..7];   offset ((cb * (K/16) + ks) * 64 + l) * 8
+struct PackJobs { VpfPackJob job[VPF_PACK_MAX_JOBS]; int n; };
+__global__ void pack_wfrag_kernel(PackJobs jobs)
+{
+    const VpfPackJob j = jobs.job[blockIdx.y];
+    const long nfrag = (long)(j.N / 32) * (j.K / 16) * 64;      // 16-byte units
+    const uint4* src = reinterpret_cast<const uint4*>(j.src);
+    uint4* dst = reinterpret_cast<uint4*>(j.dst);
+    const int ksn = j.K / 16;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < nfrag; e += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(e & 63);
+        const long f = e >> 6;
+        const int ks = (int)(f % ksn), cb = (int)(f / ksn);
+        const long row = cb * 32 + (l & 31), col = ks * 16 + 8 * (l >> 5);
+        dst[e] = src[(row * j.K + col) >> 3];
+    }
+}
+extern "C" int vpf_pack_wfrag(const VpfPackJob* jobs, int njobs, void* stream)
+{
+    (void)hipGetLastError();
+    if (!jobs) return VPF_ERR_NULL;
+    if (njobs <= 0 || njobs > VPF_PACK_MAX_JOBS) return VPF_ERR_BADSHAPE;
+    PackJobs pj;
+    pj.n = njobs;
+    for (int i = 0; i < njobs; ++i) {
+        if (!jobs[i].src || !jobs[i].dst) return VPF_ERR_NULL;
+        if (jobs[i].N <= 0 || jobs[i].K <= 0 || (jobs[i].N % 32) || (jobs[i].K % 16)) return VPF_ERR_BADSHAPE;
+        if (((uintptr_t)jobs[i].src & 15) || ((uintptr_t)jobs[i].dst & 15)) return VPF_ERR_BADALIGN;
+        pj.job[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(pack_wfrag_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, pj);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ building blocks
+// The first group (4 k-steps x 2 channel blocks) of a unit's weight fragments.  It is fetched BEFORE the stores of the
+// previous phase are issued: vmcnt retires in order, so a load queued behind 48 scattered stores would wait for all of them.
+struct SaWPre { uint4 a[8], b[8]; };            // groups 0 and 1 (k-steps 0..7) of both channel blocks
+__device__ __forceinline__ void sa_wprefetch(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb0, SaWPre& w)
+{
+    const int lane = threadIdx.x & 63;
+    const uint4* w0 = reinterpret_cast<const uint4*>(Wp) + ((size_t)cb0 * ksn + ks0) * 64 + lane;
+    const uint4* w1 = w0 + (size_t)ksn * 64;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) { w.a[kk] = w0[kk * 64]; w.b[kk] = w1[kk * 64]; }
+}
+// acc[j][i] += Wfrag(cb0 + j, ks0 + ks) . X[i*32.., ks*16..]   for ks = 0..15 (a 256-deep slice of the contraction).
+// Weight fragments stream from L2 two groups of 4 k-steps ahead of the MFMAs (the first two groups come from the caller's
+// prefetch); the compiler barriers keep the loads from being hoisted further (register pressure next to two live
+// accumulator sets).
+template <int RB>
+__device__ __forceinline__ void sa_gemm_unit(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb0, const bf16_t* act,
+                                             f32x16_t (&acc)[2][RB], const SaWPre& pre)
+{
+    const int lane = threadIdx.x & 63;
+    const uint4* w0 = reinterpret_cast<const uint4*>(Wp) + ((size_t)cb0 * ksn + ks0) * 64 + lane;
+    const uint4* w1 = w0 + (size_t)ksn * 64;
+    uint4 wa[8], wb[8];                 // groups 2 and 3
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) { wa[kk] = w0[(8 + kk) * 64]; wb[kk] = w1[(8 + kk) * 64]; }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, ks < 8 ? pre.a[ks & 7] : wa[ks & 7]);
+        const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, ks < 8 ? pre.b[ks & 7] : wb[ks & 7]);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const bf16x8_t x = sa_frag_row(act, ALD, i * 32, ks * 16);
+            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x, acc[0][i], 0, 0, 0);
+            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x, acc[1][i], 0, 0, 0);
+        }
+    }
+}
+template <int RB>
+__device__ __forceinline__ void sa_zero(f32x16_t (&acc)[2][RB])
+{
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+}
+// Accumulator element (j, i, r) of wave w <-> token i*32 + (lane & 31), channel 64 w + 32 j + 8 (r >> 2) + 4 (lane >> 5) + (r & 3):
+// a lane holds groups of 4 consecutive channels (j, g = r >> 2).
+
+// per-token sum over the 256 channels of v(j,i,r): in-lane over registers, lane ^ 32, then the 4 waves through LDS
+template <int RB>
+__device__ __forceinline__ void sa_token_sum(float (&part)[RB], float* sStat, float (&tot)[RB])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        part[i] += __shfl_xor(part[i], 32, 64);
+        if (lane < 32) sStat[(i * 32 + lane) * 4 + wave] = part[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(sStat + (i * 32 + (lane & 31)) * 4);
+        tot[i] = (v.x + v.y) + (v.z + v.w);
+    }
+}
+
+// LayerNorm over the channel axis of the values in acc (two-pass: mean, then centred second moment), in place:
+// acc <- (acc - mean) * rstd * gamma + beta.  mean / rstd of every token are returned (all lanes of the token agree).
+template <int RB>
+__device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[2][RB], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* sStatA, float* sStatB, float (&mean)[RB], float (&rstd)[RB])
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
+    float part[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[j][i][r];
+        part[i] = s;
+    }
+    sa_token_sum<RB>(part, sStatA, mean);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        mean[i] *= (1.0f / SA_D);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = acc[j][i][r] - mean[i]; s += d * d; }
+        part[i] = s;
+    }
+    sa_token_sum<RB>(part, sStatB, rstd);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rstd[i] = rsqrtf(rstd[i] * (1.0f / SA_D) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 64 * wave + 32 * j + 8 * g + 4 * hl;
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+            const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][i][4 * g + q] = (acc[j][i][4 * g + q] - mean[i]) * rstd[i] * gg[q] + bb[q];
+        }
+}
+
+// store the accumulator tile as bf16 into an LDS activation tile [tokens][ALD] (column offset col0) and, for valid tokens,
+// to a global [M][ld] matrix (column offset gcol0)
+template <int RB>
+__device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[2][RB], bf16_t* sAct, int col0, bf16_t* __restrict__ G, long ld,
+                                              int gcol0, long m0, int nvalid)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
+                u.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                const int c = 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const int tok = i * 32 + t;
+                if (sAct) *reinterpret_cast<uint2*>(sAct + tok * ALD + col0 + c) = u;
+                if (G && tok < nvalid) *reinterpret_cast<uint2*>(G + (size_t)(m0 + tok) * ld + gcol0 + c) = u;
+            }
+}
+
+// ------------------------------------------------------------------------------------------------ the layer kernel
+// one (head, 32-query block) attention unit of a wave; K / V tiles of the head are in LDS, LPT = padded sequence length
+template <int LPT>
+__device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV, const bf16x8_t (&qf)[4], int L, float c, const VpfRng& rng,
+                                             bool drop, uint64_t rbase, f32x16_t (&o)[2], float& m, float& l)
+{
+    const int hl = (threadIdx.x & 63) >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    m = -INFINITY; l = 0.f;
+#pragma unroll
+    for (int kv0 = 0; kv0 < LPT; kv0 += 32) {
+        if (kv0 >= L) break;
+        f32x16_t s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa_frag_row(sK, KLD, kv0, ks * 16), qf[ks], s, 0, 0, 0);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+            s[r] = kv < L ? s[r] * c : -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const uint32_t keep = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                const float pr = exp2f(s[r] - mn);
+                ps += pr;
+                pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
+            }
+        }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pf = sa_pack8(pv + 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa_frag_tr_perm(sV, KLD, kv0 + 16 * s2, dt * 32), pf, o[dt], 0, 0, 0);
+        }
+    }
+}
+
+// ATT = false: the attention output o is an INPUT (vpf_attention_fwd ran before); a workgroup then owns any RB*32
+// consecutive rows of the [B*L, D] token matrix, needs no K / V tiles and two workgroups fit on a CU.
+template <int RB, int HPR, int LPT, bool ATT>
+__global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
+{
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    constexpr int TOK = RB * 32;
+    constexpr int UPW = HPR * RB / 4;                 // attention units per wave and round
+    static_assert(HPR * RB % 4 == 0, "units must divide over the 4 waves");
+    bf16_t* actA = lds;                               // [TOK][ALD]   o -> n2 -> next n1
+    bf16_t* reg1 = lds + TOK * ALD;                   // K/V tiles during attention, then actH + LayerNorm exchange
+    bf16_t* actH = reg1;                              // [TOK][ALD]   one 256-wide chunk of the hidden activation
+    float* sStatA = reinterpret_cast<float*>(reg1 + TOK * ALD);   // [TOK][4]
+    float* sStatB = sStatA + TOK * 4;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int L = a.L;
+    const long mseq = (long)b * L;                    // first row of the sequence
+    const long m0 = ATT ? mseq + (long)chunk * a.chunk_rows : (long)blockIdx.x * TOK;   // first row of this workgroup
+    const int nvalid = ATT ? min(a.chunk_rows, L - chunk * a.chunk_rows) : (int)min((long)TOK, (long)a.B * L - m0);
+    const bf16_t* qkv = (const bf16_t*)a.qkv;
+    long long t0_ = 0, t1_;
+    int ph_ = 0;
+#define SA_STAMP() do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { t1_ = clock64(); a.dbg[ph_++] = t1_ - t0_; t0_ = t1_; } } while (0)
+    if (a.dbg) t0_ = clock64();
+
+    SaWPre wpre;
+    if constexpr (!ATT) {
+        // stage this workgroup's rows of the attention output (coalesced 16-byte loads)
+        sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, 2 * wave, wpre);
+        constexpr int CPT = TOK * 32 / 256;
+        uint4 r[CPT];
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.o + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            *reinterpret_cast<uint4*>(actA + row * ALD + ch * 8) = r[it];
+        }
+    }
+    // ============================================================ attention (heads in rounds of HPR)
+    if constexpr (ATT) {
+        const float c = a.scale * LOG2E;
+        const VpfRng rng = vpf_rng_init(a.rng, a.site_att, a.p_att);
+        const bool drop = a.p_att > 0.f;
+        constexpr int NCH = HPR * 2 * LPT * 8;                       // 16-byte chunks of a round's K / V tiles
+        constexpr int CPT = (NCH + 255) / 256;
+#pragma unroll 1
+        for (int round = 0; round < SA_H / HPR; ++round) {
+            if (round) __syncthreads();                       // every wave is done with the previous round's K / V
+            // stage K_h, V_h [L][64] of the round's heads (zero rows up to LPT): all loads in flight at once
+            uint4 kvr[CPT];
+#pragma unroll
+            for (int it = 0; it < CPT; ++it) {
+                const int e = threadIdx.x + it * 256;
+                const int ch = e & 7, row = (e >> 3) % LPT, kv = ((e >> 3) / LPT) & 1, slot = (e >> 3) / (2 * LPT);
+                const int hd = round * HPR + slot;
+                kvr[it] = make_uint4(0, 0, 0, 0);
+                if (e < NCH && row < L) kvr[it] = *reinterpret_cast<const uint4*>(qkv + (size_t)(mseq + row) * (3 * SA_D) + (1 + kv) * SA_D + hd * SA_DH + ch * 8);
+            }
+            // the query fragments of this wave's units
+            bf16x8_t qf[UPW][4];
+#pragma unroll
+            for (int uu = 0; uu < UPW; ++uu) {
+                const int u = wave + 4 * uu, slot = u / RB, rb = u % RB, hd = round * HPR + slot;
+                const int tok = rb * 32 + t;
+                const bool qok = tok < nvalid;
+                const bf16_t* qp = qkv + (size_t)(m0 + (qok ? tok : 0)) * (3 * SA_D) + hd * SA_DH + 8 * hl;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    qf[uu][ks] = __builtin_bit_cast(bf16x8_t, qok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0));
+            }
+#pragma unroll
+            for (int it = 0; it < CPT; ++it) {
+                const int e = threadIdx.x + it * 256;
+                const int ch = e & 7, row = (e >> 3) % LPT, kv = ((e >> 3) / LPT) & 1, slot = (e >> 3) / (2 * LPT);
+                if (e < NCH) *reinterpret_cast<uint4*>(reg1 + ((slot * 2 + kv) * LPT + row) * KLD + ch * 8) = kvr[it];
+            }
+            __syncthreads();
+            if (round + 1 == SA_H / HPR) sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, 2 * wave, wpre);   // ahead of the o stores
+#pragma unroll
+            for (int uu = 0; uu < UPW; ++uu) {
+                const int u = wave + 4 * uu, slot = u / RB, rb = u % RB, hd = round * HPR + slot;
+                const bf16_t* sK = reg1 + (slot * 2) * LPT * KLD;
+                const bf16_t* sV = sK + LPT * KLD;
+                const int tok = rb * 32 + t;
+                const bool qok = tok < nvalid;
+                const int q = chunk * a.chunk_rows + tok;             // query index inside the sequence
+                const int bh = b * SA_H + hd;
+                const uint64_t rbase = ((uint64_t)bh * L + (uint64_t)(qok ? q : 0)) * (uint64_t)L;
+                f32x16_t o[2];
+                float m, l;
+                sa_attn_unit<LPT>(sK, sV, qf[uu], L, c, rng, drop, rbase, o, m, l);
+                const float lt = l + __shfl_xor(l, 32, 64);
+                const float inv = qok ? 1.f / lt : 0.f;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        uint2 w;
+                        w.x = pack_bf16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
+                        w.y = pack_bf16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
+                        const int cc = hd * SA_DH + dt * 32 + 8 * gq + 4 * hl;
+                        *reinterpret_cast<uint2*>(actA + tok * ALD + cc) = w;
+                        if (qok) *reinterpret_cast<uint2*>((bf16_t*)a.o + (size_t)(m0 + tok) * SA_D + cc) = w;
+                    }
+                if (qok && hl == 0) a.lse[(size_t)bh * L + q] = (m + log2f(lt)) * LN2F;
+            }
+        }
+    }
+    __syncthreads();                                           // o complete in actA; K / V dead
+    SA_STAMP();     // 0: attention
+
+    f32x16_t acc[2][RB];
+    // ============================================================ x1 = base + dropout(o . Wo^T + bo);  n2 = LN2(x1)
+    {
+        // the residual base of every element this lane owns: issued before the GEMM, consumed after it
+        float4 res[2][4][RB];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    const bool ok = tok < nvalid;
+                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                    res[j][g][i] = ok ? *reinterpret_cast<const float4*>(a.base + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        sa_zero<RB>(acc);
+        sa_gemm_unit<RB>((const bf16_t*)a.Wo, SA_D / 16, 0, 2 * wave, actA, acc, wpre);
+        sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, 2 * wave, wpre);           // fc1 chunk 0, ahead of the x1 / n2 stores
+        SA_STAMP();     // 1: o_proj MFMA
+        const VpfRng rng = vpf_rng_init(a.rng, a.site_res1, a.p_res1);
+        const bool drop = a.p_res1 > 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cch = 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const float4 bo = *reinterpret_cast<const float4*>(a.bo + cch);
+                const float bb[4] = {bo.x, bo.y, bo.z, bo.w};
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);      // keep the scheduler from interleaving all the unrolled hash chains (spills)
+                    const int tok = i * 32 + t;
+                    const bool ok = tok < nvalid;
+                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + cch;
+                    const float rr[4] = {res[j][g][i].x, res[j][g][i].y, res[j][g][i].z, res[j][g][i].w};
+                    float v[4];
+                    const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float y = acc[j][i][4 * g + q] + bb[q];
+                        if (drop) y = ((keep >> q) & 1u) ? y * rng.scale : 0.f;
+                        v[q] = rr[q] + y;
+                        acc[j][i][4 * g + q] = v[q];
+                    }
+                    if (ok) *reinterpret_cast<float4*>(a.x1 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        SA_STAMP();     // 2: dropout + residual epilogue
+        float mean[RB], rstd[RB];
+        sa_layernorm<RB>(acc, a.ln2_g, a.ln2_b, sStatA, sStatB, mean, rstd);
+        if (wave == 0 && hl == 0) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                if (i * 32 + t < nvalid) { a.mean2[m0 + i * 32 + t] = mean[i]; a.rstd2[m0 + i * 32 + t] = rstd[i]; }
+        }
+        // (the LayerNorm exchange barriers guarantee every wave has finished reading o from actA)
+        sa_store_bf16<RB>(acc, actA, 0, (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
+    }
+    __syncthreads();                                           // n2 complete in actA
+    SA_STAMP();     // 3: LayerNorm 2 + store
+
+    // ============================================================ MLP: two 256-wide chunks of the hidden layer
+    f32x16_t acc2[2][RB];
+    sa_zero<RB>(acc2);
+#pragma unroll
+    for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
+        sa_zero<RB>(acc);
+        sa_gemm_unit<RB>((const bf16_t*)a.W1, SA_D / 16, 0, hc * 8 + 2 * wave, actA, acc, wpre);
+        sa_wprefetch((const bf16_t*)a.W2, SA_HID / 16, hc * 16, 2 * wave, wpre);   // this chunk's fc2 slice, ahead of the u / h stores
+        // u = bf16(acc + b1) (saved), h = gelu(u)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cch = hc * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const float4 b1 = *reinterpret_cast<const float4*>(a.b1 + cch);
+                const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    float uu[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) uu[q] = acc[j][i][4 * g + q] + bb[q];
+                    uint2 w;
+                    w.x = pack_bf16x2(uu[0], uu[1]); w.y = pack_bf16x2(uu[2], uu[3]);
+                    if (tok < nvalid) *reinterpret_cast<uint2*>((bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + cch) = w;
+                    acc[j][i][4 * g + 0] = sa_gelu(__uint_as_float(w.x << 16));
+                    acc[j][i][4 * g + 1] = sa_gelu(__uint_as_float(w.x & 0xffff0000u));
+                    acc[j][i][4 * g + 2] = sa_gelu(__uint_as_float(w.y << 16));
+                    acc[j][i][4 * g + 3] = sa_gelu(__uint_as_float(w.y & 0xffff0000u));
+                }
+            }
+        if (hc) __syncthreads();                               // every wave is done reading the previous chunk from actH
+        sa_store_bf16<RB>(acc, actH, 0, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        __syncthreads();
+        sa_gemm_unit<RB>((const bf16_t*)a.W2, SA_HID / 16, hc * 16, 2 * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, (hc + 1) * 8 + 2 * wave, wpre);
+    }
+    const bool nxt = a.qkv_next != nullptr;
+    if (nxt) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, 2 * wave, wpre);
+    SA_STAMP();     // 4: MLP (fc1 + GELU + fc2)
+
+    // ============================================================ x2 = x1 + dropout(h . W2^T + b2)  [+ pos -> next base, LN1, qkv]
+    {
+        const VpfRng rng = vpf_rng_init(a.rng, a.site_res2, a.p_res2);
+        const bool drop = a.p_res2 > 0.f;
+        int prow[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) prow[i] = a.pos ? (int)((m0 + i * 32 + t) % a.pos_rows) : 0;
+        // two batches of loads (x1 written by this very thread above, then pos), each with all its loads in flight together
+        float4 res[2][4][RB];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    const bool ok = tok < nvalid;
+                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                    res[j][g][i] = ok ? *reinterpret_cast<const float4*>(a.x1 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cch = 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + cch);
+                const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int tok = i * 32 + t;
+                    const bool ok = tok < nvalid;
+                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + cch;
+                    const float rr[4] = {res[j][g][i].x, res[j][g][i].y, res[j][g][i].z, res[j][g][i].w};
+                    const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float y = acc2[j][i][4 * g + q] + bb[q];
+                        if (drop) y = ((keep >> q) & 1u) ? y * rng.scale : 0.f;
+                        acc2[j][i][4 * g + q] = rr[q] + y;
+                    }
+                }
+            }
+        if (a.pos) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int i = 0; i < RB; ++i)
+                        res[j][g][i] = (i * 32 + t < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)prow[i] * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    if (a.pos) {
+                        acc2[j][i][4 * g + 0] += res[j][g][i].x; acc2[j][i][4 * g + 1] += res[j][g][i].y;
+                        acc2[j][i][4 * g + 2] += res[j][g][i].z; acc2[j][i][4 * g + 3] += res[j][g][i].w;
+                    }
+                    if (tok < nvalid)
+                        *reinterpret_cast<float4*>(a.out + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl) =
+                            make_float4(acc2[j][i][4 * g + 0], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]);
+                }
+        SA_STAMP();     // 5: final dropout + residual epilogue
+        if (!nxt) return;
+        float mean[RB], rstd[RB];
+        sa_layernorm<RB>(acc2, a.ln1n_g, a.ln1n_b, sStatA, sStatB, mean, rstd);
+        if (wave == 0 && hl == 0) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                if (i * 32 + t < nvalid) { a.mean1n[m0 + i * 32 + t] = mean[i]; a.rstd1n[m0 + i * 32 + t] = rstd[i]; }
+        }
+        sa_store_bf16<RB>(acc2, actA, 0, (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
+    }
+    __syncthreads();
+    SA_STAMP();     // 6: next LayerNorm 1
+    // q | k | v of the next layer: the results are held (packed bf16) and stored after the last unit, so that no weight load
+    // ever queues behind a batch of stores
+    uint2 held[3][2][RB][4];
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        sa_zero<RB>(acc);
+        sa_gemm_unit<RB>((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + 2 * wave, actA, acc, wpre);
+        if (part + 1 < 3) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + 2 * wave, wpre);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    held[part][j][i][g].x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
+                    held[part][j][i][g].y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                }
+    }
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int tok = i * 32 + t;
+                    if (tok < nvalid)
+                        *reinterpret_cast<uint2*>((bf16_t*)a.qkv_next + (size_t)(m0 + tok) * (3 * SA_D) + part * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl) = held[part][j][i][g];
+                }
+    SA_STAMP();     // 7: next q/k/v projection
+#undef SA_STAMP
+}
+
+template <int RB, int HPR, int LPT, bool ATT>
+static int sa_launch(const VpfSaLayerFwd& a, int chunks, hipStream_t st)
+{
+    const int LP = LPT, TOK = RB * 32;
+    const size_t kv = ATT ? (size_t)HPR * 2 * LP * KLD * 2 : 0, mlp = (size_t)TOK * ALD * 2 + (size_t)2 * TOK * 4 * 4;
+    const size_t lds = (size_t)TOK * ALD * 2 + (kv > mlp ? kv : mlp);
+    if (lds > 160 * 1024) return VPF_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)sa_layer_fwd_kernel<RB, HPR, LPT, ATT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return VPF_ERR_HIP;
+        attr = true;
+    }
+    const dim3 grid = ATT ? dim3(a.B, chunks) : dim3(vpf_cdiv((long)a.B * a.L, TOK), 1);
+    hipLaunchKernelGGL((sa_layer_fwd_kernel<RB, HPR, LPT, ATT>), grid, dim3(256), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfSaLayerFwd& a = *args;
+    if (!a.qkv || !a.base || !a.rng || !a.Wo || !a.bo || !a.ln2_g || !a.ln2_b || !a.W1 || !a.b1 || !a.W2 || !a.b2 || !a.o || !a.lse ||
+        !a.x1 || !a.mean2 || !a.rstd2 || !a.n2 || !a.u || !a.h || !a.out) return VPF_ERR_NULL;
+    if (a.qkv_next && (!a.ln1n_g || !a.ln1n_b || !a.Wqkv_next || !a.mean1n || !a.rstd1n || !a.n1n)) return VPF_ERR_NULL;
+    if (a.pos && a.pos_rows <= 0) return VPF_ERR_BADSHAPE;
+    if (a.B <= 0 || a.L <= 0 || a.chunk_rows <= 0) return VPF_ERR_BADSHAPE;
+    if (a.D != SA_D || a.H != SA_H || a.hidden != SA_HID) return VPF_ERR_UNSUPPORTED;
+    const int chunks = vpf_cdiv(a.L, a.chunk_rows);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.attention_done) return sa_launch<2, 2, 32, false>(a, 1, st);       // o is an input: 64-row blocks, any sequence length
+    // one chunk = up to 4 blocks of 32 tokens; all heads' K / V resident when the sequence is short, else one head per round
+    if (a.chunk_rows <= 96 && a.L <= 96) return sa_launch<3, 4, 96, true>(a, chunks, st);
+    if (a.chunk_rows <= 128 && a.L <= 224) return sa_launch<4, 1, 224, true>(a, chunks, st);
+    return VPF_ERR_UNSUPPORTED;
+}

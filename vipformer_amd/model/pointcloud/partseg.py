@@ -247,6 +247,12 @@ class Encoder(nn.Module):
     def forward(self, group_embs, pos_embs, pts_embs, layer_idx=[], pad_mask=None):
         x = self.cross_attn_1(group_embs, pts_embs, pad_mask, pos=pos_embs)
         feats = []
+        if (self.num_cross_attention_layers == 1 and not layer_idx and pad_mask is None
+                and ops.sa_stack_supported(self.sa_layers, x)):
+            # one fused kernel per self-attention layer (vpf_sa_layer_fwd)
+            params = [p for sa in self.sa_layers for p in sa.parameters()]
+            x = ops.SAStackFn.apply(x, pos_embs, self.sa_layers, self.training, *params)
+            return x if self.modal_prior else feats
         for i, sa in enumerate(self.sa_layers):
             if i + 1 < self.num_cross_attention_layers:
                 x = self.cross_attn_n(x, pts_embs, pad_mask, pos=pos_embs)

@@ -468,6 +468,203 @@ class MLPBlockFn(torch.autograd.Function):
         return (dx.view_as(dout), None, None) + (None,) * ctx.nparams
 
 
+# --------------------------------------------------------------------------- fused self-attention stack
+SA_DEBUG = []         # [int64 tensor of >= 8]: phase cycle counters of workgroup 0 of the last fused layer launch
+SA_SPLIT_ATTN = [None]  # None: per-shape default; True: vpf_attention_fwd + fused tail; False: attention inside the layer kernel
+SA_FUSED = [True]      # Encoder.forward uses the one-kernel-per-layer path when the shapes allow it
+
+
+def sa_stack_supported(layers, x) -> bool:
+    """vpf_sa_layer_fwd covers D = 256, 4 heads of 64, hidden 512, sequences of <= 96 tokens (one workgroup per
+    sequence) or <= 224 tokens (two chunks), identity drop-path."""
+    if not SA_FUSED[0] or len(layers) == 0 or x.dim() != 3:
+        return False
+    B, Lq, D = x.shape
+    if D != 256 or Lq > 224:
+        return False
+    for layer in layers:
+        att = layer[0].module.attention
+        mlp = layer[1].module
+        if att.num_heads != 4 or mlp[1].weight.shape[0] != 512:
+            return False
+        if not isinstance(layer[0].drop_path, torch.nn.Identity) or not isinstance(layer[1].drop_path, torch.nn.Identity):
+            return False
+    return True
+
+
+def _sa_packed(layers, dev):
+    """Fragment-order copies of the stack's weights (Wo, W1, W2 of every layer, Wqkv of layers >= 1), rewritten from the
+    bf16 shadow on every call (the shadow changes every optimizer step; the copy is one small kernel)."""
+    import ctypes
+    holder = layers[0]
+    D, Hd = 256, 512
+    per_layer = D * D + Hd * D + D * Hd + 3 * D * D
+    buf = getattr(holder, "_vpf_packed", None)
+    if buf is None or buf.device != dev or buf.numel() != per_layer * len(layers):
+        buf = torch.empty(per_layer * len(layers), dtype=BF16, device=dev)
+        holder._vpf_packed = buf
+    jobs = (L.PackJob * 32)()
+    views = []
+    n = 0
+    for i, layer in enumerate(layers):
+        att, mlp = layer[0].module.attention, layer[1].module
+        qkvw = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
+        pack_params(qkvw)
+        o = i * per_layer
+        v = dict(Wo=buf[o:o + D * D], W1=buf[o + D * D:o + D * D + Hd * D], W2=buf[o + D * D + Hd * D:o + D * D + 2 * Hd * D],
+                 Wqkv=buf[o + D * D + 2 * Hd * D:o + per_layer])
+        views.append(v)
+        todo = [(shadow([att.o_proj.weight]), v["Wo"], D, D), (shadow([mlp[1].weight]), v["W1"], Hd, D), (shadow([mlp[3].weight]), v["W2"], D, Hd)]
+        if i > 0:
+            todo.append((shadow(qkvw), v["Wqkv"], 3 * D, D))
+        for src, dst, N, K in todo:
+            jobs[n].src, jobs[n].dst, jobs[n].N, jobs[n].K = src.data_ptr(), dst.data_ptr(), N, K
+            n += 1
+            if n == 32:
+                L.call_struct("vpf_pack_wfrag", jobs, n)
+                n = 0
+    if n:
+        L.call_struct("vpf_pack_wfrag", jobs, n)
+    return views
+
+
+class SAStackFn(torch.autograd.Function):
+    """The self-attention stack of Encoder.forward (partseg.py:326-340: pos re-added before every SelfAttentionLayer,
+    :170-188) with ONE forward kernel per layer (vpf_sa_layer_fwd); backward runs the same dgrad / wgrad / attention /
+    LayerNorm kernels as the unfused blocks on the tensors the fused forward saved."""
+
+    @staticmethod
+    def forward(ctx, x, pos, layers, training, *params):
+        ctx.nparams = len(params)
+        B, Lq, D = x.shape
+        M, Hd, H = B * Lq, 512, 4
+        dev = x.device
+        x = x.contiguous().float()
+        nl = len(layers)
+        chunk_rows = Lq if Lq <= 96 else (Lq + 1) // 2
+        packed = _sa_packed(layers, dev)
+        st = rng.state(dev)
+        l0 = layers[0]
+        ln1 = l0[0].module.norm
+        att0 = l0[0].module.attention
+        n1, m1, r1, xsum = layernorm_fwd(x, ln1.weight.data, ln1.bias.data, pos=pos, want_sum=True)
+        base = xsum if xsum is not None else x
+        qkvw0 = [att0.q_proj.weight, att0.k_proj.weight, att0.v_proj.weight]
+        qkv = linear_fwd(n1, shadow(qkvw0), 3 * D, D)
+        pos_c = pos.contiguous().float() if pos is not None else None
+        pos_rows = pos_c.numel() // D if pos_c is not None else 0
+        flat = []
+        out = None
+        for i, layer in enumerate(layers):
+            att, mlp = layer[0].module.attention, layer[1].module
+            ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
+            last = i + 1 == nl
+            o = torch.empty(M, D, dtype=BF16, device=dev)
+            lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
+            x1 = torch.empty(M, D, dtype=F32, device=dev)
+            m2 = torch.empty(M, dtype=F32, device=dev)
+            r2 = torch.empty(M, dtype=F32, device=dev)
+            n2 = torch.empty(M, D, dtype=BF16, device=dev)
+            u = torch.empty(M, Hd, dtype=BF16, device=dev)
+            h = torch.empty(M, Hd, dtype=BF16, device=dev)
+            out = torch.empty(M, D, dtype=F32, device=dev)
+            a = L.SaLayerFwd()
+            a.B, a.L, a.chunk_rows, a.D, a.H, a.hidden = B, Lq, chunk_rows, D, H, Hd
+            a.qkv, a.base, a.rng = qkv.data_ptr(), base.data_ptr(), st.data_ptr()
+            a.scale, a.p_att, a.site_att = float(att.dp_scale), float(att.dropout.p if training else 0.0), att.site_attn
+            a.Wo, a.bo = packed[i]["Wo"].data_ptr(), att.o_proj.bias.data.data_ptr()
+            a.p_res1, a.site_res1 = float(layer[0].dropout.p if training else 0.0), layer[0].site
+            a.ln2_g, a.ln2_b = ln2.weight.data.data_ptr(), ln2.bias.data.data_ptr()
+            a.W1, a.b1 = packed[i]["W1"].data_ptr(), fc1.bias.data.data_ptr()
+            a.W2, a.b2 = packed[i]["W2"].data_ptr(), fc2.bias.data.data_ptr()
+            a.p_res2, a.site_res2 = float(layer[1].dropout.p if training else 0.0), layer[1].site
+            a.o, a.lse, a.x1, a.mean2, a.rstd2, a.n2 = o.data_ptr(), lse.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), n2.data_ptr()
+            a.u, a.h, a.out = u.data_ptr(), h.data_ptr(), out.data_ptr()
+            split = SA_SPLIT_ATTN[0] if SA_SPLIT_ATTN[0] is not None else True
+            if split:
+                L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, D // H, float(att.dp_scale),
+                       float(a.p_att), st, att.site_attn, o, D, lse)
+                a.attention_done = 1
+            nxt = None
+            if not last:
+                lnn = layers[i + 1][0].module.norm
+                nxt = (torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev),
+                       torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, 3 * D, dtype=BF16, device=dev))
+                a.pos, a.pos_rows = (pos_c.data_ptr() if pos_c is not None else None), pos_rows
+                a.ln1n_g, a.ln1n_b, a.Wqkv_next = lnn.weight.data.data_ptr(), lnn.bias.data.data_ptr(), packed[i + 1]["Wqkv"].data_ptr()
+                a.mean1n, a.rstd1n, a.n1n, a.qkv_next = nxt[0].data_ptr(), nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[3].data_ptr()
+            if SA_DEBUG:
+                a.dbg = SA_DEBUG[0].data_ptr()
+            L.call_struct("vpf_sa_layer_fwd", a)
+            flat += [base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h]
+            if not last:
+                base, m1, r1, n1, qkv = out, nxt[0], nxt[1], nxt[2], nxt[3]
+        ctx.layers, ctx.training = layers, training
+        ctx.dims = (B, Lq, D, Hd, H)
+        ctx.pos_shape = tuple(pos.shape) if pos is not None else None
+        ctx.save_for_backward(*flat)
+        return out.view(B, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        flat = ctx.saved_tensors
+        layers, training = ctx.layers, ctx.training
+        B, Lq, D, Hd, H = ctx.dims
+        M = B * Lq
+        dev = dout.device
+        d = dout.contiguous().float().view(M, D)
+        st = rng.state(dev)
+        want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
+        dsum = None
+        for i in range(len(layers) - 1, -1, -1):
+            base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[13 * i:13 * i + 13]
+            layer = layers[i]
+            sa, mlp = layer[0].module, layer[1].module
+            att, ln1 = sa.attention, sa.norm
+            ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
+            # ---- MLP residual block (MLPBlockFn.backward)
+            p2 = layer[1].dropout.p if training else 0.0
+            if p2 > 0.0:
+                dz = torch.empty(M, D, dtype=BF16, device=dev)
+                L.call("vpf_dropout_bwd", d, dz, d.numel(), st, layer[1].site, float(p2))
+            else:
+                dz = to_bf16(d).view(M, D)
+            linear_wgrad(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
+            du = linear_dgrad(dz, shadow([fc2.weight]), D, Hd, mode=EPI_GELU_BWD, aux=u, ldaux=Hd)
+            linear_wgrad(du, n2, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
+            dn = linear_dgrad(du, shadow([fc1.weight]), Hd, D)
+            dx1 = layernorm_bwd(dn, x1, m2, r2, ln2.weight, ln2.bias, d)
+            # ---- attention residual block (AttnBlockFn.backward, self-attention branch)
+            p1 = layer[0].dropout.p if training else 0.0
+            if p1 > 0.0:
+                dz = torch.empty(M, D, dtype=BF16, device=dev)
+                L.call("vpf_dropout_bwd", dx1, dz, dx1.numel(), st, layer[0].site, float(p1))
+            else:
+                dz = to_bf16(dx1).view(M, D)
+            linear_wgrad(dz, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
+            do = linear_dgrad(dz, shadow([att.o_proj.weight]), D, D)
+            qkvw = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
+            w16 = shadow(qkvw)
+            dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+            p_att = att.dropout.p if training else 0.0
+            L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
+                   float(att.dp_scale), float(p_att), st, att.site_attn, dqkv, 3 * D, dqkv[:, D:], 3 * D, dqkv[:, 2 * D:], 3 * D,
+                   torch.empty(B * H * Lq, dtype=F32, device=dev))
+            linear_wgrad(dqkv, n1, 3 * D, D, packed_grad(qkvw))
+            dn1 = linear_dgrad(dqkv, w16, 3 * D, D)
+            d = layernorm_bwd(dn1, base, m1, r1, ln1.weight, ln1.bias, dx1).view(M, D)
+            if want_pos:
+                dsum = d.clone() if dsum is None else dsum.add_(d)
+        dpos = None
+        if want_pos:
+            if ctx.pos_shape[0] == B or B == 1:
+                dpos = dsum.view(ctx.pos_shape)
+            else:
+                dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dev)
+                L.call("vpf_rowsum_mod_f32", dsum, M, D, Lq, dpos)
+        return (d.view(B, Lq, D), dpos, None, None) + (None,) * ctx.nparams
+
+
 # --------------------------------------------------------------------------- generic dropout + residual (Residual fallback)
 class DropoutAddFn(torch.autograd.Function):
     @staticmethod
