@@ -258,6 +258,12 @@ int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b
 int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev,
                    int advance_step, void* stream);
 
+/* Up to 8 weight-gradient GEMMs in one launch (the backward of nn.Linear, e.g. the four of a transformer layer,
+ * partseg.py:48-51,194-197): dW[N,K] += dy[M,N]^T x[M,K] (bf16 operands, fp32 atomics), dbias[N] += column sums of dy
+ * (dbias may be NULL).  host_jobs is a HOST array (copied into the kernel arguments: capturable). */
+typedef struct VpfWgradJob { const void* dy; const void* x; int M, N, K; float* dW; float* dbias; } VpfWgradJob;
+int vpf_wgrad_group(const VpfWgradJob* host_jobs, int njobs, void* stream);
+
 /* ------------------------------------------------------------------ fused self-attention layer
  * SelfAttentionLayer.forward (partseg.py:170-188; Residual :201-213, MultiHeadAttention :14-86, MLP :191-198) for
  * D = 256, 4 heads of 64, hidden 512, as ONE kernel per layer: attention -> o_proj + dropout + residual -> LayerNorm
@@ -298,7 +304,7 @@ typedef struct VpfSaLayerFwd {
     long long* dbg;                                 /* optional: 8 phase cycle counters of workgroup 0 (profiling aid) */
 } VpfSaLayerFwd;
 int vpf_sa_layer_fwd(const VpfSaLayerFwd* host_args, void* stream);
-/* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1): lets a binding verify its struct layout */
+/* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1) / sizeof(VpfWgradJob) (2): lets a binding verify its struct layout */
 int vpf_abi_sizeof(int which);
 
 #ifdef __cplusplus

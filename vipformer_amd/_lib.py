@@ -116,12 +116,18 @@ SIGS = {
     "vpf_pack_wfrag": [VP, I, VP],
     "vpf_sa_layer_fwd": [VP, VP],
     "vpf_abi_sizeof": [I],
+    "vpf_wgrad_group": [VP, I, VP],
 }
 
 
 class PackJob(ctypes.Structure):
     """struct VpfPackJob (include/vipformer_hip.h)."""
     _fields_ = [("src", VP), ("dst", VP), ("N", I), ("K", I)]
+
+
+class WgradJob(ctypes.Structure):
+    """struct VpfWgradJob (include/vipformer_hip.h)."""
+    _fields_ = [("dy", VP), ("x", VP), ("M", I), ("N", I), ("K", I), ("dW", VP), ("dbias", VP)]
 
 
 class SaLayerFwd(ctypes.Structure):

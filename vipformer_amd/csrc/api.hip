@@ -26,6 +26,7 @@ extern "C" int vpf_abi_sizeof(int which)
     switch (which) {
         case 0: return (int)sizeof(VpfPackJob);
         case 1: return (int)sizeof(VpfSaLayerFwd);
+        case 2: return (int)sizeof(VpfWgradJob);
         default: return -1;
     }
 }

@@ -185,7 +185,7 @@ __device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int 
 
 // ------------------------------------------------------------------ kernel
 template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
-__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     using ACfg = TileCfg<BM, ATR, BK>;
@@ -195,17 +195,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = by * BM, n0 = bx * BN;
 
     int kbeg = 0, kend = g.K;
     const bf16_t* A = g.A; const bf16_t* B = g.B;
     long cb = 0;
     if (g.splitk > 1) {
         const int per = ((g.K + g.splitk - 1) / g.splitk + BK - 1) / BK * BK;
-        kbeg = blockIdx.z * per; kend = min(g.K, kbeg + per);
+        kbeg = bz * per; kend = min(g.K, kbeg + per);
         if (kbeg >= kend) return;
     } else {
-        A += (size_t)blockIdx.z * g.sAb; B += (size_t)blockIdx.z * g.sBb; cb = (long)blockIdx.z * g.sCb;
+        A += (size_t)bz * g.sAb; B += (size_t)bz * g.sBb; cb = (long)bz * g.sCb;
     }
 
     f32x16_t acc[TM][TN];
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
     __syncthreads();
 
     // fused bias gradient (wgrad): the first column of workgroups also sums its dY tiles over the tokens
-    const bool do_bias = ATR && g.dbias != nullptr && blockIdx.x == 0;
+    const bool do_bias = ATR && g.dbias != nullptr && bx == 0;
     float bsum = 0.f;
     const int nk = (kend - kbeg + BK - 1) / BK;
     for (int kt = 0; kt < nk; ++kt) {
@@ -386,6 +386,25 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 }
 
 template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
+{
+    gemm_tile<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several independent split-K weight-gradient GEMMs in ONE launch (the four of a transformer layer): each of them alone
+// is a few hundred short workgroups whose ramp-up and tail dominate; together they fill the chip.
+#define GEMM_GROUP_MAX 8
+struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; int nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n; };
+__global__ void __launch_bounds__(256) gemm_wgrad_group_kernel(GemmGroup grp)
+{
+    int p = 0;
+    while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
+    const int local = blockIdx.x - grp.start[p];
+    const int nx = grp.nx[p], ny = grp.ny[p];
+    gemm_tile<1, 1, 2, 2, 128, true, true, 0, 0>(grp.g[p], local % nx, (local / nx) % ny, local / (nx * ny));
+}
+
+template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
 static int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -514,4 +533,48 @@ extern "C" int vpf_gemm_bf16_fused(const void* A, int a_kstrided, long lda, int 
             return VPF_ERR_UNSUPPORTED;
     }
     return gemm_dispatch(g, a_kstrided, b_kstrided, 1, (hipStream_t)stream);
+}
+
+
+// dW_i[N_i,K_i] += dY_i[M_i,N_i]^T . X_i[M_i,K_i]  (+ dbias_i[N_i] += column sums of dY_i) for up to 8 problems in one launch
+extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
+{
+    (void)hipGetLastError();
+    if (!jobs) return VPF_ERR_NULL;
+    if (njobs <= 0 || njobs > GEMM_GROUP_MAX) return VPF_ERR_BADSHAPE;
+    GemmGroup grp = {};
+    grp.n = njobs;
+    long total_tiles = 0;
+    for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, 64) * vpf_cdiv(jobs[i].K, 64);
+    int at = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const VpfWgradJob& j = jobs[i];
+        if (!j.dy || !j.x || !j.dW) return VPF_ERR_NULL;
+        if (j.M <= 0 || j.N <= 0 || j.K <= 0) return VPF_ERR_BADSHAPE;
+        if ((j.N % 8) || (j.K % 8) || ((uintptr_t)j.dy & 15) || ((uintptr_t)j.x & 15)) return VPF_ERR_BADALIGN;
+        GemmArgs& g = grp.g[i];
+        // C[m = n_out, n = k_in] += sum over tokens: A = dY read k-strided (rows = N), B = X read k-strided (rows = K)
+        g.A = (const bf16_t*)j.dy; g.B = (const bf16_t*)j.x; g.lda = j.N; g.ldb = j.K;
+        g.M = j.N; g.N = j.K; g.K = j.M; g.mode = EPI_ATOMIC; g.C = j.dW; g.ldc = j.K; g.c_f32 = 1; g.dbias = j.dbias; g.group = 1;
+        const int nx = vpf_cdiv(g.N, 64), ny = vpf_cdiv(g.M, 64);
+        // ~2048 workgroups over the whole group, every K slice at least 256 tokens deep
+        long sp = 2048 / (total_tiles > 0 ? total_tiles : 1);
+        const long maxs = vpf_cdiv(g.K, 256);
+        if (sp > maxs) sp = maxs;
+        if (sp < 2) sp = 2;                       // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
+        g.splitk = (int)sp;
+        grp.nx[i] = nx; grp.ny[i] = ny; grp.start[i] = at;
+        at += nx * ny * (int)sp;
+    }
+    grp.start[njobs] = at;
+    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<64, true, 128>::ELEMS + TileCfg<64, true, 128>::ELEMS);
+    static bool attr = false;
+    if (!attr) {
+        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(at), dim3(256), lds, (hipStream_t)stream, grp);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
 }

@@ -250,6 +250,34 @@ def linear_wgrad(dy16, x16, N, K, dW, dbias=None):
     x16.record_stream(side)
 
 
+WGRAD_GROUP = [True]
+
+
+class WgradBatch:
+    """Collects linear_wgrad calls of one layer and issues them as ONE grouped launch (vpf_wgrad_group)."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, dy16, x16, N, K, dW, dbias=None):
+        if not WGRAD_GROUP[0]:
+            linear_wgrad(dy16, x16, N, K, dW, dbias)
+            return
+        self.jobs.append((dy16, x16, dy16.numel() // N, N, K, dW, dbias))
+        if len(self.jobs) == 8:
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        arr = (L.WgradJob * 8)()
+        for i, (dy, x, M, N, K, dW, db) in enumerate(self.jobs):
+            arr[i].dy, arr[i].x, arr[i].M, arr[i].N, arr[i].K = dy.data_ptr(), x.data_ptr(), M, N, K
+            arr[i].dW, arr[i].dbias = dW.data_ptr(), (db.data_ptr() if db is not None else None)
+        L.call_struct("vpf_wgrad_group", arr, len(self.jobs))
+        self.jobs = []
+
+
 def colsum(x, C, acc, acc2=None):
     M = x.numel() // C
     L.call("vpf_colsum", x, int(x.dtype == BF16), M, C, acc, acc2)
@@ -619,6 +647,7 @@ class SAStackFn(torch.autograd.Function):
         for i in range(len(layers) - 1, -1, -1):
             base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[13 * i:13 * i + 13]
             layer = layers[i]
+            wg = WgradBatch()
             sa, mlp = layer[0].module, layer[1].module
             att, ln1 = sa.attention, sa.norm
             ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
@@ -629,9 +658,9 @@ class SAStackFn(torch.autograd.Function):
                 L.call("vpf_dropout_bwd", d, dz, d.numel(), st, layer[1].site, float(p2))
             else:
                 dz = to_bf16(d).view(M, D)
-            linear_wgrad(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
+            wg.add(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
             du = linear_dgrad(dz, shadow([fc2.weight]), D, Hd, mode=EPI_GELU_BWD, aux=u, ldaux=Hd)
-            linear_wgrad(du, n2, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
+            wg.add(du, n2, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
             dn = linear_dgrad(du, shadow([fc1.weight]), Hd, D)
             dx1 = layernorm_bwd(dn, x1, m2, r2, ln2.weight, ln2.bias, d)
             # ---- attention residual block (AttnBlockFn.backward, self-attention branch)
@@ -641,7 +670,7 @@ class SAStackFn(torch.autograd.Function):
                 L.call("vpf_dropout_bwd", dx1, dz, dx1.numel(), st, layer[0].site, float(p1))
             else:
                 dz = to_bf16(dx1).view(M, D)
-            linear_wgrad(dz, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
+            wg.add(dz, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
             do = linear_dgrad(dz, shadow([att.o_proj.weight]), D, D)
             qkvw = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
             w16 = shadow(qkvw)
@@ -650,9 +679,10 @@ class SAStackFn(torch.autograd.Function):
             L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
                    float(att.dp_scale), float(p_att), st, att.site_attn, dqkv, 3 * D, dqkv[:, D:], 3 * D, dqkv[:, 2 * D:], 3 * D,
                    torch.empty(B * H * Lq, dtype=F32, device=dev))
-            linear_wgrad(dqkv, n1, 3 * D, D, packed_grad(qkvw))
+            wg.add(dqkv, n1, 3 * D, D, packed_grad(qkvw))
             dn1 = linear_dgrad(dqkv, w16, 3 * D, D)
             d = layernorm_bwd(dn1, base, m1, r1, ln1.weight, ln1.bias, dx1).view(M, D)
+            wg.flush()
             if want_pos:
                 dsum = d.clone() if dsum is None else dsum.add_(d)
         dpos = None
