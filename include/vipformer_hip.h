@@ -273,9 +273,11 @@ int vpf_wgrad_group(const VpfWgradJob* host_jobs, int njobs, void* stream);
  * the attention itself is left to vpf_attention_fwd and a workgroup owns any 64 consecutive rows.
  * Weights are read in the MFMA fragment order produced by vpf_pack_wfrag from the natural bf16 [N,K] matrices.
  * Everything the backward needs is written as the unfused ops write it. */
-typedef struct VpfPackJob { const void* src; void* dst; int N, K; } VpfPackJob;
-#define VPF_PACK_MAX_JOBS 32
-/* natural bf16 W[N][K] -> fragment order: ((cb*(K/16) + ks)*64 + lane)*8 + j  <-  W[cb*32 + (lane&31)][ks*16 + 8*(lane>>5) + j].
+typedef struct VpfPackJob { const void* src; void* dst; int N, K; int transposed; int pad_; } VpfPackJob;
+#define VPF_PACK_MAX_JOBS 64
+/* logical A[N][K] -> fragment order: ((cb*(K/16) + ks)*64 + lane)*8 + j  <-  A[cb*32 + (lane&31)][ks*16 + 8*(lane>>5) + j];
+ * A[n][k] = src[n*K + k] (a natural nn.Linear weight, forward) or, with transposed = 1, src[k*N + n] (the same weight
+ * read for dgrad: N = in_features, K = out_features).
  * jobs is a HOST array (copied into the kernel arguments: capturable). */
 int vpf_pack_wfrag(const VpfPackJob* host_jobs, int njobs, void* stream);
 
@@ -304,6 +306,29 @@ typedef struct VpfSaLayerFwd {
     long long* dbg;                                 /* optional: 8 phase cycle counters of workgroup 0 (profiling aid) */
 } VpfSaLayerFwd;
 int vpf_sa_layer_fwd(const VpfSaLayerFwd* host_args, void* stream);
+/* The dgrad chain of the same layer (backward of partseg.py:170-213) as two row-block kernels around vpf_attention_bwd:
+ *   _mlp: d = dL/d(x2) -> dz2 = dropout'(d) -> du = (dz2 W2) * gelu'(u) -> dn = du W1 -> dx1 = LayerNorm2'(dn) + d
+ *         -> dz1 = dropout'(dx1) -> dout_attn = dz1 Wo;   dln2_g / dln2_b += this batch's LayerNorm-2 parameter gradients
+ *   _qkv: dbase = LayerNorm1'(dqkv Wqkv) + dx1 (also accumulated into dsum when set); dln1_g / dln1_b likewise.
+ * dz2, du, dz1, dqkv are the bf16 operands of the weight-gradient GEMMs (vpf_wgrad_group).  W*T = vpf_pack_wfrag with
+ * transposed = 1.  pgrad1 / pgrad2: workspaces of ceil(M/64) * 512 floats. */
+typedef struct VpfSaLayerBwd {
+    int M, D, hidden;
+    const uint32_t* rng;
+    float p_res1; uint32_t site_res1; float p_res2; uint32_t site_res2;
+    /* _mlp */
+    const float* d; const void* u; const float* x1; const float* mean2; const float* rstd2; const float* ln2_g;
+    const void* W2T; const void* W1T; const void* WoT;
+    void* dz2; void* du; float* dx1; void* dz1; void* dout_attn;
+    float* pgrad2; float* dln2_g; float* dln2_b;
+    /* _qkv */
+    const void* dqkv; const void* WqkvT; const float* base; const float* mean1; const float* rstd1; const float* ln1_g;
+    float* dbase; float* dsum;
+    float* pgrad1; float* dln1_g; float* dln1_b;
+} VpfSaLayerBwd;
+int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* host_args, void* stream);
+int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);
+/* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3) */
 /* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1) / sizeof(VpfWgradJob) (2): lets a binding verify its struct layout */
 int vpf_abi_sizeof(int which);
 

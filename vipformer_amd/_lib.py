@@ -117,12 +117,14 @@ SIGS = {
     "vpf_sa_layer_fwd": [VP, VP],
     "vpf_abi_sizeof": [I],
     "vpf_wgrad_group": [VP, I, VP],
+    "vpf_sa_layer_bwd_mlp": [VP, VP],
+    "vpf_sa_layer_bwd_qkv": [VP, VP],
 }
 
 
 class PackJob(ctypes.Structure):
     """struct VpfPackJob (include/vipformer_hip.h)."""
-    _fields_ = [("src", VP), ("dst", VP), ("N", I), ("K", I)]
+    _fields_ = [("src", VP), ("dst", VP), ("N", I), ("K", I), ("transposed", I), ("pad_", I)]
 
 
 class WgradJob(ctypes.Structure):
@@ -147,6 +149,19 @@ class SaLayerFwd(ctypes.Structure):
                 ("pos", VP), ("pos_rows", I),
                 ("ln1n_g", VP), ("ln1n_b", VP), ("Wqkv_next", VP),
                 ("mean1n", VP), ("rstd1n", VP), ("n1n", VP), ("qkv_next", VP), ("attention_done", I), ("dbg", VP)]
+
+
+class SaLayerBwd(ctypes.Structure):
+    """struct VpfSaLayerBwd (include/vipformer_hip.h) -- same field order."""
+    _fields_ = [("M", I), ("D", I), ("hidden", I), ("rng", VP),
+                ("p_res1", F), ("site_res1", U32), ("p_res2", F), ("site_res2", U32),
+                ("d", VP), ("u", VP), ("x1", VP), ("mean2", VP), ("rstd2", VP), ("ln2_g", VP),
+                ("W2T", VP), ("W1T", VP), ("WoT", VP),
+                ("dz2", VP), ("du", VP), ("dx1", VP), ("dz1", VP), ("dout_attn", VP),
+                ("pgrad2", VP), ("dln2_g", VP), ("dln2_b", VP),
+                ("dqkv", VP), ("WqkvT", VP), ("base", VP), ("mean1", VP), ("rstd1", VP), ("ln1_g", VP),
+                ("dbase", VP), ("dsum", VP),
+                ("pgrad1", VP), ("dln1_g", VP), ("dln1_b", VP)]
 
 
 def call_struct(name: str, struct, *extra) -> None:

@@ -27,6 +27,7 @@ extern "C" int vpf_abi_sizeof(int which)
         case 0: return (int)sizeof(VpfPackJob);
         case 1: return (int)sizeof(VpfSaLayerFwd);
         case 2: return (int)sizeof(VpfWgradJob);
+        case 3: return (int)sizeof(VpfSaLayerBwd);
         default: return -1;
     }
 }

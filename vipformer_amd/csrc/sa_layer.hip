@@ -80,7 +80,17 @@ __global__ void pack_wfrag_kernel(PackJobs jobs)
         const long f = e >> 6;
         const int ks = (int)(f % ksn), cb = (int)(f / ksn);
         const long row = cb * 32 + (l & 31), col = ks * 16 + 8 * (l >> 5);
-        dst[e] = src[(row * j.K + col) >> 3];
+        if (!j.transposed) {
+            dst[e] = src[(row * j.K + col) >> 3];
+        } else {
+            // logical A[row][col] = src[col * N + row]  (src stored [K][N]: the transposed view of a natural weight)
+            const bf16_t* s16 = reinterpret_cast<const bf16_t*>(j.src);
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[q] = (uint32_t)s16[(col + 2 * q) * (long)j.N + row] | ((uint32_t)s16[(col + 2 * q + 1) * (long)j.N + row] << 16);
+            dst[e] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     }
 }
 extern "C" int vpf_pack_wfrag(const VpfPackJob* jobs, int njobs, void* stream)
@@ -667,4 +677,390 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     if (a.chunk_rows <= 96 && a.L <= 96) return sa_launch<3, 4, 96, true>(a, chunks, st);
     if (a.chunk_rows <= 128 && a.L <= 224) return sa_launch<4, 1, 224, true>(a, chunks, st);
     return VPF_ERR_UNSUPPORTED;
+}
+
+// ================================================================================================ backward
+// The dgrad chain of a self-attention layer in two row-block kernels around the attention backward:
+//   vpf_sa_layer_bwd_mlp : d(x2) -> dropout' -> [dz2] -> . W2 * gelu'(u) -> [du] -> . W1 -> LayerNorm-2' (+ d) -> [dx1]
+//                          -> dropout' -> [dz1] -> . Wo -> [do]
+//   vpf_sa_layer_bwd_qkv : [dqkv] . Wqkv -> LayerNorm-1' (+ dx1) -> [dbase]
+// ([..] = written to HBM: the bf16 ones are the operands of the weight-gradient GEMMs / the attention backward.)
+// Same layout as the forward: swapped products, a lane owns a token, weights in (transposed) fragment order.
+
+// LayerNorm backward in place on the accumulator tile: acc = dL/dy -> dL/dx;  x (the forward input) from HBM.
+// The per-channel parameter gradients of this workgroup's tokens go to pgrad[0..255] (dgamma) / pgrad[256..511] (dbeta).
+template <int RB>
+__device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[2][RB], const float* __restrict__ x, const float* __restrict__ mean,
+                                                 const float* __restrict__ rstd, const float* __restrict__ gamma, float* sStat2,
+                                                 float* __restrict__ pgrad, long m0, int nvalid)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    float mu[RB], rs[RB];
+    float4 xh[2][4][RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const bool ok = i * 32 + t < nvalid;
+        mu[i] = ok ? mean[m0 + i * 32 + t] : 0.f;
+        rs[i] = ok ? rstd[m0 + i * 32 + t] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int tok = i * 32 + t;
+                xh[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(x + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    float s1[RB], s2[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    float dgam[2][4][4], dbet[2][4][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + 64 * wave + 32 * j + 8 * g + 4 * hl);
+            const float gg[4] = {ga.x, ga.y, ga.z, ga.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { dgam[j][g][q] = 0.f; dbet[j][g][q] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                float xv[4] = {xh[j][g][i].x, xh[j][g][i].y, xh[j][g][i].z, xh[j][g][i].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xn = (xv[q] - mu[i]) * rs[i];
+                    const float dy = acc[j][i][4 * g + q];
+                    dgam[j][g][q] += dy * xn;
+                    dbet[j][g][q] += dy;
+                    const float gy = dy * gg[q];
+                    s1[i] += gy;
+                    s2[i] += gy * xn;
+                    acc[j][i][4 * g + q] = gy;
+                    xv[q] = xn;
+                }
+                xh[j][g][i] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+            }
+        }
+    // per-token sums over the channels: lane ^ 32, then the 4 waves
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        s1[i] += __shfl_xor(s1[i], 32, 64);
+        s2[i] += __shfl_xor(s2[i], 32, 64);
+        if (lane < 32) *reinterpret_cast<float2*>(sStat2 + ((i * 32 + lane) * 4 + wave) * 2) = make_float2(s1[i], s2[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const float4 v0 = *reinterpret_cast<const float4*>(sStat2 + (i * 32 + t) * 8), v1 = *reinterpret_cast<const float4*>(sStat2 + (i * 32 + t) * 8 + 4);
+        s1[i] = ((v0.x + v0.z) + (v1.x + v1.z)) * (1.0f / SA_D);
+        s2[i] = ((v0.y + v0.w) + (v1.y + v1.w)) * (1.0f / SA_D);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const float xv[4] = {xh[j][g][i].x, xh[j][g][i].y, xh[j][g][i].z, xh[j][g][i].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[j][i][4 * g + q] = rs[i] * (acc[j][i][4 * g + q] - s1[i] - xv[q] * s2[i]);
+            }
+    // parameter gradients: sum over this workgroup's tokens = over the 32 lanes of each half
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = dgam[j][g][q], b = dbet[j][g][q];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (t == 0) {
+                    const int c = 64 * wave + 32 * j + 8 * g + 4 * hl + q;
+                    pgrad[c] = a;
+                    pgrad[SA_D + c] = b;
+                }
+            }
+}
+
+// dropout backward of the f32 rows `src` in accumulator layout -> acc (f32, scaled / zeroed)
+template <int RB>
+__device__ __forceinline__ void sa_load_dropout_bwd(f32x16_t (&acc)[2][RB], const float* __restrict__ src, const VpfRng& rng, bool drop,
+                                                    long m0, int nvalid)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    float4 v[2][4][RB];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int tok = i * 32 + t;
+                v[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int tok = i * 32 + t;
+                const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
+                const float s = drop ? rng.scale : 1.f;
+                acc[j][i][4 * g + 0] = (keep & 1u) ? v[j][g][i].x * s : 0.f;
+                acc[j][i][4 * g + 1] = (keep & 2u) ? v[j][g][i].y * s : 0.f;
+                acc[j][i][4 * g + 2] = (keep & 4u) ? v[j][g][i].z * s : 0.f;
+                acc[j][i][4 * g + 3] = (keep & 8u) ? v[j][g][i].w * s : 0.f;
+            }
+}
+
+template <int RB>
+__global__ void __launch_bounds__(256) sa_bwd_mlp_kernel(VpfSaLayerBwd a)
+{
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    constexpr int TOK = RB * 32;
+    bf16_t* actA = lds;                               // dz2 -> dz1
+    bf16_t* actH = lds + TOK * ALD;                   // one 256-wide chunk of du
+    float* sStat2 = reinterpret_cast<float*>(actH + TOK * ALD);   // [TOK][4] float2
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    const long M = (long)a.M;
+    const long m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, M - m0);
+
+    SaWPre wpre;
+    sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, 2 * wave, wpre);
+    f32x16_t acc[2][RB], acc2[2][RB];
+    // ---- dz2 = dropout'(d)
+    {
+        const VpfRng rng = vpf_rng_init(a.rng, a.site_res2, a.p_res2);
+        sa_load_dropout_bwd<RB>(acc, a.d, rng, a.p_res2 > 0.f, m0, nvalid);
+        sa_store_bf16<RB>(acc, actA, 0, (bf16_t*)a.dz2, SA_D, 0, m0, nvalid);
+    }
+    __syncthreads();
+    // ---- du = (dz2 . W2) * gelu'(u) ;  dn = du . W1
+    sa_zero<RB>(acc2);
+#pragma unroll
+    for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
+        uint2 uu[2][4][RB];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    uu[j][g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                                               : make_uint2(0u, 0u);
+                }
+        sa_zero<RB>(acc);
+        sa_gemm_unit<RB>((const bf16_t*)a.W2T, SA_D / 16, 0, hc * 8 + 2 * wave, actA, acc, wpre);
+        sa_wprefetch((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, 2 * wave, wpre);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    acc[j][i][4 * g + 0] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].x << 16));
+                    acc[j][i][4 * g + 1] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].x & 0xffff0000u));
+                    acc[j][i][4 * g + 2] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].y << 16));
+                    acc[j][i][4 * g + 3] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].y & 0xffff0000u));
+                }
+        if (hc) __syncthreads();
+        sa_store_bf16<RB>(acc, actH, 0, (bf16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
+        __syncthreads();
+        sa_gemm_unit<RB>((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, 2 * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + 2 * wave, wpre);
+    }
+    sa_wprefetch((const bf16_t*)a.WoT, SA_D / 16, 0, 2 * wave, wpre);
+    // ---- dx1 = LayerNorm-2'(dn) + d
+    sa_layernorm_bwd<RB>(acc2, a.x1, a.mean2, a.rstd2, a.ln2_g, sStat2, a.pgrad2 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+    {
+        float4 dv[2][4][RB];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    dv[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(a.d + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        const VpfRng rng = vpf_rng_init(a.rng, a.site_res1, a.p_res1);
+        const bool drop = a.p_res1 > 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                    float v[4] = {acc2[j][i][4 * g + 0] + dv[j][g][i].x, acc2[j][i][4 * g + 1] + dv[j][g][i].y,
+                                  acc2[j][i][4 * g + 2] + dv[j][g][i].z, acc2[j][i][4 * g + 3] + dv[j][g][i].w};
+                    if (tok < nvalid) *reinterpret_cast<float4*>(a.dx1 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
+                    const float s = drop ? rng.scale : 1.f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc2[j][i][4 * g + q] = ((keep >> q) & 1u) ? v[q] * s : 0.f;
+                }
+    }
+    // (the barriers of the hidden-chunk loop guarantee every wave has finished reading dz2 from actA)
+    sa_store_bf16<RB>(acc2, actA, 0, (bf16_t*)a.dz1, SA_D, 0, m0, nvalid);
+    __syncthreads();
+    // ---- do = dz1 . Wo
+    sa_zero<RB>(acc);
+    sa_gemm_unit<RB>((const bf16_t*)a.WoT, SA_D / 16, 0, 2 * wave, actA, acc, wpre);
+    sa_store_bf16<RB>(acc, nullptr, 0, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
+}
+
+template <int RB>
+__global__ void __launch_bounds__(256) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
+{
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    constexpr int TOK = RB * 32;
+    bf16_t* actA = lds;                                // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
+    float* sStat2 = reinterpret_cast<float*>(lds + 2 * TOK * ALD);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    const long M = (long)a.M;
+    const long m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, M - m0);
+    constexpr int CPT = TOK * 32 / 256;
+
+    SaWPre wpre;
+    sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, 0, 2 * wave, wpre);
+    uint4 r[CPT];
+    auto load_part = [&](int part) {
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dqkv + (size_t)(m0 + row) * (3 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_part = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            *reinterpret_cast<uint4*>(actA + buf * TOK * ALD + row * ALD + ch * 8) = r[it];
+        }
+    };
+    load_part(0);
+    store_part(0);
+    __syncthreads();
+    f32x16_t acc[2][RB];
+    sa_zero<RB>(acc);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        if (part + 1 < 3) load_part(part + 1);
+        sa_gemm_unit<RB>((const bf16_t*)a.WqkvT, 3 * SA_D / 16, part * 16, 2 * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
+        if (part + 1 < 3) {
+            sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, (part + 1) * 16, 2 * wave, wpre);
+            store_part((part + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // ---- dbase = LayerNorm-1'(dn1) + dx1
+    sa_layernorm_bwd<RB>(acc, a.base, a.mean1, a.rstd1, a.ln1_g, sStat2, a.pgrad1 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+    float4 dv[2][4][RB];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int tok = i * 32 + t;
+                dv[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(a.dx1 + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int tok = i * 32 + t;
+                if (tok >= nvalid) continue;
+                const size_t off = (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const float4 v = make_float4(acc[j][i][4 * g + 0] + dv[j][g][i].x, acc[j][i][4 * g + 1] + dv[j][g][i].y,
+                                             acc[j][i][4 * g + 2] + dv[j][g][i].z, acc[j][i][4 * g + 3] + dv[j][g][i].w);
+                *reinterpret_cast<float4*>(a.dbase + off) = v;
+                if (a.dsum) {
+                    float4 s = *reinterpret_cast<const float4*>(a.dsum + off);
+                    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                    *reinterpret_cast<float4*>(a.dsum + off) = s;
+                }
+            }
+}
+
+// out_g[c] += sum_r partials[r][c], out_b[c] += sum_r partials[r][256 + c]  (fixed order: deterministic)
+__global__ void sa_pgrad_reduce_kernel(const float* __restrict__ partials, int rows, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    __shared__ float fold[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;      // 8 blocks x 64 columns of the 512
+    float s = 0.f;
+    for (int r = rg; r < rows; r += 4) s += partials[(size_t)r * 2 * SA_D + c];
+    fold[rg][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rg == 0) {
+        const float tot = (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]);
+        if (c < SA_D) dgamma[c] += tot; else dbeta[c - SA_D] += tot;
+    }
+}
+
+static int sa_bwd_check(const VpfSaLayerBwd& a)
+{
+    if (a.M <= 0) return VPF_ERR_BADSHAPE;
+    if (a.D != SA_D || a.hidden != SA_HID) return VPF_ERR_UNSUPPORTED;
+    return VPF_OK;
+}
+extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfSaLayerBwd& a = *args;
+    int rc = sa_bwd_check(a);
+    if (rc) return rc;
+    if (!a.d || !a.rng || !a.u || !a.x1 || !a.mean2 || !a.rstd2 || !a.ln2_g || !a.W2T || !a.W1T || !a.WoT || !a.dz2 || !a.du || !a.dx1 ||
+        !a.dz1 || !a.dout_attn || !a.pgrad2 || !a.dln2_g || !a.dln2_b) return VPF_ERR_NULL;
+    constexpr int RB = 2, TOK = RB * 32;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 4 * 2 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    const int nwg = vpf_cdiv((long)a.M, TOK);
+    hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    VPF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, a.pgrad2, nwg, a.dln2_g, a.dln2_b);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfSaLayerBwd& a = *args;
+    int rc = sa_bwd_check(a);
+    if (rc) return rc;
+    if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1 || !a.dln1_g || !a.dln1_b) return VPF_ERR_NULL;
+    constexpr int RB = 2, TOK = RB * 32;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 4 * 2 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    const int nwg = vpf_cdiv((long)a.M, TOK);
+    hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    VPF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, a.pgrad1, nwg, a.dln1_g, a.dln1_b);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
 }

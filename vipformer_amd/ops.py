@@ -499,6 +499,7 @@ class MLPBlockFn(torch.autograd.Function):
 # --------------------------------------------------------------------------- fused self-attention stack
 SA_DEBUG = []         # [int64 tensor of >= 8]: phase cycle counters of workgroup 0 of the last fused layer launch
 SA_SPLIT_ATTN = [None]  # None: per-shape default; True: vpf_attention_fwd + fused tail; False: attention inside the layer kernel
+SA_FUSED_BWD = [True]  # backward of the stack through vpf_sa_layer_bwd_mlp / _qkv instead of the block-by-block kernels
 SA_FUSED = [True]      # Encoder.forward uses the one-kernel-per-layer path when the shapes allow it
 
 
@@ -521,17 +522,18 @@ def sa_stack_supported(layers, x) -> bool:
 
 
 def _sa_packed(layers, dev):
-    """Fragment-order copies of the stack's weights (Wo, W1, W2 of every layer, Wqkv of layers >= 1), rewritten from the
-    bf16 shadow on every call (the shadow changes every optimizer step; the copy is one small kernel)."""
-    import ctypes
+    """Fragment-order copies of the stack's weights -- forward: Wo, W1, W2 (and Wqkv of layers >= 1); backward (dgrad):
+    the transposed views W2T, W1T, WoT, WqkvT -- rewritten from the bf16 shadow on every call (the shadow changes every
+    optimizer step; the copy is one small kernel)."""
     holder = layers[0]
     D, Hd = 256, 512
-    per_layer = D * D + Hd * D + D * Hd + 3 * D * D
+    sizes = [("Wo", D * D), ("W1", Hd * D), ("W2", D * Hd), ("Wqkv", 3 * D * D), ("W2T", Hd * D), ("W1T", D * Hd), ("WoT", D * D), ("WqkvT", 3 * D * D)]
+    per_layer = sum(n for _, n in sizes)
     buf = getattr(holder, "_vpf_packed", None)
     if buf is None or buf.device != dev or buf.numel() != per_layer * len(layers):
         buf = torch.empty(per_layer * len(layers), dtype=BF16, device=dev)
         holder._vpf_packed = buf
-    jobs = (L.PackJob * 32)()
+    jobs = (L.PackJob * 64)()
     views = []
     n = 0
     for i, layer in enumerate(layers):
@@ -539,16 +541,21 @@ def _sa_packed(layers, dev):
         qkvw = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
         pack_params(qkvw)
         o = i * per_layer
-        v = dict(Wo=buf[o:o + D * D], W1=buf[o + D * D:o + D * D + Hd * D], W2=buf[o + D * D + Hd * D:o + D * D + 2 * Hd * D],
-                 Wqkv=buf[o + D * D + 2 * Hd * D:o + per_layer])
+        v = {}
+        for name, cnt in sizes:
+            v[name] = buf[o:o + cnt]
+            o += cnt
         views.append(v)
-        todo = [(shadow([att.o_proj.weight]), v["Wo"], D, D), (shadow([mlp[1].weight]), v["W1"], Hd, D), (shadow([mlp[3].weight]), v["W2"], D, Hd)]
+        wo, w1, w2, wqkv = shadow([att.o_proj.weight]), shadow([mlp[1].weight]), shadow([mlp[3].weight]), shadow(qkvw)
+        #       src   dst        N (rows of the logical operand)  K (contraction)  transposed
+        todo = [(wo, v["Wo"], D, D, 0), (w1, v["W1"], Hd, D, 0), (w2, v["W2"], D, Hd, 0),
+                (w2, v["W2T"], Hd, D, 1), (w1, v["W1T"], D, Hd, 1), (wo, v["WoT"], D, D, 1), (wqkv, v["WqkvT"], D, 3 * D, 1)]
         if i > 0:
-            todo.append((shadow(qkvw), v["Wqkv"], 3 * D, D))
-        for src, dst, N, K in todo:
-            jobs[n].src, jobs[n].dst, jobs[n].N, jobs[n].K = src.data_ptr(), dst.data_ptr(), N, K
+            todo.append((wqkv, v["Wqkv"], 3 * D, D, 0))
+        for src, dst, N, K, tr in todo:
+            jobs[n].src, jobs[n].dst, jobs[n].N, jobs[n].K, jobs[n].transposed = src.data_ptr(), dst.data_ptr(), N, K, tr
             n += 1
-            if n == 32:
+            if n == 64:
                 L.call_struct("vpf_pack_wfrag", jobs, n)
                 n = 0
     if n:
@@ -627,7 +634,7 @@ class SAStackFn(torch.autograd.Function):
             flat += [base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h]
             if not last:
                 base, m1, r1, n1, qkv = out, nxt[0], nxt[1], nxt[2], nxt[3]
-        ctx.layers, ctx.training = layers, training
+        ctx.layers, ctx.training, ctx.packed = layers, training, packed
         ctx.dims = (B, Lq, D, Hd, H)
         ctx.pos_shape = tuple(pos.shape) if pos is not None else None
         ctx.save_for_backward(*flat)
@@ -643,6 +650,8 @@ class SAStackFn(torch.autograd.Function):
         d = dout.contiguous().float().view(M, D)
         st = rng.state(dev)
         want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
+        if SA_FUSED_BWD[0]:
+            return SAStackFn._backward_fused(ctx, d, st, want_pos)
         dsum = None
         for i in range(len(layers) - 1, -1, -1):
             base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[13 * i:13 * i + 13]
@@ -685,6 +694,65 @@ class SAStackFn(torch.autograd.Function):
             wg.flush()
             if want_pos:
                 dsum = d.clone() if dsum is None else dsum.add_(d)
+        dpos = None
+        if want_pos:
+            if ctx.pos_shape[0] == B or B == 1:
+                dpos = dsum.view(ctx.pos_shape)
+            else:
+                dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dev)
+                L.call("vpf_rowsum_mod_f32", dsum, M, D, Lq, dpos)
+        return (d.view(B, Lq, D), dpos, None, None) + (None,) * ctx.nparams
+
+
+    @staticmethod
+    def _backward_fused(ctx, d, st, want_pos):
+        flat = ctx.saved_tensors
+        layers, training, packed = ctx.layers, ctx.training, ctx.packed
+        B, Lq, D, Hd, H = ctx.dims
+        M = B * Lq
+        dev = d.device
+        nwg = (M + 63) // 64
+        pg1 = torch.empty(nwg * 2 * D, dtype=F32, device=dev)
+        pg2 = torch.empty(nwg * 2 * D, dtype=F32, device=dev)
+        dsum = torch.zeros(M, D, dtype=F32, device=dev) if want_pos else None
+        for i in range(len(layers) - 1, -1, -1):
+            base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[13 * i:13 * i + 13]
+            layer = layers[i]
+            sa, mlp = layer[0].module, layer[1].module
+            att, ln1 = sa.attention, sa.norm
+            ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
+            dz2 = torch.empty(M, D, dtype=BF16, device=dev)
+            du = torch.empty(M, Hd, dtype=BF16, device=dev)
+            dx1 = torch.empty(M, D, dtype=F32, device=dev)
+            dz1 = torch.empty(M, D, dtype=BF16, device=dev)
+            do = torch.empty(M, D, dtype=BF16, device=dev)
+            dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+            dbase = torch.empty(M, D, dtype=F32, device=dev)
+            a = L.SaLayerBwd()
+            a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
+            a.p_res1, a.site_res1 = float(layer[0].dropout.p if training else 0.0), layer[0].site
+            a.p_res2, a.site_res2 = float(layer[1].dropout.p if training else 0.0), layer[1].site
+            a.d, a.u, a.x1, a.mean2, a.rstd2, a.ln2_g = d.data_ptr(), u.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), ln2.weight.data.data_ptr()
+            a.W2T, a.W1T, a.WoT = packed[i]["W2T"].data_ptr(), packed[i]["W1T"].data_ptr(), packed[i]["WoT"].data_ptr()
+            a.dz2, a.du, a.dx1, a.dz1, a.dout_attn = dz2.data_ptr(), du.data_ptr(), dx1.data_ptr(), dz1.data_ptr(), do.data_ptr()
+            a.pgrad2, a.dln2_g, a.dln2_b = pg2.data_ptr(), grad_buf(ln2.weight).data_ptr(), grad_buf(ln2.bias).data_ptr()
+            a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = (dqkv.data_ptr(), packed[i]["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(),
+                                                                 r1.data_ptr(), ln1.weight.data.data_ptr())
+            a.dbase, a.dsum = dbase.data_ptr(), (dsum.data_ptr() if dsum is not None else None)
+            a.pgrad1, a.dln1_g, a.dln1_b = pg1.data_ptr(), grad_buf(ln1.weight).data_ptr(), grad_buf(ln1.bias).data_ptr()
+            L.call_struct("vpf_sa_layer_bwd_mlp", a)
+            p_att = att.dropout.p if training else 0.0
+            L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
+                   float(att.dp_scale), float(p_att), st, att.site_attn, dqkv, 3 * D, dqkv[:, D:], 3 * D, dqkv[:, 2 * D:], 3 * D,
+                   torch.empty(B * H * Lq, dtype=F32, device=dev))
+            L.call_struct("vpf_sa_layer_bwd_qkv", a)
+            wg = WgradBatch()
+            wg.add(dz2, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
+            wg.add(du, n2, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
+            wg.add(dz1, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
+            wg.add(dqkv, n1, 3 * D, D, packed_grad([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]))
+            wg.flush()
+            d = dbase
         dpos = None
         if want_pos:
             if ctx.pos_shape[0] == B or B == 1:
