@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the image branch on the same stream as the point-cloud branch")
+    ap.add_argument("--wgrad-async", action="store_true", help="grouped weight-gradient launches on a side stream")
     ap.add_argument("--pairs", type=int, default=PER_GPU_PAIRS, help="pairs per GPU (default = BASELINE configs[1])")
     args = ap.parse_args()
 
@@ -146,6 +147,7 @@ def main():
     pc.train(); im.train()
     tr = Pretrainer(pc, im, world_size=world)
     tr.overlap = not args.no_overlap
+    ops.WGRAD_GROUP_ASYNC[0] = args.wgrad_async
     tr.broadcast_parameters(0)
     torch.manual_seed(100 + rank)                          # FPS start indices differ per rank
     t1, t2, imgs = synth_batch(args.pairs, ARCH["N"], ARCH["img"], seed=rank, device=device)

@@ -308,10 +308,12 @@ typedef struct VpfSaLayerFwd {
 int vpf_sa_layer_fwd(const VpfSaLayerFwd* host_args, void* stream);
 /* The dgrad chain of the same layer (backward of partseg.py:170-213) as two row-block kernels around vpf_attention_bwd:
  *   _mlp: d = dL/d(x2) -> dz2 = dropout'(d) -> du = (dz2 W2) * gelu'(u) -> dn = du W1 -> dx1 = LayerNorm2'(dn) + d
- *         -> dz1 = dropout'(dx1) -> dout_attn = dz1 Wo;   dln2_g / dln2_b += this batch's LayerNorm-2 parameter gradients
- *   _qkv: dbase = LayerNorm1'(dqkv Wqkv) + dx1 (also accumulated into dsum when set); dln1_g / dln1_b likewise.
+ *         -> dz1 = dropout'(dx1) -> dout_attn = dz1 Wo
+ *   _qkv: dbase = LayerNorm1'(dqkv Wqkv) + dx1 (also accumulated into dsum when set)
+ * Each writes its workgroups' LayerNorm parameter-gradient partials to pgrad2 / pgrad1 (ceil(M/64) rows of 512 floats:
+ * dgamma | dbeta); vpf_ln_pgrad_reduce folds any number of those into the gradient buffers in one launch.
  * dz2, du, dz1, dqkv are the bf16 operands of the weight-gradient GEMMs (vpf_wgrad_group).  W*T = vpf_pack_wfrag with
- * transposed = 1.  pgrad1 / pgrad2: workspaces of ceil(M/64) * 512 floats. */
+ * transposed = 1. */
 typedef struct VpfSaLayerBwd {
     int M, D, hidden;
     const uint32_t* rng;
@@ -320,15 +322,18 @@ typedef struct VpfSaLayerBwd {
     const float* d; const void* u; const float* x1; const float* mean2; const float* rstd2; const float* ln2_g;
     const void* W2T; const void* W1T; const void* WoT;
     void* dz2; void* du; float* dx1; void* dz1; void* dout_attn;
-    float* pgrad2; float* dln2_g; float* dln2_b;
+    float* pgrad2;
     /* _qkv */
     const void* dqkv; const void* WqkvT; const float* base; const float* mean1; const float* rstd1; const float* ln1_g;
     float* dbase; float* dsum;
-    float* pgrad1; float* dln1_g; float* dln1_b;
+    float* pgrad1;
 } VpfSaLayerBwd;
 int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* host_args, void* stream);
 int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);
-/* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3) */
+typedef struct VpfPgradJob { const float* partials; int rows; int pad_; float* dgamma; float* dbeta; } VpfPgradJob;
+#define VPF_PGRAD_MAX_JOBS 32
+int vpf_ln_pgrad_reduce(const VpfPgradJob* host_jobs, int njobs, void* stream);
+/* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3), sizeof(VpfPgradJob) vpf_abi_sizeof(4) */
 /* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1) / sizeof(VpfWgradJob) (2): lets a binding verify its struct layout */
 int vpf_abi_sizeof(int which);
 

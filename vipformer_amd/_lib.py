@@ -119,6 +119,7 @@ SIGS = {
     "vpf_wgrad_group": [VP, I, VP],
     "vpf_sa_layer_bwd_mlp": [VP, VP],
     "vpf_sa_layer_bwd_qkv": [VP, VP],
+    "vpf_ln_pgrad_reduce": [VP, I, VP],
 }
 
 
@@ -151,6 +152,11 @@ class SaLayerFwd(ctypes.Structure):
                 ("mean1n", VP), ("rstd1n", VP), ("n1n", VP), ("qkv_next", VP), ("attention_done", I), ("dbg", VP)]
 
 
+class PgradJob(ctypes.Structure):
+    """struct VpfPgradJob (include/vipformer_hip.h)."""
+    _fields_ = [("partials", VP), ("rows", I), ("pad_", I), ("dgamma", VP), ("dbeta", VP)]
+
+
 class SaLayerBwd(ctypes.Structure):
     """struct VpfSaLayerBwd (include/vipformer_hip.h) -- same field order."""
     _fields_ = [("M", I), ("D", I), ("hidden", I), ("rng", VP),
@@ -158,10 +164,10 @@ class SaLayerBwd(ctypes.Structure):
                 ("d", VP), ("u", VP), ("x1", VP), ("mean2", VP), ("rstd2", VP), ("ln2_g", VP),
                 ("W2T", VP), ("W1T", VP), ("WoT", VP),
                 ("dz2", VP), ("du", VP), ("dx1", VP), ("dz1", VP), ("dout_attn", VP),
-                ("pgrad2", VP), ("dln2_g", VP), ("dln2_b", VP),
+                ("pgrad2", VP),
                 ("dqkv", VP), ("WqkvT", VP), ("base", VP), ("mean1", VP), ("rstd1", VP), ("ln1_g", VP),
                 ("dbase", VP), ("dsum", VP),
-                ("pgrad1", VP), ("dln1_g", VP), ("dln1_b", VP)]
+                ("pgrad1", VP)]
 
 
 def call_struct(name: str, struct, *extra) -> None:

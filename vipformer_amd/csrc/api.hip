@@ -28,6 +28,7 @@ extern "C" int vpf_abi_sizeof(int which)
         case 1: return (int)sizeof(VpfSaLayerFwd);
         case 2: return (int)sizeof(VpfWgradJob);
         case 3: return (int)sizeof(VpfSaLayerBwd);
+        case 4: return (int)sizeof(VpfPgradJob);
         default: return -1;
     }
 }

@@ -395,13 +395,29 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 // is a few hundred short workgroups whose ramp-up and tail dominate; together they fill the chip.
 #define GEMM_GROUP_MAX 8
 struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; int nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n; };
+template <int TM, int TN, int WM, int WN, int BK>
 __global__ void __launch_bounds__(256) gemm_wgrad_group_kernel(GemmGroup grp)
 {
     int p = 0;
     while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
     const int local = blockIdx.x - grp.start[p];
     const int nx = grp.nx[p], ny = grp.ny[p];
-    gemm_tile<1, 1, 2, 2, 128, true, true, 0, 0>(grp.g[p], local % nx, (local / nx) % ny, local / (nx * ny));
+    gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0>(grp.g[p], local % nx, (local / nx) % ny, local / (nx * ny));
+}
+template <int TM, int TN, int WM, int WN, int BK>
+static int launch_wgrad_group(const GemmGroup& grp, int nblocks, hipStream_t st)
+{
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS);
+    static bool attr = false;
+    if (!attr) {
+        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<TM, TN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_wgrad_group_kernel<TM, TN, WM, WN, BK>), dim3(nblocks), dim3(256), lds, st, grp);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
 }
 
 template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
@@ -544,8 +560,11 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
     if (njobs <= 0 || njobs > GEMM_GROUP_MAX) return VPF_ERR_BADSHAPE;
     GemmGroup grp = {};
     grp.n = njobs;
+    static int cfg = -1, target = 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
+    if (cfg < 0) { const char* e = getenv("VPF_WGROUP_CFG"); cfg = e ? atoi(e) : 2; const char* t = getenv("VPF_WGROUP_WGS"); if (t) target = atoi(t); }
+    const int tm = cfg == 0 ? 64 : 128, tn = cfg == 2 ? 128 : 64;
     long total_tiles = 0;
-    for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, 64) * vpf_cdiv(jobs[i].K, 64);
+    for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
     int at = 0;
     for (int i = 0; i < njobs; ++i) {
         const VpfWgradJob& j = jobs[i];
@@ -556,9 +575,9 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
         // C[m = n_out, n = k_in] += sum over tokens: A = dY read k-strided (rows = N), B = X read k-strided (rows = K)
         g.A = (const bf16_t*)j.dy; g.B = (const bf16_t*)j.x; g.lda = j.N; g.ldb = j.K;
         g.M = j.N; g.N = j.K; g.K = j.M; g.mode = EPI_ATOMIC; g.C = j.dW; g.ldc = j.K; g.c_f32 = 1; g.dbias = j.dbias; g.group = 1;
-        const int nx = vpf_cdiv(g.N, 64), ny = vpf_cdiv(g.M, 64);
-        // ~2048 workgroups over the whole group, every K slice at least 256 tokens deep
-        long sp = 2048 / (total_tiles > 0 ? total_tiles : 1);
+        const int nx = vpf_cdiv(g.N, tn), ny = vpf_cdiv(g.M, tm);
+        // ~`target` workgroups over the whole group, every K slice at least 256 tokens deep
+        long sp = target / (total_tiles > 0 ? total_tiles : 1);
         const long maxs = vpf_cdiv(g.K, 256);
         if (sp > maxs) sp = maxs;
         if (sp < 2) sp = 2;                       // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
@@ -567,14 +586,8 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
         at += nx * ny * (int)sp;
     }
     grp.start[njobs] = at;
-    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<64, true, 128>::ELEMS + TileCfg<64, true, 128>::ELEMS);
-    static bool attr = false;
-    if (!attr) {
-        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return VPF_ERR_HIP;
-        attr = true;
-    }
-    hipLaunchKernelGGL(gemm_wgrad_group_kernel, dim3(at), dim3(256), lds, (hipStream_t)stream, grp);
-    VPF_CHECK_LAUNCH();
-    return VPF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (cfg == 2) return launch_wgrad_group<2, 2, 2, 2, 64>(grp, at, st);
+    if (cfg == 1) return launch_wgrad_group<1, 2, 4, 1, 64>(grp, at, st);
+    return launch_wgrad_group<1, 1, 2, 2, 128>(grp, at, st);
 }

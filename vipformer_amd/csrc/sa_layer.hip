@@ -998,19 +998,46 @@ __global__ void __launch_bounds__(256) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
             }
 }
 
-// out_g[c] += sum_r partials[r][c], out_b[c] += sum_r partials[r][256 + c]  (fixed order: deterministic)
-__global__ void sa_pgrad_reduce_kernel(const float* __restrict__ partials, int rows, float* __restrict__ dgamma, float* __restrict__ dbeta)
+// dgamma[c] += sum_r partials[r][c], dbeta[c] += sum_r partials[r][256 + c]  (fixed order: deterministic) for a list of
+// LayerNorms in one launch (all the LayerNorms of a layer stack at the end of its backward)
+struct PgradJobs { VpfPgradJob job[VPF_PGRAD_MAX_JOBS]; };
+__global__ void __launch_bounds__(1024) sa_pgrad_reduce_kernel(PgradJobs jobs)
 {
-    __shared__ float fold[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;      // 8 blocks x 64 columns of the 512
-    float s = 0.f;
-    for (int r = rg; r < rows; r += 4) s += partials[(size_t)r * 2 * SA_D + c];
-    fold[rg][threadIdx.x & 63] = s;
+    __shared__ float fold[16][64];
+    const VpfPgradJob j = jobs.job[blockIdx.y];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;      // 8 blocks x 64 columns of the 512; 16 row groups
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rg;
+    for (; r + 48 < j.rows; r += 64) {
+        s0 += j.partials[(size_t)r * 2 * SA_D + c];
+        s1 += j.partials[(size_t)(r + 16) * 2 * SA_D + c];
+        s2 += j.partials[(size_t)(r + 32) * 2 * SA_D + c];
+        s3 += j.partials[(size_t)(r + 48) * 2 * SA_D + c];
+    }
+    for (; r < j.rows; r += 16) s0 += j.partials[(size_t)r * 2 * SA_D + c];
+    fold[rg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0) {
-        const float tot = (fold[0][threadIdx.x] + fold[1][threadIdx.x]) + (fold[2][threadIdx.x] + fold[3][threadIdx.x]);
-        if (c < SA_D) dgamma[c] += tot; else dbeta[c - SA_D] += tot;
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += fold[k][threadIdx.x];
+        if (c < SA_D) j.dgamma[c] += tot; else j.dbeta[c - SA_D] += tot;
     }
+}
+extern "C" int vpf_ln_pgrad_reduce(const VpfPgradJob* jobs, int njobs, void* stream)
+{
+    (void)hipGetLastError();
+    if (!jobs) return VPF_ERR_NULL;
+    if (njobs <= 0 || njobs > VPF_PGRAD_MAX_JOBS) return VPF_ERR_BADSHAPE;
+    PgradJobs pj;
+    for (int i = 0; i < njobs; ++i) {
+        if (!jobs[i].partials || !jobs[i].dgamma || !jobs[i].dbeta) return VPF_ERR_NULL;
+        if (jobs[i].rows <= 0) return VPF_ERR_BADSHAPE;
+        pj.job[i] = jobs[i];
+    }
+    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(8, njobs), dim3(1024), 0, (hipStream_t)stream, pj);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
 }
 
 static int sa_bwd_check(const VpfSaLayerBwd& a)
@@ -1027,7 +1054,7 @@ extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
     int rc = sa_bwd_check(a);
     if (rc) return rc;
     if (!a.d || !a.rng || !a.u || !a.x1 || !a.mean2 || !a.rstd2 || !a.ln2_g || !a.W2T || !a.W1T || !a.WoT || !a.dz2 || !a.du || !a.dx1 ||
-        !a.dz1 || !a.dout_attn || !a.pgrad2 || !a.dln2_g || !a.dln2_b) return VPF_ERR_NULL;
+        !a.dz1 || !a.dout_attn || !a.pgrad2) return VPF_ERR_NULL;
     constexpr int RB = 2, TOK = RB * 32;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 4 * 2 * 4;
     static bool attr = false;
@@ -1038,8 +1065,6 @@ extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
     const int nwg = vpf_cdiv((long)a.M, TOK);
     hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, a.pgrad2, nwg, a.dln2_g, a.dln2_b);
-    VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
@@ -1049,7 +1074,7 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     const VpfSaLayerBwd& a = *args;
     int rc = sa_bwd_check(a);
     if (rc) return rc;
-    if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1 || !a.dln1_g || !a.dln1_b) return VPF_ERR_NULL;
+    if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
     constexpr int RB = 2, TOK = RB * 32;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 4 * 2 * 4;
     static bool attr = false;
@@ -1059,8 +1084,6 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     }
     const int nwg = vpf_cdiv((long)a.M, TOK);
     hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
-    VPF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(8), dim3(256), 0, (hipStream_t)stream, a.pgrad1, nwg, a.dln1_g, a.dln1_b);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

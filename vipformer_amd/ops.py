@@ -251,6 +251,7 @@ def linear_wgrad(dy16, x16, N, K, dW, dbias=None):
 
 
 WGRAD_GROUP = [True]
+WGRAD_GROUP_ASYNC = [False]   # issue the grouped launches on a side stream (joined by join_wgrad_streams)
 
 
 class WgradBatch:
@@ -274,7 +275,17 @@ class WgradBatch:
         for i, (dy, x, M, N, K, dW, db) in enumerate(self.jobs):
             arr[i].dy, arr[i].x, arr[i].M, arr[i].N, arr[i].K = dy.data_ptr(), x.data_ptr(), M, N, K
             arr[i].dW, arr[i].dbias = dW.data_ptr(), (db.data_ptr() if db is not None else None)
-        L.call_struct("vpf_wgrad_group", arr, len(self.jobs))
+        if WGRAD_ASYNC[0] or WGRAD_GROUP_ASYNC[0]:
+            # weight gradients are off the dgrad critical path: one grouped launch per layer on a side stream
+            cur, side = _wgrad_side()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                L.call_struct("vpf_wgrad_group", arr, len(self.jobs))
+            for dy, x, *_ in self.jobs:
+                dy.record_stream(side)
+                x.record_stream(side)
+        else:
+            L.call_struct("vpf_wgrad_group", arr, len(self.jobs))
         self.jobs = []
 
 
@@ -712,8 +723,10 @@ class SAStackFn(torch.autograd.Function):
         M = B * Lq
         dev = d.device
         nwg = (M + 63) // 64
-        pg1 = torch.empty(nwg * 2 * D, dtype=F32, device=dev)
-        pg2 = torch.empty(nwg * 2 * D, dtype=F32, device=dev)
+        nl = len(layers)
+        pg = torch.empty(nl, 2, nwg * 2 * D, dtype=F32, device=dev)       # LayerNorm parameter-gradient partials of every layer
+        pjobs = (L.PgradJob * 32)()
+        npj = 0
         dsum = torch.zeros(M, D, dtype=F32, device=dev) if want_pos else None
         for i in range(len(layers) - 1, -1, -1):
             base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[13 * i:13 * i + 13]
@@ -735,11 +748,10 @@ class SAStackFn(torch.autograd.Function):
             a.d, a.u, a.x1, a.mean2, a.rstd2, a.ln2_g = d.data_ptr(), u.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), ln2.weight.data.data_ptr()
             a.W2T, a.W1T, a.WoT = packed[i]["W2T"].data_ptr(), packed[i]["W1T"].data_ptr(), packed[i]["WoT"].data_ptr()
             a.dz2, a.du, a.dx1, a.dz1, a.dout_attn = dz2.data_ptr(), du.data_ptr(), dx1.data_ptr(), dz1.data_ptr(), do.data_ptr()
-            a.pgrad2, a.dln2_g, a.dln2_b = pg2.data_ptr(), grad_buf(ln2.weight).data_ptr(), grad_buf(ln2.bias).data_ptr()
+            a.pgrad2, a.pgrad1 = pg[i, 1].data_ptr(), pg[i, 0].data_ptr()
             a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = (dqkv.data_ptr(), packed[i]["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(),
                                                                  r1.data_ptr(), ln1.weight.data.data_ptr())
             a.dbase, a.dsum = dbase.data_ptr(), (dsum.data_ptr() if dsum is not None else None)
-            a.pgrad1, a.dln1_g, a.dln1_b = pg1.data_ptr(), grad_buf(ln1.weight).data_ptr(), grad_buf(ln1.bias).data_ptr()
             L.call_struct("vpf_sa_layer_bwd_mlp", a)
             p_att = att.dropout.p if training else 0.0
             L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
@@ -752,7 +764,16 @@ class SAStackFn(torch.autograd.Function):
             wg.add(dz1, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
             wg.add(dqkv, n1, 3 * D, D, packed_grad([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]))
             wg.flush()
+            for which, ln in ((1, ln2), (0, ln1)):
+                pjobs[npj].partials, pjobs[npj].rows = pg[i, which].data_ptr(), nwg
+                pjobs[npj].dgamma, pjobs[npj].dbeta = grad_buf(ln.weight).data_ptr(), grad_buf(ln.bias).data_ptr()
+                npj += 1
+                if npj == 32:
+                    L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
+                    npj = 0
             d = dbase
+        if npj:
+            L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
         dpos = None
         if want_pos:
             if ctx.pos_shape[0] == B or B == 1:
