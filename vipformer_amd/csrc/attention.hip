@@ -17,6 +17,7 @@
 // the workgroup's waves and double-buffered in LDS (global loads of tile t+1 in flight during
 // the matrix work on tile t).
 #include "vpf_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -240,6 +241,127 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st)
     return VPF_OK;
 }
 
+// =============================================================================== resident self-attention, forward
+// Lq == Lkv <= 224 (the encoder's self-attention: 96 latents / 196 patches): the head's whole K and V tiles are staged in
+// ONE round of loads (all of them in flight together) and every wave walks them without further barriers.  The tiled
+// kernel above pays one global-load latency plus a barrier per 64 keys, which is all there is at these sizes.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
+{
+    constexpr int NT = NW * 64, LPT = NW * 32;
+    constexpr int NCH = 2 * LPT * 8, CPT = (NCH + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t rlds[];
+    bf16_t* sK = rlds;
+    bf16_t* sV = rlds + LPT * KLD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
+    const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H, L = a.Lq;
+    const int q = wave * 32 + (lane & 31);
+    const bool qok = q < L;
+    uint4 kvr[CPT];
+#pragma unroll
+    for (int it = 0; it < CPT; ++it) {
+        const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % LPT, kv = (e >> 3) / LPT;
+        kvr[it] = make_uint4(0, 0, 0, 0);
+        if (e < NCH && row < L) {
+            const bf16_t* src = kv ? a.V + ((size_t)b * L + row) * a.ldv : a.K + ((size_t)b * L + row) * a.ldk;
+            kvr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
+        }
+    }
+    bf16x8_t qf[4];
+    {
+        const bf16_t* qp = a.Q + ((size_t)b * L + (qok ? q : 0)) * a.ldq + hd * DH + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(qp + ks * 16, qok));
+    }
+#pragma unroll
+    for (int it = 0; it < CPT; ++it) {
+        const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % LPT, kv = (e >> 3) / LPT;
+        if (e < NCH) *reinterpret_cast<uint4*>(rlds + (kv * LPT + row) * KLD + ch * 8) = kvr[it];
+    }
+    __syncthreads();
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m = -INFINITY, l = 0.f;
+    const float c = a.scale * LOG2E;
+    const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
+    const bool drop = a.p > 0.f;
+    const uint64_t rbase = ((uint64_t)bh * L + (uint64_t)(qok ? q : 0)) * (uint64_t)L;
+#pragma unroll
+    for (int kv0 = 0; kv0 < LPT; kv0 += 32) {
+        if (kv0 >= L) break;
+        f32x16_t s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, kv0, ks * 16), qf[ks], s, 0, 0, 0);
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+            s[r] = kv < L ? s[r] * c : -INFINITY;
+            tmax = fmaxf(tmax, s[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+        float pv[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const uint32_t keep = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                const float pr = exp2f(s[r] - mn);
+                ps += pr;
+                pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
+            }
+        }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pf = pack8(pv + 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sV, KLD, kv0 + 16 * s2, dt * 32), pf, o[dt], 0, 0, 0);
+        }
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = 1.f / lt;
+    if (qok) {
+        bf16_t* op = a.O + ((size_t)b * L + q) * a.ldo + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 u;
+                u.x = pack_bf16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
+                u.y = pack_bf16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
+                *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
+            }
+        if (hl == 0 && a.LSE) a.LSE[(size_t)bh * L + q] = (m + log2f(lt)) * LN2;
+    }
+}
+template <int NW>
+static int launch_res_fwd(const AttnArgs& a, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)2 * NW * 32 * KLD * sizeof(bf16_t);
+    static bool attr = false;
+    if (!attr) {
+        if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_res_fwd_kernel<NW>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 static int check_common(const AttnArgs& a)
 {
     if (!a.Q || !a.K || !a.V || !a.rng) return VPF_ERR_NULL;
@@ -265,6 +387,12 @@ extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ld
     if ((ldo % 4) || ((uintptr_t)out & 7)) return VPF_ERR_BADALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int nqb = vpf_cdiv(Lq, 32);
+    static int res = -1;
+    if (res < 0) { const char* e = getenv("VPF_ATTN_RESIDENT"); res = e ? atoi(e) : 1; }
+    if (res && Lq == Lkv && k != q) {     // self-attention with the whole head resident in LDS
+        if (nqb == 3) return launch_res_fwd<3>(a, st);
+        if (nqb == 7) return launch_res_fwd<7>(a, st);
+    }
     if (nqb <= 1) return launch_fwd<1>(a, st);
     if (nqb <= 2) return launch_fwd<2>(a, st);
     if (nqb <= 3) return launch_fwd<3>(a, st);
@@ -543,6 +671,227 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
     }
 }
 
+
+// =============================================================================== resident self-attention, backward
+// One workgroup per (batch, head) holds Q, K, V and dO of the head in LDS (one round of loads).  Phase A is the dq kernel
+// above (a wave = 32 queries, delta computed on the way), phase B the dk / dv kernel (a wave = 32 keys), both walking
+// the resident tiles without barriers: one launch and one load latency instead of two kernels that each re-stage
+// their operands tile by tile.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float* __restrict__ delta_out)
+{
+    constexpr int NT = NW * 64, LPT = NW * 32;
+    constexpr int NCH = 4 * LPT * 8, CPT = (NCH + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t rlds[];
+    bf16_t* sQ = rlds;
+    bf16_t* sK = sQ + LPT * KLD;
+    bf16_t* sV = sK + LPT * KLD;
+    bf16_t* sD = sV + LPT * KLD;
+    float* sL = reinterpret_cast<float*>(sD + LPT * KLD);        // [LPT] lse * log2e
+    float* sDel = sL + LPT;                                      // [LPT] delta
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, ql = lane & 31;
+    const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H, L = a.Lq;
+    const int q = wave * 32 + ql;                                 // phase A: this lane's query; phase B: this lane's key
+    const bool qok = q < L;
+    {
+        uint4 rr[CPT];
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % LPT, which = (e >> 3) / LPT;
+            rr[it] = make_uint4(0, 0, 0, 0);
+            if (e < NCH && row < L) {
+                const size_t gr = (size_t)b * L + row;
+                const bf16_t* src = which == 0 ? a.Q + gr * a.ldq : which == 1 ? a.K + gr * a.ldk : which == 2 ? a.V + gr * a.ldv : a.dO + gr * a.lddo;
+                rr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
+            }
+        }
+        // O fragments of this lane's query (only needed for delta) and its log-sum-exp
+        uint4 of[4];
+        {
+            const bf16_t* op = a.O + ((size_t)b * L + (qok ? q : 0)) * a.ldo + hd * DH + 8 * hl;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) of[ks] = ld16_or_zero(op + ks * 16, qok);
+        }
+        const float lse2 = qok ? a.LSE[(size_t)bh * L + q] * LOG2E : 0.f;
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % LPT, which = (e >> 3) / LPT;
+            if (e < NCH) *reinterpret_cast<uint4*>(rlds + (which * LPT + row) * KLD + ch * 8) = rr[it];
+        }
+        __syncthreads();
+        // delta[q] = sum_d dO[q,d] * O[q,d]
+        float delta = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 ud = *reinterpret_cast<const uint4*>(sD + q * KLD + ks * 16 + 8 * hl);
+            const uint32_t dw[4] = {ud.x, ud.y, ud.z, ud.w}, ow[4] = {of[ks].x, of[ks].y, of[ks].z, of[ks].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                delta += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16);
+                delta += __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+            }
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        if (hl == 0) { sL[q] = lse2; sDel[q] = delta; }
+        if (qok && hl == 0) delta_out[(size_t)bh * L + q] = delta;
+    }
+    const float c = a.scale * LOG2E;
+    const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
+    const bool drop = a.p > 0.f;
+    // ------------------------------------------------------------------ phase A: dQ (lane = query)
+    {
+        bf16x8_t qf[4], dof[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row(sQ, KLD, wave * 32, ks * 16); dof[ks] = frag_row(sD, KLD, wave * 32, ks * 16); }
+        const float lse2 = sL[q], delta = sDel[q];       // written by this very lane (hl == 0) or its partner: same wave, in order
+        const uint64_t rbase = ((uint64_t)bh * L + (uint64_t)(qok ? q : 0)) * (uint64_t)L;
+        f32x16_t dq[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+#pragma unroll
+        for (int kv0 = 0; kv0 < LPT; kv0 += 32) {
+            if (kv0 >= L) break;
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, kv0, ks * 16), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sV, KLD, kv0, ks * 16), dof[ks], dp, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint32_t kbits = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const int kv = kv0 + e + 8 * g4 + 4 * hl;
+                    const bool ok = qok && kv < L;
+                    const float pr = ok ? exp2f(s[r] * c - lse2) : 0.f;
+                    const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
+                    ds[r] = pr * (dp[r] * keep - delta) * a.scale;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t dsf = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, kv0 + 16 * s2, dt * 32), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        if (qok) {
+            bf16_t* op = a.dQ + ((size_t)b * L + q) * a.lddq + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    uint2 u;
+                    u.x = pack_bf16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
+                    u.y = pack_bf16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+                    *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
+                }
+        }
+    }
+    __syncthreads();                      // sL / sDel of every query are in LDS
+    // ------------------------------------------------------------------ phase B: dK, dV (lane = key)
+    {
+        const int kv = q;
+        const bool kvok = qok;
+        bf16x8_t kf[4], vf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(sK, KLD, wave * 32, ks * 16); vf[ks] = frag_row(sV, KLD, wave * 32, ks * 16); }
+        f32x16_t dk[2], dv[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
+        const bool quad_ok = (L & 3) == 0;
+#pragma unroll
+        for (int q0 = 0; q0 < LPT; q0 += 32) {
+            if (q0 >= L) break;
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp, 0, 0, 0);
+            }
+            float pd[16], ds[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 grp = make_uint2(0u, 0u);
+                if (drop && quad_ok) {
+                    const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
+                    grp = vpf_rand4x16(rng, (((uint64_t)bh * L + (uint64_t)qh) * (uint64_t)L + (uint64_t)kv) >> 2);
+                }
+                uint32_t gw[4];
+                {
+                    const uint32_t mine = (lane & 2) ? 1u : 0u;
+                    const uint32_t x0 = quad_bcast<0>(grp.x), x1 = quad_bcast<1>(grp.x), x2 = quad_bcast<2>(grp.x), x3 = quad_bcast<3>(grp.x);
+                    const uint32_t y0 = quad_bcast<0>(grp.y), y1 = quad_bcast<1>(grp.y), y2 = quad_bcast<2>(grp.y), y3 = quad_bcast<3>(grp.y);
+                    gw[0] = mine ? y0 : x0; gw[1] = mine ? y1 : x1; gw[2] = mine ? y2 : x2; gw[3] = mine ? y3 : x3;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const int qr = e + 8 * g4 + 4 * hl;
+                    const int qq = q0 + qr;
+                    const bool ok = kvok && qq < L;
+                    const float pr = ok ? exp2f(s[r] * c - sL[qq]) : 0.f;
+                    float keep = 1.f;
+                    if (drop) {
+                        if (quad_ok) {
+                            const uint32_t word = gw[e];
+                            keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                        } else {
+                            keep = vpf_keep(rng, ((uint64_t)bh * L + (uint64_t)qq) * (uint64_t)L + (uint64_t)kv) ? rng.scale : 0.f;
+                        }
+                    }
+                    pd[r] = pr * keep;
+                    ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (kvok) {
+            bf16_t* kp = a.dK + ((size_t)b * L + kv) * a.lddk + hd * DH;
+            bf16_t* vp = a.dV + ((size_t)b * L + kv) * a.lddv + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    uint2 u, w;
+                    u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                    w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                    *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
+                    *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
+                }
+        }
+    }
+}
+template <int NW>
+static int launch_res_bwd(const AttnArgs& a, float* delta, hipStream_t st)
+{
+    constexpr size_t lds = (size_t)4 * NW * 32 * KLD * sizeof(bf16_t) + (size_t)2 * NW * 32 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_bwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_res_bwd_kernel<NW>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a, delta);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 template <int NWQ, int NWK>
 static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
 {
@@ -582,6 +931,12 @@ extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ld
     if (((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7) || ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7)) return VPF_ERR_BADALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int nqb = vpf_cdiv(Lq, 32);
+    static int res = -1;
+    if (res < 0) { const char* e = getenv("VPF_ATTN_RESIDENT"); res = e ? atoi(e) : 1; }
+    if (res && Lq == Lkv && k != q) {
+        if (nqb == 3) return launch_res_bwd<3>(a, delta_ws, st);
+        if (nqb == 7) return launch_res_bwd<7>(a, delta_ws, st);
+    }
     if (nqb <= 1) return launch_bwd_k<1>(a, delta_ws, st);
     if (nqb <= 2) return launch_bwd_k<2>(a, delta_ws, st);
     if (nqb == 3 || nqb == 6 || nqb == 9) return launch_bwd_k<3>(a, delta_ws, st);
