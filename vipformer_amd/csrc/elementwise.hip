@@ -376,20 +376,36 @@ extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* ac
 }
 
 // out[c] = sum_r x[r, c] in a FIXED order (r ascending): deterministic fold of per-workgroup partial statistics
-__global__ void sum_rows_kernel(const float* __restrict__ x, int R, int C, float* __restrict__ out)
+__global__ void __launch_bounds__(1024) sum_rows_kernel(const float* __restrict__ x, int R, int C, float* __restrict__ out)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int r = 0; r < R; ++r) s += x[(size_t)r * C + c];
-    out[c] = s;
+    // 64 columns x 16 row groups per block; every thread keeps 4 independent partial sums so that its loads are in flight
+    // together (a single running sum serialises R load latencies); the fold order is fixed, so the result is deterministic
+    __shared__ float fold[16][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int r = rg;
+        for (; r + 48 < R; r += 64) {
+            s0 += x[(size_t)r * C + c]; s1 += x[(size_t)(r + 16) * C + c];
+            s2 += x[(size_t)(r + 32) * C + c]; s3 += x[(size_t)(r + 48) * C + c];
+        }
+        for (; r < R; r += 16) s0 += x[(size_t)r * C + c];
+    }
+    fold[rg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += fold[k][threadIdx.x];
+        out[c] = t;
+    }
 }
 extern "C" int vpf_sum_rows_f32(const float* x, int R, int C, float* out, void* stream)
 {
     (void)hipGetLastError();
     if (!x || !out) return VPF_ERR_NULL;
     if (R <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(sum_rows_kernel, dim3(vpf_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, x, R, C, out);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(vpf_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, x, R, C, out);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -682,15 +698,37 @@ extern "C" int vpf_group_max_scatter_add(const void* dg_bf16, const uint8_t* arg
 
 // =============================================================================== token pooling  partseg.py:547
 // x f32 [B,L,D] -> out f32 [B,2D] = [max over L | mean over L], arg int32 [B,D]
-__global__ void pool_fwd_kernel(const float* __restrict__ x, int B, int L, int D, float* __restrict__ out, int* __restrict__ arg)
+__global__ void __launch_bounds__(512) pool_fwd_kernel(const float* __restrict__ x, int B, int L, int D, float* __restrict__ out, int* __restrict__ arg)
 {
-    const long total = (long)B * D;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / D), d = (int)(i % D);
-        float best = -INFINITY, s = 0.f; int bi = 0;
-        for (int l = 0; l < L; ++l) { const float v = x[((size_t)b * L + l) * D + d]; s += v; if (v > best) { best = v; bi = l; } }
+    // block = (sample, 64 channels); 8 row groups walk the tokens with 4 loads in flight each; first maximum wins ties
+    __shared__ float sm[8][64], ss[8][64];
+    __shared__ int si[8][64];
+    const int b = blockIdx.y, d = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float best = -INFINITY, s = 0.f; int bi = 0;
+    if (d < D) {
+        const float* xp = x + (size_t)b * L * D + d;
+        int l = rg;
+        for (; l + 24 < L; l += 32) {
+            const float v0 = xp[(size_t)l * D], v1 = xp[(size_t)(l + 8) * D], v2 = xp[(size_t)(l + 16) * D], v3 = xp[(size_t)(l + 24) * D];
+            s += (v0 + v1) + (v2 + v3);
+            if (v0 > best) { best = v0; bi = l; }
+            if (v1 > best) { best = v1; bi = l + 8; }
+            if (v2 > best) { best = v2; bi = l + 16; }
+            if (v3 > best) { best = v3; bi = l + 24; }
+        }
+        for (; l < L; l += 8) { const float v = xp[(size_t)l * D]; s += v; if (v > best) { best = v; bi = l; } }
+    }
+    sm[rg][threadIdx.x & 63] = best; ss[rg][threadIdx.x & 63] = s; si[rg][threadIdx.x & 63] = bi;
+    __syncthreads();
+    if (rg == 0 && d < D) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const float v = sm[k][threadIdx.x]; const int vi = si[k][threadIdx.x];
+            s += ss[k][threadIdx.x];
+            if (v > best || (v == best && vi < bi)) { best = v; bi = vi; }
+        }
         out[(size_t)b * 2 * D + d] = best; out[(size_t)b * 2 * D + D + d] = s / (float)L;
-        if (arg) arg[i] = bi;
+        if (arg) arg[(size_t)b * D + d] = bi;
     }
 }
 extern "C" int vpf_pool_fwd(const float* x, int B, int L, int D, float* out, int* arg, void* stream)
@@ -699,7 +737,7 @@ extern "C" int vpf_pool_fwd(const float* x, int B, int L, int D, float* out, int
     if (!x || !out) return VPF_ERR_NULL;
     if (B < 0 || L <= 0 || D <= 0) return VPF_ERR_BADSHAPE;
     if (B == 0) return VPF_OK;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(grid_for((long)B * D, 64)), dim3(64), 0, (hipStream_t)stream, x, B, L, D, out, arg);
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(vpf_cdiv(D, 64), B), dim3(512), 0, (hipStream_t)stream, x, B, L, D, out, arg);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

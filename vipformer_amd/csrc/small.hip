@@ -268,13 +268,27 @@ __global__ void g2e_moments_to_sums_kernel(const float* __restrict__ mom, long M
     sums[c] = ws1 + (float)M * bb;
     sumsq[c] = q + 2.f * bb * ws1 + (float)M * bb * bb;
 }
-__global__ void g2e_moments_fold_kernel(const float* __restrict__ part, int nblk, float* __restrict__ mom)
+__global__ void __launch_bounds__(1024) g2e_moments_fold_kernel(const float* __restrict__ part, int nblk, float* __restrict__ mom)
 {
-    const int e = threadIdx.x;
-    if (e >= 72) return;
-    float s = 0.f;
-    for (int r = 0; r < nblk; ++r) s += part[(size_t)r * 72 + e];      // fixed order: deterministic statistics
-    mom[e] = s;
+    // 72 moments x 14 row groups, 4 loads in flight per thread, fixed fold order (deterministic statistics)
+    __shared__ float fold[14][72];
+    const int e = threadIdx.x % 72, rg = threadIdx.x / 72;
+    if (rg >= 14) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rg;
+    for (; r + 42 < nblk; r += 56) {
+        s0 += part[(size_t)r * 72 + e]; s1 += part[(size_t)(r + 14) * 72 + e];
+        s2 += part[(size_t)(r + 28) * 72 + e]; s3 += part[(size_t)(r + 42) * 72 + e];
+    }
+    for (; r < nblk; r += 14) s0 += part[(size_t)r * 72 + e];
+    fold[rg][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) t += fold[k][e];
+        mom[e] = t;
+    }
 }
 // scratch: f32 [72 + 512*72]
 extern "C" int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, const float* b, float* scratch,
@@ -286,7 +300,7 @@ extern "C" int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const 
     hipStream_t st = (hipStream_t)stream;
     const int nblk = grid_for(M, 256 * 4, 512);
     hipLaunchKernelGGL(g2e_moments_kernel, dim3(nblk), dim3(256), 0, st, x, M, C, scratch + 72);
-    hipLaunchKernelGGL(g2e_moments_fold_kernel, dim3(1), dim3(128), 0, st, (const float*)(scratch + 72), nblk, scratch);
+    hipLaunchKernelGGL(g2e_moments_fold_kernel, dim3(1), dim3(1024), 0, st, (const float*)(scratch + 72), nblk, scratch);
     hipLaunchKernelGGL(g2e_moments_to_sums_kernel, dim3(1), dim3(64), 0, st, (const float*)scratch, M, C, W, b, sums, sumsq);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
@@ -452,11 +466,22 @@ __global__ void __launch_bounds__(256) ntxent_row_kernel(const float* __restrict
     for (int c = threadIdx.x; c < D; c += blockDim.x) zi[c] = zn[(size_t)i * D + c];
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    for (int j = wv; j < n; j += nwv) {
-        float s = 0.f;
-        for (int c = lane; c < D; c += 64) s += zi[c] * zn[(size_t)j * D + c];
-        s = wave_sum(s);
-        if (lane == 0) lg[j] = (j == i) ? -INFINITY : s * invT;
+    // 8 rows per wave at a time: their loads are issued together (one running dot product per row would pay the load
+    // latency n / nwv times in sequence, and this kernel sits alone between the forward and the backward pass)
+    for (int j0 = wv * 8; j0 < n; j0 += nwv * 8) {
+        float s[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s[u] = 0.f;
+            const int j = j0 + u < n ? j0 + u : n - 1;
+            for (int c = lane; c < D; c += 64) s[u] += zi[c] * zn[(size_t)j * D + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float t = wave_sum(s[u]);
+            const int j = j0 + u;
+            if (lane == 0 && j < n) lg[j] = (j == i) ? -INFINITY : t * invT;
+        }
     }
     __syncthreads();
     __shared__ float red[8];
