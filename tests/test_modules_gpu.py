@@ -438,8 +438,8 @@ def test_fused_sa_stack_matches_unfused_blocks():
     imgs = Hh.synth_images(3, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
     start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
     results = []
-    variants = ((False, False, None), (True, False, False), (True, False, True), (True, True, True))
-    for fused, fused_bwd, split in variants:
+    variants = ((False, False, None, False), (True, False, False, False), (True, False, True, False), (True, True, True, False), (True, True, True, True))
+    for fused, fused_bwd, split, enc in variants:
         ops.clear_managed_shadows()
         ops.rng.seed(99)
         ops._site_counter[0] = 5000
@@ -450,7 +450,7 @@ def test_fused_sa_stack_matches_unfused_blocks():
         pc.train(); im.train()
         tr = Pretrainer(pc, im)
         tr.overlap = False
-        ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0] = fused, fused_bwd, split
+        ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = fused, fused_bwd, split, enc
         with forced_start(start):
             feats_pc = pc(torch.cat([t1, t2]))[1].detach().clone()        # backbone features (before the BatchNorm head)
             ops.rng.state("cuda")[2] = 0
@@ -459,13 +459,13 @@ def test_fused_sa_stack_matches_unfused_blocks():
         zero_grad = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias")
         g = {("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters() if k not in zero_grad}
         results.append((float(losses[0]), feats_pc, g))
-    ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0] = True, True, None
+    ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = True, True, None, True
     ops.clear_managed_shadows()
     l0, f0, g0 = results[0]
     allg0 = torch.cat([v.reshape(-1) for v in g0.values()])
     C = Checks("fused_sa_stack")
-    for (l1, f1, g1), (fused, fused_bwd, split) in zip(results[1:], variants[1:]):
-        tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}]"
+    for (l1, f1, g1), (fused, fused_bwd, split, enc) in zip(results[1:], variants[1:]):
+        tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}{', CA tail fused' if enc else ''}]"
         C.lt(tag + " pc backbone feats rel", rel(f1, f0), 2e-2)
         C.lt(tag + " loss rel", abs(l1 - l0) / abs(l0), 2e-2)
         allg1 = torch.cat([g1[k].reshape(-1) for k in g0])

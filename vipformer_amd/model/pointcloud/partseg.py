@@ -245,8 +245,15 @@ class Encoder(nn.Module):
         self.modal_prior = modal_prior
 
     def forward(self, group_embs, pos_embs, pts_embs, layer_idx=[], pad_mask=None):
-        x = self.cross_attn_1(group_embs, pts_embs, pad_mask, pos=pos_embs)
         feats = []
+        if (self.num_cross_attention_layers == 1 and not layer_idx and pad_mask is None
+                and ops.encoder_fused_supported(self.cross_attn_1, self.sa_layers, group_embs, pts_embs)):
+            # fused row-block kernels for the cross-attention layer's tail and every self-attention layer
+            mods = [self.cross_attn_1] + list(self.sa_layers)
+            params = [p for m in mods for p in m.parameters()]
+            x = ops.EncoderFusedFn.apply(group_embs, pos_embs, pts_embs, self.cross_attn_1, self.sa_layers, self.training, *params)
+            return x if self.modal_prior else feats
+        x = self.cross_attn_1(group_embs, pts_embs, pad_mask, pos=pos_embs)
         if (self.num_cross_attention_layers == 1 and not layer_idx and pad_mask is None
                 and ops.sa_stack_supported(self.sa_layers, x)):
             # one fused kernel per self-attention layer (vpf_sa_layer_fwd)

@@ -784,6 +784,266 @@ class SAStackFn(torch.autograd.Function):
         return (d.view(B, Lq, D), dpos, None, None) + (None,) * ctx.nparams
 
 
+# --------------------------------------------------------------------------- fused encoder: cross-attention layer + self-attention stack
+def _pack_blocks(blocks, holder, dev):
+    """blocks: list of (attention module, MLP module, want_Wqkv_forward, want_WqkvT).  Returns per-block dicts of fragment-order
+    weight views (see _sa_packed)."""
+    D, Hd = 256, 512
+    sizes = [("Wo", D * D), ("W1", Hd * D), ("W2", D * Hd), ("Wqkv", 3 * D * D), ("W2T", Hd * D), ("W1T", D * Hd), ("WoT", D * D), ("WqkvT", 3 * D * D)]
+    per = sum(n for _, n in sizes)
+    buf = getattr(holder, "_vpf_packed_enc", None)
+    if buf is None or buf.device != dev or buf.numel() != per * len(blocks):
+        buf = torch.empty(per * len(blocks), dtype=BF16, device=dev)
+        holder._vpf_packed_enc = buf
+    jobs = (L.PackJob * 64)()
+    views, n = [], 0
+    for i, (att, mlp, want_qkv, want_qkvT) in enumerate(blocks):
+        qkvw = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
+        pack_params(qkvw)
+        o = i * per
+        v = {}
+        for name, cnt in sizes:
+            v[name] = buf[o:o + cnt]
+            o += cnt
+        views.append(v)
+        wo, w1, w2 = shadow([att.o_proj.weight]), shadow([mlp[1].weight]), shadow([mlp[3].weight])
+        todo = [(wo, v["Wo"], D, D, 0), (w1, v["W1"], Hd, D, 0), (w2, v["W2"], D, Hd, 0),
+                (w2, v["W2T"], Hd, D, 1), (w1, v["W1T"], D, Hd, 1), (wo, v["WoT"], D, D, 1)]
+        if want_qkv:
+            todo.append((shadow(qkvw), v["Wqkv"], 3 * D, D, 0))
+        if want_qkvT:
+            todo.append((shadow(qkvw), v["WqkvT"], D, 3 * D, 1))
+        for src, dst, N, K, tr in todo:
+            jobs[n].src, jobs[n].dst, jobs[n].N, jobs[n].K, jobs[n].transposed = src.data_ptr(), dst.data_ptr(), N, K, tr
+            n += 1
+            if n == 64:
+                L.call_struct("vpf_pack_wfrag", jobs, n)
+                n = 0
+    if n:
+        L.call_struct("vpf_pack_wfrag", jobs, n)
+    return views
+
+
+def _tail_fwd(att, mlp, res_attn, res_mlp, pk, training, st, B, Lq, qkv_dummy, base, o, lse, nxt, pos_c, pos_rows, dev):
+    """One vpf_sa_layer_fwd launch with attention_done = 1.  nxt = (LayerNorm module, packed Wqkv) of the following
+    self-attention layer or None.  Returns (saved tensors dict, out, next-head tuple or None)."""
+    D, Hd, H = 256, 512, 4
+    M = B * Lq
+    ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
+    x1 = torch.empty(M, D, dtype=F32, device=dev)
+    m2 = torch.empty(M, dtype=F32, device=dev)
+    r2 = torch.empty(M, dtype=F32, device=dev)
+    n2 = torch.empty(M, D, dtype=BF16, device=dev)
+    u = torch.empty(M, Hd, dtype=BF16, device=dev)
+    h = torch.empty(M, Hd, dtype=BF16, device=dev)
+    out = torch.empty(M, D, dtype=F32, device=dev)
+    a = L.SaLayerFwd()
+    a.B, a.L, a.chunk_rows, a.D, a.H, a.hidden = B, Lq, 64, D, H, Hd
+    a.qkv, a.base, a.rng = qkv_dummy.data_ptr(), base.data_ptr(), st.data_ptr()
+    a.scale, a.p_att, a.site_att = float(att.dp_scale), float(att.dropout.p if training else 0.0), att.site_attn
+    a.Wo, a.bo = pk["Wo"].data_ptr(), att.o_proj.bias.data.data_ptr()
+    a.p_res1, a.site_res1 = float(res_attn.dropout.p if training else 0.0), res_attn.site
+    a.ln2_g, a.ln2_b = ln2.weight.data.data_ptr(), ln2.bias.data.data_ptr()
+    a.W1, a.b1 = pk["W1"].data_ptr(), fc1.bias.data.data_ptr()
+    a.W2, a.b2 = pk["W2"].data_ptr(), fc2.bias.data.data_ptr()
+    a.p_res2, a.site_res2 = float(res_mlp.dropout.p if training else 0.0), res_mlp.site
+    a.o, a.lse, a.x1, a.mean2, a.rstd2, a.n2 = o.data_ptr(), lse.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), n2.data_ptr()
+    a.u, a.h, a.out = u.data_ptr(), h.data_ptr(), out.data_ptr()
+    a.attention_done = 1
+    head = None
+    if nxt is not None:
+        lnn, wqkv = nxt
+        head = (torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev),
+                torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, 3 * D, dtype=BF16, device=dev))
+        a.pos, a.pos_rows = (pos_c.data_ptr() if pos_c is not None else None), pos_rows
+        a.ln1n_g, a.ln1n_b, a.Wqkv_next = lnn.weight.data.data_ptr(), lnn.bias.data.data_ptr(), wqkv.data_ptr()
+        a.mean1n, a.rstd1n, a.n1n, a.qkv_next = head[0].data_ptr(), head[1].data_ptr(), head[2].data_ptr(), head[3].data_ptr()
+    L.call_struct("vpf_sa_layer_fwd", a)
+    return (x1, m2, r2, n2, u, h), out, head
+
+
+class EncoderFusedFn(torch.autograd.Function):
+    """Encoder.forward (partseg.py:326-340) for one cross-attention layer + the self-attention stack: the cross-attention
+    layer's tail (o_proj .. MLP) and every self-attention layer run as fused row-block kernels (vpf_sa_layer_fwd /
+    vpf_sa_layer_bwd_*), each of which also prepares the next layer's LayerNorm + q/k/v projection; only the
+    cross-attention front (two LayerNorms, q and kv projections) and the attention kernels themselves are separate."""
+
+    @staticmethod
+    def forward(ctx, x, pos, xkv, ca, layers, training, *params):
+        ctx.nparams = len(params)
+        B, Lq, D = x.shape
+        M, Hd, H = B * Lq, 512, 4
+        dev = x.device
+        x = x.contiguous().float()
+        st = rng.state(dev)
+        nl = len(layers)
+        cross, cmlp = ca[0].module, ca[1].module
+        catt = cross.attention
+        blocks = [(catt, cmlp, False, False)] + [(l[0].module.attention, l[1].module, True, True) for l in layers]
+        packed = _pack_blocks(blocks, ca, dev)
+        pos_c = pos.contiguous().float() if pos is not None else None
+        pos_rows = pos_c.numel() // D if pos_c is not None else 0
+        # ---- cross-attention front (AttnBlockFn.forward up to the attention)
+        lnq, lnkv = cross.q_norm, cross.kv_norm
+        nq, mq, rq, xsum = layernorm_fwd(x, lnq.weight.data, lnq.bias.data, pos=pos, want_sum=True)
+        base_ca = xsum if xsum is not None else x
+        xkv = xkv.contiguous()
+        Lkv = xkv.shape[1]
+        Mk = B * Lkv
+        nk, mk, rk, _ = layernorm_fwd(xkv, lnkv.weight.data, lnkv.bias.data)
+        qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
+        w16 = shadow(qkvw)
+        q = linear_fwd(nq, w16[:D * D], D, D)
+        kv = linear_fwd(nk, w16[D * D:], 2 * D, D)
+        o = torch.empty(M, D, dtype=BF16, device=dev)
+        lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
+        L.call("vpf_attention_fwd", q, D, kv, 2 * D, kv[:, D:], 2 * D, B, H, Lq, Lkv, D // H, float(catt.dp_scale),
+               float(catt.dropout.p if training else 0.0), st, catt.site_attn, o, D, lse)
+        nxt = (layers[0][0].module.norm, packed[1]["Wqkv"]) if nl else None
+        saved_t, out, head = _tail_fwd(catt, cmlp, ca[0], ca[1], packed[0], training, st, B, Lq, q, base_ca, o, lse, nxt, pos_c, pos_rows, dev)
+        flat = [base_ca, mq, rq, nq, xkv, mk, rk, nk, q, kv, o, lse] + list(saved_t)        # 18 tensors
+        # ---- self-attention layers
+        for i, layer in enumerate(layers):
+            att, mlp = layer[0].module.attention, layer[1].module
+            base, (m1, r1, n1, qkv) = out, head
+            o = torch.empty(M, D, dtype=BF16, device=dev)
+            lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
+            L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, D // H, float(att.dp_scale),
+                   float(att.dropout.p if training else 0.0), st, att.site_attn, o, D, lse)
+            nxt = (layers[i + 1][0].module.norm, packed[i + 2]["Wqkv"]) if i + 1 < nl else None
+            saved_t, out, head = _tail_fwd(att, mlp, layer[0], layer[1], packed[i + 1], training, st, B, Lq, qkv, base, o, lse, nxt, pos_c,
+                                           pos_rows, dev)
+            flat += [base, m1, r1, n1, qkv, o, lse] + list(saved_t)                          # 13 per layer
+        ctx.ca, ctx.layers, ctx.training, ctx.packed = ca, layers, training, packed
+        ctx.dims = (B, Lq, Lkv, D, Hd, H)
+        ctx.pos_shape = tuple(pos.shape) if pos is not None else None
+        ctx.xkv_dtype = xkv.dtype
+        ctx.save_for_backward(*flat)
+        return out.view(B, Lq, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        flat = ctx.saved_tensors
+        ca, layers, training, packed = ctx.ca, ctx.layers, ctx.training, ctx.packed
+        B, Lq, Lkv, D, Hd, H = ctx.dims
+        M, Mk = B * Lq, B * Lkv
+        dev = dout.device
+        st = rng.state(dev)
+        d = dout.contiguous().float().view(M, D)
+        want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
+        nl = len(layers)
+        nwg = (M + 63) // 64
+        pg = torch.empty(nl + 1, 2, nwg * 2 * D, dtype=F32, device=dev)
+        pjobs = (L.PgradJob * 32)()
+        npj = 0
+        dsum = torch.zeros(M, D, dtype=F32, device=dev) if want_pos else None
+
+        def bwd_mlp(a, blk, res_attn, res_mlp, pk, d, u, x1, m2, r2, slot):
+            att, mlp = blk
+            bufs = (torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, Hd, dtype=BF16, device=dev), torch.empty(M, D, dtype=F32, device=dev),
+                    torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, D, dtype=BF16, device=dev))
+            dz2, du, dx1, dz1, do = bufs
+            a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
+            a.p_res1, a.site_res1 = float(res_attn.dropout.p if training else 0.0), res_attn.site
+            a.p_res2, a.site_res2 = float(res_mlp.dropout.p if training else 0.0), res_mlp.site
+            a.d, a.u, a.x1, a.mean2, a.rstd2, a.ln2_g = d.data_ptr(), u.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), mlp[0].weight.data.data_ptr()
+            a.W2T, a.W1T, a.WoT = pk["W2T"].data_ptr(), pk["W1T"].data_ptr(), pk["WoT"].data_ptr()
+            a.dz2, a.du, a.dx1, a.dz1, a.dout_attn = dz2.data_ptr(), du.data_ptr(), dx1.data_ptr(), dz1.data_ptr(), do.data_ptr()
+            a.pgrad2 = pg[slot, 1].data_ptr()
+            L.call_struct("vpf_sa_layer_bwd_mlp", a)
+            return bufs
+
+        def pgrad_job(slot, which, ln):
+            nonlocal npj
+            pjobs[npj].partials, pjobs[npj].rows = pg[slot, which].data_ptr(), nwg
+            pjobs[npj].dgamma, pjobs[npj].dbeta = grad_buf(ln.weight).data_ptr(), grad_buf(ln.bias).data_ptr()
+            npj += 1
+            if npj == 32:
+                L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
+                npj = 0
+
+        for i in range(nl - 1, -1, -1):
+            base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[18 + 13 * i:18 + 13 * i + 13]
+            layer = layers[i]
+            sa, mlp = layer[0].module, layer[1].module
+            att, ln1 = sa.attention, sa.norm
+            pk = packed[i + 1]
+            a = L.SaLayerBwd()
+            dz2, du, dx1, dz1, do = bwd_mlp(a, (att, mlp), layer[0], layer[1], pk, d, u, x1, m2, r2, i + 1)
+            dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+            dbase = torch.empty(M, D, dtype=F32, device=dev)
+            L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
+                   float(att.dp_scale), float(att.dropout.p if training else 0.0), st, att.site_attn, dqkv, 3 * D, dqkv[:, D:], 3 * D,
+                   dqkv[:, 2 * D:], 3 * D, torch.empty(B * H * Lq, dtype=F32, device=dev))
+            a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = (dqkv.data_ptr(), pk["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(),
+                                                                 r1.data_ptr(), ln1.weight.data.data_ptr())
+            a.dbase, a.dsum, a.pgrad1 = dbase.data_ptr(), (dsum.data_ptr() if dsum is not None else None), pg[i + 1, 0].data_ptr()
+            L.call_struct("vpf_sa_layer_bwd_qkv", a)
+            wg = WgradBatch()
+            wg.add(dz2, h, D, Hd, grad_buf(mlp[3].weight), grad_buf(mlp[3].bias))
+            wg.add(du, n2, Hd, D, grad_buf(mlp[1].weight), grad_buf(mlp[1].bias))
+            wg.add(dz1, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
+            wg.add(dqkv, n1, 3 * D, D, packed_grad([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]))
+            wg.flush()
+            pgrad_job(i + 1, 1, mlp[0])
+            pgrad_job(i + 1, 0, ln1)
+            d = dbase
+        # ---- cross-attention layer
+        base_ca, mq, rq, nq, xkv, mk, rk, nk, q, kv, o, lse, x1, m2, r2, n2, u, h = flat[:18]
+        cross, cmlp = ca[0].module, ca[1].module
+        catt, lnq, lnkv = cross.attention, cross.q_norm, cross.kv_norm
+        a = L.SaLayerBwd()
+        dz2, du, dx1, dz1, do = bwd_mlp(a, (catt, cmlp), ca[0], ca[1], packed[0], d, u, x1, m2, r2, 0)
+        pgrad_job(0, 1, cmlp[0])
+        if npj:
+            L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
+        dq = torch.empty(M, D, dtype=BF16, device=dev)
+        dkv = torch.empty(Mk, 2 * D, dtype=BF16, device=dev)
+        L.call("vpf_attention_bwd", q, D, kv, 2 * D, kv[:, D:], 2 * D, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(catt.dp_scale),
+               float(catt.dropout.p if training else 0.0), st, catt.site_attn, dq, D, dkv, 2 * D, dkv[:, D:], 2 * D,
+               torch.empty(B * H * Lq, dtype=F32, device=dev))
+        qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
+        w16, gW = shadow(qkvw), packed_grad(qkvw)
+        wg = WgradBatch()
+        wg.add(dz2, h, D, Hd, grad_buf(cmlp[3].weight), grad_buf(cmlp[3].bias))
+        wg.add(du, n2, Hd, D, grad_buf(cmlp[1].weight), grad_buf(cmlp[1].bias))
+        wg.add(dz1, o, D, D, grad_buf(catt.o_proj.weight), grad_buf(catt.o_proj.bias))
+        wg.add(dq, nq, D, D, gW[:D * D])
+        wg.flush()
+        linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
+        dnq = linear_dgrad(dq, w16[:D * D], D, D)
+        dxkv = None
+        dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
+        if ctx.needs_input_grad[2]:
+            dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16)).view(B, Lkv, D)
+        else:
+            layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
+        dx = layernorm_bwd(dnq, base_ca, mq, rq, lnq.weight, lnq.bias, dx1).view(M, D)
+        dpos = None
+        if want_pos:
+            dsum.add_(dx)
+            if ctx.pos_shape[0] == B or B == 1:
+                dpos = dsum.view(ctx.pos_shape)
+            else:
+                dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dev)
+                L.call("vpf_rowsum_mod_f32", dsum, M, D, Lq, dpos)
+        return (dx.view(B, Lq, D), dpos, dxkv, None, None, None) + (None,) * ctx.nparams
+
+
+def encoder_fused_supported(ca, layers, x, xkv) -> bool:
+    if not (SA_FUSED[0] and ENC_FUSED[0]) or not sa_stack_supported(layers, x) or xkv is None or xkv.dim() != 3:
+        return False
+    if not getattr(ca, "attention_residual", False):
+        return False
+    att, mlp = ca[0].module.attention, ca[1].module
+    if att.num_heads != 4 or mlp[1].weight.shape[0] != 512 or xkv.shape[-1] != 256:
+        return False
+    return isinstance(ca[0].drop_path, torch.nn.Identity) and isinstance(ca[1].drop_path, torch.nn.Identity)
+
+
+ENC_FUSED = [True]     # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
+
+
 # --------------------------------------------------------------------------- generic dropout + residual (Residual fallback)
 class DropoutAddFn(torch.autograd.Function):
     @staticmethod
