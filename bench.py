@@ -12,7 +12,7 @@ N > 1, fused AdamW.  Workload at every N: BASELINE.json configs[1] per GPU (E1CL
 64 pairs of 2 x 1024-point clouds + one 224x224 image, patch 16) -> weak scaling, global batch 64 N.
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline     : the dominant kernel (bf16 MFMA GEMM family) timed live with HIP events on the launch stream
+  roofline     : the dominant kernel (fused encoder-layer tail, HBM-bound) timed live with HIP events on the launch stream
   cpu_baseline : the oracle (CPU restatement of the reference path, kind "port") timed on this box's
                  host cores on a bounded sample (rank 0, N == 1 only)
 """
@@ -49,30 +49,62 @@ def synth_batch(b, N, img, seed, device):
     return t1.to(device), t2.to(device), imgs.to(device)
 
 
+# Algorithmic HBM bytes of one row (token) through sa_layer_fwd_kernel: reads o (bf16 256) + residual base
+# (f32 256) + pos (f32 256); writes x1, out (f32 256 each), n2, next n1 (bf16 256 each), u, h (bf16 512 each),
+# next qkv (bf16 768), 4 LayerNorm statistics (f32).  Weights (1.3 MB per launch, L2 resident) are not counted.
+SA_FWD_BYTES_PER_ROW = 256 * 2 + 256 * 4 + 256 * 4 + 2 * 256 * 4 + 2 * 256 * 2 + 2 * 512 * 2 + 768 * 2 + 16
+SA_FWD_FLOP_PER_ROW = 2 * 256 * (256 + 512 + 512 + 768)
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
+
+
 def time_dominant_kernel(device):
-    """Roofline leg: the largest single GEMM of the step (Group2Emb 256->256 conv over all
-    2*64*96*32 = 393216 grouped points) launched back-to-back, HIP events on the launch stream."""
+    """Roofline leg: the kernel with the largest share of the step (rocprofv3: profiles/r01_bench_c2_kernel_stats.csv),
+    sa_layer_fwd_kernel -- the fused tail of one encoder layer (o_proj + dropout + residual, LayerNorm, MLP, next layer's
+    LayerNorm + q/k/v projection) over the point-cloud branch's 2 * 64 * 96 = 12288 tokens -- launched back-to-back on
+    torch's current stream (the stream the C ABI launches on) and timed with HIP events on that stream."""
+    import torch.nn as nn
     from vipformer_amd import ops
-    M, N, K = 2 * PER_GPU_PAIRS * ARCH["G"] * ARCH["K"], 256, 256
-    A = torch.randn(M, K, device=device).to(torch.bfloat16)
-    W = (torch.randn(N, K, device=device) * 0.06).to(torch.bfloat16)
-    bias = torch.zeros(N, device=device)
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    B, Lq, D = 2 * PER_GPU_PAIRS, ARCH["G"], ARCH["D"]
+    M = B * Lq
+    layers = nn.ModuleList([SelfAttentionLayer(ARCH["H"], D, ARCH["MR"], 0.0, 0.1, 0.5) for _ in range(2)]).to(device)
+    layers.train()
+    blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
+    packed = ops._pack_blocks(blocks, layers[0], device)
+    st = ops.rng.state(device)
+    base = torch.randn(M, D, device=device)
+    pos = torch.randn(M, D, device=device)
+    o = torch.randn(M, D, device=device).to(torch.bfloat16)
+    lse = torch.zeros(B * ARCH["H"] * Lq, device=device)
+    att, mlp = layers[0][0].module.attention, layers[0][1].module
+    nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
+
+    def launch():
+        ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, Lq, o, base, o, lse, nxt, pos, M, device)
+
     for _ in range(3):
-        ops.linear_fwd(A, W, N, K, bias)
+        launch()
     iters = 20
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        ops.linear_fwd(A, W, N, K, bias)
+        launch()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * M * N * K
-    ach = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="gemm_kernel<bf16 32x32x16 MFMA> M=393216 N=256 K=256 (Group2Emb second_conv.0)",
-                achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                traffic=None, us_per_launch=round(ms * 1e3, 2), flop_per_launch=flops)
+    nbytes = float(SA_FWD_BYTES_PER_ROW) * M
+    ach = nbytes / (ms * 1e-3) / 1e9
+    traffic = None
+    try:        # HBM bytes per launch from the PMC passes of the same kernel (tools/pmc_hbm.sh), measured offline
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_sa_layer_fwd.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return dict(bound="hbm", kernel="sa_layer_fwd_kernel<2,2,32,false> (fused encoder-layer tail), 12288 tokens x 256 channels",
+                achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic,
+                us_per_launch=round(ms * 1e3, 2), bytes_per_launch=nbytes,
+                mfma_tflops=round(SA_FWD_FLOP_PER_ROW * M / (ms * 1e-3) / 1e12, 1))
 
 
 def cpu_baseline(pairs=4, timed_steps=2):

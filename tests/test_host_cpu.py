@@ -47,6 +47,18 @@ def test_ctypes_table_matches_header():
     assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror"}
 
 
+def test_ctypes_structs_match_the_library_layout():
+    """The argument structs of the fused entry points: the ctypes mirrors must have the size the library was compiled
+    with (vpf_abi_sizeof), and _lib.SIGS entries that take a struct pass it as one pointer."""
+    import ctypes
+    from vipformer_amd import _lib, build
+    build.build(verbose=False)
+    lib = _lib.lib()
+    for which, cls in enumerate((_lib.PackJob, _lib.SaLayerFwd, _lib.WgradJob, _lib.SaLayerBwd, _lib.PgradJob)):
+        assert lib.vpf_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__
+    assert lib.vpf_abi_sizeof(99) == -1
+
+
 def _build(name):
     from vipformer_amd.train import build_models
     a = Hh.ARCHS[name]
