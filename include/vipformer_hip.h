@@ -192,8 +192,8 @@ int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, c
 int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
                         const float* beta, void* out_bf16, void* stream);
 int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
-                      const float* gamma, const float* beta, int training, float* tmp128_zeroed, float* dW, float* db,
-                      float* dgamma, float* dbeta, void* stream);
+                      const float* gamma, const float* beta, int training, float* tmp128, float* dW, float* db,
+                      float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream);   /* ws: per-block partials, up to 1024 * 320 floats */
 /* Group2Emb forward for group_size == 32 as two persistent weight-stationary kernels (conv weights held in registers as
  * MFMA fragments, activations of a pair of groups in LDS; only the pre-BN2 activation h3 and what backward needs reach HBM):
  *   vpf_g2e_fold_bn1: BatchNorm-1 folded into the first conv (ab1 from vpf_bn_affine)
@@ -233,7 +233,8 @@ int vpf_g2e_concat_bwd(const void* dfeat_bf16, const uint8_t* arg, long NG, int 
 int vpf_adapter_front_fwd(const float* x, long M, int C, const float* W, const float* b, const float* gamma,
                           const float* beta, void* out_bf16, void* stream);
 int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b,
-                          const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta, void* stream);
+                          const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta,
+                          float* ws, long ws_floats, void* stream);   /* ws: per-block partials, up to 2048 * 704 floats */
 /* y = act(x W^T + b), x f32 [M,C<=8] -> bf16 [M,N]; act 1 = GELU(erf): position_emb[0:2] (partseg.py:498-500) */
 int vpf_smallk_fwd(const float* x, long M, int C, const float* W, const float* b, int N, int act, void* out_bf16, void* stream);
 int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C, const float* W, const float* b, int N, int act,

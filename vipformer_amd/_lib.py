@@ -100,7 +100,7 @@ SIGS = {
     "vpf_attention_fwd": [VP, L_, VP, L_, VP, L_, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, VP],
     "vpf_attention_bwd": [VP, L_, VP, L_, VP, L_, VP, L_, VP, L_, VP, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, L_, VP, L_, VP, VP],
     "vpf_adapter_front_fwd": [VP, L_, I, VP, VP, VP, VP, VP, VP],
-    "vpf_adapter_front_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP],
+    "vpf_adapter_front_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, L_, VP],
     "vpf_smallk_fwd": [VP, L_, I, VP, VP, I, I, VP, VP],
     "vpf_smallk_bwd": [VP, VP, L_, I, VP, VP, I, I, VP, VP, VP],
     "vpf_g2e_conv1_stats": [VP, L_, I, VP, VP, VP, VP, VP],
@@ -108,7 +108,7 @@ SIGS = {
     "vpf_group_sum": [VP, L_, I, I, VP, VP],
     "vpf_group_max_scatter_add": [VP, VP, L_, I, I, VP, VP],
     "vpf_g2e_conv1_apply": [VP, L_, I, VP, VP, VP, VP, VP, VP, VP],
-    "vpf_g2e_conv1_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP],
+    "vpf_g2e_conv1_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, L_, VP],
     "vpf_patchify": [VP, L_, L_, L_, L_, I, I, I, I, I, VP, VP],
     "vpf_ntxent_fwd": [VP, VP, I, I, F, VP, VP, VP, VP, VP, VP],
     "vpf_ntxent_bwd": [VP, VP, VP, I, I, F, VP, VP, VP, VP],

@@ -67,8 +67,7 @@ extern "C" int vpf_adapter_front_fwd(const float* x, long M, int C, const float*
 __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
                                                               const float* __restrict__ W, const float* __restrict__ b,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                              float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta)
+                                                              float* __restrict__ partial)
 {
     const int lane = threadIdx.x & 63;
     const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
@@ -106,20 +105,56 @@ __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __r
             for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[u][j];
         }
     }
-    atomicAdd(db + lane, adb); atomicAdd(dgamma + lane, adg); atomicAdd(dbeta + lane, adbe);
+    // Thousands of waves adding into the same ~400 addresses serialise in L2 (this tail used to be most of the kernel):
+    // fold the 4 waves of the block in LDS and leave ONE partial row per block for adapter_front_fold_kernel.
+    __shared__ float fold[4][64 * (3 + AD_MAXC)];
+    const int wv = threadIdx.x >> 6;
+    fold[wv][lane] = adb; fold[wv][64 + lane] = adg; fold[wv][128 + lane] = adbe;
 #pragma unroll
-    for (int j = 0; j < AD_MAXC; ++j) if (j < C) atomicAdd(dW + lane * C + j, aw[j]);
+    for (int j = 0; j < AD_MAXC; ++j) fold[wv][192 + j * 64 + lane] = aw[j];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * (3 + AD_MAXC); e += 256)
+        partial[(size_t)blockIdx.x * 64 * (3 + AD_MAXC) + e] = (fold[0][e] + fold[1][e]) + (fold[2][e] + fold[3][e]);
+}
+// db | dgamma | dbeta | dW[:, j] += sum over blocks of the partial rows (fixed order)
+__global__ void __launch_bounds__(1024) adapter_front_fold_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dW,
+                                                                 float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    __shared__ float fold[16][64];
+    constexpr int ROW = 64 * (3 + AD_MAXC);
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;       // column of the partial row
+    float s0 = 0.f, s1 = 0.f;
+    int r = rg;
+    for (; r + 16 < nblk; r += 32) { s0 += partial[(size_t)r * ROW + e]; s1 += partial[(size_t)(r + 16) * ROW + e]; }
+    for (; r < nblk; r += 16) s0 += partial[(size_t)r * ROW + e];
+    fold[rg][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += fold[k][threadIdx.x];
+        const int lane = e & 63, grp = e >> 6;
+        if (grp == 0) db[lane] += t;
+        else if (grp == 1) dgamma[lane] += t;
+        else if (grp == 2) dbeta[lane] += t;
+        else if (grp - 3 < C) dW[lane * C + (grp - 3)] += t;
+    }
 }
 extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b,
                                      const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta,
-                                     void* stream)
+                                     float* ws, long ws_floats, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !da_bf16 || !W || !b || !gamma || !beta || !dW || !db || !dgamma || !dbeta) return VPF_ERR_NULL;
+    if (!x || !da_bf16 || !W || !b || !gamma || !beta || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
-    hipLaunchKernelGGL(adapter_front_bwd_kernel, dim3(grid_for(M, 256, 512)), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C,
-                       W, b, gamma, beta, dW, db, dgamma, dbeta);
+    constexpr int ROW = 64 * (3 + AD_MAXC);
+    int nblk = grid_for(M, 64, 2048);
+    if ((long)nblk * ROW > ws_floats) nblk = (int)(ws_floats / ROW);
+    if (nblk < 1) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(adapter_front_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C,
+                       W, b, gamma, beta, ws);
+    hipLaunchKernelGGL(adapter_front_fold_kernel, dim3(3 + AD_MAXC), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -346,10 +381,9 @@ extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W
 __global__ void __launch_bounds__(512) g2e_conv1_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
                                                           const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ stat,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int training,
-                                                          float* __restrict__ tmp, int pass, float* __restrict__ dW, float* __restrict__ db,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta)
+                                                          const float* __restrict__ tmp, int pass, float* __restrict__ partial)
 {
-    __shared__ float red[64][8][5];              // [row lane][channel in group][value]  (per 8-channel group pass)
+    __shared__ float redf[16 * 320];             // [8 waves x 2 halves][5 values][64 channels]
     const int t = threadIdx.x, rl = t >> 3, cg = (t & 7) * 8;
     float w[8][3], bb[8], mu[8], rs[8], ga[8], be[8], sg[8], sgx[8];
 #pragma unroll
@@ -380,36 +414,71 @@ __global__ void __launch_bounds__(512) g2e_conv1_bwd_kernel(const float* __restr
             }
         }
     }
-    // fold the 64 row-lanes of every channel; one atomic per (block, value)
-    for (int grp = 0; grp < 8; ++grp) {
-        __syncthreads();
-        if ((t & 7) == grp) {
+    // Fold the 64 row-lanes of every channel WITHOUT atomics: lanes that share a channel group differ in lane bits 3..5
+    // (3 shuffles per value), the 8 waves meet in LDS, and the block leaves one partial row [5][64] for the fold kernel
+    // (hundreds of blocks adding into the same 320 addresses used to serialise in L2).
+    // lane ^ 8 = a rotate by 8 inside the 16-lane DPP row, lane ^ 16 = a ds_swizzle; the two 32-lane halves go to LDS separately
+#define VPF_FOLD2(v) do { v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   \
+                          v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); } while (0)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { red[rl][j][0] = a0[j]; red[rl][j][1] = a1[j]; red[rl][j][2] = aw[j][0]; red[rl][j][3] = aw[j][1]; red[rl][j][4] = aw[j][2]; }
-        }
-        __syncthreads();
-        if (t < 40) {
-            const int j = t / 5, v = t % 5;
-            float s = 0.f;
-            for (int k = 0; k < 64; ++k) s += red[k][j][v];
-            const int c = grp * 8 + j;
-            if (!pass) { if (v == 0) atomicAdd(tmp + c, s); else if (v == 1) atomicAdd(tmp + 64 + c, s); }
-            else { if (v == 0) atomicAdd(db + c, s); else if (v >= 2 && v - 2 < C) atomicAdd(dW + c * C + (v - 2), s); }
+    for (int j = 0; j < 8; ++j) { VPF_FOLD2(a0[j]); VPF_FOLD2(a1[j]); VPF_FOLD2(aw[j][0]); VPF_FOLD2(aw[j][1]); VPF_FOLD2(aw[j][2]); }
+#undef VPF_FOLD2
+    const int wv = t >> 6, lane = t & 63;
+    __syncthreads();
+    if ((lane & 31) < 8) {
+        float* dst = redf + (wv * 2 + (lane >> 5)) * 320 + (lane & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dst[j] = a0[j]; dst[64 + j] = a1[j]; dst[128 + j] = aw[j][0]; dst[192 + j] = aw[j][1]; dst[256 + j] = aw[j][2]; }
+    }
+    __syncthreads();
+    if (t < 320) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 16; ++w8) sacc += redf[w8 * 320 + t];
+        partial[(size_t)blockIdx.x * 320 + t] = sacc;
+    }
+}
+// pass 0: tmp[c] = sum g, tmp[64+c] = sum g*xhat; pass 1: db / dW += the folded partials, dgamma / dbeta += tmp
+__global__ void __launch_bounds__(1024) g2e_conv1_fold_kernel(const float* __restrict__ partial, int nblk, int C, int pass, float* __restrict__ tmp,
+                                                             float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta)
+{
+    __shared__ float fold[16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, v = blockIdx.x;      // 5 blocks: one per value
+    float s0 = 0.f, s1 = 0.f;
+    int r = rg;
+    for (; r + 16 < nblk; r += 32) { s0 += partial[(size_t)r * 320 + v * 64 + c]; s1 += partial[(size_t)(r + 16) * 320 + v * 64 + c]; }
+    for (; r < nblk; r += 16) s0 += partial[(size_t)r * 320 + v * 64 + c];
+    fold[rg][c] = s0 + s1;
+    __syncthreads();
+    if (rg == 0) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tsum += fold[k][c];
+        if (!pass) { if (v == 0) tmp[c] = tsum; else if (v == 1) tmp[64 + c] = tsum; }
+        else {
+            if (v == 0) { db[c] += tsum; dbeta[c] += tmp[c]; }
+            else if (v == 1) dgamma[c] += tmp[64 + c];
+            else if (v - 2 < C) dW[c * C + (v - 2)] += tsum;
         }
     }
-    if (pass && blockIdx.x == 0 && t < 64) { atomicAdd(dgamma + t, tmp[64 + t]); atomicAdd(dbeta + t, tmp[t]); }
 }
 extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
-                                 const float* gamma, const float* beta, int training, float* tmp128_zeroed, float* dW, float* db,
-                                 float* dgamma, float* dbeta, void* stream)
+                                 const float* gamma, const float* beta, int training, float* tmp128, float* dW, float* db,
+                                 float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !tmp128_zeroed || !dW || !db || !dgamma || !dbeta) return VPF_ERR_NULL;
+    if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !tmp128 || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > 3) return VPF_ERR_BADSHAPE;
-    const int grid = grid_for(M, 64 * 8, 1024);
-    for (int pass = 0; pass < 2; ++pass)
-        hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(512), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma,
-                           beta, training, tmp128_zeroed, pass, dW, db, dgamma, dbeta);
+    int grid = grid_for(M, 64 * 8, 1024);
+    if ((long)grid * 320 > ws_floats) grid = (int)(ws_floats / 320);
+    if (grid < 1) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(512), 0, st, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma,
+                           beta, training, (const float*)tmp128, pass, ws);
+        hipLaunchKernelGGL(g2e_conv1_fold_kernel, dim3(5), dim3(1024), 0, st, (const float*)ws, grid, C, pass, tmp128, dW, db, dgamma, dbeta);
+    }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

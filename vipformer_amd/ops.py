@@ -1243,9 +1243,10 @@ class Group2EmbFn(torch.autograd.Function):
         L.call("vpf_group_max_scatter_add", dgmax, arg2, NG, K, 128, dh2)
         linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
         da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
-        tmp = torch.zeros(128, dtype=F32, device=dev)
+        tmp = torch.empty(128, dtype=F32, device=dev)
+        ws = torch.empty(1024 * 320, dtype=F32, device=dev)                      # per-block partial sums (no atomics)
         L.call("vpf_g2e_conv1_bwd", x, da1, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
-               int(training), tmp, grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight), grad_buf(bn1.bias))
+               int(training), tmp, grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight), grad_buf(bn1.bias), ws, ws.numel())
         return (None, None, None) + (None,) * ctx.nparams
 
 
@@ -1278,8 +1279,9 @@ class AdapterFn(torch.autograd.Function):
         dy16 = to_bf16(dy).view(M, D)
         linear_wgrad(dy16, a, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
         da = linear_dgrad(dy16, shadow([l3.weight]), D, 64)
+        ws = torch.empty(2048 * 64 * 11, dtype=F32, device=x.device)          # per-block partial parameter gradients
         L.call("vpf_adapter_front_bwd", x, da, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data,
-               grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias))
+               grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias), ws, ws.numel())
         return (None, None) + (None,) * ctx.nparams
 
 
