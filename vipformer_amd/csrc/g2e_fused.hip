@@ -12,6 +12,7 @@
 //               the concat never exists)--> h3 ; per-column sum / sum^2 of h3 for BatchNorm-2
 //   g2e_fwd_b:  h3 --BN2+ReLU while staging--> conv4 (MFMA) --max over the 32 members in registers--> out, arg
 #include "vpf_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -243,6 +244,13 @@ __global__ void g2e_fold_bn1_kernel(const float* __restrict__ W1, const float* _
     for (int i = 0; i < C; ++i) w1e[c * C + i] = a * W1[c * C + i];
     b1e[c] = a * b1[c] + ab1[64 + c];
 }
+// persistent workgroups per launch: one per CU by default (VPF_G2E_GRID overrides, e.g. to leave CUs to a concurrent stream)
+static int g2e_max_grid()
+{
+    static int g = -1;
+    if (g < 0) { const char* e = getenv("VPF_G2E_GRID"); g = e ? atoi(e) : 256; if (g < 1) g = 256; }
+    return g;
+}
 extern "C" int vpf_g2e_fold_bn1(const float* W1, const float* b1, const float* ab1, int C, float* w1e, float* b1e, void* stream)
 {
     (void)hipGetLastError();
@@ -265,7 +273,7 @@ extern "C" int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, c
     if (((uintptr_t)w2_bf16 & 15) || ((uintptr_t)w3_bf16 & 15) || ((uintptr_t)a1 & 15) || ((uintptr_t)h2 & 15) || ((uintptr_t)h3 & 15)) return VPF_ERR_BADALIGN;
     G2eA p = {x, NG, C, w1e, b1e, (const bf16_t*)w2_bf16, b2, (const bf16_t*)w3_bf16, b3, (bf16_t*)a1, (bf16_t*)h2, (bf16_t*)gmax, arg2,
               (bf16_t*)h3, partials_256x512};
-    long grid = (NG + 1) / 2; if (grid > 256) grid = 256;
+    long grid = (NG + 1) / 2; if (grid > g2e_max_grid()) grid = g2e_max_grid();
     *nrows_out = (int)grid;
     hipLaunchKernelGGL(g2e_fwd_a_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
     VPF_CHECK_LAUNCH();
@@ -281,7 +289,7 @@ extern "C" int vpf_g2e_fwd_b(const void* h3_bf16, long NG, const float* ab2, con
     if (NG <= 0 || Dm <= 0 || Dm > 512 || (Dm % 32)) return VPF_ERR_BADSHAPE;
     if (((uintptr_t)h3_bf16 & 15) || ((uintptr_t)w4_bf16 & 15)) return VPF_ERR_BADALIGN;
     G2eB p = {(const bf16_t*)h3_bf16, NG, ab2, (const bf16_t*)w4_bf16, b4, Dm, out, arg4};
-    long grid = (NG + 1) / 2; if (grid > 256) grid = 256;
+    long grid = (NG + 1) / 2; if (grid > g2e_max_grid()) grid = g2e_max_grid();
     if (Dm <= 256) hipLaunchKernelGGL(g2e_fwd_b_kernel<1>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(g2e_fwd_b_kernel<2>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
     VPF_CHECK_LAUNCH();
@@ -615,7 +623,7 @@ extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long 
         if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    long grid = (NG + 1) / 2; if (grid > 256) grid = 256;
+    long grid = (NG + 1) / 2; if (grid > g2e_max_grid()) grid = g2e_max_grid();
     hipStream_t st = (hipStream_t)stream;
     if (training) hipLaunchKernelGGL(g2e_bwd_kernel<0>, dim3((unsigned)grid), dim3(512), lds, st, p);
     hipLaunchKernelGGL(g2e_bwd_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, p);

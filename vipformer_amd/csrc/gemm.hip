@@ -289,7 +289,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     // ONE barrier, then each thread finishes 4 consecutive columns of a row: GELU / GELU' / dropout+residual / group bias /
     // group max with 16-byte loads of the side inputs and 8- or 16-byte stores.
     constexpr int SLD = BN + 4;
-    static_assert(BM * SLD * 4 <= 2 * STAGE * 2, "accumulator tile must fit in the operand buffers");
+    if constexpr (BM * SLD * 4 > 2 * STAGE * 2) return;     // tile shapes instantiated for EPI_ATOMIC only (grouped wgrad)
     float* sf = reinterpret_cast<float*>(lds);
     VpfRng rng;
     if (g.mode == EPI_DROP_RES) rng = vpf_rng_init(g.rng, g.site, g.p);
@@ -562,7 +562,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
     grp.n = njobs;
     static int cfg = -1, target = 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     if (cfg < 0) { const char* e = getenv("VPF_WGROUP_CFG"); cfg = e ? atoi(e) : 2; const char* t = getenv("VPF_WGROUP_WGS"); if (t) target = atoi(t); }
-    const int tm = cfg == 0 ? 64 : 128, tn = cfg == 2 ? 128 : 64;
+    const int tm = cfg == 0 ? 64 : 128, tn = cfg >= 3 ? 256 : (cfg == 2 ? 128 : 64);
     long total_tiles = 0;
     for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
     int at = 0;
@@ -587,6 +587,8 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
     }
     grp.start[njobs] = at;
     hipStream_t st = (hipStream_t)stream;
+    if (cfg == 4) return launch_wgrad_group<2, 4, 2, 2, 64>(grp, at, st);     // wave tile 64x128: half the LDS fragment reads per MFMA
+    if (cfg == 3) return launch_wgrad_group<2, 4, 2, 2, 32>(grp, at, st);
     if (cfg == 2) return launch_wgrad_group<2, 2, 2, 2, 64>(grp, at, st);
     if (cfg == 1) return launch_wgrad_group<1, 2, 4, 1, 64>(grp, at, st);
     return launch_wgrad_group<1, 1, 2, 2, 128>(grp, at, st);
