@@ -19,6 +19,7 @@
 // Everything the existing backward needs is written exactly as the unfused path writes it (o, lse, x1, LN stats,
 // n2, u, h, next base / n1 / qkv), so forward and backward can be fused independently.
 #include "vpf_common.h"
+#include <stdlib.h>
 #include "vipformer_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -114,47 +115,52 @@ extern "C" int vpf_pack_wfrag(const VpfPackJob* jobs, int njobs, void* stream)
 // ------------------------------------------------------------------------------------------------ building blocks
 // The first group (4 k-steps x 2 channel blocks) of a unit's weight fragments.  It is fetched BEFORE the stores of the
 // previous phase are issued: vmcnt retires in order, so a load queued behind 48 scattered stores would wait for all of them.
-struct SaWPre { uint4 a[8], b[8]; };            // groups 0 and 1 (k-steps 0..7) of both channel blocks
-__device__ __forceinline__ void sa_wprefetch(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb0, SaWPre& w)
+template <int NJ>
+struct SaWPre { uint4 w[NJ][8]; };            // groups 0 and 1 (k-steps 0..7) of the wave's NJ channel blocks
+template <int NJ>
+__device__ __forceinline__ void sa_wprefetch(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb0, SaWPre<NJ>& w)
 {
     const int lane = threadIdx.x & 63;
     const uint4* w0 = reinterpret_cast<const uint4*>(Wp) + ((size_t)cb0 * ksn + ks0) * 64 + lane;
-    const uint4* w1 = w0 + (size_t)ksn * 64;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) { w.a[kk] = w0[kk * 64]; w.b[kk] = w1[kk * 64]; }
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) w.w[j][kk] = w0[((size_t)j * ksn + kk) * 64];
 }
 // acc[j][i] += Wfrag(cb0 + j, ks0 + ks) . X[i*32.., ks*16..]   for ks = 0..15 (a 256-deep slice of the contraction).
 // Weight fragments stream from L2 two groups of 4 k-steps ahead of the MFMAs (the first two groups come from the caller's
 // prefetch); the compiler barriers keep the loads from being hoisted further (register pressure next to two live
 // accumulator sets).
-template <int RB>
+template <int RB, int NJ>
 __device__ __forceinline__ void sa_gemm_unit(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb0, const bf16_t* act,
-                                             f32x16_t (&acc)[2][RB], const SaWPre& pre)
+                                             f32x16_t (&acc)[NJ][RB], const SaWPre<NJ>& pre)
 {
     const int lane = threadIdx.x & 63;
     const uint4* w0 = reinterpret_cast<const uint4*>(Wp) + ((size_t)cb0 * ksn + ks0) * 64 + lane;
-    const uint4* w1 = w0 + (size_t)ksn * 64;
-    uint4 wa[8], wb[8];                 // groups 2 and 3
+    uint4 wl[NJ][8];                    // groups 2 and 3
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) { wa[kk] = w0[(8 + kk) * 64]; wb[kk] = w1[(8 + kk) * 64]; }
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) wl[j][kk] = w0[((size_t)j * ksn + 8 + kk) * 64];
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        const bf16x8_t a0 = __builtin_bit_cast(bf16x8_t, ks < 8 ? pre.a[ks & 7] : wa[ks & 7]);
-        const bf16x8_t a1 = __builtin_bit_cast(bf16x8_t, ks < 8 ? pre.b[ks & 7] : wb[ks & 7]);
+        bf16x8_t af[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) af[j] = __builtin_bit_cast(bf16x8_t, ks < 8 ? pre.w[j][ks & 7] : wl[j][ks & 7]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const bf16x8_t x = sa_frag_row(act, ALD, i * 32, ks * 16);
-            acc[0][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, x, acc[0][i], 0, 0, 0);
-            acc[1][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, x, acc[1][i], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], x, acc[j][i], 0, 0, 0);
         }
     }
 }
-template <int RB>
-__device__ __forceinline__ void sa_zero(f32x16_t (&acc)[2][RB])
+template <int RB, int NJ>
+__device__ __forceinline__ void sa_zero(f32x16_t (&acc)[NJ][RB])
 {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -164,27 +170,33 @@ __device__ __forceinline__ void sa_zero(f32x16_t (&acc)[2][RB])
 // a lane holds groups of 4 consecutive channels (j, g = r >> 2).
 
 // per-token sum over the 256 channels of v(j,i,r): in-lane over registers, lane ^ 32, then the 4 waves through LDS
-template <int RB>
+template <int RB, int NJ>
 __device__ __forceinline__ void sa_token_sum(float (&part)[RB], float* sStat, float (&tot)[RB])
 {
+    constexpr int NWV = 8 / NJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         part[i] += __shfl_xor(part[i], 32, 64);
-        if (lane < 32) sStat[(i * 32 + lane) * 4 + wave] = part[i];
+        if (lane < 32) sStat[(i * 32 + lane) * NWV + wave] = part[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(sStat + (i * 32 + (lane & 31)) * 4);
-        tot[i] = (v.x + v.y) + (v.z + v.w);
+        float t = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < NWV; w4 += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(sStat + (i * 32 + (lane & 31)) * NWV + w4);
+            t += (v.x + v.y) + (v.z + v.w);
+        }
+        tot[i] = t;
     }
 }
 
 // LayerNorm over the channel axis of the values in acc (two-pass: mean, then centred second moment), in place:
 // acc <- (acc - mean) * rstd * gamma + beta.  mean / rstd of every token are returned (all lanes of the token agree).
-template <int RB>
-__device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[2][RB], const float* __restrict__ gamma, const float* __restrict__ beta,
+template <int RB, int NJ>
+__device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[NJ][RB], const float* __restrict__ gamma, const float* __restrict__ beta,
                                              float* sStatA, float* sStatB, float (&mean)[RB], float (&rstd)[RB])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
@@ -193,30 +205,30 @@ __device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[2][RB], const float
     for (int i = 0; i < RB; ++i) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += acc[j][i][r];
         part[i] = s;
     }
-    sa_token_sum<RB>(part, sStatA, mean);
+    sa_token_sum<RB, NJ>(part, sStatA, mean);
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         mean[i] *= (1.0f / SA_D);
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float d = acc[j][i][r] - mean[i]; s += d * d; }
         part[i] = s;
     }
-    sa_token_sum<RB>(part, sStatB, rstd);
+    sa_token_sum<RB, NJ>(part, sStatB, rstd);
 #pragma unroll
     for (int i = 0; i < RB; ++i) rstd[i] = rsqrtf(rstd[i] * (1.0f / SA_D) + 1e-5f);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int c = 64 * wave + 32 * j + 8 * g + 4 * hl;
+            const int c = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
             const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
             const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
 #pragma unroll
@@ -228,13 +240,13 @@ __device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[2][RB], const float
 
 // store the accumulator tile as bf16 into an LDS activation tile [tokens][ALD] (column offset col0) and, for valid tokens,
 // to a global [M][ld] matrix (column offset gcol0)
-template <int RB>
-__device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[2][RB], bf16_t* sAct, int col0, bf16_t* __restrict__ G, long ld,
+template <int RB, int NJ>
+__device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[NJ][RB], bf16_t* sAct, int col0, bf16_t* __restrict__ G, long ld,
                                               int gcol0, long m0, int nvalid)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -242,7 +254,7 @@ __device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[2][RB], bf16
                 uint2 u;
                 u.x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
                 u.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-                const int c = 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const int c = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                 const int tok = i * 32 + t;
                 if (sAct) *reinterpret_cast<uint2*>(sAct + tok * ALD + col0 + c) = u;
                 if (G && tok < nvalid) *reinterpret_cast<uint2*>(G + (size_t)(m0 + tok) * ld + gcol0 + c) = u;
@@ -307,9 +319,11 @@ __device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV,
 
 // ATT = false: the attention output o is an INPUT (vpf_attention_fwd ran before); a workgroup then owns any RB*32
 // consecutive rows of the [B*L, D] token matrix, needs no K / V tiles and two workgroups fit on a CU.
-template <int RB, int HPR, int LPT, bool ATT>
-__global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
+template <int RB, int HPR, int LPT, bool ATT, int NJ>
+__global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerFwd a)
 {
+    constexpr int NWV = 8 / NJ, NT = 64 * NWV;          // waves per workgroup: each owns NJ blocks of 32 channels per 256-wide chunk
+    static_assert(!ATT || NJ == 2, "the in-kernel attention distributes its units over 4 waves");
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int TOK = RB * 32;
     constexpr int UPW = HPR * RB / 4;                 // attention units per wave and round
@@ -317,8 +331,8 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
     bf16_t* actA = lds;                               // [TOK][ALD]   o -> n2 -> next n1
     bf16_t* reg1 = lds + TOK * ALD;                   // K/V tiles during attention, then actH + LayerNorm exchange
     bf16_t* actH = reg1;                              // [TOK][ALD]   one 256-wide chunk of the hidden activation
-    float* sStatA = reinterpret_cast<float*>(reg1 + TOK * ALD);   // [TOK][4]
-    float* sStatB = sStatA + TOK * 4;
+    float* sStatA = reinterpret_cast<float*>(reg1 + TOK * ALD);   // [TOK][NWV]
+    float* sStatB = sStatA + TOK * NWV;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const int b = blockIdx.x, chunk = blockIdx.y;
@@ -332,20 +346,20 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
 #define SA_STAMP() do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { t1_ = clock64(); a.dbg[ph_++] = t1_ - t0_; t0_ = t1_; } } while (0)
     if (a.dbg) t0_ = clock64();
 
-    SaWPre wpre;
+    SaWPre<NJ> wpre;
     if constexpr (!ATT) {
         // stage this workgroup's rows of the attention output (coalesced 16-byte loads)
-        sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, 2 * wave, wpre);
-        constexpr int CPT = TOK * 32 / 256;
+        sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, NJ * wave, wpre);
+        constexpr int CPT = TOK * 32 / NT;
         uint4 r[CPT];
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
-            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
             r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.o + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
-            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
             *reinterpret_cast<uint4*>(actA + row * ALD + ch * 8) = r[it];
         }
     }
@@ -388,7 +402,7 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
                 if (e < NCH) *reinterpret_cast<uint4*>(reg1 + ((slot * 2 + kv) * LPT + row) * KLD + ch * 8) = kvr[it];
             }
             __syncthreads();
-            if (round + 1 == SA_H / HPR) sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, 2 * wave, wpre);   // ahead of the o stores
+            if (round + 1 == SA_H / HPR) sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, NJ * wave, wpre);   // ahead of the o stores
 #pragma unroll
             for (int uu = 0; uu < UPW; ++uu) {
                 const int u = wave + 4 * uu, slot = u / RB, rb = u % RB, hd = round * HPR + slot;
@@ -422,33 +436,33 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
     __syncthreads();                                           // o complete in actA; K / V dead
     SA_STAMP();     // 0: attention
 
-    f32x16_t acc[2][RB];
+    f32x16_t acc[NJ][RB];
     // ============================================================ x1 = base + dropout(o . Wo^T + bo);  n2 = LN2(x1)
     {
         // the residual base of every element this lane owns: issued before the GEMM, consumed after it
-        float4 res[2][4][RB];
+        float4 res[NJ][4][RB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int tok = i * 32 + t;
                     const bool ok = tok < nvalid;
-                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                     res[j][g][i] = ok ? *reinterpret_cast<const float4*>(a.base + off) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-        sa_zero<RB>(acc);
-        sa_gemm_unit<RB>((const bf16_t*)a.Wo, SA_D / 16, 0, 2 * wave, actA, acc, wpre);
-        sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, 2 * wave, wpre);           // fc1 chunk 0, ahead of the x1 / n2 stores
+        sa_zero<RB, NJ>(acc);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wo, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, NJ * wave, wpre);           // fc1 chunk 0, ahead of the x1 / n2 stores
         SA_STAMP();     // 1: o_proj MFMA
         const VpfRng rng = vpf_rng_init(a.rng, a.site_res1, a.p_res1);
         const bool drop = a.p_res1 > 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cch = 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const int cch = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                 const float4 bo = *reinterpret_cast<const float4*>(a.bo + cch);
                 const float bb[4] = {bo.x, bo.y, bo.z, bo.w};
 #pragma unroll
@@ -472,32 +486,32 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
             }
         SA_STAMP();     // 2: dropout + residual epilogue
         float mean[RB], rstd[RB];
-        sa_layernorm<RB>(acc, a.ln2_g, a.ln2_b, sStatA, sStatB, mean, rstd);
+        sa_layernorm<RB, NJ>(acc, a.ln2_g, a.ln2_b, sStatA, sStatB, mean, rstd);
         if (wave == 0 && hl == 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
                 if (i * 32 + t < nvalid) { a.mean2[m0 + i * 32 + t] = mean[i]; a.rstd2[m0 + i * 32 + t] = rstd[i]; }
         }
         // (the LayerNorm exchange barriers guarantee every wave has finished reading o from actA)
-        sa_store_bf16<RB>(acc, actA, 0, (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
+        sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
     }
     __syncthreads();                                           // n2 complete in actA
     SA_STAMP();     // 3: LayerNorm 2 + store
 
     // ============================================================ MLP: two 256-wide chunks of the hidden layer
-    f32x16_t acc2[2][RB];
-    sa_zero<RB>(acc2);
+    f32x16_t acc2[NJ][RB];
+    sa_zero<RB, NJ>(acc2);
 #pragma unroll
     for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
-        sa_zero<RB>(acc);
-        sa_gemm_unit<RB>((const bf16_t*)a.W1, SA_D / 16, 0, hc * 8 + 2 * wave, actA, acc, wpre);
-        sa_wprefetch((const bf16_t*)a.W2, SA_HID / 16, hc * 16, 2 * wave, wpre);   // this chunk's fc2 slice, ahead of the u / h stores
+        sa_zero<RB, NJ>(acc);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, wpre);   // this chunk's fc2 slice, ahead of the u / h stores
         // u = bf16(acc + b1) (saved), h = gelu(u)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cch = hc * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const int cch = hc * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                 const float4 b1 = *reinterpret_cast<const float4*>(a.b1 + cch);
                 const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -516,13 +530,13 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
                 }
             }
         if (hc) __syncthreads();                               // every wave is done reading the previous chunk from actH
-        sa_store_bf16<RB>(acc, actH, 0, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        sa_store_bf16<RB, NJ>(acc, actH, 0, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
         __syncthreads();
-        sa_gemm_unit<RB>((const bf16_t*)a.W2, SA_HID / 16, hc * 16, 2 * wave, actH, acc2, wpre);
-        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, (hc + 1) * 8 + 2 * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
     }
     const bool nxt = a.qkv_next != nullptr;
-    if (nxt) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, 2 * wave, wpre);
+    if (nxt) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, NJ * wave, wpre);
     SA_STAMP();     // 4: MLP (fc1 + GELU + fc2)
 
     // ============================================================ x2 = x1 + dropout(h . W2^T + b2)  [+ pos -> next base, LN1, qkv]
@@ -533,23 +547,23 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
 #pragma unroll
         for (int i = 0; i < RB; ++i) prow[i] = a.pos ? (int)((m0 + i * 32 + t) % a.pos_rows) : 0;
         // two batches of loads (x1 written by this very thread above, then pos), each with all its loads in flight together
-        float4 res[2][4][RB];
+        float4 res[NJ][4][RB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int tok = i * 32 + t;
                     const bool ok = tok < nvalid;
-                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                     res[j][g][i] = ok ? *reinterpret_cast<const float4*>(a.x1 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cch = 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const int cch = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                 const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + cch);
                 const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
 #pragma unroll
@@ -570,16 +584,16 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
             }
         if (a.pos) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int i = 0; i < RB; ++i)
-                        res[j][g][i] = (i * 32 + t < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)prow[i] * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                        res[j][g][i] = (i * 32 + t < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)prow[i] * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -590,32 +604,32 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
                         acc2[j][i][4 * g + 2] += res[j][g][i].z; acc2[j][i][4 * g + 3] += res[j][g][i].w;
                     }
                     if (tok < nvalid)
-                        *reinterpret_cast<float4*>(a.out + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl) =
+                        *reinterpret_cast<float4*>(a.out + (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) =
                             make_float4(acc2[j][i][4 * g + 0], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]);
                 }
         SA_STAMP();     // 5: final dropout + residual epilogue
         if (!nxt) return;
         float mean[RB], rstd[RB];
-        sa_layernorm<RB>(acc2, a.ln1n_g, a.ln1n_b, sStatA, sStatB, mean, rstd);
+        sa_layernorm<RB, NJ>(acc2, a.ln1n_g, a.ln1n_b, sStatA, sStatB, mean, rstd);
         if (wave == 0 && hl == 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
                 if (i * 32 + t < nvalid) { a.mean1n[m0 + i * 32 + t] = mean[i]; a.rstd1n[m0 + i * 32 + t] = rstd[i]; }
         }
-        sa_store_bf16<RB>(acc2, actA, 0, (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
+        sa_store_bf16<RB, NJ>(acc2, actA, 0, (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
     }
     __syncthreads();
     SA_STAMP();     // 6: next LayerNorm 1
     // q | k | v of the next layer: the results are held (packed bf16) and stored after the last unit, so that no weight load
     // ever queues behind a batch of stores
-    uint2 held[3][2][RB][4];
+    uint2 held[3][NJ][RB][4];
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
-        sa_zero<RB>(acc);
-        sa_gemm_unit<RB>((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + 2 * wave, actA, acc, wpre);
-        if (part + 1 < 3) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + 2 * wave, wpre);
+        sa_zero<RB, NJ>(acc);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
+        if (part + 1 < 3) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + NJ * wave, wpre);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
@@ -627,34 +641,34 @@ __global__ void __launch_bounds__(256) sa_layer_fwd_kernel(VpfSaLayerFwd a)
 #pragma unroll
     for (int part = 0; part < 3; ++part)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int tok = i * 32 + t;
                     if (tok < nvalid)
-                        *reinterpret_cast<uint2*>((bf16_t*)a.qkv_next + (size_t)(m0 + tok) * (3 * SA_D) + part * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl) = held[part][j][i][g];
+                        *reinterpret_cast<uint2*>((bf16_t*)a.qkv_next + (size_t)(m0 + tok) * (3 * SA_D) + part * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) = held[part][j][i][g];
                 }
     SA_STAMP();     // 7: next q/k/v projection
 #undef SA_STAMP
 }
 
-template <int RB, int HPR, int LPT, bool ATT>
+template <int RB, int HPR, int LPT, bool ATT, int NJ>
 static int sa_launch(const VpfSaLayerFwd& a, int chunks, hipStream_t st)
 {
     const int LP = LPT, TOK = RB * 32;
-    const size_t kv = ATT ? (size_t)HPR * 2 * LP * KLD * 2 : 0, mlp = (size_t)TOK * ALD * 2 + (size_t)2 * TOK * 4 * 4;
+    const size_t kv = ATT ? (size_t)HPR * 2 * LP * KLD * 2 : 0, mlp = (size_t)TOK * ALD * 2 + (size_t)2 * TOK * (8 / NJ) * 4;
     const size_t lds = (size_t)TOK * ALD * 2 + (kv > mlp ? kv : mlp);
     if (lds > 160 * 1024) return VPF_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)sa_layer_fwd_kernel<RB, HPR, LPT, ATT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)sa_layer_fwd_kernel<RB, HPR, LPT, ATT, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return VPF_ERR_HIP;
         attr = true;
     }
     const dim3 grid = ATT ? dim3(a.B, chunks) : dim3(vpf_cdiv((long)a.B * a.L, TOK), 1);
-    hipLaunchKernelGGL((sa_layer_fwd_kernel<RB, HPR, LPT, ATT>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((sa_layer_fwd_kernel<RB, HPR, LPT, ATT, NJ>), grid, dim3(64 * (8 / NJ)), lds, st, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -672,10 +686,15 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     if (a.D != SA_D || a.H != SA_H || a.hidden != SA_HID) return VPF_ERR_UNSUPPORTED;
     const int chunks = vpf_cdiv(a.L, a.chunk_rows);
     hipStream_t st = (hipStream_t)stream;
-    if (a.attention_done) return sa_launch<2, 2, 32, false>(a, 1, st);       // o is an input: 64-row blocks, any sequence length
+    static int nj = -1;
+    if (nj < 0) { const char* e = getenv("VPF_SA_NJ"); nj = e ? atoi(e) : 1; }
+    if (a.attention_done) {                                                   // o is an input: 64-row blocks, any sequence length
+        if (nj == 2) return sa_launch<2, 2, 32, false, 2>(a, 1, st);          // 4 waves x 64 channels
+        return sa_launch<2, 2, 32, false, 1>(a, 1, st);                       // 8 waves x 32 channels: two waves per SIMD overlap MFMA, VALU and memory waits
+    }
     // one chunk = up to 4 blocks of 32 tokens; all heads' K / V resident when the sequence is short, else one head per round
-    if (a.chunk_rows <= 96 && a.L <= 96) return sa_launch<3, 4, 96, true>(a, chunks, st);
-    if (a.chunk_rows <= 128 && a.L <= 224) return sa_launch<4, 1, 224, true>(a, chunks, st);
+    if (a.chunk_rows <= 96 && a.L <= 96) return sa_launch<3, 4, 96, true, 2>(a, chunks, st);
+    if (a.chunk_rows <= 128 && a.L <= 224) return sa_launch<4, 1, 224, true, 2>(a, chunks, st);
     return VPF_ERR_UNSUPPORTED;
 }
 
@@ -689,14 +708,15 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
 
 // LayerNorm backward in place on the accumulator tile: acc = dL/dy -> dL/dx;  x (the forward input) from HBM.
 // The per-channel parameter gradients of this workgroup's tokens go to pgrad[0..255] (dgamma) / pgrad[256..511] (dbeta).
-template <int RB>
-__device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[2][RB], const float* __restrict__ x, const float* __restrict__ mean,
+template <int RB, int NJ>
+__device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[NJ][RB], const float* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ gamma, float* sStat2,
                                                  float* __restrict__ pgrad, long m0, int nvalid)
 {
+    constexpr int NWV = 8 / NJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     float mu[RB], rs[RB];
-    float4 xh[2][4][RB];
+    float4 xh[NJ][4][RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const bool ok = i * 32 + t < nvalid;
@@ -704,24 +724,24 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[2][RB], const f
         rs[i] = ok ? rstd[m0 + i * 32 + t] : 0.f;
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
-                xh[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(x + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                xh[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(x + (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
     float s1[RB], s2[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    float dgam[2][4][4], dbet[2][4][4];
+    float dgam[NJ][4][4], dbet[NJ][4][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + 64 * wave + 32 * j + 8 * g + 4 * hl);
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl);
             const float gg[4] = {ga.x, ga.y, ga.z, ga.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) { dgam[j][g][q] = 0.f; dbet[j][g][q] = 0.f; }
@@ -748,17 +768,22 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[2][RB], const f
     for (int i = 0; i < RB; ++i) {
         s1[i] += __shfl_xor(s1[i], 32, 64);
         s2[i] += __shfl_xor(s2[i], 32, 64);
-        if (lane < 32) *reinterpret_cast<float2*>(sStat2 + ((i * 32 + lane) * 4 + wave) * 2) = make_float2(s1[i], s2[i]);
+        if (lane < 32) *reinterpret_cast<float2*>(sStat2 + ((i * 32 + lane) * NWV + wave) * 2) = make_float2(s1[i], s2[i]);
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const float4 v0 = *reinterpret_cast<const float4*>(sStat2 + (i * 32 + t) * 8), v1 = *reinterpret_cast<const float4*>(sStat2 + (i * 32 + t) * 8 + 4);
-        s1[i] = ((v0.x + v0.z) + (v1.x + v1.z)) * (1.0f / SA_D);
-        s2[i] = ((v0.y + v0.w) + (v1.y + v1.w)) * (1.0f / SA_D);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w2 = 0; w2 < NWV; w2 += 2) {
+            const float4 v0 = *reinterpret_cast<const float4*>(sStat2 + ((i * 32 + t) * NWV + w2) * 2);
+            t1 += v0.x + v0.z; t2 += v0.y + v0.w;
+        }
+        s1[i] = t1 * (1.0f / SA_D);
+        s2[i] = t2 * (1.0f / SA_D);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -769,7 +794,7 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[2][RB], const f
             }
     // parameter gradients: sum over this workgroup's tokens = over the 32 lanes of each half
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -778,7 +803,7 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[2][RB], const f
 #pragma unroll
                 for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
                 if (t == 0) {
-                    const int c = 64 * wave + 32 * j + 8 * g + 4 * hl + q;
+                    const int c = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl + q;
                     pgrad[c] = a;
                     pgrad[SA_D + c] = b;
                 }
@@ -786,30 +811,30 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[2][RB], const f
 }
 
 // dropout backward of the f32 rows `src` in accumulator layout -> acc (f32, scaled / zeroed)
-template <int RB>
-__device__ __forceinline__ void sa_load_dropout_bwd(f32x16_t (&acc)[2][RB], const float* __restrict__ src, const VpfRng& rng, bool drop,
+template <int RB, int NJ>
+__device__ __forceinline__ void sa_load_dropout_bwd(f32x16_t (&acc)[NJ][RB], const float* __restrict__ src, const VpfRng& rng, bool drop,
                                                     long m0, int nvalid)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
-    float4 v[2][4][RB];
+    float4 v[NJ][4][RB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
-                v[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                v[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(src + (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
-                const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                 const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
                 const float s = drop ? rng.scale : 1.f;
                 acc[j][i][4 * g + 0] = (keep & 1u) ? v[j][g][i].x * s : 0.f;
@@ -819,8 +844,8 @@ __device__ __forceinline__ void sa_load_dropout_bwd(f32x16_t (&acc)[2][RB], cons
             }
 }
 
-template <int RB>
-__global__ void __launch_bounds__(256) sa_bwd_mlp_kernel(VpfSaLayerBwd a)
+template <int RB, int NJ>
+__global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_mlp_kernel(VpfSaLayerBwd a)
 {
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int TOK = RB * 32;
@@ -832,36 +857,36 @@ __global__ void __launch_bounds__(256) sa_bwd_mlp_kernel(VpfSaLayerBwd a)
     const long m0 = (long)blockIdx.x * TOK;
     const int nvalid = (int)min((long)TOK, M - m0);
 
-    SaWPre wpre;
-    sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, 2 * wave, wpre);
-    f32x16_t acc[2][RB], acc2[2][RB];
+    SaWPre<NJ> wpre;
+    sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, NJ * wave, wpre);
+    f32x16_t acc[NJ][RB], acc2[NJ][RB];
     // ---- dz2 = dropout'(d)
     {
         const VpfRng rng = vpf_rng_init(a.rng, a.site_res2, a.p_res2);
-        sa_load_dropout_bwd<RB>(acc, a.d, rng, a.p_res2 > 0.f, m0, nvalid);
-        sa_store_bf16<RB>(acc, actA, 0, (bf16_t*)a.dz2, SA_D, 0, m0, nvalid);
+        sa_load_dropout_bwd<RB, NJ>(acc, a.d, rng, a.p_res2 > 0.f, m0, nvalid);
+        sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.dz2, SA_D, 0, m0, nvalid);
     }
     __syncthreads();
     // ---- du = (dz2 . W2) * gelu'(u) ;  dn = du . W1
-    sa_zero<RB>(acc2);
+    sa_zero<RB, NJ>(acc2);
 #pragma unroll
     for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
-        uint2 uu[2][4][RB];
+        uint2 uu[NJ][4][RB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int tok = i * 32 + t;
-                    uu[j][g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                    uu[j][g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
                                                : make_uint2(0u, 0u);
                 }
-        sa_zero<RB>(acc);
-        sa_gemm_unit<RB>((const bf16_t*)a.W2T, SA_D / 16, 0, hc * 8 + 2 * wave, actA, acc, wpre);
-        sa_wprefetch((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, 2 * wave, wpre);
+        sa_zero<RB, NJ>(acc);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2T, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, wpre);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -872,36 +897,36 @@ __global__ void __launch_bounds__(256) sa_bwd_mlp_kernel(VpfSaLayerBwd a)
                     acc[j][i][4 * g + 3] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].y & 0xffff0000u));
                 }
         if (hc) __syncthreads();
-        sa_store_bf16<RB>(acc, actH, 0, (bf16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
+        sa_store_bf16<RB, NJ>(acc, actH, 0, (bf16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
         __syncthreads();
-        sa_gemm_unit<RB>((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, 2 * wave, actH, acc2, wpre);
-        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + 2 * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
     }
-    sa_wprefetch((const bf16_t*)a.WoT, SA_D / 16, 0, 2 * wave, wpre);
+    sa_wprefetch((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, wpre);
     // ---- dx1 = LayerNorm-2'(dn) + d
-    sa_layernorm_bwd<RB>(acc2, a.x1, a.mean2, a.rstd2, a.ln2_g, sStat2, a.pgrad2 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+    sa_layernorm_bwd<RB, NJ>(acc2, a.x1, a.mean2, a.rstd2, a.ln2_g, sStat2, a.pgrad2 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
     {
-        float4 dv[2][4][RB];
+        float4 dv[NJ][4][RB];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int tok = i * 32 + t;
-                    dv[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(a.d + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                    dv[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(a.d + (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
                                                : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
         const VpfRng rng = vpf_rng_init(a.rng, a.site_res1, a.p_res1);
         const bool drop = a.p_res1 > 0.f;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int tok = i * 32 + t;
-                    const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                    const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                     float v[4] = {acc2[j][i][4 * g + 0] + dv[j][g][i].x, acc2[j][i][4 * g + 1] + dv[j][g][i].y,
                                   acc2[j][i][4 * g + 2] + dv[j][g][i].z, acc2[j][i][4 * g + 3] + dv[j][g][i].w};
                     if (tok < nvalid) *reinterpret_cast<float4*>(a.dx1 + off) = make_float4(v[0], v[1], v[2], v[3]);
@@ -912,17 +937,18 @@ __global__ void __launch_bounds__(256) sa_bwd_mlp_kernel(VpfSaLayerBwd a)
                 }
     }
     // (the barriers of the hidden-chunk loop guarantee every wave has finished reading dz2 from actA)
-    sa_store_bf16<RB>(acc2, actA, 0, (bf16_t*)a.dz1, SA_D, 0, m0, nvalid);
+    sa_store_bf16<RB, NJ>(acc2, actA, 0, (bf16_t*)a.dz1, SA_D, 0, m0, nvalid);
     __syncthreads();
     // ---- do = dz1 . Wo
-    sa_zero<RB>(acc);
-    sa_gemm_unit<RB>((const bf16_t*)a.WoT, SA_D / 16, 0, 2 * wave, actA, acc, wpre);
-    sa_store_bf16<RB>(acc, nullptr, 0, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
+    sa_zero<RB, NJ>(acc);
+    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
+    sa_store_bf16<RB, NJ>(acc, nullptr, 0, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
 }
 
-template <int RB>
-__global__ void __launch_bounds__(256) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
+template <int RB, int NJ>
+__global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
 {
+    constexpr int NT = 64 * (8 / NJ);
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     constexpr int TOK = RB * 32;
     bf16_t* actA = lds;                                // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
@@ -931,62 +957,62 @@ __global__ void __launch_bounds__(256) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
     const long M = (long)a.M;
     const long m0 = (long)blockIdx.x * TOK;
     const int nvalid = (int)min((long)TOK, M - m0);
-    constexpr int CPT = TOK * 32 / 256;
+    constexpr int CPT = TOK * 32 / NT;
 
-    SaWPre wpre;
-    sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, 0, 2 * wave, wpre);
+    SaWPre<NJ> wpre;
+    sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, 0, NJ * wave, wpre);
     uint4 r[CPT];
     auto load_part = [&](int part) {
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
-            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
             r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dqkv + (size_t)(m0 + row) * (3 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_part = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
-            const int e = threadIdx.x + it * 256, row = e >> 5, ch = e & 31;
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
             *reinterpret_cast<uint4*>(actA + buf * TOK * ALD + row * ALD + ch * 8) = r[it];
         }
     };
     load_part(0);
     store_part(0);
     __syncthreads();
-    f32x16_t acc[2][RB];
-    sa_zero<RB>(acc);
+    f32x16_t acc[NJ][RB];
+    sa_zero<RB, NJ>(acc);
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
         if (part + 1 < 3) load_part(part + 1);
-        sa_gemm_unit<RB>((const bf16_t*)a.WqkvT, 3 * SA_D / 16, part * 16, 2 * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.WqkvT, 3 * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
         if (part + 1 < 3) {
-            sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, (part + 1) * 16, 2 * wave, wpre);
+            sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
             store_part((part + 1) & 1);
             __syncthreads();
         }
     }
     // ---- dbase = LayerNorm-1'(dn1) + dx1
-    sa_layernorm_bwd<RB>(acc, a.base, a.mean1, a.rstd1, a.ln1_g, sStat2, a.pgrad1 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
-    float4 dv[2][4][RB];
+    sa_layernorm_bwd<RB, NJ>(acc, a.base, a.mean1, a.rstd1, a.ln1_g, sStat2, a.pgrad1 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+    float4 dv[NJ][4][RB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
-                dv[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(a.dx1 + (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl)
+                dv[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(a.dx1 + (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
                 if (tok >= nvalid) continue;
-                const size_t off = (size_t)(m0 + tok) * SA_D + 64 * wave + 32 * j + 8 * g + 4 * hl;
+                const size_t off = (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                 const float4 v = make_float4(acc[j][i][4 * g + 0] + dv[j][g][i].x, acc[j][i][4 * g + 1] + dv[j][g][i].y,
                                              acc[j][i][4 * g + 2] + dv[j][g][i].z, acc[j][i][4 * g + 3] + dv[j][g][i].w);
                 *reinterpret_cast<float4*>(a.dbase + off) = v;
@@ -1040,6 +1066,12 @@ extern "C" int vpf_ln_pgrad_reduce(const VpfPgradJob* jobs, int njobs, void* str
     return VPF_OK;
 }
 
+static int sa_bwd_nj()
+{
+    static int nj = -1;
+    if (nj < 0) { const char* e = getenv("VPF_SA_NJ"); nj = e ? atoi(e) : 1; }
+    return nj;
+}
 static int sa_bwd_check(const VpfSaLayerBwd& a)
 {
     if (a.M <= 0) return VPF_ERR_BADSHAPE;
@@ -1056,14 +1088,16 @@ extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
     if (!a.d || !a.rng || !a.u || !a.x1 || !a.mean2 || !a.rstd2 || !a.ln2_g || !a.W2T || !a.W1T || !a.WoT || !a.dz2 || !a.du || !a.dx1 ||
         !a.dz1 || !a.dout_attn || !a.pgrad2) return VPF_ERR_NULL;
     constexpr int RB = 2, TOK = RB * 32;
-    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 4 * 2 * 4;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
     const int nwg = vpf_cdiv((long)a.M, TOK);
-    hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -1076,14 +1110,16 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     if (rc) return rc;
     if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
     constexpr int RB = 2, TOK = RB * 32;
-    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 4 * 2 * 4;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
     const int nwg = vpf_cdiv((long)a.M, TOK);
-    hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
