@@ -193,14 +193,18 @@ __device__ __forceinline__ void sa_token_sum(float (&part)[RB], float* sStat, fl
     }
 }
 
-// LayerNorm over the channel axis of the values in acc (two-pass: mean, then centred second moment), in place:
-// acc <- (acc - mean) * rstd * gamma + beta.  mean / rstd of every token are returned (all lanes of the token agree).
+// LayerNorm over the channel axis of the values in acc, in place: acc <- (acc - mean) * rstd * gamma + beta.
+// Every wave first reduces ITS channels of a token to (mean, centred second moment) -- two lane^32 shuffles -- and the
+// waves' pairs are merged exactly (Chan et al.): one LDS exchange and one barrier, and no E[x^2] - mean^2 cancellation.
+// mean / rstd of every token are returned (all lanes of the token agree).
 template <int RB, int NJ>
 __device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[NJ][RB], const float* __restrict__ gamma, const float* __restrict__ beta,
                                              float* sStatA, float* sStatB, float (&mean)[RB], float (&rstd)[RB])
 {
+    constexpr int NWV = 8 / NJ, CPW = 32 * NJ;          // waves, channels per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
-    float part[RB];
+    float2* sPair = reinterpret_cast<float2*>(sStatA);   // [TOK][NWV] (mean_w, M2_w); sStatA and sStatB are contiguous
+    (void)sStatB;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         float s = 0.f;
@@ -208,22 +212,30 @@ __device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[NJ][RB], const floa
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += acc[j][i][r];
-        part[i] = s;
-    }
-    sa_token_sum<RB, NJ>(part, sStatA, mean);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        mean[i] *= (1.0f / SA_D);
-        float s = 0.f;
+        s += __shfl_xor(s, 32, 64);
+        const float mw = s * (1.0f / CPW);
+        float q = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float d = acc[j][i][r] - mean[i]; s += d * d; }
-        part[i] = s;
+            for (int r = 0; r < 16; ++r) { const float d = acc[j][i][r] - mw; q += d * d; }
+        q += __shfl_xor(q, 32, 64);
+        if (lane < 32) sPair[(i * 32 + lane) * NWV + wave] = make_float2(mw, q);
     }
-    sa_token_sum<RB, NJ>(part, sStatB, rstd);
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < RB; ++i) rstd[i] = rsqrtf(rstd[i] * (1.0f / SA_D) + 1e-5f);
+    for (int i = 0; i < RB; ++i) {
+        float2 pw[NWV];
+        float ms = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { pw[w] = sPair[(i * 32 + (lane & 31)) * NWV + w]; ms += pw[w].x; }
+        const float mu = ms * (1.0f / NWV);
+        float m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { const float d = pw[w].x - mu; m2 += pw[w].y + (float)CPW * d * d; }
+        mean[i] = mu;
+        rstd[i] = rsqrtf(m2 * (1.0f / SA_D) + 1e-5f);
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
