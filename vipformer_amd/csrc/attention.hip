@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mn = fmaxf(m, tmax);           // finite: every sub-tile has >= 1 valid key
-            const float alpha = exp2f(m - mn);
+            const float alpha = vpf_exp2(m - mn);
             m = mn;
             float ps = 0.f;
             float pv[16];
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    const float pr = exp2f(s[r] - mn);
+                    const float pr = vpf_exp2(s[r] - mn);
                     ps += pr;
                     pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
                 }
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mn = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mn);
+        const float alpha = vpf_exp2(m - mn);
         m = mn;
         float ps = 0.f;
         float pv[16];
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g4 + e;
-                const float pr = exp2f(s[r] - mn);
+                const float pr = vpf_exp2(s[r] - mn);
                 ps += pr;
                 pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
             }
@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
                 const int r = 4 * g4 + e;
                 const int kv = kv0 + e + 8 * g4 + 4 * hl;
                 const bool ok = qok && kv < a.Lkv;
-                const float pr = ok ? exp2f(s[r] * c - lse2) : 0.f;
+                const float pr = ok ? vpf_exp2(s[r] * c - lse2) : 0.f;
                 const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
                 ds[r] = pr * (dp[r] * keep - delta) * a.scale;
             }
@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
                 const int qr = e + 8 * g4 + 4 * hl;
                 const int q = q0 + qr;
                 const bool ok = kvok && q < a.Lq;
-                const float pr = ok ? exp2f(s[r] * c - sL[qr]) : 0.f;
+                const float pr = ok ? vpf_exp2(s[r] * c - sL[qr]) : 0.f;
                 float keep = 1.f;
                 if (drop) {
                     if (quad_ok) {
@@ -768,7 +768,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                     const int r = 4 * g4 + e;
                     const int kv = kv0 + e + 8 * g4 + 4 * hl;
                     const bool ok = qok && kv < L;
-                    const float pr = ok ? exp2f(s[r] * c - lse2) : 0.f;
+                    const float pr = ok ? vpf_exp2(s[r] * c - lse2) : 0.f;
                     const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
                     ds[r] = pr * (dp[r] * keep - delta) * a.scale;
                 }
@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                     const int qr = e + 8 * g4 + 4 * hl;
                     const int qq = q0 + qr;
                     const bool ok = kvok && qq < L;
-                    const float pr = ok ? exp2f(s[r] * c - sL[qq]) : 0.f;
+                    const float pr = ok ? vpf_exp2(s[r] * c - sL[qq]) : 0.f;
                     float keep = 1.f;
                     if (drop) {
                         if (quad_ok) {

@@ -301,7 +301,7 @@ __device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV,
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mn = fmaxf(m, tmax);
-        const float alpha = exp2f(m - mn);
+        const float alpha = vpf_exp2(m - mn);
         m = mn;
         float ps = 0.f;
         float pv[16];
@@ -311,7 +311,7 @@ __device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV,
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g4 + e;
-                const float pr = exp2f(s[r] - mn);
+                const float pr = vpf_exp2(s[r] - mn);
                 ps += pr;
                 pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
             }
@@ -513,6 +513,27 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     // ============================================================ MLP: two 256-wide chunks of the hidden layer
     f32x16_t acc2[NJ][RB];
     sa_zero<RB, NJ>(acc2);
+    // the final epilogue's side inputs (x1, written by this very thread above, and pos): with one channel block per wave there
+    // are registers to fetch them BEHIND the last GEMM unit instead of in front of the epilogue
+    float4 resx[NJ][4][RB], resp[NJ][4][RB];
+    int prow[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) prow[i] = a.pos ? (int)((m0 + i * 32 + t) % a.pos_rows) : 0;
+    auto load_final = [&]() {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    const int tok = i * 32 + t;
+                    const bool ok = tok < nvalid;
+                    const int cch = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
+                    resx[j][g][i] = ok ? *reinterpret_cast<const float4*>(a.x1 + (size_t)(m0 + tok) * SA_D + cch) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    resp[j][g][i] = (ok && a.pos) ? *reinterpret_cast<const float4*>(a.pos + (size_t)prow[i] * SA_D + cch)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+    };
 #pragma unroll
     for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
         sa_zero<RB, NJ>(acc);
@@ -544,9 +565,11 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
         if (hc) __syncthreads();                               // every wave is done reading the previous chunk from actH
         sa_store_bf16<RB, NJ>(acc, actH, 0, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
         __syncthreads();
+        if (NJ == 1 && hc + 1 == SA_HID / SA_D) load_final();
         sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
         if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
     }
+    if (NJ != 1) load_final();
     const bool nxt = a.qkv_next != nullptr;
     if (nxt) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, NJ * wave, wpre);
     SA_STAMP();     // 4: MLP (fc1 + GELU + fc2)
@@ -555,22 +578,6 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     {
         const VpfRng rng = vpf_rng_init(a.rng, a.site_res2, a.p_res2);
         const bool drop = a.p_res2 > 0.f;
-        int prow[RB];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) prow[i] = a.pos ? (int)((m0 + i * 32 + t) % a.pos_rows) : 0;
-        // two batches of loads (x1 written by this very thread above, then pos), each with all its loads in flight together
-        float4 res[NJ][4][RB];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int tok = i * 32 + t;
-                    const bool ok = tok < nvalid;
-                    const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
-                    res[j][g][i] = ok ? *reinterpret_cast<const float4*>(a.x1 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -584,7 +591,8 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                     const int tok = i * 32 + t;
                     const bool ok = tok < nvalid;
                     const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + cch;
-                    const float rr[4] = {res[j][g][i].x, res[j][g][i].y, res[j][g][i].z, res[j][g][i].w};
+                    const float rr[4] = {resx[j][g][i].x + resp[j][g][i].x, resx[j][g][i].y + resp[j][g][i].y,
+                                         resx[j][g][i].z + resp[j][g][i].z, resx[j][g][i].w + resp[j][g][i].w};
                     const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -592,33 +600,9 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                         if (drop) y = ((keep >> q) & 1u) ? y * rng.scale : 0.f;
                         acc2[j][i][4 * g + q] = rr[q] + y;
                     }
+                    if (ok) *reinterpret_cast<float4*>(a.out + off) = make_float4(acc2[j][i][4 * g + 0], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]);
                 }
             }
-        if (a.pos) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int i = 0; i < RB; ++i)
-                        res[j][g][i] = (i * 32 + t < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)prow[i] * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
-                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < RB; ++i) {
-                    const int tok = i * 32 + t;
-                    if (a.pos) {
-                        acc2[j][i][4 * g + 0] += res[j][g][i].x; acc2[j][i][4 * g + 1] += res[j][g][i].y;
-                        acc2[j][i][4 * g + 2] += res[j][g][i].z; acc2[j][i][4 * g + 3] += res[j][g][i].w;
-                    }
-                    if (tok < nvalid)
-                        *reinterpret_cast<float4*>(a.out + (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) =
-                            make_float4(acc2[j][i][4 * g + 0], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]);
-                }
         SA_STAMP();     // 5: final dropout + residual epilogue
         if (!nxt) return;
         float mean[RB], rstd[RB];

@@ -149,7 +149,7 @@ extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
     constexpr int ROW = 64 * (3 + AD_MAXC);
-    int nblk = grid_for(M, 64, 2048);
+    int nblk = grid_for(M, 64, 512);
     if ((long)nblk * ROW > ws_floats) nblk = (int)(ws_floats / ROW);
     if (nblk < 1) return VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(adapter_front_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C,

@@ -196,6 +196,10 @@ __device__ __forceinline__ uint32_t vpf_keep4_at(const VpfRng& r, uint64_t idx0)
     return (vpf_keep(r, idx0) ? 1u : 0u) | (vpf_keep(r, idx0 + 1) ? 2u : 0u) | (vpf_keep(r, idx0 + 2) ? 4u : 0u) | (vpf_keep(r, idx0 + 3) ? 8u : 0u);
 }
 
+// 2^x as ONE v_exp_f32 (no denormal-range rescue sequence: the arguments here are score - max <= 0, where an
+// underflow to 0 is the right answer; exp2f(-inf) = 0 and exp2f(-inf - -inf) is never formed)
+__device__ __forceinline__ float vpf_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // erf with |error| <= 1.5e-7 (Abramowitz & Stegun 7.1.26) from one v_rcp_f32 and one v_exp_f32: the libm erff costs ~4x
 // as many VALU cycles, and GELU runs over every hidden activation of every MLP, forward and backward.
 // Returns erf(z) and exp(-z^2) (the Gaussian factor GELU' needs as well).
