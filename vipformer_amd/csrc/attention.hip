@@ -118,14 +118,14 @@ __device__ __forceinline__ void kv_store(bf16_t* __restrict__ S, const uint4 (&r
 }
 
 // =============================================================================== forward
-#define FWD_KT 64   // kv rows per LDS tile (two 32-row sub-tiles)
 #define FWD_MAXC 3  // ceil(64*8 / 192) chunks per thread at the smallest block (3 waves); 1-wave blocks loop 8x below
-template <int NW>
+// FWD_KT = kv rows per LDS stage (64 = two 32-row sub-tiles; 128 when there are many keys)
+template <int NW, int FWD_KT>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
 {
     constexpr int NT = NW * 64;
     constexpr int MAXC = (FWD_KT * 8 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 2 * FWD_KT * KLD];
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];               // [2 buf][K,V][FWD_KT][KLD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
     const int q = (blockIdx.y * NW + wave) * 32 + (lane & 31);
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
             kv_load<FWD_KT, MAXC>(Vg, a.ldv, a.Lkv, (t + 1) * FWD_KT, rv, NT);
         }
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < FWD_KT / 32; ++sub) {
             const int kv0 = t * FWD_KT + sub * 32;
             if (kv0 >= a.Lkv) break;
             f32x16_t s;
@@ -236,7 +236,18 @@ template <int NW>
 static int launch_fwd(const AttnArgs& a, hipStream_t st)
 {
     dim3 grid(a.B * a.H, vpf_cdiv(a.Lq, 32 * NW));
-    hipLaunchKernelGGL((attn_fwd_kernel<NW>), grid, dim3(NW * 64), 0, st, a);
+    if (a.Lkv >= 256) {
+        constexpr int KT = 128;
+        constexpr size_t lds = sizeof(bf16_t) * 2 * 2 * KT * KLD;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_fwd_kernel<NW, KT>), grid, dim3(NW * 64), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((attn_fwd_kernel<NW, 64>), grid, dim3(NW * 64), sizeof(bf16_t) * 2 * 2 * 64 * KLD, st, a);
+    }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -414,12 +425,13 @@ extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ld
 // Recomputing S and dP in both costs 8 extra MFMAs per 32x32 (q,kv) pair; it buys the absence of any
 // cross-wave reduction, which dominated an earlier single-kernel version (LDS float atomics).
 #define BWD_KT 32
-template <int NW>
+// KT = keys per LDS stage (32 for short sequences; 128 when there are many keys: a barrier and a load latency per stage)
+template <int NW, int KT>
 __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float* __restrict__ delta_out)
 {
     constexpr int NT = NW * 64;
-    constexpr int MAXC = (BWD_KT * 8 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) bf16_t sKV[2 * 2 * BWD_KT * KLD];     // [2 buf][K,V][32][KLD]
+    constexpr int MAXC = (KT * 8 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t sKV[];                  // [2 buf][K,V][KT][KLD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, ql = lane & 31;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
     const int q = (blockIdx.y * NW + wave) * 32 + ql;
@@ -459,54 +471,59 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
 
     uint4 rk[MAXC], rv[MAXC];
-    const int nt = (a.Lkv + BWD_KT - 1) / BWD_KT;
-    kv_load<BWD_KT, MAXC>(Kg, a.ldk, a.Lkv, 0, rk, NT);
-    kv_load<BWD_KT, MAXC>(Vg, a.ldv, a.Lkv, 0, rv, NT);
-    kv_store<BWD_KT, MAXC>(sKV, rk, NT);
-    kv_store<BWD_KT, MAXC>(sKV + BWD_KT * KLD, rv, NT);
+    const int nt = (a.Lkv + KT - 1) / KT;
+    kv_load<KT, MAXC>(Kg, a.ldk, a.Lkv, 0, rk, NT);
+    kv_load<KT, MAXC>(Vg, a.ldv, a.Lkv, 0, rv, NT);
+    kv_store<KT, MAXC>(sKV, rk, NT);
+    kv_store<KT, MAXC>(sKV + KT * KLD, rv, NT);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const bf16_t* sK = sKV + (t & 1) * 2 * BWD_KT * KLD;
-        const bf16_t* sV = sK + BWD_KT * KLD;
-        const int kv0 = t * BWD_KT;
+        const bf16_t* sK = sKV + (t & 1) * 2 * KT * KLD;
+        const bf16_t* sV = sK + KT * KLD;
+        const int kv0 = t * KT;
         if (t + 1 < nt) {
-            kv_load<BWD_KT, MAXC>(Kg, a.ldk, a.Lkv, (t + 1) * BWD_KT, rk, NT);
-            kv_load<BWD_KT, MAXC>(Vg, a.ldv, a.Lkv, (t + 1) * BWD_KT, rv, NT);
+            kv_load<KT, MAXC>(Kg, a.ldk, a.Lkv, (t + 1) * KT, rk, NT);
+            kv_load<KT, MAXC>(Vg, a.ldv, a.Lkv, (t + 1) * KT, rv, NT);
         }
-        f32x16_t s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int sub = 0; sub < KT / 32; ++sub) {
+            const int kvs = kv0 + sub * 32;
+            if (kvs >= a.Lkv) break;
+            f32x16_t s, dp;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, 0, ks * 16), qf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sV, KLD, 0, ks * 16), dof[ks], dp, 0, 0, 0);
-        }
-        float ds[16];
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const uint32_t kbits = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, sub * 32, ks * 16), qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sV, KLD, sub * 32, ks * 16), dof[ks], dp, 0, 0, 0);
+            }
+            float ds[16];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g4 + e;
-                const int kv = kv0 + e + 8 * g4 + 4 * hl;
-                const bool ok = qok && kv < a.Lkv;
-                const float pr = ok ? vpf_exp2(s[r] * c - lse2) : 0.f;
-                const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
-                ds[r] = pr * (dp[r] * keep - delta) * a.scale;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint32_t kbits = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kvs + 8 * g4 + 4 * hl)) : 15u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const int kv = kvs + e + 8 * g4 + 4 * hl;
+                    const bool ok = qok && kv < a.Lkv;
+                    const float pr = ok ? vpf_exp2(s[r] * c - lse2) : 0.f;
+                    const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
+                    ds[r] = pr * (dp[r] * keep - delta) * a.scale;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t dsf = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, sub * 32 + 16 * s2, dt * 32), dsf, dq[dt], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8_t dsf = pack8(ds + 8 * s2);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, 16 * s2, dt * 32), dsf, dq[dt], 0, 0, 0);
-        }
         if (t + 1 < nt) {
-            bf16_t* nK = sKV + ((t + 1) & 1) * 2 * BWD_KT * KLD;
-            kv_store<BWD_KT, MAXC>(nK, rk, NT);
-            kv_store<BWD_KT, MAXC>(nK + BWD_KT * KLD, rv, NT);
+            bf16_t* nK = sKV + ((t + 1) & 1) * 2 * KT * KLD;
+            kv_store<KT, MAXC>(nK, rk, NT);
+            kv_store<KT, MAXC>(nK + KT * KLD, rv, NT);
         }
         __syncthreads();
     }
@@ -892,11 +909,157 @@ static int launch_res_bwd(const AttnArgs& a, float* delta, hipStream_t st)
     return VPF_OK;
 }
 
+// dK / dV when the QUERY side is short (cross-attention: 96 latents against 1024 points): the head's whole Q and dO tiles,
+// lse and delta are staged in one round of loads; a wave owns 32 keys (K / V fragments in registers) and walks the
+// resident queries without barriers.  The tiled kernel above re-stages 32 queries per step behind a barrier.
+template <int NW, int QB>
+__global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, const float* __restrict__ delta_in)
+{
+    constexpr int NT = NW * 64, QPT = QB * 32;
+    constexpr int NCH = 2 * QPT * 8, CPT = (NCH + NT - 1) / NT;
+    __shared__ __attribute__((aligned(16))) bf16_t sQD[2 * QPT * KLD];
+    __shared__ float sL[QPT], sDel[QPT];
+    bf16_t* sQ = sQD;
+    bf16_t* sD = sQD + QPT * KLD;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, kl = lane & 31;
+    const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+    const int kv = (blockIdx.y * NW + wave) * 32 + kl;
+    const bool kvok = kv < a.Lkv;
+    {
+        uint4 rr[CPT];
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % QPT, which = (e >> 3) / QPT;
+            rr[it] = make_uint4(0, 0, 0, 0);
+            if (e < NCH && row < a.Lq) {
+                const size_t gr = (size_t)b * a.Lq + row;
+                const bf16_t* src = which == 0 ? a.Q + gr * a.ldq : a.dO + gr * a.lddo;
+                rr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
+            }
+        }
+        for (int qq = threadIdx.x; qq < QPT; qq += NT) {
+            sL[qq] = qq < a.Lq ? a.LSE[(size_t)bh * a.Lq + qq] * LOG2E : 0.f;
+            sDel[qq] = qq < a.Lq ? delta_in[(size_t)bh * a.Lq + qq] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % QPT, which = (e >> 3) / QPT;
+            if (e < NCH) *reinterpret_cast<uint4*>(sQD + (which * QPT + row) * KLD + ch * 8) = rr[it];
+        }
+    }
+    bf16x8_t kf[4], vf[4];
+    {
+        const size_t row = (size_t)b * a.Lkv + (kvok ? kv : 0);
+        const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+        const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, kvok));
+            vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, kvok));
+        }
+    }
+    __syncthreads();
+    const float c = a.scale * LOG2E;
+    const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
+    const bool drop = a.p > 0.f;
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
+    const bool quad_ok = (a.Lkv & 3) == 0;
+#pragma unroll
+    for (int q0 = 0; q0 < QPT; q0 += 32) {
+        if (q0 >= a.Lq) break;
+        f32x16_t s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp, 0, 0, 0);
+        }
+        float pd[16], ds[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            uint2 grp = make_uint2(0u, 0u);
+            if (drop && quad_ok) {
+                const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
+                grp = vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
+            }
+            uint32_t gw[4];
+            {
+                const uint32_t mine = (lane & 2) ? 1u : 0u;
+                const uint32_t x0 = quad_bcast<0>(grp.x), x1 = quad_bcast<1>(grp.x), x2 = quad_bcast<2>(grp.x), x3 = quad_bcast<3>(grp.x);
+                const uint32_t y0 = quad_bcast<0>(grp.y), y1 = quad_bcast<1>(grp.y), y2 = quad_bcast<2>(grp.y), y3 = quad_bcast<3>(grp.y);
+                gw[0] = mine ? y0 : x0; gw[1] = mine ? y1 : x1; gw[2] = mine ? y2 : x2; gw[3] = mine ? y3 : x3;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g4 + e;
+                const int qq = q0 + e + 8 * g4 + 4 * hl;
+                const bool ok = kvok && qq < a.Lq;
+                const float pr = ok ? vpf_exp2(s[r] * c - sL[qq]) : 0.f;
+                float keep = 1.f;
+                if (drop) {
+                    if (quad_ok) {
+                        const uint32_t word = gw[e];
+                        keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                    } else {
+                        keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
+                    }
+                }
+                pd[r] = pr * keep;
+                ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (kvok) {
+        bf16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
+        bf16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                uint2 u, w;
+                u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
+                *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
+            }
+    }
+}
+
 template <int NWQ, int NWK>
 static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
 {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), 0, st, a, delta);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<NWK>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
+    if (a.Lkv >= 256) {
+        constexpr int KT = 128;
+        constexpr size_t lds = sizeof(bf16_t) * 2 * 2 * KT * KLD;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NWQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+            attr = true;
+        }
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ, KT>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), lds, st, a, delta);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ, 32>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), sizeof(bf16_t) * 2 * 2 * 32 * KLD, st, a, delta);
+    }
+    static int res = -1;
+    if (res < 0) { const char* e = getenv("VPF_ATTN_RESIDENT"); res = e ? atoi(e) : 1; }
+    if (res && a.Lq <= 96 && NWK == 4)
+        hipLaunchKernelGGL((attn_bwd_dkv_resq_kernel<NWK, 3>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
+    else if (res && a.Lq <= 128 && NWK == 4)
+        hipLaunchKernelGGL((attn_bwd_dkv_resq_kernel<NWK, 4>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
+    else
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<NWK>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
