@@ -104,6 +104,24 @@ def sa():
     ops.SA_SPLIT_ATTN[0] = None
 
 
+def wgroup():
+    """the grouped weight-gradient launch of one encoder layer (4 problems, M = 12288 tokens)"""
+    from vipformer_amd import ops
+    M = 12288
+    shapes = [(256, 512), (512, 256), (256, 256), (768, 256)]
+    ts = []
+    for (N, K) in shapes:
+        ts.append((torch.randn(M, N, device="cuda").bfloat16(), torch.randn(M, K, device="cuda").bfloat16(), N, K,
+                   torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")))
+    def run():
+        wg = ops.WgradBatch()
+        for dy, x, N, K, dW, db in ts: wg.add(dy, x, N, K, dW, db)
+        wg.flush()
+    t = timeit(run, 100, 5)
+    fl = sum(2.0 * M * N * K for _, _, N, K, _, _ in ts)
+    print(f"wgrad group (4 problems, M={M}): {t:.1f} us ({fl/t/1e6:.0f} TF/s)")
+
+
 def g2e():
     """Group2Emb forward/backward at the benchmark size + per-phase cycle stamps of the fused backward."""
     from vipformer_amd import ops

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvipformer_hip.so")
+LIB_PATH = os.environ.get("VPF_LIB", os.path.join(_HERE, "libvipformer_hip.so"))
 _lib = None
 
 VP = ctypes.c_void_p

@@ -23,7 +23,10 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-#define LDS_PAD 8   // bf16 elements (16 B) of row padding
+#ifndef LDS_PAD_TR
+#define LDS_PAD_TR 8
+#endif
+#define LDS_PAD 8   // bf16 elements (16 B) of row padding (K-major tiles); LDS_PAD_TR for K-strided tiles
 
 enum {
     EPI_STORE = 0,       // C = acc (+bias)            -> bf16 or f32
@@ -72,7 +75,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) { return vpf_gelu_grad(x);
 // K-major operand tile: LDS [ROWS][BK + pad]; K-strided operand tile: LDS [BK][ROWS + pad].
 template <int ROWS, bool TR, int BK>
 struct TileCfg {
-    static constexpr int LD = TR ? (ROWS + LDS_PAD) : (BK + LDS_PAD);
+    static constexpr int LD = TR ? (ROWS + LDS_PAD_TR) : (BK + LDS_PAD);
     static constexpr int ELEMS = TR ? BK * LD : ROWS * LD;
     static constexpr int CHUNKS = ROWS * BK / 8;          // 16-byte chunks per tile
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
@@ -184,7 +187,7 @@ __device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int 
 }
 
 // ------------------------------------------------------------------ kernel
-template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
+template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX, int PF = 1>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -216,51 +219,63 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[ACfg::PER_THREAD], rb[BCfg::PER_THREAD];
-    tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg, kend, ra, g.xa);
-    tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg, kend, rb, g.xb);
-    tile_store<BM, ATR, BK>(lds, ra);
-    tile_store<BN, BTR, BK>(lds + ACfg::ELEMS, rb);
+    // PF register sets = PF K-stages of global loads in flight per thread (Little's law: at ~2 us of load latency one stage in
+    // flight per workgroup cannot keep the memory system busy; PF is chosen so that the VGPR count keeps the occupancy)
+    uint4 ra[PF][ACfg::PER_THREAD], rb[PF][BCfg::PER_THREAD];
+    const int nk = (kend - kbeg + BK - 1) / BK;
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (p < nk) {
+            tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg + p * BK, kend, ra[p], g.xa);
+            tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg + p * BK, kend, rb[p], g.xb);
+        }
+    tile_store<BM, ATR, BK>(lds, ra[0]);
+    tile_store<BN, BTR, BK>(lds + ACfg::ELEMS, rb[0]);
     __syncthreads();
 
     // fused bias gradient (wgrad): the first column of workgroups also sums its dY tiles over the tokens
     const bool do_bias = ATR && g.dbias != nullptr && bx == 0;
     float bsum = 0.f;
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bf16_t* cA = lds + cur * STAGE;
-        const bf16_t* cB = cA + ACfg::ELEMS;
-        bf16_t* nA = lds + (cur ^ 1) * STAGE;
-        bf16_t* nB = nA + ACfg::ELEMS;
-        if (kt + 1 < nk) {
-            tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg + (kt + 1) * BK, kend, ra, g.xa);
-            tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + 1) * BK, kend, rb, g.xb);
+    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int kt = kt0 + p;
+            if (kt >= nk) break;
+            const int cur = kt & 1;
+            const bf16_t* cA = lds + cur * STAGE;
+            const bf16_t* cB = cA + ACfg::ELEMS;
+            bf16_t* nA = lds + (cur ^ 1) * STAGE;
+            bf16_t* nB = nA + ACfg::ELEMS;
+            // register set p held stage kt, which is in LDS by now: refill it with stage kt + PF
+            if (kt + PF < nk) {
+                tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg + (kt + PF) * BK, kend, ra[p], g.xa);
+                tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + PF) * BK, kend, rb[p], g.xb);
+            }
+            if (ATR && do_bias) {
+                constexpr int RG = 256 / BM > 0 ? 256 / BM : 1;                 // row groups (BM <= 256)
+                const int c = threadIdx.x % BM, rg = threadIdx.x / BM;
+                if (rg < RG)
+                    for (int r = rg; r < BK; r += RG) bsum += bf16_to_f32(cA[r * ACfg::LD + c]);
+            }
+#pragma unroll
+            for (int s = 0; s < BK / 16; ++s) {
+                bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, s);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR, BK>(cB, (wn * TN + j) * 32, s);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) {
+                tile_store<BM, ATR, BK>(nA, ra[(p + 1) % PF]);
+                tile_store<BN, BTR, BK>(nB, rb[(p + 1) % PF]);
+            }
+            __syncthreads();
         }
-        if (ATR && do_bias) {
-            constexpr int RG = 256 / BM > 0 ? 256 / BM : 1;                 // row groups (BM <= 256)
-            const int c = threadIdx.x % BM, rg = threadIdx.x / BM;
-            if (rg < RG)
-                for (int r = rg; r < BK; r += RG) bsum += bf16_to_f32(cA[r * ACfg::LD + c]);
-        }
-#pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            bf16x8_t fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, s);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR, BK>(cB, (wn * TN + j) * 32, s);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            tile_store<BM, ATR, BK>(nA, ra);
-            tile_store<BN, BTR, BK>(nB, rb);
-        }
-        __syncthreads();
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -388,34 +403,52 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 {
-    gemm_tile<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.splitk > 1 && (g.splitk & 7) == 0) {
+        // split-K: give the tiles of one K slice ids that are congruent mod 8 (same XCD, same L2), see gemm_wgrad_group_kernel
+        const int nx = gridDim.x, ny = gridDim.y;
+        const int id = bx + nx * (by + ny * bz);
+        const int x = id & 7, u = id >> 3, tile = u % (nx * ny), zg = u / (nx * ny);
+        bz = zg * 8 + x; bx = tile % nx; by = tile / nx;
+    }
+    gemm_tile<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>(g, bx, by, bz);
 }
 
 // Several independent split-K weight-gradient GEMMs in ONE launch (the four of a transformer layer): each of them alone
 // is a few hundred short workgroups whose ramp-up and tail dominate; together they fill the chip.
 #define GEMM_GROUP_MAX 8
 struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; int nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n; };
-template <int TM, int TN, int WM, int WN, int BK>
+template <int TM, int TN, int WM, int WN, int BK, int PF>
 __global__ void __launch_bounds__(256) gemm_wgrad_group_kernel(GemmGroup grp)
 {
     int p = 0;
     while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
     const int local = blockIdx.x - grp.start[p];
-    const int nx = grp.nx[p], ny = grp.ny[p];
-    gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0>(grp.g[p], local % nx, (local / nx) % ny, local / (nx * ny));
+    const int nx = grp.nx[p], ny = grp.ny[p], sk = grp.g[p].splitk;
+    int bx, by, bz;
+    if ((sk & 7) == 0 && (grp.start[p] & 7) == 0) {
+        // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All output tiles
+        // of one token slice read the same dY / X rows, so a slice's tiles are given ids that are congruent mod 8: the
+        // slice's operands are fetched from HBM once per XCD instead of once per tile.
+        const int x = local & 7, u = local >> 3, tile = u % (nx * ny), zg = u / (nx * ny);
+        bz = zg * 8 + x; bx = tile % nx; by = tile / nx;
+    } else {
+        bx = local % nx; by = (local / nx) % ny; bz = local / (nx * ny);
+    }
+    gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0, PF>(grp.g[p], bx, by, bz);
 }
-template <int TM, int TN, int WM, int WN, int BK>
+template <int TM, int TN, int WM, int WN, int BK, int PF = 1>
 static int launch_wgrad_group(const GemmGroup& grp, int nblocks, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS);
     static bool attr = false;
     if (!attr) {
-        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<TM, TN, WM, WN, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<TM, TN, WM, WN, BK, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_wgrad_group_kernel<TM, TN, WM, WN, BK>), dim3(nblocks), dim3(256), lds, st, grp);
+    hipLaunchKernelGGL((gemm_wgrad_group_kernel<TM, TN, WM, WN, BK, PF>), dim3(nblocks), dim3(256), lds, st, grp);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -562,7 +595,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
     grp.n = njobs;
     static int cfg = -1, target = 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     if (cfg < 0) { const char* e = getenv("VPF_WGROUP_CFG"); cfg = e ? atoi(e) : 2; const char* t = getenv("VPF_WGROUP_WGS"); if (t) target = atoi(t); }
-    const int tm = cfg == 0 ? 64 : 128, tn = cfg >= 3 ? 256 : (cfg == 2 ? 128 : 64);
+    const int tm = cfg == 0 ? 64 : 128, tn = (cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64);
     long total_tiles = 0;
     for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
     int at = 0;
@@ -587,6 +620,9 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
     }
     grp.start[njobs] = at;
     hipStream_t st = (hipStream_t)stream;
+    if (cfg == 7) return launch_wgrad_group<2, 2, 2, 2, 64, 3>(grp, at, st);  // 3 stages of loads in flight
+    if (cfg == 6) return launch_wgrad_group<2, 2, 2, 2, 64, 2>(grp, at, st);  // 2 stages of loads in flight
+    if (cfg == 5) return launch_wgrad_group<2, 2, 2, 2, 32>(grp, at, st);     // 128x128, shallow stages: 4 workgroups per CU
     if (cfg == 4) return launch_wgrad_group<2, 4, 2, 2, 64>(grp, at, st);     // wave tile 64x128: half the LDS fragment reads per MFMA
     if (cfg == 3) return launch_wgrad_group<2, 4, 2, 2, 32>(grp, at, st);
     if (cfg == 2) return launch_wgrad_group<2, 2, 2, 2, 64>(grp, at, st);

@@ -123,10 +123,12 @@ __global__ void __launch_bounds__(1024) adapter_front_fold_kernel(const float* _
     __shared__ float fold[16][64];
     constexpr int ROW = 64 * (3 + AD_MAXC);
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;       // column of the partial row
+    // gridDim.y row slices (a handful of atomics per output instead of one block per column walking every row)
+    const int per = (nblk + gridDim.y - 1) / gridDim.y, rbeg = blockIdx.y * per, rend = min(nblk, rbeg + per);
     float s0 = 0.f, s1 = 0.f;
-    int r = rg;
-    for (; r + 16 < nblk; r += 32) { s0 += partial[(size_t)r * ROW + e]; s1 += partial[(size_t)(r + 16) * ROW + e]; }
-    for (; r < nblk; r += 16) s0 += partial[(size_t)r * ROW + e];
+    int r = rbeg + rg;
+    for (; r + 16 < rend; r += 32) { s0 += partial[(size_t)r * ROW + e]; s1 += partial[(size_t)(r + 16) * ROW + e]; }
+    for (; r < rend; r += 16) s0 += partial[(size_t)r * ROW + e];
     fold[rg][threadIdx.x & 63] = s0 + s1;
     __syncthreads();
     if (rg == 0) {
@@ -134,10 +136,10 @@ __global__ void __launch_bounds__(1024) adapter_front_fold_kernel(const float* _
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += fold[k][threadIdx.x];
         const int lane = e & 63, grp = e >> 6;
-        if (grp == 0) db[lane] += t;
-        else if (grp == 1) dgamma[lane] += t;
-        else if (grp == 2) dbeta[lane] += t;
-        else if (grp - 3 < C) dW[lane * C + (grp - 3)] += t;
+        if (grp == 0) atomicAdd(db + lane, t);
+        else if (grp == 1) atomicAdd(dgamma + lane, t);
+        else if (grp == 2) atomicAdd(dbeta + lane, t);
+        else if (grp - 3 < C) atomicAdd(dW + lane * C + (grp - 3), t);
     }
 }
 extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b,
@@ -149,12 +151,12 @@ extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
     constexpr int ROW = 64 * (3 + AD_MAXC);
-    int nblk = grid_for(M, 64, 512);
+    int nblk = grid_for(M, 64, 2048);
     if ((long)nblk * ROW > ws_floats) nblk = (int)(ws_floats / ROW);
     if (nblk < 1) return VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(adapter_front_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C,
                        W, b, gamma, beta, ws);
-    hipLaunchKernelGGL(adapter_front_fold_kernel, dim3(3 + AD_MAXC), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dW, db, dgamma, dbeta);
+    hipLaunchKernelGGL(adapter_front_fold_kernel, dim3(3 + AD_MAXC, 8), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
