@@ -410,6 +410,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
         const int id = bx + nx * (by + ny * bz);
         const int x = id & 7, u = id >> 3, tile = u % (nx * ny), zg = u / (nx * ny);
         bz = zg * 8 + x; bx = tile % nx; by = tile / nx;
+    } else if (g.splitk <= 1 && gridDim.z == 1 && gridDim.x > 1 && (gridDim.y & 7) == 0) {
+        // the column tiles of one row tile read the same A rows: keep them on one XCD (ids congruent mod 8)
+        const int nx = gridDim.x;
+        const int id = bx + nx * by;
+        by = (id & 7) + 8 * (id / (8 * nx)); bx = (id >> 3) % nx;
     }
     gemm_tile<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>(g, bx, by, bz);
 }
