@@ -334,7 +334,19 @@ int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);
 typedef struct VpfPgradJob { const float* partials; int rows; int pad_; float* dgamma; float* dbeta; } VpfPgradJob;
 #define VPF_PGRAD_MAX_JOBS 32
 int vpf_ln_pgrad_reduce(const VpfPgradJob* host_jobs, int njobs, void* stream);
-/* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3), sizeof(VpfPgradJob) vpf_abi_sizeof(4) */
+/* PointCloudInputAdapter.point_mlp (classifier.py:31-36) + the cross-attention kv LayerNorm and K / V projections
+ * (partseg.py:48-51,100-116) in one kernel, 64 points per workgroup, D = 256.  x f32 [M,C<=8]; W1 f32 [64,C];
+ * W2 = vpf_pack_wfrag of the bf16 [D,64] weight; Wkv = vpf_pack_wfrag of the bf16 [2D,D] k|v weights.
+ * Outputs (all also needed by the backward pass): a1 bf16 [M,64] (hidden layer), xkv bf16 [M,D] (the per-point
+ * embedding), mean / rstd f32 [M] and nk bf16 [M,D] (kv LayerNorm), kv bf16 [M,2D]. */
+typedef struct VpfAdapterKv {
+    long M; int C, D;
+    const float* x; const float* W1; const float* b1; const float* ln_g; const float* ln_b;
+    const void* W2; const float* b2; const float* lnkv_g; const float* lnkv_b; const void* Wkv;
+    void* a1; void* xkv; float* mean; float* rstd; void* nk; void* kv;
+} VpfAdapterKv;
+int vpf_adapter_kv_fwd(const VpfAdapterKv* host_args, void* stream);
+/* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3), sizeof(VpfPgradJob) vpf_abi_sizeof(4), sizeof(VpfAdapterKv) vpf_abi_sizeof(5) */
 /* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1) / sizeof(VpfWgradJob) (2): lets a binding verify its struct layout */
 int vpf_abi_sizeof(int which);
 

@@ -451,6 +451,7 @@ def test_fused_sa_stack_matches_unfused_blocks():
         tr = Pretrainer(pc, im)
         tr.overlap = False
         ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = fused, fused_bwd, split, enc
+        ops.ADAPTER_KV_FUSED[0] = enc
         with forced_start(start):
             feats_pc = pc(torch.cat([t1, t2]))[1].detach().clone()        # backbone features (before the BatchNorm head)
             ops.rng.state("cuda")[2] = 0
@@ -460,12 +461,13 @@ def test_fused_sa_stack_matches_unfused_blocks():
         g = {("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters() if k not in zero_grad}
         results.append((float(losses[0]), feats_pc, g))
     ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = True, True, None, True
+    ops.ADAPTER_KV_FUSED[0] = True
     ops.clear_managed_shadows()
     l0, f0, g0 = results[0]
     allg0 = torch.cat([v.reshape(-1) for v in g0.values()])
     C = Checks("fused_sa_stack")
     for (l1, f1, g1), (fused, fused_bwd, split, enc) in zip(results[1:], variants[1:]):
-        tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}{', CA tail fused' if enc else ''}]"
+        tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}{', CA tail + adapter/kv fused' if enc else ''}]"
         C.lt(tag + " pc backbone feats rel", rel(f1, f0), 2e-2)
         C.lt(tag + " loss rel", abs(l1 - l0) / abs(l0), 2e-2)
         allg1 = torch.cat([g1[k].reshape(-1) for k in g0])

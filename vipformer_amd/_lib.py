@@ -120,6 +120,7 @@ SIGS = {
     "vpf_sa_layer_bwd_mlp": [VP, VP],
     "vpf_sa_layer_bwd_qkv": [VP, VP],
     "vpf_ln_pgrad_reduce": [VP, I, VP],
+    "vpf_adapter_kv_fwd": [VP, VP],
 }
 
 
@@ -155,6 +156,13 @@ class SaLayerFwd(ctypes.Structure):
 class PgradJob(ctypes.Structure):
     """struct VpfPgradJob (include/vipformer_hip.h)."""
     _fields_ = [("partials", VP), ("rows", I), ("pad_", I), ("dgamma", VP), ("dbeta", VP)]
+
+
+class AdapterKv(ctypes.Structure):
+    """struct VpfAdapterKv (include/vipformer_hip.h)."""
+    _fields_ = [("M", L_), ("C", I), ("D", I), ("x", VP), ("W1", VP), ("b1", VP), ("ln_g", VP), ("ln_b", VP),
+                ("W2", VP), ("b2", VP), ("lnkv_g", VP), ("lnkv_b", VP), ("Wkv", VP),
+                ("a1", VP), ("xkv", VP), ("mean", VP), ("rstd", VP), ("nk", VP), ("kv", VP)]
 
 
 class SaLayerBwd(ctypes.Structure):

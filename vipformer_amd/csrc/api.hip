@@ -29,6 +29,7 @@ extern "C" int vpf_abi_sizeof(int which)
         case 2: return (int)sizeof(VpfWgradJob);
         case 3: return (int)sizeof(VpfSaLayerBwd);
         case 4: return (int)sizeof(VpfPgradJob);
+        case 5: return (int)sizeof(VpfAdapterKv);
         default: return -1;
     }
 }

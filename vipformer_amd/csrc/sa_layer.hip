@@ -1119,3 +1119,154 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
+
+// ================================================================================================ cross-attention K / V producer
+// PointCloudInputAdapter.point_mlp (classifier.py:31-36: Linear(C,64) -> LayerNorm(64) -> ReLU -> Linear(64,D)), the
+// cross-attention kv LayerNorm (partseg.py:100-116) and the bias-free K / V projections (partseg.py:48-51) for 64 points
+// per workgroup in ONE kernel: the per-point embedding [B*N, D] -- the largest activation of the step -- goes from the
+// 64-wide hidden layer to K / V through LDS and registers.  It is still written once (bf16, with the hidden layer and the
+// normalised rows) because the backward pass reads it, but it is never read back in the forward pass.
+template <int NJ>
+__global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapterKv a)
+{
+    constexpr int RB = 2, TOK = RB * 32, NT = 64 * (8 / NJ), NWV = 8 / NJ, A1LD = 72;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* sA1 = lds;                                  // [TOK][A1LD]  hidden layer (bf16)
+    bf16_t* actA = lds + TOK * A1LD;                    // [TOK][ALD]   normalised per-point embedding
+    float* sStat = reinterpret_cast<float*>(actA + TOK * ALD);      // [TOK][NWV] float2
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    const long M = a.M, m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, M - m0);
+    const int C = a.C;
+
+    SaWPre<NJ> wpre;
+    sa_wprefetch((const bf16_t*)a.Wkv, SA_D / 16, 0, NJ * wave, wpre);
+    // ---- hidden layer: thread = (token, 8 of the 64 channels); LayerNorm over the token's 8 threads (lanes ^1 ^2 ^4)
+    for (int e = threadIdx.x; e < TOK * 8; e += NT) {
+        const int tok = e >> 3, cg = (e & 7) * 8;
+        const bool ok = tok < nvalid;
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = (ok && j < C) ? a.x[(size_t)(m0 + tok) * C + j] : 0.f;
+        float h[8], s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = a.b1[cg + k];
+            for (int j = 0; j < C; ++j) v += a.W1[(cg + k) * C + j] * xv[j];
+            h[k] = v; s += v;
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mu = s * (1.f / 64.f);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { h[k] -= mu; q += h[k] * h[k]; }
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        const float rs = rsqrtf(q * (1.f / 64.f) + 1e-5f);
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float lo = fmaxf(h[2 * k] * rs * a.ln_g[cg + 2 * k] + a.ln_b[cg + 2 * k], 0.f);
+            const float hi = fmaxf(h[2 * k + 1] * rs * a.ln_g[cg + 2 * k + 1] + a.ln_b[cg + 2 * k + 1], 0.f);
+            w[k] = pack_bf16x2(lo, hi);
+        }
+        const uint4 v4 = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4*>(sA1 + tok * A1LD + cg) = v4;
+        if (ok) *reinterpret_cast<uint4*>((bf16_t*)a.a1 + (size_t)(m0 + tok) * 64 + cg) = v4;
+    }
+    __syncthreads();
+    // ---- per-point embedding = hidden . W2^T + b2 (K = 64), rounded to bf16 as the unfused path stores it, then kv LayerNorm
+    f32x16_t acc[NJ][RB];
+    sa_zero<RB, NJ>(acc);
+    {
+        const uint4* w0 = reinterpret_cast<const uint4*>(a.W2) + ((size_t)(NJ * wave) * 4) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t af[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) af[j] = __builtin_bit_cast(bf16x8_t, w0[((size_t)j * 4 + ks) * 64]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const bf16x8_t x = sa_frag_row(sA1, A1LD, i * 32, ks * 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], x, acc[j][i], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
+            const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + c);
+            const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                uint2 u;
+                u.x = pack_bf16x2(acc[j][i][4 * g + 0] + bb[0], acc[j][i][4 * g + 1] + bb[1]);
+                u.y = pack_bf16x2(acc[j][i][4 * g + 2] + bb[2], acc[j][i][4 * g + 3] + bb[3]);
+                const int tok = i * 32 + t;
+                if (tok < nvalid) *reinterpret_cast<uint2*>((bf16_t*)a.xkv + (size_t)(m0 + tok) * SA_D + c) = u;
+                acc[j][i][4 * g + 0] = __uint_as_float(u.x << 16); acc[j][i][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
+                acc[j][i][4 * g + 2] = __uint_as_float(u.y << 16); acc[j][i][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
+            }
+        }
+    float mean[RB], rstd[RB];
+    sa_layernorm<RB, NJ>(acc, a.lnkv_g, a.lnkv_b, sStat, sStat, mean, rstd);
+    if (wave == 0 && hl == 0) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (i * 32 + t < nvalid) { a.mean[m0 + i * 32 + t] = mean[i]; a.rstd[m0 + i * 32 + t] = rstd[i]; }
+    }
+    sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.nk, SA_D, 0, m0, nvalid);
+    __syncthreads();
+    // ---- K | V = normalised . Wkv^T   (two 256-channel halves; results held and stored after the last MFMA)
+    uint2 held[2][NJ][RB][4];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        sa_zero<RB, NJ>(acc);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wkv, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
+        if (part == 0) sa_wprefetch((const bf16_t*)a.Wkv, SA_D / 16, 0, 8 + NJ * wave, wpre);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    held[part][j][i][g].x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
+                    held[part][j][i][g].y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                }
+    }
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int tok = i * 32 + t;
+                    if (tok < nvalid)
+                        *reinterpret_cast<uint2*>((bf16_t*)a.kv + (size_t)(m0 + tok) * (2 * SA_D) + part * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) = held[part][j][i][g];
+                }
+}
+
+extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfAdapterKv& a = *args;
+    if (!a.x || !a.W1 || !a.b1 || !a.ln_g || !a.ln_b || !a.W2 || !a.b2 || !a.lnkv_g || !a.lnkv_b || !a.Wkv || !a.a1 || !a.xkv || !a.mean ||
+        !a.rstd || !a.nk || !a.kv) return VPF_ERR_NULL;
+    if (a.M <= 0 || a.C <= 0 || a.C > 8) return VPF_ERR_BADSHAPE;
+    if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
+    constexpr int TOK = 64;
+    const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)adapter_kv_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((adapter_kv_fwd_kernel<1>), dim3(vpf_cdiv(a.M, (long)TOK)), dim3(512), lds, (hipStream_t)stream, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}

@@ -244,15 +244,22 @@ class Encoder(nn.Module):
                                                      mlp_drop=mlp_drop))
         self.modal_prior = modal_prior
 
-    def forward(self, group_embs, pos_embs, pts_embs, layer_idx=[], pad_mask=None):
+    def fused_ok(self, group_embs, pts_embs, layer_idx=(), pad_mask=None):
+        return (self.num_cross_attention_layers == 1 and not layer_idx and pad_mask is None
+                and ops.encoder_fused_supported(self.cross_attn_1, self.sa_layers, group_embs, pts_embs))
+
+    def forward(self, group_embs, pos_embs, pts_embs, layer_idx=[], pad_mask=None, kv_ready=False):
+        """kv_ready (not in the reference signature, default off): pts_embs already holds the cross-attention K | V
+        projections produced by ops.AdapterKVFn."""
         feats = []
-        if (self.num_cross_attention_layers == 1 and not layer_idx and pad_mask is None
-                and ops.encoder_fused_supported(self.cross_attn_1, self.sa_layers, group_embs, pts_embs)):
+        if self.fused_ok(group_embs, pts_embs, layer_idx, pad_mask):
             # fused row-block kernels for the cross-attention layer's tail and every self-attention layer
             mods = [self.cross_attn_1] + list(self.sa_layers)
             params = [p for m in mods for p in m.parameters()]
-            x = ops.EncoderFusedFn.apply(group_embs, pos_embs, pts_embs, self.cross_attn_1, self.sa_layers, self.training, *params)
+            x = ops.EncoderFusedFn.apply(group_embs, pos_embs, pts_embs, self.cross_attn_1, self.sa_layers, self.training, kv_ready, *params)
             return x if self.modal_prior else feats
+        if kv_ready:
+            raise L.VpfError("kv_ready needs the fused encoder path")
         x = self.cross_attn_1(group_embs, pts_embs, pad_mask, pos=pos_embs)
         if (self.num_cross_attention_layers == 1 and not layer_idx and pad_mask is None
                 and ops.sa_stack_supported(self.sa_layers, x)):
@@ -313,11 +320,25 @@ class CrossFormer_pc_mp(nn.Module):
         self.latent_head = _latent_head(num_latent_channels)
 
     def backbone(self, pts):
-        pts_embs = self.input_adapter(pts)
+        enc = self.encoder
+        fuse_kv = (ops.adapter_kv_supported(self.input_adapter, pts) and enc.num_cross_attention_layers == 1 and pts.is_cuda
+                   and ops.SA_FUSED[0] and ops.ENC_FUSED[0] and self.training == enc.training)
+        if not fuse_kv:
+            pts_embs = self.input_adapter(pts)
         neighborhood, center = divide_patches(pts, self.num_groups, self.group_size)
         group_embs = self.group2emb(neighborhood)
         pos_embs = ops.PosMLPFn.apply(center, self.position_emb, *self.position_emb.parameters())
-        x = self.encoder(group_embs, pos_embs, pts_embs)
+        if fuse_kv:
+            cross = enc.cross_attn_1[0].module
+            probe = group_embs.new_empty((group_embs.shape[0], 1, 2 * group_embs.shape[2]))       # shape probe only
+            if enc.fused_ok(group_embs, probe):
+                # adapter -> kv LayerNorm -> K / V projection in one kernel: the per-point embedding is never read back
+                params = list(self.input_adapter.parameters()) + list(cross.kv_norm.parameters()) + [cross.attention.k_proj.weight, cross.attention.v_proj.weight]
+                kv = ops.AdapterKVFn.apply(pts, self.input_adapter, cross, *params)
+                x = enc(group_embs, pos_embs, kv, kv_ready=True)
+                return ops.PoolFn.apply(x)
+            pts_embs = self.input_adapter(pts)
+        x = enc(group_embs, pos_embs, pts_embs)
         return ops.PoolFn.apply(x)
 
     def forward(self, pts):

@@ -869,8 +869,10 @@ class EncoderFusedFn(torch.autograd.Function):
     cross-attention front (two LayerNorms, q and kv projections) and the attention kernels themselves are separate."""
 
     @staticmethod
-    def forward(ctx, x, pos, xkv, ca, layers, training, *params):
+    def forward(ctx, x, pos, xkv, ca, layers, training, kv_ready, *params):
+        """kv_ready: ``xkv`` already holds the cross-attention K | V projections (bf16 [B, Lkv, 2D], AdapterKVFn)."""
         ctx.nparams = len(params)
+        ctx.kv_ready = kv_ready
         B, Lq, D = x.shape
         M, Hd, H = B * Lq, 512, 4
         dev = x.device
@@ -890,11 +892,15 @@ class EncoderFusedFn(torch.autograd.Function):
         xkv = xkv.contiguous()
         Lkv = xkv.shape[1]
         Mk = B * Lkv
-        nk, mk, rk, _ = layernorm_fwd(xkv, lnkv.weight.data, lnkv.bias.data)
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         w16 = shadow(qkvw)
         q = linear_fwd(nq, w16[:D * D], D, D)
-        kv = linear_fwd(nk, w16[D * D:], 2 * D, D)
+        if kv_ready:
+            kv = xkv.view(Mk, 2 * D)
+            nk = mk = rk = xkv = torch.empty(0, device=dev)         # the kv side is AdapterKVFn's business
+        else:
+            nk, mk, rk, _ = layernorm_fwd(xkv, lnkv.weight.data, lnkv.bias.data)
+            kv = linear_fwd(nk, w16[D * D:], 2 * D, D)
         o = torch.empty(M, D, dtype=BF16, device=dev)
         lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
         L.call("vpf_attention_fwd", q, D, kv, 2 * D, kv[:, D:], 2 * D, B, H, Lq, Lkv, D // H, float(catt.dp_scale),
@@ -917,7 +923,7 @@ class EncoderFusedFn(torch.autograd.Function):
         ctx.ca, ctx.layers, ctx.training, ctx.packed = ca, layers, training, packed
         ctx.dims = (B, Lq, Lkv, D, Hd, H)
         ctx.pos_shape = tuple(pos.shape) if pos is not None else None
-        ctx.xkv_dtype = xkv.dtype
+        ctx.xkv_dtype = BF16 if kv_ready else xkv.dtype
         ctx.save_for_backward(*flat)
         return out.view(B, Lq, D)
 
@@ -1010,14 +1016,17 @@ class EncoderFusedFn(torch.autograd.Function):
         wg.add(dz1, o, D, D, grad_buf(catt.o_proj.weight), grad_buf(catt.o_proj.bias))
         wg.add(dq, nq, D, D, gW[:D * D])
         wg.flush()
-        linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
         dnq = linear_dgrad(dq, w16[:D * D], D, D)
         dxkv = None
-        dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
-        if ctx.needs_input_grad[2]:
-            dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16)).view(B, Lkv, D)
+        if ctx.kv_ready:
+            dxkv = dkv.view(B, Lkv, 2 * D)                              # AdapterKVFn.backward takes it from here
         else:
-            layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
+            linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
+            dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
+            if ctx.needs_input_grad[2]:
+                dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16)).view(B, Lkv, D)
+            else:
+                layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
         dx = layernorm_bwd(dnq, base_ca, mq, rq, lnq.weight, lnq.bias, dx1).view(M, D)
         dpos = None
         if want_pos:
@@ -1027,7 +1036,81 @@ class EncoderFusedFn(torch.autograd.Function):
             else:
                 dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dev)
                 L.call("vpf_rowsum_mod_f32", dsum, M, D, Lq, dpos)
-        return (dx.view(B, Lq, D), dpos, dxkv, None, None, None) + (None,) * ctx.nparams
+        return (dx.view(B, Lq, D), dpos, dxkv, None, None, None, None) + (None,) * ctx.nparams
+
+
+class AdapterKVFn(torch.autograd.Function):
+    """PointCloudInputAdapter (classifier.py:31-50) + the cross-attention kv LayerNorm and K / V projections
+    (partseg.py:48-51,100-116) as ONE forward kernel (vpf_adapter_kv_fwd): pts [B,N,C] -> kv bf16 [B,N,2D].
+    Backward: the block-by-block kernels on what the forward saved."""
+
+    @staticmethod
+    def forward(ctx, pts, adapter, cross, *params):
+        ctx.nparams = len(params)
+        B, N, C = pts.shape
+        D = 256
+        dev = pts.device
+        x = pts.contiguous().float().view(-1, C)
+        M = x.shape[0]
+        l0, ln, l3 = adapter.point_mlp[0], adapter.point_mlp[1], adapter.point_mlp[3]
+        catt, lnkv = cross.attention, cross.kv_norm
+        qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
+        pack_params(qkvw)
+        w16 = shadow(qkvw)
+        pk = getattr(adapter, "_vpf_packed_kv", None)
+        if pk is None or pk.device != dev:
+            pk = torch.empty(D * 64 + 2 * D * D, dtype=BF16, device=dev)
+            adapter._vpf_packed_kv = pk
+        jobs = (L.PackJob * 64)()
+        jobs[0].src, jobs[0].dst, jobs[0].N, jobs[0].K = shadow([l3.weight]).data_ptr(), pk[:D * 64].data_ptr(), D, 64
+        jobs[1].src, jobs[1].dst, jobs[1].N, jobs[1].K = w16[D * D:].data_ptr(), pk[D * 64:].data_ptr(), 2 * D, D
+        L.call_struct("vpf_pack_wfrag", jobs, 2)
+        a1 = torch.empty(M, 64, dtype=BF16, device=dev)
+        xkv = torch.empty(M, D, dtype=BF16, device=dev)
+        mk = torch.empty(M, dtype=F32, device=dev)
+        rk = torch.empty(M, dtype=F32, device=dev)
+        nk = torch.empty(M, D, dtype=BF16, device=dev)
+        kv = torch.empty(M, 2 * D, dtype=BF16, device=dev)
+        a = L.AdapterKv()
+        a.M, a.C, a.D = M, C, D
+        a.x, a.W1, a.b1, a.ln_g, a.ln_b = x.data_ptr(), l0.weight.data.data_ptr(), l0.bias.data.data_ptr(), ln.weight.data.data_ptr(), ln.bias.data.data_ptr()
+        a.W2, a.b2, a.lnkv_g, a.lnkv_b, a.Wkv = pk.data_ptr(), l3.bias.data.data_ptr(), lnkv.weight.data.data_ptr(), lnkv.bias.data.data_ptr(), pk[D * 64:].data_ptr()
+        a.a1, a.xkv, a.mean, a.rstd, a.nk, a.kv = a1.data_ptr(), xkv.data_ptr(), mk.data_ptr(), rk.data_ptr(), nk.data_ptr(), kv.data_ptr()
+        L.call_struct("vpf_adapter_kv_fwd", a)
+        ctx.mods = (adapter, cross)
+        ctx.save_for_backward(x, a1, xkv, mk, rk, nk)
+        return kv.view(B, N, 2 * D)
+
+    @staticmethod
+    def backward(ctx, dkv):
+        x, a1, xkv, mk, rk, nk = ctx.saved_tensors
+        adapter, cross = ctx.mods
+        l0, ln, l3 = adapter.point_mlp[0], adapter.point_mlp[1], adapter.point_mlp[3]
+        catt, lnkv = cross.attention, cross.kv_norm
+        D = 256
+        M, C = x.shape
+        qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
+        w16, gW = shadow(qkvw), packed_grad(qkvw)
+        dkv = to_bf16(dkv).view(M, 2 * D)
+        linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
+        dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
+        dy16 = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True).view(M, D)
+        linear_wgrad(dy16, a1, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
+        da = linear_dgrad(dy16, shadow([l3.weight]), D, 64)
+        ws = torch.empty(2048 * 64 * 11, dtype=F32, device=x.device)
+        L.call("vpf_adapter_front_bwd", x, da, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data,
+               grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias), ws, ws.numel())
+        return (None, None, None) + (None,) * ctx.nparams
+
+
+ADAPTER_KV_FUSED = [True]
+
+
+def adapter_kv_supported(adapter, pts) -> bool:
+    if not ADAPTER_KV_FUSED[0] or pts.dim() != 3 or pts.shape[-1] > 8:
+        return False
+    l3 = adapter.point_mlp[3]
+    return tuple(l3.weight.shape) == (256, 64)
 
 
 def encoder_fused_supported(ca, layers, x, xkv) -> bool:
@@ -1036,7 +1119,7 @@ def encoder_fused_supported(ca, layers, x, xkv) -> bool:
     if not getattr(ca, "attention_residual", False):
         return False
     att, mlp = ca[0].module.attention, ca[1].module
-    if att.num_heads != 4 or mlp[1].weight.shape[0] != 512 or xkv.shape[-1] != 256:
+    if att.num_heads != 4 or mlp[1].weight.shape[0] != 512 or xkv.shape[-1] not in (256, 512):
         return False
     return isinstance(ca[0].drop_path, torch.nn.Identity) and isinstance(ca[1].drop_path, torch.nn.Identity)
 
