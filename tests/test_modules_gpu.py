@@ -476,3 +476,29 @@ def test_fused_sa_stack_matches_unfused_blocks():
         report(f"fused_sa_stack {tag} worst sa grad: {worst}")
         C.gt(tag + " worst sa-layer grad cos", worst[0], 0.9)
     C.done()
+
+
+@pytest.mark.parametrize("name", ["c3", "c4"])
+def test_other_baseline_configs_train_one_step(name):
+    """BASELINE configs 3 (G = 128, 8 self-attention layers: fused row-block path, tiled attention) and 4 (D = 384, 6 heads,
+    MR 4, 2048 points: block-by-block path) build, step and produce finite losses / gradients."""
+    from vipformer_amd import ops
+    from vipformer_amd.train import Pretrainer, build_models
+    a = Hh.ARCHS[name]
+    B = 2
+    ops.clear_managed_shadows()
+    ops.rng.seed(7)
+    torch.manual_seed(3)
+    pc, im = build_models(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], N=a["N"], img=a["img"], patch=a["patch"])
+    pc.train(); im.train()
+    tr = Pretrainer(pc, im)
+    t1 = Hh.synth_points(11, B, a["N"]).cuda(); t2 = Hh.synth_points(12, B, a["N"]).cuda()
+    imgs = Hh.synth_images(13, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
+    p0 = tr.flat.p.clone()
+    losses = tr.step(t1, t2, imgs)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(l).item() for l in losses), losses
+    assert torch.isfinite(tr.flat.g).all().item()
+    assert float(tr.flat.g.abs().max()) > 0.0
+    assert torch.isfinite(tr.flat.p).all().item() and not torch.equal(tr.flat.p, p0)
+    ops.clear_managed_shadows()
