@@ -504,7 +504,20 @@ __global__ void bn_bwd_reduce_kernel(const TDY* __restrict__ dy, const TX* __res
     const float mu = stat[c], rs = stat[C + c], ga = gamma[c], be = beta[c];
     const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
     float s = 0.f, q = 0.f;
-    for (long r = r0; r < r1; ++r) {
+    long r = r0;
+    for (; r + 4 <= r1; r += 4) {          // 4 rows in flight: a single running pair would serialise the load latencies
+        float xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { xv[u] = ld_f<TX>(x, (size_t)(r + u) * C + c); gv[u] = ld_f<TDY>(dy, (size_t)(r + u) * C + c); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xh = (xv[u] - mu) * rs;
+            float g = gv[u];
+            if (relu && (xh * ga + be) <= 0.f) g = 0.f;
+            s += g; q += g * xh;
+        }
+    }
+    for (; r < r1; ++r) {
         const float xh = (ld_f<TX>(x, (size_t)r * C + c) - mu) * rs;
         float g = ld_f<TDY>(dy, (size_t)r * C + c);
         if (relu && (xh * ga + be) <= 0.f) g = 0.f;
@@ -540,7 +553,9 @@ extern "C" int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_i
     if (!dy || !x || !stat || !gamma || !beta || !tmp2C_zeroed) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
-    int rpb = 128;
+    int rpb = (int)((M + 63) / 64);          // ~64 row slabs: small batches (the projection heads: 64 .. 128 rows) must not be one serial loop
+    if (rpb < 8) rpb = 8;
+    if (rpb > 128) rpb = 128;
     while ((M + rpb - 1) / rpb > 16384) rpb *= 2;
     dim3 g1(vpf_cdiv(C, 256), (unsigned)((M + rpb - 1) / rpb));
     const int g2 = grid_for(M * C, 256);

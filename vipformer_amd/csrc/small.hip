@@ -196,16 +196,23 @@ __global__ void smallk_bwd_kernel(const float* __restrict__ x, const bf16_t* __r
     const float bb = b[n];
     float ab = 0.f;
     const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (long r = r0; r < r1; ++r) {
-        float xv[8];
-        float u = bb;
+    for (long r = r0; r < r1; r += 8) {      // 8 rows in flight (one row at a time serialises the load latencies)
+        float gv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { xv[j] = j < C ? x[(size_t)r * C + j] : 0.f; u += w[j] * xv[j]; }
-        float g = bf16_to_f32(dy[(size_t)r * N + n]);
-        if (act == 1) g *= gelu_grad_f(u);
-        ab += g;
+        for (int q = 0; q < 8; ++q) gv[q] = r + q < r1 ? bf16_to_f32(dy[(size_t)(r + q) * N + n]) : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) aw[j] += g * xv[j];
+        for (int q = 0; q < 8; ++q) {
+            const long rr = r + q < r1 ? r + q : r1 - 1;
+            float xv[8];
+            float u = bb;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { xv[j] = j < C ? x[(size_t)rr * C + j] : 0.f; u += w[j] * xv[j]; }
+            float g = gv[q];
+            if (act == 1) g *= gelu_grad_f(u);
+            ab += g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) aw[j] += g * xv[j];
+        }
     }
     atomicAdd(db + n, ab);
 #pragma unroll
@@ -541,11 +548,26 @@ __global__ void __launch_bounds__(256) ntxent_row_kernel(const float* __restrict
     // latency n / nwv times in sequence, and this kernel sits alone between the forward and the backward pass)
     for (int j0 = wv * 8; j0 < n; j0 += nwv * 8) {
         float s[8];
+        if (D == 256) {
+            // fixed trip counts: the 32 loads of the 8 rows are really in flight together
+            float zr[4], v[8][4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            s[u] = 0.f;
-            const int j = j0 + u < n ? j0 + u : n - 1;
-            for (int c = lane; c < D; c += 64) s[u] += zi[c] * zn[(size_t)j * D + c];
+            for (int k = 0; k < 4; ++k) zr[k] = zi[lane + 64 * k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u < n ? j0 + u : n - 1;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[u][k] = zn[(size_t)j * 256 + lane + 64 * k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] = (zr[0] * v[u][0] + zr[1] * v[u][1]) + (zr[2] * v[u][2] + zr[3] * v[u][3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s[u] = 0.f;
+                const int j = j0 + u < n ? j0 + u : n - 1;
+                for (int c = lane; c < D; c += 64) s[u] += zi[c] * zn[(size_t)j * D + c];
+            }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
