@@ -254,6 +254,14 @@ int vpf_ntxent_fwd(const float* z0, const float* z1, int b, int D, float tempera
                    float* loss_rows, float* loss, void* stream);
 int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b, int D, float temperature, const float* dloss,
                    float* dz0, float* dz1, void* stream);
+/* Both pre-training losses in one go (pretrain.py:196-204): f f32 [2b,D] = the two point-cloud views stacked, g f32 [b,D] =
+ * the image features; total f32[1] = imid + w*cmid, parts f32[2] = {imid = NTXent(f[:b], f[b:]), cmid = NTXent((f[:b]+f[b:])/2, g)}.
+ * Workspaces: zn [2,2b,D], inv_norm [2,2b], P [2,2b,2b], loss_rows [2,2b]; bwd: ws_dz [2,2b,D], df [2b,D], dg [b,D] from
+ * dtotal (device scalar). */
+int vpf_pretrain_loss_fwd(const float* f, const float* g, int b, int D, float temperature, float cmid_weight, float* zn,
+                          float* inv_norm, float* P, float* loss_rows, float* total, float* parts, void* stream);
+int vpf_pretrain_loss_bwd(const float* zn, const float* inv_norm, const float* P, int b, int D, float temperature, float cmid_weight,
+                          const float* dtotal, float* ws_dz, float* df, float* dg, void* stream);
 /* torch.optim.AdamW (pretrain.py:121-124,210) over a flat fp32 buffer, also rewriting the bf16 shadow the MFMA
  * kernels read.  hyper_dev (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip}. */
 int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev,

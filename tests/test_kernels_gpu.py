@@ -299,3 +299,26 @@ def test_patchify_on_permuted_nchw_view():
     sb, sh, sw, sc = imgs.stride()
     L.call("vpf_patchify", imgs, sb, sh, sw, sc, 2, 32, 48, 3, 8, out)
     assert torch.equal(out.view(2, -1, 192), bf(O.patchify(imgs.cpu(), 8)).cuda())
+
+
+def test_fused_pretrain_losses_match_the_two_ntxent_calls():
+    """vpf_pretrain_loss_fwd / _bwd (both NT-Xent losses, the view mean and the weighted sum) against the per-loss kernels
+    composed with torch ops: same values and gradients (fp32, tolerance 1e-5 relative)."""
+    from vipformer_amd import ops
+    torch.manual_seed(0)
+    b, D, w = 24, 256, 0.7
+    f = torch.randn(2 * b, D, device="cuda", requires_grad=True)
+    g = torch.randn(b, D, device="cuda", requires_grad=True)
+    total, parts = ops.pretrain_losses(f, g, 0.1, w)
+    total.backward()
+    df, dg = f.grad.clone(), g.grad.clone()
+    f.grad = None; g.grad = None
+    f1, f2 = f[:b], f[b:]
+    li = ops.ntxent_loss(f1, f2, 0.1)
+    lc = ops.ntxent_loss((f1 + f2) / 2, g, 0.1)
+    ref = li + w * lc
+    ref.backward()
+    assert abs(float(total) - float(ref)) < 1e-5 * abs(float(ref))
+    assert abs(float(parts[0]) - float(li)) < 1e-5 * abs(float(li)) and abs(float(parts[1]) - float(lc)) < 1e-5 * abs(float(lc))
+    assert (df - f.grad).abs().max().item() < 1e-5 * f.grad.abs().max().item() + 1e-9
+    assert (dg - g.grad).abs().max().item() < 1e-5 * g.grad.abs().max().item() + 1e-9

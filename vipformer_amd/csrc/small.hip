@@ -506,13 +506,50 @@ __global__ void patchify_kernel(const float* __restrict__ img, long sb, long sh,
         out[i] = f32_to_bf16(img[b * sb + (long)(th * p + p1) * sh + (long)(tw * p + p2) * sw + c * sc]);
     }
 }
+// One block per (image, row of patches): the p image rows x W x C slab is read with the thread on the w axis (contiguous
+// in the NCHW memory the loader hands over), re-ordered in LDS into the token-major output order and written back with
+// 16-byte stores (the slab's tokens are one contiguous piece of the output).  8 loads in flight per thread.
+__global__ void __launch_bounds__(256) patchify_rows_kernel(const float* __restrict__ img, long sb, long sh, long sw, long sc, int Hh, int Ww,
+                                                           int Cc, int p, bf16_t* __restrict__ out)
+{
+    extern __shared__ bf16_t tile[];                 // [wp][p*p*Cc]
+    const int wp = Ww / p, hp = Hh / p, pd = p * p * Cc;
+    const int b = blockIdx.x / hp, th = blockIdx.x % hp;
+    const float* base = img + (long)b * sb + (long)(th * p) * sh;
+    const int npl = Cc * p;                           // (channel, image row) planes of the slab
+    for (int w = threadIdx.x; w < wp * p; w += blockDim.x) {
+        const int tw = w / p, p2 = w % p;
+        for (int pl0 = 0; pl0 < npl; pl0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pl = pl0 + u < npl ? pl0 + u : npl - 1, c = pl / p, p1 = pl % p;
+                v[u] = base[(long)p1 * sh + (long)w * sw + (long)c * sc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int pl = pl0 + u;
+                if (pl < npl) { const int c = pl / p, p1 = pl % p; tile[tw * pd + (p1 * p + p2) * Cc + c] = f32_to_bf16(v[u]); }
+            }
+        }
+    }
+    __syncthreads();
+    const int nchunk = wp * pd / 8;                   // 16-byte chunks (pd % 8 == 0 checked by the launcher)
+    uint4* dst = reinterpret_cast<uint4*>(out + ((size_t)b * hp + th) * wp * pd);
+    const uint4* src = reinterpret_cast<const uint4*>(tile);
+    for (int e = threadIdx.x; e < nchunk; e += blockDim.x) dst[e] = src[e];
+}
 extern "C" int vpf_patchify(const float* img, long sb, long sh, long sw, long sc, int B, int H, int W, int C, int p, void* out_bf16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!img || !out_bf16) return VPF_ERR_NULL;
     if (B < 0 || H <= 0 || W <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p)) return VPF_ERR_BADSHAPE;
     if (B == 0) return VPF_OK;
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, img, sb, sh, sw, sc, B, H, W, C, p, (bf16_t*)out_bf16);
+    const size_t lds = sizeof(bf16_t) * (size_t)(W / p) * p * p * C;
+    if ((p * p * C) % 8 == 0 && lds <= 64 * 1024 && (((uintptr_t)out_bf16) & 15) == 0)
+        hipLaunchKernelGGL(patchify_rows_kernel, dim3(B * (H / p)), dim3(256), lds, (hipStream_t)stream, img, sb, sh, sw, sc, H, W, C, p, (bf16_t*)out_bf16);
+    else
+        hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, img, sb, sh, sw, sc, B, H, W, C, p, (bf16_t*)out_bf16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -540,6 +577,7 @@ __global__ void __launch_bounds__(256) ntxent_row_kernel(const float* __restrict
 {
     extern __shared__ float sm[];      // zi[D] + logits[n]
     const int n = 2 * b, i = blockIdx.x;
+    zn += (size_t)blockIdx.y * n * D; P += (size_t)blockIdx.y * n * n; loss_rows += (size_t)blockIdx.y * n;     // problem index (fused losses)
     float* zi = sm; float* lg = sm + D;
     for (int c = threadIdx.x; c < D; c += blockDim.x) zi[c] = zn[(size_t)i * D + c];
     __syncthreads();
@@ -621,12 +659,15 @@ extern "C" int vpf_ntxent_fwd(const float* z0, const float* z1, int b, int D, fl
 // dzn_i = (dL/n/T) * sum_j (G[i,j] + G[j,i]) zn_j,  G = P - onehot(pos);  dz = inv * (dzn - zn (zn . dzn))
 __global__ void __launch_bounds__(256) ntxent_bwd_kernel(const float* __restrict__ zn, const float* __restrict__ inv, const float* __restrict__ P,
                                                        int b, int D, float invT, const float* __restrict__ dloss, float* __restrict__ dz0,
-                                                       float* __restrict__ dz1)
+                                                       float* __restrict__ dz1, float w1)
 {
     extern __shared__ float sm[];      // coef[n] + dzn[D]
     const int n = 2 * b, i = blockIdx.x;
+    // problem index (fused losses): problem 1 is weighted by w1 and writes the second [n, D] slab of dz0 (dz1 = dz0 + b rows)
+    zn += (size_t)blockIdx.y * n * D; inv += (size_t)blockIdx.y * n; P += (size_t)blockIdx.y * n * n;
+    dz0 += (size_t)blockIdx.y * n * D; dz1 += (size_t)blockIdx.y * n * D;
     float* coef = sm; float* dzn = sm + n;
-    const float gs = dloss[0] * invT / (float)n;
+    const float gs = dloss[0] * (blockIdx.y ? w1 : 1.f) * invT / (float)n;
     for (int j = threadIdx.x; j < n; j += blockDim.x) {
         float g = P[(size_t)i * n + j] + P[(size_t)j * n + i];
         if (j == (i + b) % n) g -= 1.f;
@@ -660,7 +701,7 @@ extern "C" int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const floa
     if (!zn || !inv_norm || !P || !dloss || !dz0 || !dz1) return VPF_ERR_NULL;
     if (b <= 0 || D <= 0 || 2 * b > 8192) return VPF_ERR_BADSHAPE;
     const int n = 2 * b;
-    hipLaunchKernelGGL(ntxent_bwd_kernel, dim3(n), dim3(256), sizeof(float) * (n + D), (hipStream_t)stream, zn, inv_norm, P, b, D, 1.f / temperature, dloss, dz0, dz1);
+    hipLaunchKernelGGL(ntxent_bwd_kernel, dim3(n), dim3(256), sizeof(float) * (n + D), (hipStream_t)stream, zn, inv_norm, P, b, D, 1.f / temperature, dloss, dz0, dz1, 1.f);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -699,6 +740,80 @@ extern "C" int vpf_adamw_step(float* p, const float* g, float* m, float* v, void
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow_bf16, n, hyper_dev);
     if (advance_step) hipLaunchKernelGGL(adamw_step_kernel, dim3(1), dim3(64), 0, st, hyper_dev);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+
+// =============================================================================== both pre-training losses at once
+// pretrain.py:196-204: loss_imid = NTXent(f1, f2), loss_cmid = NTXent((f1 + f2) / 2, g), total = imid + w * cmid, with
+// f = [f1; f2] (the two point-cloud views, [2b, D]) and g the image features [b, D].  Three launches forward and two
+// backward instead of ~25 tiny kernels that sit alone between the forward and the backward pass.
+__global__ void __launch_bounds__(256) loss2_norm_kernel(const float* __restrict__ f, const float* __restrict__ g, int b, int D,
+                                                       float* __restrict__ zn, float* __restrict__ inv)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n = 2 * b;
+    if (r >= 2 * n) return;
+    const int p = r / n, rr = r % n;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float v = p == 0 ? f[(size_t)rr * D + c] : (rr < b ? 0.5f * (f[(size_t)rr * D + c] + f[(size_t)(rr + b) * D + c]) : g[(size_t)(rr - b) * D + c]);
+        s += v * v;
+    }
+    s = wave_sum(s);
+    const float iv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+    for (int c = lane; c < D; c += 64) {
+        const float v = p == 0 ? f[(size_t)rr * D + c] : (rr < b ? 0.5f * (f[(size_t)rr * D + c] + f[(size_t)(rr + b) * D + c]) : g[(size_t)(rr - b) * D + c]);
+        zn[(size_t)r * D + c] = v * iv;
+    }
+    if (lane == 0) inv[r] = iv;
+}
+__global__ void loss2_mean_kernel(const float* __restrict__ rows, int n, float w, float* __restrict__ total, float* __restrict__ parts)
+{
+    float s0 = 0.f, s1 = 0.f;
+    for (int j = threadIdx.x; j < n; j += 64) { s0 += rows[j]; s1 += rows[n + j]; }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if (threadIdx.x == 0) { const float a = s0 / (float)n, c = s1 / (float)n; total[0] = a + w * c; parts[0] = a; parts[1] = c; }
+}
+// df[r] = dzA[r] + dzC[r mod b] / 2   (r < 2b: the views feed problem A directly and problem B through their mean); dg = dzB[b + r]
+__global__ void loss2_combine_kernel(const float* __restrict__ dz, int b, int D, float* __restrict__ df, float* __restrict__ dg)
+{
+    const long nD = (long)2 * b * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nD + (long)b * D; i += (long)gridDim.x * blockDim.x) {
+        if (i < nD) {
+            const long r = i / D; const int c = (int)(i % D);
+            df[i] = dz[i] + 0.5f * dz[nD + (r % b) * D + c];
+        } else {
+            dg[i - nD] = dz[nD + (long)b * D + (i - nD)];
+        }
+    }
+}
+extern "C" int vpf_pretrain_loss_fwd(const float* f, const float* g, int b, int D, float temperature, float cmid_weight, float* zn,
+                                     float* inv_norm, float* P, float* loss_rows, float* total, float* parts, void* stream)
+{
+    (void)hipGetLastError();
+    if (!f || !g || !zn || !inv_norm || !P || !loss_rows || !total || !parts) return VPF_ERR_NULL;
+    if (b <= 0 || D <= 0 || 2 * b > 8192) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = 2 * b;
+    hipLaunchKernelGGL(loss2_norm_kernel, dim3(vpf_cdiv(2 * n, 4)), dim3(256), 0, st, f, g, b, D, zn, inv_norm);
+    hipLaunchKernelGGL(ntxent_row_kernel, dim3(n, 2), dim3(256), sizeof(float) * (D + n), st, (const float*)zn, b, D, 1.f / temperature, P, loss_rows);
+    hipLaunchKernelGGL(loss2_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)loss_rows, n, cmid_weight, total, parts);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+extern "C" int vpf_pretrain_loss_bwd(const float* zn, const float* inv_norm, const float* P, int b, int D, float temperature,
+                                     float cmid_weight, const float* dtotal, float* ws_dz, float* df, float* dg, void* stream)
+{
+    (void)hipGetLastError();
+    if (!zn || !inv_norm || !P || !dtotal || !ws_dz || !df || !dg) return VPF_ERR_NULL;
+    if (b <= 0 || D <= 0 || 2 * b > 8192) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = 2 * b;
+    hipLaunchKernelGGL(ntxent_bwd_kernel, dim3(n, 2), dim3(256), sizeof(float) * (n + D), st, zn, inv_norm, P, b, D, 1.f / temperature, dtotal,
+                       ws_dz, ws_dz + (size_t)b * D, cmid_weight);
+    hipLaunchKernelGGL(loss2_combine_kernel, dim3(grid_for((long)3 * b * D, 256)), dim3(256), 0, st, (const float*)ws_dz, b, D, df, dg);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

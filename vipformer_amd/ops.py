@@ -1525,5 +1525,44 @@ class NTXentFn(torch.autograd.Function):
         return dz0, dz1, None
 
 
+class PretrainLossFn(torch.autograd.Function):
+    """pretrain.py:196-204 in three launches: returns (total = imid + w * cmid [scalar], parts f32[2] = (imid, cmid));
+    only total carries a gradient (the parts are the logged values)."""
+
+    @staticmethod
+    def forward(ctx, f, g, temperature, w):
+        f = f.contiguous().float(); g = g.contiguous().float()
+        b, D = g.shape
+        n = 2 * b
+        dev = f.device
+        zn = torch.empty(2, n, D, dtype=F32, device=dev)
+        inv = torch.empty(2, n, dtype=F32, device=dev)
+        P = torch.empty(2, n, n, dtype=F32, device=dev)
+        rows = torch.empty(2, n, dtype=F32, device=dev)
+        total = torch.empty((), dtype=F32, device=dev)
+        parts = torch.empty(2, dtype=F32, device=dev)
+        L.call("vpf_pretrain_loss_fwd", f, g, b, D, float(temperature), float(w), zn, inv, P, rows, total, parts)
+        ctx.t, ctx.w, ctx.dims = temperature, w, (b, D)
+        ctx.save_for_backward(zn, inv, P)
+        ctx.mark_non_differentiable(parts)
+        return total, parts
+
+    @staticmethod
+    def backward(ctx, dlosses, _dparts):
+        zn, inv, P = ctx.saved_tensors
+        b, D = ctx.dims
+        dev = zn.device
+        ws = torch.empty(2, 2 * b, D, dtype=F32, device=dev)
+        df = torch.empty(2 * b, D, dtype=F32, device=dev)
+        dg = torch.empty(b, D, dtype=F32, device=dev)
+        L.call("vpf_pretrain_loss_bwd", zn, inv, P, b, D, float(ctx.t), float(ctx.w), dlosses.contiguous().float().reshape(1), ws, df, dg)
+        return df, dg, None, None
+
+
+def pretrain_losses(f, g, temperature=0.1, cmid_weight=1.0):
+    """f [2b, D]: features of cat(view1, view2); g [b, D]: image features -> (total [scalar], parts f32[2] = (imid, cmid))."""
+    return PretrainLossFn.apply(f, g, temperature, cmid_weight)
+
+
 def ntxent_loss(z0, z1, temperature=0.1):
     return NTXentFn.apply(z0, z1, temperature)

@@ -92,6 +92,7 @@ class Pretrainer:
         # the image branch is independent of the point-cloud branch until the CMC loss: it runs on its own
         # stream so its kernels fill the CUs that FPS / kNN / the small GEMMs of the pc branch leave idle
         self.overlap = True
+        self.fused_losses = True
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._graph = None
         self._static = None
@@ -119,17 +120,20 @@ class Pretrainer:
             with torch.cuda.stream(self._side):
                 img_feats = self.img_model(imgs)[0]
             feats = self.pc_model(pc)[0]
-            f1, f2 = feats[:b], feats[b:]
-            loss_imid = ops.ntxent_loss(f1, f2, self.temperature)
             main.wait_stream(self._side)
             img_feats.record_stream(main)
         else:
             feats = self.pc_model(pc)[0]
+            img_feats = self.img_model(imgs)[0]
+        if self.fused_losses:
+            # both NT-Xent losses, the view mean and the weighted sum in three launches (vpf_pretrain_loss_fwd)
+            total, parts = ops.pretrain_losses(feats, img_feats, self.temperature, self.cmid_weight)
+            loss_imid, loss_cmid = parts[0], parts[1]
+        else:
             f1, f2 = feats[:b], feats[b:]
             loss_imid = ops.ntxent_loss(f1, f2, self.temperature)
-            img_feats = self.img_model(imgs)[0]
-        loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, self.temperature)
-        total = loss_imid + self.cmid_weight * loss_cmid
+            loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, self.temperature)
+            total = loss_imid + self.cmid_weight * loss_cmid
         total.backward()
         if self.overlap and self._side is not None:
             # the kernels write weight gradients themselves (autograd sees no leaf accumulation on the side stream and
