@@ -290,6 +290,43 @@ extern "C" int vpf_rng_advance(uint32_t* rng_state, void* stream)
 // x [M,C] -> acc[c] += sum_m x ; acc2[c] += sum_m x^2 (optional).  A block owns a slab of rows; every thread
 // streams 8 consecutive columns (16-byte loads for bf16) of one row per step; the block's row-lanes meet in
 // LDS and ONE fp32 atomic per column and block leaves the CU.
+// small M: block = 64 columns (8 groups of 8) x 32 row lanes; fixed-order fold
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_small_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ acc, float* __restrict__ acc2)
+{
+    __shared__ float red[2][32][65];
+    const int t = threadIdx.x, g = t & 7, rl = t >> 3;
+    const int c0 = blockIdx.x * 64 + g * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (long r = rl; r < M; r += 32) {
+        float v[8];
+        if (sizeof(T) == 2) {
+            const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + (size_t)r * C + c0);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + c0);
+            const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + c0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += v[j]; q[j] += v[j] * v[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][rl][g * 8 + j] = s[j]; red[1][rl][g * 8 + j] = q[j]; }
+    __syncthreads();
+    if (t < 128) {
+        const int which = t >> 6, c = t & 63;
+        float a = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) a += red[which][k][c];
+        if (which == 0) acc[blockIdx.x * 64 + c] += a;
+        else if (acc2) acc2[blockIdx.x * 64 + c] += a;
+    }
+}
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, long M, int C, float* __restrict__ acc, float* __restrict__ acc2,
                                                    int rows_per_block)
@@ -359,7 +396,16 @@ extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* ac
     hipStream_t st = (hipStream_t)stream;
     if (C % 8 == 0 && (((uintptr_t)x & 15) == 0)) {
         int rpb = 32;
-        if (M <= 2048) rpb = (int)M;                        // one block: a deterministic sum (BatchNorm over a batch of samples)
+        if (M <= 2048 && C % 64 == 0) {
+            // a batch of samples (BatchNorm of the projection heads): every column is summed by ONE block in a fixed order
+            // (deterministic), but the columns are spread over C/64 blocks and the rows over 32 lanes, so that no thread walks
+            // more than M/32 rows
+            if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<bf16_t>, dim3(C / 64), dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2);
+            else hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(C / 64), dim3(256), 0, st, (const float*)x, M, C, acc, acc2);
+            VPF_CHECK_LAUNCH();
+            return VPF_OK;
+        }
+        if (M <= 2048) rpb = (int)M;                        // one block: a deterministic sum
         while ((M + rpb - 1) / rpb > 512) rpb *= 2;      // <= 512 blocks -> <= 512 atomics per column
         const int grid = (int)((M + rpb - 1) / rpb);
         if (x_is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2, rpb);
