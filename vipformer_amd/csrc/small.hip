@@ -406,22 +406,32 @@ __global__ void __launch_bounds__(512) g2e_conv1_bwd_kernel(const float* __restr
     float a0[8], a1[8], aw[8][3];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a0[j] = a1[j] = 0.f; aw[j][0] = aw[j][1] = aw[j][2] = 0.f; }
-    for (long r = (long)blockIdx.x * 64 + rl; r < M; r += (long)gridDim.x * 64) {
-        const uint4 dv = *reinterpret_cast<const uint4*>(da + (size_t)r * 64 + cg);
-        const float x0 = x[(size_t)r * C], x1 = C > 1 ? x[(size_t)r * C + 1] : 0.f, x2 = C > 2 ? x[(size_t)r * C + 2] : 0.f;
-        const uint32_t u[4] = {dv.x, dv.y, dv.z, dv.w};
+    const long rstep = (long)gridDim.x * 64;
+    auto row_math = [&](const uint4 dv, const float x0, const float x1, const float x2, const float live) {
+        const uint32_t uw[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float h = w[j][0] * x0 + w[j][1] * x1 + w[j][2] * x2 + bb[j];
             const float xh = (h - mu[j]) * rs[j];
-            float g = (j & 1) ? __uint_as_float(u[j >> 1] & 0xffff0000u) : __uint_as_float(u[j >> 1] << 16);
+            float g = (j & 1) ? __uint_as_float(uw[j >> 1] & 0xffff0000u) : __uint_as_float(uw[j >> 1] << 16);
             if (xh * ga[j] + be[j] <= 0.f) g = 0.f;
             if (!pass) { a0[j] += g; a1[j] += g * xh; }
             else {
-                const float dh = training ? ga[j] * rs[j] * (g - sg[j] - xh * sgx[j]) : ga[j] * rs[j] * g;
+                const float dh = live * (training ? ga[j] * rs[j] * (g - sg[j] - xh * sgx[j]) : ga[j] * rs[j] * g);
                 a0[j] += dh; aw[j][0] += dh * x0; aw[j][1] += dh * x1; aw[j][2] += dh * x2;
             }
         }
+    };
+    for (long r = (long)blockIdx.x * 64 + rl; r < M; r += 2 * rstep) {
+        // two rows in flight per thread (one row at a time pays the load latency M / (grid * 64) times in sequence)
+        const long rb = r + rstep;
+        const bool okb = rb < M;
+        const uint4 dva = *reinterpret_cast<const uint4*>(da + (size_t)r * 64 + cg);
+        const uint4 dvb = okb ? *reinterpret_cast<const uint4*>(da + (size_t)rb * 64 + cg) : make_uint4(0, 0, 0, 0);
+        const float xa0 = x[(size_t)r * C], xa1 = C > 1 ? x[(size_t)r * C + 1] : 0.f, xa2 = C > 2 ? x[(size_t)r * C + 2] : 0.f;
+        const float xb0 = okb ? x[(size_t)rb * C] : 0.f, xb1 = (okb && C > 1) ? x[(size_t)rb * C + 1] : 0.f, xb2 = (okb && C > 2) ? x[(size_t)rb * C + 2] : 0.f;
+        row_math(dva, xa0, xa1, xa2, 1.f);
+        row_math(dvb, xb0, xb1, xb2, okb ? 1.f : 0.f);
     }
     // Fold the 64 row-lanes of every channel WITHOUT atomics: lanes that share a channel group differ in lane bits 3..5
     // (3 shuffles per value), the 8 waves meet in LDS, and the block leaves one partial row [5][64] for the fold kernel
