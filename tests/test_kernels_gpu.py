@@ -318,6 +318,7 @@ def test_fused_pretrain_losses_match_the_two_ntxent_calls():
     lc = ops.ntxent_loss((f1 + f2) / 2, g, 0.1)
     ref = li + w * lc
     ref.backward()
+    total, ref, li, lc = total.detach(), ref.detach(), li.detach(), lc.detach()
     assert abs(float(total) - float(ref)) < 1e-5 * abs(float(ref))
     assert abs(float(parts[0]) - float(li)) < 1e-5 * abs(float(li)) and abs(float(parts[1]) - float(lc)) < 1e-5 * abs(float(lc))
     assert (df - f.grad).abs().max().item() < 1e-5 * f.grad.abs().max().item() + 1e-9
