@@ -354,7 +354,19 @@ typedef struct VpfAdapterKv {
     void* a1; void* xkv; float* mean; float* rstd; void* nk; void* kv;
 } VpfAdapterKv;
 int vpf_adapter_kv_fwd(const VpfAdapterKv* host_args, void* stream);
-/* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3), sizeof(VpfPgradJob) vpf_abi_sizeof(4), sizeof(VpfAdapterKv) vpf_abi_sizeof(5) */
+/* Backward of the same chain from dkv (bf16 [M,2D]) down to the adapter's hidden layer, one kernel: dxkv bf16 [M,D] (the
+ * operand of the adapter's second-Linear weight gradient dxkv x a1; dkv x nk is the other GEMM) and da1 bf16 [M,64] (the
+ * input of vpf_adapter_front_bwd); the kv LayerNorm's parameter gradients go to pgrad_kv (ceil(M/64) rows of 2D floats,
+ * folded by vpf_ln_pgrad_reduce).  WkvT / W2T = vpf_pack_wfrag(transposed = 1) of the bf16 [2D,D] k|v weights
+ * (N = D, K = 2D) and of the [D,64] weight (N = 64, K = D). */
+typedef struct VpfAdapterKvBwd {
+    long M; int C, D;
+    const void* dkv; const void* WkvT; const void* xkv; const float* mean; const float* rstd; const float* lnkv_g;
+    const void* W2T;
+    void* dxkv; void* da1; float* pgrad_kv;
+} VpfAdapterKvBwd;
+int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* host_args, void* stream);
+/* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3), sizeof(VpfPgradJob) (4), sizeof(VpfAdapterKv) (5), sizeof(VpfAdapterKvBwd) (6) */
 /* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1) / sizeof(VpfWgradJob) (2): lets a binding verify its struct layout */
 int vpf_abi_sizeof(int which);
 

@@ -438,7 +438,7 @@ def test_fused_sa_stack_matches_unfused_blocks():
     imgs = Hh.synth_images(3, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
     start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
     results = []
-    variants = ((False, False, None, False), (True, False, False, False), (True, False, True, False), (True, True, True, False), (True, True, True, True))
+    variants = ((False, False, None, False), (True, False, False, False), (True, False, True, False), (True, True, True, False), (True, True, True, True), (True, True, True, 2))
     for fused, fused_bwd, split, enc in variants:
         ops.clear_managed_shadows()
         ops.rng.seed(99)
@@ -450,8 +450,9 @@ def test_fused_sa_stack_matches_unfused_blocks():
         pc.train(); im.train()
         tr = Pretrainer(pc, im)
         tr.overlap = False
-        ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = fused, fused_bwd, split, enc
-        ops.ADAPTER_KV_FUSED[0] = enc
+        ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = fused, fused_bwd, split, bool(enc)
+        ops.ADAPTER_KV_FUSED[0] = bool(enc)
+        ops.ADAPTER_KV_BWD_FUSED[0] = enc == 2
         with forced_start(start):
             feats_pc = pc(torch.cat([t1, t2]))[1].detach().clone()        # backbone features (before the BatchNorm head)
             ops.rng.state("cuda")[2] = 0
@@ -462,12 +463,13 @@ def test_fused_sa_stack_matches_unfused_blocks():
         results.append((float(losses[0]), feats_pc, g))
     ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = True, True, None, True
     ops.ADAPTER_KV_FUSED[0] = True
+    ops.ADAPTER_KV_BWD_FUSED[0] = True
     ops.clear_managed_shadows()
     l0, f0, g0 = results[0]
     allg0 = torch.cat([v.reshape(-1) for v in g0.values()])
     C = Checks("fused_sa_stack")
     for (l1, f1, g1), (fused, fused_bwd, split, enc) in zip(results[1:], variants[1:]):
-        tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}{', CA tail + adapter/kv fused' if enc else ''}]"
+        tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}{(', CA tail + adapter/kv fused' + (' (bwd too)' if enc == 2 else '')) if enc else ''}]"
         C.lt(tag + " pc backbone feats rel", rel(f1, f0), 2e-2)
         C.lt(tag + " loss rel", abs(l1 - l0) / abs(l0), 2e-2)
         allg1 = torch.cat([g1[k].reshape(-1) for k in g0])
@@ -475,6 +477,9 @@ def test_fused_sa_stack_matches_unfused_blocks():
         worst = min((cosine(g1[k], g0[k]), k) for k in g0 if "sa_layers" in k and g0[k].numel() >= 256)
         report(f"fused_sa_stack {tag} worst sa grad: {worst}")
         C.gt(tag + " worst sa-layer grad cos", worst[0], 0.9)
+        front = min((cosine(g1[k], g0[k]), k) for k in g0 if ("input_adapter" in k or "kv_norm" in k or "k_proj" in k or "v_proj" in k) and k.startswith("pc."))
+        report(f"fused_sa_stack {tag} worst adapter / kv grad: {front}")
+        C.gt(tag + " worst adapter / kv-side grad cos", front[0], 0.97)
     C.done()
 
 

@@ -123,6 +123,7 @@ SIGS = {
     "vpf_sa_layer_bwd_qkv": [VP, VP],
     "vpf_ln_pgrad_reduce": [VP, I, VP],
     "vpf_adapter_kv_fwd": [VP, VP],
+    "vpf_adapter_kv_bwd": [VP, VP],
 }
 
 
@@ -165,6 +166,12 @@ class AdapterKv(ctypes.Structure):
     _fields_ = [("M", L_), ("C", I), ("D", I), ("x", VP), ("W1", VP), ("b1", VP), ("ln_g", VP), ("ln_b", VP),
                 ("W2", VP), ("b2", VP), ("lnkv_g", VP), ("lnkv_b", VP), ("Wkv", VP),
                 ("a1", VP), ("xkv", VP), ("mean", VP), ("rstd", VP), ("nk", VP), ("kv", VP)]
+
+
+class AdapterKvBwd(ctypes.Structure):
+    """struct VpfAdapterKvBwd (include/vipformer_hip.h)."""
+    _fields_ = [("M", L_), ("C", I), ("D", I), ("dkv", VP), ("WkvT", VP), ("xkv", VP), ("mean", VP), ("rstd", VP), ("lnkv_g", VP),
+                ("W2T", VP), ("dxkv", VP), ("da1", VP), ("pgrad_kv", VP)]
 
 
 class SaLayerBwd(ctypes.Structure):

@@ -30,6 +30,7 @@ extern "C" int vpf_abi_sizeof(int which)
         case 3: return (int)sizeof(VpfSaLayerBwd);
         case 4: return (int)sizeof(VpfPgradJob);
         case 5: return (int)sizeof(VpfAdapterKv);
+        case 6: return (int)sizeof(VpfAdapterKvBwd);
         default: return -1;
     }
 }

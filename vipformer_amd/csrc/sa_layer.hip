@@ -704,7 +704,7 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
 
 // LayerNorm backward in place on the accumulator tile: acc = dL/dy -> dL/dx;  x (the forward input) from HBM.
 // The per-channel parameter gradients of this workgroup's tokens go to pgrad[0..255] (dgamma) / pgrad[256..511] (dbeta).
-template <int RB, int NJ>
+template <int RB, int NJ, bool XBF = false>
 __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[NJ][RB], const float* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ gamma, float* sStat2,
                                                  float* __restrict__ pgrad, long m0, int nvalid)
@@ -726,8 +726,13 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[NJ][RB], const 
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
-                xh[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(x + (size_t)(m0 + tok) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
+                if constexpr (XBF) {          // the LayerNorm input was stored as bf16 (x points at bf16 data)
+                    const uint2 u = tok < nvalid ? *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + off) : make_uint2(0u, 0u);
+                    xh[j][g][i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                } else {
+                    xh[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
     float s1[RB], s2[RB];
 #pragma unroll
@@ -1267,6 +1272,89 @@ extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
         attr = true;
     }
     hipLaunchKernelGGL((adapter_kv_fwd_kernel<1>), dim3(vpf_cdiv(a.M, (long)TOK)), dim3(512), lds, (hipStream_t)stream, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+
+// ================================================================================================ K / V producer, backward
+// dkv [M, 2D] -> (. Wk | Wv) -> kv LayerNorm' -> dxkv (bf16, also the operand of the adapter's weight gradient) -> . W2 -> da1
+// (bf16 [M, 64]), 64 points per workgroup.  The kv LayerNorm's parameter gradients leave as per-workgroup partial rows
+// (folded by vpf_ln_pgrad_reduce); the two weight-gradient GEMMs (dkv x nk, dxkv x a1) stay GEMMs and the 3 -> 64 front's
+// backward stays vpf_adapter_front_bwd (a per-workgroup fold of its 704 parameter-gradient sums costs more than it saves).
+__global__ void __launch_bounds__(512) adapter_kv_bwd_kernel(VpfAdapterKvBwd a)
+{
+    constexpr int RB = 2, NJ = 1, TOK = 64, NT = 512;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* actA = lds;                                 // two [TOK][ALD] buffers: dk | dv rows, then dxkv in buffer 0
+    float* sStat2 = reinterpret_cast<float*>(lds + 2 * TOK * ALD);  // [TOK][8] float2
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    const long M = a.M, m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, M - m0);
+
+    SaWPre<NJ> wpre;
+    sa_wprefetch((const bf16_t*)a.WkvT, 2 * SA_D / 16, 0, wave, wpre);
+    {   // stage both halves of the dkv rows (coalesced 16-byte loads, all in flight together)
+        uint4 r[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = threadIdx.x + it * NT, part = e >> 11, row = (e >> 5) & 63, ch = e & 31;
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dkv + (size_t)(m0 + row) * (2 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = threadIdx.x + it * NT, part = e >> 11, row = (e >> 5) & 63, ch = e & 31;
+            *reinterpret_cast<uint4*>(actA + part * TOK * ALD + row * ALD + ch * 8) = r[it];
+        }
+    }
+    __syncthreads();
+    f32x16_t acc[NJ][RB];
+    sa_zero<RB, NJ>(acc);
+    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WkvT, 2 * SA_D / 16, 0, wave, actA, acc, wpre);
+    sa_wprefetch((const bf16_t*)a.WkvT, 2 * SA_D / 16, 16, wave, wpre);
+    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WkvT, 2 * SA_D / 16, 16, wave, actA + TOK * ALD, acc, wpre);
+    if (wave < 2) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, wave, wpre);
+    // the unfused path stores dnk as bf16 before the LayerNorm backward: round the same way
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][i][r] = bf16_to_f32(f32_to_bf16(acc[0][i][r]));
+    sa_layernorm_bwd<RB, NJ, true>(acc, reinterpret_cast<const float*>(a.xkv), a.mean, a.rstd, a.lnkv_g, sStat2, a.pgrad_kv + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+    // (the exchange barrier inside guarantees every wave has finished reading the dk / dv rows)
+    sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.dxkv, SA_D, 0, m0, nvalid);
+    __syncthreads();
+    // ---- da1 = dxkv . W2   (64 hidden channels: waves 0 and 1), stored as bf16 like the unfused dgrad output
+    if (wave < 2) {
+        sa_zero<RB, NJ>(acc);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2T, SA_D / 16, 0, wave, actA, acc, wpre);
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 u;
+                u.x = pack_bf16x2(acc[0][i][4 * g + 0], acc[0][i][4 * g + 1]);
+                u.y = pack_bf16x2(acc[0][i][4 * g + 2], acc[0][i][4 * g + 3]);
+                if (i * 32 + t < nvalid) *reinterpret_cast<uint2*>((bf16_t*)a.da1 + (size_t)(m0 + i * 32 + t) * 64 + 32 * wave + 8 * g + 4 * hl) = u;
+            }
+    }
+}
+
+extern "C" int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfAdapterKvBwd& a = *args;
+    if (!a.dkv || !a.WkvT || !a.xkv || !a.mean || !a.rstd || !a.lnkv_g || !a.W2T || !a.dxkv || !a.da1 || !a.pgrad_kv) return VPF_ERR_NULL;
+    if (a.M <= 0) return VPF_ERR_BADSHAPE;
+    if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
+    constexpr int TOK = 64;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)adapter_kv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL(adapter_kv_bwd_kernel, dim3((int)vpf_cdiv(a.M, (long)TOK)), dim3(512), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

@@ -142,6 +142,13 @@ __global__ void __launch_bounds__(1024) adapter_front_fold_kernel(const float* _
         else if (grp - 3 < C) atomicAdd(dW + lane * C + (grp - 3), t);
     }
 }
+// dW1 / db1 / dgamma / dbeta += the fold of nblk partial rows of 704 floats (used by vpf_adapter_front_bwd and vpf_adapter_kv_bwd)
+int vpf_adapter_front_fold(const float* partial, int nblk, int C, float* dW, float* db, float* dgamma, float* dbeta, void* stream)
+{
+    hipLaunchKernelGGL(adapter_front_fold_kernel, dim3(3 + AD_MAXC, 8), dim3(1024), 0, (hipStream_t)stream, partial, nblk, C, dW, db, dgamma, dbeta);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
 extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b,
                                      const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta,
                                      float* ws, long ws_floats, void* stream)

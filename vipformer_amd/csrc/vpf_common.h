@@ -226,3 +226,6 @@ __device__ __forceinline__ float vpf_gelu_grad(float x)
     const float cdf = 0.5f * (1.0f + vpf_erf_fast(x * 0.70710678118654752f, g));
     return cdf + x * 0.39894228040143268f * g;      // g = exp(-x^2 / 2)
 }
+// small.hip: fold of the adapter front's per-workgroup partial parameter gradients (host-side helper shared by two entry points)
+int vpf_adapter_front_fold(const float* partial, int nblk, int C, float* dW, float* db, float* dgamma, float* dbeta, void* stream);
+

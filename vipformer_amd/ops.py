@@ -1058,13 +1058,16 @@ class AdapterKVFn(torch.autograd.Function):
         pack_params(qkvw)
         w16 = shadow(qkvw)
         pk = getattr(adapter, "_vpf_packed_kv", None)
+        n2, nkv = D * 64, 2 * D * D
         if pk is None or pk.device != dev:
-            pk = torch.empty(D * 64 + 2 * D * D, dtype=BF16, device=dev)
+            pk = torch.empty(2 * (n2 + nkv), dtype=BF16, device=dev)        # W2 | Wkv | W2T | WkvT  (fragment order)
             adapter._vpf_packed_kv = pk
         jobs = (L.PackJob * 64)()
-        jobs[0].src, jobs[0].dst, jobs[0].N, jobs[0].K = shadow([l3.weight]).data_ptr(), pk[:D * 64].data_ptr(), D, 64
-        jobs[1].src, jobs[1].dst, jobs[1].N, jobs[1].K = w16[D * D:].data_ptr(), pk[D * 64:].data_ptr(), 2 * D, D
-        L.call_struct("vpf_pack_wfrag", jobs, 2)
+        w2 = shadow([l3.weight])
+        for i, (src, off, rows_, depth_, tr) in enumerate(((w2, 0, D, 64, 0), (w16[D * D:], n2, 2 * D, D, 0),
+                                                           (w2, n2 + nkv, 64, D, 1), (w16[D * D:], 2 * n2 + nkv, D, 2 * D, 1))):
+            jobs[i].src, jobs[i].dst, jobs[i].N, jobs[i].K, jobs[i].transposed = src.data_ptr(), pk[off:].data_ptr(), rows_, depth_, tr
+        L.call_struct("vpf_pack_wfrag", jobs, 4)
         a1 = torch.empty(M, 64, dtype=BF16, device=dev)
         xkv = torch.empty(M, D, dtype=BF16, device=dev)
         mk = torch.empty(M, dtype=F32, device=dev)
@@ -1074,10 +1077,11 @@ class AdapterKVFn(torch.autograd.Function):
         a = L.AdapterKv()
         a.M, a.C, a.D = M, C, D
         a.x, a.W1, a.b1, a.ln_g, a.ln_b = x.data_ptr(), l0.weight.data.data_ptr(), l0.bias.data.data_ptr(), ln.weight.data.data_ptr(), ln.bias.data.data_ptr()
-        a.W2, a.b2, a.lnkv_g, a.lnkv_b, a.Wkv = pk.data_ptr(), l3.bias.data.data_ptr(), lnkv.weight.data.data_ptr(), lnkv.bias.data.data_ptr(), pk[D * 64:].data_ptr()
+        a.W2, a.b2, a.lnkv_g, a.lnkv_b, a.Wkv = pk.data_ptr(), l3.bias.data.data_ptr(), lnkv.weight.data.data_ptr(), lnkv.bias.data.data_ptr(), pk[n2:].data_ptr()
         a.a1, a.xkv, a.mean, a.rstd, a.nk, a.kv = a1.data_ptr(), xkv.data_ptr(), mk.data_ptr(), rk.data_ptr(), nk.data_ptr(), kv.data_ptr()
         L.call_struct("vpf_adapter_kv_fwd", a)
         ctx.mods = (adapter, cross)
+        ctx.packed = pk
         ctx.save_for_backward(x, a1, xkv, mk, rk, nk)
         return kv.view(B, N, 2 * D)
 
@@ -1092,6 +1096,30 @@ class AdapterKVFn(torch.autograd.Function):
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         w16, gW = shadow(qkvw), packed_grad(qkvw)
         dkv = to_bf16(dkv).view(M, 2 * D)
+        if ADAPTER_KV_BWD_FUSED[0]:
+            pk = ctx.packed
+            n2, nkv = D * 64, 2 * D * D
+            nwg = (M + 63) // 64
+            dy16 = torch.empty(M, D, dtype=BF16, device=x.device)
+            pg = torch.empty(nwg * 2 * D, dtype=F32, device=x.device)
+            da = torch.empty(M, 64, dtype=BF16, device=x.device)
+            a = L.AdapterKvBwd()
+            a.M, a.C, a.D = M, C, D
+            a.dkv, a.WkvT, a.xkv, a.mean, a.rstd, a.lnkv_g = dkv.data_ptr(), pk[2 * n2 + nkv:].data_ptr(), xkv.data_ptr(), mk.data_ptr(), rk.data_ptr(), lnkv.weight.data.data_ptr()
+            a.W2T = pk[n2 + nkv:].data_ptr()
+            a.dxkv, a.da1, a.pgrad_kv = dy16.data_ptr(), da.data_ptr(), pg.data_ptr()
+            L.call_struct("vpf_adapter_kv_bwd", a)
+            ws = torch.empty(2048 * 64 * 11, dtype=F32, device=x.device)
+            L.call("vpf_adapter_front_bwd", x, da, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data,
+                   grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias), ws, ws.numel())
+            pj = (L.PgradJob * 32)()
+            pj[0].partials, pj[0].rows, pj[0].dgamma, pj[0].dbeta = pg.data_ptr(), nwg, grad_buf(lnkv.weight).data_ptr(), grad_buf(lnkv.bias).data_ptr()
+            L.call_struct("vpf_ln_pgrad_reduce", pj, 1)
+            wg = WgradBatch()
+            wg.add(dkv, nk, 2 * D, D, gW[D * D:])
+            wg.add(dy16, a1, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
+            wg.flush()
+            return (None, None, None) + (None,) * ctx.nparams
         linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
         dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
         dy16 = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True).view(M, D)
@@ -1104,6 +1132,7 @@ class AdapterKVFn(torch.autograd.Function):
 
 
 ADAPTER_KV_FUSED = [True]
+ADAPTER_KV_BWD_FUSED = [True]
 
 
 def adapter_kv_supported(adapter, pts) -> bool:
