@@ -844,9 +844,14 @@ __global__ void rowsum_mod_kernel(const float* __restrict__ x, long rows, int D,
     const long total = (long)period * D;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int d = (int)(i % D); const long t = i / D;
-        float s = 0.f;
-        for (long r = t; r < rows; r += period) s += x[(size_t)r * D + d];
-        acc[i] += s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long r = t;
+        for (; r + 3 * (long)period < rows; r += 4 * (long)period) {        // 4 loads in flight
+            s0 += x[(size_t)r * D + d]; s1 += x[(size_t)(r + period) * D + d];
+            s2 += x[(size_t)(r + 2 * (long)period) * D + d]; s3 += x[(size_t)(r + 3 * (long)period) * D + d];
+        }
+        for (; r < rows; r += period) s0 += x[(size_t)r * D + d];
+        acc[i] += (s0 + s1) + (s2 + s3);
     }
 }
 extern "C" int vpf_rowsum_mod_f32(const float* x, long rows, int D, int period, float* acc, void* stream)

@@ -192,24 +192,30 @@ extern "C" int vpf_smallk_fwd(const float* x, long M, int C, const float* W, con
     return VPF_OK;
 }
 // dy bf16 [M,N] -> dW[N,C] +=, db[N] +=.   thread = output channel n, block = row slab
-__global__ void smallk_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, long M, int C, const float* __restrict__ W,
-                                  const float* __restrict__ b, int N, int act, float* __restrict__ dW, float* __restrict__ db, int rows_per_block)
+// block = bx output channels x 8 row lanes (blockDim = (bx, 8)); a block owns `rows_per_block` rows, row lane rl walks rows
+// r0 + rl, r0 + rl + 8, ... four at a time; the 8 row lanes meet in LDS and ONE atomic per value and block leaves the CU
+// (one thread per channel walking the whole slab, and hundreds of blocks adding into the same addresses, was 10x slower)
+__global__ void __launch_bounds__(1024) smallk_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, long M, int C,
+                                                         const float* __restrict__ W, const float* __restrict__ b, int N, int act,
+                                                         float* __restrict__ dW, float* __restrict__ db, int rows_per_block)
 {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float fold[8][9][128];
+    const int tn = threadIdx.x, rl = threadIdx.y;
+    const int n = blockIdx.x * blockDim.x + tn;
+    const bool nok = n < N;
     float w[8], aw[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { w[j] = j < C ? W[n * C + j] : 0.f; aw[j] = 0.f; }
-    const float bb = b[n];
+    for (int j = 0; j < 8; ++j) { w[j] = (nok && j < C) ? W[n * C + j] : 0.f; aw[j] = 0.f; }
+    const float bb = nok ? b[n] : 0.f;
     float ab = 0.f;
     const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (long r = r0; r < r1; r += 8) {      // 8 rows in flight (one row at a time serialises the load latencies)
-        float gv[8];
+    for (long r = r0 + rl; r < r1; r += 32) {
+        float gv[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) gv[q] = r + q < r1 ? bf16_to_f32(dy[(size_t)(r + q) * N + n]) : 0.f;
+        for (int q = 0; q < 4; ++q) gv[q] = (nok && r + 8 * q < r1) ? bf16_to_f32(dy[(size_t)(r + 8 * q) * N + n]) : 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const long rr = r + q < r1 ? r + q : r1 - 1;
+        for (int q = 0; q < 4; ++q) {
+            const long rr = r + 8 * q < r1 ? r + 8 * q : r1 - 1;
             float xv[8];
             float u = bb;
 #pragma unroll
@@ -221,9 +227,24 @@ __global__ void smallk_bwd_kernel(const float* __restrict__ x, const bf16_t* __r
             for (int j = 0; j < 8; ++j) aw[j] += g * xv[j];
         }
     }
-    atomicAdd(db + n, ab);
+    fold[rl][0][tn] = ab;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (j < C) atomicAdd(dW + n * C + j, aw[j]);
+    for (int j = 0; j < 8; ++j) fold[rl][1 + j][tn] = aw[j];
+    __syncthreads();
+    if (rl == 0 && nok) {
+        float t0 = 0.f, tw[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tw[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            t0 += fold[k][0][tn];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tw[j] += fold[k][1 + j][tn];
+        }
+        atomicAdd(db + n, t0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < C) atomicAdd(dW + n * C + j, tw[j]);
+    }
 }
 extern "C" int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C, const float* W, const float* b, int N, int act,
                               float* dW, float* db, void* stream)
@@ -232,11 +253,11 @@ extern "C" int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C
     if (!x || !dy_bf16 || !W || !b || !dW || !db) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > 8 || N <= 0) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
-    int rpb = 64;
-    while ((M + rpb - 1) / rpb > 8192) rpb *= 2;
-    const int bx = N >= 256 ? 256 : (N >= 128 ? 128 : 64);
+    int rpb = 512;                                   // 8 row lanes x 64 rows each
+    while ((M + rpb - 1) / rpb > 4096) rpb *= 2;
+    const int bx = N >= 128 ? 128 : 64;
     dim3 grid(vpf_cdiv(N, bx), (unsigned)((M + rpb - 1) / rpb));
-    hipLaunchKernelGGL(smallk_bwd_kernel, grid, dim3(bx), 0, (hipStream_t)stream, x, (const bf16_t*)dy_bf16, M, C, W, b, N, act, dW, db, rpb);
+    hipLaunchKernelGGL(smallk_bwd_kernel, grid, dim3(bx, 8), 0, (hipStream_t)stream, x, (const bf16_t*)dy_bf16, M, C, W, b, N, act, dW, db, rpb);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
