@@ -5,6 +5,7 @@
 // keeps that true if the flag is ever dropped).
 #pragma clang fp contract(off)
 #include "vpf_common.h"
+#include <stdlib.h>
 
 // =============================================================================== FPS
 // One workgroup per cloud.  The cloud's xyz is staged once into LDS (SoA, coalesced HBM read:
@@ -291,6 +292,149 @@ __global__ void __launch_bounds__(256) knn_group_kernel(const float* __restrict_
     }
 }
 
+// wave-wide sum of a small per-lane count (single-instruction DPP adds, result broadcast through lane 63)
+__device__ __forceinline__ uint32_t wave_sum_u32_asm(uint32_t v)
+{
+    asm volatile("s_nop 4\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// kNN by SELECTION instead of K successive wave-wide minimum extractions (the extraction loop costs ~170 VALU instructions
+// per neighbour): the K-th smallest distance T is found by a most-significant-bit-first bisection over the sortable
+// distance bits (one wave-wide count per bit, starting below the bits all candidates share), ties at T are resolved
+// towards the lowest indices by a second, 12-bit bisection (only when there ARE more ties than open slots), the selected
+// keys are compacted through LDS and a 64-lane bitonic sort puts them in the canonical order (ascending distance, ties ->
+// lower index).  Same results as knn_group_kernel bit for bit; ~3.5x fewer instructions.
+template <int PPL>
+__global__ void __launch_bounds__(256) knn_group_select_kernel(const float* __restrict__ xyz, int N, int C,
+                                                              const float* __restrict__ centers, int Cc, int G, int K,
+                                                              int quirk, int centres_per_wg, int64_t* __restrict__ knn_idx,
+                                                              float* __restrict__ knn_dist, float* __restrict__ neighbors)
+{
+    extern __shared__ float smem[];
+    float* sx = smem;
+    float* sy = sx + N;
+    float* sz = sy + N;
+    float* sn = sz + N;
+    unsigned long long* sSel = reinterpret_cast<unsigned long long*>(sn + N + (N & 1));     // [4 waves][64] selected keys
+    uint32_t* sCnt = reinterpret_cast<uint32_t*>(sSel + 4 * 64);                             // [4] compaction cursors
+    const int parts = gridDim.x, nclouds = gridDim.y;
+    int b, part;
+    {
+        const int L = blockIdx.y * parts + blockIdx.x;                 // linear id (XCD-aware mapping, see knn_group_kernel)
+        const int full = (nclouds / 8) * 8;
+        const int slot = L / 8, xcd = L % 8;
+        if (L < full * parts) { b = (slot / parts) * 8 + xcd; part = slot % parts; }
+        else { const int r = L - full * parts; b = full + r / parts; part = r % parts; }
+    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* p = xyz + (size_t)b * N * C;
+    for (int i = t; i < N; i += 256) {
+        const float x = p[(size_t)i * C + 0], y = p[(size_t)i * C + 1], z = p[(size_t)i * C + 2];
+        sx[i] = x; sy[i] = y; sz[i] = z; sn[i] = sq3(x, y, z);
+    }
+    __syncthreads();
+
+    unsigned long long* mySel = sSel + wave * 64;
+    const int g0 = part * centres_per_wg;
+    const int g1 = min(G, g0 + centres_per_wg);
+    for (int g = g0 + wave; g < g1; g += 4) {
+        const float* c = centers + ((size_t)b * G + g) * Cc;
+        const float c0 = c[0], c1 = c[1], c2 = c[2];
+        const float cn = sq3(c0, c1, c2);
+        uint32_t dk[PPL];                       // sortable distance bits; padding = 0xffffffff
+        uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const int i = lane + j * 64;
+            dk[j] = i < N ? f32_sortable(sqdist3(c0, c1, c2, cn, sx[i], sy[i], sz[i], sn[i])) : 0xffffffffu;
+            lo = min(lo, dk[j]);
+            if (i < N) hi = max(hi, dk[j]);
+        }
+        // bits above the highest bit in which min and max differ are shared by every candidate
+        const uint32_t wlo = (uint32_t)wave_min_u32_asm(lo);
+        uint32_t whi;
+        { uint32_t nh = ~hi; nh = wave_min_u32_asm(nh); whi = ~nh; }
+        const uint32_t diff = wlo ^ whi;
+        int top = diff ? 31 - __builtin_clz(diff) : -1;
+        uint32_t T = top >= 0 ? (wlo & ~((2u << top) - 1u)) : wlo;      // common prefix
+        if (top == 31) T = 0u;
+        for (int bit = top; bit >= 0; --bit) {
+            const uint32_t cand = T | (1u << bit);
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PPL; ++j) cnt += dk[j] < cand ? 1u : 0u;
+            if (wave_sum_u32_asm(cnt) < (uint32_t)K) T = cand;
+        }
+        // T = K-th smallest distance.  c_lt candidates are strictly closer; the remaining slots go to ties, lowest index first
+        uint32_t clt = 0, ceq = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) { clt += dk[j] < T ? 1u : 0u; ceq += dk[j] == T ? 1u : 0u; }
+        clt = wave_sum_u32_asm(clt); ceq = wave_sum_u32_asm(ceq);
+        const uint32_t slots = (uint32_t)K - clt;                   // >= 1
+        uint32_t ilim = 0xffffffffu;                                // ties with index <= ilim are taken
+        if (ceq > slots) {
+            uint32_t I = 0;                                         // slots-th smallest index among the ties
+            for (int bit = 12; bit >= 0; --bit) {
+                const uint32_t cand = I | (1u << bit);
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int j = 0; j < PPL; ++j) cnt += (dk[j] == T && (uint32_t)(lane + j * 64) < cand) ? 1u : 0u;
+                if (wave_sum_u32_asm(cnt) < slots) I = cand;
+            }
+            ilim = I;
+        }
+        // compaction (order irrelevant: sorted below)
+        if (lane == 0) sCnt[wave] = 0;
+        uint32_t mycnt = 0;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) mycnt += (dk[j] < T || (dk[j] == T && (uint32_t)(lane + j * 64) <= ilim)) ? 1u : 0u;
+        uint32_t pos = mycnt ? atomicAdd(&sCnt[wave], mycnt) : 0u;
+#pragma unroll
+        for (int j = 0; j < PPL; ++j) {
+            const uint32_t i = (uint32_t)(lane + j * 64);
+            if (dk[j] < T || (dk[j] == T && i <= ilim)) { mySel[pos & 63] = ((unsigned long long)dk[j] << 32) | i; ++pos; }
+        }
+        unsigned long long key = lane < K ? mySel[lane] : ~0ull;
+        // 64-lane bitonic sort, ascending
+#pragma unroll
+        for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+            for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)key, j2, 64);
+                const uint32_t ohi = (uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), j2, 64);
+                const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+                const bool up = (lane & k2) == 0;                    // this block sorts ascending
+                const bool lower = (lane & j2) == 0;                 // this lane keeps the smaller of the pair when ascending
+                const bool take_min = up == lower;
+                const unsigned long long mn = key < other ? key : other, mx = key < other ? other : key;
+                key = take_min ? mn : mx;
+            }
+        }
+        if (lane < K) {
+            const int j = (int)(key & 0xffffffffull);
+            const size_t o = ((size_t)b * G + g) * K + lane;
+            if (knn_idx) knn_idx[o] = (int64_t)j;
+            if (knn_dist) knn_dist[o] = sortable_f32((uint32_t)(key >> 32));
+            if (neighbors) {
+                const bool sub = quirk && lane < 3;
+                float* dstp = neighbors + o * C;
+                const float* srcp = p + (size_t)j * C;
+                for (int ch = 0; ch < C; ++ch) {
+                    const float v = srcp[ch];
+                    dstp[ch] = sub ? (v - c[ch]) : v;
+                }
+            }
+        }
+    }
+}
+
 extern "C" int vpf_knn_group_f32(const float* xyz, int B, int N, int C, const float* centers, int Cc, int G, int K,
                                  int apply_ref_axis_quirk, int64_t* knn_idx, float* knn_dist, float* neighbors,
                                  void* stream)
@@ -306,15 +450,19 @@ extern "C" int vpf_knn_group_f32(const float* xyz, int B, int N, int C, const fl
     int cpw = 4;
     while ((long)B * vpf_cdiv(G, cpw) > 2048 && cpw < G) cpw *= 2;
     dim3 grid(vpf_cdiv(G, cpw), B);
-    const size_t lds = sizeof(float) * 4 * (size_t)N;
+    static int sel = -1;
+    if (sel < 0) { const char* e = getenv("VPF_KNN_SELECT"); sel = e ? atoi(e) : 1; }
+    const size_t lds = sizeof(float) * (4 * (size_t)N + 2) + (sel ? sizeof(unsigned long long) * 4 * 64 + 16 : 0);
 #define VPF_KNN_LAUNCH(PPL)                                                                                      \
-    hipLaunchKernelGGL((knn_group_kernel<PPL>), grid, dim3(256), lds, st, xyz, N, C, centers, Cc, G, K,            \
-                       apply_ref_axis_quirk, cpw, knn_idx, knn_dist, neighbors)
-    if (N <= 256) VPF_KNN_LAUNCH(4);
-    else if (N <= 512) VPF_KNN_LAUNCH(8);
-    else if (N <= 1024) VPF_KNN_LAUNCH(16);
-    else if (N <= 2048) VPF_KNN_LAUNCH(32);
-    else VPF_KNN_LAUNCH(64);
+    if (sel) hipLaunchKernelGGL((knn_group_select_kernel<PPL>), grid, dim3(256), lds, st, xyz, N, C, centers, Cc, G, K,  \
+                                apply_ref_axis_quirk, cpw, knn_idx, knn_dist, neighbors);                           \
+    else hipLaunchKernelGGL((knn_group_kernel<PPL>), grid, dim3(256), lds, st, xyz, N, C, centers, Cc, G, K,        \
+                            apply_ref_axis_quirk, cpw, knn_idx, knn_dist, neighbors)
+    if (N <= 256) { VPF_KNN_LAUNCH(4); }
+    else if (N <= 512) { VPF_KNN_LAUNCH(8); }
+    else if (N <= 1024) { VPF_KNN_LAUNCH(16); }
+    else if (N <= 2048) { VPF_KNN_LAUNCH(32); }
+    else { VPF_KNN_LAUNCH(64); }
 #undef VPF_KNN_LAUNCH
     VPF_CHECK_LAUNCH();
     return VPF_OK;
