@@ -254,6 +254,13 @@ int vpf_ntxent_fwd(const float* z0, const float* z1, int b, int D, float tempera
                    float* loss_rows, float* loss, void* stream);
 int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b, int D, float temperature, const float* dloss,
                    float* dz0, float* dz1, void* stream);
+/* nn.BatchNorm1d (+ ReLU) over a SMALL batch (M <= 4096 rows, C % 64 == 0: the projection heads, partseg.py:519-525) in training
+ * mode as one kernel each way: batch statistics, running-statistics update and normalisation (stat = mean | rstd is kept for the
+ * backward); backward: dx (bf16 or f32, may be NULL) and dgamma / dbeta += . */
+int vpf_bn_small_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, long long* num_batches, float* stat, void* y_bf16, int relu, void* stream);
+int vpf_bn_small_bwd(const float* dy, const float* x, const float* stat, const float* gamma, const float* beta, int M, int C, int relu,
+                     void* dx, int dx_is_bf16, float* dgamma, float* dbeta, void* stream);
 /* Both pre-training losses in one go (pretrain.py:196-204): f f32 [2b,D] = the two point-cloud views stacked, g f32 [b,D] =
  * the image features; total f32[1] = imid + w*cmid, parts f32[2] = {imid = NTXent(f[:b], f[b:]), cmid = NTXent((f[:b]+f[b:])/2, g)}.
  * Workspaces: zn [2,2b,D], inv_norm [2,2b], P [2,2b,2b], loss_rows [2,2b]; bwd: ws_dz [2,2b,D], df [2b,D], dg [b,D] from

@@ -864,3 +864,120 @@ extern "C" int vpf_rowsum_mod_f32(const float* x, long rows, int D, int period, 
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
+
+// =============================================================================== BatchNorm over a small batch, one kernel
+// nn.BatchNorm1d (+ ReLU) of the projection heads (partseg.py:519-525) in training mode: the batch is 64 .. 256 rows, so a
+// block owning 64 channels can do everything -- batch statistics, running-statistics update, normalisation + ReLU -- by
+// itself (BatchNorm is per channel), instead of a zero-fill, a column-sum, a finalize and an apply launch.
+// Block = 64 channels x 8 row lanes (512 threads), fixed-order folds (deterministic).
+__global__ void __launch_bounds__(512) bn_small_fwd_kernel(const float* __restrict__ x, int M, int C, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          long long* __restrict__ num_batches, float* __restrict__ stat,
+                                                          bf16_t* __restrict__ y, int relu)
+{
+    __shared__ float fs[8][64], fq[8][64];
+    __shared__ float smu[64], srs[64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int r = rl;
+    for (; r + 8 < M; r += 16) {
+        const float a = x[(size_t)r * C + c], b = x[(size_t)(r + 8) * C + c];
+        s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+    }
+    for (; r < M; r += 8) { const float a = x[(size_t)r * C + c]; s0 += a; q0 += a * a; }
+    fs[rl][cl] = s0 + s1; fq[rl][cl] = q0 + q1;
+    __syncthreads();
+    if (rl == 0) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s += fs[k][cl]; q += fq[k][cl]; }
+        const float mu = s / (float)M;
+        float var = q / (float)M - mu * mu;
+        var = var < 0.f ? 0.f : var;
+        const float rs = rsqrtf(var + eps);
+        smu[cl] = mu; srs[cl] = rs;
+        stat[c] = mu; stat[C + c] = rs;
+        if (running_mean) {
+            const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+        }
+        if (num_batches && blockIdx.x == 0 && cl == 0) *num_batches += 1;
+    }
+    __syncthreads();
+    const float mu = smu[cl], rs = srs[cl], ga = gamma[c], be = beta[c];
+    for (r = rl; r < M; r += 8) {
+        float v = (x[(size_t)r * C + c] - mu) * rs * ga + be;
+        if (relu) v = fmaxf(v, 0.f);
+        y[(size_t)r * C + c] = f32_to_bf16(v);
+    }
+}
+extern "C" int vpf_bn_small_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
+                                float* running_mean, float* running_var, long long* num_batches, float* stat, void* y_bf16, int relu,
+                                void* stream)
+{
+    (void)hipGetLastError();
+    if (!x || !gamma || !beta || !stat || !y_bf16) return VPF_ERR_NULL;
+    if (M <= 0 || M > 4096 || C <= 0 || (C % 64)) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C / 64), dim3(512), 0, (hipStream_t)stream, x, M, C, gamma, beta, eps, momentum, running_mean,
+                       running_var, num_batches, stat, (bf16_t*)y_bf16, relu);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// backward of the same (training mode): g = dy * relu'(y); dx = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat));
+// dgamma += sum(g * xhat), dbeta += sum(g)   (one block per 64 channels: the single writer of its columns)
+template <typename TDX>
+__global__ void __launch_bounds__(512) bn_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stat,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int M, int C, int relu,
+                                                          TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    __shared__ float fs[8][64], fq[8][64];
+    __shared__ float ssum[64], sqsum[64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const float mu = stat[c], rs = stat[C + c], ga = gamma[c], be = beta[c];
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    int r = rl;
+    for (; r + 8 < M; r += 16) {
+        const float xa = (x[(size_t)r * C + c] - mu) * rs, xb = (x[(size_t)(r + 8) * C + c] - mu) * rs;
+        float ga_ = dy[(size_t)r * C + c], gb_ = dy[(size_t)(r + 8) * C + c];
+        if (relu && (xa * ga + be) <= 0.f) ga_ = 0.f;
+        if (relu && (xb * ga + be) <= 0.f) gb_ = 0.f;
+        s0 += ga_; q0 += ga_ * xa; s1 += gb_; q1 += gb_ * xb;
+    }
+    for (; r < M; r += 8) {
+        const float xa = (x[(size_t)r * C + c] - mu) * rs;
+        float ga_ = dy[(size_t)r * C + c];
+        if (relu && (xa * ga + be) <= 0.f) ga_ = 0.f;
+        s0 += ga_; q0 += ga_ * xa;
+    }
+    fs[rl][cl] = s0 + s1; fq[rl][cl] = q0 + q1;
+    __syncthreads();
+    if (rl == 0) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s += fs[k][cl]; q += fq[k][cl]; }
+        ssum[cl] = s; sqsum[cl] = q;
+        if (dgamma) { dgamma[c] += q; dbeta[c] += s; }
+    }
+    __syncthreads();
+    if (!dx) return;
+    const float sm = ssum[cl] / (float)M, qm = sqsum[cl] / (float)M;
+    for (r = rl; r < M; r += 8) {
+        const float xh = (x[(size_t)r * C + c] - mu) * rs;
+        float g = dy[(size_t)r * C + c];
+        if (relu && (xh * ga + be) <= 0.f) g = 0.f;
+        st_f<TDX>(dx, (size_t)r * C + c, ga * rs * (g - sm - xh * qm));
+    }
+}
+extern "C" int vpf_bn_small_bwd(const float* dy, const float* x, const float* stat, const float* gamma, const float* beta, int M, int C,
+                                int relu, void* dx, int dx_is_bf16, float* dgamma, float* dbeta, void* stream)
+{
+    (void)hipGetLastError();
+    if (!dy || !x || !stat || !gamma || !beta) return VPF_ERR_NULL;
+    if (M <= 0 || M > 4096 || C <= 0 || (C % 64)) return VPF_ERR_BADSHAPE;
+    if (dx_is_bf16) hipLaunchKernelGGL(bn_small_bwd_kernel<bf16_t>, dim3(C / 64), dim3(512), 0, (hipStream_t)stream, dy, x, stat, gamma, beta, M, C, relu, (bf16_t*)dx, dgamma, dbeta);
+    else hipLaunchKernelGGL(bn_small_bwd_kernel<float>, dim3(C / 64), dim3(512), 0, (hipStream_t)stream, dy, x, stat, gamma, beta, M, C, relu, (float*)dx, dgamma, dbeta);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}

@@ -1493,11 +1493,22 @@ class HeadFn(torch.autograd.Function):
         Bn, C1 = x.shape
         C2, C3 = l1.weight.shape[0], l2.weight.shape[0]
         x = x.contiguous().float()
-        s1 = _bn_stat(x, C1, bn1, training)
-        a1 = _bn_act(x, C1, s1, bn1, True, True)
+        small = training and Bn <= 4096 and C1 % 64 == 0 and C2 % 64 == 0
+        ctx.small = small
+
+        def bn_relu(t, C, bn):
+            if not small:
+                st = _bn_stat(t, C, bn, training)
+                return st, _bn_act(t, C, st, bn, True, True)
+            st = torch.empty(2 * C, dtype=F32, device=t.device)
+            y_ = torch.empty(Bn, C, dtype=BF16, device=t.device)
+            L.call("vpf_bn_small_fwd", t, Bn, C, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), bn.running_mean,
+                   bn.running_var, bn.num_batches_tracked, st, y_, 1)
+            return st, y_
+
+        s1, a1 = bn_relu(x, C1, bn1)
         h = linear_fwd(a1, shadow([l1.weight]), C2, C1, l1.bias.data if l1.bias is not None else None, out_f32=True)
-        s2 = _bn_stat(h, C2, bn2, training)
-        a2 = _bn_act(h, C2, s2, bn2, True, True)
+        s2, a2 = bn_relu(h, C2, bn2)
         y = linear_fwd(a2, shadow([l2.weight]), C3, C2, l2.bias.data if l2.bias is not None else None, out_f32=True)
         ctx.seq, ctx.training = seq, training
         ctx.save_for_backward(x, s1, a1, h, s2, a2)
@@ -1515,12 +1526,21 @@ class HeadFn(torch.autograd.Function):
             colsum(dy16, C3, grad_buf(l2.bias))
         linear_wgrad(dy16, a2, C3, C2, grad_buf(l2.weight))
         da2 = linear_dgrad(dy16, shadow([l2.weight]), C3, C2, out_f32=True)
-        dh = _bn_bwd(da2, h, C2, s2, bn2, True, training, True)
+
+        def bn_bwd(dt, t, C, st, bn, out_bf16):
+            if not ctx.small:
+                return _bn_bwd(dt, t, C, st, bn, True, training, out_bf16)
+            dx_ = torch.empty(t.shape[0], C, dtype=BF16 if out_bf16 else F32, device=t.device)
+            L.call("vpf_bn_small_bwd", dt, t, st, bn.weight.data, bn.bias.data, t.shape[0], C, 1, dx_, int(out_bf16),
+                   grad_buf(bn.weight), grad_buf(bn.bias))
+            return dx_
+
+        dh = bn_bwd(da2, h, C2, s2, bn2, True)
         if l1.bias is not None:
             colsum(dh, C2, grad_buf(l1.bias))
         linear_wgrad(dh, a1, C2, C1, grad_buf(l1.weight))
         da1 = linear_dgrad(dh, shadow([l1.weight]), C2, C1, out_f32=True)
-        dx = _bn_bwd(da1, x, C1, s1, bn1, True, training, False)
+        dx = bn_bwd(da1, x, C1, s1, bn1, False)
         return (dx, None, None) + (None,) * ctx.nparams
 
 
