@@ -82,7 +82,7 @@ def sa():
         layers.train()
         x = torch.randn(B, Lq, 256, device="cuda"); pos = torch.randn(B if tag == "pc" else 1, Lq, 256, device="cuda")
         params = [p for l in layers for p in l.parameters()]
-        dbg = torch.zeros(8, dtype=torch.int64, device="cuda")
+        dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
         for fused, split in ((False, None), (True, False), (True, True)):
             ops.SA_FUSED[0] = fused
             ops.SA_SPLIT_ATTN[0] = split
@@ -98,7 +98,7 @@ def sa():
         ops.SA_DEBUG.append(dbg)
         run(); torch.cuda.synchronize()
         ops.SA_DEBUG.clear()
-        names = ["attention", "o_proj mfma", "drop+res epi", "LN2+store", "MLP", "final epi", "next LN1", "next qkv"]
+        names = ["attention", "o_proj mfma", "drop+res epi", "LN2 maths", "n2 stores", "barrier", "chunk0+fc1(1)", "bias+u+gelu", "barrier", "h stores", "barrier", "fc2(1)", "MLP rest", "final epi", "next LN1", "next qkv"]
         print("   phase cycles (wg 0, layer 4): " + "  ".join(f"{n} {int(c)}" for n, c in zip(names, dbg.tolist())))
     ops.SA_FUSED[0] = True
     ops.SA_SPLIT_ATTN[0] = None

@@ -32,6 +32,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define SA_H 4
 #define SA_DH 64
 #define ALD 264         // LDS row stride (bf16) of a [tokens][256] activation tile (256 + 8 pad)
+#define XLD 260         // LDS row stride (f32) of the [tokens][256] residual tile (256 + 4 pad)
 #define KLD 72          // LDS row stride (bf16) of a [tokens][64] K / V tile
 #define LOG2E 1.4426950408889634f
 #define LN2F 0.6931471805599453f
@@ -273,6 +274,19 @@ __device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[NJ][RB], bf1
             }
 }
 
+// The same tile, row-coalesced: every thread moves 16 B (8 channels) of a row, a wave-instruction writes two whole 512-byte rows.
+// (The accumulator layout above makes a wave-instruction touch 32 rows with 16 bytes each: ~5x the cycles in the address unit.)
+template <int TOK, int NT>
+__device__ __forceinline__ void sa_tile_store_rows(const bf16_t* sAct, bf16_t* __restrict__ G, long ld, int gcol0, long m0, int nvalid)
+{
+#pragma unroll
+    for (int it = 0; it < TOK * 32 / NT; ++it) {
+        const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
+        const uint4 v = *reinterpret_cast<const uint4*>(sAct + row * ALD + ch * 8);
+        if (row < nvalid) *reinterpret_cast<uint4*>(G + (size_t)(m0 + row) * ld + gcol0 + ch * 8) = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ the layer kernel
 // one (head, 32-query block) attention unit of a wave; K / V tiles of the head are in LDS, LPT = padded sequence length
 template <int LPT>
@@ -332,7 +346,7 @@ __device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV,
 // ATT = false: the attention output o is an INPUT (vpf_attention_fwd ran before); a workgroup then owns any RB*32
 // consecutive rows of the [B*L, D] token matrix, needs no K / V tiles and two workgroups fit on a CU.
 template <int RB, int HPR, int LPT, bool ATT, int NJ>
-__global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerFwd a)
+__global__ void __launch_bounds__(64 * (8 / NJ), (RB == 1 ? 4 : (NJ == 1 ? 2 : 1))) sa_layer_fwd_kernel(VpfSaLayerFwd a)
 {
     constexpr int NWV = 8 / NJ, NT = 64 * NWV;          // waves per workgroup: each owns NJ blocks of 32 channels per 256-wide chunk
     static_assert(!ATT || NJ == 2, "the in-kernel attention distributes its units over 4 waves");
@@ -345,6 +359,11 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     bf16_t* actH = reg1;                              // [TOK][ALD]   one 256-wide chunk of the hidden activation
     float* sStatA = reinterpret_cast<float*>(reg1 + TOK * ALD);   // [TOK][NWV]
     float* sStatB = sStatA + TOK * NWV;
+    // XR (no attention inside, one channel block per wave): the f32 residual stream of the workgroup's rows lives in LDS
+    // (base -> x1 -> x1 + pos -> out) and crosses HBM only in row-coalesced passes: in the accumulator layout a wave-instruction
+    // touches 32 rows with 16 .. 32 bytes each, which costs the address unit far more than the bytes do.
+    constexpr bool XR = !ATT && NJ == 1;
+    float* xres = sStatB + TOK * NWV;                 // [TOK][XLD] f32 (XR only)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const int b = blockIdx.x, chunk = blockIdx.y;
@@ -368,6 +387,20 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
         for (int it = 0; it < CPT; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
             r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.o + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+        if constexpr (XR) {                                        // the residual base, row-coalesced, into xres
+            constexpr int XPT = TOK * 64 / NT;
+            float4 rb[XPT];
+#pragma unroll
+            for (int it = 0; it < XPT; ++it) {
+                const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+                rb[it] = row < nvalid ? *reinterpret_cast<const float4*>(a.base + (size_t)(m0 + row) * SA_D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int it = 0; it < XPT; ++it) {
+                const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+                *reinterpret_cast<float4*>(xres + row * XLD + c4 * 4) = rb[it];
+            }
         }
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
@@ -452,7 +485,8 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     // ============================================================ x1 = base + dropout(o . Wo^T + bo);  n2 = LN2(x1)
     {
         // the residual base of every element this lane owns: issued before the GEMM, consumed after it
-        float4 res[NJ][4][RB];
+        float4 res[XR ? 1 : NJ][XR ? 1 : 4][XR ? 1 : RB];
+        if constexpr (!XR) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -464,6 +498,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                     const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                     res[j][g][i] = ok ? *reinterpret_cast<const float4*>(a.base + off) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+        }
         sa_zero<RB, NJ>(acc);
         sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wo, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
         sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, NJ * wave, wpre);           // fc1 chunk 0, ahead of the x1 / n2 stores
@@ -483,7 +518,10 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                     const int tok = i * 32 + t;
                     const bool ok = tok < nvalid;
                     const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + cch;
-                    const float rr[4] = {res[j][g][i].x, res[j][g][i].y, res[j][g][i].z, res[j][g][i].w};
+                    float4 rv;
+                    if constexpr (XR) rv = *reinterpret_cast<const float4*>(xres + tok * XLD + cch);
+                    else rv = res[j][g][i];
+                    const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
                     float v[4];
                     const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
 #pragma unroll
@@ -493,33 +531,58 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                         v[q] = rr[q] + y;
                         acc[j][i][4 * g + q] = v[q];
                     }
-                    if (ok) *reinterpret_cast<float4*>(a.x1 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                    if constexpr (XR) *reinterpret_cast<float4*>(xres + tok * XLD + cch) = make_float4(v[0], v[1], v[2], v[3]);
+                    else if (ok) *reinterpret_cast<float4*>(a.x1 + off) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         SA_STAMP();     // 2: dropout + residual epilogue
         float mean[RB], rstd[RB];
         sa_layernorm<RB, NJ>(acc, a.ln2_g, a.ln2_b, sStatA, sStatB, mean, rstd);
+        SA_STAMP();     // 3a: LayerNorm 2 maths
         if (wave == 0 && hl == 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
                 if (i * 32 + t < nvalid) { a.mean2[m0 + i * 32 + t] = mean[i]; a.rstd2[m0 + i * 32 + t] = rstd[i]; }
         }
         // (the LayerNorm exchange barriers guarantee every wave has finished reading o from actA)
-        sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
+        sa_store_bf16<RB, NJ>(acc, actA, 0, XR ? nullptr : (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
+        SA_STAMP();     // 3b: n2 stores
     }
     __syncthreads();                                           // n2 complete in actA
-    SA_STAMP();     // 3: LayerNorm 2 + store
+    if constexpr (XR) {
+        // x1 leaves for HBM row-coalesced; the positional term of the next base is added on the way: xres = x1 + pos
+        constexpr int XPT = TOK * 64 / NT;
+        float4 pv[XPT];
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            pv[it] = (a.pos && row < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)((m0 + row) % a.pos_rows) * SA_D + c4 * 4)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            float4 v = *reinterpret_cast<const float4*>(xres + row * XLD + c4 * 4);
+            if (row < nvalid) *reinterpret_cast<float4*>(a.x1 + (size_t)(m0 + row) * SA_D + c4 * 4) = v;
+            v.x += pv[it].x; v.y += pv[it].y; v.z += pv[it].z; v.w += pv[it].w;
+            *reinterpret_cast<float4*>(xres + row * XLD + c4 * 4) = v;
+        }
+    }
+    SA_STAMP();     // 3c: barrier
 
     // ============================================================ MLP: two 256-wide chunks of the hidden layer
     f32x16_t acc2[NJ][RB];
     sa_zero<RB, NJ>(acc2);
     // the final epilogue's side inputs (x1, written by this very thread above, and pos): with one channel block per wave there
     // are registers to fetch them BEHIND the last GEMM unit instead of in front of the epilogue
-    float4 resx[NJ][4][RB], resp[NJ][4][RB];
+    float4 resx[XR ? 1 : NJ][XR ? 1 : 4][XR ? 1 : RB], resp[XR ? 1 : NJ][XR ? 1 : 4][XR ? 1 : RB];
     int prow[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) prow[i] = a.pos ? (int)((m0 + i * 32 + t) % a.pos_rows) : 0;
     auto load_final = [&]() {
+        if constexpr (XR) return;
+        else {
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -533,12 +596,14 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                     resp[j][g][i] = (ok && a.pos) ? *reinterpret_cast<const float4*>(a.pos + (size_t)prow[i] * SA_D + cch)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+        }
     };
 #pragma unroll
     for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
         sa_zero<RB, NJ>(acc);
         sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
         sa_wprefetch((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, wpre);   // this chunk's fc2 slice, ahead of the u / h stores
+        if (hc == 1) SA_STAMP();    // 4a: (chunk 0 and) fc1 of chunk 1
         // u = bf16(acc + b1) (saved), h = gelu(u)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -562,12 +627,18 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                     acc[j][i][4 * g + 3] = sa_gelu(__uint_as_float(w.y & 0xffff0000u));
                 }
             }
+        if (hc == 1) SA_STAMP();    // 4b: bias + u store + GELU
         if (hc) __syncthreads();                               // every wave is done reading the previous chunk from actH
-        sa_store_bf16<RB, NJ>(acc, actH, 0, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        if (hc == 1) SA_STAMP();    // 4c: barrier
+        sa_store_bf16<RB, NJ>(acc, actH, 0, XR ? nullptr : (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        if (hc == 1) SA_STAMP();    // 4d: h stores
         __syncthreads();
+        if constexpr (XR) sa_tile_store_rows<TOK, NT>(actH, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        if (hc == 1) SA_STAMP();    // 4e: barrier
         if (NJ == 1 && hc + 1 == SA_HID / SA_D) load_final();
         sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
         if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
+        if (hc == 1) SA_STAMP();    // 4f: fc2 of chunk 1
     }
     if (NJ != 1) load_final();
     const bool nxt = a.qkv_next != nullptr;
@@ -591,8 +662,14 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                     const int tok = i * 32 + t;
                     const bool ok = tok < nvalid;
                     const size_t off = (size_t)(m0 + (ok ? tok : 0)) * SA_D + cch;
-                    const float rr[4] = {resx[j][g][i].x + resp[j][g][i].x, resx[j][g][i].y + resp[j][g][i].y,
-                                         resx[j][g][i].z + resp[j][g][i].z, resx[j][g][i].w + resp[j][g][i].w};
+                    float rr[4];
+                    if constexpr (XR) {
+                        const float4 rv = *reinterpret_cast<const float4*>(xres + tok * XLD + cch);
+                        rr[0] = rv.x; rr[1] = rv.y; rr[2] = rv.z; rr[3] = rv.w;
+                    } else {
+                        rr[0] = resx[j][g][i].x + resp[j][g][i].x; rr[1] = resx[j][g][i].y + resp[j][g][i].y;
+                        rr[2] = resx[j][g][i].z + resp[j][g][i].z; rr[3] = resx[j][g][i].w + resp[j][g][i].w;
+                    }
                     const uint32_t keep = drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
@@ -600,11 +677,25 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                         if (drop) y = ((keep >> q) & 1u) ? y * rng.scale : 0.f;
                         acc2[j][i][4 * g + q] = rr[q] + y;
                     }
-                    if (ok) *reinterpret_cast<float4*>(a.out + off) = make_float4(acc2[j][i][4 * g + 0], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]);
+                    if constexpr (XR) *reinterpret_cast<float4*>(xres + tok * XLD + cch) = make_float4(acc2[j][i][4 * g + 0], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]);
+                    else if (ok) *reinterpret_cast<float4*>(a.out + off) = make_float4(acc2[j][i][4 * g + 0], acc2[j][i][4 * g + 1], acc2[j][i][4 * g + 2], acc2[j][i][4 * g + 3]);
                 }
             }
         SA_STAMP();     // 5: final dropout + residual epilogue
-        if (!nxt) return;
+        auto store_out = [&]() {
+            if constexpr (XR) {
+#pragma unroll
+                for (int it = 0; it < TOK * 64 / NT; ++it) {
+                    const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+                    const float4 v = *reinterpret_cast<const float4*>(xres + row * XLD + c4 * 4);
+                    if (row < nvalid) *reinterpret_cast<float4*>(a.out + (size_t)(m0 + row) * SA_D + c4 * 4) = v;
+                }
+            }
+        };
+        if (!nxt) {
+            if constexpr (XR) { __syncthreads(); store_out(); }
+            return;
+        }
         float mean[RB], rstd[RB];
         sa_layernorm<RB, NJ>(acc2, a.ln1n_g, a.ln1n_b, sStatA, sStatB, mean, rstd);
         if (wave == 0 && hl == 0) {
@@ -612,9 +703,18 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
             for (int i = 0; i < RB; ++i)
                 if (i * 32 + t < nvalid) { a.mean1n[m0 + i * 32 + t] = mean[i]; a.rstd1n[m0 + i * 32 + t] = rstd[i]; }
         }
-        sa_store_bf16<RB, NJ>(acc2, actA, 0, (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
+        sa_store_bf16<RB, NJ>(acc2, actA, 0, XR ? nullptr : (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
     }
     __syncthreads();
+    if constexpr (XR) {
+#pragma unroll
+        for (int it = 0; it < TOK * 64 / NT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            const float4 v = *reinterpret_cast<const float4*>(xres + row * XLD + c4 * 4);
+            if (row < nvalid) *reinterpret_cast<float4*>(a.out + (size_t)(m0 + row) * SA_D + c4 * 4) = v;
+        }
+    }
+    if constexpr (XR) sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);
     SA_STAMP();     // 6: next LayerNorm 1
     // q | k | v of the next layer: the results are held (packed bf16) and stored after the last unit, so that no weight load
     // ever queues behind a batch of stores
@@ -655,7 +755,7 @@ static int sa_launch(const VpfSaLayerFwd& a, int chunks, hipStream_t st)
 {
     const int LP = LPT, TOK = RB * 32;
     const size_t kv = ATT ? (size_t)HPR * 2 * LP * KLD * 2 : 0, mlp = (size_t)TOK * ALD * 2 + (size_t)2 * TOK * (8 / NJ) * 4;
-    const size_t lds = (size_t)TOK * ALD * 2 + (kv > mlp ? kv : mlp);
+    const size_t lds = (size_t)TOK * ALD * 2 + (kv > mlp ? kv : mlp) + ((!ATT && NJ == 1) ? (size_t)TOK * XLD * 4 : 0);
     if (lds > 160 * 1024) return VPF_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
@@ -685,6 +785,9 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     static int nj = -1;
     if (nj < 0) { const char* e = getenv("VPF_SA_NJ"); nj = e ? atoi(e) : 1; }
     if (a.attention_done) {                                                   // o is an input: 64-row blocks, any sequence length
+        static int rb1 = -1;
+        if (rb1 < 0) { const char* e = getenv("VPF_SA_RB"); rb1 = (e && atoi(e) == 1) ? 1 : 0; }
+        if (rb1) return sa_launch<1, 4, 32, false, 1>(a, 1, st);              // 32-row blocks: twice the workgroups, two per CU
         if (nj == 2) return sa_launch<2, 2, 32, false, 2>(a, 1, st);          // 4 waves x 64 channels
         return sa_launch<2, 2, 32, false, 1>(a, 1, st);                       // 8 waves x 32 channels: two waves per SIMD overlap MFMA, VALU and memory waits
     }
