@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define SA_DH 64
 #define ALD 264         // LDS row stride (bf16) of a [tokens][256] activation tile (256 + 8 pad)
 #define XLD 260         // LDS row stride (f32) of the [tokens][256] residual tile (256 + 4 pad)
+#define QLD 776         // LDS row stride (bf16) of the [tokens][768] q | k | v staging tile (768 + 8 pad)
 #define KLD 72          // LDS row stride (bf16) of a [tokens][64] K / V tile
 #define LOG2E 1.4426950408889634f
 #define LN2F 0.6931471805599453f
@@ -604,6 +605,40 @@ __global__ void __launch_bounds__(64 * (8 / NJ), (RB == 1 ? 4 : (NJ == 1 ? 2 : 1
         sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
         sa_wprefetch((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, wpre);   // this chunk's fc2 slice, ahead of the u / h stores
         if (hc == 1) SA_STAMP();    // 4a: (chunk 0 and) fc1 of chunk 1
+        if constexpr (XR) {
+            // u = bf16(acc + b1) goes to actH in the accumulator layout; a row-coalesced pass then sends u to HBM, turns it into
+            // h = gelu(u) in place and sends h to HBM (16 bytes per lane, whole rows per wave-instruction)
+            if (hc) __syncthreads();                           // every wave is done reading the previous chunk from actH
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = 32 * wave + 8 * g + 4 * hl;
+                const float4 b1 = *reinterpret_cast<const float4*>(a.b1 + hc * SA_D + cl);
+#pragma unroll
+                for (int i = 0; i < RB; ++i) {
+                    uint2 w;
+                    w.x = pack_bf16x2(acc[0][i][4 * g + 0] + b1.x, acc[0][i][4 * g + 1] + b1.y);
+                    w.y = pack_bf16x2(acc[0][i][4 * g + 2] + b1.z, acc[0][i][4 * g + 3] + b1.w);
+                    *reinterpret_cast<uint2*>(actH + (i * 32 + t) * ALD + cl) = w;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < TOK * 32 / NT; ++it) {
+                const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
+                const uint4 v = *reinterpret_cast<const uint4*>(actH + row * ALD + ch * 8);
+                const size_t go = (size_t)(m0 + row) * SA_HID + hc * SA_D + ch * 8;
+                if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.u + go) = v;
+                const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+                uint32_t hh[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    hh[q] = pack_bf16x2(sa_gelu(__uint_as_float(vv[q] << 16)), sa_gelu(__uint_as_float(vv[q] & 0xffff0000u)));
+                const uint4 hv = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+                *reinterpret_cast<uint4*>(actH + row * ALD + ch * 8) = hv;
+                if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.h + go) = hv;
+            }
+            __syncthreads();
+        } else {
         // u = bf16(acc + b1) (saved), h = gelu(u)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -630,10 +665,10 @@ __global__ void __launch_bounds__(64 * (8 / NJ), (RB == 1 ? 4 : (NJ == 1 ? 2 : 1
         if (hc == 1) SA_STAMP();    // 4b: bias + u store + GELU
         if (hc) __syncthreads();                               // every wave is done reading the previous chunk from actH
         if (hc == 1) SA_STAMP();    // 4c: barrier
-        sa_store_bf16<RB, NJ>(acc, actH, 0, XR ? nullptr : (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        sa_store_bf16<RB, NJ>(acc, actH, 0, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
         if (hc == 1) SA_STAMP();    // 4d: h stores
         __syncthreads();
-        if constexpr (XR) sa_tile_store_rows<TOK, NT>(actH, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        }
         if (hc == 1) SA_STAMP();    // 4e: barrier
         if (NJ == 1 && hc + 1 == SA_HID / SA_D) load_final();
         sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
@@ -703,21 +738,41 @@ __global__ void __launch_bounds__(64 * (8 / NJ), (RB == 1 ? 4 : (NJ == 1 ? 2 : 1
             for (int i = 0; i < RB; ++i)
                 if (i * 32 + t < nvalid) { a.mean1n[m0 + i * 32 + t] = mean[i]; a.rstd1n[m0 + i * 32 + t] = rstd[i]; }
         }
+        store_out();                  // (the LayerNorm exchange barrier: every wave's part of out is in xres)
         sa_store_bf16<RB, NJ>(acc2, actA, 0, XR ? nullptr : (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
     }
-    __syncthreads();
-    if constexpr (XR) {
-#pragma unroll
-        for (int it = 0; it < TOK * 64 / NT; ++it) {
-            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
-            const float4 v = *reinterpret_cast<const float4*>(xres + row * XLD + c4 * 4);
-            if (row < nvalid) *reinterpret_cast<float4*>(a.out + (size_t)(m0 + row) * SA_D + c4 * 4) = v;
-        }
-    }
+    __syncthreads();                  // n1n complete in actA; actH, the LayerNorm exchange and xres are dead
     if constexpr (XR) sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);
     SA_STAMP();     // 6: next LayerNorm 1
     // q | k | v of the next layer: the results are held (packed bf16) and stored after the last unit, so that no weight load
     // ever queues behind a batch of stores
+    if constexpr (XR) {
+        bf16_t* qst = reg1;                                   // [TOK][QLD] over actH | exchange | xres
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            sa_zero<RB, NJ>(acc);
+            sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
+            if (part + 1 < 3) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + NJ * wave, wpre);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = pack_bf16x2(acc[0][i][4 * g + 0], acc[0][i][4 * g + 1]);
+                    w.y = pack_bf16x2(acc[0][i][4 * g + 2], acc[0][i][4 * g + 3]);
+                    *reinterpret_cast<uint2*>(qst + (i * 32 + t) * QLD + part * SA_D + 32 * wave + 8 * g + 4 * hl) = w;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < TOK * 96 / NT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e / 96, ch = e - row * 96;
+            const uint4 v = *reinterpret_cast<const uint4*>(qst + row * QLD + ch * 8);
+            if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.qkv_next + (size_t)(m0 + row) * (3 * SA_D) + ch * 8) = v;
+        }
+        SA_STAMP();     // 7: next q/k/v projection
+        return;
+    }
     uint2 held[3][NJ][RB][4];
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
