@@ -862,7 +862,8 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
 
 // LayerNorm backward in place on the accumulator tile: acc = dL/dy -> dL/dx;  x (the forward input) from HBM.
 // The per-channel parameter gradients of this workgroup's tokens go to pgrad[0..255] (dgamma) / pgrad[256..511] (dbeta).
-template <int RB, int NJ, bool XBF = false>
+// XLDS: x points at an f32 LDS tile [tokens][XLD] of the workgroup's rows (staged row-coalesced) instead of at the HBM matrix.
+template <int RB, int NJ, bool XBF = false, bool XLDS = false>
 __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[NJ][RB], const float* __restrict__ x, const float* __restrict__ mean,
                                                  const float* __restrict__ rstd, const float* __restrict__ gamma, float* sStat2,
                                                  float* __restrict__ pgrad, long m0, int nvalid)
@@ -885,7 +886,9 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[NJ][RB], const 
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
                 const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
-                if constexpr (XBF) {          // the LayerNorm input was stored as bf16 (x points at bf16 data)
+                if constexpr (XLDS) {
+                    xh[j][g][i] = *reinterpret_cast<const float4*>(x + tok * XLD + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl);
+                } else if constexpr (XBF) {   // the LayerNorm input was stored as bf16 (x points at bf16 data)
                     const uint2 u = tok < nvalid ? *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + off) : make_uint2(0u, 0u);
                     xh[j][g][i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
                 } else {
@@ -1183,6 +1186,98 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd
             }
 }
 
+// The same with every HBM access row-coalesced (8 waves x 32 channels): the LayerNorm input is staged into an f32 LDS tile at
+// the start, LayerNorm' leaves its result in that tile, and a row pass adds dx1 and writes dbase (and dsum).
+template <int RB>
+__global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
+{
+    constexpr int NJ = 1, NT = 512, TOK = RB * 32, CPT = TOK * 32 / NT, XPT = TOK * 64 / NT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* actA = lds;                                // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
+    float* sStat2 = reinterpret_cast<float*>(lds + 2 * TOK * ALD);
+    float* xt = sStat2 + TOK * 8 * 2;                  // [TOK][XLD] f32: base, then LayerNorm-1'(dn1)
+    const int wave = threadIdx.x >> 6;
+    const long M = (long)a.M;
+    const long m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, M - m0);
+
+    SaWPre<NJ> wpre;
+    sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, 0, NJ * wave, wpre);
+    uint4 r[CPT];
+    auto load_part = [&](int part) {
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dqkv + (size_t)(m0 + row) * (3 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_part = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
+            *reinterpret_cast<uint4*>(actA + buf * TOK * ALD + row * ALD + ch * 8) = r[it];
+        }
+    };
+    load_part(0);
+    {
+        float4 xb[XPT];
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            xb[it] = row < nvalid ? *reinterpret_cast<const float4*>(a.base + (size_t)(m0 + row) * SA_D + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        store_part(0);
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            *reinterpret_cast<float4*>(xt + row * XLD + c4 * 4) = xb[it];
+        }
+    }
+    __syncthreads();
+    f32x16_t acc[NJ][RB];
+    sa_zero<RB, NJ>(acc);
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+        if (part + 1 < 3) load_part(part + 1);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.WqkvT, 3 * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
+        if (part + 1 < 3) {
+            sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
+            store_part((part + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // ---- dbase = LayerNorm-1'(dn1) + dx1
+    sa_layernorm_bwd<RB, NJ, false, true>(acc, xt, a.mean1, a.rstd1, a.ln1_g, sStat2, a.pgrad1 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+    {
+        const int lane = threadIdx.x & 63, hl = lane >> 5, t = lane & 31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i)      // (the slots this lane read its x from: no other lane touches them)
+                *reinterpret_cast<float4*>(xt + (i * 32 + t) * XLD + 32 * wave + 8 * g + 4 * hl) =
+                    make_float4(acc[0][i][4 * g + 0], acc[0][i][4 * g + 1], acc[0][i][4 * g + 2], acc[0][i][4 * g + 3]);
+    }
+    float4 dv[XPT], sv[XPT];
+#pragma unroll
+    for (int it = 0; it < XPT; ++it) {
+        const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+        const size_t off = (size_t)(m0 + (row < nvalid ? row : 0)) * SA_D + c4 * 4;
+        dv[it] = *reinterpret_cast<const float4*>(a.dx1 + off);
+        if (a.dsum) sv[it] = *reinterpret_cast<const float4*>(a.dsum + off);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < XPT; ++it) {
+        const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+        if (row >= nvalid) continue;
+        const size_t off = (size_t)(m0 + row) * SA_D + c4 * 4;
+        float4 v = *reinterpret_cast<const float4*>(xt + row * XLD + c4 * 4);
+        v.x += dv[it].x; v.y += dv[it].y; v.z += dv[it].z; v.w += dv[it].w;
+        *reinterpret_cast<float4*>(a.dbase + off) = v;
+        if (a.dsum) *reinterpret_cast<float4*>(a.dsum + off) = make_float4(sv[it].x + v.x, sv[it].y + v.y, sv[it].z + v.z, sv[it].w + v.w);
+    }
+}
+
 // dgamma[c] += sum_r partials[r][c], dbeta[c] += sum_r partials[r][256 + c]  (fixed order: deterministic) for a list of
 // LayerNorms in one launch (all the LayerNorms of a layer stack at the end of its backward)
 struct PgradJobs { VpfPgradJob job[VPF_PGRAD_MAX_JOBS]; };
@@ -1274,10 +1369,14 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     if (!attr) {
         if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_bwd_qkv_rows_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
     const int nwg = vpf_cdiv((long)a.M, TOK);
+    static int rows = -1;
+    if (rows < 0) { const char* e = getenv("VPF_SA_BWD_ROWS"); rows = e ? atoi(e) : 1; }
     if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else if (rows) hipLaunchKernelGGL((sa_bwd_qkv_rows_kernel<RB>), dim3(nwg), dim3(512), lds + (size_t)TOK * XLD * 4, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
