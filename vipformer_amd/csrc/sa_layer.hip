@@ -1107,6 +1107,132 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_mlp_kernel(VpfSaLayerBwd
     sa_store_bf16<RB, NJ>(acc, nullptr, 0, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
 }
 
+// The same with every HBM access but the u loads row-coalesced (8 waves x 32 channels).  d is only ever needed element-wise
+// (dropout', + d), so it is handled in the row layout; x1 (the LayerNorm-2 input) is staged into an f32 LDS tile at the start,
+// LayerNorm-2' leaves its result in that tile and a row pass turns it into dx1 (HBM) and dz1 (LDS operand tile + HBM).
+template <int RB>
+__global__ void __launch_bounds__(512) sa_bwd_mlp_rows_kernel(VpfSaLayerBwd a)
+{
+    constexpr int NJ = 1, NT = 512, TOK = RB * 32, XPT = TOK * 64 / NT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* actA = lds;                               // dz2 -> dz1
+    bf16_t* actH = lds + TOK * ALD;                   // one 256-wide chunk of du, then do
+    float* sStat2 = reinterpret_cast<float*>(actH + TOK * ALD);   // [TOK][8] float2
+    float* xt = sStat2 + TOK * 8 * 2;                 // [TOK][XLD] f32: x1, then LayerNorm-2'(dn)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
+    const long M = (long)a.M;
+    const long m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, M - m0);
+
+    SaWPre<NJ> wpre;
+    sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, NJ * wave, wpre);
+    f32x16_t acc[NJ][RB], acc2[NJ][RB];
+    // ---- dz2 = dropout'(d)  (row layout: operand tile + HBM);  x1 -> xt
+    {
+        float4 dr[XPT], xr[XPT];
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            const size_t off = (size_t)(m0 + (row < nvalid ? row : 0)) * SA_D + c4 * 4;
+            dr[it] = *reinterpret_cast<const float4*>(a.d + off);
+            xr[it] = *reinterpret_cast<const float4*>(a.x1 + off);
+        }
+        const VpfRng rng = vpf_rng_init(a.rng, a.site_res2, a.p_res2);
+        const bool drop = a.p_res2 > 0.f;
+        const float sc = drop ? rng.scale : 1.f;
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            const bool ok = row < nvalid;
+            const size_t off = (size_t)(m0 + (ok ? row : 0)) * SA_D + c4 * 4;
+            const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u);
+            uint2 w;
+            w.x = pack_bf16x2((keep & 1u) ? dr[it].x * sc : 0.f, (keep & 2u) ? dr[it].y * sc : 0.f);
+            w.y = pack_bf16x2((keep & 4u) ? dr[it].z * sc : 0.f, (keep & 8u) ? dr[it].w * sc : 0.f);
+            *reinterpret_cast<uint2*>(actA + row * ALD + c4 * 4) = w;
+            if (ok) *reinterpret_cast<uint2*>((bf16_t*)a.dz2 + off) = w;
+            *reinterpret_cast<float4*>(xt + row * XLD + c4 * 4) = ok ? xr[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    __syncthreads();
+    // ---- du = (dz2 . W2) * gelu'(u) ;  dn = du . W1
+    sa_zero<RB, NJ>(acc2);
+#pragma unroll
+    for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
+        uint2 uu[4][RB];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int tok = i * 32 + t;
+                uu[g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 32 * wave + 8 * g + 4 * hl)
+                                        : make_uint2(0u, 0u);
+            }
+        sa_zero<RB, NJ>(acc);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2T, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, wpre);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                acc[0][i][4 * g + 0] *= vpf_gelu_grad(__uint_as_float(uu[g][i].x << 16));
+                acc[0][i][4 * g + 1] *= vpf_gelu_grad(__uint_as_float(uu[g][i].x & 0xffff0000u));
+                acc[0][i][4 * g + 2] *= vpf_gelu_grad(__uint_as_float(uu[g][i].y << 16));
+                acc[0][i][4 * g + 3] *= vpf_gelu_grad(__uint_as_float(uu[g][i].y & 0xffff0000u));
+            }
+        if (hc) __syncthreads();
+        sa_store_bf16<RB, NJ>(acc, actH, 0, nullptr, SA_HID, hc * SA_D, m0, nvalid);
+        __syncthreads();
+        sa_tile_store_rows<TOK, NT>(actH, (bf16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
+    }
+    sa_wprefetch((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, wpre);
+    // ---- LayerNorm-2'(dn) -> xt (the slots this lane read its x1 from)
+    sa_layernorm_bwd<RB, NJ, false, true>(acc2, xt, a.mean2, a.rstd2, a.ln2_g, sStat2, a.pgrad2 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            *reinterpret_cast<float4*>(xt + (i * 32 + t) * XLD + 32 * wave + 8 * g + 4 * hl) =
+                make_float4(acc2[0][i][4 * g + 0], acc2[0][i][4 * g + 1], acc2[0][i][4 * g + 2], acc2[0][i][4 * g + 3]);
+    // ---- dx1 = . + d;  dz1 = dropout'(dx1)   (row layout; every wave has left the hidden-chunk loop: dz2 in actA is dead)
+    {
+        float4 dr[XPT];
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            dr[it] = *reinterpret_cast<const float4*>(a.d + (size_t)(m0 + (row < nvalid ? row : 0)) * SA_D + c4 * 4);
+        }
+        __syncthreads();
+        const VpfRng rng = vpf_rng_init(a.rng, a.site_res1, a.p_res1);
+        const bool drop = a.p_res1 > 0.f;
+        const float sc = drop ? rng.scale : 1.f;
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            const bool ok = row < nvalid;
+            const size_t off = (size_t)(m0 + (ok ? row : 0)) * SA_D + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(xt + row * XLD + c4 * 4);
+            v.x += dr[it].x; v.y += dr[it].y; v.z += dr[it].z; v.w += dr[it].w;
+            if (ok) *reinterpret_cast<float4*>(a.dx1 + off) = v;
+            const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u);
+            uint2 w;
+            w.x = pack_bf16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
+            w.y = pack_bf16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
+            *reinterpret_cast<uint2*>(actA + row * ALD + c4 * 4) = w;
+            if (ok) *reinterpret_cast<uint2*>((bf16_t*)a.dz1 + off) = w;
+        }
+    }
+    __syncthreads();
+    // ---- do = dz1 . Wo   (staged through actH: the last du chunk is dead)
+    sa_zero<RB, NJ>(acc);
+    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
+    sa_store_bf16<RB, NJ>(acc, actH, 0, nullptr, SA_D, 0, m0, nvalid);
+    __syncthreads();
+    sa_tile_store_rows<TOK, NT>(actH, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
+}
+
 template <int RB, int NJ>
 __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
 {
@@ -1347,10 +1473,14 @@ extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
     if (!attr) {
         if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_bwd_mlp_rows_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
     const int nwg = vpf_cdiv((long)a.M, TOK);
+    static int rows = -1;
+    if (rows < 0) { const char* e = getenv("VPF_SA_BWD_ROWS"); rows = e ? atoi(e) : 1; }
     if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
+    else if (rows) hipLaunchKernelGGL((sa_bwd_mlp_rows_kernel<RB>), dim3(nwg), dim3(512), lds + (size_t)TOK * XLD * 4, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
