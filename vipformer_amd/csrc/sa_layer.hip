@@ -886,7 +886,10 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[NJ][RB], const 
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
                 const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
-                if constexpr (XLDS) {
+                if constexpr (XLDS && XBF) {  // a bf16 LDS tile [tokens][ALD]
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + tok * ALD + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl);
+                    xh[j][g][i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                } else if constexpr (XLDS) {
                     xh[j][g][i] = *reinterpret_cast<const float4*>(x + tok * XLD + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl);
                 } else if constexpr (XBF) {   // the LayerNorm input was stored as bf16 (x points at bf16 data)
                     const uint2 u = tok < nvalid ? *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + off) : make_uint2(0u, 0u);
@@ -1526,6 +1529,9 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapte
     bf16_t* sA1 = lds;                                  // [TOK][A1LD]  hidden layer (bf16)
     bf16_t* actA = lds + TOK * A1LD;                    // [TOK][ALD]   normalised per-point embedding
     float* sStat = reinterpret_cast<float*>(actA + TOK * ALD);      // [TOK][NWV] float2
+    bf16_t* sX = reinterpret_cast<bf16_t*>(sStat + TOK * NWV * 2);  // [TOK][ALD]   per-point embedding before the LayerNorm (staging for HBM)
+    bf16_t* sKV = sX + TOK * ALD;                                   // [TOK][KVLD]  K | V rows (staging for HBM)
+    constexpr int KVLD = 2 * SA_D + 8;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const long M = a.M, m0 = (long)blockIdx.x * TOK;
     const int nvalid = (int)min((long)TOK, M - m0);
@@ -1597,7 +1603,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapte
                 u.x = pack_bf16x2(acc[j][i][4 * g + 0] + bb[0], acc[j][i][4 * g + 1] + bb[1]);
                 u.y = pack_bf16x2(acc[j][i][4 * g + 2] + bb[2], acc[j][i][4 * g + 3] + bb[3]);
                 const int tok = i * 32 + t;
-                if (tok < nvalid) *reinterpret_cast<uint2*>((bf16_t*)a.xkv + (size_t)(m0 + tok) * SA_D + c) = u;
+                *reinterpret_cast<uint2*>(sX + tok * ALD + c) = u;       // to HBM in the row pass below (whole rows per wave-instruction)
                 acc[j][i][4 * g + 0] = __uint_as_float(u.x << 16); acc[j][i][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
                 acc[j][i][4 * g + 2] = __uint_as_float(u.y << 16); acc[j][i][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
             }
@@ -1609,10 +1615,11 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapte
         for (int i = 0; i < RB; ++i)
             if (i * 32 + t < nvalid) { a.mean[m0 + i * 32 + t] = mean[i]; a.rstd[m0 + i * 32 + t] = rstd[i]; }
     }
-    sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.nk, SA_D, 0, m0, nvalid);
+    sa_store_bf16<RB, NJ>(acc, actA, 0, nullptr, SA_D, 0, m0, nvalid);
     __syncthreads();
-    // ---- K | V = normalised . Wkv^T   (two 256-channel halves; results held and stored after the last MFMA)
-    uint2 held[2][NJ][RB][4];
+    sa_tile_store_rows<TOK, NT>(sX, (bf16_t*)a.xkv, SA_D, 0, m0, nvalid);
+    sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.nk, SA_D, 0, m0, nvalid);
+    // ---- K | V = normalised . Wkv^T   (two 256-channel halves, staged in LDS and stored as whole rows)
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
         sa_zero<RB, NJ>(acc);
@@ -1624,22 +1631,19 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapte
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    held[part][j][i][g].x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
-                    held[part][j][i][g].y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                    uint2 w;
+                    w.x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
+                    w.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                    *reinterpret_cast<uint2*>(sKV + (i * 32 + t) * KVLD + part * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) = w;
                 }
     }
+    __syncthreads();
 #pragma unroll
-    for (int part = 0; part < 2; ++part)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int tok = i * 32 + t;
-                    if (tok < nvalid)
-                        *reinterpret_cast<uint2*>((bf16_t*)a.kv + (size_t)(m0 + tok) * (2 * SA_D) + part * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) = held[part][j][i][g];
-                }
+    for (int it = 0; it < TOK * 64 / NT; ++it) {
+        const int e = threadIdx.x + it * NT, row = e >> 6, ch = e & 63;
+        const uint4 v = *reinterpret_cast<const uint4*>(sKV + row * KVLD + ch * 8);
+        if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.kv + (size_t)(m0 + row) * (2 * SA_D) + ch * 8) = v;
+    }
 }
 
 extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
@@ -1652,7 +1656,7 @@ extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
     if (a.M <= 0 || a.C <= 0 || a.C > 8) return VPF_ERR_BADSHAPE;
     if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
     constexpr int TOK = 64;
-    const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
+    const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2 + (size_t)TOK * (2 * SA_D + 8) * 2;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)adapter_kv_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
@@ -1675,13 +1679,25 @@ __global__ void __launch_bounds__(512) adapter_kv_bwd_kernel(VpfAdapterKvBwd a)
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
     bf16_t* actA = lds;                                 // two [TOK][ALD] buffers: dk | dv rows, then dxkv in buffer 0
     float* sStat2 = reinterpret_cast<float*>(lds + 2 * TOK * ALD);  // [TOK][8] float2
+    bf16_t* sX = reinterpret_cast<bf16_t*>(sStat2 + TOK * 8 * 2);   // [TOK][ALD] the kv LayerNorm's input rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const long M = a.M, m0 = (long)blockIdx.x * TOK;
     const int nvalid = (int)min((long)TOK, M - m0);
 
     SaWPre<NJ> wpre;
     sa_wprefetch((const bf16_t*)a.WkvT, 2 * SA_D / 16, 0, wave, wpre);
-    {   // stage both halves of the dkv rows (coalesced 16-byte loads, all in flight together)
+    {   // stage both halves of the dkv rows and the LayerNorm input rows (coalesced 16-byte loads, all in flight together)
+        uint4 rx[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
+            rx[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.xkv + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
+            *reinterpret_cast<uint4*>(sX + row * ALD + ch * 8) = rx[it];
+        }
         uint4 r[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -1706,10 +1722,11 @@ __global__ void __launch_bounds__(512) adapter_kv_bwd_kernel(VpfAdapterKvBwd a)
     for (int i = 0; i < RB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][i][r] = bf16_to_f32(f32_to_bf16(acc[0][i][r]));
-    sa_layernorm_bwd<RB, NJ, true>(acc, reinterpret_cast<const float*>(a.xkv), a.mean, a.rstd, a.lnkv_g, sStat2, a.pgrad_kv + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
+    sa_layernorm_bwd<RB, NJ, true, true>(acc, reinterpret_cast<const float*>(sX), a.mean, a.rstd, a.lnkv_g, sStat2, a.pgrad_kv + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
     // (the exchange barrier inside guarantees every wave has finished reading the dk / dv rows)
-    sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.dxkv, SA_D, 0, m0, nvalid);
+    sa_store_bf16<RB, NJ>(acc, actA, 0, nullptr, SA_D, 0, m0, nvalid);
     __syncthreads();
+    sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.dxkv, SA_D, 0, m0, nvalid);
     // ---- da1 = dxkv . W2   (64 hidden channels: waves 0 and 1), stored as bf16 like the unfused dgrad output
     if (wave < 2) {
         sa_zero<RB, NJ>(acc);
@@ -1735,7 +1752,7 @@ extern "C" int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* args, void* stream)
     if (a.M <= 0) return VPF_ERR_BADSHAPE;
     if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
     constexpr int TOK = 64;
-    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)adapter_kv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
