@@ -347,7 +347,7 @@ __device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV,
 // ATT = false: the attention output o is an INPUT (vpf_attention_fwd ran before); a workgroup then owns any RB*32
 // consecutive rows of the [B*L, D] token matrix, needs no K / V tiles and two workgroups fit on a CU.
 template <int RB, int HPR, int LPT, bool ATT, int NJ>
-__global__ void __launch_bounds__(64 * (8 / NJ), (RB == 1 ? 4 : (NJ == 1 ? 2 : 1))) sa_layer_fwd_kernel(VpfSaLayerFwd a)
+__global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerFwd a)
 {
     constexpr int NWV = 8 / NJ, NT = 64 * NWV;          // waves per workgroup: each owns NJ blocks of 32 channels per 256-wide chunk
     static_assert(!ATT || NJ == 2, "the in-kernel attention distributes its units over 4 waves");
@@ -840,9 +840,6 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     static int nj = -1;
     if (nj < 0) { const char* e = getenv("VPF_SA_NJ"); nj = e ? atoi(e) : 1; }
     if (a.attention_done) {                                                   // o is an input: 64-row blocks, any sequence length
-        static int rb1 = -1;
-        if (rb1 < 0) { const char* e = getenv("VPF_SA_RB"); rb1 = (e && atoi(e) == 1) ? 1 : 0; }
-        if (rb1) return sa_launch<1, 4, 32, false, 1>(a, 1, st);              // 32-row blocks: twice the workgroups, two per CU
         if (nj == 2) return sa_launch<2, 2, 32, false, 2>(a, 1, st);          // 4 waves x 64 channels
         return sa_launch<2, 2, 32, false, 1>(a, 1, st);                       // 8 waves x 32 channels: two waves per SIMD overlap MFMA, VALU and memory waits
     }
