@@ -223,6 +223,44 @@ def test_batchnorm_pieces():
     assert rel(ops._bn_act(x16, C, se, bn, False, False), ref(x16.float())) < 1e-5
 
 
+@pytest.mark.parametrize("M,C", [(128, 256), (37, 64), (1, 64), (256, 512)])
+def test_batchnorm_small_batch_one_kernel(M, C):
+    """vpf_bn_small_fwd / vpf_bn_small_bwd (projection heads, partseg.py:519-525: BatchNorm1d + ReLU in training mode on a
+    batch of 64 .. 256 rows as ONE kernel each way) against torch.nn.BatchNorm1d fp32.  Tolerances: the output is bf16
+    (2^-8 relative per element -> 3e-3 on the norm), statistics and gradients are fp32 sums (1e-4)."""
+    from vipformer_amd import _lib as L
+    x = rnd(11, M, C, scale=2.0) + 0.3
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    bn.weight.data = rnd(12, C) * 0.2 + 1; bn.bias.data = rnd(13, C) * 0.1
+    ref = torch.nn.BatchNorm1d(C).cuda()
+    ref.load_state_dict(bn.state_dict())
+    stat = torch.empty(2 * C, device="cuda"); y = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+    L.call("vpf_bn_small_fwd", x, M, C, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var,
+           bn.num_batches_tracked, stat, y, 1)
+    xr = x.clone().requires_grad_()
+    if M > 1:
+        yr = torch.relu(ref(xr))
+        assert rel(y.float(), yr) < 3e-3
+        assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5) and torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-6)
+    else:       # torch refuses a single row in training mode; the kernel follows the formula (var = 0 -> y = relu(beta))
+        assert torch.allclose(y.float()[0], torch.relu(bn.bias.data).to(torch.bfloat16).float(), atol=1e-6)
+        return
+    assert int(bn.num_batches_tracked) == 1
+    assert torch.allclose(stat[:C], x.mean(0), atol=1e-5)
+    dy = rnd(14, M, C)
+    for out_bf16 in (0, 1):
+        dx = torch.empty(M, C, dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+        dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
+        L.call("vpf_bn_small_bwd", dy, x, stat, bn.weight.data, bn.bias.data, M, C, 1, dx, out_bf16, dg, db)
+        if out_bf16 == 0:
+            yr.backward(dy)
+        assert rel(dx.float(), xr.grad) < (3e-3 if out_bf16 else 2e-4)
+        assert rel(dg, ref.weight.grad) < 2e-4 and rel(db, ref.bias.grad) < 2e-4
+    # shapes the kernel does not take are refused loudly
+    with pytest.raises(RuntimeError):
+        L.call("vpf_bn_small_fwd", x, M, C - 1, bn.weight.data, bn.bias.data, 1e-5, 0.1, None, None, None, stat, y, 1)
+
+
 def test_group_max_concat_pool():
     from vipformer_amd import _lib as L
     NG, K, C = 50, 32, 128
