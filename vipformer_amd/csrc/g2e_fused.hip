@@ -66,15 +66,26 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
     float ssum = 0.f, ssq = 0.f;
 
     const long npairs = (p.NG + 1) / 2;
+    // this thread's input row of the NEXT pair is requested while the current pair is processed (a load consumed at the top of
+    // the iteration that issued it exposes one HBM latency per 64 rows)
+    float nx0 = 0.f, nx1 = 0.f, nx2 = 0.f;
+    auto request = [&](long pq) {
+        const long r0 = pq * 64, nr = min((long)64, p.NG * 32 - r0);
+        if (pq < npairs && c1row < nr) {
+            const float* xr = p.x + (size_t)(r0 + c1row) * p.C;
+            nx0 = xr[0]; nx1 = xr[1]; nx2 = xr[2];
+        }
+    };
+    request(blockIdx.x);
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long row0 = pr * 64;                                   // first of 64 rows
         const long nrows = min((long)64, p.NG * 32 - row0);          // 64, or 32 for an odd tail
         // ---- conv1 + BN1 + ReLU -> a1 (LDS + HBM)
         {
             uint4 o = make_uint4(0, 0, 0, 0);
+            const float x0 = nx0, x1 = nx1, x2 = nx2;
+            request(pr + gridDim.x);
             if (c1row < nrows) {
-                const float* xr = p.x + (size_t)(row0 + c1row) * p.C;
-                const float x0 = xr[0], x1 = xr[1], x2 = xr[2];
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaxf(w1[j][0] * x0 + w1[j][1] * x1 + w1[j][2] * x2 + b1[j], 0.f);
@@ -182,6 +193,18 @@ __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
     for (int j = 0; j < 8; ++j) { aa[j] = p.ab2[(t & 31) * 8 + j]; bb[j] = p.ab2[256 + (t & 31) * 8 + j]; }
 
     const long npairs = (p.NG + 1) / 2;
+    // the next pair's h3 rows are requested before this pair's MFMAs (consumed after them): a load issued at the top of an
+    // iteration and used at once exposes the whole HBM latency every 64 rows
+    uint4 nx[4];
+    auto request = [&](long pq) {
+        const long r0 = pq * 64, nr = min((long)64, p.NG * 32 - r0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + i * 512, row = c >> 5, ch = c & 31;
+            nx[i] = (pq < npairs && row < nr) ? *reinterpret_cast<const uint4*>(p.h3 + (size_t)(r0 + row) * 256 + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    request(blockIdx.x);
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long row0 = pr * 64;
         const long nrows = min((long)64, p.NG * 32 - row0);
@@ -190,7 +213,7 @@ __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
             const int c = t + i * 512, row = c >> 5, ch = c & 31;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (row < nrows) {
-                v = *reinterpret_cast<const uint4*>(p.h3 + (size_t)(row0 + row) * 256 + ch * 8);
+                v = nx[i];
                 uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -201,6 +224,7 @@ __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
             *reinterpret_cast<uint4*>(sA3 + row * H3LD + ch * 8) = v;
         }
         __syncthreads();
+        request(pr + gridDim.x);
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const int n = (w + 8 * q) * 32 + l31;
@@ -321,31 +345,44 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
     for (int j = 0; j < 128; ++j) acc[j] = 0.f;
     float accb = 0.f;
 
-    auto stage = [&](long g, int buf) {
+    // request = the global loads of a group (registers), commit = BatchNorm affine + ReLU into the LDS buffer: the loads of the
+    // NEXT group are in flight while this group's rows are accumulated (issued and consumed back to back they cost one HBM
+    // latency per group of 32 rows)
+    uint4 hv[2];
+    float dn = 0.f;
+    uint8_t rn = 0;
+    auto request = [&](long g) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = t + i * 512, row = c >> 5, ch = c & 31;
-            uint4 v = *reinterpret_cast<const uint4*>(p.h3 + ((size_t)g * 32 + row) * 256 + ch * 8);
-            uint32_t u[4] = {v.x, v.y, v.z, v.w};
+            hv[i] = *reinterpret_cast<const uint4*>(p.h3 + ((size_t)g * 32 + row) * 256 + ch * 8);
+        }
+        if (t < 256) {
+            const bool ok = n < p.Dm;
+            dn = ok ? p.dout[(size_t)g * p.Dm + n] : 0.f;
+            rn = ok ? p.arg4[(size_t)g * p.Dm + n] : 0;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + i * 512, row = c >> 5, ch = c & 31;
+            uint32_t u[4] = {hv[i].x, hv[i].y, hv[i].z, hv[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 u[j] = pack_bf16x2(fmaxf(fmaf(aa[2 * j], __uint_as_float(u[j] << 16), bb[2 * j]), 0.f),
                                    fmaxf(fmaf(aa[2 * j + 1], __uint_as_float(u[j] & 0xffff0000u), bb[2 * j + 1]), 0.f));
             *reinterpret_cast<uint4*>(&sA3[buf][row * H3LD + ch * 8]) = make_uint4(u[0], u[1], u[2], u[3]);
         }
-        if (t < 256) {
-            const bool ok = n < p.Dm;
-            sD[buf][t] = ok ? p.dout[(size_t)g * p.Dm + n] : 0.f;
-            sR[buf][t] = ok ? p.arg4[(size_t)g * p.Dm + n] : 0;
-        }
+        if (t < 256) { sD[buf][t] = dn; sR[buf][t] = rn; }
     };
     long g = blockIdx.x;
     int buf = 0;
-    if (g < p.NG) stage(g, 0);
+    if (g < p.NG) { request(g); commit(0); }
     __syncthreads();
     for (; g < p.NG; g += gridDim.x) {
         const long gn = g + gridDim.x;
-        if (gn < p.NG) stage(gn, buf ^ 1);
+        if (gn < p.NG) request(gn);
         const float d = sD[buf][nl];
         const bf16_t* row = &sA3[buf][(int)sR[buf][nl] * H3LD + kh * 128];
         if (kh == 0) accb += d;
@@ -359,6 +396,7 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
                 acc[q * 8 + 2 * j + 1] = fmaf(d, __uint_as_float(u[j] & 0xffff0000u), acc[q * 8 + 2 * j + 1]);
             }
         }
+        if (gn < p.NG) commit(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
