@@ -475,7 +475,19 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
     bf16_t* sD4 = smem;                         // [64][H3LD]  dh4 tile (Dm <= 256), later dh2 staging
     bf16_t* sH3 = smem + 64 * H3LD;             // [64][H3LD]  h3, overwritten by dh3
+    bf16_t* sW3 = sH3 + 64 * H3LD;              // PASS 1: W3b^T in MFMA fragment order, [4 column tiles][16 k-steps][64 lanes] x 16 B = 64 KB
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hl = lane >> 5, l31 = lane & 31;
+    if (PASS == 1) {
+        // (64 more live registers would spill, and fetched from L2 inside the loop every pair paid that latency in front of
+        // its 16 MFMAs: ~4.5 us of a 12 us iteration)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = t + i * 512, f = e >> 6, ln = e & 63, ct = f >> 4, ks = f & 15;
+            *reinterpret_cast<uint4*>(sW3 + (size_t)e * 8) =
+                *reinterpret_cast<const uint4*>(p.w3bt + (size_t)(ct * 32 + (ln & 31)) * 256 + ks * 16 + 8 * (ln >> 5));
+        }
+        // (visible to every wave after the first barrier of the loop)
+    }
     const int KS4 = p.Dm / 16;                  // k-steps of the dh4 . W4 product (<= 16)
     bf16x8_t w4f[16];
 #pragma unroll
@@ -606,13 +618,11 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             f32x16_t a2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) a2[r] = 0.f;
-            // W3b^T fragments come from L2 every pair (64 more live registers would spill); the pointer is laundered so the
-            // loads are not hoisted out of the persistent loop
-            const bf16_t* wp = p.w3bt + (size_t)(ct2 * 32 + l31) * 256 + 8 * hl;
-            asm volatile("" : "+v"(wp));
+            // W3b^T fragments from the LDS copy (conflict-free 16-byte reads, lane-contiguous)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sH3 + (rt2 * 32 + l31) * H3LD + ks * 16 + 8 * hl), ldfrag(wp + ks * 16), a2, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sH3 + (rt2 * 32 + l31) * H3LD + ks * 16 + 8 * hl),
+                                                             ldfrag(sW3 + ((size_t)(ct2 * 16 + ks) * 64 + lane) * 8), a2, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
@@ -654,17 +664,17 @@ extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long 
     if (NG <= 0 || Dm <= 0 || Dm > 256 || (Dm % 16)) return VPF_ERR_BADSHAPE;
     G2eBwd p = {dout, arg4, Dm, NG, (const bf16_t*)h3_bf16, stat2, gamma2, beta2, (const bf16_t*)w4t_bf16, (const bf16_t*)w3bt_bf16, tmp512_zeroed,
                 1.0f / (float)(NG * 32), training, (bf16_t*)dh3_bf16, dgb, (bf16_t*)dh2_bf16, dbg};
-    const size_t lds = sizeof(bf16_t) * 2 * 64 * H3LD;
+    const size_t lds = sizeof(bf16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
-        if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
     long grid = (NG + 1) / 2; if (grid > g2e_max_grid()) grid = g2e_max_grid();
     hipStream_t st = (hipStream_t)stream;
     if (training) hipLaunchKernelGGL(g2e_bwd_kernel<0>, dim3((unsigned)grid), dim3(512), lds, st, p);
-    hipLaunchKernelGGL(g2e_bwd_kernel<1>, dim3((unsigned)grid), dim3(512), lds, st, p);
+    hipLaunchKernelGGL(g2e_bwd_kernel<1>, dim3((unsigned)grid), dim3(512), lds1, st, p);
     if (training) hipLaunchKernelGGL(g2e_bn2_param_grad_kernel, dim3(1), dim3(256), 0, st, (const float*)tmp512_zeroed, dgamma2, dbeta2);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
