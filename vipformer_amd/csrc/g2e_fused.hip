@@ -512,6 +512,21 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
         }
     };
     load_h3(blockIdx.x);
+    uint2 nar = make_uint2(0xffffffffu, 0xffffffffu);
+    float4 nd0 = make_float4(0.f, 0.f, 0.f, 0.f), nd1 = nd0;
+    auto load_d4 = [&](long pq) {
+        const int gi = t >> 8, ch = (t >> 3) & 31;
+        const long g = pq * 2 + gi;
+        nar = make_uint2(0xffffffffu, 0xffffffffu);
+        nd0 = make_float4(0.f, 0.f, 0.f, 0.f); nd1 = nd0;
+        if (ch * 8 < p.Dm && pq < npairs && g < p.NG) {
+            const size_t o = (size_t)g * p.Dm + ch * 8;
+            nar = *reinterpret_cast<const uint2*>(p.arg4 + o);
+            nd0 = *reinterpret_cast<const float4*>(p.dout + o);
+            nd1 = *reinterpret_cast<const float4*>(p.dout + o + 4);
+        }
+    };
+    load_d4(blockIdx.x);
     long long ph[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
 #define STAMP(i) do { if (p.dbg) { t1 = clock64(); ph[i] += t1 - t0; t0 = t1; } } while (0)
     if (p.dbg) t0 = clock64();
@@ -522,16 +537,12 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
         {
             const int gi = t >> 8, ch = (t >> 3) & 31, sl = t & 7;
             const long g = pr * 2 + gi;
+            (void)g;
             if (ch * 8 < p.Dm) {
-                uint32_t aw[2] = {0xffffffffu, 0xffffffffu};
-                float dd[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (g < p.NG) {
-                    const size_t o = (size_t)g * p.Dm + ch * 8;
-                    const uint2 ar = *reinterpret_cast<const uint2*>(p.arg4 + o);
-                    aw[0] = ar.x; aw[1] = ar.y;
-                    const float4 d0 = *reinterpret_cast<const float4*>(p.dout + o), d1 = *reinterpret_cast<const float4*>(p.dout + o + 4);
-                    dd[0] = d0.x; dd[1] = d0.y; dd[2] = d0.z; dd[3] = d0.w; dd[4] = d1.x; dd[5] = d1.y; dd[6] = d1.z; dd[7] = d1.w;
-                }
+                // (winner indices and gradients of this pair were requested during the previous pair's BatchNorm epilogue: read
+                // and used at once they cost one HBM latency per pair)
+                uint32_t aw[2] = {nar.x, nar.y};
+                float dd[8] = {nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, nd1.z, nd1.w};
                 // the 8 gradients as bf16 pairs once; every member row then keeps a pair element iff it won the max
                 uint32_t dp[4];
 #pragma unroll
@@ -569,36 +580,35 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                     acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sD4 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[ks], acc[rt], 0, 0, 0);
             }
         STAMP(1);
+        load_d4(pr + gridDim.x);
         if (PASS == 0) load_h3(pr + gridDim.x);
         float gsum[2] = {0.f, 0.f};
-        // all 32 h3 values of this lane first (independent LDS reads in flight together), then the math, then the stores
-        bf16_t hraw[2][16];
+        // one row tile at a time: its 16 h3 values of this lane first (independent LDS reads in flight together), then the
+        // math, then the stores (both row tiles at once held 64 registers here and the kernel spilled)
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int rt = 0; rt < 2; ++rt) {
+            bf16_t hraw[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) hraw[rt][r] = sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col];
-        bf16_t dres[2][16];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+            for (int r = 0; r < 16; ++r) hraw[r] = sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col];
+            bf16_t dres[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                const float xh = (bf16_to_f32(hraw[rt][r]) - mean) * rstd;
+                const float xh = (bf16_to_f32(hraw[r]) - mean) * rstd;
                 float g = bf16_to_f32(f32_to_bf16(acc[rt][r]));            // da3 is a bf16 tensor in the unfused path
                 if (xh * ga + be <= 0.f || row >= nrows) g = 0.f;
                 if (PASS == 0) { a0 += g; a1 += g * xh; }
                 else {
                     const float dv = p.training ? ga * rstd * (g - sg - xh * sgx) : ga * rstd * g;
                     const bf16_t db = (row < nrows) ? f32_to_bf16(dv) : (bf16_t)0;
-                    dres[rt][r] = db;
+                    dres[r] = db;
                     gsum[rt] += bf16_to_f32(db);
                 }
             }
-        if (PASS == 1) {
+            if (PASS == 1) {
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col] = dres[rt][r];
+                for (int r = 0; r < 16; ++r) sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col] = dres[r];
+            }
         }
         if (PASS == 1) {
 #pragma unroll
