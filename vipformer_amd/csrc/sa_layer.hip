@@ -365,6 +365,17 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     // touches 32 rows with 16 .. 32 bytes each, which costs the address unit far more than the bytes do.
     constexpr bool XR = !ATT && NJ == 1;
     float* xres = sStatB + TOK * NWV;                 // [TOK][XLD] f32 (XR only)
+    // XR: the per-channel vectors of the epilogues (bo | ln2 gamma | ln2 beta | b1 [512] | b2 | next ln1 gamma | beta = 2048 floats)
+    // are fetched once at the start (one 16-byte load per thread) and read from LDS: fetched where they are used, every
+    // epilogue and LayerNorm starts with an L2 round trip that nothing overlaps
+    float* sPar = xres + TOK * XLD;
+    const float* bo_p = XR ? sPar : a.bo;
+    const float* g2_p = XR ? sPar + 256 : a.ln2_g;
+    const float* be2_p = XR ? sPar + 512 : a.ln2_b;
+    const float* b1_p = XR ? sPar + 768 : a.b1;
+    const float* b2_p = XR ? sPar + 1280 : a.b2;
+    const float* g1n_p = XR ? sPar + 1536 : a.ln1n_g;
+    const float* be1n_p = XR ? sPar + 1792 : a.ln1n_b;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const int b = blockIdx.x, chunk = blockIdx.y;
@@ -391,6 +402,12 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
         }
         if constexpr (XR) {                                        // the residual base, row-coalesced, into xres
             constexpr int XPT = TOK * 64 / NT;
+            {
+                const float* src = wave == 0 ? a.bo : wave == 1 ? a.ln2_g : wave == 2 ? a.ln2_b : wave == 3 ? a.b1 : wave == 4 ? a.b1 + 256
+                                 : wave == 5 ? a.b2 : wave == 6 ? a.ln1n_g : a.ln1n_b;
+                const float4 pz = src ? *reinterpret_cast<const float4*>(src + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(sPar + wave * 256 + lane * 4) = pz;
+            }
             float4 rb[XPT];
 #pragma unroll
             for (int it = 0; it < XPT; ++it) {
@@ -511,7 +528,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cch = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
-                const float4 bo = *reinterpret_cast<const float4*>(a.bo + cch);
+                const float4 bo = *reinterpret_cast<const float4*>(bo_p + cch);
                 const float bb[4] = {bo.x, bo.y, bo.z, bo.w};
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
@@ -538,7 +555,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
             }
         SA_STAMP();     // 2: dropout + residual epilogue
         float mean[RB], rstd[RB];
-        sa_layernorm<RB, NJ>(acc, a.ln2_g, a.ln2_b, sStatA, sStatB, mean, rstd);
+        sa_layernorm<RB, NJ>(acc, g2_p, be2_p, sStatA, sStatB, mean, rstd);
         SA_STAMP();     // 3a: LayerNorm 2 maths
         if (wave == 0 && hl == 0) {
 #pragma unroll
@@ -612,7 +629,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cl = 32 * wave + 8 * g + 4 * hl;
-                const float4 b1 = *reinterpret_cast<const float4*>(a.b1 + hc * SA_D + cl);
+                const float4 b1 = *reinterpret_cast<const float4*>(b1_p + hc * SA_D + cl);
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     uint2 w;
@@ -645,7 +662,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cch = hc * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
-                const float4 b1 = *reinterpret_cast<const float4*>(a.b1 + cch);
+                const float4 b1 = *reinterpret_cast<const float4*>(b1_p + cch);
                 const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
@@ -689,7 +706,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cch = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
-                const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + cch);
+                const float4 b2 = *reinterpret_cast<const float4*>(b2_p + cch);
                 const float bb[4] = {b2.x, b2.y, b2.z, b2.w};
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
@@ -732,7 +749,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
             return;
         }
         float mean[RB], rstd[RB];
-        sa_layernorm<RB, NJ>(acc2, a.ln1n_g, a.ln1n_b, sStatA, sStatB, mean, rstd);
+        sa_layernorm<RB, NJ>(acc2, g1n_p, be1n_p, sStatA, sStatB, mean, rstd);
         if (wave == 0 && hl == 0) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -810,7 +827,7 @@ static int sa_launch(const VpfSaLayerFwd& a, int chunks, hipStream_t st)
 {
     const int LP = LPT, TOK = RB * 32;
     const size_t kv = ATT ? (size_t)HPR * 2 * LP * KLD * 2 : 0, mlp = (size_t)TOK * ALD * 2 + (size_t)2 * TOK * (8 / NJ) * 4;
-    const size_t lds = (size_t)TOK * ALD * 2 + (kv > mlp ? kv : mlp) + ((!ATT && NJ == 1) ? (size_t)TOK * XLD * 4 : 0);
+    const size_t lds = (size_t)TOK * ALD * 2 + (kv > mlp ? kv : mlp) + ((!ATT && NJ == 1) ? (size_t)TOK * XLD * 4 + 2048 * 4 : 0);
     if (lds > 160 * 1024) return VPF_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
