@@ -113,6 +113,8 @@ SIGS = {
     "vpf_ntxent_fwd": [VP, VP, I, I, F, VP, VP, VP, VP, VP, VP],
     "vpf_ntxent_bwd": [VP, VP, VP, I, I, F, VP, VP, VP, VP],
     "vpf_adamw_step": [VP, VP, VP, VP, VP, L_, VP, I, VP],
+    "vpf_g2e_bn1_prepare": [VP, L_, I, VP, VP, VP, VP, VP, F, F, VP, VP, VP, VP, VP, VP, VP, VP],
+    "vpf_bn_partials_finalize": [VP, I, I, L_, VP, VP, F, F, VP, VP, VP, VP, VP, VP],
     "vpf_bn_small_fwd": [VP, I, I, VP, VP, F, F, VP, VP, VP, VP, VP, I, VP],
     "vpf_bn_small_bwd": [VP, VP, VP, VP, VP, I, I, I, VP, I, VP, VP, VP],
     "vpf_pretrain_loss_fwd": [VP, VP, I, I, F, F, VP, VP, VP, VP, VP, VP, VP],

@@ -378,6 +378,132 @@ extern "C" int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const 
     return VPF_OK;
 }
 
+// Everything between the input moments and the first persistent kernel in ONE single-block launch (training mode): fold of the
+// per-block moment partials (fixed order) -> per-channel sum / sum^2 of the first conv's output -> BatchNorm-1 batch statistics
+// + running-statistics update -> the BatchNorm as an affine (a | b) -> the affine folded into the conv (w1e, b1e).  Five
+// dependent 64-thread launches of ~5 us each sat on the point-cloud branch's critical path for this.
+__global__ void __launch_bounds__(1024) g2e_bn1_prepare_kernel(const float* __restrict__ part, int nblk, long M, int C, const float* __restrict__ W,
+                                                              const float* __restrict__ b, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, float momentum,
+                                                              float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                              long long* __restrict__ num_batches, float* __restrict__ stat,
+                                                              float* __restrict__ ab, float* __restrict__ w1e, float* __restrict__ b1e)
+{
+    __shared__ float fold[14][72];
+    __shared__ float mom[72];
+    const int e = threadIdx.x % 72, rg = threadIdx.x / 72;
+    if (rg < 14) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = rg;
+        for (; r + 42 < nblk; r += 56) {
+            s0 += part[(size_t)r * 72 + e]; s1 += part[(size_t)(r + 14) * 72 + e];
+            s2 += part[(size_t)(r + 28) * 72 + e]; s3 += part[(size_t)(r + 42) * 72 + e];
+        }
+        for (; r < nblk; r += 14) s0 += part[(size_t)r * 72 + e];
+        fold[rg][e] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (rg == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) t += fold[k][e];
+        mom[e] = t;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    float ws1 = 0.f, q = 0.f;
+    for (int i = 0; i < C; ++i) {
+        ws1 += W[c * C + i] * mom[i];
+        for (int j = 0; j < C; ++j) { const float s2 = j <= i ? mom[8 + i * 8 + j] : mom[8 + j * 8 + i]; q += W[c * C + i] * W[c * C + j] * s2; }
+    }
+    const float bb = b[c];
+    const float sum = ws1 + (float)M * bb, sumsq = q + 2.f * bb * ws1 + (float)M * bb * bb;
+    const float mu = sum / (float)M;
+    float var = sumsq / (float)M - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    const float rs = rsqrtf(var + eps);
+    stat[c] = mu; stat[64 + c] = rs;
+    if (running_mean) {
+        const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+    if (num_batches && c == 0) *num_batches += 1;
+    const float a = rs * gamma[c], bo = beta[c] - mu * a;
+    ab[c] = a; ab[64 + c] = bo;
+    for (int i = 0; i < C; ++i) w1e[c * C + i] = a * W[c * C + i];
+    b1e[c] = a * bb + bo;
+}
+// scratch: f32 [72 + 512*72]
+extern "C" int vpf_g2e_bn1_prepare(const float* x, long M, int C, const float* W, const float* b, float* scratch, const float* gamma,
+                                   const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                   long long* num_batches, float* stat, float* ab, float* w1e, float* b1e, void* stream)
+{
+    (void)hipGetLastError();
+    if (!x || !W || !b || !scratch || !gamma || !beta || !stat || !ab || !w1e || !b1e) return VPF_ERR_NULL;
+    if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = grid_for(M, 256 * 4, 512);
+    hipLaunchKernelGGL(g2e_moments_kernel, dim3(nblk), dim3(256), 0, st, x, M, C, scratch + 72);
+    hipLaunchKernelGGL(g2e_bn1_prepare_kernel, dim3(1), dim3(1024), 0, st, (const float*)(scratch + 72), nblk, M, C, W, b, gamma, beta, eps, momentum,
+                       running_mean, running_var, num_batches, stat, ab, w1e, b1e);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// BatchNorm (training mode) from per-workgroup partial rows [nrows][2C] = (sum | sum^2) in one single-block launch: fixed-order
+// fold -> batch statistics + running-statistics update -> the BatchNorm as an affine (ab = a | b).  C <= 256.
+__global__ void __launch_bounds__(1024) bn_partials_finalize_kernel(const float* __restrict__ part, int nrows, int C, long M, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float eps, float momentum,
+                                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                    long long* __restrict__ num_batches, float* __restrict__ stat, float* __restrict__ ab)
+{
+    __shared__ float fold[4][512];
+    const int W2 = 2 * C, ng = 1024 / W2 < 4 ? 1024 / W2 : 4;       // row groups (W2 = 512 -> 2)
+    const int e = threadIdx.x % W2, rg = threadIdx.x / W2;
+    if (rg < ng) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = rg;
+        for (; r + 3 * ng < nrows; r += 4 * ng) {
+            s0 += part[(size_t)r * W2 + e]; s1 += part[(size_t)(r + ng) * W2 + e];
+            s2 += part[(size_t)(r + 2 * ng) * W2 + e]; s3 += part[(size_t)(r + 3 * ng) * W2 + e];
+        }
+        for (; r < nrows; r += ng) s0 += part[(size_t)r * W2 + e];
+        fold[rg][e] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    float sum = 0.f, sumsq = 0.f;
+    for (int k = 0; k < ng; ++k) { sum += fold[k][c]; sumsq += fold[k][C + c]; }
+    const float mu = sum / (float)M;
+    float var = sumsq / (float)M - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    const float rs = rsqrtf(var + eps);
+    stat[c] = mu; stat[C + c] = rs;
+    if (running_mean) {
+        const float unb = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+    if (num_batches && c == 0) *num_batches += 1;
+    const float a = rs * gamma[c];
+    ab[c] = a; ab[C + c] = beta[c] - mu * a;
+}
+extern "C" int vpf_bn_partials_finalize(const float* partials, int nrows, int C, long M, const float* gamma, const float* beta, float eps,
+                                        float momentum, float* running_mean, float* running_var, long long* num_batches, float* stat,
+                                        float* ab, void* stream)
+{
+    (void)hipGetLastError();
+    if (!partials || !gamma || !beta || !stat || !ab) return VPF_ERR_NULL;
+    if (nrows <= 0 || C <= 0 || C > 256 || M <= 0) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, nrows, C, M, gamma, beta, eps, momentum,
+                       running_mean, running_var, num_batches, stat, ab);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 __global__ void __launch_bounds__(256) g2e_conv1_apply_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W,
                                                             const float* __restrict__ b, const float* __restrict__ stat,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ out)

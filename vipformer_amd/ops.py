@@ -17,6 +17,7 @@ accumulation, bf16 activations between fused ops, fp32 statistics (LayerNorm/Bat
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -1209,6 +1210,7 @@ def _bn_bwd(dy, x, C, stat, bn, relu, training, out_bf16, want_dx=True):
 
 
 # --------------------------------------------------------------------------- Group2Emb (utils.py:144-189)
+G2E_BN_MERGED = [os.environ.get("VPF_G2E_BN_MERGED", "1") != "0"]   # BatchNorm bookkeeping of Group2Emb as single launches
 G2E_DEBUG = {}      # {"dbg": int64 tensor [256*2*6]} -> per-phase cycle stamps of vpf_g2e_bwd (diagnostic)
 
 
@@ -1231,7 +1233,16 @@ class Group2EmbFn(torch.autograd.Function):
         Dm = c4.weight.shape[0]
         w1 = c1.weight.data.view(64, C)
         stat1 = torch.empty(128, dtype=F32, device=dev)
-        if training:
+        fast = K == 32 and C == 3 and Dm % 32 == 0 and Dm <= 512
+        merged = training and fast and G2E_BN_MERGED[0]
+        if merged:
+            # moments -> statistics -> affine -> folded conv in two launches (vpf_g2e_bn1_prepare)
+            scratch = torch.empty(72 + 512 * 72, dtype=F32, device=dev)
+            ab1 = torch.empty(128, dtype=F32, device=dev)
+            w1e = torch.empty(64 * C + 64, dtype=F32, device=dev)
+            L.call("vpf_g2e_bn1_prepare", x, M, C, w1, c1.bias.data, scratch, bn1.weight.data, bn1.bias.data, float(bn1.eps),
+                   float(bn1.momentum), bn1.running_mean, bn1.running_var, bn1.num_batches_tracked, stat1, ab1, w1e, w1e[64 * C:])
+        elif training:
             scratch = torch.empty(72 + 512 * 72, dtype=F32, device=dev)
             sums = torch.empty(128, dtype=F32, device=dev)
             L.call("vpf_g2e_conv1_stats_moments", x, M, C, w1, c1.bias.data, scratch, sums[:64], sums[64:])
@@ -1240,12 +1251,13 @@ class Group2EmbFn(torch.autograd.Function):
         else:
             L.call("vpf_bn_finalize", None, None, M, 64, float(bn1.eps), float(bn1.momentum), 0, bn1.running_mean,
                    bn1.running_var, None, stat1)
-        if K == 32 and C == 3 and Dm % 32 == 0 and Dm <= 512:
+        if fast:
             # two persistent weight-stationary kernels: activations of a pair of groups never leave the CU except h3
-            ab1 = torch.empty(128, dtype=F32, device=dev)
-            L.call("vpf_bn_affine", stat1, bn1.weight.data, bn1.bias.data, 64, ab1)
-            w1e = torch.empty(64 * C + 64, dtype=F32, device=dev)
-            L.call("vpf_g2e_fold_bn1", w1, c1.bias.data, ab1, C, w1e, w1e[64 * C:])
+            if not merged:
+                ab1 = torch.empty(128, dtype=F32, device=dev)
+                L.call("vpf_bn_affine", stat1, bn1.weight.data, bn1.bias.data, 64, ab1)
+                w1e = torch.empty(64 * C + 64, dtype=F32, device=dev)
+                L.call("vpf_g2e_fold_bn1", w1, c1.bias.data, ab1, C, w1e, w1e[64 * C:])
             a1 = torch.empty(M, 64, dtype=BF16, device=dev)
             h2 = torch.empty(M, 128, dtype=BF16, device=dev)
             gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
@@ -1255,17 +1267,22 @@ class Group2EmbFn(torch.autograd.Function):
             nwg = ctypes.c_int(0)
             L.call("vpf_g2e_fwd_a", x, NG, C, w1e, w1e[64 * C:], shadow([c2.weight]), c2.bias.data, shadow([c3.weight]), c3.bias.data,
                    a1, h2, gmax, arg2, h3, part, ctypes.addressof(nwg))
-            sums2 = torch.empty(512, dtype=F32, device=dev)
-            L.call("vpf_sum_rows_f32", part, nwg.value, 512, sums2)          # fixed order: deterministic BatchNorm-2 statistics
             stat2 = torch.empty(512, dtype=F32, device=dev)
-            if training:
-                L.call("vpf_bn_finalize", sums2[:256], sums2[256:], M, 256, float(bn2.eps), float(bn2.momentum), 1, bn2.running_mean,
-                       bn2.running_var, bn2.num_batches_tracked, stat2)
-            else:
-                L.call("vpf_bn_finalize", None, None, M, 256, float(bn2.eps), float(bn2.momentum), 0, bn2.running_mean,
-                       bn2.running_var, None, stat2)
             ab2 = torch.empty(512, dtype=F32, device=dev)
-            L.call("vpf_bn_affine", stat2, bn2.weight.data, bn2.bias.data, 256, ab2)
+            if merged:
+                # fixed-order fold of the per-workgroup partials (deterministic BatchNorm-2 statistics) + statistics + affine: one launch
+                L.call("vpf_bn_partials_finalize", part, nwg.value, 256, M, bn2.weight.data, bn2.bias.data, float(bn2.eps),
+                       float(bn2.momentum), bn2.running_mean, bn2.running_var, bn2.num_batches_tracked, stat2, ab2)
+            else:
+                if training:
+                    sums2 = torch.empty(512, dtype=F32, device=dev)
+                    L.call("vpf_sum_rows_f32", part, nwg.value, 512, sums2)
+                    L.call("vpf_bn_finalize", sums2[:256], sums2[256:], M, 256, float(bn2.eps), float(bn2.momentum), 1, bn2.running_mean,
+                           bn2.running_var, bn2.num_batches_tracked, stat2)
+                else:
+                    L.call("vpf_bn_finalize", None, None, M, 256, float(bn2.eps), float(bn2.momentum), 0, bn2.running_mean,
+                           bn2.running_var, None, stat2)
+                L.call("vpf_bn_affine", stat2, bn2.weight.data, bn2.bias.data, 256, ab2)
             out = torch.empty(NG, Dm, dtype=F32, device=dev)
             arg4 = torch.empty(NG, Dm, dtype=torch.uint8, device=dev)
             L.call("vpf_g2e_fwd_b", h3, NG, ab2, shadow([c4.weight]), c4.bias.data, Dm, out, arg4)
