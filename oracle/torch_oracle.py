@@ -311,6 +311,28 @@ def pc_forward(sd, pts, start_idx, a: Arch, train: bool, masks: Optional[Masks] 
     return latent_head(sd, "latent_head.", bb, train, buffers), bb
 
 
+def finetune_head(sd, pre: str, x, train: bool, buffers=None):
+    """partseg.py:572-581: three blocks BN1d - ReLU - Linear (with bias): 2D -> D -> D/2 -> num_obj_classes."""
+    h = x
+    for i in (0, 3, 6):
+        h = Q(F.relu(_bn(sd, pre + f"{i}.", h, train, buffers)))
+        h = F.linear(h, Q(sd[pre + f"{i + 2}.weight"]), sd[pre + f"{i + 2}.bias"])
+    return h
+
+
+def pc_ft_forward(sd, pts, start_idx, a: Arch, train: bool, masks: Optional[Masks] = None, buffers=None):
+    """CrossFormer_pc_mp_ft.forward, partseg.py:583-605 (the ModelNet fine-tuning classifier): the pre-training backbone
+    (pc_forward above without latent_head) followed by finetune_head.  Returns the logits [B, num_obj_classes]."""
+    masks = masks or Masks("off")
+    kv = adapter(sd, "input_adapter.", pts)
+    fidx = fps_indices(pts, start_idx, a.G)
+    nb, ct, _ = divide_patches(pts, fidx, a.K, True)
+    tok = group2emb(sd, "group2emb.", nb, train, buffers)
+    pos = pos_mlp(sd, "position_emb.", ct)
+    x, _ = encoder(sd, "encoder.", tok, pos, kv, a, masks)
+    return finetune_head(sd, "finetune_head.", pool(x), train, buffers)
+
+
 def patchify(imgs, p: int):
     """partseg.py:632: 'b (h p1) (w p2) c -> b (h w) (p1 p2 c)'."""
     B, Hh, Ww, C = imgs.shape

@@ -277,6 +277,44 @@ def main():
             save(f"dropout_{name}.npz", pc_feats=fd, pc_backbone=bd, img_feats=fid, img_backbone=bid)
     print("done")
 
+def make_ft(names=("tiny", "c1")):
+    """CrossFormer_pc_mp_ft (partseg.py:553-605, the ModelNet fine-tuning classifier: the pre-training backbone + a 3-block
+    BatchNorm-ReLU-Linear head): eval / train logits (dropout 0), the gradients of a loss linear in the logits with respect to
+    the head, and the first BatchNorm's running statistics after one training-mode forward."""
+    NCLS = 40
+    for name in names:
+        a = Hh.ARCHS[name]
+        torch.manual_seed(0)
+        ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+        ft = RP.CrossFormer_pc_mp_ft(ad, a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.0, 0.0, True, NCLS)
+        json.dump(keyshapes(ft), open(os.path.join(HERE, f"keys_pcft_{name}.json"), "w"))
+        ft.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pcft_{name}.json"), 100))
+        B = Hh.MODEL_BATCH[name]
+        pts = Hh.synth_points(300, 2 * B, a["N"], 3, "uniform")
+        start = Hh.synth_start(300, 2 * B, a["N"])
+        res = {}
+        RU.knn_point = canonical_knn
+        ft.eval()
+        with torch.no_grad(), forced_start(start):
+            res["eval_logits"] = ft(pts)
+        ft.train(); ft.zero_grad()
+        with forced_start(start):
+            y = ft(pts)
+        res["train_logits"] = y
+        (y * Hh.synth_like(710, y.shape)).sum().backward()
+        hp = [(k, p) for k, p in ft.named_parameters() if k.startswith("finetune_head.")]
+        res["head_grad_norms"] = np.array([p.grad.double().norm().item() for _, p in hp])
+        json.dump([k for k, _ in hp], open(os.path.join(HERE, f"grad_names_pcft_{name}.json"), "w"))
+        for k in ("finetune_head.0.running_mean", "finetune_head.0.running_var", "finetune_head.6.running_var"):
+            res["buf." + k] = ft.state_dict()[k].clone()
+        RU.knn_point = _orig_knn
+        save(f"modelft_{name}.npz", **res)
+        print("ft fixture", name, {k: tuple(np.asarray(v.detach() if torch.is_tensor(v) else v).shape) for k, v in res.items()})
+
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ft":
+        make_ft()
+    else:
+        main()
+        make_ft()

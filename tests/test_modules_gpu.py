@@ -265,6 +265,44 @@ def test_models_vs_reference_golden(name):
     ck.done()
 
 
+@pytest.mark.parametrize("name", ["tiny", "c1"])
+def test_finetune_classifier_vs_reference_golden(name):
+    """CrossFormer_pc_mp_ft (partseg.py:553-605): eval / train logits and the head's gradients against the
+    reference fixture (tests/golden/make_golden.py make_ft).  Tolerances as for the pre-training heads: a whole network of bf16
+    operand rounding in eval mode (2 x FWD_TOL), BatchNorm over 8-16 samples amplifying it in training mode (10 x FWD_TOL)."""
+    from vipformer_amd.model.pointcloud import CrossFormer_pc_mp_ft, PointCloudInputAdapter
+    a = Hh.ARCHS[name]
+    ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+    ft = CrossFormer_pc_mp_ft(ad, a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.0, 0.0, True, 40)
+    ft.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pcft_{name}.json"), 100))      # strict: same keys as the reference
+    ft = ft.cuda()
+    g = Hh.golden(f"modelft_{name}.npz")
+    ck = Checks(f"finetune[{name}]")
+    B = Hh.MODEL_BATCH[name]
+    pts = Hh.synth_points(300, 2 * B, a["N"]).cuda()
+    start = Hh.synth_start(300, 2 * B, a["N"]).cuda()
+    ft.eval()
+    with torch.no_grad(), forced_start(start):
+        y = ft(pts)
+    ck.lt("eval logits rel", rel(y, g["eval_logits"]), 2 * FWD_TOL)
+    ft.train(); ft.zero_grad()
+    with forced_start(start):
+        y = ft(pts)
+    ck.lt("train logits rel", rel(y, g["train_logits"]), 10 * FWD_TOL)
+    (y * Hh.synth_like(710, y.shape).cuda()).sum().backward()
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_pcft_{name}.json")))
+    params = dict(ft.named_parameters())
+    norms = np.array([params[k].grad.double().norm().item() for k in names])
+    refn = g["head_grad_norms"]
+    big = refn > 1e-3 * refn.max()
+    ratio = norms[big] / refn[big]
+    report(f"finetune[{name}] head grad-norm ratio min {ratio.min():.3f} max {ratio.max():.3f}")
+    ck.lt("head grad-norm ratio max dev", float(np.abs(ratio - 1).max()), 0.08)
+    for k in ("finetune_head.0.running_mean", "finetune_head.0.running_var", "finetune_head.6.running_var"):
+        ck.lt(f"buffer {k} rel", rel(ft.state_dict()[k], g["buf." + k]), 3e-2)
+    ck.done()
+
+
 def _site_masks(model, B_tokens, kv_len, a, device):
     """Export, from the kernels' RNG, the keep mask of every dropout site of ``model.encoder`` under the
     oracle's site names."""

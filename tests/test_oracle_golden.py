@@ -164,3 +164,27 @@ def test_param_counts_match_paper_tables():
     c = json.load(open(os.path.join(Hh.GOLDEN_DIR, "param_counts.json")))
     assert c["c1"]["pc_params"] == 4074368 and c["c3"]["pc_params"] == 5127040 and c["c4"]["pc_params"] == 16654336
     assert c["c1"]["pc_state"] == 148 and c["c1"]["img_state"] == 123 and c["c3"]["pc_state"] == 174
+
+
+@pytest.mark.parametrize("name", ["tiny", "c1"])
+def test_finetune_classifier_vs_reference(name):
+    """oracle.pc_ft_forward vs CrossFormer_pc_mp_ft of the reference (partseg.py:553-605; fixture: make_golden.py make_ft)."""
+    arch, a = _arch(name)
+    g = Hh.golden(f"modelft_{name}.npz")
+    B = Hh.MODEL_BATCH[name]
+    sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pcft_{name}.json"), 100)
+    pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
+    with torch.no_grad():
+        _close(O.pc_ft_forward(sd, pts, start, arch, False), g["eval_logits"], 1e-4, 1e-4)
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_pcft_{name}.json")))
+    hp = {k: sd[k].clone().requires_grad_() for k in names}
+    sd2 = dict(sd); sd2.update(hp)
+    for k in list(sd2):
+        if "cross_attn_1." in k:
+            sd2[k] = sd2[k.replace("cross_attn_1.", "cross_attn_n.")]
+    bufs = {}
+    y = O.pc_ft_forward(sd2, pts, start, arch, True, O.Masks("off"), bufs)
+    _close(y, g["train_logits"], 2e-4, 2e-4)
+    (y * Hh.synth_like(710, y.shape)).sum().backward()
+    norms = np.array([hp[k].grad.double().norm().item() for k in names])
+    np.testing.assert_allclose(norms, g["head_grad_norms"], rtol=2e-3, atol=1e-5)

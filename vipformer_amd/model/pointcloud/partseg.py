@@ -347,6 +347,31 @@ class CrossFormer_pc_mp(nn.Module):
         return feats, backbone_feats
 
 
+class CrossFormer_pc_mp_ft(CrossFormer_pc_mp):
+    """partseg.py:553-605: the ModelNet fine-tuning classifier = the pre-training backbone + a three-block BatchNorm - ReLU -
+    Linear head.  forward(pts [B,N,3]) -> logits [B, num_obj_classes].  (latent_head stays a member, unused, as in the
+    reference: a pre-trained pc_model_best.pth loads with strict=False either way.)"""
+
+    def __init__(self, input_adapter=None, num_latents=128, num_latent_channels=384, group_size=32,
+                 num_cross_attention_layers=1, num_cross_attention_heads=6, num_self_attention_layers=6,
+                 num_self_attention_heads=6, mlp_widen_factor=4, max_dpr=0, atten_drop=0.1, mlp_drop=0.5, modal_prior=True,
+                 num_obj_classes=40):
+        super().__init__(input_adapter, num_latents, num_latent_channels, group_size, num_cross_attention_layers,
+                         num_cross_attention_heads, num_self_attention_layers, num_self_attention_heads, mlp_widen_factor, max_dpr,
+                         atten_drop, mlp_drop, modal_prior)
+        D = num_latent_channels
+        self.finetune_head = nn.Sequential(nn.BatchNorm1d(2 * D), nn.ReLU(), nn.Linear(2 * D, D),
+                                           nn.BatchNorm1d(D), nn.ReLU(), nn.Linear(D, D // 2),
+                                           nn.BatchNorm1d(D // 2), nn.ReLU(), nn.Linear(D // 2, num_obj_classes))
+
+    def forward(self, pts):
+        h = self.backbone(pts)
+        head = self.finetune_head
+        for i in (0, 3, 6):
+            h = ops.BnReluLinearFn.apply(h, head[i], head[i + 2], self.training, *head[i].parameters(), *head[i + 2].parameters())
+        return h
+
+
 class CrossFormer_img_mp(nn.Module):
     """partseg.py:608-680: image branch.  forward(imgs [B,H,W,3]) -> (feats [B,D], backbone [B,2D]).
     ``imgs`` may be the permuted NCHW view pretrain.py:179 hands over (strides are honoured)."""

@@ -1561,6 +1561,48 @@ class HeadFn(torch.autograd.Function):
         return (dx, None, None) + (None,) * ctx.nparams
 
 
+class BnReluLinearFn(torch.autograd.Function):
+    """One BatchNorm1d - ReLU - Linear block of an MLP head (finetune_head, partseg.py:572-581), fp32 in / out: the same kernels
+    as HeadFn (one-kernel BatchNorm for small batches, MFMA GEMM with a fused bias) for any number of blocks."""
+
+    @staticmethod
+    def forward(ctx, x, bn, lin, training, *params):
+        ctx.nparams = len(params)
+        Bn, C1 = x.shape
+        C2 = lin.weight.shape[0]
+        x = x.contiguous().float()
+        small = training and Bn <= 4096 and C1 % 64 == 0
+        if small:
+            st = torch.empty(2 * C1, dtype=F32, device=x.device)
+            a = torch.empty(Bn, C1, dtype=BF16, device=x.device)
+            L.call("vpf_bn_small_fwd", x, Bn, C1, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), bn.running_mean,
+                   bn.running_var, bn.num_batches_tracked, st, a, 1)
+        else:
+            st = _bn_stat(x, C1, bn, training)
+            a = _bn_act(x, C1, st, bn, True, True)
+        y = linear_fwd(a, shadow([lin.weight]), C2, C1, lin.bias.data if lin.bias is not None else None, out_f32=True)
+        ctx.mods, ctx.training, ctx.small = (bn, lin), training, small
+        ctx.save_for_backward(x, st, a)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, a = ctx.saved_tensors
+        bn, lin = ctx.mods
+        C1, C2 = x.shape[1], lin.weight.shape[0]
+        dy16 = to_bf16(dy)
+        if lin.bias is not None:
+            colsum(dy16, C2, grad_buf(lin.bias))
+        linear_wgrad(dy16, a, C2, C1, grad_buf(lin.weight))
+        da = linear_dgrad(dy16, shadow([lin.weight]), C2, C1, out_f32=True)
+        if ctx.small:
+            dx = torch.empty(x.shape[0], C1, dtype=F32, device=x.device)
+            L.call("vpf_bn_small_bwd", da, x, st, bn.weight.data, bn.bias.data, x.shape[0], C1, 1, dx, 0, grad_buf(bn.weight), grad_buf(bn.bias))
+        else:
+            dx = _bn_bwd(da, x, C1, st, bn, True, ctx.training, False)
+        return (dx, None, None, None) + (None,) * ctx.nparams
+
+
 # --------------------------------------------------------------------------- NT-Xent
 class NTXentFn(torch.autograd.Function):
     """lightly==1.1.21 NTXentLoss(temperature, memory_bank_size=0) -- pretrain.py:155,196,202."""
