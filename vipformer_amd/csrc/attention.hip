@@ -755,6 +755,24 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
     const float c = a.scale * LOG2E;
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
     const bool drop = a.p > 0.f;
+    // A wave's [32 x 64] result tiles (dQ, dK, dV) leave through ITS OWN 32 rows of the K / V tiles, which only it reads once
+    // phase B has its fragments in registers: the accumulator layout would store 8 bytes per lane into 32 different rows,
+    // from LDS the same tile goes out as 128-byte rows (16 bytes per lane, 8 rows per wave-instruction).
+    uint2 dqp[2][4];
+    auto tile_out = [&](bf16_t* S, const uint2 (&tp)[2][4], bf16_t* G, long ld) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<uint2*>(S + (wave * 32 + ql) * KLD + dt * 32 + 8 * gq + 4 * hl) = tp[dt][gq];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave: LDS operations complete in order
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = wave * 32 + it * 8 + (lane >> 3), ch = (lane & 7) * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(S + row * KLD + ch);
+            if (row < L) *reinterpret_cast<uint4*>(G + ((size_t)b * L + row) * ld + hd * DH + ch) = v;
+        }
+    };
     // ------------------------------------------------------------------ phase A: dQ (lane = query)
     {
         bf16x8_t qf[4], dof[4];
@@ -798,20 +816,15 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                     dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, kv0 + 16 * s2, dt * 32), dsf, dq[dt], 0, 0, 0);
             }
         }
-        if (qok) {
-            bf16_t* op = a.dQ + ((size_t)b * L + q) * a.lddq + hd * DH;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    uint2 u;
-                    u.x = pack_bf16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
-                    u.y = pack_bf16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
-                    *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
-                }
-        }
+            for (int gq = 0; gq < 4; ++gq) {
+                dqp[dt][gq].x = pack_bf16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
+                dqp[dt][gq].y = pack_bf16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+            }
     }
-    __syncthreads();                      // sL / sDel of every query are in LDS
+    __syncthreads();                      // sL / sDel of every query are in LDS; no wave reads K / V rows of another wave any more
     // ------------------------------------------------------------------ phase B: dK, dV (lane = key)
     {
         const int kv = q;
@@ -819,6 +832,8 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
         bf16x8_t kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(sK, KLD, wave * 32, ks * 16); vf[ks] = frag_row(sV, KLD, wave * 32, ks * 16); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers before the rows are reused
+        tile_out(sK, dqp, a.dQ, a.lddq);
         f32x16_t dk[2], dv[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
@@ -879,19 +894,18 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                 }
             }
         }
-        if (kvok) {
-            bf16_t* kp = a.dK + ((size_t)b * L + kv) * a.lddk + hd * DH;
-            bf16_t* vp = a.dV + ((size_t)b * L + kv) * a.lddv + hd * DH;
+        {
+            (void)kvok; (void)kv;
+            uint2 tk[2][4], tv[2][4];
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    uint2 u, w;
-                    u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
-                    w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
-                    *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
-                    *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
+                    tk[dt][gq].x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); tk[dt][gq].y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                    tv[dt][gq].x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); tv[dt][gq].y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
                 }
+            tile_out(sK, tk, a.dK, a.lddk);
+            tile_out(sV, tv, a.dV, a.lddv);
         }
     }
 }
