@@ -345,8 +345,10 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
     }
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = 1.f / lt;
-    if (qok) {
-        bf16_t* op = a.O + ((size_t)b * L + q) * a.ldo + hd * DH;
+    {
+        // the wave's [32 x 64] output tile goes through its own LDS staging rows and leaves as 128-byte rows (16 bytes per lane,
+        // 8 rows per wave-instruction) instead of 8 bytes per lane into 32 different rows
+        bf16_t* sO = rlds + 2 * LPT * KLD + wave * 32 * KLD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -354,15 +356,24 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
                 uint2 u;
                 u.x = pack_bf16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
                 u.y = pack_bf16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
-                *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
+                *reinterpret_cast<uint2*>(sO + (lane & 31) * KLD + dt * 32 + 8 * gq + 4 * hl) = u;
             }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave: LDS operations complete in order
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int rl = it * 8 + (lane >> 3), row = wave * 32 + rl, ch = (lane & 7) * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(sO + rl * KLD + ch);
+            if (row < L) *reinterpret_cast<uint4*>(a.O + ((size_t)b * L + row) * a.ldo + hd * DH + ch) = v;
+        }
+    }
+    if (qok) {
         if (hl == 0 && a.LSE) a.LSE[(size_t)bh * L + q] = (m + log2f(lt)) * LN2;
     }
 }
 template <int NW>
 static int launch_res_fwd(const AttnArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)2 * NW * 32 * KLD * sizeof(bf16_t);
+    constexpr size_t lds = (size_t)3 * NW * 32 * KLD * sizeof(bf16_t);      // K, V and the per-wave output staging rows
     static bool attr = false;
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
