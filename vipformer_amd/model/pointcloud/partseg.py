@@ -319,15 +319,32 @@ class CrossFormer_pc_mp(nn.Module):
                                 mlp_drop, modal_prior)
         self.latent_head = _latent_head(num_latent_channels)
 
-    def backbone(self, pts):
+    def backbone(self, pts, _groups=None):
+        """_groups (an extension the trainer uses, not part of the reference signature): (neighborhood, center, event) computed by
+        divide_patches on ANOTHER stream; the K / V producer -- which needs only the raw points -- is then issued first and this
+        stream waits for the event only in front of Group2Emb, so FPS / kNN (latency-bound, a few workgroups) run beside it."""
         enc = self.encoder
         fuse_kv = (ops.adapter_kv_supported(self.input_adapter, pts) and enc.num_cross_attention_layers == 1 and pts.is_cuda
                    and ops.SA_FUSED[0] and ops.ENC_FUSED[0] and self.training == enc.training)
+        kv = None
         if not fuse_kv:
             pts_embs = self.input_adapter(pts)
-        neighborhood, center = divide_patches(pts, self.num_groups, self.group_size)
+        elif _groups is not None and pts.shape[0] * self.num_groups * pts.shape[2] > 0:
+            cross = enc.cross_attn_1[0].module
+            probe = pts.new_empty((pts.shape[0], self.num_groups, self.group2emb.second_conv[3].weight.shape[0]))
+            if enc.fused_ok(probe, pts.new_empty((pts.shape[0], 1, 2 * probe.shape[2]))):
+                params = list(self.input_adapter.parameters()) + list(cross.kv_norm.parameters()) + [cross.attention.k_proj.weight, cross.attention.v_proj.weight]
+                kv = ops.AdapterKVFn.apply(pts, self.input_adapter, cross, *params)
+        if _groups is not None:
+            neighborhood, center, ev = _groups
+            torch.cuda.current_stream().wait_event(ev)
+        else:
+            neighborhood, center = divide_patches(pts, self.num_groups, self.group_size)
         group_embs = self.group2emb(neighborhood)
         pos_embs = ops.PosMLPFn.apply(center, self.position_emb, *self.position_emb.parameters())
+        if kv is not None:
+            x = enc(group_embs, pos_embs, kv, kv_ready=True)
+            return ops.PoolFn.apply(x)
         if fuse_kv:
             cross = enc.cross_attn_1[0].module
             probe = group_embs.new_empty((group_embs.shape[0], 1, 2 * group_embs.shape[2]))       # shape probe only
@@ -341,8 +358,8 @@ class CrossFormer_pc_mp(nn.Module):
         x = enc(group_embs, pos_embs, pts_embs)
         return ops.PoolFn.apply(x)
 
-    def forward(self, pts):
-        backbone_feats = self.backbone(pts)
+    def forward(self, pts, _groups=None):
+        backbone_feats = self.backbone(pts, _groups)
         feats = ops.HeadFn.apply(backbone_feats, self.latent_head, self.training, *self.latent_head.parameters())
         return feats, backbone_feats
 

@@ -24,6 +24,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -93,6 +95,7 @@ class Pretrainer:
         # stream so its kernels fill the CUs that FPS / kNN / the small GEMMs of the pc branch leave idle
         self.overlap = True
         self.fused_losses = True
+        self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "1") == "1"
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._graph = None
         self._static = None
@@ -117,9 +120,19 @@ class Pretrainer:
         if self.overlap and self._side is not None:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
+            groups = None
             with torch.cuda.stream(self._side):
+                if self.preproc_on_side:
+                    # FPS + kNN grouping ahead of the image branch on ITS stream (it has ~0.6 ms of slack): the point-cloud
+                    # stream starts with the K / V producer, which needs only the raw points, and meets the groups later
+                    from .model.pointcloud.utils import divide_patches
+                    nb, ct = divide_patches(pc, self.pc_model.num_groups, self.pc_model.group_size)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    nb.record_stream(main); ct.record_stream(main)
+                    groups = (nb, ct, ev)
                 img_feats = self.img_model(imgs)[0]
-            feats = self.pc_model(pc)[0]
+            feats = self.pc_model(pc, _groups=groups)[0] if groups is not None else self.pc_model(pc)[0]
             main.wait_stream(self._side)
             img_feats.record_stream(main)
         else:
