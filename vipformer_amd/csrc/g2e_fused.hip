@@ -44,13 +44,11 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
 
     // ---- per-thread constants: conv1 (BN folded) for 8 channels of one row
     const int c1row = t >> 3, c1ch = (t & 7) * 8;
-    float w1[8][3], b1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        b1[j] = p.b1e[c1ch + j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) w1[j][i] = i < p.C ? p.w1e[(c1ch + j) * p.C + i] : 0.f;
-    }
+    // (kept in LDS as [channel][w0 w1 w2 b]: 32 registers per thread for them made the kernel spill next to the two weight-stationary
+    // fragment sets)
+    __shared__ float4 sW1[64];
+    if (t < 64) sW1[t] = make_float4(p.C > 0 ? p.w1e[t * p.C + 0] : 0.f, p.C > 1 ? p.w1e[t * p.C + 1] : 0.f, p.C > 2 ? p.w1e[t * p.C + 2] : 0.f, p.b1e[t]);
+    __syncthreads();
     // ---- weight-stationary MFMA B fragments
     // conv2: wave w -> row tile rt2 = w >> 2, column tile ct2 = w & 3 ; B[k][n] = W2[n][k], lane holds n = ct2*32 + l31, k = ks*16 + 8h + j
     const int rt2 = w >> 2, ct2 = w & 3;
@@ -88,7 +86,7 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
             if (c1row < nrows) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(w1[j][0] * x0 + w1[j][1] * x1 + w1[j][2] * x2 + b1[j], 0.f);
+                for (int j = 0; j < 8; ++j) { const float4 wv = sW1[c1ch + j]; v[j] = fmaxf(wv.x * x0 + wv.y * x1 + wv.z * x2 + wv.w, 0.f); }
                 o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
                 *reinterpret_cast<uint4*>(p.a1 + (size_t)(row0 + c1row) * 64 + c1ch) = o;
             }
