@@ -423,7 +423,9 @@ extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, co
     if (!h3_bf16 || !ab2 || !dout || !arg4 || !dW4 || !db4) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0) return VPF_ERR_BADSHAPE;
     G2eW4 p = {(const bf16_t*)h3_bf16, NG, ab2, dout, arg4, Dm, dW4, db4};
-    long gx = NG < 128 ? NG : 128;
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("VPF_G2E_W4_GRID"); cap = e ? atoi(e) : 256; if (cap < 1) cap = 256; }      // one workgroup per CU: twice the flush atomics of 128 workgroups, half the walk (168 -> ~110 us)
+    long gx = NG < cap ? NG : cap;
     hipLaunchKernelGGL(g2e_wgrad4_kernel, dim3((unsigned)gx, vpf_cdiv(Dm, 256)), dim3(512), 0, (hipStream_t)stream, p);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
