@@ -257,7 +257,7 @@ int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b
 /* Group2Emb (utils.py:150-189), training mode, the BatchNorm bookkeeping between the kernels as single launches:
  * vpf_g2e_bn1_prepare = vpf_g2e_conv1_stats_moments + vpf_bn_finalize + vpf_bn_affine + vpf_g2e_fold_bn1 (stat = mean | rstd [128],
  * ab = a | b [128], w1e [64*C], b1e [64]; scratch f32 [72 + 512*72]);  vpf_bn_partials_finalize = vpf_sum_rows_f32 + vpf_bn_finalize
- * + vpf_bn_affine on per-workgroup partial rows [nrows][2C] (C <= 256). */
+ * + vpf_bn_affine on per-workgroup partial rows [nrows][2C] (C % 64 == 0). */
 int vpf_g2e_bn1_prepare(const float* x, long M, int C, const float* W, const float* b, float* scratch, const float* gamma, const float* beta,
                         float eps, float momentum, float* running_mean, float* running_var, long long* num_batches, float* stat, float* ab,
                         float* w1e, float* b1e, void* stream);

@@ -457,31 +457,32 @@ extern "C" int vpf_g2e_bn1_prepare(const float* x, long M, int C, const float* W
     return VPF_OK;
 }
 
-// BatchNorm (training mode) from per-workgroup partial rows [nrows][2C] = (sum | sum^2) in one single-block launch: fixed-order
-// fold -> batch statistics + running-statistics update -> the BatchNorm as an affine (ab = a | b).  C <= 256.
+// BatchNorm (training mode) from per-workgroup partial rows [nrows][2C] = (sum | sum^2) in one launch: fixed-order fold -> batch
+// statistics + running-statistics update -> the BatchNorm as an affine (ab = a | b).  C % 64 == 0; one block per 64 channels
+// (their 64 sums and 64 sums of squares x 8 row groups = 1024 threads, 4 loads in flight per thread).
 __global__ void __launch_bounds__(1024) bn_partials_finalize_kernel(const float* __restrict__ part, int nrows, int C, long M, const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, float eps, float momentum,
                                                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                     long long* __restrict__ num_batches, float* __restrict__ stat, float* __restrict__ ab)
 {
-    __shared__ float fold[4][512];
-    const int W2 = 2 * C, ng = 1024 / W2 < 4 ? 1024 / W2 : 4;       // row groups (W2 = 512 -> 2)
-    const int e = threadIdx.x % W2, rg = threadIdx.x / W2;
-    if (rg < ng) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int r = rg;
-        for (; r + 3 * ng < nrows; r += 4 * ng) {
-            s0 += part[(size_t)r * W2 + e]; s1 += part[(size_t)(r + ng) * W2 + e];
-            s2 += part[(size_t)(r + 2 * ng) * W2 + e]; s3 += part[(size_t)(r + 3 * ng) * W2 + e];
-        }
-        for (; r < nrows; r += ng) s0 += part[(size_t)r * W2 + e];
-        fold[rg][e] = (s0 + s1) + (s2 + s3);
+    __shared__ float fold[8][128];
+    const int W2 = 2 * C;
+    const int e = threadIdx.x & 127, rg = threadIdx.x >> 7;
+    const int col = e < 64 ? blockIdx.x * 64 + e : C + blockIdx.x * 64 + (e - 64);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = rg;
+    for (; r + 24 < nrows; r += 32) {
+        s0 += part[(size_t)r * W2 + col]; s1 += part[(size_t)(r + 8) * W2 + col];
+        s2 += part[(size_t)(r + 16) * W2 + col]; s3 += part[(size_t)(r + 24) * W2 + col];
     }
+    for (; r < nrows; r += 8) s0 += part[(size_t)r * W2 + col];
+    fold[rg][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    const int c = threadIdx.x;
-    if (c >= C) return;
+    if (threadIdx.x >= 64) return;
+    const int c = blockIdx.x * 64 + threadIdx.x;
     float sum = 0.f, sumsq = 0.f;
-    for (int k = 0; k < ng; ++k) { sum += fold[k][c]; sumsq += fold[k][C + c]; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sum += fold[k][threadIdx.x]; sumsq += fold[k][64 + threadIdx.x]; }
     const float mu = sum / (float)M;
     float var = sumsq / (float)M - mu * mu;
     var = var < 0.f ? 0.f : var;
@@ -502,8 +503,8 @@ extern "C" int vpf_bn_partials_finalize(const float* partials, int nrows, int C,
 {
     (void)hipGetLastError();
     if (!partials || !gamma || !beta || !stat || !ab) return VPF_ERR_NULL;
-    if (nrows <= 0 || C <= 0 || C > 256 || M <= 0) return VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, nrows, C, M, gamma, beta, eps, momentum,
+    if (nrows <= 0 || C <= 0 || (C % 64) || M <= 0) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(bn_partials_finalize_kernel, dim3(C / 64), dim3(1024), 0, (hipStream_t)stream, partials, nrows, C, M, gamma, beta, eps, momentum,
                        running_mean, running_var, num_batches, stat, ab);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
