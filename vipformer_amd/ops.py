@@ -1016,13 +1016,14 @@ class EncoderFusedFn(torch.autograd.Function):
         wg.add(du, n2, Hd, D, grad_buf(cmlp[1].weight), grad_buf(cmlp[1].bias))
         wg.add(dz1, o, D, D, grad_buf(catt.o_proj.weight), grad_buf(catt.o_proj.bias))
         wg.add(dq, nq, D, D, gW[:D * D])
+        if not ctx.kv_ready:
+            wg.add(dkv, nk, 2 * D, D, gW[D * D:])                      # (image branch: K / V weights' gradient in the same grouped launch)
         wg.flush()
         dnq = linear_dgrad(dq, w16[:D * D], D, D)
         dxkv = None
         if ctx.kv_ready:
             dxkv = dkv.view(B, Lkv, 2 * D)                              # AdapterKVFn.backward takes it from here
         else:
-            linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
             dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
             if ctx.needs_input_grad[2]:
                 dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16)).view(B, Lkv, D)
