@@ -382,6 +382,33 @@ typedef struct VpfAdapterKvBwd {
     void* dxkv; void* da1; float* pgrad_kv;
 } VpfAdapterKvBwd;
 int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* host_args, void* stream);
+/* ------------------------------------------------------------------ part segmentation (BASELINE config 5)
+ * CrossFormer_partseg.forward partseg.py:407-470 + PointNetFeaturePropagation.forward utils.py:205-242: everything that the
+ * pre-training entry points above do not already cover (the 1x1 convolutions are vpf_gemm_bf16, BatchNorm the entries above). */
+/* utils.py:219-230: the three nearest of S centres per point by the exact square_distance recipe (the reference sorts all S),
+ * weights 1/(d + 1e-8) normalised; idx int32 [B,N,3], weight f32 [B,N,3]; ties -> lower centre index. */
+int vpf_three_nn_f32(const float* xyz, int B, int N, int C, const float* centers, int Cc, int S, int* idx, float* weight,
+                     void* stream);
+/* partseg.py:427-435: LayerNorm (one parameter set) of up to four encoder taps f32 [rows,D] into the concatenated feature
+ * xcat f32 [rows, nl*D]; mean / rstd f32 [nl, rows].  Backward: d taps from dxcat, dgamma / dbeta += . */
+int vpf_ln_taps_fwd(const float* x0, const float* x1, const float* x2, const float* x3, int nl, long rows, int D,
+                    const float* gamma, const float* beta, float eps, float* xcat, float* mean, float* rstd, void* stream);
+int vpf_ln_taps_bwd(const float* dxcat, const float* x0, const float* x1, const float* x2, const float* x3, int nl, long rows,
+                    int D, const float* mean, const float* rstd, const float* gamma, float* d0, float* d1, float* d2,
+                    float* d3, float* dgamma, float* dbeta, void* stream);
+/* utils.py:230-236: A bf16 [B*N, Kp] = [ xyz (C) | sum_k weight_k * feat[b, idx_k, :] (F) | 0 ]: the operand of mlp_convs[0] on
+ * cat([points1, interpolated_points]).  Backward: dfeat f32 [B*S, F] += (zeroed by the caller; fp32 atomics). */
+int vpf_interp_rows_fwd(const float* feat, const float* xyz, int B, int N, int C, int S, int F, const int* idx,
+                        const float* weight, int Kp, void* A_bf16, void* stream);
+int vpf_interp_rows_bwd(const void* dA_bf16, int B, int N, int C, int S, int F, const int* idx, const float* weight, int Kp,
+                        float* dfeat, void* stream);
+/* dst bf16 [rows_out, Kp] = src [rows, K] (f32 or bf16, row stride ld) zero-padded: GEMM operands whose contraction or output
+ * dimension is not a multiple of 8 (3 + nl*D input channels of mlp_convs[0]; the 50 part classes of conv3). */
+int vpf_pad_bf16(const void* src, int src_is_bf16, long rows, int K, long ld, long rows_out, int Kp, void* dst_bf16, void* stream);
+/* ft_partseg.py:128,155: CrossEntropyLoss(label_smoothing = eps), mean over rows.  logits f32 [rows, ld] (first C columns),
+ * target int64 [rows]; partial_ws f32 [1024]; loss f32 [1]; dlogits (nullable) f32 [rows, lddz] = d loss / d logits. */
+int vpf_ce_smooth(const float* logits, long ld, const long long* target, long rows, int C, float eps, float* partial_ws,
+                  float* loss, float* dlogits, long lddz, void* stream);
 /* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3), sizeof(VpfPgradJob) (4), sizeof(VpfAdapterKv) (5), sizeof(VpfAdapterKvBwd) (6) */
 /* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1) / sizeof(VpfWgradJob) (2): lets a binding verify its struct layout */
 int vpf_abi_sizeof(int which);

@@ -111,8 +111,10 @@ def grad_summary(model):
     return names, np.array(norms), np.stack(heads)
 
 
-def main():
+def main(only_models=None):
     torch.set_num_threads(8)
+    if only_models:
+        return make_models(only_models)
     # ------------------------------------------------------------ key lists / param counts
     counts = {}
     for name in ("c1", "c3", "c4", "tiny", "tiny2"):
@@ -163,10 +165,18 @@ def main():
              sqdist_bits=(d.numpy().view(np.uint32) if small else d[:, :4, :].contiguous().numpy().view(np.uint32)),
              knn_dist=torch.gather(d, 2, can), meta=np.array([seed, B, N, C, G, K]))
 
+    make_models(("tiny", "tiny2", "c1", "c3", "c4"))
+    print("done")
+
+
+SLICED = ("c1", "c3", "c4")      # full-size architectures: stage outputs / big gradients are stored as slices
+
+
+def make_models(names):
     # ------------------------------------------------------------ stage + model goldens
     RU.knn_point = canonical_knn
     RP.divide_patches.__globals__["knn_point"] = canonical_knn
-    for name in ("tiny", "tiny2", "c1"):
+    for name in names:
         a = Hh.ARCHS[name]
         B = 2
         pc, im = build_ref(a, drops=(0.0, 0.0))
@@ -214,7 +224,7 @@ def main():
         out["sa_out"] = ysa; out["sa_dx"] = x2.grad.clone()
         for k, p in enc.sa_layers[0].named_parameters():
             out["sa_grad." + k] = p.grad.clone()
-        if name == "c1":   # keep the c1 fixture small: stage outputs only as slices
+        if name in SLICED:   # keep the full-size fixtures small: stage outputs only as slices
             for k in list(out):
                 if k.startswith(("ca_grad.", "sa_grad.", "g2e_grad.")) and out[k].numel() > 4096:
                     out[k] = out[k].reshape(-1)[:4096].clone()
@@ -264,7 +274,7 @@ def main():
         json.dump(dict(pc=n, img=n2), open(os.path.join(HERE, f"grad_names_{name}.json"), "w"))
 
         # ---- dropout placement pin (oracle-only test): train mode, real p, torch RNG stream
-        if name != "c1":
+        if name not in SLICED:
             pcd, imd = build_ref(a, drops=(0.1, 0.5))
             pcd.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100))
             imd.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200))
@@ -275,7 +285,6 @@ def main():
             torch.manual_seed(78)
             fid, bid = imd(imgs)
             save(f"dropout_{name}.npz", pc_feats=fd, pc_backbone=bd, img_feats=fid, img_backbone=bid)
-    print("done")
 
 def make_ft(names=("tiny", "c1")):
     """CrossFormer_pc_mp_ft (partseg.py:553-605, the ModelNet fine-tuning classifier: the pre-training backbone + a 3-block
@@ -315,6 +324,8 @@ def make_ft(names=("tiny", "c1")):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ft":
         make_ft()
+    elif len(sys.argv) > 2 and sys.argv[1] == "models":        # python make_golden.py models c3 c4
+        main(only_models=tuple(sys.argv[2:]))
     else:
         main()
         make_ft()

@@ -113,4 +113,4 @@ ARCHS = {
 }
 
 # pairs per batch used by the model_* / dropout-step fixtures and tests
-MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4}
+MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4, "c3": 4, "c4": 4}

@@ -1,0 +1,198 @@
+"""The drop-in boundary as pretrain.py uses it WITHOUT vipformer_amd.train.Pretrainer (VERDICT r01 row b):
+
+  * DistributedDataParallel around the mirrored models (pretrain.py:104-105): weight gradients come back through autograd, so
+    AccumulateGrad runs, ``p.grad`` is populated and the reducer's hooks fire;
+  * a torch optimizer + the loop body of pretrain.py:174-211: parameters move, dropout masks are fresh every forward pass and the
+    backward pass regenerates the masks of ITS forward pass even if other forward passes ran in between;
+  * writes to parameters that bump ``p._version`` (load_state_dict, optimizers) reach the bf16 MFMA operands, also for parameters
+    a Pretrainer owns.
+"""
+import os
+
+import pytest
+import torch
+
+from tests import helpers as Hh
+from tests.test_modules_gpu import build, cosine, forced_start, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(a, B, seed=0):
+    t1 = Hh.synth_points(seed + 1, B, a["N"]).cuda(); t2 = Hh.synth_points(seed + 2, B, a["N"]).cuda()
+    imgs = Hh.synth_images(seed + 3, B, a["img"], a["img"]).cuda()
+    start = Hh.synth_start(seed + 4, 2 * B, a["N"]).cuda()
+    return t1, t2, imgs, start
+
+
+def _loop_body(pc, im, t1, t2, imgs, start):
+    """pretrain.py:183-207 with the models as the caller holds them (possibly DDP-wrapped)."""
+    from vipformer_amd import ops
+    b = t1.shape[0]
+    with forced_start(start):
+        feats = pc(torch.cat([t1, t2]))[0]
+    f1, f2 = feats[:b], feats[b:]
+    loss_imid = ops.ntxent_loss(f1, f2, 0.1)
+    img_feats = im(imgs)[0]
+    loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, 0.1)
+    return loss_imid + 1.0 * loss_cmid
+
+
+def test_ddp_wrapped_models_populate_grads_and_fire_reducer_hooks():
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from vipformer_amd.train import Pretrainer
+    pc, im, a = build("tiny", (0.1, 0.5))
+    pc.train(); im.train()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # "nccl" IS RCCL on ROCm
+    try:
+        pc_ddp = DDP(pc, device_ids=[0], find_unused_parameters=False)        # pretrain.py:104-105
+        im_ddp = DDP(im, device_ids=[0], find_unused_parameters=False)
+        fired = {"pc": 0, "img": 0}
+
+        def hook(tag):
+            def h(state, bucket):
+                fired[tag] += 1
+                fut = torch.futures.Future()
+                fut.set_result(bucket.buffer())
+                return fut
+            return h
+
+        pc_ddp.register_comm_hook(None, hook("pc")); im_ddp.register_comm_hook(None, hook("img"))
+        t1, t2, imgs, start = _batch(a, 8)
+        loss = _loop_body(pc_ddp, im_ddp, t1, t2, imgs, start)
+        loss.backward()                                                        # pretrain.py:209
+        torch.cuda.synchronize()
+        assert fired["pc"] >= 1 and fired["img"] >= 1, fired                   # the reducers ran
+        zero_ok = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias")
+        for tag, m in (("pc", pc), ("img", im)):
+            for k, p in m.named_parameters():
+                assert p.grad is not None, (tag, k)
+                assert torch.isfinite(p.grad).all(), (tag, k)
+                if k not in zero_ok:
+                    assert float(p.grad.abs().max()) > 0.0, (tag, k)
+        # the same step through the Pretrainer (direct accumulation into its flat buffer): same gradients
+        got = {("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters()}
+    finally:
+        if created:
+            dist.destroy_process_group()
+    pc2, im2, _ = build("tiny", (0.1, 0.5))
+    pc2.train(); im2.train()
+    tr = Pretrainer(pc2, im2)
+    tr.overlap = False
+    from vipformer_amd import ops
+    # the DDP run drew its masks from snapshots s, s+1, ... of the process state; gradients of a dropout network are only comparable
+    # mask by mask, so compare the dropout-free sub-network instead: switch the probabilities off on both sides
+    for m in (pc, im, pc2, im2):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    pc.zero_grad(); im.zero_grad()
+    loss = _loop_body(pc, im, t1, t2, imgs, start)
+    loss.backward()
+    with forced_start(start):
+        tr.forward_backward(t1, t2, imgs.permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    for m_a, m_b in ((pc, pc2), (im, im2)):
+        for (k, p), (_, q) in zip(m_a.named_parameters(), m_b.named_parameters()):
+            if k in zero_ok or float(q.grad.norm()) < 1e-6:
+                continue
+            assert cosine(p.grad, q.grad) > 0.9999, k
+            assert rel(p.grad, q.grad) < 1e-2, k
+
+
+def test_torch_optimizer_loop_trains_with_fresh_dropout_masks():
+    """pretrain.py:174-211 with torch.optim.AdamW and no Pretrainer: two consecutive training-mode forward passes draw different
+    masks, the parameters move, and the bf16 operands follow the optimizer's in-place updates."""
+    pc, im, a = build("tiny", (0.1, 0.5))
+    pc.train(); im.train()
+    opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3)
+    t1, t2, imgs, start = _batch(a, 8)
+    with forced_start(start), torch.no_grad():
+        b1 = pc(torch.cat([t1, t2]))[1].clone()
+        b2 = pc(torch.cat([t1, t2]))[1].clone()
+    assert not torch.equal(b1, b2), "two training-mode forward passes drew the same dropout masks"
+    losses = []
+    before = [p.detach().clone() for p in pc.parameters()]
+    for it in range(3):
+        opt.zero_grad(set_to_none=True)                                       # pretrain.py:174
+        loss = _loop_body(pc, im, t1, t2, imgs, start)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(l == l for l in losses)
+    moved = sum(int(not torch.equal(p.detach(), q)) for p, q in zip(pc.parameters(), before))
+    assert moved > 0.9 * len(before)
+    # eval forward with the updated weights == a fresh model loaded with them (the shadow followed the optimizer)
+    pc.eval()
+    sd = {k: v.clone() for k, v in pc.state_dict().items()}
+    pcf, _, _ = build("tiny", (0.1, 0.5))
+    pcf.load_state_dict(sd); pcf.eval()
+    with torch.no_grad(), forced_start(start):
+        x = pc(torch.cat([t1, t2]))[1]
+        y = pcf(torch.cat([t1, t2]))[1]
+    assert torch.equal(x, y)
+
+
+def test_backward_regenerates_the_masks_of_its_own_forward():
+    """Residual dropout: out = dropout(y) + res.  d out / d y is the keep mask / (1 - p): it must be the mask of the forward pass
+    the gradient belongs to, even when another forward pass of the same site ran in between."""
+    from vipformer_amd import ops
+    site = ops.new_site()
+    y = torch.ones(4, 64, 256, device="cuda", requires_grad=True)
+    res = torch.zeros(4, 64, 256, device="cuda")
+    o1 = ops.DropoutAddFn.apply(y, res, 0.5, site)
+    o2 = ops.DropoutAddFn.apply(y, res, 0.5, site)
+    assert not torch.equal(o1, o2)
+    (g1,) = torch.autograd.grad(o1.sum(), y, retain_graph=True)
+    (g2,) = torch.autograd.grad(o2.sum(), y)
+    assert torch.equal(g1 != 0, o1 != 0) and torch.equal(g2 != 0, o2 != 0)
+    with ops.rng.pinned():          # a trainer's regime: the owner advances the state, same state -> same mask
+        o3 = ops.DropoutAddFn.apply(y, res, 0.5, site)
+        o4 = ops.DropoutAddFn.apply(y, res, 0.5, site)
+    assert torch.equal(o3, o4)
+
+
+def test_load_state_dict_after_pretrainer_reaches_the_mfma_operands():
+    """the trainer-owned bf16 shadow must follow load_state_dict (--resume, best checkpoint before eval)."""
+    from vipformer_amd.train import Pretrainer
+    pc, im, a = build("tiny")
+    tr = Pretrainer(pc, im)                                                  # noqa: F841  (owns the parameters from here on)
+    t1, t2, imgs, start = _batch(a, 4)
+    other = Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_tiny.json"), 4242)
+    pc.load_state_dict(other)
+    pc.eval()
+    with torch.no_grad(), forced_start(start):
+        got = pc(torch.cat([t1, t2]))[1]
+    from vipformer_amd.model.pointcloud import CrossFormer_pc_mp, PointCloudInputAdapter
+    ref = CrossFormer_pc_mp(PointCloudInputAdapter((a["N"], 3), a["D"]), a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"],
+                            0.0, 0.0, 0.0, True)
+    ref.load_state_dict(other)
+    ref = ref.cuda().eval()
+    with torch.no_grad(), forced_start(start):
+        want = ref(torch.cat([t1, t2]))[1]
+    assert torch.equal(got, want)
+
+
+def test_two_trainers_in_one_process_do_not_alias():
+    """ownership lives on the parameters (weak references), dropout sites on module names."""
+    from vipformer_amd.train import Pretrainer
+    a = Hh.ARCHS["tiny"]
+    t1, t2, imgs, start = _batch(a, 4)
+    outs = []
+    trainers = []
+    for _ in range(2):
+        pc, im, _ = build("tiny", (0.1, 0.5))
+        pc.train(); im.train()
+        trainers.append(Pretrainer(pc, im))
+    for tr in trainers:                     # interleaved use: each trainer reads ITS OWN shadow and writes ITS OWN gradients
+        with forced_start(start):
+            losses = tr.forward_backward(t1, t2, imgs.permute(0, 3, 1, 2))
+        outs.append((float(losses[0]), tr.flat.g.clone()))
+    assert abs(outs[0][0] - outs[1][0]) < 1e-6 * abs(outs[0][0])            # same weights, same sites, same state -> same loss
+    assert cosine(outs[0][1], outs[1][1]) > 0.999999
+    assert trainers[0].flat.g.data_ptr() != trainers[1].flat.g.data_ptr()

@@ -125,20 +125,81 @@ def test_error_behaviour_matches_reference_and_no_cpu_fallback():
         U.Group2Emb(64)(torch.zeros(1, 2, 4, 3))
 
 
-def test_install_as_vipformer_aliases():
+def _vipformer_modules_saved():
+    import sys
+    return {k: v for k, v in sys.modules.items() if k == "vipformer" or k.startswith("vipformer.")}
+
+
+def _vipformer_modules_restore(saved):
+    import sys
+    for k in [k for k in sys.modules if k == "vipformer" or k.startswith("vipformer.")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+
+
+def test_install_as_vipformer_standalone():
+    """No reference checkout on sys.path (the GPU box): every import root utils.py:12-16 and pretrain.py:27 make must resolve --
+    the implemented names to this package, the names outside the hot path to placeholders that fail loudly when USED."""
     import sys
     import vipformer_amd
-    saved = {k: v for k, v in sys.modules.items() if k == "vipformer" or k.startswith("vipformer.")}
+    from vipformer_amd import _lib
+    saved = _vipformer_modules_saved()
+    path = list(sys.path)
     try:
-        vipformer_amd.install_as_vipformer()
-        from vipformer.model.pointcloud import CrossFormer_img_mp, CrossFormer_pc_mp, PointCloudInputAdapter  # noqa: F401
+        _vipformer_modules_restore({})
+        sys.path[:] = [p for p in sys.path if not os.path.isdir(os.path.join(p, "vipformer"))]
+        assert vipformer_amd.install_as_vipformer() == "standalone"
+        # the import lines of the reference's utils.py:12-16
+        from vipformer.model.core import PerceiverEncoder, PerceiverEncoder_feats_head  # noqa: F401
+        from vipformer.model.core import PerceiverDecoder, PerceiverIO, ClassificationOutputAdapter  # noqa: F401
+        from vipformer.model.image import ImageInputAdapter  # noqa: F401
+        from vipformer.model.pointcloud import PointCloudInputAdapter, CrossFormer_partseg, CrossFormer_semseg  # noqa: F401
+        from vipformer.model.pointcloud import CrossFormer_pc_mp, CrossFormer_img_mp, CrossFormer_pc_mp_ft  # noqa: F401
         from vipformer.model.pointcloud.utils import Group2Emb, divide_patches, farthest_point_sample, knn_point  # noqa: F401
         from vipformer.preproc import fps  # noqa: F401
-        assert CrossFormer_pc_mp.__module__.startswith("vipformer_amd")
+        assert CrossFormer_pc_mp.__module__.startswith("vipformer_amd") and CrossFormer_partseg.__module__.startswith("vipformer_amd")
+        with pytest.raises(_lib.VpfError):
+            PerceiverEncoder()
+        with pytest.raises(_lib.VpfError):
+            CrossFormer_semseg()
     finally:
-        for k in [k for k in sys.modules if k == "vipformer" or k.startswith("vipformer.")]:
-            del sys.modules[k]
-        sys.modules.update(saved)
+        sys.path[:] = path
+        _vipformer_modules_restore(saved)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/vipformer"), reason="needs the reference checkout (build container only)")
+def test_install_as_vipformer_overlays_a_reference_checkout():
+    """With the reference importable, it stays in place: only the implemented names are replaced, everything else
+    (vipformer.model.core, .image, semseg) is the reference's own (the drop-in must not hide those)."""
+    import sys
+    import types
+    import torch.nn as nn
+    import vipformer_amd
+    saved = _vipformer_modules_saved()
+    path = list(sys.path)
+    shims = {}
+    try:
+        _vipformer_modules_restore({})
+        fs = types.ModuleType("fairscale"); fsnn = types.ModuleType("fairscale.nn"); fsnn.checkpoint_wrapper = lambda m, *a, **k: m; fs.nn = fsnn
+        timm = types.ModuleType("timm"); tm = types.ModuleType("timm.models"); tl = types.ModuleType("timm.models.layers")
+        tl.DropPath = type("DropPath", (nn.Identity,), {}); timm.models = tm; tm.layers = tl
+        shims = {"fairscale": fs, "fairscale.nn": fsnn, "timm": timm, "timm.models": tm, "timm.models.layers": tl}
+        shims = {k: v for k, v in shims.items() if k not in sys.modules}
+        sys.modules.update(shims)
+        sys.path.insert(0, "/root/reference")
+        assert vipformer_amd.install_as_vipformer() == "overlay"
+        import vipformer.model.core as core
+        import vipformer.model.pointcloud as pcd
+        from vipformer.model.pointcloud import utils as RU
+        assert core.PerceiverEncoder.__module__ == "vipformer.model.core.modules"          # the reference's own
+        assert pcd.CrossFormer_semseg.__module__ == "vipformer.model.pointcloud.semseg"
+        assert pcd.CrossFormer_pc_mp.__module__.startswith("vipformer_amd")
+        assert RU.divide_patches.__module__.startswith("vipformer_amd") and RU.Group2Emb.__module__.startswith("vipformer_amd")
+    finally:
+        sys.path[:] = path
+        for k in shims:
+            sys.modules.pop(k, None)
+        _vipformer_modules_restore(saved)
 
 
 # ------------------------------------------------------------------------------------------ data parallel over gloo

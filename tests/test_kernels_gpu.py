@@ -124,7 +124,8 @@ def test_dropout_add_and_mask_statistics():
     y, res = bf(rnd(1, n)), rnd(2, n)
     for p in (0.1, 0.5):
         site = ops.new_site()
-        out = ops.DropoutAddFn.apply(y, res, p, site)
+        with ops.rng.pinned():               # draw from the process state itself, so the exported mask is the one used
+            out = ops.DropoutAddFn.apply(y, res, p, site)
         keep = ops.dropout_keep_mask(site, p, (n,), "cuda").float()
         assert abs(keep.mean().item() - (1 - p)) < 3e-3                    # ~3 sigma at n = 1M is 1.5e-3
         assert torch.allclose(out, res + y.float() * keep / (1 - p), rtol=1e-6, atol=1e-6)

@@ -128,6 +128,13 @@ SIGS = {
     "vpf_ln_pgrad_reduce": [VP, I, VP],
     "vpf_adapter_kv_fwd": [VP, VP],
     "vpf_adapter_kv_bwd": [VP, VP],
+    "vpf_three_nn_f32": [VP, I, I, I, VP, I, I, VP, VP, VP],
+    "vpf_ln_taps_fwd": [VP, VP, VP, VP, I, L_, I, VP, VP, F, VP, VP, VP, VP],
+    "vpf_ln_taps_bwd": [VP, VP, VP, VP, VP, I, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP],
+    "vpf_interp_rows_fwd": [VP, VP, I, I, I, I, I, VP, VP, I, VP, VP],
+    "vpf_interp_rows_bwd": [VP, I, I, I, I, I, VP, VP, I, VP, VP],
+    "vpf_pad_bf16": [VP, I, L_, I, L_, L_, I, VP, VP],
+    "vpf_ce_smooth": [VP, L_, VP, L_, I, F, VP, VP, VP, L_, VP],
 }
 
 

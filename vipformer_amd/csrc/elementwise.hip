@@ -521,7 +521,7 @@ __global__ void bn_act_fwd_kernel(const TIN* __restrict__ x, const float* __rest
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         float v = (ld_f<TIN>(x, i) - stat[c]) * stat[C + c] * gamma[c] + beta[c];
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu == 1) v = fmaxf(v, 0.f); else if (relu == 2) v = v > 0.f ? v : 0.2f * v;   // 2: LeakyReLU(0.2), partseg.py:393
         st_f<TOUT>(y, i, v);
     }
 }
@@ -565,14 +565,14 @@ __global__ void bn_bwd_reduce_kernel(const TDY* __restrict__ dy, const TX* __res
         for (int u = 0; u < 4; ++u) {
             const float xh = (xv[u] - mu) * rs;
             float g = gv[u];
-            if (relu && (xh * ga + be) <= 0.f) g = 0.f;
+            if (relu && (xh * ga + be) <= 0.f) g = relu == 2 ? 0.2f * g : 0.f;
             s += g; q += g * xh;
         }
     }
     for (; r < r1; ++r) {
         const float xh = (ld_f<TX>(x, (size_t)r * C + c) - mu) * rs;
         float g = ld_f<TDY>(dy, (size_t)r * C + c);
-        if (relu && (xh * ga + be) <= 0.f) g = 0.f;
+        if (relu && (xh * ga + be) <= 0.f) g = relu == 2 ? 0.2f * g : 0.f;
         s += g; q += g * xh;
     }
     atomicAdd(tmp + c, s); atomicAdd(tmp + C + c, q);
@@ -590,7 +590,7 @@ __global__ void bn_bwd_apply_kernel(const TDY* __restrict__ dy, const TX* __rest
         const float rs = stat[C + c], ga = gamma[c];
         const float xh = (ld_f<TX>(x, i) - stat[c]) * rs;
         float g = ld_f<TDY>(dy, i);
-        if (relu && (xh * ga + beta[c]) <= 0.f) g = 0.f;
+        if (relu && (xh * ga + beta[c]) <= 0.f) g = relu == 2 ? 0.2f * g : 0.f;
         const float v = training ? ga * rs * (g - tmp[c] * invM - xh * tmp[C + c] * invM) : ga * rs * g;
         if (dx) st_f<TDX>(dx, i, v);
     }
@@ -915,7 +915,7 @@ __global__ void __launch_bounds__(512) bn_small_fwd_kernel(const float* __restri
     const float mu = smu[cl], rs = srs[cl], ga = gamma[c], be = beta[c];
     for (r = rl; r < M; r += 8) {
         float v = (x[(size_t)r * C + c] - mu) * rs * ga + be;
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu == 1) v = fmaxf(v, 0.f); else if (relu == 2) v = v > 0.f ? v : 0.2f * v;   // 2: LeakyReLU(0.2), partseg.py:393
         y[(size_t)r * C + c] = f32_to_bf16(v);
     }
 }
@@ -947,14 +947,14 @@ __global__ void __launch_bounds__(512) bn_small_bwd_kernel(const float* __restri
     for (; r + 8 < M; r += 16) {
         const float xa = (x[(size_t)r * C + c] - mu) * rs, xb = (x[(size_t)(r + 8) * C + c] - mu) * rs;
         float ga_ = dy[(size_t)r * C + c], gb_ = dy[(size_t)(r + 8) * C + c];
-        if (relu && (xa * ga + be) <= 0.f) ga_ = 0.f;
-        if (relu && (xb * ga + be) <= 0.f) gb_ = 0.f;
+        if (relu && (xa * ga + be) <= 0.f) ga_ = relu == 2 ? 0.2f * ga_ : 0.f;
+        if (relu && (xb * ga + be) <= 0.f) gb_ = relu == 2 ? 0.2f * gb_ : 0.f;
         s0 += ga_; q0 += ga_ * xa; s1 += gb_; q1 += gb_ * xb;
     }
     for (; r < M; r += 8) {
         const float xa = (x[(size_t)r * C + c] - mu) * rs;
         float ga_ = dy[(size_t)r * C + c];
-        if (relu && (xa * ga + be) <= 0.f) ga_ = 0.f;
+        if (relu && (xa * ga + be) <= 0.f) ga_ = relu == 2 ? 0.2f * ga_ : 0.f;
         s0 += ga_; q0 += ga_ * xa;
     }
     fs[rl][cl] = s0 + s1; fq[rl][cl] = q0 + q1;
@@ -972,7 +972,7 @@ __global__ void __launch_bounds__(512) bn_small_bwd_kernel(const float* __restri
     for (r = rl; r < M; r += 8) {
         const float xh = (x[(size_t)r * C + c] - mu) * rs;
         float g = dy[(size_t)r * C + c];
-        if (relu && (xh * ga + be) <= 0.f) g = 0.f;
+        if (relu && (xh * ga + be) <= 0.f) g = relu == 2 ? 0.2f * g : 0.f;
         st_f<TDX>(dx, (size_t)r * C + c, ga * rs * (g - sm - xh * qm));
     }
 }

@@ -318,6 +318,7 @@ class CrossFormer_pc_mp(nn.Module):
                                 num_self_attention_layers, num_self_attention_heads, mlp_widen_factor, max_dpr, atten_drop,
                                 mlp_drop, modal_prior)
         self.latent_head = _latent_head(num_latent_channels)
+        ops.assign_sites(self, "pc")          # dropout sites by module name: independent of what else the process built
 
     def backbone(self, pts, _groups=None):
         """_groups (an extension the trainer uses, not part of the reference signature): (neighborhood, center, event) computed by
@@ -405,6 +406,7 @@ class CrossFormer_img_mp(nn.Module):
                                 num_self_attention_layers, num_self_attention_heads, mlp_widen_factor, max_dpr, atten_drop,
                                 mlp_drop, modal_prior)
         self.latent_head = _latent_head(num_latent_channels)
+        ops.assign_sites(self, "img")
 
     def forward(self, imgs):
         lin = self.patch2emb[1]

@@ -7,9 +7,12 @@ parameter bookkeeping the fused kernels need:
   * bf16 "shadow" copies of fp32 master weights (MFMA operands), refreshed when the
     parameter changes, or owned by the trainer's fused AdamW (which writes them directly);
   * packed q/k/v weights and gradients (one [3D,D] GEMM instead of three);
-  * weight gradients are accumulated by the wgrad kernels straight into ``param.grad``
-    (fp32 atomics, split over the token dimension), so the Functions return ``None`` for
-    parameters and nothing is re-added by autograd.
+  * weight gradients: the wgrad kernels accumulate with fp32 atomics (split over the token
+    dimension) into a buffer chosen per parameter by ``_GradSink`` -- the trainer's flat
+    gradient buffer for parameters a ``Pretrainer`` owns (the Function then returns None:
+    nothing is re-added by autograd), a zeroed temporary RETURNED through autograd for every
+    other parameter, so ``p.grad`` is populated the standard way and DistributedDataParallel's
+    reducer hooks fire (pretrain.py:104-105,209).
 
 Precision contract: fp32 master weights, fp32 residual stream, bf16 MFMA operands with fp32
 accumulation, bf16 activations between fused ops, fp32 statistics (LayerNorm/BatchNorm/softmax).
@@ -17,7 +20,11 @@ accumulation, bf16 activations between fused ops, fp32 statistics (LayerNorm/Bat
 from __future__ import annotations
 
 import ctypes
+import functools
 import os
+import threading
+import weakref
+import zlib
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -32,15 +39,32 @@ EPI_STORE, EPI_GELU, EPI_DROP_RES, EPI_GELU_BWD, EPI_ATOMIC, EPI_RELU, EPI_GROUP
 
 # --------------------------------------------------------------------------- RNG state
 class _Rng:
-    """Device-resident dropout state {seed_lo, seed_hi, step, 0}; ``step`` is bumped on the
-    device (vpf_rng_advance) so a captured hipGraph draws fresh masks on every replay."""
+    """Device-resident dropout state {seed_lo, seed_hi, step, 0}.  A keep decision is a pure function of (state, site,
+    element index), so backward regenerates forward's mask from the state the forward pass used.
+
+    Two regimes:
+      * default: every training-mode autograd Function that draws masks takes a SNAPSHOT of the state (``acquire``) and bumps the
+        process state behind it, keeps the snapshot for its backward pass -- consecutive forward passes (and two calls of the same
+        module inside one forward pass) therefore never share masks, whoever drives the loop (pretrain.py's own loop body, a
+        torch optimizer, DistributedDataParallel ...);
+      * ``with rng.pinned():`` (the Pretrainer, and tests that export the kernels' masks): every Function draws from the process
+        state itself and nobody bumps it implicitly -- the owner calls ``advance`` once per step, on the device, so a captured
+        hipGraph replays with fresh masks and costs no extra launches."""
 
     def __init__(self):
         self.states = {}
         self.seed_value = 0x1234ABCD5678EF01
+        self._pin = 0
+
+    @staticmethod
+    def _index(device) -> int:
+        if torch.device(device).type != "cuda":
+            raise L.VpfError("vipformer_amd ops run on an MI355X only (got a CPU tensor); there is no CPU fallback")
+        idx = torch.device(device).index
+        return torch.cuda.current_device() if idx is None else idx
 
     def state(self, device) -> torch.Tensor:
-        key = torch.device(device).index or 0
+        key = self._index(device)
         st = self.states.get(key)
         if st is None:
             lo, hi = self.seed_value & 0xFFFFFFFF, (self.seed_value >> 32) & 0xFFFFFFFF
@@ -56,37 +80,93 @@ class _Rng:
     def advance(self, device) -> None:
         L.call("vpf_rng_advance", self.state(device))
 
+    def acquire(self, device, training: bool = True) -> torch.Tensor:
+        """The state a Function draws its masks from (and keeps for its backward pass)."""
+        st = self.state(device)
+        if self._pin or not training:
+            return st
+        snap = st.clone()
+        L.call("vpf_rng_advance", st)
+        return snap
+
+    def pinned(self):
+        return _Pinned(self)
+
+
+class _Pinned:
+    def __init__(self, r):
+        self.r = r
+
+    def __enter__(self):
+        self.r._pin += 1
+        return self.r
+
+    def __exit__(self, *exc):
+        self.r._pin -= 1
+
 
 rng = _Rng()
 _site_counter = [0]
 
 
 def new_site() -> int:
+    """A dropout site id that is unique in the process (modules built on their own).  Top-level models overwrite the sites of
+    their sub-modules with ``assign_sites`` so that masks do not depend on how many modules were built before."""
     _site_counter[0] += 1
     return _site_counter[0]
 
 
-def dropout_keep_mask(site: int, p: float, shape, device) -> torch.Tensor:
-    """The keep mask (uint8) the kernels use for ``site`` at the current rng state (tests)."""
+def assign_sites(model: torch.nn.Module, salt: str) -> None:
+    """Deterministic dropout sites: crc32 of (salt, qualified module name).  Independent of construction order and of every
+    other model in the process; ``salt`` keeps the point-cloud and the image branch (same module names) on different masks."""
+    for name, m in model.named_modules():
+        for attr in ("site", "site_attn"):
+            if hasattr(m, attr):
+                setattr(m, attr, zlib.crc32(f"{salt}:{name}:{attr}".encode()) & 0xFFFFFFFF)
+
+
+def dropout_keep_mask(site: int, p: float, shape, device, state: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The keep mask (uint8) the kernels use for ``site`` at ``state`` (default: the process state -- what the Functions draw
+    from inside ``rng.pinned()``).  Tests."""
     n = 1
     for s in shape:
         n *= int(s)
     out = torch.empty(n, dtype=torch.uint8, device=device)
-    L.call("vpf_dropout_mask", out, n, rng.state(device), site, float(p))
+    L.call("vpf_dropout_mask", out, n, state if state is not None else rng.state(device), site, float(p))
     return out.view(*shape)
 
 
-# --------------------------------------------------------------------------- parameter packing / shadows
-_managed_shadow: List[Tuple[int, int, torch.Tensor, torch.Tensor]] = []   # (ptr_begin, ptr_end, flat_f32, flat_bf16)
+# --------------------------------------------------------------------------- parameter packing / shadows / gradient sinks
+class ManagedFlat:
+    """What a trainer registers for parameters it owns (train.FlatParams): flat fp32 values, flat fp32 gradients the weight-
+    gradient kernels accumulate into DIRECTLY, and the bf16 shadow its fused AdamW rewrites.  Parameters carry a weak reference
+    (``p._vpf_managed``) -- no process-wide registry, two trainers in one process never alias, a dead trainer costs nothing."""
+
+    def __init__(self, flat_f32: torch.Tensor, flat_bf16: torch.Tensor):
+        self.p, self.s = flat_f32, flat_bf16
+
+    def adopt(self, param: torch.nn.Parameter, offset: int) -> None:
+        param._vpf_managed = (weakref.ref(self), offset)
+        param._vpf_ver = param._version
+
+    def recast(self, param: torch.nn.Parameter, offset: int) -> None:
+        n = param.numel()
+        L.call("vpf_cast_f32_bf16", self.p[offset:offset + n], self.s[offset:offset + n], n)
+        param._vpf_ver = param._version
 
 
-def register_managed_shadow(flat_f32: torch.Tensor, flat_bf16: torch.Tensor) -> None:
-    """The trainer's flat fp32 parameter buffer and its bf16 shadow (kept fresh by vpf_adamw_step)."""
-    _managed_shadow.append((flat_f32.data_ptr(), flat_f32.data_ptr() + flat_f32.numel() * 4, flat_f32, flat_bf16))
+def _managed(p):
+    m = getattr(p, "_vpf_managed", None)
+    if m is None:
+        return None, 0
+    owner = m[0]()
+    if owner is None or p.data_ptr() != owner.p.data_ptr() + 4 * m[1]:       # trainer gone, or the parameter was re-pointed (.to())
+        return None, 0
+    return owner, m[1]
 
 
 def clear_managed_shadows() -> None:
-    _managed_shadow.clear()
+    """Kept for callers of the round-1 API: ownership now lives on the parameters (weak references), nothing to clear."""
 
 
 def _adjacent(ts: Sequence[torch.Tensor]) -> bool:
@@ -109,8 +189,87 @@ def pack_params(params: Sequence[torch.nn.Parameter]) -> None:
         off += p.numel()
 
 
+class _GradSink:
+    """Where the weight-gradient kernels of ONE Function.backward write.
+
+    * parameters owned by a trainer (``ManagedFlat``): straight into the trainer's flat gradient buffer (``p.grad`` is a view of
+      it); the Function returns None for them -- nothing is re-added by autograd;
+    * every other parameter: into a zeroed temporary that the Function RETURNS as that input's gradient, so autograd's
+      AccumulateGrad runs -- ``p.grad`` is populated the standard way and DistributedDataParallel's reducer hooks fire
+      (pretrain.py:104-105,209)."""
+
+    def __init__(self, params):
+        self.params = params
+        self.tmp = {}
+
+    def buf(self, p):
+        owner, _ = _managed(p)
+        if owner is not None and p.grad is not None:
+            return p.grad
+        t = self.tmp.get(id(p))
+        if t is None:
+            t = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
+            self.tmp[id(p)] = t
+        return t
+
+    def packed(self, params):
+        if all(_managed(p)[0] is not None and p.grad is not None for p in params):
+            grads = [p.grad for p in params]
+            if _adjacent(grads):
+                n = sum(p.numel() for p in params)
+                g0 = grads[0]
+                return torch.as_strided(g0, (n,), (1,), g0.storage_offset()) if len(params) > 1 else g0.view(-1)
+        hit = [self.tmp.get(id(p)) for p in params]
+        if all(h is not None for h in hit) and _adjacent(hit):
+            n = sum(p.numel() for p in params)
+            return torch.as_strided(hit[0], (n,), (1,), hit[0].storage_offset()) if len(params) > 1 else hit[0].view(-1)
+        if any(h is not None for h in hit):
+            raise L.VpfError("packed gradient requested after a separate gradient buffer of the same parameters")
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=F32, device=params[0].device)
+        off = 0
+        for p in params:
+            self.tmp[id(p)] = flat[off:off + p.numel()].view_as(p.data)
+            off += p.numel()
+        return flat
+
+    def collect(self):
+        return tuple(self.tmp.get(id(p)) for p in self.params)
+
+
+_tls = threading.local()
+
+
+def _sink_stack():
+    st = getattr(_tls, "stack", None)
+    if st is None:
+        st = _tls.stack = []
+    return st
+
+
+def _sinked(backward):
+    """Decorator of Function.backward: the trailing ``len(ctx.params)`` entries of the returned tuple (the parameters' slots)
+    are replaced by what the weight-gradient kernels wrote for unmanaged parameters (see _GradSink)."""
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        sk = _GradSink(ctx.params)
+        stack = _sink_stack()
+        stack.append(sk)
+        try:
+            out = backward(ctx, *grads)
+        finally:
+            stack.pop()
+        n = len(ctx.params)
+        return out if n == 0 else tuple(out[:len(out) - n]) + sk.collect()
+
+    return wrapped
+
+
 def packed_grad(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
-    """fp32 gradient buffer covering ``params`` contiguously (views installed as p.grad)."""
+    """fp32 gradient buffer covering ``params`` contiguously (inside a Function.backward: see _GradSink)."""
+    stack = _sink_stack()
+    if stack:
+        return stack[-1].packed(list(params))
     grads = [p.grad for p in params]
     if all(g is not None for g in grads) and _adjacent(grads):
         n = sum(p.numel() for p in params)
@@ -128,20 +287,37 @@ def packed_grad(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
 
 
 def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:
+    """The fp32 buffer the weight-gradient kernels accumulate into for ``p`` (inside a Function.backward: see _GradSink;
+    outside -- direct kernel tests -- ``p.grad``)."""
+    stack = _sink_stack()
+    if stack:
+        return stack[-1].buf(p)
     if p.grad is None:
         p.grad = torch.zeros_like(p.data)
     return p.grad
 
 
 def shadow(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
-    """bf16 copy of the (adjacent) parameters as one flat tensor."""
+    """bf16 copy of the (adjacent) parameters as one flat tensor.  Trainer-owned parameters: a slice of the trainer's shadow
+    (rewritten by its fused AdamW), re-cast here if somebody else wrote the parameter since (load_state_dict, an external
+    optimizer: anything that bumps ``p._version``; raw ``p.data`` writes do not -- call FlatParams.refresh_shadow() then).
+    Other parameters: a cached cast keyed on (version, pointer)."""
     p0 = params[0]
     n = sum(p.numel() for p in params)
-    ptr = p0.data_ptr()
-    for (b, e, f32, b16) in _managed_shadow:
-        if b <= ptr and ptr + n * 4 <= e:
-            off = (ptr - b) // 4
-            return b16[off:off + n]
+    owner, off = _managed(p0)
+    if owner is not None:
+        end = off
+        ok = True
+        for p in params:
+            o2, f2 = _managed(p)
+            if o2 is not owner or f2 != end:
+                ok = False
+                break
+            if p._version != p._vpf_ver:
+                owner.recast(p, f2)
+            end = f2 + p.numel()
+        if ok:
+            return owner.s[off:off + n]
     # cached on the first parameter OBJECT (dies with it; a (pointer, size) key could alias a freed model)
     ver = tuple((p._version, p.data_ptr()) for p in params)
     hit = getattr(p0, "_vpf_shadow", None)
@@ -179,8 +355,9 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
 
 
 def gemm(A, a_tr, lda, Bm, b_tr, ldb, M, N, K, C, ldc, *, c_f32, mode=EPI_STORE, bias=None, C2=None, ldc2=0, res=None,
-         ldres=0, aux=None, ldaux=0, gbias=None, group=1, site=0, p=0.0, splitk=0, batch=1, sAb=0, sBb=0, sCb=0, dbias=None):
-    st = rng.state(C.device) if mode == EPI_DROP_RES else None
+         ldres=0, aux=None, ldaux=0, gbias=None, group=1, site=0, p=0.0, splitk=0, batch=1, sAb=0, sBb=0, sCb=0, dbias=None,
+         rng_state=None):
+    st = (rng_state if rng_state is not None else rng.state(C.device)) if mode == EPI_DROP_RES else None
     L.call("vpf_gemm_bf16", A, int(a_tr), lda, Bm, int(b_tr), ldb, M, N, K, batch, sAb, sBb, sCb, C, ldc, int(c_f32), mode,
            bias, C2, ldc2, res, ldres, aux, ldaux, gbias, group, st, site, float(p), splitk, dbias)
 
@@ -326,12 +503,13 @@ class AttnBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, pos, xkv, mod, cfg, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         # mod: the MultiHeadAttention module (weights); cfg: dict(ln_q, ln_kv (modules or None), residual, p_res, site_res, training)
         B, Lq, D = xq.shape
         H = mod.num_heads
         dev = xq.device
         training = cfg["training"]
+        st = ctx.rng_st = rng.acquire(dev, training)
         is_self = xkv is None
         lnq, lnkv = cfg["ln_q"], cfg["ln_kv"]
         xq = xq.contiguous()
@@ -371,13 +549,13 @@ class AttnBlockFn(torch.autograd.Function):
         lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
         p_att = mod.dropout.p if training else 0.0
         L.call("vpf_attention_fwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lkv, D // H, float(mod.dp_scale), float(p_att),
-               rng.state(dev), mod.site_attn, o, D, lse)
+               st, mod.site_attn, o, D, lse)
         wo16 = shadow([mod.o_proj.weight])
         residual = cfg["residual"]
         p_res = cfg["p_res"] if training else 0.0
         if residual:
             out = linear_fwd(o, wo16, D, D, mod.o_proj.bias.data, out_f32=True, mode=EPI_DROP_RES, res=base, ldres=D,
-                             site=cfg["site_res"], p=p_res)
+                             site=cfg["site_res"], p=p_res, rng_state=st)
         else:
             out = linear_fwd(o, wo16, D, D, mod.o_proj.bias.data, out_f32=True)
         ctx.mod, ctx.cfg = mod, cfg
@@ -389,6 +567,7 @@ class AttnBlockFn(torch.autograd.Function):
         return out.view(B, Lq, D)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dout):
         base, mq, rq, nq, xkv, mk, rk, nk, qkv, kv, o, lse = ctx.saved_tensors
         mod, cfg = ctx.mod, ctx.cfg
@@ -399,7 +578,7 @@ class AttnBlockFn(torch.autograd.Function):
         residual = cfg["residual"]
         if residual and p_res > 0.0:
             dz = torch.empty(Mq, D, dtype=BF16, device=dev)
-            L.call("vpf_dropout_bwd", dout, dz, dout.numel(), rng.state(dev), cfg["site_res"], float(p_res))
+            L.call("vpf_dropout_bwd", dout, dz, dout.numel(), ctx.rng_st, cfg["site_res"], float(p_res))
         else:
             dz = to_bf16(dout).view(Mq, D)
         linear_wgrad(dz, o, D, D, grad_buf(mod.o_proj.weight), grad_buf(mod.o_proj.bias))
@@ -417,7 +596,7 @@ class AttnBlockFn(torch.autograd.Function):
             q, k, v, ldq, ldk, ldv = qkv, kv, kv[:, D:], D, 2 * D, 2 * D
             dk, dv, lddq, lddk, lddv = dkv, dkv[:, D:], D, 2 * D, 2 * D
         L.call("vpf_attention_bwd", q, ldq, k, ldk, v, ldv, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(mod.dp_scale),
-               float(p_att), rng.state(dev), mod.site_attn, dq, lddq, dk, lddk, dv, lddv,
+               float(p_att), ctx.rng_st, mod.site_attn, dq, lddq, dk, lddk, dv, lddv,
                torch.empty(B * H * Lq, dtype=F32, device=dev))
         dxkv = None
         if is_self:
@@ -464,7 +643,7 @@ class MLPBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, mod, cfg, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         shp = x.shape
         D = shp[-1]
         x = x.contiguous().float()
@@ -476,9 +655,10 @@ class MLPBlockFn(torch.autograd.Function):
         h = linear_fwd(n, shadow([fc1.weight]), Hd, D, fc1.bias.data, mode=EPI_GELU, C2=u, ldc2=Hd)
         training, residual = cfg["training"], cfg["residual"]
         p_res = cfg["p_res"] if training else 0.0
+        ctx.rng_st = rng.acquire(x.device, training and residual and p_res > 0.0)
         if residual:
             out = linear_fwd(h, shadow([fc2.weight]), D, Hd, fc2.bias.data, out_f32=True, mode=EPI_DROP_RES, res=x, ldres=D,
-                             site=cfg["site_res"], p=p_res)
+                             site=cfg["site_res"], p=p_res, rng_state=ctx.rng_st)
         else:
             out = linear_fwd(h, shadow([fc2.weight]), D, Hd, fc2.bias.data, out_f32=True)
         ctx.mod, ctx.cfg, ctx.p_res = mod, cfg, p_res
@@ -486,6 +666,7 @@ class MLPBlockFn(torch.autograd.Function):
         return out.view(shp)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dout):
         x, mean, rstd, n, u, h = ctx.saved_tensors
         mod, cfg, p_res = ctx.mod, ctx.cfg, ctx.p_res
@@ -497,7 +678,7 @@ class MLPBlockFn(torch.autograd.Function):
         residual = cfg["residual"]
         if residual and p_res > 0.0:
             dz = torch.empty(M, D, dtype=BF16, device=x.device)
-            L.call("vpf_dropout_bwd", dout, dz, dout.numel(), rng.state(x.device), cfg["site_res"], float(p_res))
+            L.call("vpf_dropout_bwd", dout, dz, dout.numel(), ctx.rng_st, cfg["site_res"], float(p_res))
         else:
             dz = to_bf16(dout).view(M, D)
         linear_wgrad(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
@@ -582,7 +763,7 @@ class SAStackFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, layers, training, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         B, Lq, D = x.shape
         M, Hd, H = B * Lq, 512, 4
         dev = x.device
@@ -590,7 +771,7 @@ class SAStackFn(torch.autograd.Function):
         nl = len(layers)
         chunk_rows = Lq if Lq <= 96 else (Lq + 1) // 2
         packed = _sa_packed(layers, dev)
-        st = rng.state(dev)
+        st = ctx.rng_st = rng.acquire(dev, training)
         l0 = layers[0]
         ln1 = l0[0].module.norm
         att0 = l0[0].module.attention
@@ -653,6 +834,7 @@ class SAStackFn(torch.autograd.Function):
         return out.view(B, Lq, D)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dout):
         flat = ctx.saved_tensors
         layers, training = ctx.layers, ctx.training
@@ -660,7 +842,7 @@ class SAStackFn(torch.autograd.Function):
         M = B * Lq
         dev = dout.device
         d = dout.contiguous().float().view(M, D)
-        st = rng.state(dev)
+        st = ctx.rng_st
         want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
         if SA_FUSED_BWD[0]:
             return SAStackFn._backward_fused(ctx, d, st, want_pos)
@@ -872,13 +1054,13 @@ class EncoderFusedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pos, xkv, ca, layers, training, kv_ready, *params):
         """kv_ready: ``xkv`` already holds the cross-attention K | V projections (bf16 [B, Lkv, 2D], AdapterKVFn)."""
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         ctx.kv_ready = kv_ready
         B, Lq, D = x.shape
         M, Hd, H = B * Lq, 512, 4
         dev = x.device
         x = x.contiguous().float()
-        st = rng.state(dev)
+        st = ctx.rng_st = rng.acquire(dev, training)
         nl = len(layers)
         cross, cmlp = ca[0].module, ca[1].module
         catt = cross.attention
@@ -929,13 +1111,14 @@ class EncoderFusedFn(torch.autograd.Function):
         return out.view(B, Lq, D)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dout):
         flat = ctx.saved_tensors
         ca, layers, training, packed = ctx.ca, ctx.layers, ctx.training, ctx.packed
         B, Lq, Lkv, D, Hd, H = ctx.dims
         M, Mk = B * Lq, B * Lkv
         dev = dout.device
-        st = rng.state(dev)
+        st = ctx.rng_st
         d = dout.contiguous().float().view(M, D)
         want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
         nl = len(layers)
@@ -1010,7 +1193,7 @@ class EncoderFusedFn(torch.autograd.Function):
                float(catt.dropout.p if training else 0.0), st, catt.site_attn, dq, D, dkv, 2 * D, dkv[:, D:], 2 * D,
                torch.empty(B * H * Lq, dtype=F32, device=dev))
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
-        w16, gW = shadow(qkvw), packed_grad(qkvw)
+        w16, gW = shadow(qkvw), packed_grad(qkvw[:1] if ctx.kv_ready else qkvw)      # (K / V weights: AdapterKVFn's business then)
         wg = WgradBatch()
         wg.add(dz2, h, D, Hd, grad_buf(cmlp[3].weight), grad_buf(cmlp[3].bias))
         wg.add(du, n2, Hd, D, grad_buf(cmlp[1].weight), grad_buf(cmlp[1].bias))
@@ -1048,7 +1231,7 @@ class AdapterKVFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, adapter, cross, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         B, N, C = pts.shape
         D = 256
         dev = pts.device
@@ -1088,6 +1271,7 @@ class AdapterKVFn(torch.autograd.Function):
         return kv.view(B, N, 2 * D)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dkv):
         x, a1, xkv, mk, rk, nk = ctx.saved_tensors
         adapter, cross = ctx.mods
@@ -1096,7 +1280,7 @@ class AdapterKVFn(torch.autograd.Function):
         D = 256
         M, C = x.shape
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
-        w16, gW = shadow(qkvw), packed_grad(qkvw)
+        w16, gKV = shadow(qkvw), packed_grad(qkvw[1:])
         dkv = to_bf16(dkv).view(M, 2 * D)
         if ADAPTER_KV_BWD_FUSED[0]:
             pk = ctx.packed
@@ -1118,11 +1302,11 @@ class AdapterKVFn(torch.autograd.Function):
             pj[0].partials, pj[0].rows, pj[0].dgamma, pj[0].dbeta = pg.data_ptr(), nwg, grad_buf(lnkv.weight).data_ptr(), grad_buf(lnkv.bias).data_ptr()
             L.call_struct("vpf_ln_pgrad_reduce", pj, 1)
             wg = WgradBatch()
-            wg.add(dkv, nk, 2 * D, D, gW[D * D:])
+            wg.add(dkv, nk, 2 * D, D, gKV)
             wg.add(dy16, a1, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
             wg.flush()
             return (None, None, None) + (None,) * ctx.nparams
-        linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
+        linear_wgrad(dkv, nk, 2 * D, D, gKV)
         dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
         dy16 = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True).view(M, D)
         linear_wgrad(dy16, a1, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
@@ -1165,7 +1349,8 @@ class DropoutAddFn(torch.autograd.Function):
         y16 = to_bf16(y)
         res = res.contiguous().float()
         out = torch.empty(res.shape, dtype=F32, device=res.device)
-        L.call("vpf_dropout_add_fwd", y16, res, out, out.numel(), rng.state(res.device), site, float(p))
+        ctx.rng_st = rng.acquire(res.device, p > 0.0)
+        L.call("vpf_dropout_add_fwd", y16, res, out, out.numel(), ctx.rng_st, site, float(p))
         ctx.p, ctx.site, ctx.ydt = p, site, y.dtype
         return out
 
@@ -1173,7 +1358,7 @@ class DropoutAddFn(torch.autograd.Function):
     def backward(ctx, dout):
         dout = dout.contiguous().float()
         dy = torch.empty(dout.shape, dtype=BF16, device=dout.device)
-        L.call("vpf_dropout_bwd", dout, dy, dout.numel(), rng.state(dout.device), ctx.site, float(ctx.p))
+        L.call("vpf_dropout_bwd", dout, dy, dout.numel(), ctx.rng_st, ctx.site, float(ctx.p))
         return (dy if ctx.ydt == BF16 else to_f32(dy)), dout, None, None
 
 
@@ -1224,7 +1409,7 @@ class Group2EmbFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, groups, mod, training, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         Bq, G, K, C = groups.shape
         dev = groups.device
         x = groups.contiguous().float().view(-1, C)
@@ -1318,6 +1503,7 @@ class Group2EmbFn(torch.autograd.Function):
         return out.view(Bq, G, Dm)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dout):
         x, stat1, a1, arg2, h2, gmax, h3, stat2, ab2, arg4 = ctx.saved_tensors
         mod, training = ctx.mod, ctx.training
@@ -1386,7 +1572,7 @@ class AdapterFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, pts, mod, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         B, N, C = pts.shape
         x = pts.contiguous().float().view(-1, C)
         M = x.shape[0]
@@ -1400,6 +1586,7 @@ class AdapterFn(torch.autograd.Function):
         return y.view(B, N, D)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dy):
         x, a = ctx.saved_tensors
         mod = ctx.mod
@@ -1420,7 +1607,7 @@ class PosMLPFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, centers, seq, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         B, G, C = centers.shape
         x = centers.contiguous().float().view(-1, C)
         M = x.shape[0]
@@ -1434,6 +1621,7 @@ class PosMLPFn(torch.autograd.Function):
         return y.view(B, G, D)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
         l0, l2 = ctx.seq[0], ctx.seq[2]
@@ -1451,7 +1639,7 @@ class PatchEmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, imgs, lin, p, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         B, Hh, Ww, C = imgs.shape
         if imgs.dtype != F32:
             imgs = imgs.float()
@@ -1468,6 +1656,7 @@ class PatchEmbedFn(torch.autograd.Function):
         return y.view(B, T, D)
 
     @staticmethod
+    @_sinked
     def backward(ctx, dy):
         (patches,) = ctx.saved_tensors
         lin = ctx.lin
@@ -1506,7 +1695,7 @@ class HeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, seq, training, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         bn1, l1, bn2, l2 = seq[0], seq[2], seq[3], seq[5]
         Bn, C1 = x.shape
         C2, C3 = l1.weight.shape[0], l2.weight.shape[0]
@@ -1533,6 +1722,7 @@ class HeadFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_sinked
     def backward(ctx, dy):
         x, s1, a1, h, s2, a2 = ctx.saved_tensors
         seq, training = ctx.seq, ctx.training
@@ -1568,7 +1758,7 @@ class BnReluLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bn, lin, training, *params):
-        ctx.nparams = len(params)
+        ctx.nparams, ctx.params = len(params), params
         Bn, C1 = x.shape
         C2 = lin.weight.shape[0]
         x = x.contiguous().float()
@@ -1587,6 +1777,7 @@ class BnReluLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_sinked
     def backward(ctx, dy):
         x, st, a = ctx.saved_tensors
         bn, lin = ctx.mods

@@ -7,3 +7,5 @@ HIP-backed functions here.
 """
 from ..model.pointcloud.utils import (divide_patches, farthest_point_sample, fps, index_points,  # noqa: F401
                                       knn_point, square_distance)
+
+__all__ = ["divide_patches", "farthest_point_sample", "fps", "index_points", "knn_point", "square_distance"]

@@ -57,16 +57,21 @@ class FlatParams:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.s = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        self.managed = ops.ManagedFlat(self.p, self.s)      # parameters point at it weakly: no process-wide registry
         for p, o in zip(params, offs):
             self.p[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.p[o:o + p.numel()].view_as(p.data)
             p.grad = self.g[o:o + p.numel()].view_as(p.data)
+            self.managed.adopt(p, o)
         self.offsets = offs
         self.refresh_shadow()
-        ops.register_managed_shadow(self.p, self.s)
 
     def refresh_shadow(self) -> None:
+        """Re-cast the whole bf16 shadow from the fp32 values.  ops.shadow() does this per parameter when ``p._version`` moved
+        (load_state_dict, an external optimizer); raw writes through ``p.data`` / ``flat.p`` do not bump it: call this then."""
         L.call("vpf_cast_f32_bf16", self.p, self.s, self.numel)
+        for p in self.params:
+            p._vpf_ver = p._version
 
     def attach_grads(self) -> None:
         """Re-install the flat views (after an optimizer.zero_grad(set_to_none=True))."""
@@ -113,6 +118,10 @@ class Pretrainer:
 
     def forward_backward(self, pc_t1, pc_t2, imgs):
         """pretrain.py:174-209 (modality 'both').  imgs: [b,3,H,W] as the loader yields it."""
+        with ops.rng.pinned():       # one dropout state per step, advanced on the device by optimizer_step (graph-replayable)
+            return self._forward_backward(pc_t1, pc_t2, imgs)
+
+    def _forward_backward(self, pc_t1, pc_t2, imgs):
         self.flat.g.zero_()
         imgs = imgs.permute(0, 2, 3, 1)                     # pretrain.py:179 (a view; strides go to the kernel)
         b = pc_t1.shape[0]
@@ -160,6 +169,11 @@ class Pretrainer:
         if self.world > 1:
             dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM, group=self.group)
 
+    def set_lr(self, lr: float) -> None:
+        """The learning-rate schedule's hook (the reference steps a cosine / warm-restart schedule per epoch, pretrain.py:136-142,
+        311): writes the device-resident hyper-parameter the AdamW kernel reads, so it also takes effect in a captured graph."""
+        self.hyper[0] = float(lr)
+
     def optimizer_step(self) -> None:
         f = self.flat
         L.call("vpf_adamw_step", f.p, f.g, f.m, f.v, f.s, f.numel, self.hyper, 1)
@@ -177,12 +191,25 @@ class Pretrainer:
         """Capture forward+backward (+AdamW when single-rank) into a hipGraph on static input buffers.
         Returns the static (pc_t1, pc_t2, imgs) tensors to copy new batches into."""
         self._static = (pc_t1.clone(), pc_t2.clone(), imgs.clone())
+        # warm-up (lazy allocations, packed-weight buffers, func attributes) must not train: AdamW runs with its skip flag
+        # (parameters, moments and the bias-correction step stay put), BatchNorm buffers and the dropout step are restored
+        bufs = [b for m in (self.pc_model, self.img_model) for b in m.buffers()]
+        keep = [b.clone() for b in bufs]
+        rng_keep = ops.rng.state(self.device).clone()
+        skip_keep = self.hyper[7].clone()
+        self.hyper[7] = 1.0
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self.step(*self._static)
         torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.hyper[7] = skip_keep
+        ops.rng.state(self.device).copy_(rng_keep)
+        with torch.no_grad():
+            for b, k in zip(bufs, keep):
+                b.copy_(k)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
