@@ -10,13 +10,20 @@ resident in HBM: zero_grad, point-cloud forward on cat(view1, view2) (FPS + kNN 
 CA/SA encoder + head), image forward, two NT-Xent losses, backward, gradient all-reduce (RCCL) when
 N > 1, fused AdamW.  Workload at every N: BASELINE.json configs[1] per GPU (E1CL6SL-H4D256-L96-MR2,
 64 pairs of 2 x 1024-point clouds + one 224x224 image, patch 16) -> weak scaling, global batch 64 N.
+(--arch c3 / c4 runs configs[2] / configs[3] per GPU instead: side lines, never the default.)
 
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline     : the dominant kernel (fused encoder-layer tail, HBM-bound) timed live with HIP events on the launch stream
-  cpu_baseline : the oracle (CPU restatement of the reference path, kind "port") timed on this box's
-                 host cores on a bounded sample (rank 0, N == 1 only)
+  roofline     : the kernel that is FIRST in the rocprofv3 kernel statistics of this very command
+                 (profiles/r02_bench_c2_kernel_stats.csv), timed live with HIP events on the launch stream; fractions of both
+                 rooflines; the in-step average of the committed whole-step trace beside the stand-alone time
+  kernels      : the same for the other named kernels -- FPS and kNN grouping (HBM GB/s, ns per FPS iteration), the attention
+                 kernels (MFMA TFLOP/s; MFMA-busy from the PMC pass under profiles/), the fused encoder-layer tail
+  variants     : host-fed (adds the reference's H2D copy, pretrain.py:177) and duplicate-heavy inputs (RandomInputDropout)
+  cpu_baseline : the oracle (CPU restatement of the reference path, kind "port") on this box's host cores on a bounded
+                 sample (rank 0, N == 1 only): config 1 (8 pairs), physical cores and 8 threads, + the augmentation leg
 """
 import argparse
+import csv
 import json
 import os
 import sys
@@ -28,136 +35,276 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ARCH = dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=1024, img=224, patch=16)     # configs[1] / c2
-PER_GPU_PAIRS = 64
-GFLOP_PER_PAIR = 17.4          # fwd+bwd, 2 FLOP/MAC, backward = 2x forward
+ARCHS = {"c2": dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=1024, img=224, patch=16),      # configs[1] (and configs[0])
+         "c3": dict(D=256, H=4, G=128, K=32, S=8, MR=2, N=1024, img=224, patch=16),     # configs[2]: 32 pairs / GPU
+         "c4": dict(D=384, H=6, G=128, K=32, S=8, MR=4, N=2048, img=224, patch=16)}     # configs[3]: 16 pairs / GPU
+PAIRS = {"c2": 64, "c3": 32, "c4": 16}
+NAMES = {"c2": "E1CL6SL-H4D256-L96-MR2", "c3": "E1CL8SL-H4D256-L128-MR2", "c4": "E1CL8SL-H6D384-L128-MR4"}
+GFLOP_PER_PAIR = {"c2": 17.4, "c3": 24.2, "c4": 64.7}   # fwd+bwd, 2 FLOP/MAC, backward = 2x forward
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guide: MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r02_bench_c2_kernel_stats.csv")
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
-def synth_batch(b, N, img, seed, device):
-    """ShapeNetRender-shaped synthetic pairs: two augmented views of a unit-sphere cloud
-    (independent noise clouds, each centred and scaled like PointcloudNormalize) + a ~N(0,1) image."""
+def synth_batch(b, N, img, seed, device, dups=False):
+    """ShapeNetRender-shaped synthetic pairs: two augmented views of a unit-sphere cloud (independent noise clouds, each
+    centred and scaled like PointcloudNormalize) + a ~N(0,1) image.  dups: additionally PointcloudRandomInputDropout
+    (data_utils.py:181-199): a random 0 .. 87.5 % of each cloud's points replaced by its first point."""
     g = torch.Generator(device="cpu").manual_seed(seed)
 
     def cloud():
         p = torch.randn(b, N, 3, generator=g)
         p = p - p.mean(1, keepdim=True)
-        return p / p.norm(dim=2).max(dim=1)[0].view(b, 1, 1)
+        p = p / p.norm(dim=2).max(dim=1)[0].view(b, 1, 1)
+        if dups:
+            ratio = torch.rand(b, 1, generator=g) * 0.875
+            drop = torch.rand(b, N, generator=g) <= ratio
+            p = torch.where(drop.unsqueeze(-1), p[:, :1, :].expand(b, N, 3), p)
+        return p
 
     t1, t2 = cloud(), cloud()
     imgs = torch.randn(b, 3, img, img, generator=g)
     return t1.to(device), t2.to(device), imgs.to(device)
 
 
-# Algorithmic HBM bytes of one row (token) through sa_layer_fwd_kernel (DESIGN.md section 4): reads o (bf16 256) + residual base
-# (f32 256) + pos (f32 256); writes x1, out (f32 256 each), n2, next n1 (bf16 256 each), u, h (bf16 512 each),
-# next qkv (bf16 768), 4 LayerNorm statistics (f32).  Weights (1.3 MB per launch, L2 resident) are not counted.
-SA_FWD_BYTES_PER_ROW = 256 * 2 + 256 * 4 + 256 * 4 + 2 * 256 * 4 + 2 * 256 * 2 + 2 * 512 * 2 + 768 * 2 + 16
-SA_FWD_FLOP_PER_ROW = 2 * 256 * (256 + 512 + 512 + 768)
-PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
-
-
-def time_dominant_kernel(device):
-    """Roofline leg: the kernel with the largest share of the step (rocprofv3: profiles/r01_bench_c2_kernel_stats.csv),
-    sa_layer_fwd_kernel -- the fused tail of one encoder layer (o_proj + dropout + residual, LayerNorm, MLP, next layer's
-    LayerNorm + q/k/v projection) over the point-cloud branch's 2 * 64 * 96 = 12288 tokens -- launched back-to-back on
-    torch's current stream (the stream the C ABI launches on) and timed with HIP events on that stream."""
-    import torch.nn as nn
-    from vipformer_amd import ops
-    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
-    B, Lq, D = 2 * PER_GPU_PAIRS, ARCH["G"], ARCH["D"]
-    M = B * Lq
-    layers = nn.ModuleList([SelfAttentionLayer(ARCH["H"], D, ARCH["MR"], 0.0, 0.1, 0.5) for _ in range(2)]).to(device)
-    layers.train()
-    blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
-    packed = ops._pack_blocks(blocks, layers[0], device)
-    st = ops.rng.state(device)
-    base = torch.randn(M, D, device=device)
-    pos = torch.randn(M, D, device=device)
-    o = torch.randn(M, D, device=device).to(torch.bfloat16)
-    lse = torch.zeros(B * ARCH["H"] * Lq, device=device)
-    att, mlp = layers[0][0].module.attention, layers[0][1].module
-    nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
-
-    def launch():
-        ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, Lq, o, base, o, lse, nxt, pos, M, device)
-
-    for _ in range(3):
-        launch()
-    iters = 20
+# ----------------------------------------------------------------------------------------------- kernel legs
+def _events(fn, iters=30, warm=5):
+    """Mean microseconds per call of fn, HIP events on torch's current stream (the stream the C ABI launches on)."""
+    for _ in range(warm):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        launch()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    nbytes = float(SA_FWD_BYTES_PER_ROW) * M
-    ach = nbytes / (ms * 1e-3) / 1e9
-    traffic = None
-    try:        # HBM bytes per launch from the PMC passes of the same kernel (tools/pmc_hbm.sh), measured offline
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_sa_layer_fwd.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return dict(bound="hbm", kernel="sa_layer_fwd_kernel<2,2,32,false> (fused encoder-layer tail), 12288 tokens x 256 channels",
-                achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic,
-                us_per_launch=round(ms * 1e3, 2), bytes_per_launch=nbytes,
-                mfma_tflops=round(SA_FWD_FLOP_PER_ROW * M / (ms * 1e-3) / 1e12, 1))
+    return e0.elapsed_time(e1) / iters * 1e3
 
 
-def cpu_baseline(pairs=4, timed_steps=2):
-    """The oracle (fp32 torch-CPU restatement of the reference step, pinned against the reference by the
-    golden fixtures) on this box's host cores: forward + backward + AdamW on `pairs` c1-shaped pairs."""
+def _leg(name, us, nbytes, flops, bound, note):
+    gbs, tf = nbytes / us / 1e3, flops / us / 1e6
+    d = dict(kernel=name, us_per_launch=round(us, 2), bytes_per_launch=float(nbytes), flops_per_launch=float(flops),
+             hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4), mfma_tflops=round(tf, 1),
+             mfma_frac=round(tf / PEAK_BF16_TFLOPS, 4), bound=bound, note=note)
+    return d
+
+
+def kernel_legs(device, a, pairs):
+    """Stand-alone, live timings of the named kernels at the benchmark's shapes.  Algorithmic bytes / flops: DESIGN.md section 4."""
+    import torch.nn as nn
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud import utils as U
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    legs = {}
+    B, N, G, K, D, H = 2 * pairs, a["N"], a["G"], a["K"], a["D"], a["H"]
+    M = B * G
+    g = torch.Generator(device="cpu").manual_seed(5)
+    # ---- FPS / kNN grouping (SURVEY 8d: 12N + 8G and 12N + 12GK + 12G bytes per cloud; fp32 xyz, int64 indices as the reference)
+    pts = torch.randn(B, N, 3, generator=g).to(device)
+    start = torch.randint(0, N, (B,), generator=g).to(device)
+    us = _events(lambda: U._fps_from_start(pts, G, start))
+    leg = _leg("fps_kernel", us, B * (12 * N + 8 * G), 0, "latency",
+               f"{B} clouds x {N} points, {G} dependent iterations; one workgroup per cloud, cloud resident in LDS + registers")
+    leg["ns_per_iteration"] = round(us * 1e3 / G, 1)
+    legs["fps_kernel"] = leg
+    ct = U.index_points(pts, U._fps_from_start(pts, G, start))
+    us = _events(lambda: U._knn_group(pts, ct, K, True, False, False, True))
+    legs["knn_group_select_kernel"] = _leg("knn_group_select_kernel", us, B * (12 * N + 12 * G * K + 12 * G), 2.0 * 3 * B * G * N, "latency",
+                                           f"{B * G} centres x {N} candidates -> {K} neighbours each, fused gather + utils.py:36 quirk")
+    # ---- attention (4 B H Lq Lkv dh flops forward; backward 2.5x)
+    st = ops.rng.state(device)
+    T = (a["img"] // a["patch"]) ** 2
+    for tag, (Bq, Lq, Lkv) in (("cross-attention pc", (B, G, N)), ("self-attention pc", (B, G, G)), ("self-attention img", (pairs, T, T))):
+        q = torch.randn(Bq * Lq, D, generator=g).to(device).bfloat16(); k = torch.randn(Bq * Lkv, D, generator=g).to(device).bfloat16()
+        v = torch.randn(Bq * Lkv, D, generator=g).to(device).bfloat16(); do = torch.randn(Bq * Lq, D, generator=g).to(device).bfloat16()
+        o = torch.empty_like(q); lse = torch.empty(Bq * H * Lq, device=device)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dl = torch.empty(Bq * H * Lq, dtype=torch.float32, device=device)
+        fl = 4.0 * Bq * H * Lq * Lkv * 64
+        io_f = 2.0 * D * (2 * Bq * Lq + 2 * Bq * Lkv)
+        us = _events(lambda: L.call("vpf_attention_fwd", q, D, k, D, v, D, Bq, H, Lq, Lkv, 64, 0.125, 0.1, st, 7, o, D, lse), 20, 3)
+        kn = "attn_fwd_kernel" if Lkv > 224 else "attn_res_fwd_kernel"
+        legs[f"{kn} ({tag})"] = _leg(kn, us, io_f, fl, "mfma", f"{tag}: B {Bq} H {H} Lq {Lq} Lkv {Lkv} dh 64, dropout 0.1")
+        us = _events(lambda: L.call("vpf_attention_bwd", q, D, k, D, v, D, o, D, do, D, lse, Bq, H, Lq, Lkv, 64, 0.125, 0.1, st, 7,
+                                    dq, D, dk, D, dv, D, dl), 20, 3)
+        kn = "attn_bwd_dq/dkv_kernel" if Lkv > 224 else "attn_res_bwd_kernel"
+        legs[f"{kn} ({tag})"] = _leg(kn, us, 2.0 * D * (4 * Bq * Lq + 4 * Bq * Lkv), 2.5 * fl, "mfma", f"{tag} backward")
+    if D != 256:
+        return legs
+    # ---- grouped weight gradients of one encoder layer: dW = dY^T X for fc2, fc1, o_proj, qkv over M tokens
+    shapes = [(D, 2 * D), (2 * D, D), (D, D), (3 * D, D)]
+    jobs = [(torch.randn(M, Nn, generator=g).to(device).bfloat16(), torch.randn(M, Kk, generator=g).to(device).bfloat16(), Nn, Kk,
+             torch.zeros(Nn, Kk, device=device), torch.zeros(Nn, device=device)) for Nn, Kk in shapes]
+
+    def wgroup():
+        wg = ops.WgradBatch()
+        for dy, x, Nn, Kk, dW, db in jobs:
+            wg.add(dy, x, Nn, Kk, dW, db)
+        wg.flush()
+
+    us = _events(wgroup, 50, 5)
+    nbytes = sum(2.0 * M * (Nn + Kk) + 4.0 * Nn * Kk for Nn, Kk in shapes)
+    legs["gemm_wgrad_group_kernel"] = _leg("gemm_wgrad_group_kernel", us, nbytes, sum(2.0 * M * Nn * Kk for Nn, Kk in shapes), "hbm",
+                                           f"4 weight gradients of one encoder layer, {M} tokens: operands read once + dW written once")
+    # ---- fused encoder-layer tail (o_proj .. MLP .. next layer's LayerNorm + q/k/v): 9232 B and 2*256*2048 flop per token
+    layers = nn.ModuleList([SelfAttentionLayer(H, D, a["MR"], 0.0, 0.1, 0.5) for _ in range(2)]).to(device)
+    layers.train()
+    blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
+    packed = ops._pack_blocks(blocks, layers[0], device)
+    base = torch.randn(M, D, device=device); pos = torch.randn(M, D, device=device)
+    o = torch.randn(M, D, device=device).to(torch.bfloat16)
+    lse = torch.zeros(B * H * G, device=device)
+    att, mlp = layers[0][0].module.attention, layers[0][1].module
+    nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
+    us = _events(lambda: ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, M, device), 20, 3)
+    per_row = 256 * 2 + 256 * 4 + 256 * 4 + 2 * 256 * 4 + 2 * 256 * 2 + 2 * 512 * 2 + 768 * 2 + 16
+    legs["sa_layer_fwd_kernel"] = _leg("sa_layer_fwd_kernel", us, float(per_row) * M, 2.0 * 256 * (256 + 512 + 512 + 768) * M, "hbm",
+                                       f"fused encoder-layer tail, {M} tokens x 256 channels")
+    return legs
+
+
+def _profile_rows():
+    try:
+        with open(PROFILE_STATS) as f:
+            return list(csv.DictReader(f))
+    except OSError:
+        return []
+
+
+def _pmc():
+    try:
+        with open(PROFILE_PMC) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def attach_profile(legs):
+    """Per leg: the in-step average of the committed whole-step rocprofv3 trace (same command), its share of the step's kernel time,
+    and the PMC numbers of the committed counter passes (HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
+    correction; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs x 4 SIMDs))."""
+    rows = _profile_rows()
+    pmc = _pmc()
+    tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    for key, leg in legs.items():
+        base = leg["kernel"].split("/")[0].replace("attn_bwd_dq", "attn_bwd_dq")
+        hit = [r for r in rows if base.split(" ")[0] in r["Name"]]
+        if hit:
+            ns = sum(float(r["TotalDurationNs"]) for r in hit); calls = sum(float(r["Calls"]) for r in hit)
+            leg["in_step_avg_us"] = round(ns / calls / 1e3, 2)
+            leg["share_of_step_kernel_time"] = round(ns / tot, 4)
+        p = pmc.get(key) or pmc.get(leg["kernel"])
+        if p:
+            leg.update(p)
+    return rows
+
+
+def dominant(legs, rows):
+    """The leg whose kernel is first in the whole-step kernel statistics (largest total time); the grouped weight gradient if the
+    profile is absent."""
+    for r in rows:
+        for key, leg in legs.items():
+            if leg["kernel"].split("/")[0].split(" ")[0] in r["Name"]:
+                return key
+    return "gemm_wgrad_group_kernel" if "gemm_wgrad_group_kernel" in legs else next(iter(legs))
+
+
+# ----------------------------------------------------------------------------------------------- CPU baseline
+def physical_cores():
+    try:
+        seen = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or os.cpu_count()
+    except OSError:
+        return os.cpu_count()
+
+
+def cpu_baseline(a, pairs=8, timed_steps=3):
+    """The oracle (fp32 torch-CPU restatement of the reference step, pinned against the reference by the golden fixtures) on this
+    box's host cores: forward + backward + AdamW on config 1 (8 c1-shaped pairs), all physical cores and 8 threads; beside it the
+    DataLoader-worker leg (datasets/data.py:97-112: two trans_1 views + one image transform per pair, single thread x cores)."""
+    from oracle import augment as A
     from oracle import torch_oracle as O
     from tests import helpers as Hh
-    a = ARCH
     arch = O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"])
     pc_sd = Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c1.json"), 100)
     im_sd = Hh.synth_state_dict(Hh.load_keyshapes("keys_img_c1.json"), 200)
     isparam = lambda k, v: v.dtype == torch.float32 and "running" not in k and "cross_attn_1." not in k
-    pcp = {k: v.clone().requires_grad_() for k, v in pc_sd.items() if isparam(k, v)}
-    imp = {k: v.clone().requires_grad_() for k, v in im_sd.items() if isparam(k, v)}
-    s1, s2 = dict(pc_sd), dict(im_sd)
-    s1.update(pcp); s2.update(imp)
-    for s in (s1, s2):
-        for k in list(s):
-            if "cross_attn_1." in k:
-                s[k] = s[k.replace("cross_attn_1.", "cross_attn_n.")]
     t1, t2, imgs = synth_batch(pairs, a["N"], a["img"], 0, "cpu")
     imgs = imgs.permute(0, 2, 3, 1)
-    params = {**{"pc." + k: v for k, v in pcp.items()}, **{"img." + k: v for k, v in imp.items()}}
-    state = {}
-    times = []
-    for it in range(1 + timed_steps):
-        t0 = time.perf_counter()
-        for v in params.values():
-            v.grad = None
-        start = torch.randint(0, a["N"], (2 * pairs,))
-        loss, _, _ = O.pretrain_losses(s1, s2, t1, t2, imgs, start, arch, True, O.Masks("torch"), O.Masks("torch"), {}, {})
-        loss.backward()
-        with torch.no_grad():
-            O.adamw_step({k: v for k, v in params.items()}, {k: v.grad for k, v in params.items()}, state, it + 1)
-        if it > 0:
-            times.append(time.perf_counter() - t0)
-    sec = sum(times) / len(times)
-    return dict(value=round(pairs / sec, 3), unit="pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{timed_steps} timed steps (after 1 warm-up) of {pairs} pairs, E1CL6SL-H4D256-L96-MR2, 1024 pts + 224x224 "
-                       f"img, fp32 torch-CPU oracle incl. FPS/kNN (C), fwd+bwd+AdamW; {sec:.2f} s/step")
+
+    def run(threads, steps):
+        torch.set_num_threads(threads)
+        pcp = {k: v.clone().requires_grad_() for k, v in pc_sd.items() if isparam(k, v)}
+        imp = {k: v.clone().requires_grad_() for k, v in im_sd.items() if isparam(k, v)}
+        s1, s2 = dict(pc_sd), dict(im_sd)
+        s1.update(pcp); s2.update(imp)
+        for s in (s1, s2):
+            for k in list(s):
+                if "cross_attn_1." in k:
+                    s[k] = s[k.replace("cross_attn_1.", "cross_attn_n.")]
+        params = {**{"pc." + k: v for k, v in pcp.items()}, **{"img." + k: v for k, v in imp.items()}}
+        state, times = {}, []
+        for it in range(1 + steps):
+            t0 = time.perf_counter()
+            for v in params.values():
+                v.grad = None
+            start = torch.randint(0, a["N"], (2 * pairs,))
+            loss, _, _ = O.pretrain_losses(s1, s2, t1, t2, imgs, start, arch, True, O.Masks("torch"), O.Masks("torch"), {}, {})
+            loss.backward()
+            with torch.no_grad():
+                O.adamw_step({k: v for k, v in params.items()}, {k: v.grad for k, v in params.items()}, state, it + 1)
+            if it > 0:
+                times.append(time.perf_counter() - t0)
+        return sum(times) / len(times)
+
+    default_threads = torch.get_num_threads()
+    cores = physical_cores()
+    sec = run(cores, timed_steps)
+    sec8 = run(min(8, cores), 2)
+    torch.set_num_threads(1)
+    t_view, t_img = A.time_sample(a["N"], a["img"], a["img"], repeats=30)
+    torch.set_num_threads(default_threads)
+    aug_pair = 2 * t_view + t_img
+    return dict(value=round(pairs / sec, 3), unit="pairs/s", cores=cores, kind="port",
+                sample=f"{timed_steps} timed steps (after 1 warm-up) of {pairs} pairs = BASELINE configs[0] (E1CL6SL-H4D256-L96-MR2, 1024 pts + "
+                       f"224x224 img), fp32 torch-CPU oracle incl. FPS/kNN (C), fwd+bwd+AdamW; {sec:.2f} s/step on {cores} threads",
+                pairs_per_s_8_threads=round(pairs / sec8, 3),
+                augmentation=dict(ms_per_view_trans_1=round(t_view * 1e3, 3), ms_per_image_transform=round(t_img * 1e3, 3),
+                                  ms_per_pair_one_thread=round(aug_pair * 1e3, 3), pairs_per_s_all_cores=round(cores / aug_pair, 1),
+                                  note="datasets/data.py:16-25,97-112 restated (oracle/augment.py): trans_1 pinned bit-exactly against the "
+                                       "reference's data_utils.py; image transform = torchvision semantics restated with PIL + numpy (unpinned)"),
+                torch=torch.__version__, logical_cpus=os.cpu_count())
 
 
+# ----------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", choices=sorted(ARCHS), default="c2", help="c2 = BASELINE configs[1] (the metric's workload)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone kernel legs (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="run the image branch on the same stream as the point-cloud branch")
     ap.add_argument("--wgrad-async", action="store_true", help="grouped weight-gradient launches on a side stream")
-    ap.add_argument("--pairs", type=int, default=PER_GPU_PAIRS, help="pairs per GPU (default = BASELINE configs[1])")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the configuration's per-GPU batch)")
     args = ap.parse_args()
+    a = ARCHS[args.arch]
+    pairs = args.pairs or PAIRS[args.arch]
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -175,21 +322,22 @@ def main():
 
     torch.manual_seed(1)                                   # parser.py:17 default seed; same init on every rank
     ops.rng.seed(1234 + rank)
-    pc, im = build_models(**ARCH, device=device)
+    pc, im = build_models(**a, device=device)
     pc.train(); im.train()
     tr = Pretrainer(pc, im, world_size=world)
     tr.overlap = not args.no_overlap
     ops.WGRAD_GROUP_ASYNC[0] = args.wgrad_async
     tr.broadcast_parameters(0)
     torch.manual_seed(100 + rank)                          # FPS start indices differ per rank
-    t1, t2, imgs = synth_batch(args.pairs, ARCH["N"], ARCH["img"], seed=rank, device=device)
+    t1, t2, imgs = synth_batch(pairs, a["N"], a["img"], seed=rank, device=device)
 
     use_graph = not args.no_graph
     if use_graph:
-        tr.capture(t1, t2, imgs, warmup=2)
+        static = tr.capture(t1, t2, imgs, warmup=2)
         run = tr.replay
     else:
-        run = lambda: tr.step(t1, t2, imgs)
+        static = (t1, t2, imgs)
+        run = lambda: tr.step(*static)
     for _ in range(args.warmup):
         run()
 
@@ -199,40 +347,86 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = te.item()
+    def timed(fn, steps):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = te.item()
+        return el
+
+    elapsed = timed(run, args.steps)
     losses = [float(x) for x in tr.losses]
     finite = all(map(lambda v: v == v and abs(v) != float("inf"), losses))
 
-    roof = time_dominant_kernel(device) if rank == 0 else None
+    # ---- variants (not `value`): host-fed = the reference's synchronous H2D of the batch (pretrain.py:177) in front of every step
+    variants = {}
+    if use_graph:
+        host = [t.cpu().pin_memory() for t in (t1, t2, imgs)]
+        h2d_bytes = sum(t.numel() * 4 for t in host)
+
+        def host_fed():
+            for dst, src in zip(static, host):
+                dst.copy_(src, non_blocking=True)
+            run()
+
+        vs = max(5, args.steps // 2)
+        for _ in range(2):
+            host_fed()
+        el = timed(host_fed, vs)
+        variants["host_fed"] = dict(value=round(pairs * world / (el / vs), 2), ms_per_step=round(el / vs * 1e3, 3),
+                                    h2d_mb_per_step=round(h2d_bytes / 1e6, 1),
+                                    note="pinned host batch copied into the graph's static buffers before every replay (PCIe-inclusive; never `value`)")
+        d1, d2, _ = synth_batch(pairs, a["N"], a["img"], seed=1000 + rank, device=device, dups=True)
+        static[0].copy_(d1); static[1].copy_(d2)
+        for _ in range(2):
+            run()
+        el = timed(run, vs)
+        variants["duplicate_heavy_inputs"] = dict(value=round(pairs * world / (el / vs), 2), ms_per_step=round(el / vs * 1e3, 3),
+                                                  note="clouds after PointcloudRandomInputDropout (0 .. 87.5 % of the points replaced by "
+                                                       "point 0): what FPS / kNN see on augmented ShapeNetRender data")
+        static[0].copy_(t1); static[1].copy_(t2)
+
+    legs, roof = {}, None
+    if rank == 0 and not args.no_kernels:
+        legs = kernel_legs(device, a, pairs)
+        rows = attach_profile(legs) if args.arch == "c2" else []
+        key = dominant(legs, rows)
+        d = legs[key]
+        bound = d["bound"] if d["bound"] in ("hbm", "mfma") else "hbm"
+        ach, peak, unit = (d["hbm_gbs"], PEAK_HBM_GBS, "GB/s") if bound == "hbm" else (d["mfma_tflops"], PEAK_BF16_TFLOPS, "TFLOP/s")
+        roof = dict(bound=bound, kernel=f"{d['kernel']}: {d['note']}", achieved=ach, peak=peak, unit=unit, frac=round(ach / peak, 4),
+                    traffic=d.get("hbm_bytes_per_launch"), us_per_launch=d["us_per_launch"], in_step_avg_us=d.get("in_step_avg_us"),
+                    frac_in_step=(round(ach * d["us_per_launch"] / d["in_step_avg_us"] / peak, 4) if d.get("in_step_avg_us") else None),
+                    hbm_frac=d["hbm_frac"], mfma_frac=d["mfma_frac"], bytes_per_launch=d["bytes_per_launch"],
+                    flops_per_launch=d["flops_per_launch"], share_of_step_kernel_time=d.get("share_of_step_kernel_time"),
+                    source="live HIP-event timing on the launch stream; in-step average and traffic from profiles/r02_* (same command)")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()
+        cpu = cpu_baseline(ARCHS["c2"])
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = args.pairs * world / (elapsed / args.steps)
+        value = pairs * world / (elapsed / args.steps)
+        gf = GFLOP_PER_PAIR[args.arch]
         out = {
-            "metric": "pretrain pairs/sec (1024 pts + 224^2 img, L96 H4D256)",
+            "metric": "pretrain pairs/sec (1024 pts + 224^2 img, L96 H4D256)" if args.arch == "c2" else f"pretrain pairs/sec ({NAMES[args.arch]})",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "E1CL6SL-H4D256-L96-MR2, per-GPU batch %d pairs (2x1024-pt clouds + 224x224 img, patch 16), "
-                                   "fwd+bwd+AdamW, NT-Xent IMC+CMC, dropout 0.1/0.5" % args.pairs,
-                       "global_batch": args.pairs * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "two_stream_overlap": tr.overlap,
+            "config": {"workload": "%s, per-GPU batch %d pairs (2x%d-pt clouds + 224x224 img, patch 16), fwd+bwd+AdamW, NT-Xent IMC+CMC, "
+                                   "dropout 0.1/0.5" % (NAMES[args.arch], pairs, a["N"]),
+                       "global_batch": pairs * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "two_stream_overlap": tr.overlap,
                        "last_losses": losses, "losses_finite": finite,
-                       "step_tflops_algorithmic": round(value * GFLOP_PER_PAIR / 1e3, 2),
-                       "step_mfma_frac": round(value * GFLOP_PER_PAIR / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
-                       "version": __version__},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "step_tflops_algorithmic": round(value * gf / 1e3, 2),
+                       "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+                       "graph_nodes": getattr(tr, "graph_nodes", None), "version": __version__},
+            "roofline": roof, "kernels": legs, "variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

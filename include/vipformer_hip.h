@@ -287,7 +287,11 @@ int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf
  * partseg.py:48-51,194-197): dW[N,K] += dy[M,N]^T x[M,K] (bf16 operands, fp32 atomics), dbias[N] += column sums of dy
  * (dbias may be NULL).  host_jobs is a HOST array (copied into the kernel arguments: capturable). */
 typedef struct VpfWgradJob { const void* dy; const void* x; int M, N, K; float* dW; float* dbias; } VpfWgradJob;
-int vpf_wgrad_group(const VpfWgradJob* host_jobs, int njobs, void* stream);
+/* ws (nullable): >= 4096 + 65536 * (number of workgroups, <= ~640) bytes of scratch, 16-byte aligned, whose first 4096 bytes were
+ * zeroed ONCE by the caller (arrival counters; the kernel leaves them zero), private to the stream: with it the split-K slices
+ * exchange their partial tiles through the workspace and the last-arriving slice of a tile writes dW -- no atomics on dW;
+ * without it (or if it is too small) fp32 atomics as before. */
+int vpf_wgrad_group(const VpfWgradJob* host_jobs, int njobs, void* ws, long ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ fused self-attention layer
  * SelfAttentionLayer.forward (partseg.py:170-188; Residual :201-213, MultiHeadAttention :14-86, MLP :191-198) for
@@ -409,6 +413,17 @@ int vpf_pad_bf16(const void* src, int src_is_bf16, long rows, int K, long ld, lo
  * target int64 [rows]; partial_ws f32 [1024]; loss f32 [1]; dlogits (nullable) f32 [rows, lddz] = d loss / d logits. */
 int vpf_ce_smooth(const float* logits, long ld, const long long* target, long rows, int C, float eps, float* partial_ws,
                   float* loss, float* dlogits, long lddz, void* stream);
+/* ------------------------------------------------------------------ on-device augmentation
+ * trans_1 / trans_2 of datasets/data.py:16-36 (datasets/data_utils.py:56-221: Normalize, Scale(0.5,2), Rotate about y, Translate(0.5),
+ * Jitter(0.01, clip 0.05), RandomInputDropout(0.875)) on a batch of raw clouds pts f32 [B,N,C>=3] -> out f32 [B,N,3], N <= 4096.
+ * Random draws: the library's counter-based stream (rng_state, site), statistically -- not bitwise -- the reference's numpy / torch
+ * draws; params_out (nullable) f32 [B,8] = {scale, angle, tx, ty, tz (unit draws), dropout ratio, radius, 0} for replay. */
+int vpf_augment_points(const float* pts, int B, int N, int C, const uint32_t* rng_state, uint32_t site, float* out,
+                       float* params_out, void* stream);
+/* ToTensor + Normalize(mean, std) + RandomHorizontalFlip(p_flip) of utils.py:21-25 on uint8 img [B,H,W,3] -> f32 [B,3,H,W]
+ * (mean3 / std3: HOST arrays of 3 floats; rng_state nullable = no flip; flips_out nullable u8 [B]). */
+int vpf_image_u8_normalize(const void* img_u8, int B, int H, int W, const float* mean3_host, const float* std3_host,
+                           const uint32_t* rng_state, uint32_t site, float p_flip, float* out, void* flips_out, void* stream);
 /* sizeof(VpfSaLayerBwd) is vpf_abi_sizeof(3), sizeof(VpfPgradJob) (4), sizeof(VpfAdapterKv) (5), sizeof(VpfAdapterKvBwd) (6) */
 /* sizeof(VpfPackJob) (which = 0) / sizeof(VpfSaLayerFwd) (1) / sizeof(VpfWgradJob) (2): lets a binding verify its struct layout */
 int vpf_abi_sizeof(int which);

@@ -333,6 +333,72 @@ def pc_ft_forward(sd, pts, start_idx, a: Arch, train: bool, masks: Optional[Mask
     return finetune_head(sd, "finetune_head.", pool(x), train, buffers)
 
 
+def three_nn(xyz1, xyz2):
+    """utils.py:219-230: for every point of xyz1 [B,N,3] the three nearest of xyz2 [B,S,3] by square_distance (bit-exact recipe,
+    C oracle) and their normalised inverse-distance weights; canonical tie order (stable sort = lower index first)."""
+    d = square_distance(xyz1.detach(), xyz2.detach())
+    dist, idx = torch.sort(d, dim=-1, stable=True)
+    dist, idx = dist[:, :, :3], idx[:, :, :3]
+    recip = 1.0 / (dist + 1e-8)
+    return idx, recip / recip.sum(dim=2, keepdim=True)
+
+
+def feature_propagation(sd, pre: str, xyz1, xyz2, points1, points2, train: bool, buffers=None):
+    """PointNetFeaturePropagation.forward, utils.py:205-242, in row-major layouts: xyz1 [B,N,3], xyz2 [B,S,3], points1 [B,N,C1] or
+    None, points2 [B,S,F] -> [B,N,mlp[-1]]."""
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    if S == 1:
+        interp = points2.repeat(1, N, 1)
+    else:
+        idx, w = three_nn(xyz1, xyz2)
+        gathered = torch.gather(points2.unsqueeze(1).expand(B, N, S, points2.shape[2]), 2,
+                                idx.unsqueeze(-1).expand(B, N, 3, points2.shape[2]))
+        interp = torch.sum(gathered * w.view(B, N, 3, 1), dim=2)
+    x = torch.cat([points1, interp], dim=-1) if points1 is not None else interp
+    x = Q(x).permute(0, 2, 1)
+    i = 0
+    while pre + f"mlp_convs.{i}.weight" in sd:
+        h = F.conv1d(x, Q(sd[pre + f"mlp_convs.{i}.weight"]), sd[pre + f"mlp_convs.{i}.bias"])      # (pre-BatchNorm: fp32 on the HIP path)
+        x = Q(F.relu(_bn(sd, pre + f"mlp_bns.{i}.", h, train, buffers)))
+        i += 1
+    return x.permute(0, 2, 1)
+
+
+def partseg_forward(sd, pts, start_idx, cls_label, a: Arch, layer_idx, train: bool, masks: Optional[Masks] = None, buffers=None,
+                    head_mask=None):
+    """CrossFormer_partseg.forward, partseg.py:407-470 -> logits [B,N,num_part_classes].  head_mask: keep mask [B*N,512] of dp1
+    (None: torch's RNG when train, nothing in eval)."""
+    masks = masks or Masks("off")
+    B, N, _ = pts.shape
+    kv = adapter(sd, "input_adapter.", pts)
+    fidx = fps_indices(pts, start_idx, a.G)
+    nb, ct, _ = divide_patches(pts, fidx, a.K, True)
+    tok = group2emb(sd, "group2emb.", nb, train, buffers)
+    pos = pos_mlp(sd, "position_emb.", ct)
+    _, feats = encoder(sd, "encoder.", tok, pos, kv, a, masks, taps=tuple(layer_idx))
+    D = a.D
+    x = torch.cat([F.layer_norm(f, (D,), sd["norm.weight"], sd["norm.bias"], 1e-5) for f in feats], dim=2)      # [B,G,nl*D]
+    x_max, x_avg = x.max(dim=1)[0], x.mean(dim=1)
+    lab = F.conv1d(Q(cls_label.view(B, 16, 1)), Q(sd["label_conv.0.weight"]))
+    lab = Q(F.leaky_relu(_bn(sd, "label_conv.1.", lab, train, buffers), 0.2)).view(B, 64)
+    glob = Q(torch.cat([x_max, x_avg, lab], dim=1))                                                             # [B, 2*nl*D + 64]
+    f0 = feature_propagation(sd, "propagation.", pts[:, :, :3], ct[:, :, :3], pts, x, train, buffers)          # [B,N,1024]
+    h = torch.cat([f0, glob.unsqueeze(1).expand(B, N, glob.shape[1])], dim=2).permute(0, 2, 1)                  # [B, 1024 + ..., N]
+    h = F.conv1d(h, Q(sd["conv1.weight"]), sd["conv1.bias"])
+    h = Q(F.relu(_bn(sd, "bn1.", h, train, buffers)))
+    if train:
+        if head_mask is not None:
+            h = h * head_mask.view(B, N, -1).permute(0, 2, 1).to(h.dtype) * 2.0
+        else:
+            h = F.dropout(h, 0.5, True)
+        h = Q(h)
+    h = F.conv1d(h, Q(sd["conv2.weight"]), sd["conv2.bias"])
+    h = Q(F.relu(_bn(sd, "bn2.", h, train, buffers)))
+    h = F.conv1d(h, Q(sd["conv3.weight"]), sd["conv3.bias"])
+    return h.permute(0, 2, 1)
+
+
 def patchify(imgs, p: int):
     """partseg.py:632: 'b (h p1) (w p2) c -> b (h w) (p1 p2 c)'."""
     B, Hh, Ww, C = imgs.shape

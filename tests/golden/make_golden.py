@@ -321,11 +321,102 @@ def make_ft(names=("tiny", "c1")):
         print("ft fixture", name, {k: tuple(np.asarray(v.detach() if torch.is_tensor(v) else v).shape) for k, v in res.items()})
 
 
+def make_partseg(names=("tinyseg", "c3")):
+    """CrossFormer_partseg (partseg.py:345-470; BASELINE config 5 is the c3 architecture): key list, eval / train logits with every
+    encoder dropout at 0 (the head's Dropout(0.5) is only active in train mode, so the train-mode fixture is taken with the head
+    dropout patched to 0 as well and checked for the BatchNorm batch statistics), gradients of a loss linear in the logits, the
+    3-NN indices / weights of PointNetFeaturePropagation, and the label-smoothed cross entropy of ft_partseg.py:128."""
+    NPART = 50
+    for name in names:
+        a = Hh.ARCHS[name]
+        lidx = Hh.PARTSEG_LAYERS[name]
+        torch.manual_seed(0)
+        ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+        m = RP.CrossFormer_partseg(ad, a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.0, 0.0, lidx, NPART)
+        json.dump(keyshapes(m), open(os.path.join(HERE, f"keys_partseg_{name}.json"), "w"))
+        m.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_partseg_{name}.json"), 100))
+        B = Hh.MODEL_BATCH[name]
+        pts = Hh.synth_points(320, B, a["N"], 3, "uniform")
+        start = Hh.synth_start(320, B, a["N"])
+        cls = torch.zeros(B, 16)
+        cls[torch.arange(B), torch.arange(B) % 16] = 1.0
+        target = torch.from_numpy((np.random.default_rng(321).random((B, a["N"])) * NPART).astype(np.int64))
+        res = {}
+        RU.knn_point = canonical_knn
+        m.eval()
+        with torch.no_grad(), forced_start(start):
+            res["eval_logits"] = m(pts, cls)[:, :64].clone()
+        m.train(); m.zero_grad()
+        m.dp1.p = 0.0
+        with forced_start(start):
+            y = m(pts, cls)
+        res["train_logits"] = y[:, :64].clone()
+        loss = torch.nn.CrossEntropyLoss(label_smoothing=0.2)(y.reshape(-1, NPART), target.reshape(-1))
+        res["ce_loss"] = np.array([loss.item()])
+        (y * Hh.synth_like(720, y.shape)).sum().backward()
+        names_ = [k for k, p in m.named_parameters() if p.grad is not None]
+        res["grad_norms"] = np.array([dict(m.named_parameters())[k].grad.double().norm().item() for k in names_])
+        json.dump(names_, open(os.path.join(HERE, f"grad_names_partseg_{name}.json"), "w"))
+        for k in ("bn1.running_mean", "bn1.running_var", "propagation.mlp_bns.1.running_var", "label_conv.1.running_var"):
+            res["buf." + k] = m.state_dict()[k].clone()
+        # the 3-NN stage on its own
+        with forced_start(start):
+            _, ct = RU.divide_patches(pts, a["G"], a["K"])
+        d = RU.square_distance(pts, ct)
+        dist, idx = torch.sort(d, dim=-1, stable=True)
+        recip = 1.0 / (dist[:, :, :3] + 1e-8)
+        res["nn_idx"] = idx[:, :, :3].clone()
+        res["nn_weight_bits"] = (recip / recip.sum(dim=2, keepdim=True)).numpy().view(np.uint32)
+        res["nn_tie_free"] = np.array(bool((dist[:, :, 2] != dist[:, :, 3]).all() and (dist[:, :, 0] != dist[:, :, 1]).all()
+                                           and (dist[:, :, 1] != dist[:, :, 2]).all()))
+        RU.knn_point = _orig_knn
+        save(f"partseg_{name}.npz", **res)
+
+
+def make_augment():
+    """datasets/data.py:16-25 (trans_1) run with the reference's own data_utils.py classes (loaded by file path: the datasets
+    package itself imports h5py / torchvision) under np.random.seed / torch.manual_seed -> augment_trans1.npz."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_data_utils", os.path.join(REF, "datasets", "data_utils.py"))
+    du = importlib.util.module_from_spec(spec); spec.loader.exec_module(du)
+    steps = [du.PointcloudToTensor(), du.PointcloudNormalize(), du.PointcloudScale(lo=0.5, hi=2, p=1), du.PointcloudRotate(),
+             du.PointcloudTranslate(0.5, p=1), du.PointcloudJitter(p=1), du.PointcloudRandomInputDropout(p=1)]
+    outs = {}
+    for case, (seed, n) in enumerate(((11, 1024), (12, 2048), (13, 300))):
+        cloud = (np.random.default_rng(seed).random((n, 3)) * 2.0 - 1.0).astype(np.float32) * np.array([1.0, 0.5, 2.0], np.float32) + 0.3
+        np.random.seed(seed); torch.manual_seed(seed)
+        x = cloud.copy()
+        for t in steps:
+            x = t(x)
+        outs[f"out{case}"] = x.numpy().copy()
+        outs[f"meta{case}"] = np.array([seed, n])
+    save("augment_trans1.npz", **outs)
+
+
+def make_ckpt():
+    """A pc_model_best.pth exactly as pretrain.py:283-285 writes it -- torch.save(module.state_dict()) of the REFERENCE's
+    CrossFormer_pc_mp (tiny architecture, synthetic weights, seed 100) -> ckpt_pc_tiny.pth (a data file: tensors + key order)."""
+    a = Hh.ARCHS["tiny"]
+    pc, _ = build_ref(a)
+    pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_tiny.json"), 100))
+    torch.save(pc.state_dict(), os.path.join(HERE, "ckpt_pc_tiny.pth"))
+    print("wrote ckpt_pc_tiny.pth", os.path.getsize(os.path.join(HERE, "ckpt_pc_tiny.pth")))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ft":
         make_ft()
+    elif len(sys.argv) > 1 and sys.argv[1] == "partseg":
+        make_partseg()
+    elif len(sys.argv) > 1 and sys.argv[1] == "augment":
+        make_augment()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ckpt":
+        make_ckpt()
     elif len(sys.argv) > 2 and sys.argv[1] == "models":        # python make_golden.py models c3 c4
         main(only_models=tuple(sys.argv[2:]))
     else:
         main()
         make_ft()
+        make_partseg()
+        make_augment()
+        make_ckpt()

@@ -110,7 +110,11 @@ ARCHS = {
     "c1": dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=1024, img=224, patch=16),
     "c3": dict(D=256, H=4, G=128, K=32, S=8, MR=2, N=1024, img=224, patch=16),
     "c4": dict(D=384, H=6, G=128, K=32, S=8, MR=4, N=2048, img=224, patch=16),
+    "tinyseg": dict(D=64, H=1, G=16, K=8, S=3, MR=2, N=256, img=32, patch=8),       # CrossFormer_partseg needs >= 3 layers to tap
 }
 
 # pairs per batch used by the model_* / dropout-step fixtures and tests
-MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4, "c3": 4, "c4": 4}
+MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4, "c3": 4, "c4": 4, "tinyseg": 8}
+
+# CrossFormer_partseg taps (1-based self-attention layer numbers; the reference needs 3 or 4 of them, partseg.py:430-435)
+PARTSEG_LAYERS = {"tinyseg": [1, 2, 3], "c3": [2, 5, 8]}

@@ -196,3 +196,15 @@ def test_two_trainers_in_one_process_do_not_alias():
     assert abs(outs[0][0] - outs[1][0]) < 1e-6 * abs(outs[0][0])            # same weights, same sites, same state -> same loss
     assert cosine(outs[0][1], outs[1][1]) > 0.999999
     assert trainers[0].flat.g.data_ptr() != trainers[1].flat.g.data_ptr()
+
+
+def test_data_parallel_two_ranks_on_one_gpu():
+    """The N > 1 sequence of bench.py / Pretrainer (hipGraph forward + backward, region-wise asynchronous gradient all-reduce on the
+    communication stream, AdamW per region) with two real processes sharing this GPU over gloo (tools/dp2_one_gpu.py; RCCL itself
+    needs two GPUs): reduced gradient == sum of the ranks' local gradients, parameters bitwise identical across ranks and equal to
+    AdamW on the mean gradient."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp2_one_gpu.py"), "4", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "dp2 on one GPU: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

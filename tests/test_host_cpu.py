@@ -206,25 +206,31 @@ def test_install_as_vipformer_overlays_a_reference_checkout():
 def _dp_worker(rank, world, port, q):
     import torch.distributed as dist
     from oracle import torch_oracle as O
-    from vipformer_amd.train import Pretrainer
+    from vipformer_amd.train import GradientExchange
     dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
-
-    class Flat:          # the flat buffers Pretrainer.allreduce_gradients works on (CPU stand-in)
-        pass
-    tr = Pretrainer.__new__(Pretrainer)
-    tr.world, tr.group, tr.flat = world, None, Flat()
-    n = 1000
+    # the REAL exchange object of Pretrainer (train.GradientExchange), on CPU tensors over gloo: two regions launched
+    # asynchronously in backward-completion order (image model first), finished one by one
+    n, cut = 1000, 616
     g = torch.Generator().manual_seed(10 + rank)
-    tr.flat.g = torch.randn(n, generator=g)
-    mine = tr.flat.g.clone()
-    tr.allreduce_gradients()                                     # the step's single collective
+    flat_g = torch.randn(n, generator=g)
+    mine = flat_g.clone()
+    ex = GradientExchange(flat_g, [("img", cut, n), ("pc", 0, cut)], world)
+    ex.start("img")
+    after_first_launch = flat_g[:cut].clone()                    # the pc region is still local while img travels
+    ex.start("pc")
+    ex.finish("img"); ex.finish("pc")
     gathered = [torch.zeros(n) for _ in range(world)]
     dist.all_gather(gathered, mine)
-    ok_sum = torch.allclose(tr.flat.g, sum(gathered), atol=1e-6)
+    ok_sum = torch.allclose(flat_g, sum(gathered), atol=1e-6) and torch.equal(after_first_launch, mine[:cut])
+    try:
+        GradientExchange(flat_g, [("a", 0, 10), ("b", 12, n)], world)
+        ok_sum = False                                           # regions that do not tile the buffer must be rejected
+    except ValueError:
+        pass
     # AdamW with grad_scale = 1/world on the SUM == AdamW on the mean of the per-rank gradients
     p0 = torch.linspace(-1, 1, n)
     pa, pb = {"w": p0.clone()}, {"w": p0.clone()}
-    O.adamw_step(pa, {"w": tr.flat.g / world}, {}, 1)
+    O.adamw_step(pa, {"w": flat_g / world}, {}, 1)
     O.adamw_step(pb, {"w": sum(gathered) / world}, {}, 1)
     ok_step = torch.equal(pa["w"], pb["w"])
     # every rank ends with identical parameters
@@ -248,3 +254,65 @@ def test_gradient_allreduce_world_size_2_gloo():
         p.join(60)
     assert sorted(r[0] for r in res) == [0, 1]
     assert all(r[1] and r[2] and r[3] for r in res), res
+
+
+# ------------------------------------------------------------------------------------------ CrossFormer_partseg (config 5)
+def _build_partseg(name):
+    from vipformer_amd.model.pointcloud import CrossFormer_partseg, PointCloudInputAdapter
+    a = Hh.ARCHS[name]
+    ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+    return CrossFormer_partseg(ad, a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.0, 0.0, Hh.PARTSEG_LAYERS[name], 50)
+
+
+@pytest.mark.parametrize("name", ["tinyseg", "c3"])
+def test_partseg_state_dict_matches_reference_and_loads_a_pretraining_checkpoint(name):
+    m = _build_partseg(name)
+    want = Hh.load_keyshapes(f"keys_partseg_{name}.json")
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == want
+    m.load_state_dict(Hh.synth_state_dict(want, 3), strict=True)
+    if name == "c3":
+        # ft_partseg.py:80-83: a hot-path pc_model_best.pth goes in with strict=False -- 162 shared keys, the 12 latent_head.* are
+        # unexpected, the part-segmentation head's keys are missing
+        pre = Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c3.json"), 100)
+        res = m.load_state_dict(pre, strict=False)
+        assert len(res.unexpected_keys) == 12 and all(k.startswith("latent_head.") for k in res.unexpected_keys)
+        assert len(pre) - 12 == 162
+        assert len(res.missing_keys) == 33
+        assert torch.equal(m.state_dict()["encoder.sa_layers.7.1.module.3.weight"], pre["encoder.sa_layers.7.1.module.3.weight"])
+    with pytest.raises(ValueError):
+        from vipformer_amd.model.pointcloud import CrossFormer_partseg, PointCloudInputAdapter
+        bad = CrossFormer_partseg(PointCloudInputAdapter((64, 3), 64), 8, 64, 8, 1, 1, 3, 1, 2, 0.0, 0.0, 0.0, [1, 2], 50)
+        bad(torch.zeros(1, 64, 3), torch.zeros(1, 16))            # the reference only defines 3 or 4 taps (partseg.py:430-435)
+
+
+# ------------------------------------------------------------------------------------------ checkpoint files
+def test_checkpoint_files_interchange_with_the_reference(tmp_path):
+    """tests/golden/ckpt_pc_tiny.pth was WRITTEN BY THE REFERENCE (torch.save(module.state_dict()), pretrain.py:283-285; made by
+    make_golden.py make_ckpt).  It must load strictly into the mirrored model; a file written by probe.save_best must hold the same
+    keys in the same order with the same bytes; and the fine-tuning convention ("module." prefix, strict=False) must work on it."""
+    from vipformer_amd import probe
+    from vipformer_amd.model.pointcloud import CrossFormer_pc_mp_ft, PointCloudInputAdapter
+    ref_file = os.path.join(Hh.GOLDEN_DIR, "ckpt_pc_tiny.pth")
+    ref_sd = torch.load(ref_file, map_location="cpu")
+    pc, im = _build("tiny")
+    res = pc.load_state_dict(ref_sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    want = Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_tiny.json"), 100)
+    assert all(torch.equal(ref_sd[k], want[k]) for k in want)
+    p1, p2 = probe.save_best(pc, im, str(tmp_path))
+    mine = torch.load(p1, map_location="cpu")
+    assert list(mine.keys()) == list(ref_sd.keys())
+    assert all(torch.equal(mine[k], ref_sd[k]) and mine[k].dtype == ref_sd[k].dtype for k in ref_sd)
+    assert os.path.exists(p2)
+    # ft_cls.py:92-98: a DDP-style wrapper receives "module."-prefixed keys, strict=False
+    a = Hh.ARCHS["tiny"]
+    ft = CrossFormer_pc_mp_ft(PointCloudInputAdapter((a["N"], 3), a["D"]), a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"],
+                              0.0, 0.1, 0.5, True, 40)
+
+    class Wrapper(torch.nn.Module):          # what DistributedDataParallel looks like to load_state_dict
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    res = probe.load_pretrained(Wrapper(ft), ref_file)
+    assert res.unexpected_keys == [] and all(k.startswith("module.finetune_head.") for k in res.missing_keys)
+    assert torch.equal(ft.state_dict()["encoder.sa_layers.1.1.module.3.weight"], ref_sd["encoder.sa_layers.1.1.module.3.weight"])

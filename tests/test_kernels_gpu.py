@@ -362,3 +362,35 @@ def test_fused_pretrain_losses_match_the_two_ntxent_calls():
     assert abs(float(parts[0]) - float(li)) < 1e-5 * abs(float(li)) and abs(float(parts[1]) - float(lc)) < 1e-5 * abs(float(lc))
     assert (df - f.grad).abs().max().item() < 1e-5 * f.grad.abs().max().item() + 1e-9
     assert (dg - g.grad).abs().max().item() < 1e-5 * g.grad.abs().max().item() + 1e-9
+
+
+def test_grouped_wgrad_workspace_split_k():
+    """vpf_wgrad_group with the split-K workspace (partial tiles + last-arriver reduction, no atomics on dW): the four weight
+    gradients of an encoder layer at the benchmark's token count and at ragged sizes, accumulated INTO non-zero buffers, launched
+    twice in a row (the arrival counters must come back to zero), against fp32 matmuls of the same bf16 operands."""
+    from vipformer_amd import ops
+    ops.WGRAD_DETERMINISTIC[0] = True
+    try:
+        _grouped_wgrad_cases(ops)
+        ws = ops.wgrad_workspace("cuda")
+        assert int(ws[:1024].view(torch.int32).abs().sum()) == 0          # counters are back to zero
+    finally:
+        ops.WGRAD_DETERMINISTIC[0] = False
+    _grouped_wgrad_cases(ops)                                             # the default: fp32 atomics
+
+
+def _grouped_wgrad_cases(ops):
+    for M, shapes in ((12288, [(256, 512), (512, 256), (256, 256), (768, 256)]), (1000, [(64, 128), (136, 72)]), (40, [(8, 8)])):
+        jobs = []
+        for i, (N, K) in enumerate(shapes):
+            dy, x = bf(rnd(10 + i, M, N)), bf(rnd(20 + i, M, K))
+            jobs.append((dy, x, N, K, torch.ones(N, K, device="cuda"), torch.ones(N, device="cuda")))
+        for rep in range(2):
+            wg = ops.WgradBatch()
+            for dy, x, N, K, dW, db in jobs:
+                wg.add(dy, x, N, K, dW, db)
+            wg.flush()
+        for dy, x, N, K, dW, db in jobs:
+            ref = dy.float().t() @ x.float()
+            assert rel(dW, 1.0 + 2.0 * ref) < 2e-5, (M, N, K, rel(dW, 1.0 + 2.0 * ref))
+            assert rel(db, 1.0 + 2.0 * dy.float().sum(0)) < 2e-5

@@ -188,3 +188,66 @@ def test_finetune_classifier_vs_reference(name):
     (y * Hh.synth_like(710, y.shape)).sum().backward()
     norms = np.array([hp[k].grad.double().norm().item() for k in names])
     np.testing.assert_allclose(norms, g["head_grad_norms"], rtol=2e-3, atol=1e-5)
+
+
+def _partseg_inputs(name):
+    a = Hh.ARCHS[name]
+    B = Hh.MODEL_BATCH[name]
+    pts = Hh.synth_points(320, B, a["N"]); start = Hh.synth_start(320, B, a["N"])
+    cls = torch.zeros(B, 16)
+    cls[torch.arange(B), torch.arange(B) % 16] = 1.0
+    target = torch.from_numpy((np.random.default_rng(321).random((B, a["N"])) * 50).astype(np.int64))
+    return a, B, pts, start, cls, target
+
+
+@pytest.mark.parametrize("name", ["tinyseg", "c3"])
+def test_partseg_vs_reference(name):
+    """oracle.partseg_forward / feature_propagation / three_nn vs CrossFormer_partseg + PointNetFeaturePropagation of the reference
+    (partseg.py:345-470, utils.py:192-242; fixture: make_golden.py make_partseg).  BASELINE config 5 = the c3 architecture."""
+    arch, _ = _arch(name)
+    a, B, pts, start, cls, target = _partseg_inputs(name)
+    lidx = Hh.PARTSEG_LAYERS[name]
+    g = Hh.golden(f"partseg_{name}.npz")
+    sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_partseg_{name}.json"), 100)
+    with torch.no_grad():
+        _close(O.partseg_forward(sd, pts, start, cls, arch, lidx, False)[:, :64], g["eval_logits"], 2e-4, 2e-4)
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_partseg_{name}.json")))
+    hp = {k: sd[k].clone().requires_grad_() for k in names}
+    sd2 = dict(sd); sd2.update(hp)
+    for k in list(sd2):
+        if "cross_attn_1." in k:
+            sd2[k] = sd2[k.replace("cross_attn_1.", "cross_attn_n.")]
+    bufs = {}
+    keep_all = torch.full((B * a["N"], 512), 0.5)               # the fixture ran the head's Dropout(0.5) at p = 0: keep * 2 == 1
+    y = O.partseg_forward(sd2, pts, start, cls, arch, lidx, True, O.Masks("off"), bufs, head_mask=keep_all)
+    _close(y[:, :64], g["train_logits"], 5e-4, 5e-4)
+    loss = torch.nn.functional.cross_entropy(y.reshape(-1, 50), target.reshape(-1), label_smoothing=0.2)
+    np.testing.assert_allclose(loss.item(), g["ce_loss"][0], rtol=1e-5)
+    (y * Hh.synth_like(720, y.shape)).sum().backward()
+    norms = np.array([hp[k].grad.double().norm().item() if hp[k].grad is not None else 0.0 for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-3, atol=1e-4 * float(g["grad_norms"].max()))
+    for k in ("bn1.running_mean", "bn1.running_var", "propagation.mlp_bns.1.running_var", "label_conv.1.running_var"):
+        _close(bufs[k], g["buf." + k], 1e-4, 1e-5)
+    # the 3-NN stage: indices and weight BITS
+    nb, ct, _ = O.divide_patches(pts, O.fps_indices(pts, start, arch.G), arch.K)
+    idx, w = O.three_nn(pts, ct)
+    assert bool(g["nn_tie_free"])
+    assert np.array_equal(idx.numpy(), g["nn_idx"])
+    assert np.array_equal(w.numpy().view(np.uint32), g["nn_weight_bits"])
+
+
+def test_augmentation_trans1_vs_reference():
+    """oracle/augment.py trans_1 vs the reference's data_utils.py classes under the same numpy / torch seeds
+    (datasets/data.py:16-25; fixture: make_golden.py make_augment).  Exact: same operations, same RNG draws."""
+    from oracle import augment as A
+    g = Hh.golden("augment_trans1.npz")
+    for case in range(3):
+        seed, n = (int(v) for v in g[f"meta{case}"])
+        cloud = (np.random.default_rng(seed).random((n, 3)) * 2.0 - 1.0).astype(np.float32) * np.array([1.0, 0.5, 2.0], np.float32) + 0.3
+        np.random.seed(seed); torch.manual_seed(seed)
+        out = A.trans_1(cloud.copy())
+        assert np.array_equal(out.numpy(), g[f"out{case}"]), case
+    img = (np.random.default_rng(1).random((137, 137, 3)) * 255).astype(np.uint8)
+    np.random.seed(3)
+    y = A.image_transform(img, 224)
+    assert y.shape == (3, 224, 224) and y.dtype == np.float32 and np.isfinite(y).all()

@@ -1,0 +1,215 @@
+"""GPU parity of CrossFormer_partseg + PointNetFeaturePropagation (BASELINE config 5 = the c3 architecture) against the
+reference fixtures (tests/golden/partseg_*.npz, make_golden.py make_partseg) and the oracle:
+  * 3-NN indices and inverse-distance weights: BIT-exact (integer / IEEE work);
+  * logits eval / train: rel-L2 <= 2e-2 / 4e-2 (bf16 MFMA operands through the whole network + five BatchNorms over B*N rows);
+  * label-smoothed cross entropy value, gradient norms per parameter, BatchNorm running statistics;
+  * the head's Dropout(0.5) with the kernels' own mask handed to the oracle;
+  * the ft_partseg.py:145-176 step (strict=False load of a pre-training checkpoint, CE(label_smoothing=0.2), clip_grad_norm_(10),
+    torch optimizer) trains.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+from tests.test_modules_gpu import Checks, cosine, forced_start, rel, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(name):
+    a = Hh.ARCHS[name]
+    B = Hh.MODEL_BATCH[name]
+    pts = Hh.synth_points(320, B, a["N"]); start = Hh.synth_start(320, B, a["N"])
+    cls = torch.zeros(B, 16)
+    cls[torch.arange(B), torch.arange(B) % 16] = 1.0
+    target = torch.from_numpy((np.random.default_rng(321).random((B, a["N"])) * 50).astype(np.int64))
+    return a, B, pts, start, cls, target
+
+
+def _build(name, drops=(0.0, 0.0)):
+    from vipformer_amd.model.pointcloud import CrossFormer_partseg, PointCloudInputAdapter
+    a = Hh.ARCHS[name]
+    ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+    m = CrossFormer_partseg(ad, a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, drops[0], drops[1], Hh.PARTSEG_LAYERS[name], 50)
+    m.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_partseg_{name}.json"), 100))
+    return m.cuda()
+
+
+@pytest.mark.parametrize("name", ["tinyseg", "c3"])
+def test_three_nn_bit_exact_vs_reference(name):
+    from vipformer_amd import _lib as L
+    from vipformer_amd.model.pointcloud import utils as U
+    a, B, pts, start, cls, target = _inputs(name)
+    g = Hh.golden(f"partseg_{name}.npz")
+    assert bool(g["nn_tie_free"])
+    with forced_start(start.cuda()):
+        _, ct = U.divide_patches(pts.cuda(), a["G"], a["K"])
+    idx = torch.empty(B * a["N"] * 3, dtype=torch.int32, device="cuda")
+    w = torch.empty(B * a["N"] * 3, dtype=torch.float32, device="cuda")
+    L.call("vpf_three_nn_f32", pts.cuda(), B, a["N"], 3, ct.contiguous(), 3, a["G"], idx, w)
+    assert np.array_equal(idx.view(B, a["N"], 3).cpu().numpy().astype(np.int64), g["nn_idx"])
+    assert np.array_equal(w.view(B, a["N"], 3).cpu().numpy().view(np.uint32), g["nn_weight_bits"])
+
+
+@pytest.mark.parametrize("name", ["tinyseg", "c3"])
+def test_partseg_vs_reference_golden(name):
+    from vipformer_amd import ops_seg as S
+    a, B, pts, start, cls, target = _inputs(name)
+    g = Hh.golden(f"partseg_{name}.npz")
+    ck = Checks(f"partseg[{name}]")
+    m = _build(name)
+    m.eval()
+    with torch.no_grad(), forced_start(start.cuda()):
+        y = m(pts.cuda(), cls.cuda())
+    assert tuple(y.shape) == (B, a["N"], 50)
+    ck.lt("eval logits rel", rel(y[:, :64], g["eval_logits"]), 2e-2)
+    m.train(); m.zero_grad()
+    m.dp1.p = 0.0                                              # as the fixture (the dropout test below runs it at 0.5)
+    with forced_start(start.cuda()):
+        y = m(pts.cuda(), cls.cuda())
+    ck.lt("train logits rel", rel(y[:, :64], g["train_logits"]), 4e-2)
+    loss = S.cross_entropy_smooth(y, target.cuda(), 0.2)
+    ref_loss = torch.nn.functional.cross_entropy(y.detach().reshape(-1, 50), target.cuda().reshape(-1), label_smoothing=0.2)
+    ck.lt("CE(label_smoothing 0.2) kernel vs torch on the same logits", abs(loss.item() - ref_loss.item()), 1e-5)
+    ck.lt("CE loss abs diff vs reference", abs(loss.item() - float(g["ce_loss"][0])), 5e-3)
+    # d CE / d logits of the kernel vs autograd of torch's CE
+    yl = y.detach().clone().requires_grad_()
+    torch.nn.functional.cross_entropy(yl.reshape(-1, 50), target.cuda().reshape(-1), label_smoothing=0.2).backward()
+    yk = y.detach().clone().requires_grad_()
+    S.cross_entropy_smooth(yk, target.cuda(), 0.2).backward()
+    ck.lt("CE gradient rel vs torch", rel(yk.grad, yl.grad), 1e-5)
+    (y * Hh.synth_like(720, y.shape).cuda()).sum().backward()
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_partseg_{name}.json")))
+    params = dict(m.named_parameters())
+    norms = np.array([params[k].grad.double().norm().item() if params[k].grad is not None else 0.0 for k in names])
+    refn = g["grad_norms"]
+    zero_before_bn = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias", "conv1.bias", "conv2.bias",
+                      "propagation.mlp_convs.0.bias", "propagation.mlp_convs.1.bias")
+    # tensors that carry >= 3 % of the largest gradient norm: within 8 %.  The small ones (1e-3 .. 3e-2 of the largest: e.g. the q / k
+    # projections of the last tapped layer, whose softmax gradient P * (dP - delta) is a difference of nearly equal numbers) carry the
+    # bf16 rounding of P / dO / O as noise of their own size; the bf16-emulating oracle reproduces them to cosine > 0.98 (next test).
+    for lo, hi, bound, tag in ((3e-2, 2.0, 0.08, "large"), (1e-3, 3e-2, 0.30, "small")):
+        sel = np.array([(lo * refn.max() < refn[i] <= hi * refn.max()) and (k not in zero_before_bn) for i, k in enumerate(names)])
+        ratio = norms[sel] / refn[sel]
+        worst = sorted(zip(np.abs(ratio - 1), np.array(names)[sel]))[-3:]
+        report(f"partseg[{name}] grad-norm ratio ({tag} tensors) min {ratio.min():.3f} max {ratio.max():.3f} worst {worst}")
+        ck.lt(f"grad-norm ratio max dev ({tag} tensors)", float(np.abs(ratio - 1).max()), bound)
+    for k in ("bn1.running_mean", "bn1.running_var", "propagation.mlp_bns.1.running_var", "label_conv.1.running_var"):
+        ck.lt(f"buffer {k} rel", rel(m.state_dict()[k], g["buf." + k]), 3e-2)
+    ck.done()
+
+
+@pytest.mark.parametrize("name", ["tinyseg", "c3"])
+def test_partseg_training_step_with_dropout_vs_oracle(name):
+    """Train mode, encoder dropouts 0.1 / 0.5 and the head's Dropout(0.5), every keep mask exported from the kernels and handed to
+    the oracle: logits and every parameter gradient against the bf16-emulating oracle (kernel logic) and the fp32 oracle."""
+    from oracle import torch_oracle as O
+    from vipformer_amd import ops
+    from tests.test_modules_gpu import _site_masks
+    a, B, pts, start, cls, target = _inputs(name)
+    lidx = Hh.PARTSEG_LAYERS[name]
+    ck = Checks(f"partseg-dropout[{name}]")
+    ops.rng.seed(777)
+    with ops.rng.pinned():
+        m = _build(name, (0.1, 0.5))
+        m.train(); m.zero_grad()
+        with forced_start(start.cuda()):
+            y = m(pts.cuda(), cls.cuda())
+        R = Hh.synth_like(720, y.shape)
+        (y * R.cuda()).sum().backward()
+        masks = O.Masks("given", _site_masks(m, (B, a["G"]), a["N"], a, "cuda"))
+        head_mask = ops.dropout_keep_mask(m.dp1.site, 0.5, (B * a["N"], 512), "cuda").float().cpu()
+    sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_partseg_{name}.json"), 100)
+    isparam = lambda k, v: v.dtype == torch.float32 and "running" not in k and "cross_attn_1." not in k
+    hp = {k: v.clone().requires_grad_() for k, v in sd.items() if isparam(k, v)}
+    s2 = dict(sd); s2.update(hp)
+    for k in list(s2):
+        if "cross_attn_1." in k:
+            s2[k] = s2[k.replace("cross_attn_1.", "cross_attn_n.")]
+    arch = O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"], atten_drop=0.1, mlp_drop=0.5)
+    with torch.no_grad():
+        yr = O.partseg_forward(s2, pts, start, cls, arch, lidx, True, masks, {}, head_mask=head_mask)
+    ck.lt("logits rel (fp32 oracle)", rel(y, yr), 4e-2)
+    with O.emulate_bf16():
+        ye = O.partseg_forward(s2, pts, start, cls, arch, lidx, True, masks, {}, head_mask=head_mask)
+    # (dropout p = 0.5 in every encoder layer and in the head scales activations by 2 ahead of five training-mode BatchNorms: the
+    #  dropout-free comparison above sits at 5e-3, this one at ~1.1e-2)
+    ck.lt("[emulated] logits rel", rel(y, ye), 2e-2)
+    (ye * R).sum().backward()
+    cosines = []
+    zero_before_bn = ("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias", "conv1.bias", "conv2.bias", "mlp_convs.0.bias",
+                      "mlp_convs.1.bias")
+    for k, p in m.named_parameters():
+        r = hp[k].grad
+        if r is None or p.grad is None or k.endswith(zero_before_bn) or float(r.norm()) < 1e-7:
+            continue
+        cosines.append((cosine(p.grad, r), k, float(r.norm())))
+    top = max(c[2] for c in cosines)
+    cosines = sorted(c for c in cosines if c[2] > 1e-5 * top)      # (norm.bias: shifts every channel ahead of BatchNorms -- |grad| ~ 1e-6 of the rest)
+    for cc, k, nr in cosines[:5]:
+        report(f"partseg-dropout[{name}] lowest grad cosine {cc:.5f} {k} |ref| {nr:.2e}")
+    head = [c for c in cosines if c[1].startswith(("conv", "bn", "propagation", "label_conv", "norm"))]
+    ck.gt("[emulated] lowest head-parameter gradient cosine", min(head)[0], 0.98)
+    ck.gt("[emulated] median per-tensor gradient cosine", float(np.median([c[0] for c in cosines])), 0.985)
+    ck.gt("[emulated] lowest per-tensor gradient cosine", cosines[0][0], 0.95)
+    ck.done()
+
+
+def test_feature_propagation_module_vs_oracle():
+    """PointNetFeaturePropagation on its own with the reference's [B,C,N] layouts (utils.py:205-242), with and without points1."""
+    from oracle import torch_oracle as O
+    from vipformer_amd.model.pointcloud.utils import PointNetFeaturePropagation
+    B, N, S, Fd = 3, 500, 40, 64
+    xyz1 = Hh.synth_points(1, B, N); xyz2 = Hh.synth_points(2, B, S)
+    feat = Hh.synth_like(3, (B, S, Fd))
+    for with_p1 in (True, False):
+        torch.manual_seed(0)
+        fp = PointNetFeaturePropagation(Fd + (3 if with_p1 else 0), [128, 64]).cuda()
+        sd = {"p." + k: v.detach().cpu().clone() for k, v in fp.state_dict().items()}
+        fp.train()
+        f = feat.cuda().requires_grad_()
+        y = fp(xyz1.cuda().permute(0, 2, 1), xyz2.cuda().permute(0, 2, 1), xyz1.cuda().permute(0, 2, 1) if with_p1 else None, f.permute(0, 2, 1))
+        assert tuple(y.shape) == (B, 64, N)
+        R = Hh.synth_like(4, (B, N, 64))
+        (y.permute(0, 2, 1) * R.cuda()).sum().backward()
+        fr = feat.clone().requires_grad_()
+        with O.emulate_bf16():
+            yr = O.feature_propagation(sd, "p.", xyz1, xyz2, xyz1 if with_p1 else None, fr, True, {})
+        (yr * R).sum().backward()
+        assert rel(y.permute(0, 2, 1), yr) < 1e-2, rel(y.permute(0, 2, 1), yr)
+        assert cosine(f.grad, fr.grad) > 0.999, cosine(f.grad, fr.grad)
+
+
+def test_ft_partseg_step_trains_from_a_pretraining_checkpoint():
+    """ft_partseg.py:80-83 + :145-176: strict=False load of a hot-path checkpoint, then the loop body -- forward(points, onehot),
+    CrossEntropyLoss(label_smoothing=0.2), backward, clip_grad_norm_(10), optimizer.step -- with a torch optimizer."""
+    from vipformer_amd import ops_seg as S
+    name = "tinyseg"
+    a, B, pts, start, cls, target = _inputs(name)
+    m = _build(name, (0.1, 0.5))
+    pre = {k: v for k, v in Hh.synth_state_dict(Hh.load_keyshapes(f"keys_partseg_{name}.json"), 5).items()
+           if k.startswith(("encoder.", "group2emb.", "position_emb.", "input_adapter."))}
+    pre["latent_head.0.weight"] = torch.zeros(128)             # what a pc_model_best.pth has and this model has not
+    res = m.load_state_dict(pre, strict=False)
+    assert res.unexpected_keys == ["latent_head.0.weight"] and any(k.startswith("conv1.") for k in res.missing_keys)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=0.05)
+    # a learnable target: the part label is a function of the point's position
+    tgt = ((pts[:, :, 0] > 0).long() + 2 * (pts[:, :, 1] > 0).long()).cuda()
+    losses = []
+    for it in range(30):
+        opt.zero_grad(set_to_none=True)
+        with forced_start(start.cuda()):
+            pred = m(pts.cuda(), cls.cuda())
+        loss = S.cross_entropy_smooth(pred.reshape(-1, 50), tgt.reshape(-1), 0.2)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 10, norm_type=2)
+        assert torch.isfinite(gn)
+        opt.step()
+        losses.append(loss.item())
+    report(f"ft_partseg losses first {losses[0]:.4f} last {losses[-1]:.4f}")
+    assert losses[-1] < 0.75 * losses[0], losses

@@ -104,6 +104,27 @@ def sa():
     ops.SA_SPLIT_ATTN[0] = None
 
 
+def satail():
+    """the fused encoder-layer tail exactly as bench.py's kernel leg launches it (pc shape: 12288 tokens)"""
+    import torch.nn as nn
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    B, G, D, H = 128, 96, 256, 4
+    M = B * G
+    layers = nn.ModuleList([SelfAttentionLayer(H, D, 2, 0.0, 0.1, 0.5) for _ in range(2)]).cuda()
+    layers.train()
+    blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
+    packed = ops._pack_blocks(blocks, layers[0], "cuda")
+    st = ops.rng.state("cuda")
+    base = torch.randn(M, D, device="cuda"); pos = torch.randn(M, D, device="cuda")
+    o = torch.randn(M, D, device="cuda").to(torch.bfloat16)
+    lse = torch.zeros(B * H * G, device="cuda")
+    att, mlp = layers[0][0].module.attention, layers[0][1].module
+    nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
+    t = timeit(lambda: ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, M, "cuda"), 20, 3)
+    print(f"sa_layer_fwd tail (12288 tokens): {t:.1f} us")
+
+
 def wgroup():
     """the grouped weight-gradient launch of one encoder layer (4 problems, M = 12288 tokens)"""
     from vipformer_amd import ops

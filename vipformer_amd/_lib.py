@@ -122,7 +122,7 @@ SIGS = {
     "vpf_pack_wfrag": [VP, I, VP],
     "vpf_sa_layer_fwd": [VP, VP],
     "vpf_abi_sizeof": [I],
-    "vpf_wgrad_group": [VP, I, VP],
+    "vpf_wgrad_group": [VP, I, VP, L_, VP],
     "vpf_sa_layer_bwd_mlp": [VP, VP],
     "vpf_sa_layer_bwd_qkv": [VP, VP],
     "vpf_ln_pgrad_reduce": [VP, I, VP],
@@ -135,6 +135,8 @@ SIGS = {
     "vpf_interp_rows_bwd": [VP, I, I, I, I, I, VP, VP, I, VP, VP],
     "vpf_pad_bf16": [VP, I, L_, I, L_, L_, I, VP, VP],
     "vpf_ce_smooth": [VP, L_, VP, L_, I, F, VP, VP, VP, L_, VP],
+    "vpf_augment_points": [VP, I, I, I, VP, U32, VP, VP, VP],
+    "vpf_image_u8_normalize": [VP, I, I, I, VP, VP, VP, U32, F, VP, VP, VP],
 }
 
 

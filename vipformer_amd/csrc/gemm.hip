@@ -22,6 +22,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #ifndef LDS_PAD_TR
 #define LDS_PAD_TR 8
@@ -37,6 +38,7 @@ enum {
     EPI_RELU = 5,        // C = relu(acc + bias)
     EPI_GROUPBIAS = 6,   // C = acc + gbias[(m / group) * N + n]   (f32 row-group bias), bf16/f32 out
     EPI_GROUPMAX = 7,    // C(f32)[m / group, n] = max over the group's rows of bf16(acc + bias); C2(u8) = first arg-max
+    EPI_PARTIAL = 8,     // split-K without atomics: partial tiles to a workspace, the last-arriving slice of a tile adds them up (grouped wgrad)
 };
 
 // Operand prologue: what a 16-byte chunk (8 values along the operand's contiguous dimension = channel axis) becomes
@@ -66,6 +68,7 @@ struct GemmArgs {
     const uint32_t* rng; uint32_t site; float p;   // dropout
     float* dbias;                                   // EPI_ATOMIC with a k-strided A: dbias[m] += sum_k A(m,k)
     int uneven;                                     // split-K slices of alternating length (4/3, 2/3 of the mean): see vpf_wgrad_group
+    float* part; int* cnt; int ntx;                 // EPI_PARTIAL: partial tiles [tile][slice][BM*BN] (accumulator order), arrival counters [tile], tiles per row
     OpXform xa, xb;                                 // operand prologues (kind 0 = none)
 };
 
@@ -211,7 +214,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             const int base = (bz >> 1) * 2 * per, cut = base + (((6 + g.uneven) * per) / 6 + BK - 1) / BK * BK;      // uneven = 2: 4/3 and 2/3
             if (bz & 1) { kbeg = cut; kend = min(g.K, base + 2 * per); } else { kbeg = base; kend = min(g.K, cut); }
         }
-        if (kbeg >= kend) return;
+        if (kbeg >= kend) {
+            if (g.mode != EPI_PARTIAL) return;
+            kend = kbeg;                            // an empty slice still takes part in the arrival count (with a zero tile)
+        }
     } else {
         A += (size_t)bz * g.sAb; B += (size_t)bz * g.sBb; cb = (long)bz * g.sCb;
     }
@@ -289,6 +295,73 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     if (ATR && do_bias) {
         const int c = threadIdx.x % BM;
         if (threadIdx.x / BM < (256 / BM > 0 ? 256 / BM : 1) && m0 + c < g.M) atomicAdd(g.dbias + m0 + c, bsum);
+    }
+    if (g.mode == EPI_PARTIAL) {
+        // Split-K without atomics (OPTIONAL: the caller hands over a workspace; measured SLOWER than the atomics on MI355X, see
+        // DESIGN.md section 4 -- kept because it is deterministic: dW no longer depends on the order in which atomics land).
+        // Every slice parks its 64 KB accumulator tile in the workspace with 16-byte stores IN ACCUMULATOR ORDER (lane-contiguous: one
+        // wave instruction = 1 KB, no LDS staging, and the reader owns the same positions), takes a ticket, and the slice that
+        // arrives last adds the others' tiles to its registers in slice order and updates dW with ordinary loads and stores -- it
+        // is the only writer of that tile.
+        const int tile = by * g.ntx + bx;
+        // Hand-off without cache maintenance: an agent-scope release / acquire pair would write back and INVALIDATE the XCD's L2 for
+        // every workgroup (measured: 2.4x slower, the operand reuse of the slices still running is gone).  Instead every store of the
+        // partial tile is an sc1 (device-coherent, write-through) store, drained (s_waitcnt) before the workgroup's barrier and the
+        // ticket, and every load of another slice's tile is an sc1 load -- MI355X_MICROARCH.md, "Inter-workgroup visibility".
+        float* P = g.part + ((size_t)tile * g.splitk + bz) * (size_t)(BM * BN);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                    float* dst = P + ((size_t)(((wave * TM + i) * TN + j) * 4 + q) * 64 + lane) * 4;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tile has left for the coherence point before the ticket is taken
+        int* flag = reinterpret_cast<int*>(lds);
+        __syncthreads();
+        if (threadIdx.x == 0) *flag = (atomicAdd(g.cnt + tile, 1) == g.splitk - 1);
+        __syncthreads();
+        if (!*flag) return;
+        for (int z = 0; z < g.splitk; ++z) {
+            if (z == bz) continue;
+            const float* Q = g.part + ((size_t)tile * g.splitk + z) * (size_t)(BM * BN);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x4_t v0, v1, v2, v3;
+                    const float* src = Q + ((size_t)(((wave * TM + i) * TN + j) * 4) * 64 + lane) * 4;
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                                 "global_load_dwordx4 %1, %4, off offset:1024 sc1\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:2048 sc1\n\t"
+                                 "global_load_dwordx4 %3, %4, off offset:3072 sc1\n\t"
+                                 "s_waitcnt vmcnt(0)"
+                                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(src) : "memory");
+                    acc[i][j][0] += v0.x; acc[i][j][1] += v0.y; acc[i][j][2] += v0.z; acc[i][j][3] += v0.w;
+                    acc[i][j][4] += v1.x; acc[i][j][5] += v1.y; acc[i][j][6] += v1.z; acc[i][j][7] += v1.w;
+                    acc[i][j][8] += v2.x; acc[i][j][9] += v2.y; acc[i][j][10] += v2.z; acc[i][j][11] += v2.w;
+                    acc[i][j][12] += v3.x; acc[i][j][13] += v3.y; acc[i][j][14] += v3.z; acc[i][j][15] += v3.w;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 32 + col_l;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rsub;
+                    if (n < g.N && m < g.M) {
+                        float* o = reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n;
+                        *o += acc[i][j][r];                // dW += : the gradient buffer may already hold other contributions
+                    }
+                }
+            }
+        if (threadIdx.x == 0) g.cnt[tile] = 0;            // ready for the next launch (ordered by the kernel boundary)
+        return;
     }
     if (g.mode == EPI_ATOMIC) {
         // split-K partial sums: fp32 atomics straight from the accumulators (128-byte row segments)
@@ -596,7 +669,8 @@ extern "C" int vpf_gemm_bf16_fused(const void* A, int a_kstrided, long lda, int 
 
 
 // dW_i[N_i,K_i] += dY_i[M_i,N_i]^T . X_i[M_i,K_i]  (+ dbias_i[N_i] += column sums of dY_i) for up to 8 problems in one launch
-extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
+#define WGROUP_CNT_INTS 1024        // arrival counters at the head of the workspace (zeroed ONCE by the caller; the kernel re-zeroes what it used)
+extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, long ws_bytes, void* stream)
 {
     (void)hipGetLastError();
     if (!jobs) return VPF_ERR_NULL;
@@ -605,6 +679,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
     grp.n = njobs;
     static int cfg = -1, target = 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     if (cfg < 0) { const char* e = getenv("VPF_WGROUP_CFG"); cfg = e ? atoi(e) : 2; const char* t = getenv("VPF_WGROUP_WGS"); if (t) target = atoi(t); }
+    const int partial = ws != nullptr;
     const int tm = cfg == 0 ? 64 : 128, tn = (cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64);
     long total_tiles = 0;
     for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
@@ -634,6 +709,16 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* stream)
     }
     grp.start[njobs] = at;
     hipStream_t st = (hipStream_t)stream;
+    // workspace split-K (EPI_PARTIAL) when the caller handed over enough scratch: [counters | one tm x tn f32 tile per workgroup]
+    if (partial && ws && total_tiles <= WGROUP_CNT_INTS && ws_bytes >= (long)(WGROUP_CNT_INTS * 4 + (size_t)at * tm * tn * 4) && !((uintptr_t)ws & 15)) {
+        float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + WGROUP_CNT_INTS * 4);
+        int* cnt = reinterpret_cast<int*>(ws);
+        for (int i = 0; i < njobs; ++i) {
+            GemmArgs& g = grp.g[i];
+            g.mode = EPI_PARTIAL; g.part = part + (size_t)grp.start[i] * tm * tn; g.cnt = cnt; g.ntx = grp.nx[i];
+            cnt += grp.nx[i] * grp.ny[i];
+        }
+    }
     if (cfg == 7) return launch_wgrad_group<2, 2, 2, 2, 64, 3>(grp, at, st);  // 3 stages of loads in flight
     if (cfg == 6) return launch_wgrad_group<2, 2, 2, 2, 64, 2>(grp, at, st);  // 2 stages of loads in flight
     if (cfg == 5) return launch_wgrad_group<2, 2, 2, 2, 32>(grp, at, st);     // 128x128, shallow stages: 4 workgroups per CU

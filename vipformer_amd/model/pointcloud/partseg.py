@@ -245,7 +245,7 @@ class Encoder(nn.Module):
         self.modal_prior = modal_prior
 
     def fused_ok(self, group_embs, pts_embs, layer_idx=(), pad_mask=None):
-        return (self.num_cross_attention_layers == 1 and not layer_idx and pad_mask is None
+        return (self.num_cross_attention_layers == 1 and pad_mask is None
                 and ops.encoder_fused_supported(self.cross_attn_1, self.sa_layers, group_embs, pts_embs))
 
     def forward(self, group_embs, pos_embs, pts_embs, layer_idx=[], pad_mask=None, kv_ready=False):
@@ -256,8 +256,10 @@ class Encoder(nn.Module):
             # fused row-block kernels for the cross-attention layer's tail and every self-attention layer
             mods = [self.cross_attn_1] + list(self.sa_layers)
             params = [p for m in mods for p in m.parameters()]
-            x = ops.EncoderFusedFn.apply(group_embs, pos_embs, pts_embs, self.cross_attn_1, self.sa_layers, self.training, kv_ready, *params)
-            return x if self.modal_prior else feats
+            taps = tuple(sorted({int(i) for i in layer_idx if 1 <= int(i) <= len(self.sa_layers)}))      # partseg.py:336: i+1 in layer_idx
+            outs = ops.EncoderFusedFn.apply(group_embs, pos_embs, pts_embs, self.cross_attn_1, self.sa_layers, self.training, kv_ready,
+                                            taps, *params)
+            return outs[0] if self.modal_prior else list(outs[1:])
         if kv_ready:
             raise L.VpfError("kv_ready needs the fused encoder path")
         x = self.cross_attn_1(group_embs, pts_embs, pad_mask, pos=pos_embs)
@@ -301,27 +303,16 @@ def _encoder(D, n_ca, h_ca, n_sa, h_sa, mr, max_dpr, atten_drop, mlp_drop, modal
                    modal_prior=modal_prior)
 
 
-class CrossFormer_pc_mp(nn.Module):
-    """partseg.py:473-550: point-cloud branch of --mp pre-training.
-    forward(pts [B,N,3]) -> (feats [B,D], backbone [B,2D])."""
-
-    def __init__(self, input_adapter=None, num_latents=128, num_latent_channels=384, group_size=32,
-                 num_cross_attention_layers=1, num_cross_attention_heads=6, num_self_attention_layers=6,
-                 num_self_attention_heads=6, mlp_widen_factor=4, max_dpr=.0, atten_drop=0.1, mlp_drop=.5, modal_prior=True):
-        super().__init__()
-        self.num_groups = num_latents
-        self.group_size = group_size
-        self.group2emb = Group2Emb(num_latent_channels)
-        self.position_emb = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, num_latent_channels))
-        self.input_adapter = input_adapter
-        self.encoder = _encoder(num_latent_channels, num_cross_attention_layers, num_cross_attention_heads,
-                                num_self_attention_layers, num_self_attention_heads, mlp_widen_factor, max_dpr, atten_drop,
-                                mlp_drop, modal_prior)
-        self.latent_head = _latent_head(num_latent_channels)
-        ops.assign_sites(self, "pc")          # dropout sites by module name: independent of what else the process built
+class _PointBackbone(nn.Module):
+    """What CrossFormer_pc_mp, CrossFormer_pc_mp_ft and CrossFormer_partseg share (partseg.py:407-425, 527-545): per-point adapter,
+    divide_patches, Group2Emb, position MLP, Encoder.  Sub-classes create the members under the reference's names."""
 
     def backbone(self, pts, _groups=None):
-        """_groups (an extension the trainer uses, not part of the reference signature): (neighborhood, center, event) computed by
+        return ops.PoolFn.apply(self._encode(pts, (), _groups)[0])
+
+    def _encode(self, pts, layer_idx=(), _groups=None):
+        """Everything up to and including the encoder (partseg.py:527-545 / :407-425) -> (encoder output, group centres).
+        _groups (an extension the trainer uses, not part of the reference signature): (neighborhood, center, event) computed by
         divide_patches on ANOTHER stream; the K / V producer -- which needs only the raw points -- is then issued first and this
         stream waits for the event only in front of Group2Emb, so FPS / kNN (latency-bound, a few workgroups) run beside it."""
         enc = self.encoder
@@ -344,8 +335,7 @@ class CrossFormer_pc_mp(nn.Module):
         group_embs = self.group2emb(neighborhood)
         pos_embs = ops.PosMLPFn.apply(center, self.position_emb, *self.position_emb.parameters())
         if kv is not None:
-            x = enc(group_embs, pos_embs, kv, kv_ready=True)
-            return ops.PoolFn.apply(x)
+            return enc(group_embs, pos_embs, kv, layer_idx, kv_ready=True), center
         if fuse_kv:
             cross = enc.cross_attn_1[0].module
             probe = group_embs.new_empty((group_embs.shape[0], 1, 2 * group_embs.shape[2]))       # shape probe only
@@ -353,11 +343,29 @@ class CrossFormer_pc_mp(nn.Module):
                 # adapter -> kv LayerNorm -> K / V projection in one kernel: the per-point embedding is never read back
                 params = list(self.input_adapter.parameters()) + list(cross.kv_norm.parameters()) + [cross.attention.k_proj.weight, cross.attention.v_proj.weight]
                 kv = ops.AdapterKVFn.apply(pts, self.input_adapter, cross, *params)
-                x = enc(group_embs, pos_embs, kv, kv_ready=True)
-                return ops.PoolFn.apply(x)
+                return enc(group_embs, pos_embs, kv, layer_idx, kv_ready=True), center
             pts_embs = self.input_adapter(pts)
-        x = enc(group_embs, pos_embs, pts_embs)
-        return ops.PoolFn.apply(x)
+        return enc(group_embs, pos_embs, pts_embs, layer_idx), center
+
+
+class CrossFormer_pc_mp(_PointBackbone):
+    """partseg.py:473-550: point-cloud branch of --mp pre-training.
+    forward(pts [B,N,3]) -> (feats [B,D], backbone [B,2D])."""
+
+    def __init__(self, input_adapter=None, num_latents=128, num_latent_channels=384, group_size=32,
+                 num_cross_attention_layers=1, num_cross_attention_heads=6, num_self_attention_layers=6,
+                 num_self_attention_heads=6, mlp_widen_factor=4, max_dpr=.0, atten_drop=0.1, mlp_drop=.5, modal_prior=True):
+        super().__init__()
+        self.num_groups = num_latents
+        self.group_size = group_size
+        self.group2emb = Group2Emb(num_latent_channels)
+        self.position_emb = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, num_latent_channels))
+        self.input_adapter = input_adapter
+        self.encoder = _encoder(num_latent_channels, num_cross_attention_layers, num_cross_attention_heads,
+                                num_self_attention_layers, num_self_attention_heads, mlp_widen_factor, max_dpr, atten_drop,
+                                mlp_drop, modal_prior)
+        self.latent_head = _latent_head(num_latent_channels)
+        ops.assign_sites(self, "pc")          # dropout sites by module name: independent of what else the process built
 
     def forward(self, pts, _groups=None):
         backbone_feats = self.backbone(pts, _groups)
@@ -388,6 +396,62 @@ class CrossFormer_pc_mp_ft(CrossFormer_pc_mp):
         for i in (0, 3, 6):
             h = ops.BnReluLinearFn.apply(h, head[i], head[i + 2], self.training, *head[i].parameters(), *head[i + 2].parameters())
         return h
+
+
+class CrossFormer_partseg(_PointBackbone):
+    """partseg.py:345-470: ShapeNetPart part segmentation = the pre-training backbone with taps at the self-attention layers
+    ``layer_idx`` (1-based) + LayerNorm + global max / mean + object-label branch + PointNetFeaturePropagation + a three-layer
+    per-point head.  forward(pts [B,N,3], cls_label [B,16]) -> logits [B,N,num_part_classes].
+
+    Same member names as the reference, so a hot-path ``pc_model_best.pth`` loads with strict=False exactly like
+    ft_partseg.py:80-83 does it (the 12 ``latent_head.*`` keys are unexpected, the head's keys missing)."""
+
+    def __init__(self, input_adapter=None, num_latents=128, num_latent_channels=384, group_size=32,
+                 num_cross_attention_layers=1, num_cross_attention_heads=6, num_self_attention_layers=12,
+                 num_self_attention_heads=6, mlp_widen_factor=4, max_dpr=0.1, atten_drop=.0, mlp_drop=.0, layer_idx=[],
+                 num_part_classes=50):
+        super().__init__()
+        from .utils import PointNetFeaturePropagation
+        D = num_latent_channels
+        self.num_groups = num_latents
+        self.group_size = group_size
+        self.group2emb = Group2Emb(D)
+        self.position_emb = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D))
+        self.input_adapter = input_adapter
+        self.encoder = _encoder(D, num_cross_attention_layers, num_cross_attention_heads, num_self_attention_layers,
+                                num_self_attention_heads, mlp_widen_factor, max_dpr, atten_drop, mlp_drop, False)
+        self.layer_idx = layer_idx
+        self.norm = nn.LayerNorm(D)
+        self.label_conv = nn.Sequential(nn.Conv1d(16, 64, kernel_size=1, bias=False), nn.BatchNorm1d(64), nn.LeakyReLU(0.2))
+        self.num_layer_idx = len(layer_idx)
+        self.propagation = PointNetFeaturePropagation(in_channel=self.num_layer_idx * D + 3, mlp=[mlp_widen_factor * D, 1024])
+        self.conv1 = nn.Conv1d(2 * self.num_layer_idx * D + 64 + 1024, 512, 1)
+        self.bn1 = nn.BatchNorm1d(512)
+        self.dp1 = nn.Dropout(0.5)
+        self.dp1.site = ops.new_site()
+        self.conv2 = nn.Conv1d(512, 256, 1)
+        self.bn2 = nn.BatchNorm1d(256)
+        self.conv3 = nn.Conv1d(256, num_part_classes, 1)
+        self.relu = nn.ReLU()
+        ops.assign_sites(self, "pcseg")
+
+    def forward(self, pts, cls_label):
+        from ... import ops_seg as S
+        if self.num_layer_idx not in (3, 4):
+            # partseg.py:430-435 only defines x for 3 or 4 taps (UnboundLocalError otherwise)
+            raise ValueError("layer_idx must hold 3 or 4 layer numbers")
+        feats, center = self._encode(pts, self.layer_idx)
+        if len(feats) != self.num_layer_idx:
+            raise ValueError(f"layer_idx {self.layer_idx} must be distinct values in 1..{len(self.encoder.sa_layers)}")
+        nl = len(feats)
+        xcat = S.LnTapsFn.apply(self.norm, nl, *feats, *self.norm.parameters())                     # [B,G,nl*D]
+        pooled = ops.PoolFn.apply(xcat)                                                             # [B, 2*nl*D] = [x_max | x_avg]
+        lf = S.LabelBranchFn.apply(cls_label, self.label_conv, self.training, *self.label_conv.parameters())
+        prop = self.propagation
+        f0 = S.FeaturePropFn.apply(pts, center, pts[:, :, :3], xcat, prop, self.training, *prop.parameters())
+        gvec = torch.cat([pooled, lf], dim=1)                                                       # conv1's per-cloud input channels
+        head = [self.conv1, self.bn1, self.conv2, self.bn2, self.conv3]
+        return S.SegConvFn.apply(f0, gvec, self, self.training, *[p for m in head for p in m.parameters()])
 
 
 class CrossFormer_img_mp(nn.Module):

@@ -132,3 +132,26 @@ class Sequential(nn.Sequential):
         for layer in self:
             x = layer(*x) if type(x) == tuple else layer(x)
         return x
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """utils.py:192-242 with the reference's layouts: xyz1 [B,C,N], xyz2 [B,C,S], points1 [B,D1,N] or None, points2 [B,D2,S]
+    -> [B,mlp[-1],N].  3-NN inverse-distance interpolation (a running 3-minimum instead of the full sort of :224) + concat +
+    (conv1d(k=1) + BatchNorm + ReLU) per entry of ``mlp``, through ops_seg.FeaturePropFn."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv1d(last_channel, out_channel, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(out_channel))
+            last_channel = out_channel
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        from ... import ops_seg as S
+        x1, x2 = xyz1.permute(0, 2, 1), xyz2.permute(0, 2, 1)
+        p1 = points1.permute(0, 2, 1) if points1 is not None else None
+        y = S.FeaturePropFn.apply(x1, x2, p1, points2.permute(0, 2, 1), self, self.training, *self.parameters())
+        return y.float().permute(0, 2, 1)

@@ -432,6 +432,26 @@ WGRAD_GROUP = [True]
 WGRAD_GROUP_ASYNC = [False]   # issue the grouped launches on a side stream (joined by join_wgrad_streams)
 
 
+WGRAD_WS_BYTES = 4096 + 1024 * 65536      # arrival counters + one 128 x 128 f32 partial tile for up to 1024 workgroups
+WGRAD_DETERMINISTIC = [False]             # grouped weight gradients through the split-K workspace instead of fp32 atomics (slower, bitwise reproducible)
+_wgrad_ws = {}
+
+
+def wgrad_workspace(device):
+    """The split-K scratch of vpf_wgrad_group, private to (device, current stream): two branches that run their grouped weight
+    gradients concurrently on two streams must not share partial tiles.  Counters zeroed once; the kernel leaves them zero.
+    None unless WGRAD_DETERMINISTIC: the library then adds the slices' tiles into dW with fp32 atomics."""
+    if not WGRAD_DETERMINISTIC[0]:
+        return None
+    key = (_Rng._index(device), torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None:
+        ws = torch.empty(WGRAD_WS_BYTES // 4, dtype=F32, device=f"cuda:{key[0]}")
+        ws[:1024].zero_()
+        _wgrad_ws[key] = ws
+    return ws
+
+
 class WgradBatch:
     """Collects linear_wgrad calls of one layer and issues them as ONE grouped launch (vpf_wgrad_group)."""
 
@@ -458,12 +478,14 @@ class WgradBatch:
             cur, side = _wgrad_side()
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                L.call_struct("vpf_wgrad_group", arr, len(self.jobs))
+                ws = wgrad_workspace(self.jobs[0][0].device)
+                L.call_struct("vpf_wgrad_group", arr, len(self.jobs), ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0)
             for dy, x, *_ in self.jobs:
                 dy.record_stream(side)
                 x.record_stream(side)
         else:
-            L.call_struct("vpf_wgrad_group", arr, len(self.jobs))
+            ws = wgrad_workspace(self.jobs[0][0].device)
+            L.call_struct("vpf_wgrad_group", arr, len(self.jobs), ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0)
         self.jobs = []
 
 
@@ -1052,10 +1074,13 @@ class EncoderFusedFn(torch.autograd.Function):
     cross-attention front (two LayerNorms, q and kv projections) and the attention kernels themselves are separate."""
 
     @staticmethod
-    def forward(ctx, x, pos, xkv, ca, layers, training, kv_ready, *params):
-        """kv_ready: ``xkv`` already holds the cross-attention K | V projections (bf16 [B, Lkv, 2D], AdapterKVFn)."""
+    def forward(ctx, x, pos, xkv, ca, layers, training, kv_ready, taps, *params):
+        """kv_ready: ``xkv`` already holds the cross-attention K | V projections (bf16 [B, Lkv, 2D], AdapterKVFn).
+        taps: ascending 1-based self-attention layer numbers whose output is returned as well (Encoder.forward's ``layer_idx``,
+        partseg.py:336-337).  Returns (x after the last layer, *tapped layer outputs)."""
         ctx.nparams, ctx.params = len(params), params
-        ctx.kv_ready = kv_ready
+        ctx.kv_ready, ctx.taps = kv_ready, tuple(taps)
+        ctx.set_materialize_grads(False)
         B, Lq, D = x.shape
         M, Hd, H = B * Lq, 512, 4
         dev = x.device
@@ -1091,6 +1116,7 @@ class EncoderFusedFn(torch.autograd.Function):
         nxt = (layers[0][0].module.norm, packed[1]["Wqkv"]) if nl else None
         saved_t, out, head = _tail_fwd(catt, cmlp, ca[0], ca[1], packed[0], training, st, B, Lq, q, base_ca, o, lse, nxt, pos_c, pos_rows, dev)
         flat = [base_ca, mq, rq, nq, xkv, mk, rk, nk, q, kv, o, lse] + list(saved_t)        # 18 tensors
+        tapped = []
         # ---- self-attention layers
         for i, layer in enumerate(layers):
             att, mlp = layer[0].module.attention, layer[1].module
@@ -1103,23 +1129,27 @@ class EncoderFusedFn(torch.autograd.Function):
             saved_t, out, head = _tail_fwd(att, mlp, layer[0], layer[1], packed[i + 1], training, st, B, Lq, qkv, base, o, lse, nxt, pos_c,
                                            pos_rows, dev)
             flat += [base, m1, r1, n1, qkv, o, lse] + list(saved_t)                          # 13 per layer
+            if i + 1 in ctx.taps:
+                # the kernel stores x + pos for every layer but the last (the next layer's residual base, partseg.py:335); the tap is x
+                tapped.append(out.view(B, Lq, D) - pos_c.view(-1, Lq, D) if (i + 1 < nl and pos_c is not None) else out.view(B, Lq, D).clone())
         ctx.ca, ctx.layers, ctx.training, ctx.packed = ca, layers, training, packed
         ctx.dims = (B, Lq, Lkv, D, Hd, H)
         ctx.pos_shape = tuple(pos.shape) if pos is not None else None
         ctx.xkv_dtype = BF16 if kv_ready else xkv.dtype
         ctx.save_for_backward(*flat)
-        return out.view(B, Lq, D)
+        return (out.view(B, Lq, D),) + tuple(tapped)
 
     @staticmethod
     @_sinked
-    def backward(ctx, dout):
+    def backward(ctx, dout, *dtaps):
         flat = ctx.saved_tensors
         ca, layers, training, packed = ctx.ca, ctx.layers, ctx.training, ctx.packed
         B, Lq, Lkv, D, Hd, H = ctx.dims
         M, Mk = B * Lq, B * Lkv
-        dev = dout.device
+        dev = flat[0].device
         st = ctx.rng_st
-        d = dout.contiguous().float().view(M, D)
+        tap_grad = {t: g for t, g in zip([t for t in ctx.taps if 1 <= t <= len(layers)], dtaps) if g is not None}
+        d = dout.contiguous().float().view(M, D) if dout is not None else None
         want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
         nl = len(layers)
         nwg = (M + 63) // 64
@@ -1153,6 +1183,12 @@ class EncoderFusedFn(torch.autograd.Function):
                 npj = 0
 
         for i in range(nl - 1, -1, -1):
+            tg = tap_grad.get(i + 1)
+            if tg is not None:                              # the tapped output feeds the head AND the next layer
+                tg = tg.contiguous().float().view(M, D)
+                d = tg if d is None else d + tg
+            if d is None:
+                continue                                    # nothing downstream of this layer was used (untapped tail of the stack)
             base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[18 + 13 * i:18 + 13 * i + 13]
             layer = layers[i]
             sa, mlp = layer[0].module, layer[1].module
@@ -1221,7 +1257,7 @@ class EncoderFusedFn(torch.autograd.Function):
             else:
                 dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dev)
                 L.call("vpf_rowsum_mod_f32", dsum, M, D, Lq, dpos)
-        return (dx.view(B, Lq, D), dpos, dxkv, None, None, None, None) + (None,) * ctx.nparams
+        return (dx.view(B, Lq, D), dpos, dxkv, None, None, None, None, None) + (None,) * ctx.nparams
 
 
 class AdapterKVFn(torch.autograd.Function):

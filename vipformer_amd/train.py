@@ -79,6 +79,61 @@ class FlatParams:
             p.grad = self.g[o:o + p.numel()].view_as(p.data)
 
 
+class GradientExchange:
+    """The data-parallel exchange step (what the two DistributedDataParallel reducers of pretrain.py:104-105 do during
+    ``backward``): SUM all-reduce of the flat gradient over the ranks, as independent REGIONS that are launched asynchronously on a
+    communication stream the moment their producer has finished -- the image branch's gradients travel while the point-cloud
+    branch's backward is still running, and AdamW of a region starts when that region has arrived.  The mean (1 / world) is folded
+    into the AdamW kernel's gradient scale.  No kernels of this library are involved: the class works on CPU tensors over gloo
+    (tests/test_host_cpu.py) exactly as on HBM over RCCL / xGMI."""
+
+    def __init__(self, flat_g: torch.Tensor, regions, world: int, group=None, wire_bf16: bool = False):
+        self.g, self.world, self.group, self.wire_bf16 = flat_g, world, group, wire_bf16
+        self.regions = [(str(n), int(a), int(b)) for n, a, b in regions]
+        covered = sorted((a, b) for _, a, b in self.regions)
+        if covered[0][0] != 0 or covered[-1][1] != flat_g.numel() or any(x[1] != y[0] for x, y in zip(covered[:-1], covered[1:])):
+            raise ValueError("regions must tile the flat gradient buffer exactly")
+        self._cuda = flat_g.is_cuda
+        self._comm = torch.cuda.Stream(device=flat_g.device) if self._cuda else None
+        self._pending = {}
+
+    def start(self, name: str) -> None:
+        """Launch the all-reduce of region ``name``; on a GPU it is ordered after everything queued so far on the CURRENT stream
+        (the stream that produced the region) and runs on the communication stream."""
+        if self.world == 1:
+            return
+        _, a, b = next(r for r in self.regions if r[0] == name)
+        view = self.g[a:b]
+        if self._cuda:
+            self._comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                buf = view.to(torch.bfloat16) if self.wire_bf16 else view
+                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending[name] = (work, buf, view)
+        else:
+            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending[name] = (work, view, view)
+
+    def finish(self, name: str) -> None:
+        """Make the current stream (GPU) / the caller (CPU) wait for region ``name``."""
+        item = self._pending.pop(name, None)
+        if item is None:
+            return
+        work, buf, view = item
+        work.wait()
+        if self._cuda:
+            if buf is not view:
+                with torch.cuda.stream(self._comm):
+                    view.copy_(buf)
+            torch.cuda.current_stream().wait_stream(self._comm)
+
+    def all(self) -> None:
+        for n, _, _ in self.regions:
+            self.start(n)
+        for n, _, _ in self.regions:
+            self.finish(n)
+
+
 class Pretrainer:
     """One object = the reference's models + AdamW + NT-Xent loop state for one rank."""
 
@@ -105,6 +160,13 @@ class Pretrainer:
         self._graph = None
         self._static = None
         self.losses = None
+        # gradient regions in the order backward finishes them: the image model (second half of the flat buffer; its backward runs
+        # on the side stream and ends first), then the point-cloud model (Group2Emb / adapter weight gradients come last)
+        n_pc = len({id(p) for p in pc_model.parameters()})
+        cut = self.flat.offsets[n_pc] if n_pc < len(self.flat.offsets) else self.flat.numel
+        self.regions = [("img", cut, self.flat.numel), ("pc", 0, cut)]
+        self.exchange = GradientExchange(self.flat.g, self.regions, world_size, process_group,
+                                         wire_bf16=os.environ.get("VPF_GRAD_WIRE", "f32") == "bf16")
 
     # ------------------------------------------------------------------ pieces
     def broadcast_parameters(self, src: int = 0) -> None:
@@ -165,9 +227,24 @@ class Pretrainer:
         return total.detach(), loss_imid.detach(), loss_cmid.detach()
 
     def allreduce_gradients(self) -> None:
-        """The step's single collective: SUM of the flat gradient over ranks (mean folded into AdamW)."""
-        if self.world > 1:
-            dist.all_reduce(self.flat.g, op=dist.ReduceOp.SUM, group=self.group)
+        """The step's exchange: SUM of the flat gradient over ranks (mean folded into AdamW), region by region."""
+        self.exchange.all()
+
+    def _adamw_region(self, a: int, b: int, advance: bool) -> None:
+        f = self.flat
+        L.call("vpf_adamw_step", f.p[a:b], f.g[a:b], f.m[a:b], f.v[a:b], f.s[a:b], b - a, self.hyper, int(advance))
+
+    def exchange_and_step(self) -> None:
+        """N > 1: regions are reduced asynchronously on the communication stream; AdamW of a region runs as soon as it has
+        arrived (the image region's update overlaps the point-cloud region's transfer).  The bias-correction step counter advances
+        with the last region; the dropout state once per step."""
+        ex = self.exchange
+        for n, _, _ in self.regions:
+            ex.start(n)
+        for i, (n, a, b) in enumerate(self.regions):
+            ex.finish(n)
+            self._adamw_region(a, b, i + 1 == len(self.regions))
+        ops.rng.advance(self.device)
 
     def set_lr(self, lr: float) -> None:
         """The learning-rate schedule's hook (the reference steps a cosine / warm-restart schedule per epoch, pretrain.py:136-142,
@@ -182,8 +259,10 @@ class Pretrainer:
     # ------------------------------------------------------------------ whole step
     def step(self, pc_t1, pc_t2, imgs):
         losses = self.forward_backward(pc_t1, pc_t2, imgs)
-        self.allreduce_gradients()
-        self.optimizer_step()
+        if self.world > 1:
+            self.exchange_and_step()
+        else:
+            self.optimizer_step()
         self.losses = losses
         return losses
 
@@ -212,7 +291,7 @@ class Pretrainer:
                 b.copy_(k)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
+        with torch.cuda.graph(self._graph, stream=side):        # (the warm-up's stream: per-stream scratch buffers exist already)
             self.losses = self.forward_backward(*self._static)
             if self.world == 1:
                 self.optimizer_step()
@@ -222,8 +301,7 @@ class Pretrainer:
         """One captured step (inputs are whatever the static buffers hold)."""
         self._graph.replay()
         if self.world > 1:
-            self.allreduce_gradients()
-            self.optimizer_step()
+            self.exchange_and_step()
         return self.losses
 
 
