@@ -182,23 +182,40 @@ def _pmc():
         return {}
 
 
+PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step trace whose average durations add up to one "launch" of the leg
+    "fps_kernel": ["fps_kernel"],
+    "knn_group_select_kernel": ["knn_group_select_kernel"],
+    "gemm_wgrad_group_kernel": ["gemm_wgrad_group_kernel"],
+    "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel"],
+    "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel"],
+    "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel", "attn_bwd_dkv"],
+    "attn_res_fwd_kernel (self-attention pc)": ["attn_res_fwd_kernel<3>"],
+    "attn_res_fwd_kernel (self-attention img)": ["attn_res_fwd_kernel<7>"],
+    "attn_res_bwd_kernel (self-attention pc)": ["attn_res_bwd_kernel<3>"],
+    "attn_res_bwd_kernel (self-attention img)": ["attn_res_bwd_kernel<7>"],
+}
+
+
 def attach_profile(legs):
     """Per leg: the in-step average of the committed whole-step rocprofv3 trace (same command), its share of the step's kernel time,
     and the PMC numbers of the committed counter passes (HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
-    correction; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs x 4 SIMDs))."""
+    correction; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs))."""
     rows = _profile_rows()
     pmc = _pmc()
     tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
     for key, leg in legs.items():
-        base = leg["kernel"].split("/")[0].replace("attn_bwd_dq", "attn_bwd_dq")
-        hit = [r for r in rows if base.split(" ")[0] in r["Name"]]
-        if hit:
-            ns = sum(float(r["TotalDurationNs"]) for r in hit); calls = sum(float(r["Calls"]) for r in hit)
-            leg["in_step_avg_us"] = round(ns / calls / 1e3, 2)
-            leg["share_of_step_kernel_time"] = round(ns / tot, 4)
+        avg, ns_all, found = 0.0, 0.0, False
+        for sub in PROFILE_NAMES.get(key, [leg["kernel"]]):
+            hit = [r for r in rows if sub in r["Name"]]
+            if hit:
+                ns = sum(float(r["TotalDurationNs"]) for r in hit); calls = sum(float(r["Calls"]) for r in hit)
+                avg += ns / calls; ns_all += ns; found = True
+        if found:
+            leg["in_step_avg_us"] = round(avg / 1e3, 2)
+            leg["share_of_step_kernel_time"] = round(ns_all / tot, 4)
         p = pmc.get(key) or pmc.get(leg["kernel"])
         if p:
-            leg.update(p)
+            leg.update({k: v for k, v in p.items() if k != "pmc"})
     return rows
 
 
@@ -206,8 +223,8 @@ def dominant(legs, rows):
     """The leg whose kernel is first in the whole-step kernel statistics (largest total time); the grouped weight gradient if the
     profile is absent."""
     for r in rows:
-        for key, leg in legs.items():
-            if leg["kernel"].split("/")[0].split(" ")[0] in r["Name"]:
+        for key in legs:
+            if any(sub in r["Name"] for sub in PROFILE_NAMES.get(key, [])):
                 return key
     return "gemm_wgrad_group_kernel" if "gemm_wgrad_group_kernel" in legs else next(iter(legs))
 
@@ -272,16 +289,19 @@ def cpu_baseline(a, pairs=8, timed_steps=3):
 
     default_threads = torch.get_num_threads()
     cores = physical_cores()
-    sec = run(cores, timed_steps)
-    sec8 = run(min(8, cores), 2)
+    sec_all = run(cores, timed_steps)
+    sec8 = run(min(8, cores), timed_steps)
     torch.set_num_threads(1)
     t_view, t_img = A.time_sample(a["N"], a["img"], a["img"], repeats=30)
     torch.set_num_threads(default_threads)
     aug_pair = 2 * t_view + t_img
-    return dict(value=round(pairs / sec, 3), unit="pairs/s", cores=cores, kind="port",
+    # the CPU path's best foot forward: 8 pairs are too little work for 128 threads (torch's intra-op parallelism loses to its own
+    # synchronisation), so `value` is the faster of the two thread counts and `cores` says which one it was
+    sec, used = (sec_all, cores) if sec_all <= sec8 else (sec8, min(8, cores))
+    return dict(value=round(pairs / sec, 3), unit="pairs/s", cores=used, kind="port",
                 sample=f"{timed_steps} timed steps (after 1 warm-up) of {pairs} pairs = BASELINE configs[0] (E1CL6SL-H4D256-L96-MR2, 1024 pts + "
-                       f"224x224 img), fp32 torch-CPU oracle incl. FPS/kNN (C), fwd+bwd+AdamW; {sec:.2f} s/step on {cores} threads",
-                pairs_per_s_8_threads=round(pairs / sec8, 3),
+                       f"224x224 img), fp32 torch-CPU oracle incl. FPS/kNN (C), fwd+bwd+AdamW; {sec:.2f} s/step on {used} threads",
+                pairs_per_s_all_physical_cores=round(pairs / sec_all, 3), physical_cores=cores, pairs_per_s_8_threads=round(pairs / sec8, 3),
                 augmentation=dict(ms_per_view_trans_1=round(t_view * 1e3, 3), ms_per_image_transform=round(t_img * 1e3, 3),
                                   ms_per_pair_one_thread=round(aug_pair * 1e3, 3), pairs_per_s_all_cores=round(cores / aug_pair, 1),
                                   note="datasets/data.py:16-25,97-112 restated (oracle/augment.py): trans_1 pinned bit-exactly against the "

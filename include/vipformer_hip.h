@@ -280,7 +280,8 @@ int vpf_pretrain_loss_bwd(const float* zn, const float* inv_norm, const float* P
                           const float* dtotal, float* ws_dz, float* df, float* dg, void* stream);
 /* torch.optim.AdamW (pretrain.py:121-124,210) over a flat fp32 buffer, also rewriting the bf16 shadow the MFMA
  * kernels read.  hyper_dev (device, 8 floats) = {lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip}. */
-int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev,
+/* advance_step: bit 0 = advance the bias-correction step, bit 1 = zero g after use (the next step's optimizer.zero_grad()) */
+int vpf_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev,
                    int advance_step, void* stream);
 
 /* Up to 8 weight-gradient GEMMs in one launch (the backward of nn.Linear, e.g. the four of a transformer layer,
@@ -356,6 +357,7 @@ typedef struct VpfSaLayerBwd {
     const void* dqkv; const void* WqkvT; const float* base; const float* mean1; const float* rstd1; const float* ln1_g;
     float* dbase; float* dsum;
     float* pgrad1;
+    int dsum_init;          /* 1: dsum = dbase (the first layer of a backward pass initialises the sum: no zero-fill launch); 0: dsum += dbase */
 } VpfSaLayerBwd;
 int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* host_args, void* stream);
 int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);

@@ -403,6 +403,32 @@ def make_ckpt():
     print("wrote ckpt_pc_tiny.pth", os.path.getsize(os.path.join(HERE, "ckpt_pc_tiny.pth")))
 
 
+def make_ca2():
+    """Encoder with num_cross_attention_layers = 2 (partseg.py:297-300,331-334: a separate cross_attn_1, cross_attn_n re-applied in front
+    of the first self-attention layer): key list + eval-mode features of the tiny architecture -> model_tiny_ca2.npz."""
+    a = Hh.ARCHS["tiny"]
+    torch.manual_seed(0)
+    ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+    pc = CrossFormer_pc_mp(ad, a["G"], a["D"], a["K"], 2, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.0, 0.0, True)
+    json.dump(keyshapes(pc), open(os.path.join(HERE, "keys_pc_tiny_ca2.json"), "w"))
+    pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_tiny_ca2.json"), 100, alias_ca=False))
+    B = Hh.MODEL_BATCH["tiny"]
+    pts = Hh.synth_points(300, 2 * B, a["N"], 3, "uniform")
+    start = Hh.synth_start(300, 2 * B, a["N"])
+    RU.knn_point = canonical_knn
+    pc.eval()
+    with torch.no_grad(), forced_start(start):
+        f, bb = pc(pts)
+    pc.train(); pc.zero_grad()
+    with forced_start(start):
+        f2, bb2 = pc(pts)
+    (bb2 * Hh.synth_like(700, bb2.shape)).sum().backward()
+    n, norms, heads = grad_summary(pc)
+    RU.knn_point = _orig_knn
+    json.dump(n, open(os.path.join(HERE, "grad_names_tiny_ca2.json"), "w"))
+    save("model_tiny_ca2.npz", pc_eval_feats=f, pc_eval_backbone=bb, pc_train_backbone=bb2, pc_grad_norms=norms)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ft":
         make_ft()
@@ -412,6 +438,8 @@ if __name__ == "__main__":
         make_augment()
     elif len(sys.argv) > 1 and sys.argv[1] == "ckpt":
         make_ckpt()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ca2":
+        make_ca2()
     elif len(sys.argv) > 2 and sys.argv[1] == "models":        # python make_golden.py models c3 c4
         main(only_models=tuple(sys.argv[2:]))
     else:
@@ -420,3 +448,4 @@ if __name__ == "__main__":
         make_partseg()
         make_augment()
         make_ckpt()
+        make_ca2()

@@ -22,17 +22,17 @@ def _uniform(rng: np.random.Generator, shape, lo: float, hi: float) -> torch.Ten
     return torch.from_numpy(a.astype(np.float32))
 
 
-def synth_state_dict(keyshapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int) -> Dict[str, torch.Tensor]:
+def synth_state_dict(keyshapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int, alias_ca: bool = True) -> Dict[str, torch.Tensor]:
     """Deterministic, well-conditioned values for a reference-shaped state dict.
     Matrices ~U(+-sqrt(3/fan_in)) (unit gain), norm scales 1+-0.2, shifts/biases +-0.1,
     running_var in [0.5,1.5].  ``encoder.cross_attn_1.*`` aliases ``cross_attn_n.*``
-    (one parameter set in the reference, partseg.py:297-298)."""
+    (one parameter set in the reference, partseg.py:297-298) unless alias_ca is False (num_cross_attention_layers > 1)."""
     rng = np.random.default_rng(seed)
     out: Dict[str, torch.Tensor] = {}
     ks = sorted(keyshapes, key=lambda t: t[0])
     for key, shape in ks:
         shape = tuple(shape)
-        if "cross_attn_1." in key:
+        if alias_ca and "cross_attn_1." in key:
             continue
         if key.endswith("num_batches_tracked"):
             out[key] = torch.zeros((), dtype=torch.int64)
@@ -51,7 +51,7 @@ def synth_state_dict(keyshapes: Iterable[Tuple[str, Tuple[int, ...]]], seed: int
         else:                                  # biases, norm shifts
             out[key] = _uniform(rng, shape, -0.1, 0.1)
     for key, shape in ks:
-        if "cross_attn_1." in key:
+        if alias_ca and "cross_attn_1." in key:
             out[key] = out[key.replace("cross_attn_1.", "cross_attn_n.")]
     return out
 

@@ -451,7 +451,7 @@ def test_trainer_stream_and_graph_variants_agree():
         with forced_start(start):
             if graph:
                 tr.hyper[0] = 0.0; tr.hyper[4] = 0.0            # lr = wd = 0: the warm-up steps of capture() leave the weights alone
-                tr.capture(t1, t2, imgs, warmup=1)
+                tr.capture(t1, t2, imgs, warmup=1, keep_grads=True)    # (the comparison below reads the gradients after the replay)
                 ops.rng.state("cuda")[2] = 0                # same dropout step as the eager variants (the graph holds this tensor)
                 losses = tr.replay()
             else:
@@ -552,3 +552,42 @@ def test_other_baseline_configs_train_one_step(name):
     assert float(tr.flat.g.abs().max()) > 0.0
     assert torch.isfinite(tr.flat.p).all().item() and not torch.equal(tr.flat.p, p0)
     ops.clear_managed_shadows()
+
+
+def test_two_cross_attention_layers_vs_reference_golden():
+    """Encoder with num_cross_attention_layers = 2 (the branch of partseg.py:331-334 was never exercised):
+    separate cross_attn_1 / cross_attn_n parameter sets, cross_attn_n re-applied in front of the first self-attention layer.
+    Eval / train backbone and gradient norms against the reference fixture (make_golden.py make_ca2)."""
+    from vipformer_amd.model.pointcloud import CrossFormer_pc_mp, PointCloudInputAdapter
+    a = Hh.ARCHS["tiny"]
+    ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+    pc = CrossFormer_pc_mp(ad, a["G"], a["D"], a["K"], 2, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.0, 0.0, True)
+    want = Hh.load_keyshapes("keys_pc_tiny_ca2.json")
+    assert [(k, tuple(v.shape)) for k, v in pc.state_dict().items()] == want
+    assert pc.encoder.cross_attn_1 is not pc.encoder.cross_attn_n
+    pc.load_state_dict(Hh.synth_state_dict(want, 100, alias_ca=False))
+    pc = pc.cuda()
+    g = Hh.golden("model_tiny_ca2.npz")
+    ck = Checks("two-ca")
+    B = Hh.MODEL_BATCH["tiny"]
+    pts = Hh.synth_points(300, 2 * B, a["N"]).cuda(); start = Hh.synth_start(300, 2 * B, a["N"]).cuda()
+    pc.eval()
+    with torch.no_grad(), forced_start(start):
+        f, bb = pc(pts)
+    ck.lt("eval feats rel", rel(f, g["pc_eval_feats"]), 2 * FWD_TOL)
+    ck.lt("eval backbone rel", rel(bb, g["pc_eval_backbone"]), 2 * FWD_TOL)
+    pc.train(); pc.zero_grad()
+    with forced_start(start):
+        f, bb = pc(pts)
+    ck.lt("train backbone rel", rel(bb, g["pc_train_backbone"]), 2 * FWD_TOL)
+    (bb * Hh.synth_like(700, bb.shape).cuda()).sum().backward()
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, "grad_names_tiny_ca2.json")))
+    params = dict(pc.named_parameters())
+    norms = np.array([params[k].grad.double().norm().item() if params[k].grad is not None else 0.0 for k in names])
+    refn = g["pc_grad_norms"]
+    zero_before_bn = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias")
+    big = np.array([(refn[i] > 1e-3 * refn.max()) and (k not in zero_before_bn) and not k.startswith("latent_head") for i, k in enumerate(names)])
+    ratio = norms[big] / refn[big]
+    report(f"two-ca grad-norm ratio min {ratio.min():.3f} max {ratio.max():.3f}")
+    ck.lt("grad-norm ratio max dev", float(np.abs(ratio - 1).max()), 0.08)
+    ck.done()

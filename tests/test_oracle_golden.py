@@ -251,3 +251,16 @@ def test_augmentation_trans1_vs_reference():
     np.random.seed(3)
     y = A.image_transform(img, 224)
     assert y.shape == (3, 224, 224) and y.dtype == np.float32 and np.isfinite(y).all()
+
+
+def test_two_cross_attention_layers_vs_reference():
+    """Encoder with num_cross_attention_layers = 2 (partseg.py:297-300,331-334; fixture: make_golden.py make_ca2)."""
+    arch, a = _arch("tiny")
+    arch.n_ca = 2
+    g = Hh.golden("model_tiny_ca2.npz")
+    sd = Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_tiny_ca2.json"), 100, alias_ca=False)
+    B = Hh.MODEL_BATCH["tiny"]
+    pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
+    with torch.no_grad():
+        f, bb = O.pc_forward(sd, pts, start, arch, False)
+    _close(f, g["pc_eval_feats"], 1e-4, 1e-4); _close(bb, g["pc_eval_backbone"], 1e-4, 1e-4)

@@ -29,7 +29,7 @@ def worker(rank, world, pairs, steps, port):
     tr.broadcast_parameters(0)
     torch.manual_seed(100 + rank)
     t1, t2, imgs = bench.synth_batch(pairs, A["N"], A["img"], seed=rank, device=dev)
-    tr.capture(t1, t2, imgs, warmup=2)
+    tr.capture(t1, t2, imgs, warmup=2, keep_grads=True)        # (this check reads the reduced gradients after the step)
     for s in range(steps):
         tr._graph.replay()
         torch.cuda.synchronize()

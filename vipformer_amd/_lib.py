@@ -197,7 +197,7 @@ class SaLayerBwd(ctypes.Structure):
                 ("pgrad2", VP),
                 ("dqkv", VP), ("WqkvT", VP), ("base", VP), ("mean1", VP), ("rstd1", VP), ("ln1_g", VP),
                 ("dbase", VP), ("dsum", VP),
-                ("pgrad1", VP)]
+                ("pgrad1", VP), ("dsum_init", I)]
 
 
 def call_struct(name: str, struct, *extra) -> None:

@@ -68,6 +68,7 @@ struct GemmArgs {
     const uint32_t* rng; uint32_t site; float p;   // dropout
     float* dbias;                                   // EPI_ATOMIC with a k-strided A: dbias[m] += sum_k A(m,k)
     int uneven;                                     // split-K slices of alternating length (4/3, 2/3 of the mean): see vpf_wgrad_group
+    int dbg;                                        // timing experiments only (VPF_WGROUP_DBG): 1 = no flush, 2 = no MFMA, 4 = no LDS fragment reads
     float* part; int* cnt; int ntx;                 // EPI_PARTIAL: partial tiles [tile][slice][BM*BN] (accumulator order), arrival counters [tile], tiles per row
     OpXform xa, xb;                                 // operand prologues (kind 0 = none)
 };
@@ -268,18 +269,20 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
                 if (rg < RG)
                     for (int r = rg; r < BK; r += RG) bsum += bf16_to_f32(cA[r * ACfg::LD + c]);
             }
+            if (!(g.dbg & 2)) {
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
                 bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, s);
+                for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, (g.dbg & 4) ? 0 : s);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR, BK>(cB, (wn * TN + j) * 32, s);
+                for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR, BK>(cB, (wn * TN + j) * 32, (g.dbg & 4) ? 0 : s);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
             }
             if (kt + 1 < nk) {
                 tile_store<BM, ATR, BK>(nA, ra[(p + 1) % PF]);
@@ -364,6 +367,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         return;
     }
     if (g.mode == EPI_ATOMIC) {
+        if (g.dbg & 1) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(g.C)[0] = 1.f; return; }
         // split-K partial sums: fp32 atomics straight from the accumulators (128-byte row segments)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -627,7 +631,7 @@ extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void
     g.C = C; g.ldc = ldc; g.c_f32 = c_is_f32; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
     g.aux = (const bf16_t*)aux; g.ldaux = ldaux; g.gbias = gbias; g.group = group > 0 ? group : 1;
     g.rng = rng_state; g.site = site; g.p = p; g.dbias = dbias;
-    g.xa.kind = 0; g.xb.kind = 0; g.uneven = 0;
+    g.xa.kind = 0; g.xb.kind = 0; g.uneven = 0; g.dbg = 0;
     if (dbias && !(mode == EPI_ATOMIC && a_kstrided)) return VPF_ERR_UNSUPPORTED;
     if (mode < 0 || mode > EPI_GROUPBIAS) return VPF_ERR_UNSUPPORTED;   // EPI_GROUPMAX: vpf_gemm_bf16_fused
     if (mode == EPI_GELU && !C2) return VPF_ERR_NULL;
@@ -704,6 +708,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
         // 512 workgroups flushing together at the end (-0.035 ms/step, 15 launches)
         { static int un = -1; if (un < 0) { const char* e = getenv("VPF_WGROUP_UNEVEN"); un = e ? atoi(e) : 2; } g.uneven = un; }
+        { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VPF_WGROUP_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
         grp.nx[i] = nx; grp.ny[i] = ny; grp.start[i] = at;
         at += nx * ny * (int)sp;
     }
@@ -719,6 +724,8 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
             cnt += grp.nx[i] * grp.ny[i];
         }
     }
+    // (measured and removed: 256 x 256 tiles with the accumulators in all 512 registers of a lane -- half the operand bytes staged
+    //  per output element, but 154 us against 59: 67 MB of flush atomics and one wave per SIMD with nothing to hide behind)
     if (cfg == 7) return launch_wgrad_group<2, 2, 2, 2, 64, 3>(grp, at, st);  // 3 stages of loads in flight
     if (cfg == 6) return launch_wgrad_group<2, 2, 2, 2, 64, 2>(grp, at, st);  // 2 stages of loads in flight
     if (cfg == 5) return launch_wgrad_group<2, 2, 2, 2, 32>(grp, at, st);     // 128x128, shallow stages: 4 workgroups per CU

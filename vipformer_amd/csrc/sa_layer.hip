@@ -1322,7 +1322,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd
                                              acc[j][i][4 * g + 2] + dv[j][g][i].z, acc[j][i][4 * g + 3] + dv[j][g][i].w);
                 *reinterpret_cast<float4*>(a.dbase + off) = v;
                 if (a.dsum) {
-                    float4 s = *reinterpret_cast<const float4*>(a.dsum + off);
+                    float4 s = a.dsum_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.dsum + off);
                     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                     *reinterpret_cast<float4*>(a.dsum + off) = s;
                 }
@@ -1406,7 +1406,7 @@ __global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
         const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
         const size_t off = (size_t)(m0 + (row < nvalid ? row : 0)) * SA_D + c4 * 4;
         dv[it] = *reinterpret_cast<const float4*>(a.dx1 + off);
-        if (a.dsum) sv[it] = *reinterpret_cast<const float4*>(a.dsum + off);
+        if (a.dsum) sv[it] = a.dsum_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.dsum + off);
     }
     __syncthreads();
 #pragma unroll

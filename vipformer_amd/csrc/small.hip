@@ -879,8 +879,8 @@ extern "C" int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const floa
 // =============================================================================== fused AdamW over a flat buffer (+ bf16 shadow)
 // torch.optim.AdamW semantics (decoupled weight decay, bias correction).  hyper (device, 8 floats):
 // {lr, beta1, beta2, eps, weight_decay, grad_scale, step (float, incremented here), skip_flag}
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             bf16_t* __restrict__ shadow, long n, const float* __restrict__ hyper)
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             bf16_t* __restrict__ shadow, long n, const float* __restrict__ hyper, int zero_grad)
 {
     const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gs = hyper[5], step = hyper[6] + 1.f;
     const bool skip = hyper[7] != 0.f;
@@ -898,18 +898,19 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
             p[i] = pv;
         }
         if (shadow) shadow[i] = f32_to_bf16(pv);
+        if (zero_grad) g[i] = 0.f;          // optimizer.zero_grad() of the NEXT step (pretrain.py:174) folded in: no 33 MB fill launch
     }
 }
 __global__ void adamw_step_kernel(float* hyper) { if (threadIdx.x == 0 && hyper[7] == 0.f) hyper[6] += 1.f; }
-extern "C" int vpf_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev, int advance_step,
+extern "C" int vpf_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev, int advance_step,
                               void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!p || !g || !m || !v || !hyper_dev) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow_bf16, n, hyper_dev);
-    if (advance_step) hipLaunchKernelGGL(adamw_step_kernel, dim3(1), dim3(64), 0, st, hyper_dev);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow_bf16, n, hyper_dev, (advance_step >> 1) & 1);
+    if (advance_step & 1) hipLaunchKernelGGL(adamw_step_kernel, dim3(1), dim3(64), 0, st, hyper_dev);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

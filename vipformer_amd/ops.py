@@ -452,6 +452,42 @@ def wgrad_workspace(device):
     return ws
 
 
+class WgradDeferral:
+    """Weight gradients are off the backward critical path: nothing reads them before the optimizer.  A trainer that runs two
+    branches on two streams opens a deferral around ``backward``: grouped weight-gradient launches issued from streams other than
+    ``target`` are not launched where they arise but queued (with an event marking the point their operands are complete), and
+    ``drain`` issues them on ``target`` -- the stream of the SHORTER branch, behind that branch's own work.  The long branch's
+    stream then carries only its dgrad chain.  No extra stream is created (a third stream costs more than it overlaps on this
+    stack)."""
+
+    def __init__(self, target: torch.cuda.Stream):
+        self.target = target
+        self.queue = []
+
+    def take(self, jobs, arr) -> bool:
+        cur = torch.cuda.current_stream()
+        if cur == self.target:
+            return False
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.queue.append((ev, jobs, arr))
+        return True
+
+    def drain(self) -> None:
+        with torch.cuda.stream(self.target):
+            for ev, jobs, arr in self.queue:
+                self.target.wait_event(ev)
+                ws = wgrad_workspace(jobs[0][0].device)
+                L.call_struct("vpf_wgrad_group", arr, len(jobs), ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0)
+                for dy, x, *_ in jobs:
+                    dy.record_stream(self.target)
+                    x.record_stream(self.target)
+        self.queue = []
+
+
+WGRAD_DEFER = [None]      # the open WgradDeferral, if any (module-level: autograd runs backward on its own thread)
+
+
 class WgradBatch:
     """Collects linear_wgrad calls of one layer and issues them as ONE grouped launch (vpf_wgrad_group)."""
 
@@ -473,6 +509,9 @@ class WgradBatch:
         for i, (dy, x, M, N, K, dW, db) in enumerate(self.jobs):
             arr[i].dy, arr[i].x, arr[i].M, arr[i].N, arr[i].K = dy.data_ptr(), x.data_ptr(), M, N, K
             arr[i].dW, arr[i].dbias = dW.data_ptr(), (db.data_ptr() if db is not None else None)
+        if WGRAD_DEFER[0] is not None and WGRAD_DEFER[0].take(self.jobs, arr):
+            self.jobs = []
+            return
         if WGRAD_ASYNC[0] or WGRAD_GROUP_ASYNC[0]:
             # weight gradients are off the dgrad critical path: one grouped launch per layer on a side stream
             cur, side = _wgrad_side()
@@ -932,7 +971,7 @@ class SAStackFn(torch.autograd.Function):
         pg = torch.empty(nl, 2, nwg * 2 * D, dtype=F32, device=dev)       # LayerNorm parameter-gradient partials of every layer
         pjobs = (L.PgradJob * 32)()
         npj = 0
-        dsum = torch.zeros(M, D, dtype=F32, device=dev) if want_pos else None
+        dsum = torch.empty(M, D, dtype=F32, device=dev) if want_pos else None      # written (not accumulated) by the first layer processed
         for i in range(len(layers) - 1, -1, -1):
             base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h = flat[13 * i:13 * i + 13]
             layer = layers[i]
@@ -957,6 +996,7 @@ class SAStackFn(torch.autograd.Function):
             a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = (dqkv.data_ptr(), packed[i]["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(),
                                                                  r1.data_ptr(), ln1.weight.data.data_ptr())
             a.dbase, a.dsum = dbase.data_ptr(), (dsum.data_ptr() if dsum is not None else None)
+            a.dsum_init = int(i == len(layers) - 1)
             L.call_struct("vpf_sa_layer_bwd_mlp", a)
             p_att = att.dropout.p if training else 0.0
             L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
@@ -1156,7 +1196,8 @@ class EncoderFusedFn(torch.autograd.Function):
         pg = torch.empty(nl + 1, 2, nwg * 2 * D, dtype=F32, device=dev)
         pjobs = (L.PgradJob * 32)()
         npj = 0
-        dsum = torch.zeros(M, D, dtype=F32, device=dev) if want_pos else None
+        dsum = torch.empty(M, D, dtype=F32, device=dev) if want_pos else None      # written (not accumulated) by the first layer processed
+        dsum_started = False
 
         def bwd_mlp(a, blk, res_attn, res_mlp, pk, d, u, x1, m2, r2, slot):
             att, mlp = blk
@@ -1204,6 +1245,8 @@ class EncoderFusedFn(torch.autograd.Function):
             a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = (dqkv.data_ptr(), pk["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(),
                                                                  r1.data_ptr(), ln1.weight.data.data_ptr())
             a.dbase, a.dsum, a.pgrad1 = dbase.data_ptr(), (dsum.data_ptr() if dsum is not None else None), pg[i + 1, 0].data_ptr()
+            a.dsum_init = int(not dsum_started)
+            dsum_started = True
             L.call_struct("vpf_sa_layer_bwd_qkv", a)
             wg = WgradBatch()
             wg.add(dz2, h, D, Hd, grad_buf(mlp[3].weight), grad_buf(mlp[3].bias))
@@ -1251,7 +1294,10 @@ class EncoderFusedFn(torch.autograd.Function):
         dx = layernorm_bwd(dnq, base_ca, mq, rq, lnq.weight, lnq.bias, dx1).view(M, D)
         dpos = None
         if want_pos:
-            dsum.add_(dx)
+            if dsum_started:
+                dsum.add_(dx)
+            else:
+                dsum = dx.clone()
             if ctx.pos_shape[0] == B or B == 1:
                 dpos = dsum.view(ctx.pos_shape)
             else:
@@ -1881,6 +1927,7 @@ class PretrainLossFn(torch.autograd.Function):
         ctx.t, ctx.w, ctx.dims = temperature, w, (b, D)
         ctx.save_for_backward(zn, inv, P)
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)            # no zero-filled gradient for `parts` (a launch per step)
         return total, parts
 
     @staticmethod

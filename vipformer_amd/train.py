@@ -156,10 +156,17 @@ class Pretrainer:
         self.overlap = True
         self.fused_losses = True
         self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "1") == "1"
+        # optional: the point-cloud branch's grouped weight gradients on the image branch's stream behind its backward (ops.WgradDeferral).
+        # Measured +0.11 ms/step on MI355X: the two branches already share the CUs for most of the step, the step is bound by the SUM
+        # of kernel time (6.9 ms over 4.55 ms of wall), not by the longer stream
+        self.defer_wgrad = os.environ.get("VPF_DEFER_WGRAD", "0") == "1"
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._graph = None
         self._static = None
         self.losses = None
+        self.zero_grad_in_optimizer = False      # AdamW leaves the gradient buffer zeroed for the next step (set by capture())
+        self._g_clean = False
+        self._one = torch.ones((), dtype=torch.float32, device=dev)
         # gradient regions in the order backward finishes them: the image model (second half of the flat buffer; its backward runs
         # on the side stream and ends first), then the point-cloud model (Group2Emb / adapter weight gradients come last)
         n_pc = len({id(p) for p in pc_model.parameters()})
@@ -184,10 +191,17 @@ class Pretrainer:
             return self._forward_backward(pc_t1, pc_t2, imgs)
 
     def _forward_backward(self, pc_t1, pc_t2, imgs):
-        self.flat.g.zero_()
+        if not self._g_clean:
+            self.flat.g.zero_()                             # pretrain.py:174 (skipped when the last AdamW launch left it zero)
+        self._g_clean = False
         imgs = imgs.permute(0, 2, 3, 1)                     # pretrain.py:179 (a view; strides go to the kernel)
         b = pc_t1.shape[0]
-        pc = torch.cat([pc_t1, pc_t2], dim=0)               # pretrain.py:183
+        if (pc_t1.is_contiguous() and pc_t2.is_contiguous() and pc_t1.shape == pc_t2.shape
+                and pc_t1.untyped_storage().data_ptr() == pc_t2.untyped_storage().data_ptr()
+                and pc_t1.data_ptr() + pc_t1.numel() * pc_t1.element_size() == pc_t2.data_ptr()):
+            pc = torch.as_strided(pc_t1, (2 * b,) + tuple(pc_t1.shape[1:]), pc_t1.stride(), pc_t1.storage_offset())   # the views ARE cat(t1, t2)
+        else:
+            pc = torch.cat([pc_t1, pc_t2], dim=0)           # pretrain.py:183
         if self.overlap and self._side is not None:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
@@ -218,7 +232,14 @@ class Pretrainer:
             loss_imid = ops.ntxent_loss(f1, f2, self.temperature)
             loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, self.temperature)
             total = loss_imid + self.cmid_weight * loss_cmid
-        total.backward()
+        defer = ops.WgradDeferral(self._side) if (self.overlap and self._side is not None and self.defer_wgrad) else None
+        ops.WGRAD_DEFER[0] = defer
+        try:
+            total.backward(self._one)                       # (a persistent 1.0: no ones_like fill launch per step)
+        finally:
+            ops.WGRAD_DEFER[0] = None
+        if defer is not None:
+            defer.drain()                                   # the point-cloud branch's grouped weight gradients, behind the image branch's backward
         if self.overlap and self._side is not None:
             # the kernels write weight gradients themselves (autograd sees no leaf accumulation on the side stream and
             # therefore does not join it): the image branch's backward must land before anything reads the gradients
@@ -232,7 +253,8 @@ class Pretrainer:
 
     def _adamw_region(self, a: int, b: int, advance: bool) -> None:
         f = self.flat
-        L.call("vpf_adamw_step", f.p[a:b], f.g[a:b], f.m[a:b], f.v[a:b], f.s[a:b], b - a, self.hyper, int(advance))
+        L.call("vpf_adamw_step", f.p[a:b], f.g[a:b], f.m[a:b], f.v[a:b], f.s[a:b], b - a, self.hyper,
+               int(advance) | (2 if self.zero_grad_in_optimizer else 0))
 
     def exchange_and_step(self) -> None:
         """N > 1: regions are reduced asynchronously on the communication stream; AdamW of a region runs as soon as it has
@@ -244,6 +266,7 @@ class Pretrainer:
         for i, (n, a, b) in enumerate(self.regions):
             ex.finish(n)
             self._adamw_region(a, b, i + 1 == len(self.regions))
+        self._g_clean = self.zero_grad_in_optimizer
         ops.rng.advance(self.device)
 
     def set_lr(self, lr: float) -> None:
@@ -253,7 +276,8 @@ class Pretrainer:
 
     def optimizer_step(self) -> None:
         f = self.flat
-        L.call("vpf_adamw_step", f.p, f.g, f.m, f.v, f.s, f.numel, self.hyper, 1)
+        L.call("vpf_adamw_step", f.p, f.g, f.m, f.v, f.s, f.numel, self.hyper, 1 | (2 if self.zero_grad_in_optimizer else 0))
+        self._g_clean = self.zero_grad_in_optimizer
         ops.rng.advance(self.device)
 
     # ------------------------------------------------------------------ whole step
@@ -266,10 +290,15 @@ class Pretrainer:
         self.losses = losses
         return losses
 
-    def capture(self, pc_t1, pc_t2, imgs, warmup: int = 3):
+    def capture(self, pc_t1, pc_t2, imgs, warmup: int = 3, keep_grads: bool = False):
         """Capture forward+backward (+AdamW when single-rank) into a hipGraph on static input buffers.
-        Returns the static (pc_t1, pc_t2, imgs) tensors to copy new batches into."""
-        self._static = (pc_t1.clone(), pc_t2.clone(), imgs.clone())
+        Returns the static (pc_t1, pc_t2, imgs) tensors to copy new batches into.  The two views live in ONE buffer (cat(t1, t2) of
+        pretrain.py:183 is then a view, not a copy per step); unless keep_grads, AdamW leaves the flat gradient zeroed for the next
+        replay (no 33 MB fill per step) -- flat.g then reads zero after a step."""
+        both = torch.cat([pc_t1, pc_t2], dim=0).contiguous()
+        b = pc_t1.shape[0]
+        self._static = (both[:b], both[b:], imgs.clone())
+        self.zero_grad_in_optimizer = not keep_grads
         # warm-up (lazy allocations, packed-weight buffers, func attributes) must not train: AdamW runs with its skip flag
         # (parameters, moments and the bias-correction step stay put), BatchNorm buffers and the dropout step are restored
         bufs = [b for m in (self.pc_model, self.img_model) for b in m.buffers()]
