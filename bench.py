@@ -353,7 +353,7 @@ def main():
 
     use_graph = not args.no_graph
     if use_graph:
-        static = tr.capture(t1, t2, imgs, warmup=2)
+        static = tr.capture(t1, t2, imgs, warmup=2, count_nodes=(rank == 0))
         run = tr.replay
     else:
         static = (t1, t2, imgs)

@@ -38,6 +38,8 @@ extern "C" {
 
 int vpf_version(void);
 const char* vpf_strerror(int code);
+/* "VPF_BUILD_ID=<sha256 of the library's sources>": vipformer_amd/build.py rebuilds when it does not match the tree */
+const char* vpf_build_id(void);
 
 /* ------------------------------------------------------------------ point-cloud preproc */
 

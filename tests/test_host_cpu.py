@@ -26,7 +26,10 @@ def test_library_exports_every_declared_symbol():
     assert len(fns) >= 40
     for name in fns:
         assert hasattr(lib, name), f"{name} declared in include/vipformer_hip.h but not exported"
-    assert lib.vpf_version() >= 100
+    assert lib.vpf_version() >= 200
+    import ctypes
+    lib.vpf_build_id.restype = ctypes.c_char_p
+    assert lib.vpf_build_id().decode() == "VPF_BUILD_ID=" + build.source_hash()      # the .so was compiled from THIS tree
     assert _lib.lib().vpf_strerror(-3).decode().startswith("unsupported")
 
 
@@ -44,7 +47,7 @@ def test_ctypes_table_matches_header():
                 t = p.split()[1] if p.startswith("const") else p.split()[0]
                 want.append({"int": "i", "long": "l", "float": "f", "uint32_t": "u"}[t])
         assert [kind[t] for t in sig] == want, name
-    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror"}
+    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id"}
 
 
 def test_ctypes_structs_match_the_library_layout():

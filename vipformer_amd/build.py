@@ -24,6 +24,28 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
 
 
+def source_hash() -> str:
+    """sha256 over every source the library is compiled from (csrc/*.hip, csrc/*.h, include/*.h) and the compile flags."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(HERE), "include", "vipformer_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    h.update(" ".join(COMMON[:6] + sorted(sum(PER_FILE.values(), []))).encode())
+    return h.hexdigest()
+
+
+def built_hash() -> str:
+    """The id embedded in the existing .so ('' if there is none): scanned from the file, nothing is loaded."""
+    if not os.path.exists(LIB):
+        return ""
+    data = open(LIB, "rb").read()
+    i = data.find(b"VPF_BUILD_ID=")
+    return data[i + 13:i + 13 + 64].decode("ascii", "replace") if i >= 0 else ""
+
+
 def _newest_header() -> float:
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "vipformer_hip.h"))
@@ -34,12 +56,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdr = _newest_header()
+    want = source_hash()
+    have = built_hash()
+    if have != want and os.path.exists(LIB) and verbose:
+        print(f"libvipformer_hip.so was built from other sources (id {have[:12] or 'none'} != {want[:12]}): recompiling every object")
+    stale = have != want and os.path.exists(LIB)        # timestamps cannot be trusted for a library that travelled: rebuild all
     jobs = []
     for f in srcs:
         src = os.path.join(CSRC, f)
         obj = os.path.join(OBJ, f[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr):
-            jobs.append((["hipcc"] + COMMON + PER_FILE.get(f, []) + ["-c", src, "-o", obj], f))
+        extra = ['-DVPF_BUILD_ID="' + want + '"'] if f == "api.hip" else []
+        if (force or stale or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr)
+                or (f == "api.hip" and have != want)):
+            jobs.append((["hipcc"] + COMMON + PER_FILE.get(f, []) + extra + ["-c", src, "-o", obj], f))
 
     def run(job):
         cmd, name = job

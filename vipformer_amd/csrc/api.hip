@@ -4,7 +4,17 @@
 
 extern "C" int vpf_version(void)
 {
-    return 100;   // 0.1.0
+    return 200;   // 0.2.0
+}
+
+// sha256 over every source of the library (csrc/*.hip, csrc/*.h, include/*.h), injected by vipformer_amd/build.py: build() compares it
+// with the tree and rebuilds on a mismatch, so a prebuilt .so can never stand in for sources it was not compiled from.
+#ifndef VPF_BUILD_ID
+#define VPF_BUILD_ID "unknown"
+#endif
+extern "C" const char* vpf_build_id(void)
+{
+    return "VPF_BUILD_ID=" VPF_BUILD_ID;
 }
 
 extern "C" const char* vpf_strerror(int code)

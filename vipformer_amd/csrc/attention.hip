@@ -239,7 +239,7 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st)
     if (a.Lkv >= 256) {
         constexpr int KT = 128;
         constexpr size_t lds = sizeof(bf16_t) * 2 * 2 * KT * KLD;
-        static bool attr = false;
+        static VpfPerDevice attr_dev; bool& attr = attr_dev();
         if (!attr) {
             if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
             attr = true;
@@ -374,7 +374,7 @@ template <int NW>
 static int launch_res_fwd(const AttnArgs& a, hipStream_t st)
 {
     constexpr size_t lds = (size_t)3 * NW * 32 * KLD * sizeof(bf16_t);      // K, V and the per-wave output staging rows
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
@@ -924,7 +924,7 @@ template <int NW>
 static int launch_res_bwd(const AttnArgs& a, float* delta, hipStream_t st)
 {
     constexpr size_t lds = (size_t)4 * NW * 32 * KLD * sizeof(bf16_t) + (size_t)2 * NW * 32 * sizeof(float);
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_bwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
@@ -1068,7 +1068,7 @@ static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
     if (a.Lkv >= 256) {
         constexpr int KT = 128;
         constexpr size_t lds = sizeof(bf16_t) * 2 * 2 * KT * KLD;
-        static bool attr = false;
+        static VpfPerDevice attr_dev; bool& attr = attr_dev();
         if (!attr) {
             if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NWQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
             attr = true;

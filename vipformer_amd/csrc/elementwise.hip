@@ -192,7 +192,7 @@ extern "C" int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf
     if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return VPF_ERR_NULL;
     if (rows < 0 || D <= 0 || D > 64 * LN_MAXI) return VPF_ERR_BADSHAPE;
     if (rows == 0) return VPF_OK;
-    int grid = grid_for(rows, 16, 1024);
+    int grid = grid_for(rows, rows >= 65536 ? 16 : 4, 1024);      // a wave per row for the encoder-sized inputs (4 k .. 12 k rows): the row loop is a latency chain
     hipStream_t st = (hipStream_t)stream;
     // workspace of 2 * grid * D floats -> per-block partial sums + a finishing pass; without it: fp32 atomics
     float* wsp = (ws && ws_floats >= 2L * grid * D && grid > 8) ? ws : nullptr;

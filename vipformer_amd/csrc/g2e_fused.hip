@@ -675,7 +675,7 @@ extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long 
     G2eBwd p = {dout, arg4, Dm, NG, (const bf16_t*)h3_bf16, stat2, gamma2, beta2, (const bf16_t*)w4t_bf16, (const bf16_t*)w3bt_bf16, tmp512_zeroed,
                 1.0f / (float)(NG * 32), training, (bf16_t*)dh3_bf16, dgb, (bf16_t*)dh2_bf16, dbg};
     const size_t lds = sizeof(bf16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return VPF_ERR_HIP;

@@ -529,7 +529,7 @@ static int launch_wgrad_group(const GemmGroup& grp, int nblocks, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS);
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<TM, TN, WM, WN, BK, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VPF_ERR_HIP;
@@ -545,7 +545,7 @@ static int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, ATR, BK>::ELEMS + TileCfg<BN, BTR, BK>::ELEMS);
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;

@@ -829,7 +829,7 @@ static int sa_launch(const VpfSaLayerFwd& a, int chunks, hipStream_t st)
     const size_t kv = ATT ? (size_t)HPR * 2 * LP * KLD * 2 : 0, mlp = (size_t)TOK * ALD * 2 + (size_t)2 * TOK * (8 / NJ) * 4;
     const size_t lds = (size_t)TOK * ALD * 2 + (kv > mlp ? kv : mlp) + ((!ATT && NJ == 1) ? (size_t)TOK * XLD * 4 + 2048 * 4 : 0);
     if (lds > 160 * 1024) return VPF_ERR_UNSUPPORTED;
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)sa_layer_fwd_kernel<RB, HPR, LPT, ATT, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return VPF_ERR_HIP;
@@ -1486,7 +1486,7 @@ extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
         !a.dz1 || !a.dout_attn || !a.pgrad2) return VPF_ERR_NULL;
     constexpr int RB = 2, TOK = RB * 32;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         if (hipFuncSetAttribute((const void*)sa_bwd_mlp_kernel<RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
@@ -1512,7 +1512,7 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
     constexpr int RB = 2, TOK = RB * 32;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         if (hipFuncSetAttribute((const void*)sa_bwd_qkv_kernel<RB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
@@ -1671,7 +1671,7 @@ extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
     if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
     constexpr int TOK = 64;
     const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2 + (size_t)TOK * (2 * SA_D + 8) * 2;
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)adapter_kv_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
@@ -1767,7 +1767,7 @@ extern "C" int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* args, void* stream)
     if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
     constexpr int TOK = 64;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2;
-    static bool attr = false;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)adapter_kv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;

@@ -14,6 +14,14 @@
 
 static inline int vpf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE opt-in: a process-wide "done" flag would leave the second GPU a
+// process touches without it and the launch would fail.  One flag per device ordinal.
+#define VPF_MAX_DEVICES 64
+struct VpfPerDevice {
+    bool done[VPF_MAX_DEVICES] = {};
+    bool& operator()() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= VPF_MAX_DEVICES) d = 0; return done[d]; }
+};
+
 // ------------------------------------------------------------------ bf16 helpers
 typedef uint16_t bf16_t;
 

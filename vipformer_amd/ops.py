@@ -642,7 +642,8 @@ class AttnBlockFn(torch.autograd.Function):
             L.call("vpf_dropout_bwd", dout, dz, dout.numel(), ctx.rng_st, cfg["site_res"], float(p_res))
         else:
             dz = to_bf16(dout).view(Mq, D)
-        linear_wgrad(dz, o, D, D, grad_buf(mod.o_proj.weight), grad_buf(mod.o_proj.bias))
+        wg = WgradBatch()                      # the block's weight gradients as ONE grouped launch at the end (they are off the dgrad chain)
+        wg.add(dz, o, D, D, grad_buf(mod.o_proj.weight), grad_buf(mod.o_proj.bias))
         do = linear_dgrad(dz, shadow([mod.o_proj.weight]), D, D)
         qkvw = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
         w16 = shadow(qkvw)
@@ -661,12 +662,12 @@ class AttnBlockFn(torch.autograd.Function):
                torch.empty(B * H * Lq, dtype=F32, device=dev))
         dxkv = None
         if is_self:
-            linear_wgrad(dqkv, nq, 3 * D, D, gW)
+            wg.add(dqkv, nq, 3 * D, D, gW)
             dnq = linear_dgrad(dqkv, w16, 3 * D, D)
         else:
-            linear_wgrad(dq, nq, D, D, gW[:D * D])
+            wg.add(dq, nq, D, D, gW[:D * D])
             dnq = linear_dgrad(dq, w16[:D * D], D, D)
-            linear_wgrad(dkv, nk, 2 * D, D, gW[D * D:])
+            wg.add(dkv, nk, 2 * D, D, gW[D * D:])
             if ctx.needs_input_grad[2]:
                 dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
                 lnkv = cfg["ln_kv"]
@@ -680,6 +681,7 @@ class AttnBlockFn(torch.autograd.Function):
                 dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
                 lnkv = cfg["ln_kv"]
                 layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
+        wg.flush()
         lnq = cfg["ln_q"]
         if lnq is not None:
             dbase = layernorm_bwd(dnq, base, mq, rq, lnq.weight, lnq.bias, dout if residual else None)
@@ -742,10 +744,12 @@ class MLPBlockFn(torch.autograd.Function):
             L.call("vpf_dropout_bwd", dout, dz, dout.numel(), ctx.rng_st, cfg["site_res"], float(p_res))
         else:
             dz = to_bf16(dout).view(M, D)
-        linear_wgrad(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
+        wg = WgradBatch()
+        wg.add(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
         du = linear_dgrad(dz, shadow([fc2.weight]), D, Hd, mode=EPI_GELU_BWD, aux=u, ldaux=Hd)
-        linear_wgrad(du, n, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
+        wg.add(du, n, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
         dn = linear_dgrad(du, shadow([fc1.weight]), Hd, D)
+        wg.flush()
         dx = layernorm_bwd(dn, x, mean, rstd, ln.weight, ln.bias, dout if residual else None)
         return (dx.view_as(dout), None, None) + (None,) * ctx.nparams
 

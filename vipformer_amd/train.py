@@ -290,7 +290,7 @@ class Pretrainer:
         self.losses = losses
         return losses
 
-    def capture(self, pc_t1, pc_t2, imgs, warmup: int = 3, keep_grads: bool = False):
+    def capture(self, pc_t1, pc_t2, imgs, warmup: int = 3, keep_grads: bool = False, count_nodes: bool = False):
         """Capture forward+backward (+AdamW when single-rank) into a hipGraph on static input buffers.
         Returns the static (pc_t1, pc_t2, imgs) tensors to copy new batches into.  The two views live in ONE buffer (cat(t1, t2) of
         pretrain.py:183 is then a view, not a copy per step); unless keep_grads, AdamW leaves the flat gradient zeroed for the next
@@ -320,10 +320,23 @@ class Pretrainer:
                 b.copy_(k)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
+        if count_nodes:
+            self._graph.enable_debug_mode()                     # keeps the hipGraph_t so that it can be dumped and its nodes counted
         with torch.cuda.graph(self._graph, stream=side):        # (the warm-up's stream: per-stream scratch buffers exist already)
             self.losses = self.forward_backward(*self._static)
             if self.world == 1:
                 self.optimizer_step()
+        self.graph_nodes = None
+        if count_nodes:
+            import tempfile
+            try:
+                with tempfile.TemporaryDirectory() as d:
+                    path = os.path.join(d, "step.dot")
+                    self._graph.debug_dump(path)
+                    txt = open(path).read()
+                self.graph_nodes = sum(1 for line in txt.splitlines() if "label" in line and "->" not in line)
+            except (RuntimeError, OSError):
+                self.graph_nodes = None
         return self._static
 
     def replay(self):
