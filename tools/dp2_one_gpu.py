@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Data-parallel path on ONE GPU: two ranks (processes) share cuda:0 and exchange gradients over gloo, exercising exactly what
-bench.py does at --gpus N > 1 except the RCCL transport: graph = forward + backward, then Pretrainer.exchange_and_step (region-wise
-asynchronous all-reduce on the communication stream, AdamW per region).
-Checks every step: the reduced gradient equals the sum of the two ranks' local gradients, parameters stay bitwise identical across
-ranks, losses finite, and the parameters equal a single-process AdamW on the mean gradient.
+bench.py does at --gpus N > 1 except the RCCL transport.  Two modes of Pretrainer are run from identical states:
+  plain   : hipGraph = forward + backward, then region-wise asynchronous all-reduce + AdamW per region;
+  overlap : backward split into two graphs (down to the encoder's inputs | the input stages); the gradients the first graph completed
+            travel while the second runs (Pretrainer.overlap_comm, the default for N > 1).
+Checks every step: (plain) the reduced gradient equals the sum of the two ranks' local gradients and the parameters equal a
+single-process AdamW on the mean gradient; (both) parameters and reduced gradients bitwise identical across ranks; (overlap vs plain)
+same parameters and same reduced gradients up to the order of fp32 atomics.
 usage: python tools/dp2_one_gpu.py [pairs=8] [steps=3]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,11 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def worker(rank, world, pairs, steps, port):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def run_mode(overlap, rank, world, pairs, steps, dev):
     import bench
     from vipformer_amd import ops
     from vipformer_amd.train import Pretrainer, build_models
@@ -26,37 +25,68 @@ def worker(rank, world, pairs, steps, port):
     pc, im = build_models(**A, device=dev)
     pc.train(); im.train()
     tr = Pretrainer(pc, im, world_size=world)
+    tr.overlap_comm = overlap
     tr.broadcast_parameters(0)
     torch.manual_seed(100 + rank)
     t1, t2, imgs = bench.synth_batch(pairs, A["N"], A["img"], seed=rank, device=dev)
-    tr.capture(t1, t2, imgs, warmup=2, keep_grads=True)        # (this check reads the reduced gradients after the step)
+    tr.capture(t1, t2, imgs, warmup=2, keep_grads=True)        # (these checks read the reduced gradients after the step)
+    assert (tr._graph2 is not None) == overlap
+    out = []
     for s in range(steps):
-        tr._graph.replay()
-        torch.cuda.synchronize()
-        local = tr.flat.g.clone()
-        p_before, m_before, v_before = tr.flat.p.clone(), tr.flat.m.clone(), tr.flat.v.clone()
-        step_no = float(tr.hyper[6])
-        tr.exchange_and_step()
-        torch.cuda.synchronize()
-        both = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(both, local)
-        err = float((tr.flat.g - (both[0] + both[1])).abs().max())
+        torch.manual_seed(500 + 10 * s + rank)                   # the FPS start indices of this step (drawn inside the graph? no: at capture)
+        if overlap:
+            tr.replay()
+            torch.cuda.synchronize()
+        else:
+            tr._graph.replay()
+            torch.cuda.synchronize()
+            local = tr.flat.g.clone()
+            p_before, m_before, v_before = tr.flat.p.clone(), tr.flat.m.clone(), tr.flat.v.clone()
+            step_no = float(tr.hyper[6])
+            tr.exchange_and_step()
+            torch.cuda.synchronize()
+            both = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(both, local)
+            err = float((tr.flat.g - (both[0] + both[1])).abs().max())
+            gm = (both[0] + both[1]) / world                     # single-process AdamW (torch formulas, fp32) on the MEAN gradient
+            b1, b2, lr, eps, wd = 0.9, 0.999, 1e-3, 1e-8, 0.01
+            t = step_no + 1
+            m = b1 * m_before + (1 - b1) * gm
+            v = b2 * v_before + (1 - b2) * gm * gm
+            ref = p_before * (1 - lr * wd) - (lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps)
+            dp = float((tr.flat.p - ref).abs().max())
+            assert err == 0.0 and dp < 1e-5, (err, dp)
         ps = [torch.empty_like(tr.flat.p) for _ in range(world)]
         dist.all_gather(ps, tr.flat.p)
-        same = bool(torch.equal(ps[0], ps[1]))
-        # single-process AdamW (torch formulas, fp32) on the MEAN gradient from the same state
-        gm = (both[0] + both[1]) / world
-        b1, b2, lr, eps, wd = 0.9, 0.999, 1e-3, 1e-8, 0.01
-        t = step_no + 1
-        m = b1 * m_before + (1 - b1) * gm
-        v = b2 * v_before + (1 - b2) * gm * gm
-        ref = p_before * (1 - lr * wd) - (lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps)
-        dp = float((tr.flat.p - ref).abs().max())
+        gs = [torch.empty_like(tr.flat.g) for _ in range(world)]
+        dist.all_gather(gs, tr.flat.g)
+        assert torch.equal(ps[0], ps[1]) and torch.equal(gs[0], gs[1]), "ranks diverged"
         losses = [float(x) for x in tr.losses]
+        assert all(v == v for v in losses)
+        out.append((tr.flat.p.clone(), tr.flat.g.clone(), losses))
+    return out
+
+
+def worker(rank, world, pairs, steps, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plain = run_mode(False, rank, world, pairs, steps, dev)
+    over = run_mode(True, rank, world, pairs, steps, dev)
+    for s, ((p0, g0, l0), (p1, g1, l1)) in enumerate(zip(plain, over)):
+        cos = float(torch.nn.functional.cosine_similarity(g0.double(), g1.double(), dim=0))
+        # Adam's first steps move every parameter by ~lr * sign(g): parameters whose exact gradient is 0 (a conv bias ahead of a
+        # BatchNorm) carry only fp32-atomic-order noise and may step in opposite directions -- bounded by 2 lr, and rare
+        d = (p0 - p1).abs()
+        dpm, frac = float(d.max()), float((d > 1e-5).float().mean())
         if rank == 0:
-            print(f"step {s}: losses {losses}, |allreduce - sum of local grads|max {err:.3e}, parameters identical across ranks: {same}, "
-                  f"|p - AdamW(mean grad)|max {dp:.2e}", flush=True)
-        assert same and err == 0.0 and all(v == v for v in losses) and dp < 1e-5, (same, err, dp)
+            print(f"step {s}: losses plain {l0} overlap {l1}; reduced-gradient cosine {cos:.12f}; |p_plain - p_overlap| max {dpm:.2e}, "
+                  f"fraction > 1e-5: {frac:.2e}", flush=True)
+        if s == 0:
+            # only the FIRST step starts from bitwise identical states: Adam moves a parameter whose gradient is below the fp32 summation
+            # noise by +-lr whichever way the noise points, so two equally valid runs drift apart from the second step on
+            assert abs(l0[0] - l1[0]) <= 1e-5 * abs(l0[0]) and cos > 0.99999999 and dpm < 2.5e-3 and frac < 2e-3, (l0, l1, cos, dpm, frac)
     dist.destroy_process_group()
 
 

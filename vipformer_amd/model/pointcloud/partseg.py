@@ -307,10 +307,25 @@ class _PointBackbone(nn.Module):
     """What CrossFormer_pc_mp, CrossFormer_pc_mp_ft and CrossFormer_partseg share (partseg.py:407-425, 527-545): per-point adapter,
     divide_patches, Group2Emb, position MLP, Encoder.  Sub-classes create the members under the reference's names."""
 
-    def backbone(self, pts, _groups=None):
-        return ops.PoolFn.apply(self._encode(pts, (), _groups)[0])
+    def backbone(self, pts, _groups=None, _cut=None):
+        return ops.PoolFn.apply(self._encode(pts, (), _groups, _cut)[0])
 
-    def _encode(self, pts, layer_idx=(), _groups=None):
+    def _cut_here(self, _cut, *tensors):
+        """_cut (a list, trainer extension): the encoder consumes DETACHED copies of its inputs and the (produced, consumed) pairs are
+        recorded, so that backward can run in two calls -- everything down to the encoder's inputs first, then (from the detached
+        copies' .grad) the input stages: Group2Emb, position MLP, point adapter / K,V producer.  Between the two a data-parallel
+        trainer already sends the gradients the first call completed (train.Pretrainer)."""
+        if _cut is None:
+            return tensors
+        out = []
+        for t in tensors:
+            d = t.detach().requires_grad_(t.requires_grad)
+            if t.requires_grad:
+                _cut.append((t, d))
+            out.append(d)
+        return tuple(out)
+
+    def _encode(self, pts, layer_idx=(), _groups=None, _cut=None):
         """Everything up to and including the encoder (partseg.py:527-545 / :407-425) -> (encoder output, group centres).
         _groups (an extension the trainer uses, not part of the reference signature): (neighborhood, center, event) computed by
         divide_patches on ANOTHER stream; the K / V producer -- which needs only the raw points -- is then issued first and this
@@ -335,6 +350,7 @@ class _PointBackbone(nn.Module):
         group_embs = self.group2emb(neighborhood)
         pos_embs = ops.PosMLPFn.apply(center, self.position_emb, *self.position_emb.parameters())
         if kv is not None:
+            group_embs, pos_embs, kv = self._cut_here(_cut, group_embs, pos_embs, kv)
             return enc(group_embs, pos_embs, kv, layer_idx, kv_ready=True), center
         if fuse_kv:
             cross = enc.cross_attn_1[0].module
@@ -343,8 +359,10 @@ class _PointBackbone(nn.Module):
                 # adapter -> kv LayerNorm -> K / V projection in one kernel: the per-point embedding is never read back
                 params = list(self.input_adapter.parameters()) + list(cross.kv_norm.parameters()) + [cross.attention.k_proj.weight, cross.attention.v_proj.weight]
                 kv = ops.AdapterKVFn.apply(pts, self.input_adapter, cross, *params)
+                group_embs, pos_embs, kv = self._cut_here(_cut, group_embs, pos_embs, kv)
                 return enc(group_embs, pos_embs, kv, layer_idx, kv_ready=True), center
             pts_embs = self.input_adapter(pts)
+        group_embs, pos_embs, pts_embs = self._cut_here(_cut, group_embs, pos_embs, pts_embs)
         return enc(group_embs, pos_embs, pts_embs, layer_idx), center
 
 
@@ -367,8 +385,8 @@ class CrossFormer_pc_mp(_PointBackbone):
         self.latent_head = _latent_head(num_latent_channels)
         ops.assign_sites(self, "pc")          # dropout sites by module name: independent of what else the process built
 
-    def forward(self, pts, _groups=None):
-        backbone_feats = self.backbone(pts, _groups)
+    def forward(self, pts, _groups=None, _cut=None):
+        backbone_feats = self.backbone(pts, _groups, _cut)
         feats = ops.HeadFn.apply(backbone_feats, self.latent_head, self.training, *self.latent_head.parameters())
         return feats, backbone_feats
 

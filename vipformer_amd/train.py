@@ -171,9 +171,30 @@ class Pretrainer:
         # on the side stream and ends first), then the point-cloud model (Group2Emb / adapter weight gradients come last)
         n_pc = len({id(p) for p in pc_model.parameters()})
         cut = self.flat.offsets[n_pc] if n_pc < len(self.flat.offsets) else self.flat.numel
-        self.regions = [("img", cut, self.flat.numel), ("pc", 0, cut)]
+        # N > 1 with a captured step: backward runs as two graphs -- everything down to the encoder's inputs, then the input stages
+        # (Group2Emb, position MLP, point adapter + the cross-attention K / V projections: ~1.2 of the step's 4.5 ms).  The gradients
+        # the first graph completes (the image model, the point-cloud encoder and head: 95 % of the bytes) are on the wire while
+        # the second graph runs.  "late" = parameters whose gradient the second graph writes.
+        late = ("group2emb.", "position_emb.", "input_adapter.", "encoder.cross_attn_n.0.module.kv_norm.",
+                "encoder.cross_attn_n.0.module.attention.q_proj.", "encoder.cross_attn_n.0.module.attention.k_proj.",
+                "encoder.cross_attn_n.0.module.attention.v_proj.")      # (q_proj sits between kv_norm and k_proj in the flat order)
+        names = [k for k, _ in pc_model.named_parameters()]
+        ends = self.flat.offsets[1:n_pc] + [cut]
+        runs = []                                             # maximal runs of early / late parameters of the point-cloud model
+        for k, a0, b0 in zip(names, self.flat.offsets[:n_pc], ends):
+            is_late = k.startswith(late)
+            if runs and runs[-1][0] == is_late:
+                runs[-1][2] = b0
+            else:
+                runs.append([is_late, a0, b0])
+        self.regions = [("img", cut, self.flat.numel)]
+        self.regions += [(f"pc.early{i}", a0, b0) for i, (l, a0, b0) in enumerate(runs) if not l]
+        self.late_regions = [(f"pc.late{i}", a0, b0) for i, (l, a0, b0) in enumerate(runs) if l]
+        self.regions += self.late_regions
         self.exchange = GradientExchange(self.flat.g, self.regions, world_size, process_group,
                                          wire_bf16=os.environ.get("VPF_GRAD_WIRE", "f32") == "bf16")
+        self.overlap_comm = os.environ.get("VPF_COMM_OVERLAP", "1") == "1"
+        self._graph2, self._cut = None, None
 
     # ------------------------------------------------------------------ pieces
     def broadcast_parameters(self, src: int = 0) -> None:
@@ -190,7 +211,16 @@ class Pretrainer:
         with ops.rng.pinned():       # one dropout state per step, advanced on the device by optimizer_step (graph-replayable)
             return self._forward_backward(pc_t1, pc_t2, imgs)
 
-    def _forward_backward(self, pc_t1, pc_t2, imgs):
+    def backward_inputs(self, cut) -> None:
+        """Second half of a split backward pass: from the gradients that arrived at the encoder's (detached) inputs through Group2Emb,
+        the position MLP and the point adapter / K,V producer (see _PointBackbone._cut_here)."""
+        with ops.rng.pinned():
+            pairs = [(t, d.grad) for t, d in cut if d.grad is not None]
+            if pairs:
+                torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+            ops.join_wgrad_streams()
+
+    def _forward_backward(self, pc_t1, pc_t2, imgs, cut=None):
         if not self._g_clean:
             self.flat.g.zero_()                             # pretrain.py:174 (skipped when the last AdamW launch left it zero)
         self._g_clean = False
@@ -217,11 +247,11 @@ class Pretrainer:
                     nb.record_stream(main); ct.record_stream(main)
                     groups = (nb, ct, ev)
                 img_feats = self.img_model(imgs)[0]
-            feats = self.pc_model(pc, _groups=groups)[0] if groups is not None else self.pc_model(pc)[0]
+            feats = self.pc_model(pc, _groups=groups, _cut=cut)[0]
             main.wait_stream(self._side)
             img_feats.record_stream(main)
         else:
-            feats = self.pc_model(pc)[0]
+            feats = self.pc_model(pc, _cut=cut)[0]
             img_feats = self.img_model(imgs)[0]
         if self.fused_losses:
             # both NT-Xent losses, the view mean and the weighted sum in three launches (vpf_pretrain_loss_fwd)
@@ -256,13 +286,20 @@ class Pretrainer:
         L.call("vpf_adamw_step", f.p[a:b], f.g[a:b], f.m[a:b], f.v[a:b], f.s[a:b], b - a, self.hyper,
                int(advance) | (2 if self.zero_grad_in_optimizer else 0))
 
-    def exchange_and_step(self) -> None:
+    def exchange_and_step(self, between=None) -> None:
         """N > 1: regions are reduced asynchronously on the communication stream; AdamW of a region runs as soon as it has
-        arrived (the image region's update overlaps the point-cloud region's transfer).  The bias-correction step counter advances
+        arrived (the image region's update overlaps the point-cloud region's transfer).  between: the second half of a split
+        backward pass, launched after the early regions' transfers and before the late regions'.  The bias-correction step counter advances
         with the last region; the dropout state once per step."""
         ex = self.exchange
+        late = [n for n, _, _ in self.late_regions] if between is not None else []     # (a LIST: every rank must launch its collectives in the same order)
         for n, _, _ in self.regions:
-            ex.start(n)
+            if n not in late:
+                ex.start(n)                                    # (with `between`: the gradients the first backward graph completed)
+        if between is not None:
+            between()                                          # the second backward graph runs while they travel
+            for n in late:
+                ex.start(n)
         for i, (n, a, b) in enumerate(self.regions):
             ex.finish(n)
             self._adamw_region(a, b, i + 1 == len(self.regions))
@@ -322,10 +359,18 @@ class Pretrainer:
         self._graph = torch.cuda.CUDAGraph()
         if count_nodes:
             self._graph.enable_debug_mode()                     # keeps the hipGraph_t so that it can be dumped and its nodes counted
+        split = self.world > 1 and self.overlap_comm
+        self._cut = [] if split else None
         with torch.cuda.graph(self._graph, stream=side):        # (the warm-up's stream: per-stream scratch buffers exist already)
-            self.losses = self.forward_backward(*self._static)
+            with ops.rng.pinned():
+                self.losses = self._forward_backward(*self._static, cut=self._cut)
             if self.world == 1:
                 self.optimizer_step()
+        self._graph2 = None
+        if split and self._cut:
+            self._graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph2, stream=side, pool=self._graph.pool()):
+                self.backward_inputs(self._cut)
         self.graph_nodes = None
         if count_nodes:
             import tempfile
@@ -343,7 +388,7 @@ class Pretrainer:
         """One captured step (inputs are whatever the static buffers hold)."""
         self._graph.replay()
         if self.world > 1:
-            self.exchange_and_step()
+            self.exchange_and_step(self._graph2.replay if self._graph2 is not None else None)
         return self.losses
 
 
