@@ -417,7 +417,10 @@ def img_forward(sd, imgs, a: Arch, train: bool, masks: Optional[Masks] = None, b
 
 def ntxent(z0, z1, temperature: float = 0.1):
     """lightly==1.1.21 NTXentLoss(memory_bank_size=0) -- PARITY UNPINNED (third party,
-    absent from the reference tree; call sites pretrain.py:155,196,202).
+    absent from the reference tree; call sites pretrain.py:155,196,202).  Restates
+    lightly/loss/ntx_ent_loss.py::NTXentLoss.forward as published at tag v1.1.21 (the
+    `memory_bank_size == 0` branch: no negatives from a bank, and -- in that version -- no
+    gather across ranks):
     L2-normalise; out = cat(z0,z1); logits = out.out^T / T with the diagonal removed;
     positive of row i is row i+b (mod 2b); mean cross-entropy over the 2b rows."""
     b = z0.shape[0]

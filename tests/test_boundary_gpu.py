@@ -196,6 +196,11 @@ def test_two_trainers_in_one_process_do_not_alias():
     assert abs(outs[0][0] - outs[1][0]) < 1e-6 * abs(outs[0][0])            # same weights, same sites, same state -> same loss
     assert cosine(outs[0][1], outs[1][1]) > 0.999999
     assert trainers[0].flat.g.data_ptr() != trainers[1].flat.g.data_ptr()
+    # the gradient regions of the data-parallel exchange: image model, then the point-cloud parameters whose gradients the first
+    # backward graph completes, then the input stages' (one contiguous run each: three collectives per step)
+    regs = trainers[0].regions
+    assert [n for n, _, _ in regs] == ["img", "pc.early1", "pc.late0"]
+    assert sorted((a, b) for _, a, b in regs)[0][0] == 0 and sum(b - a for _, a, b in regs) == trainers[0].flat.numel
 
 
 def test_data_parallel_two_ranks_on_one_gpu():

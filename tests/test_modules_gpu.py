@@ -420,9 +420,11 @@ def _training_step_with_dropout_vs_oracle(name):
         for v in r.values():
             v.grad = None
     le.backward()
-    # the contrastive loss at temperature 0.1 on top of a BatchNorm over a handful of samples turns the ~1e-2
-    # forward difference of the projected features into a visibly different dL/dfeats: reported, loosely bounded
-    compare("emulated, NT-Xent loss", lambda p: p.grad, 0.85, 0.90, 0.65)
+    # the contrastive loss at temperature 0.1 on top of a BatchNorm over 8 samples turns the ~1e-2 forward difference of the
+    # projected features into a rotation of dL/dfeats that every parameter gradient inherits.  Measured over the five architectures
+    # (profiles/r02_parity_report.txt): all-parameter 0.981 - 0.998, median 0.982 - 0.998, lowest tensor 0.953 - 0.987; at 32 pairs
+    # (BatchNorm over 64 samples, tests/test_fullsize_gpu.py) 0.992 / 0.991 / 0.986 and the loss within 3e-5 of the fp32 oracle.
+    compare("emulated, NT-Xent loss", lambda p: p.grad, 0.97, 0.97, 0.93)
     ck.done()
 
 

@@ -175,9 +175,11 @@ class Pretrainer:
         # (Group2Emb, position MLP, point adapter + the cross-attention K / V projections: ~1.2 of the step's 4.5 ms).  The gradients
         # the first graph completes (the image model, the point-cloud encoder and head: 95 % of the bytes) are on the wire while
         # the second graph runs.  "late" = parameters whose gradient the second graph writes.
-        late = ("group2emb.", "position_emb.", "input_adapter.", "encoder.cross_attn_n.0.module.kv_norm.",
+        late = ("group2emb.", "position_emb.", "input_adapter.", "encoder.cross_attn_n.0.module.q_norm.", "encoder.cross_attn_n.0.module.kv_norm.",
                 "encoder.cross_attn_n.0.module.attention.q_proj.", "encoder.cross_attn_n.0.module.attention.k_proj.",
-                "encoder.cross_attn_n.0.module.attention.v_proj.")      # (q_proj sits between kv_norm and k_proj in the flat order)
+                "encoder.cross_attn_n.0.module.attention.v_proj.")
+        # (q_norm and q_proj are complete after the first graph, but they sit between late parameters in the flat order: counting them
+        #  late makes the late set ONE run -- three collectives per step (image, early, late) instead of seven)
         names = [k for k, _ in pc_model.named_parameters()]
         ends = self.flat.offsets[1:n_pc] + [cut]
         runs = []                                             # maximal runs of early / late parameters of the point-cloud model
@@ -327,7 +329,7 @@ class Pretrainer:
         self.losses = losses
         return losses
 
-    def capture(self, pc_t1, pc_t2, imgs, warmup: int = 3, keep_grads: bool = False, count_nodes: bool = False):
+    def capture(self, pc_t1, pc_t2, imgs, warmup: int = 3, keep_grads: bool = False):
         """Capture forward+backward (+AdamW when single-rank) into a hipGraph on static input buffers.
         Returns the static (pc_t1, pc_t2, imgs) tensors to copy new batches into.  The two views live in ONE buffer (cat(t1, t2) of
         pretrain.py:183 is then a view, not a copy per step); unless keep_grads, AdamW leaves the flat gradient zeroed for the next
@@ -357,8 +359,6 @@ class Pretrainer:
                 b.copy_(k)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        if count_nodes:
-            self._graph.enable_debug_mode()                     # keeps the hipGraph_t so that it can be dumped and its nodes counted
         split = self.world > 1 and self.overlap_comm
         self._cut = [] if split else None
         with torch.cuda.graph(self._graph, stream=side):        # (the warm-up's stream: per-stream scratch buffers exist already)
@@ -371,17 +371,6 @@ class Pretrainer:
             self._graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph2, stream=side, pool=self._graph.pool()):
                 self.backward_inputs(self._cut)
-        self.graph_nodes = None
-        if count_nodes:
-            import tempfile
-            try:
-                with tempfile.TemporaryDirectory() as d:
-                    path = os.path.join(d, "step.dot")
-                    self._graph.debug_dump(path)
-                    txt = open(path).read()
-                self.graph_nodes = sum(1 for line in txt.splitlines() if "label" in line and "->" not in line)
-            except (RuntimeError, OSError):
-                self.graph_nodes = None
         return self._static
 
     def replay(self):
