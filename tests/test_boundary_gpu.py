@@ -213,3 +213,49 @@ def test_data_parallel_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "dp2_one_gpu.py"), "4", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dp2 on one GPU: ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_data_parallel_code_path_over_rccl_in_a_one_rank_group():
+    """Everything bench.py does at --gpus N > 1 -- broadcast, hipGraph capture with a live RCCL process group (watchdog thread
+    running), backward split into two graphs, region-wise asynchronous all-reduce on the communication stream between and behind
+    them, AdamW per region -- with the collectives really issued to RCCL ("nccl" backend) in a one-rank group, which is what one GPU
+    allows.  A sum over one rank is the identity: the parameters must equal the single-rank trainer's (same seeds, same dropout
+    state) up to fp32 atomic order, step after step."""
+    import torch.distributed as dist
+    from vipformer_amd import ops
+    from vipformer_amd.train import Pretrainer, build_models
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 1000))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        a = Hh.ARCHS["c1"]
+        B = 4
+        t1 = Hh.synth_points(1, B, a["N"]).cuda(); t2 = Hh.synth_points(2, B, a["N"]).cuda()
+        imgs = Hh.synth_images(3, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
+        start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
+        results = []
+        for force in (False, True):
+            ops.rng.seed(99)
+            torch.manual_seed(5)
+            pc, im = build_models(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], N=a["N"], img=a["img"], patch=a["patch"])
+            pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c1.json"), 100))
+            im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_img_c1.json"), 200))
+            pc.train(); im.train()
+            tr = Pretrainer(pc, im, world_size=1, force_data_parallel=force)
+            tr.broadcast_parameters(0)
+            with forced_start(start):
+                tr.capture(t1, t2, imgs, warmup=1, keep_grads=True)
+                assert (tr._graph2 is not None) == force
+                losses = tr.replay()
+                torch.cuda.synchronize()
+            results.append((float(losses[0]), tr.flat.g.clone(), tr.flat.p.clone()))
+        (l0, g0, p0), (l1, g1, p1) = results
+        assert abs(l0 - l1) < 1e-6 * abs(l0), (l0, l1)
+        assert cosine(g0, g1) > 0.999999, cosine(g0, g1)
+        d = (p0 - p1).abs()
+        assert float(d.max()) < 2.5e-3 and float((d > 1e-5).float().mean()) < 2e-3       # Adam: +- lr on noise-level gradients, rare
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -87,8 +87,9 @@ class GradientExchange:
     into the AdamW kernel's gradient scale.  No kernels of this library are involved: the class works on CPU tensors over gloo
     (tests/test_host_cpu.py) exactly as on HBM over RCCL / xGMI."""
 
-    def __init__(self, flat_g: torch.Tensor, regions, world: int, group=None, wire_bf16: bool = False):
+    def __init__(self, flat_g: torch.Tensor, regions, world: int, group=None, wire_bf16: bool = False, always: bool = False):
         self.g, self.world, self.group, self.wire_bf16 = flat_g, world, group, wire_bf16
+        self.always = always          # run the collectives even in a one-rank group (tests: the RCCL code path on a single GPU)
         self.regions = [(str(n), int(a), int(b)) for n, a, b in regions]
         covered = sorted((a, b) for _, a, b in self.regions)
         if covered[0][0] != 0 or covered[-1][1] != flat_g.numel() or any(x[1] != y[0] for x, y in zip(covered[:-1], covered[1:])):
@@ -100,7 +101,7 @@ class GradientExchange:
     def start(self, name: str) -> None:
         """Launch the all-reduce of region ``name``; on a GPU it is ordered after everything queued so far on the CURRENT stream
         (the stream that produced the region) and runs on the communication stream."""
-        if self.world == 1:
+        if self.world == 1 and not self.always:
             return
         _, a, b = next(r for r in self.regions if r[0] == name)
         view = self.g[a:b]
@@ -138,7 +139,7 @@ class Pretrainer:
     """One object = the reference's models + AdamW + NT-Xent loop state for one rank."""
 
     def __init__(self, pc_model, img_model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, temperature=0.1,
-                 cmid_weight=1.0, process_group=None, world_size: Optional[int] = None):
+                 cmid_weight=1.0, process_group=None, world_size: Optional[int] = None, force_data_parallel: bool = False):
         self.pc_model, self.img_model = pc_model, img_model
         self.temperature, self.cmid_weight = temperature, cmid_weight
         self.flat = FlatParams([pc_model, img_model])
@@ -146,6 +147,9 @@ class Pretrainer:
         if world_size is None:
             world_size = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         self.world = world_size
+        # the N > 1 code path (split capture, region-wise exchange, AdamW per region) can be forced in a one-rank group: that is how the
+        # RCCL path is exercised on a single GPU (tests/test_boundary_gpu.py)
+        self.dp = world_size > 1 or force_data_parallel
         dev = self.flat.p.device
         # {lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip}
         self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / world_size, 0.0, 0.0],
@@ -194,14 +198,14 @@ class Pretrainer:
         self.late_regions = [(f"pc.late{i}", a0, b0) for i, (l, a0, b0) in enumerate(runs) if l]
         self.regions += self.late_regions
         self.exchange = GradientExchange(self.flat.g, self.regions, world_size, process_group,
-                                         wire_bf16=os.environ.get("VPF_GRAD_WIRE", "f32") == "bf16")
+                                         wire_bf16=os.environ.get("VPF_GRAD_WIRE", "f32") == "bf16", always=force_data_parallel)
         self.overlap_comm = os.environ.get("VPF_COMM_OVERLAP", "1") == "1"
         self._graph2, self._cut = None, None
 
     # ------------------------------------------------------------------ pieces
     def broadcast_parameters(self, src: int = 0) -> None:
         """DDP constructor semantics (pretrain.py:104-105): rank 0's parameters and buffers everywhere."""
-        if self.world > 1:
+        if self.dp:
             dist.broadcast(self.flat.p, src, group=self.group)
             for m in (self.pc_model, self.img_model):
                 for b in m.buffers():
@@ -322,7 +326,7 @@ class Pretrainer:
     # ------------------------------------------------------------------ whole step
     def step(self, pc_t1, pc_t2, imgs):
         losses = self.forward_backward(pc_t1, pc_t2, imgs)
-        if self.world > 1:
+        if self.dp:
             self.exchange_and_step()
         else:
             self.optimizer_step()
@@ -359,24 +363,26 @@ class Pretrainer:
                 b.copy_(k)
         torch.cuda.synchronize()
         self._graph = torch.cuda.CUDAGraph()
-        split = self.world > 1 and self.overlap_comm
+        split = self.dp and self.overlap_comm
         self._cut = [] if split else None
-        with torch.cuda.graph(self._graph, stream=side):        # (the warm-up's stream: per-stream scratch buffers exist already)
+        # with a process group alive, RCCL's watchdog thread polls events while we capture: only THIS thread's calls may be checked
+        mode = "thread_local" if (self.dp or (dist.is_available() and dist.is_initialized())) else "global"
+        with torch.cuda.graph(self._graph, stream=side, capture_error_mode=mode):   # (the warm-up's stream: per-stream scratch buffers exist already)
             with ops.rng.pinned():
                 self.losses = self._forward_backward(*self._static, cut=self._cut)
-            if self.world == 1:
+            if not self.dp:
                 self.optimizer_step()
         self._graph2 = None
         if split and self._cut:
             self._graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph2, stream=side, pool=self._graph.pool()):
+            with torch.cuda.graph(self._graph2, stream=side, pool=self._graph.pool(), capture_error_mode=mode):
                 self.backward_inputs(self._cut)
         return self._static
 
     def replay(self):
         """One captured step (inputs are whatever the static buffers hold)."""
         self._graph.replay()
-        if self.world > 1:
+        if self.dp:
             self.exchange_and_step(self._graph2.replay if self._graph2 is not None else None)
         return self.losses
 
