@@ -333,8 +333,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    # VPF_FORCE_DP=1 (diagnostic): run the N > 1 code path -- process group, split capture, region-wise all-reduce, AdamW per region --
+    # in a one-rank group; its ms/step minus the plain one's is what data parallelism costs before any byte crosses xGMI
+    force_dp = os.environ.get("VPF_FORCE_DP", "0") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" IS RCCL on ROCm
 
     from vipformer_amd import __version__, ops
@@ -344,7 +348,7 @@ def main():
     ops.rng.seed(1234 + rank)
     pc, im = build_models(**a, device=device)
     pc.train(); im.train()
-    tr = Pretrainer(pc, im, world_size=world)
+    tr = Pretrainer(pc, im, world_size=world, force_data_parallel=force_dp)
     tr.overlap = not args.no_overlap
     ops.WGRAD_GROUP_ASYNC[0] = args.wgrad_async
     tr.broadcast_parameters(0)
@@ -441,7 +445,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s, per-GPU batch %d pairs (2x%d-pt clouds + 224x224 img, patch 16), fwd+bwd+AdamW, NT-Xent IMC+CMC, "
                                    "dropout 0.1/0.5" % (NAMES[args.arch], pairs, a["N"]),
-                       "global_batch": pairs * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "two_stream_overlap": tr.overlap,
+                       "global_batch": pairs * world, "parallelism": f"dp{world}" + (" (data-parallel code path forced in a one-rank group)" if force_dp else ""), "hip_graph": use_graph, "two_stream_overlap": tr.overlap,
                        "last_losses": losses, "losses_finite": finite,
                        "step_tflops_algorithmic": round(value * gf / 1e3, 2),
                        "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
@@ -450,7 +454,7 @@ def main():
             "roofline": roof, "kernels": legs, "variants": variants, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 
