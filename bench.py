@@ -331,6 +331,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run")
+    # VPF_DIST_BACKEND=gloo VPF_SINGLE_GPU=1 (diagnostic): N ranks sharing cuda:0 and exchanging over gloo -- the N > 1 flow of this
+    # script on a one-GPU box (the driver's own N > 1 runs use RCCL, one GPU per rank)
+    backend = os.environ.get("VPF_DIST_BACKEND", "nccl")
+    if os.environ.get("VPF_SINGLE_GPU", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     # VPF_FORCE_DP=1 (diagnostic): run the N > 1 code path -- process group, split capture, region-wise all-reduce, AdamW per region --
@@ -339,7 +344,10 @@ def main():
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" IS RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" IS RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from vipformer_amd import __version__, ops
     from vipformer_amd.train import Pretrainer, build_models
