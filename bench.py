@@ -414,6 +414,27 @@ def main():
         variants["host_fed"] = dict(value=round(pairs * world / (el / vs), 2), ms_per_step=round(el / vs * 1e3, 3),
                                     h2d_mb_per_step=round(h2d_bytes / 1e6, 1),
                                     note="pinned host batch copied into the graph's static buffers before every replay (PCIe-inclusive; never `value`)")
+        # host-fed with the DataLoader-worker work moved to the GPU: the host ships ONE raw cloud per pair and the uint8
+        # image; trans_1 twice + ToTensor / Normalize / flip run as HIP kernels in front of the replay
+        from vipformer_amd import augment as G
+        raw_h = t1.cpu().mul(2.5).add(0.3).pin_memory()
+        u8_h = (torch.rand(pairs, a["img"], a["img"], 3) * 255).to(torch.uint8).pin_memory()
+        raw_d, u8_d = torch.empty_like(raw_h, device=device), torch.empty_like(u8_h, device=device)
+
+        def host_fed_u8():
+            raw_d.copy_(raw_h, non_blocking=True); u8_d.copy_(u8_h, non_blocking=True)
+            static[0].copy_(G.augment_points(raw_d)); static[1].copy_(G.augment_points(raw_d))
+            static[2].copy_(G.image_u8_normalize(u8_d))
+            run()
+
+        for _ in range(2):
+            host_fed_u8()
+        el = timed(host_fed_u8, vs)
+        variants["host_fed_raw_clouds_uint8_images"] = dict(
+            value=round(pairs * world / (el / vs), 2), ms_per_step=round(el / vs * 1e3, 3),
+            h2d_mb_per_step=round((raw_h.numel() * 4 + u8_h.numel()) / 1e6, 1),
+            note="host ships one raw cloud per pair + the uint8 image; trans_1 x 2 and ToTensor/Normalize/flip run on the GPU "
+                 "(vipformer_amd.augment) in front of every replay")
         d1, d2, _ = synth_batch(pairs, a["N"], a["img"], seed=1000 + rank, device=device, dups=True)
         static[0].copy_(d1); static[1].copy_(d2)
         for _ in range(2):
