@@ -414,6 +414,22 @@ def main():
         variants["host_fed"] = dict(value=round(pairs * world / (el / vs), 2), ms_per_step=round(el / vs * 1e3, 3),
                                     h2d_mb_per_step=round(h2d_bytes / 1e6, 1),
                                     note="pinned host batch copied into the graph's static buffers before every replay (PCIe-inclusive; never `value`)")
+        # the same bytes, pipelined: the next batch travels on a copy stream while the current step runs (train.HostFeeder)
+        from vipformer_amd.train import HostFeeder
+        feeder = HostFeeder(tr)
+        feeder.submit(*host)
+
+        def host_fed_pipelined():
+            feeder.step()
+            feeder.submit(*host)
+
+        for _ in range(2):
+            host_fed_pipelined()
+        el = timed(host_fed_pipelined, vs)
+        variants["host_fed_pipelined"] = dict(value=round(pairs * world / (el / vs), 2), ms_per_step=round(el / vs * 1e3, 3),
+                                              h2d_mb_per_step=round(h2d_bytes / 1e6, 1),
+                                              note="the same pinned fp32 batch, but the NEXT batch is copied on a separate stream into staging "
+                                                   "buffers while the current step runs (train.HostFeeder); a device-to-device copy feeds the graph")
         # host-fed with the DataLoader-worker work moved to the GPU: the host ships ONE raw cloud per pair and the uint8
         # image; trans_1 twice + ToTensor / Normalize / flip run as HIP kernels in front of the replay
         from vipformer_amd import augment as G

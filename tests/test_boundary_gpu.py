@@ -259,3 +259,40 @@ def test_data_parallel_code_path_over_rccl_in_a_one_rank_group():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_host_feeder_pipelines_batches_into_the_captured_step():
+    """train.HostFeeder: the batch submitted BEFORE a step is the one that step consumes (losses equal the resident replay's on the same
+    data), a new batch can be submitted while the step runs, and unpinned tensors are rejected."""
+    from vipformer_amd import _lib
+    from vipformer_amd.train import HostFeeder, Pretrainer
+    pc, im, a = build("tiny")                                     # dropout 0: the loss is a function of the batch and the weights only
+    pc.train(); im.train()
+    tr = Pretrainer(pc, im)
+    tr.hyper[0] = 0.0; tr.hyper[4] = 0.0                          # lr = wd = 0: the weights stay put, so losses are comparable across steps
+    B = 8
+    batches = [(Hh.synth_points(10 + i, B, a["N"]), Hh.synth_points(20 + i, B, a["N"]),
+                Hh.synth_images(30 + i, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous()) for i in range(3)]
+    start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
+    with forced_start(start):
+        static = tr.capture(*(t.cuda() for t in batches[0]), warmup=1)
+        want = []
+        for t1, t2, im_ in batches:
+            for dst, src in zip(static, (t1, t2, im_)):
+                dst.copy_(src.cuda())
+            want.append(float(tr.replay()[0]))
+        feeder = HostFeeder(tr)
+        with pytest.raises(_lib.VpfError):
+            feeder.submit(*batches[0])                             # not pinned
+        pinned = [tuple(t.pin_memory() for t in b) for b in batches]
+        got = []
+        feeder.submit(*pinned[0])
+        for i in range(3):
+            loss = feeder.step()[0]
+            if i + 1 < 3:
+                feeder.submit(*pinned[i + 1])                      # travels while step i runs
+            got.append(float(loss))
+        with pytest.raises(_lib.VpfError):
+            feeder.step()                                          # nothing submitted
+    assert len({round(w, 4) for w in want}) == 3                   # three different batches give three different losses
+    assert all(abs(g - w) < 1e-6 * abs(w) for g, w in zip(got, want)), (got, want)
