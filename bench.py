@@ -451,6 +451,20 @@ def main():
             h2d_mb_per_step=round((raw_h.numel() * 4 + u8_h.numel()) / 1e6, 1),
             note="host ships one raw cloud per pair + the uint8 image; trans_1 x 2 and ToTensor/Normalize/flip run on the GPU "
                  "(vipformer_amd.augment) in front of every replay")
+        feeder.submit_raw(raw_h, u8_h)
+
+        def host_fed_pipelined_raw():
+            feeder.step()
+            feeder.submit_raw(raw_h, u8_h)
+
+        for _ in range(2):
+            host_fed_pipelined_raw()
+        el = timed(host_fed_pipelined_raw, vs)
+        variants["host_fed_pipelined_raw_clouds_uint8_images"] = dict(
+            value=round(pairs * world / (el / vs), 2), ms_per_step=round(el / vs * 1e3, 3),
+            h2d_mb_per_step=round((raw_h.numel() * 4 + u8_h.numel()) / 1e6, 1),
+            note="both: raw clouds + uint8 images travel while the current step runs, augmentation on the GPU in front of the replay")
+        feeder.step()
         d1, d2, _ = synth_batch(pairs, a["N"], a["img"], seed=1000 + rank, device=device, dups=True)
         static[0].copy_(d1); static[1].copy_(d2)
         for _ in range(2):

@@ -294,5 +294,12 @@ def test_host_feeder_pipelines_batches_into_the_captured_step():
             got.append(float(loss))
         with pytest.raises(_lib.VpfError):
             feeder.step()                                          # nothing submitted
+        # raw clouds + uint8 images: the augmentation runs on the device in front of the replay
+        raw = (Hh.synth_points(50, B, a["N"]) * 3.0 + 1.0).pin_memory()
+        u8 = (torch.rand(B, a["img"], a["img"], 3) * 255).to(torch.uint8).pin_memory()
+        feeder.submit_raw(raw, u8)
+        l_raw = float(feeder.step()[0])
+        assert l_raw == l_raw and abs(l_raw) < 1e3
+        assert float(static[0].norm(dim=2).max()) < 2.0 * 1.8 + 1.0   # the graph's inputs are augmented clouds: normalised, scaled <= 2, translated, jittered
     assert len({round(w, 4) for w in want}) == 3                   # three different batches give three different losses
     assert all(abs(g - w) < 1e-6 * abs(w) for g, w in zip(got, want)), (got, want)

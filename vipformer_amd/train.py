@@ -410,6 +410,7 @@ class HostFeeder:
         self.consumed = torch.cuda.Event()
         self.consumed.record(torch.cuda.current_stream())
         self._pending = False
+        self._raw = None
 
     def submit(self, pc_t1, pc_t2, imgs) -> None:
         for t in (pc_t1, pc_t2, imgs):
@@ -422,13 +423,36 @@ class HostFeeder:
             self.filled.record(self.copy_stream)
         self._pending = True
 
+    def submit_raw(self, raw_clouds, imgs_u8) -> None:
+        """The DataLoader workers' augmentations moved to the GPU (vipformer_amd.augment): the host ships ONE raw cloud per pair
+        (fp32 [b,N,3]) and the decoded uint8 image ([b,H,W,3]); step() draws the two views (trans_1 twice) and normalises / flips the
+        image on the device.  10 MB instead of 40 MB per 64 pairs."""
+        for t in (raw_clouds, imgs_u8):
+            if t.device.type != "cpu" or not t.is_pinned():
+                raise L.VpfError("HostFeeder.submit_raw takes pinned host tensors")
+        if self._raw is None or self._raw[0].shape != raw_clouds.shape or self._raw[1].shape != imgs_u8.shape:
+            self._raw = (torch.empty(raw_clouds.shape, dtype=torch.float32, device=self.tr.device),
+                         torch.empty(imgs_u8.shape, dtype=torch.uint8, device=self.tr.device))
+        self.copy_stream.wait_event(self.consumed)
+        with torch.cuda.stream(self.copy_stream):
+            self._raw[0].copy_(raw_clouds, non_blocking=True)
+            self._raw[1].copy_(imgs_u8, non_blocking=True)
+            self.filled.record(self.copy_stream)
+        self._pending = "raw"
+
     def step(self):
         if not self._pending:
             raise L.VpfError("HostFeeder.step without a submitted batch")
         cur = torch.cuda.current_stream()
         cur.wait_event(self.filled)
-        for dst, src in zip(self.tr._static, self.stage):
-            dst.copy_(src, non_blocking=True)
+        if self._pending == "raw":
+            from . import augment as G
+            st = self.tr._static
+            st[0].copy_(G.augment_points(self._raw[0])); st[1].copy_(G.augment_points(self._raw[0]))
+            st[2].copy_(G.image_u8_normalize(self._raw[1]))
+        else:
+            for dst, src in zip(self.tr._static, self.stage):
+                dst.copy_(src, non_blocking=True)
         self.consumed.record(cur)
         self._pending = False
         return self.tr.replay()
