@@ -212,6 +212,15 @@ class Pretrainer:
                     dist.broadcast(b, src, group=self.group)
             self.flat.refresh_shadow()
 
+    def sync_buffers(self, src: int = 0) -> None:
+        """DistributedDataParallel(broadcast_buffers=True) re-broadcasts rank 0's BatchNorm running statistics in front of every forward
+        pass (pretrain.py:104-105).  Training-mode BatchNorm never reads them, so the step does not pay for that; call this before
+        anything that does -- the per-epoch eval-mode probe (pretrain.py:228-276), saving a checkpoint from a rank other than 0."""
+        if self.dp:
+            for m in (self.pc_model, self.img_model):
+                for b in m.buffers():
+                    dist.broadcast(b, src, group=self.group)
+
     def forward_backward(self, pc_t1, pc_t2, imgs):
         """pretrain.py:174-209 (modality 'both').  imgs: [b,3,H,W] as the loader yields it."""
         with ops.rng.pinned():       # one dropout state per step, advanced on the device by optimizer_step (graph-replayable)
