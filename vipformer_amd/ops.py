@@ -25,7 +25,7 @@ import os
 import threading
 import weakref
 import zlib
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence
 
 import torch
 
