@@ -593,3 +593,35 @@ def test_two_cross_attention_layers_vs_reference_golden():
     report(f"two-ca grad-norm ratio min {ratio.min():.3f} max {ratio.max():.3f}")
     ck.lt("grad-norm ratio max dev", float(np.abs(ratio - 1).max()), 0.08)
     ck.done()
+
+
+def test_stochastic_depth_takes_the_block_by_block_path():
+    """max_dpr > 0 (parser.py:99 defaults to 0.5; every shipped script passes 0.0): Residual.drop_path is a real DropPath, so the fused
+    row-block kernels step aside and the block-by-block path runs with timm-style stochastic depth on top.  Eval mode: DropPath is the
+    identity -- same output as the max_dpr = 0 model with the same weights (c1 architecture: the fused path on one side, the
+    block-by-block path on the other); train mode: finite outputs and gradients for every parameter."""
+    from vipformer_amd.model.pointcloud import CrossFormer_pc_mp, PointCloudInputAdapter
+    a = Hh.ARCHS["c1"]
+    sd = Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c1.json"), 100)
+    models = []
+    for dpr in (0.0, 0.3):
+        m = CrossFormer_pc_mp(PointCloudInputAdapter((a["N"], 3), a["D"]), a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], dpr, 0.1, 0.5, True)
+        m.load_state_dict(sd)
+        models.append(m.cuda())
+    B = 4
+    pts = Hh.synth_points(300, 2 * B, a["N"]).cuda(); start = Hh.synth_start(300, 2 * B, a["N"]).cuda()
+    outs = []
+    for m in models:
+        m.eval()
+        with torch.no_grad(), forced_start(start):
+            outs.append(m(pts)[1])
+    assert rel(outs[1], outs[0]) < 5e-3, rel(outs[1], outs[0])          # two kernel paths, same mathematics (bf16 intermediates differ)
+    m = models[1]
+    m.train(); m.zero_grad()
+    torch.manual_seed(0)
+    with forced_start(start):
+        f, bb = m(pts)
+    ((bb * Hh.synth_like(700, bb.shape).cuda()).sum() + (f * Hh.synth_like(701, f.shape).cuda()).sum()).backward()
+    assert torch.isfinite(bb).all() and torch.isfinite(f).all()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
