@@ -303,3 +303,22 @@ def test_host_feeder_pipelines_batches_into_the_captured_step():
         assert float(static[0].norm(dim=2).max()) < 2.0 * 1.8 + 1.0   # the graph's inputs are augmented clouds: normalised, scaled <= 2, translated, jittered
     assert len({round(w, 4) for w in want}) == 3                   # three different batches give three different losses
     assert all(abs(g - w) < 1e-6 * abs(w) for g, w in zip(got, want)), (got, want)
+
+
+def test_zero_grad_set_to_none_does_not_detach_a_trainer_from_its_gradients():
+    """pretrain.py:174 calls optimizer.zero_grad(set_to_none=True).  On models a Pretrainer owns that drops the flat-buffer views
+    installed as ``p.grad``; the next backward pass must put them back (not write into temporaries AdamW never sees)."""
+    from vipformer_amd.train import Pretrainer
+    pc, im, a = build("tiny")
+    pc.train(); im.train()
+    tr = Pretrainer(pc, im)
+    t1, t2, imgs, start = _batch(a, 4)
+    pc.zero_grad(set_to_none=True); im.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in pc.parameters())
+    with forced_start(start):
+        tr.forward_backward(t1, t2, imgs.permute(0, 3, 1, 2))
+    torch.cuda.synchronize()
+    assert float(tr.flat.g.abs().max()) > 0.0
+    base = tr.flat.g.data_ptr()
+    for p, off in zip(tr.flat.params, tr.flat.offsets):
+        assert p.grad is not None and p.grad.data_ptr() == base + 4 * off

@@ -142,8 +142,20 @@ class ManagedFlat:
     gradient kernels accumulate into DIRECTLY, and the bf16 shadow its fused AdamW rewrites.  Parameters carry a weak reference
     (``p._vpf_managed``) -- no process-wide registry, two trainers in one process never alias, a dead trainer costs nothing."""
 
-    def __init__(self, flat_f32: torch.Tensor, flat_bf16: torch.Tensor):
-        self.p, self.s = flat_f32, flat_bf16
+    def __init__(self, flat_f32: torch.Tensor, flat_bf16: torch.Tensor, flat_grad: Optional[torch.Tensor] = None):
+        self.p, self.s, self.g = flat_f32, flat_bf16, flat_grad
+
+    def grad_view(self, param: torch.nn.Parameter, offset: int) -> torch.Tensor:
+        """``param.grad`` as the view of the flat gradient buffer it must be -- re-installed if somebody dropped it
+        (optimizer.zero_grad(set_to_none=True), model.zero_grad()) or replaced it."""
+        g = param.grad
+        if g is None or self.g is None or g.data_ptr() != self.g.data_ptr() + 4 * offset:
+            if self.g is None:
+                if g is None:
+                    param.grad = torch.zeros_like(param.data)
+                return param.grad
+            param.grad = self.g[offset:offset + param.numel()].view_as(param.data)
+        return param.grad
 
     def adopt(self, param: torch.nn.Parameter, offset: int) -> None:
         param._vpf_managed = (weakref.ref(self), offset)
@@ -203,9 +215,9 @@ class _GradSink:
         self.tmp = {}
 
     def buf(self, p):
-        owner, _ = _managed(p)
-        if owner is not None and p.grad is not None:
-            return p.grad
+        owner, off = _managed(p)
+        if owner is not None:
+            return owner.grad_view(p, off)
         t = self.tmp.get(id(p))
         if t is None:
             t = torch.zeros_like(p.data, memory_format=torch.contiguous_format)
@@ -213,8 +225,9 @@ class _GradSink:
         return t
 
     def packed(self, params):
-        if all(_managed(p)[0] is not None and p.grad is not None for p in params):
-            grads = [p.grad for p in params]
+        owners = [_managed(p) for p in params]
+        if all(o is not None for o, _ in owners):
+            grads = [o.grad_view(p, off) for p, (o, off) in zip(params, owners)]
             if _adjacent(grads):
                 n = sum(p.numel() for p in params)
                 g0 = grads[0]

@@ -57,7 +57,7 @@ class FlatParams:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.s = torch.empty(n, dtype=torch.bfloat16, device=dev)
-        self.managed = ops.ManagedFlat(self.p, self.s)      # parameters point at it weakly: no process-wide registry
+        self.managed = ops.ManagedFlat(self.p, self.s, self.g)      # parameters point at it weakly: no process-wide registry
         for p, o in zip(params, offs):
             self.p[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.p[o:o + p.numel()].view_as(p.data)
@@ -74,9 +74,14 @@ class FlatParams:
             p._vpf_ver = p._version
 
     def attach_grads(self) -> None:
-        """Re-install the flat views (after an optimizer.zero_grad(set_to_none=True))."""
+        """(Re-)install the flat views as ``p.grad`` wherever they are missing: after optimizer.zero_grad(set_to_none=True)
+        (pretrain.py:174) a parameter that receives its gradient through autograd (the image model's ``position_emb``) would otherwise
+        get a fresh tensor AdamW never sees."""
+        base = self.g.data_ptr()
         for p, o in zip(self.params, self.offsets):
-            p.grad = self.g[o:o + p.numel()].view_as(p.data)
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * o:
+                p.grad = self.g[o:o + p.numel()].view_as(p.data)
 
 
 class GradientExchange:
@@ -236,6 +241,7 @@ class Pretrainer:
             ops.join_wgrad_streams()
 
     def _forward_backward(self, pc_t1, pc_t2, imgs, cut=None):
+        self.flat.attach_grads()
         if not self._g_clean:
             self.flat.g.zero_()                             # pretrain.py:174 (skipped when the last AdamW launch left it zero)
         self._g_clean = False
