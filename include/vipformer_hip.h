@@ -158,6 +158,10 @@ int vpf_dropout_bwd(const float* dout, void* dy_bf16, long n, const uint32_t* rn
 int vpf_dropout_mask(uint8_t* out, long n, const uint32_t* rng_state, uint32_t site, float p, void* stream);
 /* rng_state = {seed_lo, seed_hi, step, 0}: step += 1 on the device (fresh masks per hipGraph replay) */
 int vpf_rng_advance(uint32_t* rng_state, void* stream);
+/* Timeline diagnostics (tools/step_timeline.py): slots[slot] = the device's constant-rate clock (vpf_wall_clock_khz ticks per ms) when the
+ * stream reaches this point; capturable, so the replayed graph of the step (pretrain.py:173-211) can be timed branch by branch. */
+int vpf_stamp(unsigned long long* slots, int slot, void* stream);
+int vpf_wall_clock_khz(void);
 int vpf_cast_f32_bf16(const float* x, void* y_bf16, long n, void* stream);
 int vpf_cast_bf16_f32(const void* x_bf16, float* y, long n, void* stream);
 /* acc[c] += sum_m x[m,c]; acc2[c] += sum_m x^2 (nullable): bias gradients and BatchNorm statistics */

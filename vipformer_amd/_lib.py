@@ -77,6 +77,8 @@ SIGS = {
     "vpf_dropout_bwd": [VP, VP, L_, VP, U32, F, VP],
     "vpf_dropout_mask": [VP, L_, VP, U32, F, VP],
     "vpf_rng_advance": [VP, VP],
+    "vpf_stamp": [VP, I, VP],
+    "vpf_wall_clock_khz": [],
     "vpf_colsum": [VP, I, L_, I, VP, VP, VP],
     "vpf_bn_finalize": [VP, VP, L_, I, F, F, I, VP, VP, VP, VP, VP],
     "vpf_bn_affine": [VP, VP, VP, I, VP, VP],

@@ -282,6 +282,25 @@ extern "C" int vpf_dropout_mask(uint8_t* out, long n, const uint32_t* rng_state,
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
+// Timeline diagnostics: one lane writes the device's constant-rate clock.  Captured into the step's hipGraph at branch boundaries it
+// shows when the REPLAYED graph really runs each branch (a kernel trace serialises differently from the unprofiled replay).
+__global__ void stamp_kernel(unsigned long long* slot) { if (threadIdx.x == 0 && blockIdx.x == 0) *slot = wall_clock64(); }
+extern "C" int vpf_stamp(unsigned long long* slots, int slot, void* stream)
+{
+    (void)hipGetLastError();
+    if (!slots) return VPF_ERR_NULL;
+    if (slot < 0) return VPF_ERR_BADSHAPE;
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots + slot);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+extern "C" int vpf_wall_clock_khz(void)
+{
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+    return khz;
+}
 __global__ void rng_advance_kernel(uint32_t* st) { if (threadIdx.x == 0 && blockIdx.x == 0) st[2] += 1u; }
 extern "C" int vpf_rng_advance(uint32_t* rng_state, void* stream)
 {

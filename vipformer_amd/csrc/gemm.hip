@@ -245,9 +245,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     tile_store<BN, BTR, BK>(lds + ACfg::ELEMS, rb[0]);
     __syncthreads();
 
-    // fused bias gradient (wgrad): the first column of workgroups also sums its dY tiles over the tokens
-    const bool do_bias = ATR && g.dbias != nullptr && bx == 0;
-    float bsum = 0.f;
+    // fused bias gradient (wgrad): the waves that own the first column of wave tiles in the first column of workgroups also sum their
+    // dY fragments over the tokens.  A lane's fragment holds 8 tokens of ONE output row: four v_dot2c_f32_bf16 against (1, 1) add them
+    // to a per-lane partial; lanes r and r + 32 (the two token halves of row r) meet in the epilogue.  The scalar LDS column sums this
+    // replaces (32 two-byte LDS reads per thread and stage) cost 11 us of the 59 us grouped launch.
+    const bool do_bias = ATR && g.dbias != nullptr && bx == 0 && wn == 0;
+    float bsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);              // bf16 (1.0, 1.0)
     for (int kt0 = 0; kt0 < nk; kt0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
@@ -263,12 +270,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
                 tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg + (kt + PF) * BK, kend, ra[p], g.xa);
                 tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + PF) * BK, kend, rb[p], g.xb);
             }
-            if (ATR && do_bias) {
-                constexpr int RG = 256 / BM > 0 ? 256 / BM : 1;                 // row groups (BM <= 256)
-                const int c = threadIdx.x % BM, rg = threadIdx.x / BM;
-                if (rg < RG)
-                    for (int r = rg; r < BK; r += RG) bsum += bf16_to_f32(cA[r * ACfg::LD + c]);
-            }
             if (!(g.dbg & 2)) {
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
@@ -282,6 +283,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                if (ATR && do_bias) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const uint4 w = __builtin_bit_cast(uint4, fa[i]);
+                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), ones2, bsum[i], false);
+                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), ones2, bsum[i], false);
+                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), ones2, bsum[i], false);
+                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), ones2, bsum[i], false);
+                    }
+                }
             }
             }
             if (kt + 1 < nk) {
@@ -296,8 +307,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     // C/D layout of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const int col_l = lane & 31, rsub = 4 * (lane >> 5);
     if (ATR && do_bias) {
-        const int c = threadIdx.x % BM;
-        if (threadIdx.x / BM < (256 / BM > 0 ? 256 / BM : 1) && m0 + c < g.M) atomicAdd(g.dbias + m0 + c, bsum);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);             // the fragment's two k halves (frag_read: lanes r and r + 32)
+            const int row = m0 + (wm * TM + i) * 32 + col_l;
+            if (lane < 32 && row < g.M) atomicAdd(g.dbias + row, tot);
+        }
     }
     if (g.mode == EPI_PARTIAL) {
         // Split-K without atomics (OPTIONAL: the caller hands over a workspace; measured SLOWER than the atomics on MI355X, see

@@ -1124,6 +1124,10 @@ def _tail_fwd(att, mlp, res_attn, res_mlp, pk, training, st, B, Lq, qkv_dummy, b
     return (x1, m2, r2, n2, u, h), out, head
 
 
+ENC_BWD_HOOK = [None]      # schedule experiments (tools/step_timeline.py): callable(cross_attention_layer, i) in front of layer i of
+                           # EncoderFusedFn.backward (i = -1: the cross-attention layer)
+
+
 class EncoderFusedFn(torch.autograd.Function):
     """Encoder.forward (partseg.py:326-340) for one cross-attention layer + the self-attention stack: the cross-attention
     layer's tail (o_proj .. MLP) and every self-attention layer run as fused row-block kernels (vpf_sa_layer_fwd /
@@ -1241,6 +1245,8 @@ class EncoderFusedFn(torch.autograd.Function):
                 npj = 0
 
         for i in range(nl - 1, -1, -1):
+            if ENC_BWD_HOOK[0] is not None:
+                ENC_BWD_HOOK[0](ca, i)
             tg = tap_grad.get(i + 1)
             if tg is not None:                              # the tapped output feeds the head AND the next layer
                 tg = tg.contiguous().float().view(M, D)
@@ -1275,6 +1281,8 @@ class EncoderFusedFn(torch.autograd.Function):
             pgrad_job(i + 1, 0, ln1)
             d = dbase
         # ---- cross-attention layer
+        if ENC_BWD_HOOK[0] is not None:
+            ENC_BWD_HOOK[0](ca, -1)
         base_ca, mq, rq, nq, xkv, mk, rk, nk, q, kv, o, lse, x1, m2, r2, n2, u, h = flat[:18]
         cross, cmlp = ca[0].module, ca[1].module
         catt, lnq, lnkv = cross.attention, cross.q_norm, cross.kv_norm
@@ -1922,6 +1930,51 @@ class NTXentFn(torch.autograd.Function):
         dz1 = torch.empty(b, D, dtype=F32, device=zn.device)
         L.call("vpf_ntxent_bwd", zn, inv, P, b, D, float(ctx.t), dloss.contiguous().float().reshape(1), dz0, dz1)
         return dz0, dz1, None
+
+
+class Timeline:
+    """Device timestamps at named points of the step (vpf_stamp: one lane writes the constant-rate clock).  The marks are ordinary
+    launches on torch's current stream, so they are captured with the step and every replay refreshes them: `read()` after a replay
+    tells when the replayed graph reached each point -- what a kernel trace cannot (it changes the overlap it observes)."""
+
+    def __init__(self, device, slots: int = 128):
+        self.buf = torch.zeros(slots, dtype=torch.int64, device=device)
+        self.names = []
+        fn = L.lib().vpf_wall_clock_khz
+        fn.argtypes, fn.restype = [], L.I
+        self.khz = int(fn())
+        if self.khz <= 0:
+            raise VpfError("vpf_wall_clock_khz failed")
+
+    def mark(self, name: str) -> None:
+        if name not in self.names:
+            if len(self.names) == self.buf.numel():
+                raise VpfError("Timeline: out of slots")
+            self.names.append(name)
+        L.call("vpf_stamp", self.buf, self.names.index(name))
+
+    def read(self) -> dict:
+        """{name: microseconds since the earliest mark} (call after a synchronize)."""
+        v = self.buf[:len(self.names)].cpu().tolist()
+        t0 = min(v)
+        return {n: (t - t0) * 1e3 / self.khz for n, t in zip(self.names, v)}
+
+
+class StampFn(torch.autograd.Function):
+    """Identity that marks `fwd_name` in the forward pass and `bwd_name` when the gradient comes back through it."""
+
+    @staticmethod
+    def forward(ctx, x, timeline, fwd_name, bwd_name):
+        ctx.timeline, ctx.bwd_name = timeline, bwd_name
+        if fwd_name:
+            timeline.mark(fwd_name)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.bwd_name:
+            ctx.timeline.mark(ctx.bwd_name)
+        return g, None, None, None
 
 
 class PretrainLossFn(torch.autograd.Function):

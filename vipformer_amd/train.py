@@ -165,6 +165,7 @@ class Pretrainer:
         self.overlap = True
         self.fused_losses = True
         self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "1") == "1"
+        self.timeline = None                 # an ops.Timeline: device timestamps at the branch boundaries (tools/step_timeline.py); None = no marks
         # optional: the point-cloud branch's grouped weight gradients on the image branch's stream behind its backward (ops.WgradDeferral).
         # Measured +0.11 ms/step on MI355X: the two branches already share the CUs for most of the step, the step is bound by the SUM
         # of kernel time (6.9 ms over 4.55 ms of wall), not by the longer stream
@@ -253,11 +254,17 @@ class Pretrainer:
             pc = torch.as_strided(pc_t1, (2 * b,) + tuple(pc_t1.shape[1:]), pc_t1.stride(), pc_t1.storage_offset())   # the views ARE cat(t1, t2)
         else:
             pc = torch.cat([pc_t1, pc_t2], dim=0)           # pretrain.py:183
+        tl = self.timeline
+        stamp = (lambda x, f, b: ops.StampFn.apply(x, tl, f, b)) if tl is not None else (lambda x, f, b: x)
+        if tl is not None:
+            tl.mark("step.begin")
         if self.overlap and self._side is not None:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
             groups = None
             with torch.cuda.stream(self._side):
+                if tl is not None:
+                    tl.mark("side.begin")
                 if self.preproc_on_side:
                     # FPS + kNN grouping ahead of the image branch on ITS stream (it has ~0.6 ms of slack): the point-cloud
                     # stream starts with the K / V producer, which needs only the raw points, and meets the groups later
@@ -267,8 +274,12 @@ class Pretrainer:
                     ev.record(self._side)
                     nb.record_stream(main); ct.record_stream(main)
                     groups = (nb, ct, ev)
-                img_feats = self.img_model(imgs)[0]
-            feats = self.pc_model(pc, _groups=groups, _cut=cut)[0]
+                    if tl is not None:
+                        tl.mark("side.preproc.end")
+                img_feats = stamp(self.img_model(imgs)[0], "img.fwd.end", "img.bwd.begin")
+            if tl is not None:
+                tl.mark("pc.fwd.begin")
+            feats = stamp(self.pc_model(pc, _groups=groups, _cut=cut)[0], "pc.fwd.end", "pc.bwd.begin")
             main.wait_stream(self._side)
             img_feats.record_stream(main)
         else:
@@ -291,6 +302,11 @@ class Pretrainer:
             ops.WGRAD_DEFER[0] = None
         if defer is not None:
             defer.drain()                                   # the point-cloud branch's grouped weight gradients, behind the image branch's backward
+        if tl is not None:
+            tl.mark("main.bwd.end")
+            if self.overlap and self._side is not None:
+                with torch.cuda.stream(self._side):
+                    tl.mark("side.bwd.end")
         if self.overlap and self._side is not None:
             # the kernels write weight gradients themselves (autograd sees no leaf accumulation on the side stream and
             # therefore does not join it): the image branch's backward must land before anything reads the gradients
