@@ -197,9 +197,13 @@ int vpf_g2e_conv1_stats_moments(const float* x, long M, int C, const float* W, c
                                 float* sums, float* sumsq, void* stream);
 int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
                         const float* beta, void* out_bf16, void* stream);
+/* backward in ONE pass over da (the gradient of the ReLU output): sum g, sum g xhat, sum g x_i per channel, combined with the input
+ * moments of the forward pass (mom = the first 72 floats of vpf_g2e_conv1_stats_moments' / vpf_g2e_bn1_prepare's scratch: sum x |
+ * sum x x^T; may be null when training == 0) into dW / db / dgamma / dbeta (+=).  ws: per-block partials, (blocks + 1) * 320 floats,
+ * up to 1025 * 320. */
 int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
-                      const float* gamma, const float* beta, int training, float* tmp128, float* dW, float* db,
-                      float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream);   /* ws: per-block partials, up to 1024 * 320 floats */
+                      const float* gamma, const float* beta, int training, const float* mom, float* dW, float* db,
+                      float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream);
 /* Group2Emb forward for group_size == 32 as two persistent weight-stationary kernels (conv weights held in registers as
  * MFMA fragments, activations of a pair of groups in LDS; only the pre-BN2 activation h3 and what backward needs reach HBM):
  *   vpf_g2e_fold_bn1: BatchNorm-1 folded into the first conv (ab1 from vpf_bn_affine)
@@ -262,7 +266,7 @@ int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const float* P, int b
                    float* dz0, float* dz1, void* stream);
 /* Group2Emb (utils.py:150-189), training mode, the BatchNorm bookkeeping between the kernels as single launches:
  * vpf_g2e_bn1_prepare = vpf_g2e_conv1_stats_moments + vpf_bn_finalize + vpf_bn_affine + vpf_g2e_fold_bn1 (stat = mean | rstd [128],
- * ab = a | b [128], w1e [64*C], b1e [64]; scratch f32 [72 + 512*72]);  vpf_bn_partials_finalize = vpf_sum_rows_f32 + vpf_bn_finalize
+ * ab = a | b [128], w1e [64*C], b1e [64]; scratch f32 [72 + 512*72], its first 72 floats hold the input moments on return);  vpf_bn_partials_finalize = vpf_sum_rows_f32 + vpf_bn_finalize
  * + vpf_bn_affine on per-workgroup partial rows [nrows][2C] (C % 64 == 0). */
 int vpf_g2e_bn1_prepare(const float* x, long M, int C, const float* W, const float* b, float* scratch, const float* gamma, const float* beta,
                         float eps, float momentum, float* running_mean, float* running_var, long long* num_batches, float* stat, float* ab,

@@ -392,7 +392,8 @@ __global__ void __launch_bounds__(1024) g2e_bn1_prepare_kernel(const float* __re
                                                               const float* __restrict__ beta, float eps, float momentum,
                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
                                                               long long* __restrict__ num_batches, float* __restrict__ stat,
-                                                              float* __restrict__ ab, float* __restrict__ w1e, float* __restrict__ b1e)
+                                                              float* __restrict__ ab, float* __restrict__ w1e, float* __restrict__ b1e,
+                                                              float* __restrict__ mom_out)
 {
     __shared__ float fold[14][72];
     __shared__ float mom[72];
@@ -413,6 +414,7 @@ __global__ void __launch_bounds__(1024) g2e_bn1_prepare_kernel(const float* __re
 #pragma unroll
         for (int k = 0; k < 14; ++k) t += fold[k][e];
         mom[e] = t;
+        mom_out[e] = t;                      // kept for the backward pass (vpf_g2e_conv1_bwd)
     }
     __syncthreads();
     const int c = threadIdx.x;
@@ -452,7 +454,7 @@ extern "C" int vpf_g2e_bn1_prepare(const float* x, long M, int C, const float* W
     const int nblk = grid_for(M, 256 * 4, 512);
     hipLaunchKernelGGL(g2e_moments_kernel, dim3(nblk), dim3(256), 0, st, x, M, C, scratch + 72);
     hipLaunchKernelGGL(g2e_bn1_prepare_kernel, dim3(1), dim3(1024), 0, st, (const float*)(scratch + 72), nblk, M, C, W, b, gamma, beta, eps, momentum,
-                       running_mean, running_var, num_batches, stat, ab, w1e, b1e);
+                       running_mean, running_var, num_batches, stat, ab, w1e, b1e, scratch);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -545,119 +547,140 @@ extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-// backward: pass 0 tmp[c] += sum g, tmp[64+c] += sum g*xhat ; pass 1 dW/db (and dgamma/dbeta from tmp).
-// thread = (row, 8 channels): 16-byte loads of the incoming gradient, per-thread partial sums, LDS fold per block.
-__global__ void __launch_bounds__(512) g2e_conv1_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
+// Backward of Conv1d(C, 64) + BatchNorm-1 + ReLU in ONE pass over the incoming gradient.  With g = da masked by the ReLU and
+// xh = the normalised activation, BatchNorm's backward is dh = gamma rs (g - mean(g) - xh mean(g xh)); every gradient is a combination of
+//   S_g = sum g,  S_gxh = sum g xh,  S_gx[i] = sum g x_i                      (this kernel: 5 values per channel)
+// and of sums over the INPUT alone, which the forward pass already has (g2e_moments_kernel: S1 = sum x, S2 = sum x x^T):
+//   sum_r xh_c = 0,   sum_r xh_c x_i = rs_c (sum_j W_cj S2[j][i] + (b_c - mu_c) S1[i])
+//   dW_ci = gamma_c rs_c (S_gx[i] - S_g / M S1[i] - S_gxh / M sum_r xh_c x_i),   db_c = 0,   dgamma_c = S_gxh,   dbeta_c = S_g.
+// (The two-pass form -- statistics, then dh -- read the 50 MB gradient twice: 2 x 117 us of the point-cloud branch's tail.)
+// thread = (row, 8 channels): 16-byte loads of the incoming gradient, four rows in flight, per-thread partial sums, LDS fold per block.
+__global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
                                                           const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ stat,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta, int training,
-                                                          const float* __restrict__ tmp, int pass, float* __restrict__ partial)
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ partial)
 {
-    __shared__ float redf[16 * 320];             // [8 waves x 2 halves][5 values][64 channels]
+    __shared__ float redf[8 * 320];              // [4 waves x 2 halves][5 values][64 channels]
     const int t = threadIdx.x, rl = t >> 3, cg = (t & 7) * 8;
-    float w[8][3], bb[8], mu[8], rs[8], ga[8], be[8], sg[8], sgx[8];
+    float wr[8][3], br[8], ga[8], be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = cg + j;
-        bb[j] = b[c]; mu[j] = stat[c]; rs[j] = stat[64 + c]; ga[j] = gamma[c]; be[j] = beta[c];
-        sg[j] = pass ? tmp[c] / (float)M : 0.f; sgx[j] = pass ? tmp[64 + c] / (float)M : 0.f;
+        const float rs = stat[64 + c];
+        br[j] = (b[c] - stat[c]) * rs; ga[j] = gamma[c]; be[j] = beta[c];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) w[j][i] = i < C ? W[c * C + i] : 0.f;
+        for (int i = 0; i < 3; ++i) wr[j][i] = i < C ? W[c * C + i] * rs : 0.f;
     }
     float a0[8], a1[8], aw[8][3];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { a0[j] = a1[j] = 0.f; aw[j][0] = aw[j][1] = aw[j][2] = 0.f; }
-    const long rstep = (long)gridDim.x * 64;
-    auto row_math = [&](const uint4 dv, const float x0, const float x1, const float x2, const float live) {
+    const long rstep = (long)gridDim.x * 32;
+    auto row_math = [&](const uint4 dv, const float x0, const float x1, const float x2) {
         const uint32_t uw[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float h = w[j][0] * x0 + w[j][1] * x1 + w[j][2] * x2 + bb[j];
-            const float xh = (h - mu[j]) * rs[j];
+            const float xh = wr[j][0] * x0 + wr[j][1] * x1 + wr[j][2] * x2 + br[j];
             float g = (j & 1) ? __uint_as_float(uw[j >> 1] & 0xffff0000u) : __uint_as_float(uw[j >> 1] << 16);
             if (xh * ga[j] + be[j] <= 0.f) g = 0.f;
-            if (!pass) { a0[j] += g; a1[j] += g * xh; }
-            else {
-                const float dh = live * (training ? ga[j] * rs[j] * (g - sg[j] - xh * sgx[j]) : ga[j] * rs[j] * g);
-                a0[j] += dh; aw[j][0] += dh * x0; aw[j][1] += dh * x1; aw[j][2] += dh * x2;
-            }
+            a0[j] += g; a1[j] += g * xh; aw[j][0] += g * x0; aw[j][1] += g * x1; aw[j][2] += g * x2;
         }
     };
-    for (long r = (long)blockIdx.x * 64 + rl; r < M; r += 2 * rstep) {
-        // two rows in flight per thread (one row at a time pays the load latency M / (grid * 64) times in sequence)
-        const long rb = r + rstep;
-        const bool okb = rb < M;
-        const uint4 dva = *reinterpret_cast<const uint4*>(da + (size_t)r * 64 + cg);
-        const uint4 dvb = okb ? *reinterpret_cast<const uint4*>(da + (size_t)rb * 64 + cg) : make_uint4(0, 0, 0, 0);
-        const float xa0 = x[(size_t)r * C], xa1 = C > 1 ? x[(size_t)r * C + 1] : 0.f, xa2 = C > 2 ? x[(size_t)r * C + 2] : 0.f;
-        const float xb0 = okb ? x[(size_t)rb * C] : 0.f, xb1 = (okb && C > 1) ? x[(size_t)rb * C + 1] : 0.f, xb2 = (okb && C > 2) ? x[(size_t)rb * C + 2] : 0.f;
-        row_math(dva, xa0, xa1, xa2, 1.f);
-        row_math(dvb, xb0, xb1, xb2, okb ? 1.f : 0.f);
+    for (long r = (long)blockIdx.x * 32 + rl; r < M; r += 4 * rstep) {
+        uint4 dv[4]; float xv[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long ru = r + u * rstep;
+            const bool ok = ru < M;
+            dv[u] = ok ? *reinterpret_cast<const uint4*>(da + (size_t)ru * 64 + cg) : make_uint4(0, 0, 0, 0);     // (a zero gradient adds nothing)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xv[u][i] = (ok && i < C) ? x[(size_t)ru * C + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row_math(dv[u], xv[u][0], xv[u][1], xv[u][2]);
     }
-    // Fold the 64 row-lanes of every channel WITHOUT atomics: lanes that share a channel group differ in lane bits 3..5
-    // (3 shuffles per value), the 8 waves meet in LDS, and the block leaves one partial row [5][64] for the fold kernel
-    // (hundreds of blocks adding into the same 320 addresses used to serialise in L2).
-    // lane ^ 8 = a rotate by 8 inside the 16-lane DPP row, lane ^ 16 = a ds_swizzle; the two 32-lane halves go to LDS separately
+    // Fold the 8 row-lanes of every channel group WITHOUT atomics: lanes that share a channel group differ in lane bits 3..5
+    // (lane ^ 8 = a rotate by 8 inside the 16-lane DPP row, lane ^ 16 = a ds_swizzle; the two 32-lane halves go to LDS separately),
+    // the 4 waves meet in LDS, and the block leaves one partial row [5][64] for the fold kernel
 #define VPF_FOLD2(v) do { v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));   \
                           v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); } while (0)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { VPF_FOLD2(a0[j]); VPF_FOLD2(a1[j]); VPF_FOLD2(aw[j][0]); VPF_FOLD2(aw[j][1]); VPF_FOLD2(aw[j][2]); }
 #undef VPF_FOLD2
     const int wv = t >> 6, lane = t & 63;
-    __syncthreads();
     if ((lane & 31) < 8) {
         float* dst = redf + (wv * 2 + (lane >> 5)) * 320 + (lane & 7) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { dst[j] = a0[j]; dst[64 + j] = a1[j]; dst[128 + j] = aw[j][0]; dst[192 + j] = aw[j][1]; dst[256 + j] = aw[j][2]; }
     }
     __syncthreads();
-    if (t < 320) {
+    for (int e = t; e < 320; e += 256) {
         float sacc = 0.f;
 #pragma unroll
-        for (int w8 = 0; w8 < 16; ++w8) sacc += redf[w8 * 320 + t];
-        partial[(size_t)blockIdx.x * 320 + t] = sacc;
+        for (int w8 = 0; w8 < 8; ++w8) sacc += redf[w8 * 320 + e];
+        partial[(size_t)blockIdx.x * 320 + e] = sacc;
     }
 }
-// pass 0: tmp[c] = sum g, tmp[64+c] = sum g*xhat; pass 1: db / dW += the folded partials, dgamma / dbeta += tmp
-__global__ void __launch_bounds__(1024) g2e_conv1_fold_kernel(const float* __restrict__ partial, int nblk, int C, int pass, float* __restrict__ tmp,
-                                                             float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta)
+// fold of the per-block partial rows [nblk][320] in a fixed order: block = 32 of the 320 columns x 32 row groups -> sums[320]
+__global__ void __launch_bounds__(1024) g2e_conv1_fold_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ sums)
 {
-    __shared__ float fold[16][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, v = blockIdx.x;      // 5 blocks: one per value
-    float s0 = 0.f, s1 = 0.f;
+    __shared__ float fold[32][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5, col = blockIdx.x * 32 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = rg;
-    for (; r + 16 < nblk; r += 32) { s0 += partial[(size_t)r * 320 + v * 64 + c]; s1 += partial[(size_t)(r + 16) * 320 + v * 64 + c]; }
-    for (; r < nblk; r += 16) s0 += partial[(size_t)r * 320 + v * 64 + c];
-    fold[rg][c] = s0 + s1;
+    for (; r + 96 < nblk; r += 128) {
+        s0 += partial[(size_t)r * 320 + col]; s1 += partial[(size_t)(r + 32) * 320 + col];
+        s2 += partial[(size_t)(r + 64) * 320 + col]; s3 += partial[(size_t)(r + 96) * 320 + col];
+    }
+    for (; r < nblk; r += 32) s0 += partial[(size_t)r * 320 + col];
+    fold[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0) {
         float tsum = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tsum += fold[k][c];
-        if (!pass) { if (v == 0) tmp[c] = tsum; else if (v == 1) tmp[64 + c] = tsum; }
-        else {
-            if (v == 0) { db[c] += tsum; dbeta[c] += tmp[c]; }
-            else if (v == 1) dgamma[c] += tmp[64 + c];
-            else if (v - 2 < C) dW[c * C + (v - 2)] += tsum;
-        }
+        for (int k = 0; k < 32; ++k) tsum += fold[k][cl];
+        sums[col] = tsum;
+    }
+}
+// the algebra of the header comment, in double (the terms of dW cancel to a few percent of their size)
+__global__ void g2e_conv1_grads_kernel(const float* __restrict__ sums, const float* __restrict__ mom, long M, int C, const float* __restrict__ W,
+                                       const float* __restrict__ b, const float* __restrict__ stat, const float* __restrict__ gamma, int training,
+                                       float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    const double Sg = sums[c], Sgxh = sums[64 + c], rs = stat[64 + c], ga = gamma[c];
+    dgamma[c] += (float)Sgxh;
+    dbeta[c] += (float)Sg;
+    if (!training) {
+        db[c] += (float)(ga * rs * Sg);
+        for (int i = 0; i < C; ++i) dW[c * C + i] += (float)(ga * rs * (double)sums[128 + 64 * i + c]);
+        return;
+    }
+    // (db = gamma rs (S_g - M mean(g) - mean(g xh) sum xh) = 0: a bias in front of a training-mode BatchNorm has no gradient)
+    for (int i = 0; i < C; ++i) {
+        double sxhx = ((double)b[c] - (double)stat[c]) * (double)mom[i];
+        for (int j = 0; j < C; ++j) sxhx += (double)W[c * C + j] * (double)(j <= i ? mom[8 + i * 8 + j] : mom[8 + j * 8 + i]);
+        sxhx *= rs;
+        const double v = (double)sums[128 + 64 * i + c] - Sg / (double)M * (double)mom[i] - Sgxh / (double)M * sxhx;
+        dW[c * C + i] += (float)(ga * rs * v);
     }
 }
 extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
-                                 const float* gamma, const float* beta, int training, float* tmp128, float* dW, float* db,
+                                 const float* gamma, const float* beta, int training, const float* mom, float* dW, float* db,
                                  float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !tmp128 || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
+    if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
+    if (training && !mom) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > 3) return VPF_ERR_BADSHAPE;
-    int grid = grid_for(M, 64 * 8, 1024);
-    if ((long)grid * 320 > ws_floats) grid = (int)(ws_floats / 320);
+    int grid = grid_for(M, 32 * 4, 1024);
+    if ((long)(grid + 1) * 320 > ws_floats) grid = (int)(ws_floats / 320) - 1;
     if (grid < 1) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
-    for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(512), 0, st, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma,
-                           beta, training, (const float*)tmp128, pass, ws);
-        hipLaunchKernelGGL(g2e_conv1_fold_kernel, dim3(5), dim3(1024), 0, st, (const float*)ws, grid, C, pass, tmp128, dW, db, dgamma, dbeta);
-    }
+    float* sums = ws + (size_t)grid * 320;
+    hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(256), 0, st, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma, beta, ws);
+    hipLaunchKernelGGL(g2e_conv1_fold_kernel, dim3(10), dim3(1024), 0, st, (const float*)ws, grid, sums);
+    hipLaunchKernelGGL(g2e_conv1_grads_kernel, dim3(1), dim3(64), 0, st, (const float*)sums, mom, M, C, W, b, stat, gamma, training, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

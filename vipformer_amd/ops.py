@@ -1526,6 +1526,7 @@ class Group2EmbFn(torch.autograd.Function):
         Dm = c4.weight.shape[0]
         w1 = c1.weight.data.view(64, C)
         stat1 = torch.empty(128, dtype=F32, device=dev)
+        scratch = None
         fast = K == 32 and C == 3 and Dm % 32 == 0 and Dm <= 512
         merged = training and fast and G2E_BN_MERGED[0]
         if merged:
@@ -1606,6 +1607,7 @@ class Group2EmbFn(torch.autograd.Function):
                 h4 = linear_fwd(a3, shadow([c4.weight]), Dm, 256, c4.bias.data)
                 L.call("vpf_group_max_fwd", h4, NG, K, Dm, out, 0, arg4)
         ctx.mod, ctx.training, ctx.dims, ctx.fused = mod, training, (Bq, G, K, C, Dm), fused
+        ctx.mom = scratch[:72] if scratch is not None else None          # sum x | sum x x^T: the one-pass BatchNorm-1 backward needs them
         ctx.save_for_backward(x, stat1, a1, arg2, h2, gmax, h3, stat2, ab2, arg4)
         return out.view(Bq, G, Dm)
 
@@ -1666,10 +1668,9 @@ class Group2EmbFn(torch.autograd.Function):
         L.call("vpf_group_max_scatter_add", dgmax, arg2, NG, K, 128, dh2)
         linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
         da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
-        tmp = torch.empty(128, dtype=F32, device=dev)
-        ws = torch.empty(1024 * 320, dtype=F32, device=dev)                      # per-block partial sums (no atomics)
+        ws = torch.empty(1025 * 320, dtype=F32, device=dev)                      # per-block partial sums (no atomics)
         L.call("vpf_g2e_conv1_bwd", x, da1, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
-               int(training), tmp, grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight), grad_buf(bn1.bias), ws, ws.numel())
+               int(training), ctx.mom, grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight), grad_buf(bn1.bias), ws, ws.numel())
         return (None, None, None) + (None,) * ctx.nparams
 
 
