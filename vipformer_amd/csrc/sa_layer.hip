@@ -1543,9 +1543,9 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapte
     bf16_t* sA1 = lds;                                  // [TOK][A1LD]  hidden layer (bf16)
     bf16_t* actA = lds + TOK * A1LD;                    // [TOK][ALD]   normalised per-point embedding
     float* sStat = reinterpret_cast<float*>(actA + TOK * ALD);      // [TOK][NWV] float2
-    bf16_t* sX = reinterpret_cast<bf16_t*>(sStat + TOK * NWV * 2);  // [TOK][ALD]   per-point embedding before the LayerNorm (staging for HBM)
-    bf16_t* sKV = sX + TOK * ALD;                                   // [TOK][KVLD]  K | V rows (staging for HBM)
-    constexpr int KVLD = 2 * SA_D + 8;
+    bf16_t* sX = reinterpret_cast<bf16_t*>(sStat + TOK * NWV * 2);  // [TOK][ALD]   per-point embedding before the LayerNorm, then the K rows, then
+                                                                    //              the V rows (staging for HBM).  79 KB in all: two workgroups share a
+                                                                    //              CU and one's MFMA phases fill the other's LayerNorm / store phases
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const long M = a.M, m0 = (long)blockIdx.x * TOK;
     const int nvalid = (int)min((long)TOK, M - m0);
@@ -1633,30 +1633,16 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapte
     __syncthreads();
     sa_tile_store_rows<TOK, NT>(sX, (bf16_t*)a.xkv, SA_D, 0, m0, nvalid);
     sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.nk, SA_D, 0, m0, nvalid);
-    // ---- K | V = normalised . Wkv^T   (two 256-channel halves, staged in LDS and stored as whole rows)
+    // ---- K | V = normalised . Wkv^T   (two 256-channel halves, each staged in LDS and stored as whole 512-byte half rows)
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
         sa_zero<RB, NJ>(acc);
         sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wkv, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
         if (part == 0) sa_wprefetch((const bf16_t*)a.Wkv, SA_D / 16, 0, 8 + NJ * wave, wpre);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    uint2 w;
-                    w.x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
-                    w.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-                    *reinterpret_cast<uint2*>(sKV + (i * 32 + t) * KVLD + part * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) = w;
-                }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < TOK * 64 / NT; ++it) {
-        const int e = threadIdx.x + it * NT, row = e >> 6, ch = e & 63;
-        const uint4 v = *reinterpret_cast<const uint4*>(sKV + row * KVLD + ch * 8);
-        if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.kv + (size_t)(m0 + row) * (2 * SA_D) + ch * 8) = v;
+        __syncthreads();                                             // the row pass that read sX last is done
+        sa_store_bf16<RB, NJ>(acc, sX, 0, nullptr, SA_D, 0, m0, nvalid);
+        __syncthreads();
+        sa_tile_store_rows<TOK, NT>(sX, (bf16_t*)a.kv, 2 * SA_D, part * SA_D, m0, nvalid);
     }
 }
 
@@ -1670,7 +1656,8 @@ extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
     if (a.M <= 0 || a.C <= 0 || a.C > 8) return VPF_ERR_BADSHAPE;
     if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
     constexpr int TOK = 64;
-    const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2 + (size_t)TOK * (2 * SA_D + 8) * 2;
+    const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2;
+    static_assert(TOK * 72 * 2 + TOK * ALD * 2 + TOK * 8 * 2 * 4 + TOK * ALD * 2 <= 80 * 1024, "two workgroups per CU");
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)adapter_kv_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
