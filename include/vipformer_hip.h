@@ -204,6 +204,11 @@ int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const flo
 int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
                       const float* gamma, const float* beta, int training, const float* mom, float* dW, float* db,
                       float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream);
+/* ... the same with the second conv's input gradient folded in: da = dh2 . W2 (W2 = Conv1d(64, 128).weight as bf16 [128][64]) is formed
+ * on the matrix cores and consumed in registers; dh2 bf16 [M, 128], 16-byte aligned */
+int vpf_g2e_conv1_bwd_fused(const float* x, const void* dh2_bf16, long M, int C, const float* W, const float* b, const float* stat,
+                            const float* gamma, const float* beta, int training, const float* mom, const void* W2_bf16,
+                            float* dW, float* db, float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream);
 /* Group2Emb forward for group_size == 32 as two persistent weight-stationary kernels (conv weights held in registers as
  * MFMA fragments, activations of a pair of groups in LDS; only the pre-BN2 activation h3 and what backward needs reach HBM):
  *   vpf_g2e_fold_bn1: BatchNorm-1 folded into the first conv (ab1 from vpf_bn_affine)

@@ -625,3 +625,30 @@ def test_stochastic_depth_takes_the_block_by_block_path():
     assert torch.isfinite(bb).all() and torch.isfinite(f).all()
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_group2emb_first_conv_backward_fused_matches_two_kernels():
+    """vpf_g2e_conv1_bwd_fused (conv2's input gradient formed on the matrix cores and consumed in registers) against the dgrad GEMM +
+    vpf_g2e_conv1_bwd pair it replaces: the same first-conv / BatchNorm-1 gradients up to the bf16 rounding of the gradient tensor the
+    pair materialises."""
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.utils import Group2Emb
+    torch.manual_seed(3)
+    grads = []
+    for fused in (False, True):
+        ops.G2E_CONV1_BWD_FUSED[0] = fused
+        ops.clear_managed_shadows()
+        torch.manual_seed(7)
+        g2e = Group2Emb(256).cuda().train()
+        x = Hh.synth_points(11, 6 * 96, 32).view(6, 96, 32, 3).cuda()
+        out = g2e(x)
+        (out * Hh.synth_like(12, out.shape).cuda()).sum().backward()
+        grads.append({k: p.grad.clone() for k, p in g2e.named_parameters()})
+    ops.G2E_CONV1_BWD_FUSED[0] = True
+    ops.clear_managed_shadows()
+    for k in ("first_conv.0.weight", "first_conv.1.weight", "first_conv.1.bias"):
+        a, b = grads[0][k], grads[1][k]
+        assert cosine(a, b) > 0.9999 and rel(a, b) < 1e-2, (k, cosine(a, b), rel(a, b))
+    for k in grads[0]:
+        if not k.startswith("first_conv.0") and not k.startswith("first_conv.1"):
+            assert cosine(grads[0][k], grads[1][k]) > 0.9999, k          # (untouched by the switch: fp32 atomic order only)

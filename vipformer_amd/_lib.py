@@ -111,6 +111,7 @@ SIGS = {
     "vpf_group_max_scatter_add": [VP, VP, L_, I, I, VP, VP],
     "vpf_g2e_conv1_apply": [VP, L_, I, VP, VP, VP, VP, VP, VP, VP],
     "vpf_g2e_conv1_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, L_, VP],
+    "vpf_g2e_conv1_bwd_fused": [VP, VP, L_, I, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, VP, L_, VP],
     "vpf_patchify": [VP, L_, L_, L_, L_, I, I, I, I, I, VP, VP],
     "vpf_ntxent_fwd": [VP, VP, I, I, F, VP, VP, VP, VP, VP, VP],
     "vpf_ntxent_bwd": [VP, VP, VP, I, I, F, VP, VP, VP, VP],

@@ -620,6 +620,108 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restr
         partial[(size_t)blockIdx.x * 320 + e] = sacc;
     }
 }
+// The same sums with the second conv's input gradient folded in: da = dh2 . W2 (Conv1d(64, 128) backward, K = 128) is produced on the
+// matrix cores from dh2 rows read straight from HBM in A-fragment layout and consumed in the accumulator registers -- the 50 MB bf16
+// da tensor is neither written nor read (a 42 us GEMM + a 55 us sums pass -> one pass over dh2).  A wave owns 32 rows x 64 channels per
+// iteration; in the accumulator layout a lane owns ONE channel per 32-channel tile (column = lane & 31) and 16 of the 32 rows, so the
+// five per-channel sums are plain per-lane accumulations; the rows' inputs x sit in a wave-private LDS slot.
+typedef __attribute__((ext_vector_type(8))) __bf16 g2e_bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float g2e_f32x16_t;
+__global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dh2, long M, int C,
+                                                                const float* __restrict__ W, const float* __restrict__ b,
+                                                                const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const bf16_t* __restrict__ W2,
+                                                                float* __restrict__ partial)
+{
+    __shared__ float redf[4 * 320];              // [4 waves][5 values][64 channels]
+    // one buffer, two lives: W2 [128 out][64 in] (rows padded to 72) while the fragments are built, then per wave the accumulator tile
+    // [16][64] f32
+    __shared__ __attribute__((aligned(16))) bf16_t sBuf[128 * 72];
+    bf16_t* sW2 = sBuf;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, hl = lane >> 5;
+    // W2 as B fragments: column n = input channel (lane & 31, + 32 j), 8 consecutive k = output channels 16 ks + 8 hl ..  The matrix is
+    // k-strided for that ([k][n] rows): staged in LDS and read with the transposing ds_read_b64_tr_b16 (as gemm.hip's frag_read), once.
+    for (int e = threadIdx.x; e < 128 * 8; e += 256)
+        *reinterpret_cast<uint4*>(sW2 + (e >> 3) * 72 + (e & 7) * 8) = *reinterpret_cast<const uint4*>(W2 + (size_t)e * 8);
+    __syncthreads();
+    g2e_bf16x8_t bw[2][8];
+    {
+        typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, h = g >> 1, roff = 16 * (g & 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const bf16_t* a0 = sW2 + (ks * 16 + 8 * h + q) * 72 + 32 * j + roff + 4 * p4;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * 72));
+                s16x8_t v;
+                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+                bw[j][ks] = __builtin_bit_cast(g2e_bf16x8_t, v);
+            }
+    }
+    __syncthreads();                             // W2 is in registers: the buffer now belongs to the waves' tiles
+    float* sAcc = reinterpret_cast<float*>(sBuf) + wave * 16 * 64;          // [16][64] (4 x 4 KB of the 18 KB)
+    float wr[2][3], br[2], ga[2], be[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = 32 * j + cl;
+        const float rs = stat[64 + c];
+        br[j] = (b[c] - stat[c]) * rs; ga[j] = gamma[c]; be[j] = beta[c];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wr[j][i] = i < C ? W[c * C + i] * rs : 0.f;
+    }
+    float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, aw[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    __shared__ float4 sXrow[4][32];              // the current tile's input rows, per wave
+    const long ntiles = (M + 31) / 32, tstep = (long)gridDim.x * 4;
+    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += tstep) {
+        const long rr = min(tile * 32 + cl, M - 1);                // (rows past the end: clamped loads, their gradient is zeroed below)
+        const int nrows = (int)min(32L, M - tile * 32);
+        const bf16_t* src = dh2 + (size_t)rr * 128 + 8 * hl;      // A-fragment layout: row = lane & 31, 8 values at k = 16 ks + 8 hl
+        uint4 af[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const uint4*>(src + ks * 16);
+        {
+            const float* xp = x + (size_t)rr * C;
+            sXrow[wave][cl] = make_float4(xp[0], C > 1 ? xp[1] : 0.f, C > 2 ? xp[2] : 0.f, 0.f);   // (wave-private: the wave's own LDS accesses are ordered)
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            g2e_f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g2e_bf16x8_t, af[ks]), bw[j][ks], acc, 0, 0, 0);
+            // the 16 accumulator registers go through a wave-private LDS slot so that the per-row arithmetic can be a ROLLED loop: fully
+            // unrolled, the scheduler keeps ~180 registers of row products alive (280 in all, one wave per SIMD, 100 us)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sAcc[r * 64 + lane] = acc[r];
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;    // C / D layout of the 32 x 32 MFMA
+                const float4 xr = sXrow[wave][row];
+                const float xh = wr[j][0] * xr.x + wr[j][1] * xr.y + wr[j][2] * xr.z + br[j];
+                float g = sAcc[r * 64 + lane];
+                if (xh * ga[j] + be[j] <= 0.f || row >= nrows) g = 0.f;
+                a0[j] += g; a1[j] += g * xh; aw[j][0] += g * xr.x; aw[j][1] += g * xr.y; aw[j][2] += g * xr.z;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        a0[j] += __shfl_xor(a0[j], 32); a1[j] += __shfl_xor(a1[j], 32);
+        aw[j][0] += __shfl_xor(aw[j][0], 32); aw[j][1] += __shfl_xor(aw[j][1], 32); aw[j][2] += __shfl_xor(aw[j][2], 32);
+        if (hl == 0) {
+            float* dst = redf + wave * 320 + 32 * j + cl;
+            dst[0] = a0[j]; dst[64] = a1[j]; dst[128] = aw[j][0]; dst[192] = aw[j][1]; dst[256] = aw[j][2];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 320; e += 256)
+        partial[(size_t)blockIdx.x * 320 + e] = (redf[e] + redf[320 + e]) + (redf[640 + e] + redf[960 + e]);
+}
 // fold of the per-block partial rows [nblk][320] in a fixed order: block = 32 of the 320 columns x 32 row groups -> sums[320]
 __global__ void __launch_bounds__(1024) g2e_conv1_fold_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ sums)
 {
@@ -679,6 +781,28 @@ extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, in
     hipStream_t st = (hipStream_t)stream;
     float* sums = ws + (size_t)grid * 320;
     hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(256), 0, st, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma, beta, ws);
+    hipLaunchKernelGGL(g2e_conv1_fold_kernel, dim3(10), dim3(1024), 0, st, (const float*)ws, grid, sums);
+    hipLaunchKernelGGL(g2e_conv1_grads_kernel, dim3(1), dim3(64), 0, st, (const float*)sums, mom, M, C, W, b, stat, gamma, training, dW, db, dgamma, dbeta);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+extern "C" int vpf_g2e_conv1_bwd_fused(const float* x, const void* dh2_bf16, long M, int C, const float* W, const float* b, const float* stat,
+                                       const float* gamma, const float* beta, int training, const float* mom, const void* W2_bf16,
+                                       float* dW, float* db, float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream)
+{
+    (void)hipGetLastError();
+    if (!x || !dh2_bf16 || !W || !b || !stat || !gamma || !beta || !W2_bf16 || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
+    if (training && !mom) return VPF_ERR_NULL;
+    if (M <= 0 || C <= 0 || C > 3) return VPF_ERR_BADSHAPE;
+    if ((uintptr_t)dh2_bf16 & 15) return VPF_ERR_BADALIGN;
+    int grid = grid_for(M, 32 * 4 * 3, 1024);
+    if ((long)(grid + 1) * 320 > ws_floats) grid = (int)(ws_floats / 320) - 1;
+    if (grid < 1) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = ws + (size_t)grid * 320;
+    hipLaunchKernelGGL(g2e_conv1_bwd_fused_kernel, dim3(grid), dim3(256), 0, st, x, (const bf16_t*)dh2_bf16, M, C, W, b, stat, gamma, beta,
+                       (const bf16_t*)W2_bf16, ws);
     hipLaunchKernelGGL(g2e_conv1_fold_kernel, dim3(10), dim3(1024), 0, st, (const float*)ws, grid, sums);
     hipLaunchKernelGGL(g2e_conv1_grads_kernel, dim3(1), dim3(64), 0, st, (const float*)sums, mom, M, C, W, b, stat, gamma, training, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();

@@ -1507,6 +1507,9 @@ G2E_BN_MERGED = [os.environ.get("VPF_G2E_BN_MERGED", "1") != "0"]   # BatchNorm 
 G2E_DEBUG = {}      # {"dbg": int64 tensor [256*2*6]} -> per-phase cycle stamps of vpf_g2e_bwd (diagnostic)
 
 
+G2E_CONV1_BWD_FUSED = [os.environ.get("VPF_G2E_CONV1_FUSED", "1") == "1"]      # conv2 dgrad inside the first conv's backward (tests run both)
+
+
 class Group2EmbFn(torch.autograd.Function):
     """conv(C,64) BN ReLU conv(64,128) -> max over K -> cat[global, local] -> conv(256,256) BN ReLU conv(256,D) -> max over K.
 
@@ -1667,10 +1670,16 @@ class Group2EmbFn(torch.autograd.Function):
         gemm(dgb16, 0, 256, w3, 1, 256, NG, 128, 256, dgmax, 128, c_f32=False)                             # dglobal
         L.call("vpf_group_max_scatter_add", dgmax, arg2, NG, K, 128, dh2)
         linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
-        da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
         ws = torch.empty(1025 * 320, dtype=F32, device=dev)                      # per-block partial sums (no atomics)
-        L.call("vpf_g2e_conv1_bwd", x, da1, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
-               int(training), ctx.mom, grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight), grad_buf(bn1.bias), ws, ws.numel())
+        if G2E_CONV1_BWD_FUSED[0]:
+            # conv2's input gradient is formed and consumed inside the first conv's backward: da1 [M, 64] never exists
+            L.call("vpf_g2e_conv1_bwd_fused", x, dh2, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
+                   int(training), ctx.mom, shadow([c2.weight]), grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight),
+                   grad_buf(bn1.bias), ws, ws.numel())
+        else:
+            da1 = linear_dgrad(dh2, shadow([c2.weight]), 128, 64)
+            L.call("vpf_g2e_conv1_bwd", x, da1, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
+                   int(training), ctx.mom, grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight), grad_buf(bn1.bias), ws, ws.numel())
         return (None, None, None) + (None,) * ctx.nparams
 
 
