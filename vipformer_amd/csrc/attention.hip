@@ -348,7 +348,10 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
     {
         // the wave's [32 x 64] output tile goes through its own LDS staging rows and leaves as 128-byte rows (16 bytes per lane,
         // 8 rows per wave-instruction) instead of 8 bytes per lane into 32 different rows
-        bf16_t* sO = rlds + 2 * LPT * KLD + wave * 32 * KLD;
+        // (the staging rows take over the K tile once every wave is past its last Q K^T: 2 instead of 3 tiles of LDS -- 64 KB at 196
+        // patches, so two workgroups share a CU)
+        __syncthreads();
+        bf16_t* sO = rlds + wave * 32 * KLD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -373,7 +376,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
 template <int NW>
 static int launch_res_fwd(const AttnArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)3 * NW * 32 * KLD * sizeof(bf16_t);      // K, V and the per-wave output staging rows
+    constexpr size_t lds = (size_t)2 * NW * 32 * KLD * sizeof(bf16_t);      // K and V (the per-wave output staging rows reuse K)
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;

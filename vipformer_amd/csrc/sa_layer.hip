@@ -1536,7 +1536,7 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
 // 64-wide hidden layer to K / V through LDS and registers.  It is still written once (bf16, with the hidden layer and the
 // normalised rows) because the backward pass reads it, but it is never read back in the forward pass.
 template <int NJ>
-__global__ void __launch_bounds__(64 * (8 / NJ)) adapter_kv_fwd_kernel(VpfAdapterKv a)
+__global__ void __launch_bounds__(64 * (8 / NJ), 4) adapter_kv_fwd_kernel(VpfAdapterKv a)
 {
     constexpr int RB = 2, TOK = RB * 32, NT = 64 * (8 / NJ), NWV = 8 / NJ, A1LD = 72;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
