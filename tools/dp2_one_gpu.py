@@ -29,17 +29,66 @@ def run_mode(overlap, rank, world, pairs, steps, dev):
     tr.broadcast_parameters(0)
     torch.manual_seed(100 + rank)
     t1, t2, imgs = bench.synth_batch(pairs, A["N"], A["img"], seed=rank, device=dev)
-    tr.capture(t1, t2, imgs, warmup=2, keep_grads=True)        # (these checks read the reduced gradients after the step)
+    dbg = {}
+    if os.environ.get("DP2_TRACE") == "1":                      # diagnostics: checksums of the stages' outputs (copies captured into the graph)
+        from vipformer_amd.model.pointcloud import utils as U
+
+        def keep(name, t):
+            dbg[name] = t.detach().clone()
+        real_dp = U.divide_patches
+
+        def dp(*a, **k):
+            nb, ct = real_dp(*a, **k)
+            keep("1 groups", nb); keep("0 centres", ct)
+            return nb, ct
+        U.divide_patches = dp
+        g2e = pc.group2emb.forward
+        pc.group2emb.forward = lambda *a, **k: (lambda y: (keep("2 group2emb", y), y)[1])(g2e(*a, **k))
+        enc = pc.encoder.forward
+
+        def encf(x, pos, kv, *a, **k):
+            keep("3 pos", pos); keep("4 kv", kv)
+            y = enc(x, pos, kv, *a, **k)
+            keep("5 pc encoder", y)
+            return y
+        pc.encoder.forward = encf
+        ienc = im.encoder.forward
+
+        def iencf(x, pos, kv, *a, **k):
+            keep("6 img patches", x)
+            y = ienc(x, pos, kv, *a, **k)
+            keep("7 img encoder", y)
+            return y
+        im.encoder.forward = iencf
+    pin = os.environ.get("DP2_PIN_START") == "1"
+    if pin:                                                     # diagnostics: farthest_point_sample's start indices as a constant of the graph
+        start = torch.randint(0, A["N"], (2 * pairs,), device=dev, generator=torch.Generator(device=dev).manual_seed(77 + rank))
+        real = torch.randint
+        torch.randint = lambda *a, **k: start.clone()
+    try:
+        tr.capture(t1, t2, imgs, warmup=2, keep_grads=True)    # (these checks read the reduced gradients after the step)
+    finally:
+        if pin:
+            torch.randint = real
     assert (tr._graph2 is not None) == overlap
     out = []
+
+    def forward_backward_in_turns():
+        # The two ranks replay the forward + backward graph ONE AFTER THE OTHER.  Time-sharing one GPU between two processes exposes an open
+        # issue: next to another process's GEMM kernels fps_kernel occasionally picks a wrong point (never seen with
+        # a GPU per process, which is how N > 1 really runs); side by side ~20 % of these comparisons would see two different samplings.
+        for r in range(world):
+            if r == rank:
+                tr._graph.replay()
+                torch.cuda.synchronize()
+            dist.barrier()
     for s in range(steps):
         torch.manual_seed(500 + 10 * s + rank)                   # the FPS start indices of this step (drawn inside the graph? no: at capture)
+        forward_backward_in_turns()
         if overlap:
-            tr.replay()
+            tr.exchange_and_step(tr._graph2.replay)              # (= Pretrainer.replay() after its first graph)
             torch.cuda.synchronize()
         else:
-            tr._graph.replay()
-            torch.cuda.synchronize()
             local = tr.flat.g.clone()
             p_before, m_before, v_before = tr.flat.p.clone(), tr.flat.m.clone(), tr.flat.v.clone()
             step_no = float(tr.hyper[6])
@@ -63,6 +112,8 @@ def run_mode(overlap, rank, world, pairs, steps, dev):
         assert torch.equal(ps[0], ps[1]) and torch.equal(gs[0], gs[1]), "ranks diverged"
         losses = [float(x) for x in tr.losses]
         assert all(v == v for v in losses)
+        if dbg and rank == 0:
+            print(("overlap" if overlap else "plain  ") + f" step {s}: " + "; ".join(f"{k} {float(dbg[k].double().sum()):.6f}" for k in sorted(dbg)), flush=True)
         out.append((tr.flat.p.clone(), tr.flat.g.clone(), losses))
     return out
 

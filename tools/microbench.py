@@ -186,3 +186,21 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["preproc"]
     for w in which:
         globals()[w]()
+
+
+def _one_gemm(kind):
+    """neighbour loads for tools/diag_fps_shared.py: one GEMM flavour in a loop"""
+    from vipformer_amd import ops
+    M, N, K = 12288, 512, 256
+    A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    dY = torch.randn(M, N, device="cuda").bfloat16(); dW = torch.zeros(N, K, device="cuda")
+    for _ in range(200):
+        if kind == "fwd": ops.linear_fwd(A, W, N, K, None)
+        elif kind == "dgrad": ops.linear_dgrad(dY, W, N, K)
+        else: ops.linear_wgrad(dY, A, N, K, dW)
+    torch.cuda.synchronize()
+
+
+def gemm_fwd(): _one_gemm("fwd")
+def gemm_dgrad(): _one_gemm("dgrad")
+def gemm_wgrad(): _one_gemm("wgrad")
