@@ -78,3 +78,30 @@ def test_errors_are_loud():
         U.knn_point(4, torch.zeros(1, 8, 3), torch.zeros(1, 2, 3))          # CPU tensors: no fallback
     with pytest.raises(_lib.VpfError):
         U.knn_point(65, torch.zeros(1, 128, 3).cuda(), torch.zeros(1, 2, 3).cuda())   # K > 64
+
+
+def test_fps_is_stable_beside_gemms_on_another_stream():
+    """fps_kernel sharing CUs with gemm_kernel workgroups (MFMAs fed by LDS fragment reads) used to return a wrong sampling in a third
+    or more of the launches; it now takes a CU of its own.  The two-stream reproduction: the sampling must be the
+    C oracle's, launch after launch."""
+    from oracle import torch_oracle as O
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud import utils as U
+    pts = Hh.synth_points(21, 128, 1024)
+    start = Hh.synth_start(21, 128, 1024)
+    want = O.fps_indices(pts, start, 96)
+    pts_d, start_d = pts.cuda(), start.cuda()
+    M, N, K = 12288, 512, 256
+    dY = torch.randn(M, N, device="cuda").bfloat16()
+    W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    bad = 0
+    for _ in range(300):
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                ops.linear_dgrad(dY, W, N, K)
+        idx = U._fps_from_start(pts_d, 96, start_d)
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(idx.cpu(), want))
+    assert bad == 0, f"{bad} of 300 launches beside dgrad GEMMs differ from the oracle's sampling"

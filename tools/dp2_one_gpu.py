@@ -73,22 +73,14 @@ def run_mode(overlap, rank, world, pairs, steps, dev):
     assert (tr._graph2 is not None) == overlap
     out = []
 
-    def forward_backward_in_turns():
-        # The two ranks replay the forward + backward graph ONE AFTER THE OTHER.  Time-sharing one GPU between two processes exposes an open
-        # issue: next to another process's GEMM kernels fps_kernel occasionally picks a wrong point (never seen with
-        # a GPU per process, which is how N > 1 really runs); side by side ~20 % of these comparisons would see two different samplings.
-        for r in range(world):
-            if r == rank:
-                tr._graph.replay()
-                torch.cuda.synchronize()
-            dist.barrier()
     for s in range(steps):
         torch.manual_seed(500 + 10 * s + rank)                   # the FPS start indices of this step (drawn inside the graph? no: at capture)
-        forward_backward_in_turns()
         if overlap:
-            tr.exchange_and_step(tr._graph2.replay)              # (= Pretrainer.replay() after its first graph)
+            tr.replay()
             torch.cuda.synchronize()
         else:
+            tr._graph.replay()
+            torch.cuda.synchronize()
             local = tr.flat.g.clone()
             p_before, m_before, v_before = tr.flat.p.clone(), tr.flat.m.clone(), tr.flat.v.clone()
             step_no = float(tr.hyper[6])

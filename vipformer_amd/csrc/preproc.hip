@@ -97,8 +97,16 @@ __global__ void __launch_bounds__(NT) fps_kernel(const float* __restrict__ pts, 
 template <int NT, int PPT>
 static int launch_fps(const float* pts, int B, int N, int C, const int64_t* start, int G, int64_t* out, hipStream_t st)
 {
-    const size_t lds = sizeof(float4) * (size_t)N + sizeof(uint2) * 2 * (NT / 64) + sizeof(int) * (size_t)G;
+    size_t lds = sizeof(float4) * (size_t)N + sizeof(uint2) * 2 * (NT / 64) + sizeof(int) * (size_t)G;
     if (lds > 160 * 1024) return VPF_ERR_BADSHAPE;
+    // A CU of its own for every cloud: the request is padded to the whole 160 KB of LDS, so no other workgroup is placed beside this one.
+    // Reason (open issue): next to workgroups of gemm_kernel (MFMAs fed by LDS fragment reads) this kernel
+    // occasionally returns a wrong sampling -- reproduced in one process with two streams, cause not found; alone on its CU it is
+    // bit-exact launch after launch.  The sampler is latency-bound (one workgroup per cloud, ~0.4 us per dependent iteration): it
+    // uses a fraction of a CU either way, what it gives up is the overlap with a neighbour on the same CU.
+    static int exclusive = -1;
+    if (exclusive < 0) { const char* e = getenv("VPF_FPS_EXCLUSIVE_CU"); exclusive = e ? atoi(e) : 1; }
+    if (exclusive) lds = 160 * 1024;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)fps_kernel<NT, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return VPF_ERR_HIP;
