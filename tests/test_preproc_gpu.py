@@ -82,8 +82,8 @@ def test_errors_are_loud():
 
 def test_fps_is_stable_beside_gemms_on_another_stream():
     """fps_kernel sharing CUs with gemm_kernel workgroups (MFMAs fed by LDS fragment reads) used to return a wrong sampling in a third
-    or more of the launches; it now takes a CU of its own.  The two-stream reproduction: the sampling must be the
-    C oracle's, launch after launch."""
+    or more of the launches (the packed-fp32 instructions of its distance update; preproc.hip is compiled without
+    them now).  The two-stream reproduction: the sampling must be the C oracle's, launch after launch."""
     from oracle import torch_oracle as O
     from vipformer_amd import ops
     from vipformer_amd.model.pointcloud import utils as U

@@ -21,7 +21,10 @@ ARCH = "gfx950"
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # bit-exact fp32 index kernels: no implicit FMA contraction
-PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
+# preproc.hip: bit-exact kernels.  No fused multiply-adds the source does not spell out, and no packed-fp32 instructions
+# (-fno-slp-vectorize: the SLP vectoriser pairs the per-point distance arithmetic into v_pk_add_f32 / v_pk_mul_f32, and with those
+# fps_kernel mis-sampled whenever gemm_kernel workgroups -- MFMAs fed by LDS fragment reads -- shared its CU: DESIGN.md section 6)
+PER_FILE = {"preproc.hip": ["-ffp-contract=off", "-fno-slp-vectorize"]}
 
 
 def source_hash() -> str:

@@ -99,13 +99,12 @@ static int launch_fps(const float* pts, int B, int N, int C, const int64_t* star
 {
     size_t lds = sizeof(float4) * (size_t)N + sizeof(uint2) * 2 * (NT / 64) + sizeof(int) * (size_t)G;
     if (lds > 160 * 1024) return VPF_ERR_BADSHAPE;
-    // A CU of its own for every cloud: the request is padded to the whole 160 KB of LDS, so no other workgroup is placed beside this one.
-    // Reason (open issue): next to workgroups of gemm_kernel (MFMAs fed by LDS fragment reads) this kernel
-    // occasionally returns a wrong sampling -- reproduced in one process with two streams, cause not found; alone on its CU it is
-    // bit-exact launch after launch.  The sampler is latency-bound (one workgroup per cloud, ~0.4 us per dependent iteration): it
-    // uses a fraction of a CU either way, what it gives up is the overlap with a neighbour on the same CU.
+    // VPF_FPS_EXCLUSIVE_CU=1 pads the request to the whole 160 KB of LDS (a CU of its own per cloud): the containment used while the
+    // mis-sampling beside gemm_kernel workgroups was not understood.  The trigger were the packed-fp32
+    // instructions the SLP vectoriser formed in the distance update; this file is now compiled without them (build.py) and the sampler
+    // shares its CU again (1 000 of 1 000 launches bit-identical beside dgrad GEMMs either way).
     static int exclusive = -1;
-    if (exclusive < 0) { const char* e = getenv("VPF_FPS_EXCLUSIVE_CU"); exclusive = e ? atoi(e) : 1; }
+    if (exclusive < 0) { const char* e = getenv("VPF_FPS_EXCLUSIVE_CU"); exclusive = e ? atoi(e) : 0; }
     if (exclusive) lds = 160 * 1024;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)fps_kernel<NT, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
