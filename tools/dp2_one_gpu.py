@@ -111,6 +111,8 @@ def run_mode(overlap, rank, world, pairs, steps, dev):
 
 
 def worker(rank, world, pairs, steps, port):
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("DP2_WATCHDOG_S", "150")), exit=True)      # a rank that hangs says where, and ends
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -131,6 +133,7 @@ def worker(rank, world, pairs, steps, port):
             # noise by +-lr whichever way the noise points, so two equally valid runs drift apart from the second step on
             assert abs(l0[0] - l1[0]) <= 1e-5 * abs(l0[0]) and cos > 0.99999999 and dpm < 2.5e-3 and frac < 2e-3, (l0, l1, cos, dpm, frac)
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 def main(pairs=8, steps=3, port=29577):
