@@ -508,7 +508,7 @@ def main():
                        "last_losses": losses, "losses_finite": finite,
                        "step_tflops_algorithmic": round(value * gf / 1e3, 2),
                        "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
-                       "kernels_per_step": 189 if (args.arch == "c2" and use_graph) else None,   # rocprofv3 kernel trace of one replay (round 1: 196)
+                       "kernels_per_step": 187 if (args.arch == "c2" and use_graph) else None,   # rocprofv3 kernel trace of one replay (round 1: 196)
                        "version": __version__},
             "roofline": roof, "kernels": legs, "variants": variants, "cpu_baseline": cpu,
         }
