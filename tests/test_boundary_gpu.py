@@ -339,3 +339,23 @@ def test_zero_grad_set_to_none_does_not_detach_a_trainer_from_its_gradients():
     base = tr.flat.g.data_ptr()
     for p, off in zip(tr.flat.params, tr.flat.offsets):
         assert p.grad is not None and p.grad.data_ptr() == base + 4 * off
+
+
+def test_bench_json_line_is_the_last_stdout_line_with_rccl_alive():
+    """bench.py's contract: ONE JSON line from rank 0.  RCCL prints a banner into the C library's stdout buffer, which used to be flushed
+    at exit -- behind the JSON line; a driver reading the last line of stdout would have found "Librccl path : ...".  The N > 1 code path
+    in a one-rank RCCL group (VPF_FORCE_DP=1): the last line must be the JSON object, with the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VPF_FORCE_DP="1", MASTER_PORT=str(29800 + os.getpid() % 100))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernels"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    d = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["config"]["hip_graph"] is True and d["config"]["capture"] == "split" and d["config"]["losses_finite"]
