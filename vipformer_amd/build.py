@@ -24,7 +24,8 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 # preproc.hip: bit-exact kernels.  No fused multiply-adds the source does not spell out, and no packed-fp32 instructions
 # (-fno-slp-vectorize: the SLP vectoriser pairs the per-point distance arithmetic into v_pk_add_f32 / v_pk_mul_f32, and with those
 # fps_kernel mis-sampled whenever gemm_kernel workgroups -- MFMAs fed by LDS fragment reads -- shared its CU: DESIGN.md section 6)
-PER_FILE = {"preproc.hip": ["-ffp-contract=off", "-fno-slp-vectorize"]}
+PER_FILE = {"preproc.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
+            "augment.hip": ["-fno-slp-vectorize"]}          # (bit-exact against the oracle as well: same precaution)
 
 
 def source_hash() -> str:
