@@ -349,7 +349,7 @@ def test_bench_json_line_is_the_last_stdout_line_with_rccl_alive():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VPF_FORCE_DP="1", MASTER_PORT=str(29800 + os.getpid() % 100))
+    env = dict(os.environ, VPF_FORCE_DP="1", MASTER_PORT=str(28600 + os.getpid() % 1000))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernels"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -359,3 +359,15 @@ def test_bench_json_line_is_the_last_stdout_line_with_rccl_alive():
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["config"]["hip_graph"] is True and d["config"]["capture"] == "split" and d["config"]["losses_finite"]
+
+
+def test_replayed_step_is_bitwise_reproducible():
+    """Race detector: with lr = wd = 0, the dropout step pinned and the FPS start indices a constant of the graph, every replay runs the
+    same forward pass on the same weights -- the three losses must be bitwise equal replay after replay (tools/diag_replay_determinism.py;
+    a kernel reading memory it did not write, or a missing edge between the two branches, shows up as a second value)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("diag_replay_determinism", os.path.join(root, "tools", "diag_replay_determinism.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main("c2", 8, 150) == 1

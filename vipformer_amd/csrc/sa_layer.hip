@@ -1426,24 +1426,26 @@ __global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
 struct PgradJobs { VpfPgradJob job[VPF_PGRAD_MAX_JOBS]; };
 __global__ void __launch_bounds__(1024) sa_pgrad_reduce_kernel(PgradJobs jobs)
 {
-    __shared__ float fold[16][64];
+    // block = 16 of the 512 columns x 64 row groups (a job with 2 048 partial rows -- the K / V producer's LayerNorm -- is 32 dependent
+    // loads per thread this way; with 64 columns x 16 row groups it was 128 and took 21 us at the very end of the backward pass)
+    __shared__ float fold[64][17];
     const VpfPgradJob j = jobs.job[blockIdx.y];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;      // 8 blocks x 64 columns of the 512; 16 row groups
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = rg;
-    for (; r + 48 < j.rows; r += 64) {
+    for (; r + 192 < j.rows; r += 256) {
         s0 += j.partials[(size_t)r * 2 * SA_D + c];
-        s1 += j.partials[(size_t)(r + 16) * 2 * SA_D + c];
-        s2 += j.partials[(size_t)(r + 32) * 2 * SA_D + c];
-        s3 += j.partials[(size_t)(r + 48) * 2 * SA_D + c];
+        s1 += j.partials[(size_t)(r + 64) * 2 * SA_D + c];
+        s2 += j.partials[(size_t)(r + 128) * 2 * SA_D + c];
+        s3 += j.partials[(size_t)(r + 192) * 2 * SA_D + c];
     }
-    for (; r < j.rows; r += 16) s0 += j.partials[(size_t)r * 2 * SA_D + c];
-    fold[rg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    for (; r < j.rows; r += 64) s0 += j.partials[(size_t)r * 2 * SA_D + c];
+    fold[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0) {
         float tot = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tot += fold[k][threadIdx.x];
+        for (int k = 0; k < 64; ++k) tot += fold[k][cl];
         if (c < SA_D) j.dgamma[c] += tot; else j.dbeta[c - SA_D] += tot;
     }
 }
@@ -1458,7 +1460,7 @@ extern "C" int vpf_ln_pgrad_reduce(const VpfPgradJob* jobs, int njobs, void* str
         if (jobs[i].rows <= 0) return VPF_ERR_BADSHAPE;
         pj.job[i] = jobs[i];
     }
-    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(8, njobs), dim3(1024), 0, (hipStream_t)stream, pj);
+    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(32, njobs), dim3(1024), 0, (hipStream_t)stream, pj);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
