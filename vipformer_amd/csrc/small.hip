@@ -634,35 +634,29 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* _
                                                                 float* __restrict__ partial)
 {
     __shared__ float redf[4 * 320];              // [4 waves][5 values][64 channels]
-    // one buffer, two lives: W2 [128 out][64 in] (rows padded to 72) while the fragments are built, then per wave the accumulator tile
-    // [16][64] f32
-    __shared__ __attribute__((aligned(16))) bf16_t sBuf[128 * 72];
-    bf16_t* sW2 = sBuf;
+    __shared__ __attribute__((aligned(16))) bf16_t sW2[128 * 72];     // W2 [128 out][64 in], rows padded to 72
+    __shared__ float sAccAll[4 * 16 * 64];                            // per wave: the accumulator tile [16][64] f32
+    __shared__ float4 sXrow[4][32];                                   // per wave: the current tile's input rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, hl = lane >> 5;
-    // W2 as B fragments: column n = input channel (lane & 31, + 32 j), 8 consecutive k = output channels 16 ks + 8 hl ..  The matrix is
-    // k-strided for that ([k][n] rows): staged in LDS and read with the transposing ds_read_b64_tr_b16 (as gemm.hip's frag_read), once.
     for (int e = threadIdx.x; e < 128 * 8; e += 256)
         *reinterpret_cast<uint4*>(sW2 + (e >> 3) * 72 + (e & 7) * 8) = *reinterpret_cast<const uint4*>(W2 + (size_t)e * 8);
     __syncthreads();
-    g2e_bf16x8_t bw[2][8];
-    {
-        typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-        const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, p4 = i16 & 3, h = g >> 1, roff = 16 * (g & 1);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16_t* a0 = sW2 + (ks * 16 + 8 * h + q) * 72 + 32 * j + roff + 4 * p4;
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * 72));
-                s16x8_t v;
-                v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-                bw[j][ks] = __builtin_bit_cast(g2e_bf16x8_t, v);
-            }
-    }
-    __syncthreads();                             // W2 is in registers: the buffer now belongs to the waves' tiles
-    float* sAcc = reinterpret_cast<float*>(sBuf) + wave * 16 * 64;          // [16][64] (4 x 4 KB of the 18 KB)
+    // W2 as B fragments: column n = input channel (lane & 31, + 32 j), 8 consecutive k = output channels 16 ks + 8 hl ..  The matrix is
+    // k-strided for that ([k][n] rows): read from LDS with the transposing ds_read_b64_tr_b16 (as gemm.hip's frag_read) in front of
+    // every MFMA -- holding the 16 fragments in registers instead costs 64 VGPRs, i.e. a wave per SIMD and the room for the next tile's loads
+    typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const bf16_t* wfrag = sW2 + (8 * (g16 >> 1) + (i16 >> 2)) * 72 + 16 * (g16 & 1) + 4 * (i16 & 3);
+    auto bfrag = [&](int j, int ks) {
+        const bf16_t* a0p = wfrag + ks * 16 * 72 + 32 * j;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0p));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0p + 4 * 72));
+        s16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(g2e_bf16x8_t, v);
+    };
+    float* sAcc = sAccAll + wave * 16 * 64;
     float wr[2][3], br[2], ga[2], be[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -673,31 +667,39 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* _
         for (int i = 0; i < 3; ++i) wr[j][i] = i < C ? W[c * C + i] * rs : 0.f;
     }
     float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f}, aw[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-    __shared__ float4 sXrow[4][32];              // the current tile's input rows, per wave
     const long ntiles = (M + 31) / 32, tstep = (long)gridDim.x * 4;
-    for (long tile = (long)blockIdx.x * 4 + wave; tile < ntiles; tile += tstep) {
-        const long rr = min(tile * 32 + cl, M - 1);                // (rows past the end: clamped loads, their gradient is zeroed below)
-        const int nrows = (int)min(32L, M - tile * 32);
-        const bf16_t* src = dh2 + (size_t)rr * 128 + 8 * hl;      // A-fragment layout: row = lane & 31, 8 values at k = 16 ks + 8 hl
-        uint4 af[8];
+    uint4 af[8]; float4 xr0;
+    auto load_tile = [&](long tile) {                             // A fragments straight from HBM: row = lane & 31, 8 values at k = 16 ks + 8 hl
+        const long rr = min(min(tile, ntiles - 1) * 32 + cl, M - 1);      // (rows / tiles past the end: clamped loads, their gradient is zeroed below)
+        const bf16_t* src = dh2 + (size_t)rr * 128 + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const uint4*>(src + ks * 16);
-        {
-            const float* xp = x + (size_t)rr * C;
-            sXrow[wave][cl] = make_float4(xp[0], C > 1 ? xp[1] : 0.f, C > 2 ? xp[2] : 0.f, 0.f);   // (wave-private: the wave's own LDS accesses are ordered)
+        const float* xp = x + (size_t)rr * C;
+        xr0 = make_float4(xp[0], C > 1 ? xp[1] : 0.f, C > 2 ? xp[2] : 0.f, 0.f);
+    };
+    long tile = (long)blockIdx.x * 4 + wave;
+    load_tile(tile);
+    for (; tile < ntiles; tile += tstep) {
+        const int nrows = (int)min(32L, M - tile * 32);
+        sXrow[wave][cl] = xr0;                                     // (wave-private: the wave's own LDS accesses are ordered)
+        g2e_f32x16_t acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const g2e_bf16x8_t a = __builtin_bit_cast(g2e_bf16x8_t, af[ks]);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag(0, ks), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag(1, ks), acc[1], 0, 0, 0);
         }
+        load_tile(tile + tstep);                                  // the next tile's rows travel under this tile's per-row arithmetic
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            g2e_f32x16_t acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(g2e_bf16x8_t, af[ks]), bw[j][ks], acc, 0, 0, 0);
             // the 16 accumulator registers go through a wave-private LDS slot so that the per-row arithmetic can be a ROLLED loop: fully
             // unrolled, the scheduler keeps ~180 registers of row products alive (280 in all, one wave per SIMD, 100 us)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sAcc[r * 64 + lane] = acc[r];
+            for (int r = 0; r < 16; ++r) sAcc[r * 64 + lane] = acc[j][r];
 #pragma unroll 1
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;    // C / D layout of the 32 x 32 MFMA
