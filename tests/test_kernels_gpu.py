@@ -394,3 +394,31 @@ def _grouped_wgrad_cases(ops):
             ref = dy.float().t() @ x.float()
             assert rel(dW, 1.0 + 2.0 * ref) < 2e-5, (M, N, K, rel(dW, 1.0 + 2.0 * ref))
             assert rel(db, 1.0 + 2.0 * dy.float().sum(0)) < 2e-5
+
+
+def test_timeline_marks_are_ordered_and_capturable():
+    """ops.Timeline (vpf_stamp): marks on a stream come back in issue order, microseconds apart by at least the work between them, and a
+    mark captured into a hipGraph is refreshed by every replay."""
+    from vipformer_amd import ops
+    tl = ops.Timeline(torch.device("cuda", 0))
+    x = torch.randn(4096, 4096, device="cuda")
+    tl.mark("a")
+    y = x @ x
+    tl.mark("b")
+    torch.cuda.synchronize()
+    t = tl.read()
+    assert t["a"] == 0.0 and 1.0 < t["b"] < 1e6, t
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        tl.mark("c")                                    # (warm-up of the launch path outside capture)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        tl.mark("c")
+    g.replay(); torch.cuda.synchronize()
+    c1 = int(tl.buf[tl.names.index("c")])
+    g.replay(); torch.cuda.synchronize()
+    c2 = int(tl.buf[tl.names.index("c")])
+    assert c2 > c1 > 0 and float(y[0, 0]) == float(y[0, 0])
