@@ -18,14 +18,14 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libvipformer_hip.so")
 ARCH = "gfx950"
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+# -fno-slp-vectorize: no packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 ...) anywhere in the library.  With them fps_kernel
+# mis-sampled whenever gemm_kernel workgroups shared its CU (the mechanism is not understood, so the
+# instruction class goes everywhere, not only from the bit-exact kernels) -- and the step is 0.03 ms FASTER without them (A/B on one
+# box, 4 alternating pairs: 4.296 vs 4.329 ms).
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
-# bit-exact fp32 index kernels: no implicit FMA contraction
-# preproc.hip: bit-exact kernels.  No fused multiply-adds the source does not spell out, and no packed-fp32 instructions
-# (-fno-slp-vectorize: the SLP vectoriser pairs the per-point distance arithmetic into v_pk_add_f32 / v_pk_mul_f32, and with those
-# fps_kernel mis-sampled whenever gemm_kernel workgroups -- MFMAs fed by LDS fragment reads -- shared its CU: DESIGN.md section 6)
-PER_FILE = {"preproc.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
-            "augment.hip": ["-fno-slp-vectorize"]}          # (bit-exact against the oracle as well: same precaution)
+# preproc.hip: bit-exact kernels -- no fused multiply-adds the source does not spell out
+PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
 
 
 def source_hash() -> str:
@@ -37,7 +37,7 @@ def source_hash() -> str:
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
-    h.update(" ".join(COMMON[:6] + sorted(sum(PER_FILE.values(), []))).encode())
+    h.update(" ".join(COMMON[:7] + sorted(sum(PER_FILE.values(), []))).encode())
     return h.hexdigest()
 
 
