@@ -319,6 +319,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone kernel legs (profiling runs)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the host-fed / duplicate-heavy variants (profiling runs)")
     ap.add_argument("--no-overlap", action="store_true", help="run the image branch on the same stream as the point-cloud branch")
     ap.add_argument("--wgrad-async", action="store_true", help="grouped weight-gradient launches on a side stream")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the configuration's per-GPU batch)")
@@ -358,7 +359,7 @@ def main():
     pc.train(); im.train()
     tr = Pretrainer(pc, im, world_size=world, force_data_parallel=force_dp)
     tr.overlap = not args.no_overlap
-    ops.WGRAD_GROUP_ASYNC[0] = args.wgrad_async
+    ops.cfg.wgrad_group_async = args.wgrad_async
     tr.broadcast_parameters(0)
     torch.manual_seed(100 + rank)                          # FPS start indices differ per rank
     t1, t2, imgs = synth_batch(pairs, a["N"], a["img"], seed=rank, device=device)
@@ -429,7 +430,7 @@ def main():
 
     # ---- variants (not `value`): host-fed = the reference's synchronous H2D of the batch (pretrain.py:177) in front of every step
     variants = {}
-    if use_graph:
+    if use_graph and not args.no_variants:
         host = [t.cpu().pin_memory() for t in (t1, t2, imgs)]
         h2d_bytes = sum(t.numel() * 4 for t in host)
 

@@ -40,6 +40,10 @@ int vpf_version(void);
 const char* vpf_strerror(int code);
 /* "VPF_BUILD_ID=<sha256 of the library's sources>": vipformer_amd/build.py rebuilds when it does not match the tree */
 const char* vpf_build_id(void);
+/* Launch-time experiment knobs (kernel variants, grid caps: csrc/vpf_common.h VpfDebug) by name; the library reads the VPF_*
+ * environment variables once, when the first launcher asks, and never again.  Not a user-facing option: tests and tools only. */
+int vpf_debug_set(const char* key, int value);
+int vpf_debug_get(const char* key, int* value);
 
 /* ------------------------------------------------------------------ point-cloud preproc */
 
@@ -407,7 +411,8 @@ int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* host_args, void* stream);
  * CrossFormer_partseg.forward partseg.py:407-470 + PointNetFeaturePropagation.forward utils.py:205-242: everything that the
  * pre-training entry points above do not already cover (the 1x1 convolutions are vpf_gemm_bf16, BatchNorm the entries above). */
 /* utils.py:219-230: the three nearest of S centres per point by the exact square_distance recipe (the reference sorts all S),
- * weights 1/(d + 1e-8) normalised; idx int32 [B,N,3], weight f32 [B,N,3]; ties -> lower centre index. */
+ * weights 1/(d + 1e-8) normalised; idx int32 [B,N,3], weight f32 [B,N,3]; ties -> lower centre index.  S == 1: the broadcast of
+ * utils.py:216-217 (weight exactly 1 on the one centre).  S <= 4096 (16 S bytes of LDS), else VPF_ERR_UNSUPPORTED. */
 int vpf_three_nn_f32(const float* xyz, int B, int N, int C, const float* centers, int Cc, int S, int* idx, float* weight,
                      void* stream);
 /* partseg.py:427-435: LayerNorm (one parameter set) of up to four encoder taps f32 [rows,D] into the concatenated feature
@@ -427,7 +432,8 @@ int vpf_interp_rows_bwd(const void* dA_bf16, int B, int N, int C, int S, int F, 
  * dimension is not a multiple of 8 (3 + nl*D input channels of mlp_convs[0]; the 50 part classes of conv3). */
 int vpf_pad_bf16(const void* src, int src_is_bf16, long rows, int K, long ld, long rows_out, int Kp, void* dst_bf16, void* stream);
 /* ft_partseg.py:128,155: CrossEntropyLoss(label_smoothing = eps), mean over rows.  logits f32 [rows, ld] (first C columns),
- * target int64 [rows]; partial_ws f32 [1024]; loss f32 [1]; dlogits (nullable) f32 [rows, lddz] = d loss / d logits. */
+ * target int64 [rows]; partial_ws f32 [1024]; loss f32 [1]; dlogits (nullable) f32 [rows, lddz] = d loss / d logits.
+ * A target outside [0, C) (torch raises; ignore_index is not used by the reference) makes the loss and that row's gradient NaN. */
 int vpf_ce_smooth(const float* logits, long ld, const long long* target, long rows, int C, float eps, float* partial_ws,
                   float* loss, float* dlogits, long lddz, void* stream);
 /* ------------------------------------------------------------------ on-device augmentation

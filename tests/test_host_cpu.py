@@ -261,6 +261,66 @@ def test_gradient_allreduce_world_size_2_gloo():
     assert all(r[1] and r[2] and r[3] for r in res), res
 
 
+def _dp_split_worker(rank, world, port, wire_bf16, q):
+    """The split-capture exchange order of Pretrainer.exchange_and_step (GradientExchange.exchange): early regions travel while
+    `between` (the second backward graph) writes the late regions, which follow; AdamW per region on arrival."""
+    import torch.distributed as dist
+    from vipformer_amd.train import GradientExchange
+    dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+    n = 4096
+    regions = [("img", 2048, n), ("pc.early0", 0, 256), ("pc.early1", 1024, 2048), ("pc.late0", 256, 1024)]   # Pretrainer's layout
+    g = torch.Generator().manual_seed(50 + rank)
+    full = torch.randn(n, generator=g)                     # what both backward graphs produce on this rank
+    if wire_bf16:
+        full = full.bfloat16().float()                     # exactly representable on the wire: the check below stays tight
+    flat_g = full.clone()
+    flat_g[256:1024] = 0.0                                 # the late region is not written until `between` runs
+    ex = GradientExchange(flat_g, regions, world, wire_bf16=wire_bf16)
+    arrived, seen_between = [], {}
+
+    def between():
+        seen_between["pending"] = sorted(ex._pending)      # the early collectives are in flight, the late one is not launched
+        flat_g[256:1024] = full[256:1024]
+
+    def on_arrival(i, name, a, b):
+        arrived.append(name)
+        assert name not in ex._pending
+
+    ex.exchange(["pc.late0"], between, on_arrival)
+    gathered = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(gathered, full)
+    want = sum(gathered)
+    tol = 2e-2 * world if wire_bf16 else 1e-5              # bf16 wire: the SUM is rounded to 8 bits per hop
+    ok_sum = torch.allclose(flat_g, want, atol=tol, rtol=tol)
+    ok_order = arrived == [r[0] for r in regions] and seen_between.get("pending") == ["img", "pc.early0", "pc.early1"]
+    # every rank holds the same reduced gradient (bitwise: all-reduce delivers one result)
+    allg = [torch.zeros(n) for _ in range(world)]
+    dist.all_gather(allg, flat_g)
+    ok_same = all(torch.equal(allg[0], t) for t in allg)
+    # without `between` nothing is late: one launch wave
+    flat2 = full.clone()
+    GradientExchange(flat2, regions, world, wire_bf16=wire_bf16).exchange(["pc.late0"], None, None)
+    ok_plain = torch.allclose(flat2, want, atol=tol, rtol=tol)
+    q.put((rank, ok_sum, ok_order, ok_same, ok_plain))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,wire_bf16", [(4, False), (8, False), (4, True)])
+def test_split_exchange_order_gloo(world, wire_bf16):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world * 3 + int(wire_bf16)
+    procs = [ctx.Process(target=_dp_split_worker, args=(r, world, port, wire_bf16, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(all(r[1:]) for r in res), res
+
+
 # ------------------------------------------------------------------------------------------ CrossFormer_partseg (config 5)
 def _build_partseg(name):
     from vipformer_amd.model.pointcloud import CrossFormer_partseg, PointCloudInputAdapter

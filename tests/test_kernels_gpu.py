@@ -369,13 +369,13 @@ def test_grouped_wgrad_workspace_split_k():
     gradients of an encoder layer at the benchmark's token count and at ragged sizes, accumulated INTO non-zero buffers, launched
     twice in a row (the arrival counters must come back to zero), against fp32 matmuls of the same bf16 operands."""
     from vipformer_amd import ops
-    ops.WGRAD_DETERMINISTIC[0] = True
+    ops.cfg.wgrad_deterministic = True
     try:
         _grouped_wgrad_cases(ops)
         ws = ops.wgrad_workspace("cuda")
         assert int(ws[:1024].view(torch.int32).abs().sum()) == 0          # counters are back to zero
     finally:
-        ops.WGRAD_DETERMINISTIC[0] = False
+        ops.cfg.wgrad_deterministic = False
     _grouped_wgrad_cases(ops)                                             # the default: fp32 atomics
 
 

@@ -449,7 +449,7 @@ def test_trainer_stream_and_graph_variants_agree():
         pc.train(); im.train()
         tr = Pretrainer(pc, im)
         tr.overlap = overlap
-        ops.WGRAD_ASYNC[0] = wasync
+        ops.cfg.wgrad_async = wasync
         with forced_start(start):
             if graph:
                 tr.hyper[0] = 0.0; tr.hyper[4] = 0.0            # lr = wd = 0: the warm-up steps of capture() leave the weights alone
@@ -463,7 +463,7 @@ def test_trainer_stream_and_graph_variants_agree():
         zero_grad = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias")
         g = torch.cat([p.grad.reshape(-1) for m in (pc, im) for k, p in m.named_parameters() if k not in zero_grad])
         results.append((float(losses[0]), g.clone()))
-    ops.WGRAD_ASYNC[0] = False
+    ops.cfg.wgrad_async = False
     ops.clear_managed_shadows()
     l0, g0 = results[0]
     for (l, g), tag in zip(results[1:], ("two-stream", "two-stream + async wgrad", "hipGraph")):
@@ -494,9 +494,9 @@ def test_fused_sa_stack_matches_unfused_blocks():
         pc.train(); im.train()
         tr = Pretrainer(pc, im)
         tr.overlap = False
-        ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = fused, fused_bwd, split, bool(enc)
-        ops.ADAPTER_KV_FUSED[0] = bool(enc)
-        ops.ADAPTER_KV_BWD_FUSED[0] = enc == 2
+        ops.cfg.sa_fused, ops.cfg.sa_fused_bwd, ops.cfg.sa_split_attn, ops.cfg.enc_fused = fused, fused_bwd, split, bool(enc)
+        ops.cfg.adapter_kv_fused = bool(enc)
+        ops.cfg.adapter_kv_bwd_fused = enc == 2
         with forced_start(start), ops.rng.pinned():
             feats_pc = pc(torch.cat([t1, t2]))[1].detach().clone()        # backbone features (before the BatchNorm head)
             ops.rng.state("cuda")[2] = 0
@@ -505,9 +505,9 @@ def test_fused_sa_stack_matches_unfused_blocks():
         zero_grad = ("group2emb.first_conv.0.bias", "group2emb.first_conv.3.bias", "group2emb.second_conv.0.bias")
         g = {("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters() if k not in zero_grad}
         results.append((float(losses[0]), feats_pc, g))
-    ops.SA_FUSED[0], ops.SA_FUSED_BWD[0], ops.SA_SPLIT_ATTN[0], ops.ENC_FUSED[0] = True, True, None, True
-    ops.ADAPTER_KV_FUSED[0] = True
-    ops.ADAPTER_KV_BWD_FUSED[0] = True
+    ops.cfg.sa_fused, ops.cfg.sa_fused_bwd, ops.cfg.sa_split_attn, ops.cfg.enc_fused = True, True, None, True
+    ops.cfg.adapter_kv_fused = True
+    ops.cfg.adapter_kv_bwd_fused = True
     ops.clear_managed_shadows()
     l0, f0, g0 = results[0]
     allg0 = torch.cat([v.reshape(-1) for v in g0.values()])
@@ -636,7 +636,7 @@ def test_group2emb_first_conv_backward_fused_matches_two_kernels():
     torch.manual_seed(3)
     grads = []
     for fused in (False, True):
-        ops.G2E_CONV1_BWD_FUSED[0] = fused
+        ops.cfg.g2e_conv1_bwd_fused = fused
         ops.clear_managed_shadows()
         torch.manual_seed(7)
         g2e = Group2Emb(256).cuda().train()
@@ -644,7 +644,7 @@ def test_group2emb_first_conv_backward_fused_matches_two_kernels():
         out = g2e(x)
         (out * Hh.synth_like(12, out.shape).cuda()).sum().backward()
         grads.append({k: p.grad.clone() for k, p in g2e.named_parameters()})
-    ops.G2E_CONV1_BWD_FUSED[0] = True
+    ops.cfg.g2e_conv1_bwd_fused = True
     ops.clear_managed_shadows()
     for k in ("first_conv.0.weight", "first_conv.1.weight", "first_conv.1.bias"):
         a, b = grads[0][k], grads[1][k]

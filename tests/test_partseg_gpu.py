@@ -184,6 +184,40 @@ def test_feature_propagation_module_vs_oracle():
         assert cosine(f.grad, fr.grad) > 0.999, cosine(f.grad, fr.grad)
 
 
+def test_three_nn_edge_cases_one_and_two_centres_and_bad_ce_target():
+    """utils.py:216-217: ONE centre is broadcast (weight exactly 1); two centres cannot give three neighbours (the reference's
+    weight.view(B, N, 3, 1) raises); a cross-entropy target outside [0, C) must not read out of bounds (torch raises; here NaN)."""
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops_seg as S
+    from vipformer_amd.model.pointcloud.utils import PointNetFeaturePropagation
+    B, N = 2, 70
+    xyz1 = Hh.synth_points(11, B, N).cuda()
+    one = Hh.synth_points(12, B, 1).cuda()
+    idx = torch.empty(B * N * 3, dtype=torch.int32, device="cuda"); w = torch.empty(B * N * 3, dtype=torch.float32, device="cuda")
+    L.call("vpf_three_nn_f32", xyz1, B, N, 3, one, 3, 1, idx, w)
+    assert torch.equal(idx, torch.zeros_like(idx))
+    assert torch.equal(w.view(-1, 3), torch.tensor([1.0, 0.0, 0.0], device="cuda").expand(B * N, 3))
+    with pytest.raises(L.VpfError):
+        L.call("vpf_three_nn_f32", xyz1, B, N, 3, Hh.synth_points(13, B, 5000).cuda(), 3, 5000, idx, w)       # 16 S bytes of LDS: S <= 4096
+    torch.manual_seed(0)
+    fp = PointNetFeaturePropagation(16, [32]).cuda().eval()
+    feat = Hh.synth_like(14, (B, 1, 16)).cuda()
+    y = fp(xyz1.permute(0, 2, 1), one.permute(0, 2, 1), None, feat.permute(0, 2, 1))
+    y2 = fp(xyz1.permute(0, 2, 1)[:, :, :5], one.permute(0, 2, 1), None, feat.permute(0, 2, 1))
+    assert torch.equal(y[:, :, :1].expand_as(y), y) and torch.equal(y[:, :, :5], y2)          # every point gets the one centre's feature
+    with pytest.raises(RuntimeError):
+        fp(xyz1.permute(0, 2, 1), Hh.synth_points(15, B, 2).cuda().permute(0, 2, 1), None, Hh.synth_like(16, (B, 2, 16)).cuda().permute(0, 2, 1))
+    z = Hh.synth_like(17, (6, 50)).cuda().requires_grad_()
+    t = torch.tensor([0, 49, 3, 7, 1, 2], device="cuda")
+    good = S.cross_entropy_smooth(z, t, 0.2)
+    ref = torch.nn.functional.cross_entropy(z.detach().cpu(), t.cpu(), label_smoothing=0.2)
+    assert abs(good.item() - ref.item()) < 1e-5
+    for bad_t in (-100, 50):
+        tb = t.clone(); tb[2] = bad_t
+        lossb = S.cross_entropy_smooth(z, tb, 0.2)
+        assert torch.isnan(lossb).item()
+
+
 def test_ft_partseg_step_trains_from_a_pretraining_checkpoint():
     """ft_partseg.py:80-83 + :145-176: strict=False load of a hot-path checkpoint, then the loop body -- forward(points, onehot),
     CrossEntropyLoss(label_smoothing=0.2), backward, clip_grad_norm_(10), optimizer.step -- with a torch optimizer."""

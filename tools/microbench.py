@@ -84,8 +84,8 @@ def sa():
         params = [p for l in layers for p in l.parameters()]
         dbg = torch.zeros(16, dtype=torch.int64, device="cuda")
         for fused, split in ((False, None), (True, False), (True, True)):
-            ops.SA_FUSED[0] = fused
-            ops.SA_SPLIT_ATTN[0] = split
+            ops.cfg.sa_fused = fused
+            ops.cfg.sa_split_attn = split
             def run():
                 with torch.no_grad():
                     if fused:
@@ -95,13 +95,13 @@ def sa():
                     return y
             t = timeit(run, 20, 3)
             print(f"sa stack fwd {tag} B={B} L={Lq} fused={fused} split_attn={split}: {t:.1f} us / 6 layers = {t/6:.1f} us per layer")
-        ops.SA_DEBUG.append(dbg)
+        ops.cfg.sa_debug = dbg
         run(); torch.cuda.synchronize()
-        ops.SA_DEBUG.clear()
+        ops.cfg.sa_debug = None
         names = ["attention", "o_proj mfma", "drop+res epi", "LN2 maths", "n2 stores", "barrier", "chunk0+fc1(1)", "bias+u+gelu", "barrier", "h stores", "barrier", "fc2(1)", "MLP rest", "final epi", "next LN1", "next qkv"]
         print("   phase cycles (wg 0, layer 4): " + "  ".join(f"{n} {int(c)}" for n, c in zip(names, dbg.tolist())))
-    ops.SA_FUSED[0] = True
-    ops.SA_SPLIT_ATTN[0] = None
+    ops.cfg.sa_fused = True
+    ops.cfg.sa_split_attn = None
 
 
 def satail():

@@ -64,7 +64,7 @@ def gate_image_backward(pc, im, tl, after):
         def hook(ca, i):
             if ca is pc_ca and i == after:
                 ev.record(torch.cuda.current_stream())
-        ops.ENC_BWD_HOOK[0] = hook
+        ops.cfg.enc_bwd_hook = hook
     else:
         g2e = pc.group2emb.forward
         pc.group2emb.forward = lambda *a, **k: EventFn.apply(g2e(*a, **k), ev)

@@ -1,5 +1,7 @@
 // api.hip -- version / error strings of the C ABI.
 #include "vpf_common.h"
+#include <stdlib.h>
+#include <string.h>
 #include "vipformer_hip.h"
 
 extern "C" int vpf_version(void)
@@ -43,4 +45,51 @@ extern "C" int vpf_abi_sizeof(int which)
         case 6: return (int)sizeof(VpfAdapterKvBwd);
         default: return -1;
     }
+}
+
+// ------------------------------------------------------------------ VpfDebug: the one place that reads the environment
+struct VpfDebugKey { const char* name; const char* env; int VpfDebug::*field; int dflt; };
+static const VpfDebugKey kDebugKeys[] = {
+    {"attn_resident", "VPF_ATTN_RESIDENT", &VpfDebug::attn_resident, 1},
+    {"g2e_grid", "VPF_G2E_GRID", &VpfDebug::g2e_grid, 256},
+    {"g2e_w4_grid", "VPF_G2E_W4_GRID", &VpfDebug::g2e_w4_grid, 256},
+    {"wgrad_cfg", "VPF_WGRAD_CFG", &VpfDebug::wgrad_cfg, 0},
+    {"wgrad_wgs", "VPF_WGRAD_WGS", &VpfDebug::wgrad_wgs, 0},
+    {"gemm_cfg", "VPF_GEMM_CFG", &VpfDebug::gemm_cfg, -1},
+    {"wgroup_cfg", "VPF_WGROUP_CFG", &VpfDebug::wgroup_cfg, 2},
+    {"wgroup_wgs", "VPF_WGROUP_WGS", &VpfDebug::wgroup_wgs, 0},
+    {"wgroup_uneven", "VPF_WGROUP_UNEVEN", &VpfDebug::wgroup_uneven, 2},
+    {"wgroup_dbg", "VPF_WGROUP_DBG", &VpfDebug::wgroup_dbg, 0},
+    {"fps_exclusive_cu", "VPF_FPS_EXCLUSIVE_CU", &VpfDebug::fps_exclusive_cu, 0},
+    {"knn_select", "VPF_KNN_SELECT", &VpfDebug::knn_select, 1},
+    {"sa_nj", "VPF_SA_NJ", &VpfDebug::sa_nj, 1},
+    {"sa_bwd_rows", "VPF_SA_BWD_ROWS", &VpfDebug::sa_bwd_rows, 1},
+    {"smallk_rpb", "VPF_SMALLK_RPB", &VpfDebug::smallk_rpb, 0},
+    {"sa_wg2", "VPF_SA_WG2", &VpfDebug::sa_wg2, 1},
+};
+VpfDebug& vpf_debug()
+{
+    static VpfDebug d = [] {
+        VpfDebug v;
+        for (const VpfDebugKey& k : kDebugKeys) {
+            const char* e = getenv(k.env);
+            v.*(k.field) = e ? atoi(e) : k.dflt;
+        }
+        return v;
+    }();
+    return d;
+}
+extern "C" int vpf_debug_set(const char* key, int value)
+{
+    if (!key) return VPF_ERR_NULL;
+    for (const VpfDebugKey& k : kDebugKeys)
+        if (!strcmp(k.name, key)) { vpf_debug().*(k.field) = value; return VPF_OK; }
+    return VPF_ERR_UNSUPPORTED;
+}
+extern "C" int vpf_debug_get(const char* key, int* value)
+{
+    if (!key || !value) return VPF_ERR_NULL;
+    for (const VpfDebugKey& k : kDebugKeys)
+        if (!strcmp(k.name, key)) { *value = vpf_debug().*(k.field); return VPF_OK; }
+    return VPF_ERR_UNSUPPORTED;
 }

@@ -412,8 +412,7 @@ extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ld
     if ((ldo % 4) || ((uintptr_t)out & 7)) return VPF_ERR_BADALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int nqb = vpf_cdiv(Lq, 32);
-    static int res = -1;
-    if (res < 0) { const char* e = getenv("VPF_ATTN_RESIDENT"); res = e ? atoi(e) : 1; }
+    const int res = vpf_debug().attn_resident;
     if (res && Lq == Lkv && k != q) {     // self-attention with the whole head resident in LDS
         if (nqb == 3) return launch_res_fwd<3>(a, st);
         if (nqb == 7) return launch_res_fwd<7>(a, st);
@@ -1080,8 +1079,7 @@ static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
     } else {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ, 32>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), sizeof(bf16_t) * 2 * 2 * 32 * KLD, st, a, delta);
     }
-    static int res = -1;
-    if (res < 0) { const char* e = getenv("VPF_ATTN_RESIDENT"); res = e ? atoi(e) : 1; }
+    const int res = vpf_debug().attn_resident;
     if (res && a.Lq <= 96 && NWK == 4)
         hipLaunchKernelGGL((attn_bwd_dkv_resq_kernel<NWK, 3>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
     else if (res && a.Lq <= 128 && NWK == 4)
@@ -1122,8 +1120,7 @@ extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ld
     if (((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7) || ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7)) return VPF_ERR_BADALIGN;
     hipStream_t st = (hipStream_t)stream;
     const int nqb = vpf_cdiv(Lq, 32);
-    static int res = -1;
-    if (res < 0) { const char* e = getenv("VPF_ATTN_RESIDENT"); res = e ? atoi(e) : 1; }
+    const int res = vpf_debug().attn_resident;
     if (res && Lq == Lkv && k != q) {
         if (nqb == 3) return launch_res_bwd<3>(a, delta_ws, st);
         if (nqb == 7) return launch_res_bwd<7>(a, delta_ws, st);

@@ -269,9 +269,8 @@ __global__ void g2e_fold_bn1_kernel(const float* __restrict__ W1, const float* _
 // persistent workgroups per launch: one per CU by default (VPF_G2E_GRID overrides, e.g. to leave CUs to a concurrent stream)
 static int g2e_max_grid()
 {
-    static int g = -1;
-    if (g < 0) { const char* e = getenv("VPF_G2E_GRID"); g = e ? atoi(e) : 256; if (g < 1) g = 256; }
-    return g;
+    const int g = vpf_debug().g2e_grid;
+    return g < 1 ? 256 : g;
 }
 extern "C" int vpf_g2e_fold_bn1(const float* W1, const float* b1, const float* ab1, int C, float* w1e, float* b1e, void* stream)
 {
@@ -423,8 +422,7 @@ extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, co
     if (!h3_bf16 || !ab2 || !dout || !arg4 || !dW4 || !db4) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0) return VPF_ERR_BADSHAPE;
     G2eW4 p = {(const bf16_t*)h3_bf16, NG, ab2, dout, arg4, Dm, dW4, db4};
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("VPF_G2E_W4_GRID"); cap = e ? atoi(e) : 256; if (cap < 1) cap = 256; }      // one workgroup per CU: twice the flush atomics of 128 workgroups, half the walk (168 -> ~110 us)
+    const int cap = vpf_debug().g2e_w4_grid < 1 ? 256 : vpf_debug().g2e_w4_grid;      // one workgroup per CU: twice the flush atomics of 128 workgroups, half the walk (168 -> ~110 us)
     long gx = NG < cap ? NG : cap;
     hipLaunchKernelGGL(g2e_wgrad4_kernel, dim3((unsigned)gx, vpf_cdiv(Dm, 256)), dim3(512), 0, (hipStream_t)stream, p);
     VPF_CHECK_LAUNCH();

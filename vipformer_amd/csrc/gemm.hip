@@ -599,8 +599,7 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return VPF_ERR_BADALIGN;
     if (g.mode == EPI_ATOMIC) {
         if (!g.c_f32) return VPF_ERR_UNSUPPORTED;
-        static int wcfg = -1, wtarget = 512;
-        if (wcfg < 0) { const char* e = getenv("VPF_WGRAD_CFG"); wcfg = e ? atoi(e) : 0; const char* t = getenv("VPF_WGRAD_WGS"); if (t) wtarget = atoi(t); }
+        const int wcfg = vpf_debug().wgrad_cfg, wtarget = vpf_debug().wgrad_wgs > 0 ? vpf_debug().wgrad_wgs : 512;
         const int tm = wcfg == 0 ? 64 : 128, tn = wcfg == 2 ? 128 : 64;
         if (g.splitk <= 0) {
             // fill ~512 workgroups of 64x64 tiles
@@ -620,8 +619,7 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
     g.splitk = 0;
     // Tile choice.  These GEMMs are small (M ~ 12 k tokens, N, K in 256..768) and bound by the bytes each CU has to pull
     // (A re-read once per column tile, W once per row tile), so the largest tile that still gives every CU a workgroup wins.
-    static int forced = -2;
-    if (forced == -2) { const char* e = getenv("VPF_GEMM_CFG"); forced = e ? atoi(e) : -1; }
+    const int forced = vpf_debug().gemm_cfg;
     const long wg128 = (long)vpf_cdiv(g.M, 128) * vpf_cdiv(g.N, 128) * batch;
     const long wg_128x64 = (long)vpf_cdiv(g.M, 128) * vpf_cdiv(g.N, 64) * batch;
     int cfg = (wg128 >= 160 && g.N >= 128) ? 2 : (wg_128x64 >= 192 ? 1 : 0);
@@ -696,8 +694,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
     if (njobs <= 0 || njobs > GEMM_GROUP_MAX) return VPF_ERR_BADSHAPE;
     GemmGroup grp = {};
     grp.n = njobs;
-    static int cfg = -1, target = 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
-    if (cfg < 0) { const char* e = getenv("VPF_WGROUP_CFG"); cfg = e ? atoi(e) : 2; const char* t = getenv("VPF_WGROUP_WGS"); if (t) target = atoi(t); }
+    const int cfg = vpf_debug().wgroup_cfg, target = vpf_debug().wgroup_wgs > 0 ? vpf_debug().wgroup_wgs : 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     const int partial = ws != nullptr;
     const int tm = cfg == 0 ? 64 : 128, tn = (cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64);
     long total_tiles = 0;
@@ -722,8 +719,8 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at
         // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
         // 512 workgroups flushing together at the end (-0.035 ms/step, 15 launches)
-        { static int un = -1; if (un < 0) { const char* e = getenv("VPF_WGROUP_UNEVEN"); un = e ? atoi(e) : 2; } g.uneven = un; }
-        { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VPF_WGROUP_DBG"); dbg = e ? atoi(e) : 0; } g.dbg = dbg; }
+        g.uneven = vpf_debug().wgroup_uneven;
+        g.dbg = vpf_debug().wgroup_dbg;
         grp.nx[i] = nx; grp.ny[i] = ny; grp.start[i] = at;
         at += nx * ny * (int)sp;
     }

@@ -223,14 +223,16 @@ __global__ void __launch_bounds__(256) ce_smooth_kernel(const float* __restrict_
         for (int c = lane; c < C; c += 64) { s += __expf(zr[c] - m); sum += zr[c]; }
         s = wave_sum(s); sum = wave_sum(sum);
         const float lse = m + __logf(s);
-        const int yy = (int)y[r];
-        const float zy = zr[yy];
+        const long long yl = y[r];
+        const bool bad = yl < 0 || yl >= (long long)C;      // torch.nn.CrossEntropyLoss raises on such a target (ft_partseg.py never
+        const int yy = bad ? 0 : (int)yl;                   // passes ignore_index); a kernel cannot: the loss and the row's gradient
+        const float zy = bad ? __builtin_nanf("") : zr[yy]; // become NaN instead of an out-of-bounds read
         acc += (1.f - eps) * (lse - zy) + eps * (lse - sum / (float)C);
         if (dz) {
             float* d = dz + r * lddz;
             const float inv = 1.f / (float)rows;
             for (int c = lane; c < C; c += 64)
-                d[c] = (__expf(zr[c] - lse) - ((c == yy ? 1.f - eps : 0.f) + eps / (float)C)) * inv;
+                d[c] = bad ? __builtin_nanf("") : (__expf(zr[c] - lse) - ((c == yy ? 1.f - eps : 0.f) + eps / (float)C)) * inv;
         }
     }
     if (lane == 0) sp[wid] = acc;

@@ -103,8 +103,7 @@ static int launch_fps(const float* pts, int B, int N, int C, const int64_t* star
     // mis-sampling beside gemm_kernel workgroups was not understood.  The trigger were the packed-fp32
     // instructions the SLP vectoriser formed in the distance update; this file is now compiled without them (build.py) and the sampler
     // shares its CU again (1 000 of 1 000 launches bit-identical beside dgrad GEMMs either way).
-    static int exclusive = -1;
-    if (exclusive < 0) { const char* e = getenv("VPF_FPS_EXCLUSIVE_CU"); exclusive = e ? atoi(e) : 0; }
+    const int exclusive = vpf_debug().fps_exclusive_cu;
     if (exclusive) lds = 160 * 1024;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)fps_kernel<NT, PPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -457,8 +456,7 @@ extern "C" int vpf_knn_group_f32(const float* xyz, int B, int N, int C, const fl
     int cpw = 4;
     while ((long)B * vpf_cdiv(G, cpw) > 2048 && cpw < G) cpw *= 2;
     dim3 grid(vpf_cdiv(G, cpw), B);
-    static int sel = -1;
-    if (sel < 0) { const char* e = getenv("VPF_KNN_SELECT"); sel = e ? atoi(e) : 1; }
+    const int sel = vpf_debug().knn_select;
     const size_t lds = sizeof(float) * (4 * (size_t)N + 2) + (sel ? sizeof(unsigned long long) * 4 * 64 + 16 : 0);
 #define VPF_KNN_LAUNCH(PPL)                                                                                      \
     if (sel) hipLaunchKernelGGL((knn_group_select_kernel<PPL>), grid, dim3(256), lds, st, xyz, N, C, centers, Cc, G, K,  \
@@ -510,10 +508,12 @@ __global__ void __launch_bounds__(256) three_nn_kernel(const float* __restrict__
         }
     }
     const size_t o = ((size_t)b * N + n) * 3;
-    if (S < 3) {        // (the reference would fail to slice three neighbours; S == 1 is handled by the caller as a broadcast)
-        if (S < 2) { d1 = d0; i1 = i0; }
-        d2 = d1; i2 = i1;
+    if (S == 1) {       // utils.py:216-217: a single centre is broadcast (points2.repeat): weight exactly 1 on it, nothing else
+        idx[o] = 0; idx[o + 1] = 0; idx[o + 2] = 0;
+        w[o] = 1.0f; w[o + 1] = 0.0f; w[o + 2] = 0.0f;
+        return;
     }
+    if (S < 3) { d2 = d1; i2 = i1; }       // S == 2: the reference cannot slice three neighbours (the caller raises); keep the kernel total
     const float r0 = 1.0f / (d0 + 1e-8f), r1 = 1.0f / (d1 + 1e-8f), r2 = 1.0f / (d2 + 1e-8f);
     float norm = r0 + r1;
     norm = norm + r2;
@@ -525,7 +525,8 @@ extern "C" int vpf_three_nn_f32(const float* xyz, int B, int N, int C, const flo
 {
     (void)hipGetLastError();
     if (!xyz || !centers || !idx || !weight) return VPF_ERR_NULL;
-    if (B < 0 || N < 0 || S <= 0 || C < 3 || Cc < 3 || B > 65535 || S > 8192) return VPF_ERR_BADSHAPE;
+    if (B < 0 || N < 0 || S <= 0 || C < 3 || Cc < 3 || B > 65535) return VPF_ERR_BADSHAPE;
+    if (S > 4096) return VPF_ERR_UNSUPPORTED;       // 16 S bytes of LDS for the staged centres: 64 KB without an opt-in (the path uses S <= 128)
     if (B == 0 || N == 0) return VPF_OK;
     hipLaunchKernelGGL(three_nn_kernel, dim3(vpf_cdiv(N, 256), B), dim3(256), sizeof(float) * 4 * S, (hipStream_t)stream, xyz, C, centers, Cc,
                        N, S, idx, weight);

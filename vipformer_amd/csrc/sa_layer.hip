@@ -854,8 +854,7 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     if (a.D != SA_D || a.H != SA_H || a.hidden != SA_HID) return VPF_ERR_UNSUPPORTED;
     const int chunks = vpf_cdiv(a.L, a.chunk_rows);
     hipStream_t st = (hipStream_t)stream;
-    static int nj = -1;
-    if (nj < 0) { const char* e = getenv("VPF_SA_NJ"); nj = e ? atoi(e) : 1; }
+    const int nj = vpf_debug().sa_nj;
     if (a.attention_done) {                                                   // o is an input: 64-row blocks, any sequence length
         if (nj == 2) return sa_launch<2, 2, 32, false, 2>(a, 1, st);          // 4 waves x 64 channels
         return sa_launch<2, 2, 32, false, 1>(a, 1, st);                       // 8 waves x 32 channels: two waves per SIMD overlap MFMA, VALU and memory waits
@@ -1467,9 +1466,7 @@ extern "C" int vpf_ln_pgrad_reduce(const VpfPgradJob* jobs, int njobs, void* str
 
 static int sa_bwd_nj()
 {
-    static int nj = -1;
-    if (nj < 0) { const char* e = getenv("VPF_SA_NJ"); nj = e ? atoi(e) : 1; }
-    return nj;
+    return vpf_debug().sa_nj;
 }
 static int sa_bwd_check(const VpfSaLayerBwd& a)
 {
@@ -1496,8 +1493,7 @@ extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
         attr = true;
     }
     const int nwg = vpf_cdiv((long)a.M, TOK);
-    static int rows = -1;
-    if (rows < 0) { const char* e = getenv("VPF_SA_BWD_ROWS"); rows = e ? atoi(e) : 1; }
+    const int rows = vpf_debug().sa_bwd_rows;
     if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else if (rows) hipLaunchKernelGGL((sa_bwd_mlp_rows_kernel<RB>), dim3(nwg), dim3(512), lds + (size_t)TOK * XLD * 4, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((sa_bwd_mlp_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
@@ -1522,8 +1518,7 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
         attr = true;
     }
     const int nwg = vpf_cdiv((long)a.M, TOK);
-    static int rows = -1;
-    if (rows < 0) { const char* e = getenv("VPF_SA_BWD_ROWS"); rows = e ? atoi(e) : 1; }
+    const int rows = vpf_debug().sa_bwd_rows;
     if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else if (rows) hipLaunchKernelGGL((sa_bwd_qkv_rows_kernel<RB>), dim3(nwg), dim3(512), lds + (size_t)TOK * XLD * 4, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);

@@ -255,8 +255,7 @@ extern "C" int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C
     if (M == 0) return VPF_OK;
     // ~100 row blocks: with 24 (512 rows each) the kernel ran on 24 CUs and took 51 us for 12 k rows; with many more the
     // atomics of the blocks on the same N x (C + 1) addresses serialise in L2
-    static int rpb0 = -1;
-    if (rpb0 < 0) { const char* e = getenv("VPF_SMALLK_RPB"); rpb0 = e ? atoi(e) : 0; }
+    const int rpb0 = vpf_debug().smallk_rpb;
     int rpb = rpb0 > 0 ? rpb0 : (int)(((M + 95) / 96 + 31) / 32 * 32);
     if (rpb < 128) rpb = 128;                        // 8 row lanes x rpb / 8 rows each
     while ((M + rpb - 1) / rpb > 4096) rpb *= 2;

@@ -22,6 +22,30 @@ struct VpfPerDevice {
     bool& operator()() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= VPF_MAX_DEVICES) d = 0; return done[d]; }
 };
 
+// ------------------------------------------------------------------ launch-time experiment knobs, in ONE place
+// Every A/B switch the launchers consult (kernel variant, grid caps, ...).  Filled ONCE per process (api.hip: the VPF_* environment
+// variables named there, read when the first launcher asks) and changed only through vpf_debug_set (tests / tools).  No launcher reads
+// the environment itself.  The defaults are the measured-fastest parity-green variants.
+struct VpfDebug {
+    int attn_resident;      // VPF_ATTN_RESIDENT     1: whole-head resident attention kernels when the sequence fits (0: tiled ones)
+    int g2e_grid;           // VPF_G2E_GRID          persistent Group2Emb workgroups
+    int g2e_w4_grid;        // VPF_G2E_W4_GRID       workgroups of the sparse dW4 walk
+    int wgrad_cfg;          // VPF_WGRAD_CFG         tile configuration of the single weight-gradient GEMM (0: by shape)
+    int wgrad_wgs;          // VPF_WGRAD_WGS         its target workgroup count (0: default)
+    int gemm_cfg;           // VPF_GEMM_CFG          forced tile configuration of vpf_gemm_bf16 (-1: by shape)
+    int wgroup_cfg;         // VPF_WGROUP_CFG        tile configuration of the grouped weight gradient
+    int wgroup_wgs;         // VPF_WGROUP_WGS        its target workgroup count (0: default)
+    int wgroup_uneven;      // VPF_WGROUP_UNEVEN     K slices of alternating length (2), equal (0)
+    int wgroup_dbg;         // VPF_WGROUP_DBG        anatomy switches of tools/microbench.py wgroup (0 in production)
+    int fps_exclusive_cu;   // VPF_FPS_EXCLUSIVE_CU  1: a CU of its own per cloud (160 KB LDS request); containment of DESIGN.md section 6
+    int knn_select;         // VPF_KNN_SELECT        1: bisection select kernel, 0: K successive extractions
+    int sa_nj;              // VPF_SA_NJ             channel blocks per wave of the encoder row-block kernels (1: 8 waves, 2: 4 waves)
+    int sa_bwd_rows;        // VPF_SA_BWD_ROWS       1: row-coalesced backward row-block kernels
+    int smallk_rpb;         // VPF_SMALLK_RPB        rows per block of the K = 3 front kernels (0: default)
+    int sa_wg2;             // VPF_SA_WG2            1: encoder row-block kernels built for two workgroups per CU (round 3)
+};
+VpfDebug& vpf_debug();
+
 // ------------------------------------------------------------------ bf16 helpers
 typedef uint16_t bf16_t;
 

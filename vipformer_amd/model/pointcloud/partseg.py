@@ -332,7 +332,7 @@ class _PointBackbone(nn.Module):
         stream waits for the event only in front of Group2Emb, so FPS / kNN (latency-bound, a few workgroups) run beside it."""
         enc = self.encoder
         fuse_kv = (ops.adapter_kv_supported(self.input_adapter, pts) and enc.num_cross_attention_layers == 1 and pts.is_cuda
-                   and ops.SA_FUSED[0] and ops.ENC_FUSED[0] and self.training == enc.training)
+                   and ops.cfg.sa_fused and ops.cfg.enc_fused and self.training == enc.training)
         kv = None
         if not fuse_kv:
             pts_embs = self.input_adapter(pts)

@@ -37,6 +37,35 @@ F32 = torch.float32
 EPI_STORE, EPI_GELU, EPI_DROP_RES, EPI_GELU_BWD, EPI_ATOMIC, EPI_RELU, EPI_GROUPBIAS = range(7)
 
 
+class OpsConfig:
+    """Every path switch of this module in ONE object (``ops.cfg``), read once at import; A/B tests and tools flip attributes.
+    None of them is a user-facing option: the defaults are the measured-fastest parity-green paths (DESIGN.md sections 4, 5).
+    The library's own launch-time knobs live in its VpfDebug struct (``_lib.debug_get`` / ``debug_set``)."""
+    __slots__ = ("wgrad_async", "wgrad_group", "wgrad_group_async", "wgrad_deterministic", "wgrad_defer", "sa_debug", "sa_split_attn",
+                 "sa_fused_bwd", "sa_fused", "enc_bwd_hook", "adapter_kv_fused", "adapter_kv_bwd_fused", "enc_fused", "g2e_bn_merged",
+                 "g2e_conv1_bwd_fused")
+
+    def __init__(self, env=os.environ):
+        self.wgrad_async = False          # weight-gradient GEMMs on a side stream: measured slower (cross-stream event cost > overlap gain)
+        self.wgrad_group = True           # one grouped launch per layer for the weight gradients (vpf_wgrad_group)
+        self.wgrad_group_async = False    # issue the grouped launches on a side stream (joined by join_wgrad_streams)
+        self.wgrad_deterministic = False  # grouped weight gradients through the split-K workspace instead of fp32 atomics (slower, bitwise reproducible)
+        self.wgrad_defer = None           # the open WgradDeferral, if any (process-wide: autograd runs backward on its own thread)
+        self.sa_debug = None              # int64 tensor of >= 8: phase cycle counters of workgroup 0 of the last fused layer launch
+        self.sa_split_attn = None         # None: per-shape default; True: vpf_attention_fwd + fused tail; False: attention inside the layer kernel
+        self.sa_fused_bwd = True          # backward of the stack through vpf_sa_layer_bwd_mlp / _qkv instead of the block-by-block kernels
+        self.sa_fused = True              # Encoder.forward uses the one-kernel-per-layer path when the shapes allow it
+        self.enc_bwd_hook = None          # schedule experiments (tools/step_timeline.py): callable(cross_attention_layer, i)
+        self.adapter_kv_fused = True      # point adapter + kv LayerNorm + K / V projections as one kernel
+        self.adapter_kv_bwd_fused = True
+        self.enc_fused = True             # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
+        self.g2e_bn_merged = env.get("VPF_G2E_BN_MERGED", "1") != "0"          # BatchNorm bookkeeping of Group2Emb as single launches
+        self.g2e_conv1_bwd_fused = env.get("VPF_G2E_CONV1_FUSED", "1") == "1"  # conv2 dgrad inside the first conv's backward (tests run both)
+
+
+cfg = OpsConfig()
+
+
 # --------------------------------------------------------------------------- RNG state
 class _Rng:
     """Device-resident dropout state {seed_lo, seed_hi, step, 0}.  A keep decision is a pure function of (state, site,
@@ -406,7 +435,6 @@ def linear_dgrad(dy16, w16, N, K, *, out_f32=False, mode=EPI_STORE, **kw):
 
 # Weight gradients are off the backward critical path (nothing downstream reads them before the optimizer), so they CAN be
 # issued on a side stream per compute stream (dgrad chain on the main stream, wgrad GEMMs on idle CUs).  Optional:
-WGRAD_ASYNC = [False]     # measured slower on MI355X at these kernel sizes (cross-stream event cost > overlap gain)
 _wgrad_streams = {}
 
 
@@ -430,7 +458,7 @@ def linear_wgrad(dy16, x16, N, K, dW, dbias=None):
     """dW[N,K] += dy16[M,N]^T @ x16[M,K]   (both operands k-strided, split over M, fp32 atomics);
     dbias[N] += column sums of dy16 in the same pass."""
     M = dy16.numel() // N
-    if not WGRAD_ASYNC[0]:
+    if not cfg.wgrad_async:
         gemm(dy16, 1, N, x16, 1, K, N, K, M, dW, K, c_f32=True, mode=EPI_ATOMIC, dbias=dbias)
         return
     cur, side = _wgrad_side()
@@ -441,20 +469,17 @@ def linear_wgrad(dy16, x16, N, K, dW, dbias=None):
     x16.record_stream(side)
 
 
-WGRAD_GROUP = [True]
-WGRAD_GROUP_ASYNC = [False]   # issue the grouped launches on a side stream (joined by join_wgrad_streams)
 
 
 WGRAD_WS_BYTES = 4096 + 1024 * 65536      # arrival counters + one 128 x 128 f32 partial tile for up to 1024 workgroups
-WGRAD_DETERMINISTIC = [False]             # grouped weight gradients through the split-K workspace instead of fp32 atomics (slower, bitwise reproducible)
 _wgrad_ws = {}
 
 
 def wgrad_workspace(device):
     """The split-K scratch of vpf_wgrad_group, private to (device, current stream): two branches that run their grouped weight
     gradients concurrently on two streams must not share partial tiles.  Counters zeroed once; the kernel leaves them zero.
-    None unless WGRAD_DETERMINISTIC: the library then adds the slices' tiles into dW with fp32 atomics."""
-    if not WGRAD_DETERMINISTIC[0]:
+    None unless cfg.wgrad_deterministic: the library then adds the slices' tiles into dW with fp32 atomics."""
+    if not cfg.wgrad_deterministic:
         return None
     key = (_Rng._index(device), torch.cuda.current_stream().cuda_stream)
     ws = _wgrad_ws.get(key)
@@ -498,7 +523,6 @@ class WgradDeferral:
         self.queue = []
 
 
-WGRAD_DEFER = [None]      # the open WgradDeferral, if any (module-level: autograd runs backward on its own thread)
 
 
 class WgradBatch:
@@ -508,7 +532,7 @@ class WgradBatch:
         self.jobs = []
 
     def add(self, dy16, x16, N, K, dW, dbias=None):
-        if not WGRAD_GROUP[0]:
+        if not cfg.wgrad_group:
             linear_wgrad(dy16, x16, N, K, dW, dbias)
             return
         self.jobs.append((dy16, x16, dy16.numel() // N, N, K, dW, dbias))
@@ -522,10 +546,10 @@ class WgradBatch:
         for i, (dy, x, M, N, K, dW, db) in enumerate(self.jobs):
             arr[i].dy, arr[i].x, arr[i].M, arr[i].N, arr[i].K = dy.data_ptr(), x.data_ptr(), M, N, K
             arr[i].dW, arr[i].dbias = dW.data_ptr(), (db.data_ptr() if db is not None else None)
-        if WGRAD_DEFER[0] is not None and WGRAD_DEFER[0].take(self.jobs, arr):
+        if cfg.wgrad_defer is not None and cfg.wgrad_defer.take(self.jobs, arr):
             self.jobs = []
             return
-        if WGRAD_ASYNC[0] or WGRAD_GROUP_ASYNC[0]:
+        if cfg.wgrad_async or cfg.wgrad_group_async:
             # weight gradients are off the dgrad critical path: one grouped launch per layer on a side stream
             cur, side = _wgrad_side()
             side.wait_stream(cur)
@@ -768,16 +792,12 @@ class MLPBlockFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- fused self-attention stack
-SA_DEBUG = []         # [int64 tensor of >= 8]: phase cycle counters of workgroup 0 of the last fused layer launch
-SA_SPLIT_ATTN = [None]  # None: per-shape default; True: vpf_attention_fwd + fused tail; False: attention inside the layer kernel
-SA_FUSED_BWD = [True]  # backward of the stack through vpf_sa_layer_bwd_mlp / _qkv instead of the block-by-block kernels
-SA_FUSED = [True]      # Encoder.forward uses the one-kernel-per-layer path when the shapes allow it
 
 
 def sa_stack_supported(layers, x) -> bool:
     """vpf_sa_layer_fwd covers D = 256, 4 heads of 64, hidden 512, sequences of <= 96 tokens (one workgroup per
     sequence) or <= 224 tokens (two chunks), identity drop-path."""
-    if not SA_FUSED[0] or len(layers) == 0 or x.dim() != 3:
+    if not cfg.sa_fused or len(layers) == 0 or x.dim() != 3:
         return False
     B, Lq, D = x.shape
     if D != 256 or Lq > 224:
@@ -886,7 +906,7 @@ class SAStackFn(torch.autograd.Function):
             a.p_res2, a.site_res2 = float(layer[1].dropout.p if training else 0.0), layer[1].site
             a.o, a.lse, a.x1, a.mean2, a.rstd2, a.n2 = o.data_ptr(), lse.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), n2.data_ptr()
             a.u, a.h, a.out = u.data_ptr(), h.data_ptr(), out.data_ptr()
-            split = SA_SPLIT_ATTN[0] if SA_SPLIT_ATTN[0] is not None else True
+            split = cfg.sa_split_attn if cfg.sa_split_attn is not None else True
             if split:
                 L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, D // H, float(att.dp_scale),
                        float(a.p_att), st, att.site_attn, o, D, lse)
@@ -899,8 +919,8 @@ class SAStackFn(torch.autograd.Function):
                 a.pos, a.pos_rows = (pos_c.data_ptr() if pos_c is not None else None), pos_rows
                 a.ln1n_g, a.ln1n_b, a.Wqkv_next = lnn.weight.data.data_ptr(), lnn.bias.data.data_ptr(), packed[i + 1]["Wqkv"].data_ptr()
                 a.mean1n, a.rstd1n, a.n1n, a.qkv_next = nxt[0].data_ptr(), nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[3].data_ptr()
-            if SA_DEBUG:
-                a.dbg = SA_DEBUG[0].data_ptr()
+            if cfg.sa_debug is not None:
+                a.dbg = cfg.sa_debug.data_ptr()
             L.call_struct("vpf_sa_layer_fwd", a)
             flat += [base, m1, r1, n1, qkv, o, lse, x1, m2, r2, n2, u, h]
             if not last:
@@ -922,7 +942,7 @@ class SAStackFn(torch.autograd.Function):
         d = dout.contiguous().float().view(M, D)
         st = ctx.rng_st
         want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
-        if SA_FUSED_BWD[0]:
+        if cfg.sa_fused_bwd:
             return SAStackFn._backward_fused(ctx, d, st, want_pos)
         dsum = None
         for i in range(len(layers) - 1, -1, -1):
@@ -1124,7 +1144,6 @@ def _tail_fwd(att, mlp, res_attn, res_mlp, pk, training, st, B, Lq, qkv_dummy, b
     return (x1, m2, r2, n2, u, h), out, head
 
 
-ENC_BWD_HOOK = [None]      # schedule experiments (tools/step_timeline.py): callable(cross_attention_layer, i) in front of layer i of
                            # EncoderFusedFn.backward (i = -1: the cross-attention layer)
 
 
@@ -1245,8 +1264,8 @@ class EncoderFusedFn(torch.autograd.Function):
                 npj = 0
 
         for i in range(nl - 1, -1, -1):
-            if ENC_BWD_HOOK[0] is not None:
-                ENC_BWD_HOOK[0](ca, i)
+            if cfg.enc_bwd_hook is not None:
+                cfg.enc_bwd_hook(ca, i)
             tg = tap_grad.get(i + 1)
             if tg is not None:                              # the tapped output feeds the head AND the next layer
                 tg = tg.contiguous().float().view(M, D)
@@ -1281,8 +1300,8 @@ class EncoderFusedFn(torch.autograd.Function):
             pgrad_job(i + 1, 0, ln1)
             d = dbase
         # ---- cross-attention layer
-        if ENC_BWD_HOOK[0] is not None:
-            ENC_BWD_HOOK[0](ca, -1)
+        if cfg.enc_bwd_hook is not None:
+            cfg.enc_bwd_hook(ca, -1)
         base_ca, mq, rq, nq, xkv, mk, rk, nk, q, kv, o, lse, x1, m2, r2, n2, u, h = flat[:18]
         cross, cmlp = ca[0].module, ca[1].module
         catt, lnq, lnkv = cross.attention, cross.q_norm, cross.kv_norm
@@ -1389,7 +1408,7 @@ class AdapterKVFn(torch.autograd.Function):
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         w16, gKV = shadow(qkvw), packed_grad(qkvw[1:])
         dkv = to_bf16(dkv).view(M, 2 * D)
-        if ADAPTER_KV_BWD_FUSED[0]:
+        if cfg.adapter_kv_bwd_fused:
             pk = ctx.packed
             n2, nkv = D * 64, 2 * D * D
             nwg = (M + 63) // 64
@@ -1424,19 +1443,17 @@ class AdapterKVFn(torch.autograd.Function):
         return (None, None, None) + (None,) * ctx.nparams
 
 
-ADAPTER_KV_FUSED = [True]
-ADAPTER_KV_BWD_FUSED = [True]
 
 
 def adapter_kv_supported(adapter, pts) -> bool:
-    if not ADAPTER_KV_FUSED[0] or pts.dim() != 3 or pts.shape[-1] > 8:
+    if not cfg.adapter_kv_fused or pts.dim() != 3 or pts.shape[-1] > 8:
         return False
     l3 = adapter.point_mlp[3]
     return tuple(l3.weight.shape) == (256, 64)
 
 
 def encoder_fused_supported(ca, layers, x, xkv) -> bool:
-    if not (SA_FUSED[0] and ENC_FUSED[0]) or not sa_stack_supported(layers, x) or xkv is None or xkv.dim() != 3:
+    if not (cfg.sa_fused and cfg.enc_fused) or not sa_stack_supported(layers, x) or xkv is None or xkv.dim() != 3:
         return False
     if not getattr(ca, "attention_residual", False):
         return False
@@ -1446,7 +1463,6 @@ def encoder_fused_supported(ca, layers, x, xkv) -> bool:
     return isinstance(ca[0].drop_path, torch.nn.Identity) and isinstance(ca[1].drop_path, torch.nn.Identity)
 
 
-ENC_FUSED = [True]     # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
 
 
 # --------------------------------------------------------------------------- generic dropout + residual (Residual fallback)
@@ -1503,11 +1519,9 @@ def _bn_bwd(dy, x, C, stat, bn, relu, training, out_bf16, want_dx=True):
 
 
 # --------------------------------------------------------------------------- Group2Emb (utils.py:144-189)
-G2E_BN_MERGED = [os.environ.get("VPF_G2E_BN_MERGED", "1") != "0"]   # BatchNorm bookkeeping of Group2Emb as single launches
 G2E_DEBUG = {}      # {"dbg": int64 tensor [256*2*6]} -> per-phase cycle stamps of vpf_g2e_bwd (diagnostic)
 
 
-G2E_CONV1_BWD_FUSED = [os.environ.get("VPF_G2E_CONV1_FUSED", "1") == "1"]      # conv2 dgrad inside the first conv's backward (tests run both)
 
 
 class Group2EmbFn(torch.autograd.Function):
@@ -1531,7 +1545,7 @@ class Group2EmbFn(torch.autograd.Function):
         stat1 = torch.empty(128, dtype=F32, device=dev)
         scratch = None
         fast = K == 32 and C == 3 and Dm % 32 == 0 and Dm <= 512
-        merged = training and fast and G2E_BN_MERGED[0]
+        merged = training and fast and cfg.g2e_bn_merged
         if merged:
             # moments -> statistics -> affine -> folded conv in two launches (vpf_g2e_bn1_prepare)
             scratch = torch.empty(72 + 512 * 72, dtype=F32, device=dev)
@@ -1671,7 +1685,7 @@ class Group2EmbFn(torch.autograd.Function):
         L.call("vpf_group_max_scatter_add", dgmax, arg2, NG, K, 128, dh2)
         linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
         ws = torch.empty(1025 * 320, dtype=F32, device=dev)                      # per-block partial sums (no atomics)
-        if G2E_CONV1_BWD_FUSED[0]:
+        if cfg.g2e_conv1_bwd_fused:
             # conv2's input gradient is formed and consumed inside the first conv's backward: da1 [M, 64] never exists
             L.call("vpf_g2e_conv1_bwd_fused", x, dh2, M, C, c1.weight.data.view(64, C), c1.bias.data, stat1, bn1.weight.data, bn1.bias.data,
                    int(training), ctx.mom, shadow([c2.weight]), grad_buf(c1.weight), grad_buf(c1.bias), grad_buf(bn1.weight),
@@ -1954,12 +1968,12 @@ class Timeline:
         fn.argtypes, fn.restype = [], L.I
         self.khz = int(fn())
         if self.khz <= 0:
-            raise VpfError("vpf_wall_clock_khz failed")
+            raise L.VpfError("vpf_wall_clock_khz failed")
 
     def mark(self, name: str) -> None:
         if name not in self.names:
             if len(self.names) == self.buf.numel():
-                raise VpfError("Timeline: out of slots")
+                raise L.VpfError("Timeline: out of slots")
             self.names.append(name)
         L.call("vpf_stamp", self.buf, self.names.index(name))
 

@@ -139,6 +139,9 @@ class FeaturePropFn(torch.autograd.Function):
         L.need_cuda(xyz1, xyz2, feat)
         B, N, _ = xyz1.shape
         S, Fd = xyz2.shape[1], feat.shape[2]
+        if S == 2:
+            # utils.py:224-230: dists[:, :, :3] of two centres has two columns and weight.view(B, N, 3, 1) raises
+            raise RuntimeError("PointNetFeaturePropagation: three neighbours cannot be taken from S = 2 centres (the reference raises here too)")
         dev = feat.device
         xyz1c, xyz2c = xyz1.detach().contiguous().float(), xyz2.detach().contiguous().float()
         featc = feat.contiguous().float()

@@ -117,8 +117,9 @@ class GradientExchange:
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending[name] = (work, buf, view)
         else:
-            work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending[name] = (work, view, view)
+            buf = view.to(torch.bfloat16) if self.wire_bf16 else view
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending[name] = (work, buf, view)
 
     def finish(self, name: str) -> None:
         """Make the current stream (GPU) / the caller (CPU) wait for region ``name``."""
@@ -126,18 +127,40 @@ class GradientExchange:
         if item is None:
             return
         work, buf, view = item
-        work.wait()
-        if self._cuda:
+        if self._cuda and buf is not view:
+            # bf16 wire: the copy back into the fp32 gradient runs on the communication stream, so THAT stream must wait for the
+            # collective (work.wait() orders only the stream that is current when it is called; RCCL runs on a stream of its own)
+            with torch.cuda.stream(self._comm):
+                work.wait()
+                view.copy_(buf)
+        else:
+            work.wait()
             if buf is not view:
-                with torch.cuda.stream(self._comm):
-                    view.copy_(buf)
+                view.copy_(buf)
+        if self._cuda:
             torch.cuda.current_stream().wait_stream(self._comm)
 
     def all(self) -> None:
+        self.exchange()
+
+    def exchange(self, late=(), between=None, on_arrival=None) -> None:
+        """One step's exchange.  Every region not in ``late`` is launched at once (list order: every rank must issue its collectives
+        in the same order); then ``between()`` runs -- the second half of a split backward pass, which WRITES the late regions while
+        the early ones travel -- and the late regions follow.  Regions are finished in list order; ``on_arrival(i, name, a, b)``
+        is called for each as soon as it has arrived (AdamW of that region).  Without ``between`` nothing is late."""
+        late = [n for n in late] if between is not None else []
         for n, _, _ in self.regions:
-            self.start(n)
-        for n, _, _ in self.regions:
+            if n not in late:
+                self.start(n)
+        if between is not None:
+            between()
+            for n, _, _ in self.regions:
+                if n in late:
+                    self.start(n)
+        for i, (n, a, b) in enumerate(self.regions):
             self.finish(n)
+            if on_arrival is not None:
+                on_arrival(i, n, a, b)
 
 
 class Pretrainer:
@@ -295,11 +318,11 @@ class Pretrainer:
             loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, self.temperature)
             total = loss_imid + self.cmid_weight * loss_cmid
         defer = ops.WgradDeferral(self._side) if (self.overlap and self._side is not None and self.defer_wgrad) else None
-        ops.WGRAD_DEFER[0] = defer
+        ops.cfg.wgrad_defer = defer
         try:
             total.backward(self._one)                       # (a persistent 1.0: no ones_like fill launch per step)
         finally:
-            ops.WGRAD_DEFER[0] = None
+            ops.cfg.wgrad_defer = None
         if defer is not None:
             defer.drain()                                   # the point-cloud branch's grouped weight gradients, behind the image branch's backward
         if tl is not None:
@@ -328,18 +351,9 @@ class Pretrainer:
         arrived (the image region's update overlaps the point-cloud region's transfer).  between: the second half of a split
         backward pass, launched after the early regions' transfers and before the late regions'.  The bias-correction step counter advances
         with the last region; the dropout state once per step."""
-        ex = self.exchange
-        late = [n for n, _, _ in self.late_regions] if between is not None else []     # (a LIST: every rank must launch its collectives in the same order)
-        for n, _, _ in self.regions:
-            if n not in late:
-                ex.start(n)                                    # (with `between`: the gradients the first backward graph completed)
-        if between is not None:
-            between()                                          # the second backward graph runs while they travel
-            for n in late:
-                ex.start(n)
-        for i, (n, a, b) in enumerate(self.regions):
-            ex.finish(n)
-            self._adamw_region(a, b, i + 1 == len(self.regions))
+        last = len(self.regions) - 1
+        self.exchange.exchange([n for n, _, _ in self.late_regions], between,
+                               lambda i, n, a, b: self._adamw_region(a, b, i == last))
         self._g_clean = self.zero_grad_in_optimizer
         ops.rng.advance(self.device)
 
