@@ -47,7 +47,15 @@ def test_ctypes_table_matches_header():
                 t = p.split()[1] if p.startswith("const") else p.split()[0]
                 want.append({"int": "i", "long": "l", "float": "f", "uint32_t": "u"}[t])
         assert [kind[t] for t in sig] == want, name
-    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id"}
+    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id", "vpf_debug_set", "vpf_debug_get"}
+    # the launch-time knobs: one struct, read by name, environment consulted once (csrc/api.hip)
+    assert _lib.debug_get("knn_select") == 1 and _lib.debug_get("wgroup_cfg") == 2
+    _lib.debug_set("knn_select", 0)
+    assert _lib.debug_get("knn_select") == 0
+    _lib.debug_set("knn_select", 1)
+    import pytest as _pt
+    with _pt.raises(_lib.VpfError):
+        _lib.debug_get("no_such_knob")
 
 
 def test_ctypes_structs_match_the_library_layout():

@@ -240,3 +240,20 @@ def call(name: str, *args) -> None:
     rc = fn(*conv)
     if rc != 0:
         raise VpfError(f"{name} failed: {lib().vpf_strerror(rc).decode()} (rc={rc})")
+
+
+def debug_set(key: str, value: int) -> None:
+    """Set one launch-time experiment knob of the library (csrc/vpf_common.h VpfDebug; tests and tools only)."""
+    fn = lib().vpf_debug_set
+    fn.argtypes = [ctypes.c_char_p, I]
+    fn.restype = I
+    check(fn(key.encode(), int(value)), f"vpf_debug_set({key})")
+
+
+def debug_get(key: str) -> int:
+    fn = lib().vpf_debug_get
+    fn.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]
+    fn.restype = I
+    v = ctypes.c_int(0)
+    check(fn(key.encode(), ctypes.byref(v)), f"vpf_debug_get({key})")
+    return v.value
