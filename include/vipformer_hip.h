@@ -315,7 +315,7 @@ int vpf_wgrad_group(const VpfWgradJob* host_jobs, int njobs, void* ws, long ws_b
 
 /* ------------------------------------------------------------------ fused self-attention layer
  * SelfAttentionLayer.forward (partseg.py:170-188; Residual :201-213, MultiHeadAttention :14-86, MLP :191-198) for
- * D = 256, 4 heads of 64, hidden 512, as ONE kernel per layer: attention -> o_proj + dropout + residual -> LayerNorm
+ * D = 256, 4 heads of 64, hidden 512 (with attention_done also D = 384, 6 heads, hidden 1536: BASELINE config 4), as ONE kernel per layer: attention -> o_proj + dropout + residual -> LayerNorm
  * -> fc1 + GELU -> fc2 + dropout + residual, and -- when qkv_next is set -- the NEXT layer's (+pos) -> LayerNorm ->
  * q/k/v projection (Encoder.forward re-adds pos before every layer, partseg.py:326-335).  One workgroup owns
  * chunk_rows tokens of one sequence (L <= 96: the whole sequence; L <= 224: chunk_rows <= 128); with attention_done
@@ -380,9 +380,11 @@ typedef struct VpfSaLayerBwd {
 } VpfSaLayerBwd;
 int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* host_args, void* stream);
 int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);
-typedef struct VpfPgradJob { const float* partials; int rows; int pad_; float* dgamma; float* dbeta; } VpfPgradJob;
+typedef struct VpfPgradJob { const float* partials; int rows; int D; float* dgamma; float* dbeta; } VpfPgradJob;   /* D = 0 means 256 */
 #define VPF_PGRAD_MAX_JOBS 32
 int vpf_ln_pgrad_reduce(const VpfPgradJob* host_jobs, int njobs, void* stream);
+/* number of partial rows (2 D floats each) the two backward kernels write for M tokens: size pgrad1 / pgrad2 and the reduce job with it */
+int vpf_sa_layer_pgrad_rows(long M, int D);
 /* PointCloudInputAdapter.point_mlp (classifier.py:31-36) + the cross-attention kv LayerNorm and K / V projections
  * (partseg.py:48-51,100-116) in one kernel, 64 points per workgroup, D = 256.  x f32 [M,C<=8]; W1 f32 [64,C];
  * W2 = vpf_pack_wfrag of the bf16 [D,64] weight; Wkv = vpf_pack_wfrag of the bf16 [2D,D] k|v weights.

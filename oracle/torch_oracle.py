@@ -157,7 +157,27 @@ class _RoundBF16(torch.autograd.Function):
         return g
 
 
-_EMULATE = [False]
+class _RoundGradBF16(torch.autograd.Function):
+    """Identity forward; the gradient that arrives is rounded to bf16 -- the backward kernels store these gradients as the bf16
+    operands of the next dgrad / wgrad product."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+# Rounding points of the HIP path, by tag.  Forward (activations / weights stored as bf16):
+#   w weights | adapter | g2e | pos | ln (LayerNorm outputs fed to a GEMM) | qkv | p (attention probabilities) | o (attention output)
+#   | u (fc1 pre-activation) | h (GELU output) | head
+# Backward (gradients stored as bf16 operands; only with emulate_bf16(backward=True)):
+#   dz (gradient of a residual branch's output, behind dropout') | du | do | dqkv | ds (score gradient inside the attention backward)
+FWD_TAGS = ("w", "adapter", "g2e", "pos", "ln", "qkv", "p", "o", "u", "h", "head")
+BWD_TAGS = ("dz", "du", "do", "dqkv", "ds")
+_EMULATE = [frozenset()]
 
 
 class emulate_bf16:
@@ -165,18 +185,30 @@ class emulate_bf16:
     path stores bf16 (GEMM operand weights, LayerNorm / activation / projection outputs, attention
     probabilities and outputs).  Off (the default) the oracle is the plain fp32 restatement that the
     golden fixtures pin against the reference.  On, it predicts the HIP path to ~1e-3 -- in particular
-    the same max-pool winners -- which separates kernel logic errors from bf16 precision effects."""
+    the same max-pool winners -- which separates kernel logic errors from bf16 precision effects.
+
+    only: an iterable of tags (FWD_TAGS / BWD_TAGS) -- round at those points alone (the per-stage error budget of
+    tools/rounding_budget.py); backward=True: also round the GRADIENTS the backward kernels store as bf16."""
+
+    def __init__(self, only=None, backward=False):
+        if only is None:
+            only = FWD_TAGS + (BWD_TAGS if backward else ())
+        self.tags = frozenset(only)
 
     def __enter__(self):
         self.prev = _EMULATE[0]
-        _EMULATE[0] = True
+        _EMULATE[0] = self.tags
 
     def __exit__(self, *a):
         _EMULATE[0] = self.prev
 
 
-def Q(x):
-    return _RoundBF16.apply(x) if _EMULATE[0] else x
+def Q(x, tag="w"):
+    return _RoundBF16.apply(x) if tag in _EMULATE[0] else x
+
+
+def QB(x, tag):
+    return _RoundGradBF16.apply(x) if tag in _EMULATE[0] else x
 
 
 # --------------------------------------------------------------------------- float stages
@@ -184,8 +216,8 @@ def adapter(sd, pre: str, pts):
     """classifier.py:31-36,48: Linear(C,64) -> LayerNorm(64) -> ReLU -> Linear(64,D)."""
     h = F.linear(pts, sd[pre + "point_mlp.0.weight"], sd[pre + "point_mlp.0.bias"])
     h = F.layer_norm(h, (64,), sd[pre + "point_mlp.1.weight"], sd[pre + "point_mlp.1.bias"], 1e-5)
-    h = Q(F.relu(h))
-    return Q(F.linear(h, Q(sd[pre + "point_mlp.3.weight"]), sd[pre + "point_mlp.3.bias"]))
+    h = Q(F.relu(h), "adapter")
+    return Q(F.linear(h, Q(sd[pre + "point_mlp.3.weight"]), sd[pre + "point_mlp.3.bias"]), "adapter")
 
 
 def _bn(sd, pre, x, train, buffers):
@@ -207,19 +239,19 @@ def group2emb(sd, pre: str, neighbors, train: bool, buffers=None):
     B, G, K, C = neighbors.shape
     x = neighbors.reshape(B * G, K, C).transpose(2, 1)                       # [BG, C, K]
     h = F.conv1d(x, sd[pre + "first_conv.0.weight"], sd[pre + "first_conv.0.bias"])
-    h = Q(F.relu(_bn(sd, pre + "first_conv.1.", h, train, buffers)))
-    h = Q(F.conv1d(h, Q(sd[pre + "first_conv.3.weight"]), sd[pre + "first_conv.3.bias"]))   # [BG,128,K]
+    h = Q(F.relu(_bn(sd, pre + "first_conv.1.", h, train, buffers)), "g2e")
+    h = Q(F.conv1d(h, Q(sd[pre + "first_conv.3.weight"]), sd[pre + "first_conv.3.bias"]), "g2e")   # [BG,128,K]
     g = h.max(dim=2, keepdim=True)[0]
     h = torch.cat([g.expand(-1, -1, K), h], dim=1)                            # [BG,256,K]
-    h = Q(F.conv1d(h, Q(sd[pre + "second_conv.0.weight"]), sd[pre + "second_conv.0.bias"]))
-    h = Q(F.relu(_bn(sd, pre + "second_conv.1.", h, train, buffers)))
-    h = Q(F.conv1d(h, Q(sd[pre + "second_conv.3.weight"]), sd[pre + "second_conv.3.bias"]))
+    h = Q(F.conv1d(h, Q(sd[pre + "second_conv.0.weight"]), sd[pre + "second_conv.0.bias"]), "g2e")
+    h = Q(F.relu(_bn(sd, pre + "second_conv.1.", h, train, buffers)), "g2e")
+    h = Q(F.conv1d(h, Q(sd[pre + "second_conv.3.weight"]), sd[pre + "second_conv.3.bias"]), "g2e")
     return h.max(dim=2)[0].reshape(B, G, -1)
 
 
 def pos_mlp(sd, pre: str, centers):
     """partseg.py:498-501: Linear(3,128) -> GELU(erf) -> Linear(128,D)."""
-    h = Q(F.gelu(F.linear(centers, sd[pre + "0.weight"], sd[pre + "0.bias"])))
+    h = Q(F.gelu(F.linear(centers, sd[pre + "0.weight"], sd[pre + "0.bias"])), "pos")
     return F.linear(h, Q(sd[pre + "2.weight"]), sd[pre + "2.bias"])
 
 
@@ -228,23 +260,23 @@ def mha(sd, pre: str, xq, xkv, H: int, p: float, masks: Masks, site: str):
     B, Lq, D = xq.shape
     Lk = xkv.shape[1]
     dh = D // H
-    xq, xkv = Q(xq), Q(xkv)
-    q = Q(F.linear(xq, Q(sd[pre + "q_proj.weight"]))).reshape(B, Lq, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lq, dh)
-    k = Q(F.linear(xkv, Q(sd[pre + "k_proj.weight"]))).reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
-    v = Q(F.linear(xkv, Q(sd[pre + "v_proj.weight"]))).reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
-    a = torch.bmm(q, k.transpose(1, 2)) * (dh ** -0.5)
+    xq, xkv = Q(xq, "ln"), Q(xkv, "ln")
+    q = QB(Q(F.linear(xq, Q(sd[pre + "q_proj.weight"])), "qkv"), "dqkv").reshape(B, Lq, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lq, dh)
+    k = QB(Q(F.linear(xkv, Q(sd[pre + "k_proj.weight"])), "qkv"), "dqkv").reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
+    v = QB(Q(F.linear(xkv, Q(sd[pre + "v_proj.weight"])), "qkv"), "dqkv").reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
+    a = QB(torch.bmm(q, k.transpose(1, 2)), "ds") * (dh ** -0.5)
     a = a.softmax(dim=-1)
-    a = Q(masks.apply(a, site, p))
-    o = Q(torch.bmm(a, v)).reshape(B, H, Lq, dh).permute(0, 2, 1, 3).reshape(B, Lq, D)
-    return F.linear(o, Q(sd[pre + "o_proj.weight"]), sd[pre + "o_proj.bias"])
+    a = Q(masks.apply(a, site, p), "p")
+    o = QB(Q(torch.bmm(a, v), "o"), "do").reshape(B, H, Lq, dh).permute(0, 2, 1, 3).reshape(B, Lq, D)
+    return QB(F.linear(o, Q(sd[pre + "o_proj.weight"]), sd[pre + "o_proj.bias"]), "dz")
 
 
 def mlp(sd, pre: str, x):
     """partseg.py:191-198: LN -> Linear -> GELU -> Linear."""
     D = x.shape[-1]
-    h = Q(F.layer_norm(x, (D,), sd[pre + "0.weight"], sd[pre + "0.bias"], 1e-5))
-    h = Q(F.gelu(Q(F.linear(h, Q(sd[pre + "1.weight"]), sd[pre + "1.bias"]))))
-    return F.linear(h, Q(sd[pre + "3.weight"]), sd[pre + "3.bias"])
+    h = Q(F.layer_norm(x, (D,), sd[pre + "0.weight"], sd[pre + "0.bias"], 1e-5), "ln")
+    h = Q(F.gelu(QB(Q(F.linear(h, Q(sd[pre + "1.weight"]), sd[pre + "1.bias"]), "u"), "du")), "h")
+    return QB(F.linear(h, Q(sd[pre + "3.weight"]), sd[pre + "3.bias"]), "dz")
 
 
 def ca_layer(sd, pre: str, xq, xkv, a: Arch, masks: Masks, tag: str):
@@ -287,9 +319,9 @@ def encoder(sd, pre: str, tokens, pos, kv, a: Arch, masks: Masks, taps=()):
 
 def latent_head(sd, pre: str, x, train: bool, buffers=None):
     """partseg.py:519-525: BN1d(2D) ReLU Linear(2D,D,no bias) BN1d(D) ReLU Linear(D,D,no bias)."""
-    h = Q(F.relu(_bn(sd, pre + "0.", x, train, buffers)))
+    h = Q(F.relu(_bn(sd, pre + "0.", x, train, buffers)), "head")
     h = F.linear(h, Q(sd[pre + "2.weight"]))
-    h = Q(F.relu(_bn(sd, pre + "3.", h, train, buffers)))
+    h = Q(F.relu(_bn(sd, pre + "3.", h, train, buffers)), "head")
     return F.linear(h, Q(sd[pre + "5.weight"]))
 
 

@@ -422,3 +422,111 @@ def test_timeline_marks_are_ordered_and_capturable():
     g.replay(); torch.cuda.synchronize()
     c2 = int(tl.buf[tl.names.index("c")])
     assert c2 > c1 > 0 and float(y[0, 0]) == float(y[0, 0])
+
+
+# ------------------------------------------------------------------------------------------ encoder row-block kernels, round 3
+def _tail_case(B, Lq, with_next, with_pos, seed, training=True):
+    """A closure that runs one vpf_sa_layer_fwd launch (attention_done) at D = 256 on seeded operands -- the SAME modules (dropout
+    sites), weights and dropout state every call -- and returns every tensor the kernel writes."""
+    import torch.nn as nn
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    D, H = 256, 4
+    M = B * Lq
+    torch.manual_seed(seed)
+    layers = nn.ModuleList([SelfAttentionLayer(H, D, 2, 0.0, 0.1, 0.5) for _ in range(2)]).cuda()
+    layers.train(training)
+    blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
+    packed = ops._pack_blocks(blocks, layers[0], "cuda")
+    st = ops.rng.state("cuda")
+    base = rnd(seed + 1, M, D); pos = rnd(seed + 2, Lq, D) if with_pos else None
+    o = bf(rnd(seed + 3, M, D)); lse = torch.zeros(B * H * Lq, device="cuda")
+    att, mlp = layers[0][0].module.attention, layers[0][1].module
+    nxt = (layers[1][0].module.norm, packed[1]["Wqkv"]) if with_next else None
+
+    def run():
+        with ops.rng.pinned():
+            saved, out, head = ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], training, st, B, Lq, o, base, o, lse, nxt, pos,
+                                             Lq if with_pos else 0, "cuda")
+        torch.cuda.synchronize()
+        return list(saved) + [out] + (list(head) if head is not None else [])
+    return run
+
+
+@pytest.mark.parametrize("B,Lq,with_next,with_pos", [(128, 96, True, True), (3, 50, True, True), (2, 196, False, False), (1, 7, True, False)])
+def test_sa_rows_fwd_equals_the_one_per_cu_kernel_bitwise(B, Lq, with_next, with_pos):
+    """sa_rows_fwd_kernel (two workgroups per CU: residual in registers, wave-private transposition slices) performs the SAME
+    arithmetic in the same order as sa_layer_fwd_kernel<.., false, 1> (one per CU, f32 residual tile in LDS): every output -- x1,
+    LayerNorm statistics, n2, u, h, out (+ pos), next n1 and q|k|v -- must be bit-identical, dropout on, whole and ragged blocks."""
+    from vipformer_amd import _lib
+    run = _tail_case(B, Lq, with_next, with_pos, 40)
+    outs = []
+    for wg2 in (0, 1, 1):
+        _lib.debug_set("sa_wg2", wg2)
+        try:
+            outs.append(run())
+        finally:
+            _lib.debug_set("sa_wg2", 0)
+    names = ["x1", "mean2", "rstd2", "n2", "u", "h", "out", "mean1n", "rstd1n", "n1n", "qkv_next"]
+    assert len(outs[0]) == len(outs[1])
+    for n, p, q, r in zip(names, outs[0], outs[1], outs[2]):
+        assert torch.equal(q, r), ("not reproducible", n)
+        assert torch.equal(p, q), (n, (p.float() - q.float()).abs().max().item(), (p != q).float().mean().item())
+
+
+@pytest.mark.parametrize("M,with_dsum,dsum_init", [(12288, True, 1), (150, True, 0), (392, False, 0)])
+def test_sa_rows_bwd_equals_the_one_per_cu_kernels_bitwise(M, with_dsum, dsum_init):
+    """sa_rows_bwd_mlp_kernel / sa_rows_bwd_qkv_kernel against sa_bwd_mlp_rows_kernel / sa_bwd_qkv_rows_kernel at D = 256 on the same
+    operands, dropout on: dz2, du, dx1, dz1, do, dbase and the running positional-gradient sum must be bit-identical (same arithmetic,
+    same order); the LayerNorm parameter-gradient partials are grouped per 32 instead of 64 tokens, so their fold agrees to fp32
+    summation order."""
+    import torch.nn as nn
+    from vipformer_amd import _lib, ops
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    D, Hd = 256, 512
+    torch.manual_seed(3)
+    layer = SelfAttentionLayer(4, D, 2, 0.0, 0.1, 0.5).cuda()
+    layer.train()
+    pk = ops._pack_blocks([(layer[0].module.attention, layer[1].module, True, True)], layer, "cuda")[0]
+    st = ops.rng.state("cuda")
+    d = rnd(1, M, D); u = bf(rnd(2, M, Hd)); x1 = rnd(3, M, D); base = rnd(4, M, D); dqkv = bf(rnd(5, M, 3 * D, scale=0.1))
+    m2 = x1.mean(1).contiguous(); r2 = (x1.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    m1 = base.mean(1).contiguous(); r1 = (base.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dsum0 = rnd(6, M, D)
+    ln1, ln2 = layer[0].module.norm, layer[1].module[0]
+    with torch.no_grad():
+        ln1.weight.copy_(rnd(7, D) * 0.2 + 1.0); ln2.weight.copy_(rnd(8, D) * 0.2 + 1.0)
+
+    def run():
+        nwg = ops.pgrad_rows(M, D)
+        out = dict(dz2=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"), du=torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda"),
+                   dx1=torch.empty(M, D, device="cuda"), dz1=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"),
+                   do=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"), dbase=torch.empty(M, D, device="cuda"), dsum=dsum0.clone())
+        pg = torch.zeros(2, nwg * 2 * D, device="cuda")
+        a = _lib.SaLayerBwd()
+        a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
+        a.p_res1, a.site_res1, a.p_res2, a.site_res2 = 0.5, layer[0].site, 0.5, layer[1].site
+        a.d, a.u, a.x1, a.mean2, a.rstd2, a.ln2_g = d.data_ptr(), u.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), ln2.weight.data.data_ptr()
+        a.W2T, a.W1T, a.WoT = pk["W2T"].data_ptr(), pk["W1T"].data_ptr(), pk["WoT"].data_ptr()
+        a.dz2, a.du, a.dx1, a.dz1, a.dout_attn = (out[k].data_ptr() for k in ("dz2", "du", "dx1", "dz1", "do"))
+        a.pgrad2, a.pgrad1 = pg[1].data_ptr(), pg[0].data_ptr()
+        a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = dqkv.data_ptr(), pk["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(), r1.data_ptr(), ln1.weight.data.data_ptr()
+        a.dbase, a.dsum, a.dsum_init = out["dbase"].data_ptr(), (out["dsum"].data_ptr() if with_dsum else None), dsum_init
+        _lib.call_struct("vpf_sa_layer_bwd_mlp", a)
+        _lib.call_struct("vpf_sa_layer_bwd_qkv", a)
+        torch.cuda.synchronize()
+        out["pg2"] = pg[1].view(nwg, 2 * D).sum(0); out["pg1"] = pg[0].view(nwg, 2 * D).sum(0)
+        return out
+
+    res = []
+    for wg2 in (0, 1, 1):
+        _lib.debug_set("sa_wg2", wg2)
+        try:
+            res.append(run())
+        finally:
+            _lib.debug_set("sa_wg2", 0)
+    for k in ("dz2", "du", "dx1", "dz1", "do", "dbase", "dsum"):
+        assert torch.equal(res[1][k], res[2][k]), ("not reproducible", k)
+        assert torch.equal(res[0][k], res[1][k]), (k, (res[0][k].float() - res[1][k].float()).abs().max().item())
+    for k in ("pg1", "pg2"):
+        assert rel(res[1][k], res[0][k]) < 1e-5, (k, rel(res[1][k], res[0][k]))

@@ -393,38 +393,58 @@ def _training_step_with_dropout_vs_oracle(name):
     ck.lt("[emulated] img feats rel", rel(fi, fie), 5e-2)
     ck.lt("[emulated] loss abs diff", abs(loss.item() - le.item()), 5e-2)
 
-    def compare(tag, hip_grad_of, lo_all, lo_med, lo_min):
-        cosines = []
-        for model, ref in ((pc, pcp), (im, imp)):
-            for k, p in model.named_parameters():
-                r = ref[k].grad
-                if r is None or hip_grad_of(p) is None or k.endswith(("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias")):
-                    continue
-                cosines.append((cosine(hip_grad_of(p), r), k, float(r.norm())))
-        cosines.sort()
-        for cc, k, nr in cosines[:4]:
-            report(f"dropout-step[{name}] [{tag}] lowest grad cosine {cc:.5f} {k} |ref| {nr:.2e}")
-        hip = torch.cat([(hip_grad_of(p) if hip_grad_of(p) is not None else torch.zeros_like(p)).reshape(-1).cpu()
-                         for m in (pc, im) for _, p in m.named_parameters()])
-        ref = torch.cat([(r[k].grad if r[k].grad is not None else torch.zeros_like(r[k])).reshape(-1)
-                         for m, r in ((pc, pcp), (im, imp)) for k, _ in m.named_parameters()])
-        ck.gt(f"[{tag}] all-parameter gradient cosine", cosine(hip, ref), lo_all)
-        ck.gt(f"[{tag}] median per-tensor gradient cosine", float(np.median([c[0] for c in cosines])), lo_med)
-        ck.gt(f"[{tag}] lowest per-tensor gradient cosine", cosines[0][0], lo_min)
+    # ---- gradients.  Three sets per loss: HIP, the bf16-emulating oracle (same rounding points, exact fp32 backward) and the fp32
+    # oracle.  tests/rounding_budget.py (profiles/r03_rounding_budget_*.txt) shows where the angle against fp32 goes: the bf16
+    # WEIGHTS alone cost 0.4 % of the linear-loss gradient's direction at 4 pairs (0.9958), all forward rounding points together
+    # 0.9963, the gradients the backward kernels round to bf16 nothing (1.00000) -- SURVEY 8c's 0.999 is not attainable with bf16
+    # MFMA operands at this batch and dropout 0.5, whatever the kernels do.  The floors are therefore not constants fitted to a
+    # build: for THIS batch the test measures the precision budget itself -- deficit(emulated vs fp32), deficit = 1 - cosine -- and
+    # holds HIP to at most 3 x that budget against fp32 AND against the emulation (a kernel logic error shows as a multiple of it).
+    def grads_of(ref_pair):
+        return [{k: v.grad.clone() for k, v in d.items() if v.grad is not None} for d in ref_pair]
 
+    def clear(ref_pair):
+        for d in ref_pair:
+            for v in d.values():
+                v.grad = None
+
+    skip = ("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias")      # exactly zero by BatchNorm's shift invariance
+
+    def budget_check(tag, hip_grad_of, g_emu, g_f32, slack_all, slack_min):
+        rows = []
+        for model, ge, gf in ((pc, g_emu[0], g_f32[0]), (im, g_emu[1], g_f32[1])):
+            for k, p in model.named_parameters():
+                if k.endswith(skip) or k not in ge or k not in gf or hip_grad_of(p) is None:
+                    continue
+                h = hip_grad_of(p).cpu()
+                rows.append((k, h, ge[k], gf[k]))
+        cat = lambda i: torch.cat([r[i].reshape(-1) for r in rows])
+        d_hf, d_ef, d_he = 1 - cosine(cat(1), cat(3)), 1 - cosine(cat(2), cat(3)), 1 - cosine(cat(1), cat(2))
+        per = [(1 - cosine(r[1], r[3]), 1 - cosine(r[2], r[3]), 1 - cosine(r[1], r[2]), r[0]) for r in rows]
+        w_hf, w_ef, w_he = max(x[0] for x in per), max(x[1] for x in per), max(x[2] for x in per)
+        for x in sorted(per, reverse=True)[:3]:
+            report(f"dropout-step[{name}] [{tag}] largest deficit vs fp32: hip {x[0]:.5f} emulated {x[1]:.5f} hip-vs-emulated {x[2]:.5f} {x[3]}")
+        report(f"dropout-step[{name}] [{tag}] all-parameter deficit (1 - cos): hip/fp32 {d_hf:.5f}  emulated/fp32 (the budget) {d_ef:.5f}  hip/emulated {d_he:.5f}")
+        ck.lt(f"[{tag}] all-parameter deficit hip vs fp32 / budget", d_hf / (3 * d_ef + slack_all), 1.0)
+        ck.lt(f"[{tag}] all-parameter deficit hip vs emulated / budget", d_he / (3 * d_ef + slack_all), 1.0)
+        ck.lt(f"[{tag}] worst per-tensor deficit hip vs fp32 / budget", w_hf / (3 * w_ef + slack_min), 1.0)
+        ck.lt(f"[{tag}] worst per-tensor deficit hip vs emulated / budget", w_he / (3 * w_ef + slack_min), 1.0)
+
+    # fp32 oracle gradients (its graph is still alive), then the emulated ones
+    ((bbr * Rb).sum() + (bbir * Rbi).sum()).backward(retain_graph=True)
+    lin_f32 = grads_of((pcp, imp)); clear((pcp, imp))
+    lref.backward()
+    ntx_f32 = grads_of((pcp, imp)); clear((pcp, imp))
     ((bbe * Rb).sum() + (bbie * Rbi).sum()).backward(retain_graph=True)
-    # residual differences: bf16 rounding of the backward activations, and max-pool winners (token pooling,
-    # group pooling) that flip between near-tied candidates -- a discontinuous re-routing of the gradient
-    compare("emulated, linear loss", lambda p: lin_grads.get(id(p)), 0.99, 0.99, 0.97)
-    for r in (pcp, imp):
-        for v in r.values():
-            v.grad = None
+    lin_emu = grads_of((pcp, imp)); clear((pcp, imp))
     le.backward()
-    # the contrastive loss at temperature 0.1 on top of a BatchNorm over 8 samples turns the ~1e-2 forward difference of the
-    # projected features into a rotation of dL/dfeats that every parameter gradient inherits.  Measured over the five architectures
-    # (profiles/r02_parity_report.txt): all-parameter 0.981 - 0.998, median 0.982 - 0.998, lowest tensor 0.953 - 0.987; at 32 pairs
-    # (BatchNorm over 64 samples, tests/test_fullsize_gpu.py) 0.992 / 0.991 / 0.986 and the loss within 3e-5 of the fp32 oracle.
-    compare("emulated, NT-Xent loss", lambda p: p.grad, 0.97, 0.97, 0.93)
+    ntx_emu = grads_of((pcp, imp)); clear((pcp, imp))
+    # loss linear in the backbone features: the well-conditioned check of every backward kernel (residual differences: max-pool
+    # winners -- token pooling, group pooling -- that flip between near-tied candidates re-route a gradient discontinuously)
+    budget_check("linear loss", lambda p: lin_grads.get(id(p)), lin_emu, lin_f32, 2e-4, 2e-3)
+    # the pre-training loss: BatchNorm over 2B / B samples and the temperature-0.1 softmax amplify every forward difference into a
+    # rotation of dL/dfeats that all parameter gradients inherit -- the budget measures exactly that amplification for this batch
+    budget_check("NT-Xent loss", lambda p: p.grad, ntx_emu, ntx_f32, 1e-3, 5e-3)
     ck.done()
 
 
@@ -471,26 +491,29 @@ def test_trainer_stream_and_graph_variants_agree():
         assert cosine(g, g0) > 0.999999, (tag, cosine(g, g0))      # gradients: fp32 atomic ordering only
 
 
-def test_fused_sa_stack_matches_unfused_blocks():
+@pytest.mark.parametrize("name", ["c1", "c4"])
+def test_fused_sa_stack_matches_unfused_blocks(name):
     """vpf_sa_layer_fwd / vpf_sa_layer_bwd_* (fused self-attention layers) against the block-by-block kernels they
     replace: same dropout masks (same sites / state), so the loss and the gradients agree up to bf16 rounding of
-    intermediates."""
+    intermediates.  c4 (D = 384, 6 heads, hidden 1536: BASELINE config 4) runs the round-3 row-block kernels (sa_rows.hip)."""
     from vipformer_amd import ops
     from vipformer_amd.train import Pretrainer, build_models
-    a = Hh.ARCHS["c1"]
+    a = Hh.ARCHS[name]
     B = 4
     t1 = Hh.synth_points(1, B, a["N"]).cuda(); t2 = Hh.synth_points(2, B, a["N"]).cuda()
     imgs = Hh.synth_images(3, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
     start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
     results = []
     variants = ((False, False, None, False), (True, False, False, False), (True, False, True, False), (True, True, True, False), (True, True, True, True), (True, True, True, 2))
+    if name != "c1":          # attention inside the layer kernel and the fused K / V producer exist at D = 256 only
+        variants = ((False, False, None, False), (True, False, True, False), (True, True, True, False), (True, True, True, True))
     for fused, fused_bwd, split, enc in variants:
         ops.clear_managed_shadows()
         ops.rng.seed(99)
         torch.manual_seed(5)
         pc, im = build_models(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], N=a["N"], img=a["img"], patch=a["patch"])
-        pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c1.json"), 100))
-        im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_img_c1.json"), 200))
+        pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100))
+        im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200))
         pc.train(); im.train()
         tr = Pretrainer(pc, im)
         tr.overlap = False
@@ -511,7 +534,7 @@ def test_fused_sa_stack_matches_unfused_blocks():
     ops.clear_managed_shadows()
     l0, f0, g0 = results[0]
     allg0 = torch.cat([v.reshape(-1) for v in g0.values()])
-    C = Checks("fused_sa_stack")
+    C = Checks(f"fused_sa_stack {name}")
     for (l1, f1, g1), (fused, fused_bwd, split, enc) in zip(results[1:], variants[1:]):
         tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}{(', CA tail + adapter/kv fused' + (' (bwd too)' if enc == 2 else '')) if enc else ''}]"
         C.lt(tag + " pc backbone feats rel", rel(f1, f0), 2e-2)

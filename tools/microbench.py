@@ -123,6 +123,34 @@ def satail():
     nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
     t = timeit(lambda: ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, M, "cuda"), 20, 3)
     print(f"sa_layer_fwd tail (12288 tokens): {t:.1f} us")
+    dbg = torch.zeros(32 + 4 * 2048, dtype=torch.int64, device="cuda")
+    ops.cfg.sa_debug = dbg
+    ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, M, "cuda")
+    torch.cuda.synchronize()
+    ops.cfg.sa_debug = None
+    names = ["loads+barrier", "o_proj", "epi1+x1 out", "LN2+tile+barrier", "n2 out", "fc1(0)", "u+gelu pass(0)", "barrier", "fc2(0)",
+             "chunk1 fc1..gelu + x1,pos in", "fc2(1)", "epi2+out", "LN1n+tile+barrier", "n1 out", "qkv"]
+    c = dbg.tolist()
+    print("   phase cycles (wg 0): " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, c)) + f"  total {sum(c[:15])}")
+    rec = dbg[32:].view(-1, 4).cpu()
+    rec = rec[rec[:, 1] > 0]
+    if len(rec):
+        import collections
+        t0 = int(rec[:, 0].min())
+        per_cu = collections.Counter((int(r[2]), int(r[3]) & 0xff00) for r in rec)      # (XCC, HW_ID without the wave-slot bits)
+        dur = (rec[:, 1] - rec[:, 0]).double() / 100.0
+        print(f"   {len(rec)} workgroups: duration us min {dur.min():.1f} median {dur.median():.1f} max {dur.max():.1f}; first start -> last end "
+              f"{(int(rec[:, 1].max()) - t0) / 100.0:.1f} us; start spread {(int(rec[:, 0].max()) - t0) / 100.0:.1f} us; "
+              f"workgroups per (XCC, CU): {sorted(collections.Counter(per_cu.values()).items())}")
+        if os.environ.get("WG_DUMP"):
+            order = sorted(range(len(rec)), key=lambda i: int(rec[i, 0]))
+            for i in order[:: max(1, len(order) // 48)]:
+                r = rec[i]
+                print(f"      block {i:4d} start {(int(r[0]) - t0) / 100.0:6.2f} us  dur {(int(r[1]) - int(r[0])) / 100.0:6.2f}  xcc {int(r[2])} hw_id {int(r[3]) & 0xffff:#06x}")
+        shared = [i for i, r in enumerate(rec) if per_cu[(int(r[2]), int(r[3]) & 0xff00)] > 1]
+        alone = [i for i, r in enumerate(rec) if per_cu[(int(r[2]), int(r[3]) & 0xff00)] == 1]
+        if shared and alone:
+            print(f"   alone on a CU: median {dur[alone].median():.1f} us ({len(alone)}); sharing a CU: median {dur[shared].median():.1f} us ({len(shared)})")
 
 
 def wgroup():

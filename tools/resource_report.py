@@ -38,6 +38,6 @@ if __name__ == "__main__":
     flt = sys.argv[2] if len(sys.argv) > 2 else ""
     print(f"{'kernel':<72} {'VGPR':>5} {'AGPR':>5} {'scratch':>8} {'LDS':>7} {'occ':>4} {'SGPR':>5}")
     for r in report(f, flt):
-        nm = re.sub(r"\(.*\)$", "", r["name"])[:72]
+        nm = re.sub(r"\(anonymous namespace\)::", "", r["name"]); nm = re.sub(r"^void ", "", nm); nm = re.sub(r"\(.*\)$", "", nm)[:72]
         print(f"{nm:<72} {r.get('VGPRs', '?'):>5} {r.get('AGPRs', '?'):>5} {r.get('ScratchSize [bytes/lane]', '?'):>8} "
               f"{r.get('LDS Size [bytes/block]', '?'):>7} {r.get('Occupancy [waves/SIMD]', '?'):>4} {r.get('TotalSGPRs', '?'):>5}")

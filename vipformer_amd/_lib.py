@@ -174,7 +174,7 @@ class SaLayerFwd(ctypes.Structure):
 
 class PgradJob(ctypes.Structure):
     """struct VpfPgradJob (include/vipformer_hip.h)."""
-    _fields_ = [("partials", VP), ("rows", I), ("pad_", I), ("dgamma", VP), ("dbeta", VP)]
+    _fields_ = [("partials", VP), ("rows", I), ("D", I), ("dgamma", VP), ("dbeta", VP)]
 
 
 class AdapterKv(ctypes.Structure):

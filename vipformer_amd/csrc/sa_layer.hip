@@ -21,6 +21,7 @@
 #include "vpf_common.h"
 #include <stdlib.h>
 #include "vipformer_hip.h"
+#include "sa_rows.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
@@ -851,9 +852,14 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     if (a.qkv_next && (!a.ln1n_g || !a.ln1n_b || !a.Wqkv_next || !a.mean1n || !a.rstd1n || !a.n1n)) return VPF_ERR_NULL;
     if (a.pos && a.pos_rows <= 0) return VPF_ERR_BADSHAPE;
     if (a.B <= 0 || a.L <= 0 || a.chunk_rows <= 0) return VPF_ERR_BADSHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    // round 3: the row-block kernels built for two workgroups per CU (sa_rows.hip); D = 384 / hidden 1536 exists only there
+    if (a.attention_done && sa_rows_supported(a.D, a.hidden) && (vpf_debug().sa_wg2 || a.D != SA_D)) {
+        if (a.D != a.H * SA_DH) return VPF_ERR_UNSUPPORTED;
+        return sa_rows_fwd_launch(a, st);
+    }
     if (a.D != SA_D || a.H != SA_H || a.hidden != SA_HID) return VPF_ERR_UNSUPPORTED;
     const int chunks = vpf_cdiv(a.L, a.chunk_rows);
-    hipStream_t st = (hipStream_t)stream;
     const int nj = vpf_debug().sa_nj;
     if (a.attention_done) {                                                   // o is an input: 64-row blocks, any sequence length
         if (nj == 2) return sa_launch<2, 2, 32, false, 2>(a, 1, st);          // 4 waves x 64 channels
@@ -1425,27 +1431,29 @@ __global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
 struct PgradJobs { VpfPgradJob job[VPF_PGRAD_MAX_JOBS]; };
 __global__ void __launch_bounds__(1024) sa_pgrad_reduce_kernel(PgradJobs jobs)
 {
-    // block = 16 of the 512 columns x 64 row groups (a job with 2 048 partial rows -- the K / V producer's LayerNorm -- is 32 dependent
+    // block = 16 of the 2 D columns x 64 row groups (a job with 2 048 partial rows -- the K / V producer's LayerNorm -- is 32 dependent
     // loads per thread this way; with 64 columns x 16 row groups it was 128 and took 21 us at the very end of the backward pass)
     __shared__ float fold[64][17];
     const VpfPgradJob j = jobs.job[blockIdx.y];
+    const int D = j.D > 0 ? j.D : SA_D;
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    if (blockIdx.x * 16 >= 2 * D) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int r = rg;
     for (; r + 192 < j.rows; r += 256) {
-        s0 += j.partials[(size_t)r * 2 * SA_D + c];
-        s1 += j.partials[(size_t)(r + 64) * 2 * SA_D + c];
-        s2 += j.partials[(size_t)(r + 128) * 2 * SA_D + c];
-        s3 += j.partials[(size_t)(r + 192) * 2 * SA_D + c];
+        s0 += j.partials[(size_t)r * 2 * D + c];
+        s1 += j.partials[(size_t)(r + 64) * 2 * D + c];
+        s2 += j.partials[(size_t)(r + 128) * 2 * D + c];
+        s3 += j.partials[(size_t)(r + 192) * 2 * D + c];
     }
-    for (; r < j.rows; r += 64) s0 += j.partials[(size_t)r * 2 * SA_D + c];
+    for (; r < j.rows; r += 64) s0 += j.partials[(size_t)r * 2 * D + c];
     fold[rg][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0) {
         float tot = 0.f;
 #pragma unroll
         for (int k = 0; k < 64; ++k) tot += fold[k][cl];
-        if (c < SA_D) j.dgamma[c] += tot; else j.dbeta[c - SA_D] += tot;
+        if (c < D) j.dgamma[c] += tot; else j.dbeta[c - D] += tot;
     }
 }
 extern "C" int vpf_ln_pgrad_reduce(const VpfPgradJob* jobs, int njobs, void* stream)
@@ -1454,23 +1462,40 @@ extern "C" int vpf_ln_pgrad_reduce(const VpfPgradJob* jobs, int njobs, void* str
     if (!jobs) return VPF_ERR_NULL;
     if (njobs <= 0 || njobs > VPF_PGRAD_MAX_JOBS) return VPF_ERR_BADSHAPE;
     PgradJobs pj;
+    int dmax = SA_D;
     for (int i = 0; i < njobs; ++i) {
         if (!jobs[i].partials || !jobs[i].dgamma || !jobs[i].dbeta) return VPF_ERR_NULL;
-        if (jobs[i].rows <= 0) return VPF_ERR_BADSHAPE;
+        if (jobs[i].rows <= 0 || jobs[i].D < 0 || (jobs[i].D % 8)) return VPF_ERR_BADSHAPE;
         pj.job[i] = jobs[i];
+        if (jobs[i].D > dmax) dmax = jobs[i].D;
     }
-    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(32, njobs), dim3(1024), 0, (hipStream_t)stream, pj);
+    hipLaunchKernelGGL(sa_pgrad_reduce_kernel, dim3(2 * dmax / 16, njobs), dim3(1024), 0, (hipStream_t)stream, pj);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
+}
+// rows of LayerNorm parameter-gradient partials (2 D floats each) that vpf_sa_layer_bwd_mlp / _qkv write for M tokens: the caller
+// sizes pgrad1 / pgrad2 and the reduce job with it (one row per 64 tokens for the D = 256 kernels of rounds 1 - 2, per 32 tokens for
+// the round-3 kernels)
+extern "C" int vpf_sa_layer_pgrad_rows(long M, int D)
+{
+    if (M <= 0) return 0;
+    if (D == SA_D && !vpf_debug().sa_wg2) return vpf_cdiv(M, 64);
+    const int t = sa_rows_bwd_pgrad_tokens(D);
+    return D == SA_D ? vpf_cdiv(M, 64) * (64 / t) : vpf_cdiv(M, t);
 }
 
 static int sa_bwd_nj()
 {
     return vpf_debug().sa_nj;
 }
+static bool sa_bwd_rows3(const VpfSaLayerBwd& a)      // the round-3 kernels (sa_rows.hip): any supported width when asked for, the only ones beyond D = 256
+{
+    return sa_rows_supported(a.D, a.hidden) && (vpf_debug().sa_wg2 || a.D != SA_D);
+}
 static int sa_bwd_check(const VpfSaLayerBwd& a)
 {
     if (a.M <= 0) return VPF_ERR_BADSHAPE;
+    if (sa_bwd_rows3(a)) return VPF_OK;
     if (a.D != SA_D || a.hidden != SA_HID) return VPF_ERR_UNSUPPORTED;
     return VPF_OK;
 }
@@ -1483,6 +1508,7 @@ extern "C" int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* args, void* stream)
     if (rc) return rc;
     if (!a.d || !a.rng || !a.u || !a.x1 || !a.mean2 || !a.rstd2 || !a.ln2_g || !a.W2T || !a.W1T || !a.WoT || !a.dz2 || !a.du || !a.dx1 ||
         !a.dz1 || !a.dout_attn || !a.pgrad2) return VPF_ERR_NULL;
+    if (sa_bwd_rows3(a)) return sa_rows_bwd_mlp_launch(a, (hipStream_t)stream);
     constexpr int RB = 2, TOK = RB * 32;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
@@ -1508,6 +1534,7 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     int rc = sa_bwd_check(a);
     if (rc) return rc;
     if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
+    if (sa_bwd_rows3(a)) return sa_rows_bwd_qkv_launch(a, (hipStream_t)stream);
     constexpr int RB = 2, TOK = RB * 32;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4;
     static VpfPerDevice attr_dev; bool& attr = attr_dev();

@@ -1,0 +1,10 @@
+// sa_rows.h -- launchers of the round-3 encoder row-block kernels (sa_rows.hip), called from the C-ABI entry points in sa_layer.hip.
+#pragma once
+#include "vpf_common.h"
+
+// D = 256 (hidden 512, two workgroups per CU) or D = 384 (hidden 1536): VPF_OK, or VPF_ERR_UNSUPPORTED for any other width.
+int sa_rows_fwd_launch(const VpfSaLayerFwd& a, hipStream_t st);
+int sa_rows_bwd_mlp_launch(const VpfSaLayerBwd& a, hipStream_t st);
+int sa_rows_bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st);
+bool sa_rows_supported(int D, int hidden);
+int sa_rows_bwd_pgrad_tokens(int D);

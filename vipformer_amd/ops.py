@@ -795,21 +795,36 @@ class MLPBlockFn(torch.autograd.Function):
 
 
 def sa_stack_supported(layers, x) -> bool:
-    """vpf_sa_layer_fwd covers D = 256, 4 heads of 64, hidden 512, sequences of <= 96 tokens (one workgroup per
-    sequence) or <= 224 tokens (two chunks), identity drop-path."""
+    """The row-block kernels cover D = 256 / 4 heads / hidden 512 and D = 384 / 6 heads / hidden 1536 (heads of 64: every BASELINE
+    architecture), sequences of <= 224 tokens (the resident attention kernels), identity drop-path."""
     if not cfg.sa_fused or len(layers) == 0 or x.dim() != 3:
         return False
     B, Lq, D = x.shape
-    if D != 256 or Lq > 224:
+    if (D, FUSED_WIDTHS.get(D)) not in ((256, (4, 512)), (384, (6, 1536))) or Lq > 224:
         return False
     for layer in layers:
         att = layer[0].module.attention
         mlp = layer[1].module
-        if att.num_heads != 4 or mlp[1].weight.shape[0] != 512:
+        if (att.num_heads, mlp[1].weight.shape[0]) != FUSED_WIDTHS[D] or mlp[1].weight.shape[1] != D:
             return False
         if not isinstance(layer[0].drop_path, torch.nn.Identity) or not isinstance(layer[1].drop_path, torch.nn.Identity):
             return False
     return True
+
+
+FUSED_WIDTHS = {256: (4, 512), 384: (6, 1536)}      # model width -> (heads, MLP hidden) the fused encoder kernels are built for
+
+
+def _block_dims(att, mlp):
+    """(D, hidden, heads) of one attention + MLP block."""
+    return mlp[1].weight.shape[1], mlp[1].weight.shape[0], att.num_heads
+
+
+def pgrad_rows(M: int, D: int) -> int:
+    """Partial rows the backward row-block kernels write per LayerNorm (vpf_sa_layer_pgrad_rows)."""
+    fn = L.lib().vpf_sa_layer_pgrad_rows
+    fn.argtypes, fn.restype = [ctypes.c_long, ctypes.c_int], ctypes.c_int
+    return int(fn(M, D))
 
 
 def _sa_packed(layers, dev):
@@ -817,7 +832,7 @@ def _sa_packed(layers, dev):
     the transposed views W2T, W1T, WoT, WqkvT -- rewritten from the bf16 shadow on every call (the shadow changes every
     optimizer step; the copy is one small kernel)."""
     holder = layers[0]
-    D, Hd = 256, 512
+    D, Hd, _ = _block_dims(layers[0][0].module.attention, layers[0][1].module)
     sizes = [("Wo", D * D), ("W1", Hd * D), ("W2", D * Hd), ("Wqkv", 3 * D * D), ("W2T", Hd * D), ("W1T", D * Hd), ("WoT", D * D), ("WqkvT", 3 * D * D)]
     per_layer = sum(n for _, n in sizes)
     buf = getattr(holder, "_vpf_packed", None)
@@ -863,7 +878,8 @@ class SAStackFn(torch.autograd.Function):
     def forward(ctx, x, pos, layers, training, *params):
         ctx.nparams, ctx.params = len(params), params
         B, Lq, D = x.shape
-        M, Hd, H = B * Lq, 512, 4
+        M = B * Lq
+        _, Hd, H = _block_dims(layers[0][0].module.attention, layers[0][1].module)
         dev = x.device
         x = x.contiguous().float()
         nl = len(layers)
@@ -906,7 +922,7 @@ class SAStackFn(torch.autograd.Function):
             a.p_res2, a.site_res2 = float(layer[1].dropout.p if training else 0.0), layer[1].site
             a.o, a.lse, a.x1, a.mean2, a.rstd2, a.n2 = o.data_ptr(), lse.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), n2.data_ptr()
             a.u, a.h, a.out = u.data_ptr(), h.data_ptr(), out.data_ptr()
-            split = cfg.sa_split_attn if cfg.sa_split_attn is not None else True
+            split = cfg.sa_split_attn if (cfg.sa_split_attn is not None and D == 256) else True      # (attention inside the layer kernel: D = 256 only)
             if split:
                 L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, D // H, float(att.dp_scale),
                        float(a.p_att), st, att.site_attn, o, D, lse)
@@ -1003,7 +1019,7 @@ class SAStackFn(torch.autograd.Function):
         B, Lq, D, Hd, H = ctx.dims
         M = B * Lq
         dev = d.device
-        nwg = (M + 63) // 64
+        nwg = pgrad_rows(M, D)
         nl = len(layers)
         pg = torch.empty(nl, 2, nwg * 2 * D, dtype=F32, device=dev)       # LayerNorm parameter-gradient partials of every layer
         pjobs = (L.PgradJob * 32)()
@@ -1047,7 +1063,7 @@ class SAStackFn(torch.autograd.Function):
             wg.add(dqkv, n1, 3 * D, D, packed_grad([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]))
             wg.flush()
             for which, ln in ((1, ln2), (0, ln1)):
-                pjobs[npj].partials, pjobs[npj].rows = pg[i, which].data_ptr(), nwg
+                pjobs[npj].partials, pjobs[npj].rows, pjobs[npj].D = pg[i, which].data_ptr(), nwg, D
                 pjobs[npj].dgamma, pjobs[npj].dbeta = grad_buf(ln.weight).data_ptr(), grad_buf(ln.bias).data_ptr()
                 npj += 1
                 if npj == 32:
@@ -1070,7 +1086,7 @@ class SAStackFn(torch.autograd.Function):
 def _pack_blocks(blocks, holder, dev):
     """blocks: list of (attention module, MLP module, want_Wqkv_forward, want_WqkvT).  Returns per-block dicts of fragment-order
     weight views (see _sa_packed)."""
-    D, Hd = 256, 512
+    D, Hd, _ = _block_dims(blocks[0][0], blocks[0][1])
     sizes = [("Wo", D * D), ("W1", Hd * D), ("W2", D * Hd), ("Wqkv", 3 * D * D), ("W2T", Hd * D), ("W1T", D * Hd), ("WoT", D * D), ("WqkvT", 3 * D * D)]
     per = sum(n for _, n in sizes)
     buf = getattr(holder, "_vpf_packed_enc", None)
@@ -1109,7 +1125,7 @@ def _pack_blocks(blocks, holder, dev):
 def _tail_fwd(att, mlp, res_attn, res_mlp, pk, training, st, B, Lq, qkv_dummy, base, o, lse, nxt, pos_c, pos_rows, dev):
     """One vpf_sa_layer_fwd launch with attention_done = 1.  nxt = (LayerNorm module, packed Wqkv) of the following
     self-attention layer or None.  Returns (saved tensors dict, out, next-head tuple or None)."""
-    D, Hd, H = 256, 512, 4
+    D, Hd, H = _block_dims(att, mlp)
     M = B * Lq
     ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
     x1 = torch.empty(M, D, dtype=F32, device=dev)
@@ -1132,6 +1148,8 @@ def _tail_fwd(att, mlp, res_attn, res_mlp, pk, training, st, B, Lq, qkv_dummy, b
     a.o, a.lse, a.x1, a.mean2, a.rstd2, a.n2 = o.data_ptr(), lse.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), n2.data_ptr()
     a.u, a.h, a.out = u.data_ptr(), h.data_ptr(), out.data_ptr()
     a.attention_done = 1
+    if cfg.sa_debug is not None:
+        a.dbg = cfg.sa_debug.data_ptr()
     head = None
     if nxt is not None:
         lnn, wqkv = nxt
@@ -1162,13 +1180,14 @@ class EncoderFusedFn(torch.autograd.Function):
         ctx.kv_ready, ctx.taps = kv_ready, tuple(taps)
         ctx.set_materialize_grads(False)
         B, Lq, D = x.shape
-        M, Hd, H = B * Lq, 512, 4
+        M = B * Lq
         dev = x.device
         x = x.contiguous().float()
         st = ctx.rng_st = rng.acquire(dev, training)
         nl = len(layers)
         cross, cmlp = ca[0].module, ca[1].module
         catt = cross.attention
+        _, Hd, H = _block_dims(catt, cmlp)
         blocks = [(catt, cmlp, False, False)] + [(l[0].module.attention, l[1].module, True, True) for l in layers]
         packed = _pack_blocks(blocks, ca, dev)
         pos_c = pos.contiguous().float() if pos is not None else None
@@ -1232,7 +1251,7 @@ class EncoderFusedFn(torch.autograd.Function):
         d = dout.contiguous().float().view(M, D) if dout is not None else None
         want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
         nl = len(layers)
-        nwg = (M + 63) // 64
+        nwg = pgrad_rows(M, D)
         pg = torch.empty(nl + 1, 2, nwg * 2 * D, dtype=F32, device=dev)
         pjobs = (L.PgradJob * 32)()
         npj = 0
@@ -1256,7 +1275,7 @@ class EncoderFusedFn(torch.autograd.Function):
 
         def pgrad_job(slot, which, ln):
             nonlocal npj
-            pjobs[npj].partials, pjobs[npj].rows = pg[slot, which].data_ptr(), nwg
+            pjobs[npj].partials, pjobs[npj].rows, pjobs[npj].D = pg[slot, which].data_ptr(), nwg, D
             pjobs[npj].dgamma, pjobs[npj].dbeta = grad_buf(ln.weight).data_ptr(), grad_buf(ln.bias).data_ptr()
             npj += 1
             if npj == 32:
@@ -1458,7 +1477,8 @@ def encoder_fused_supported(ca, layers, x, xkv) -> bool:
     if not getattr(ca, "attention_residual", False):
         return False
     att, mlp = ca[0].module.attention, ca[1].module
-    if att.num_heads != 4 or mlp[1].weight.shape[0] != 512 or xkv.shape[-1] not in (256, 512):
+    D = x.shape[-1]
+    if (att.num_heads, mlp[1].weight.shape[0]) != FUSED_WIDTHS[D] or xkv.shape[-1] not in (D, 2 * D):
         return False
     return isinstance(ca[0].drop_path, torch.nn.Identity) and isinstance(ca[1].drop_path, torch.nn.Identity)
 
