@@ -17,7 +17,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     depth, out = 0, []
     for ch in name:                     # drop the (parameter list) but keep <template arguments>
         if ch == "(" and depth == 0:

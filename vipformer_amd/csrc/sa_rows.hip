@@ -957,23 +957,23 @@ int sa_rows_fwd_launch(const VpfSaLayerFwd& a, hipStream_t st)
             default: return fwd_launch<256, 512, 1, 1, 4>(a, st, true);
         }
     }
-    if (a.D == 384 && a.hidden == 1536) return fwd_launch<384, 1536, 1, 1, 3>(a, st);
+    if (a.D == 384 && a.hidden == 1536) return vpf_debug().sa_rb == 2 ? fwd_launch<384, 1536, 2, 1, 3>(a, st) : fwd_launch<384, 1536, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
 }
 
 // tokens per LayerNorm-parameter-gradient partial row of the backward kernels (one row per wave group): the caller sizes pgrad1 /
 // pgrad2 as ceil(M / this) rows of 2 D floats
-int sa_rows_bwd_pgrad_tokens(int D) { (void)D; return 32; }
+int sa_rows_bwd_pgrad_tokens(int D) { return (D == 384 && vpf_debug().sa_rb == 2) ? 64 : 32; }
 
 int sa_rows_bwd_mlp_launch(const VpfSaLayerBwd& a, hipStream_t st)
 {
     if (a.D == 256 && a.hidden == 512) return bwd_mlp_launch<256, 512, 1, 2, 4>(a, st);      // 16 waves x 32 tokens each (the 8-wave x 64 shape spills at 128 registers)
-    if (a.D == 384 && a.hidden == 1536) return bwd_mlp_launch<384, 1536, 1, 1, 3>(a, st);
+    if (a.D == 384 && a.hidden == 1536) return vpf_debug().sa_rb == 2 ? bwd_mlp_launch<384, 1536, 2, 1, 3>(a, st) : bwd_mlp_launch<384, 1536, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
 }
 int sa_rows_bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st)
 {
     if (a.D == 256) return bwd_qkv_launch<256, 1, 2, 4>(a, st);
-    if (a.D == 384) return bwd_qkv_launch<384, 1, 1, 3>(a, st);
+    if (a.D == 384) return vpf_debug().sa_rb == 2 ? bwd_qkv_launch<384, 2, 1, 3>(a, st) : bwd_qkv_launch<384, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
 }
