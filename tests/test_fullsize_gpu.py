@@ -4,9 +4,9 @@ the HIP path runs configs 2, 3 and 4 at their per-GPU batch (64 / 32 / 16 pairs)
 
   * eval-mode forward of both models: backbone and projected features, rel-L2 <= 2e-2 (a whole network of bf16 operand rounding,
     the bound test_models_vs_reference_golden uses);
-  * c2 at 32 pairs, train mode with the real dropout probabilities and the kernels' own masks: the NT-Xent loss and its gradients
-    with the projection head's BatchNorm over 64 / 32 samples, where the contract's bounds (loss abs <= 5e-3, gradient cosine)
-    are meaningful -- the 4-pair fixtures normalise over 8 samples and amplify every forward difference.
+  * the c2 architecture at 32 pairs, config 3 at 32 and config 4 at 16 pairs, train mode with the real dropout probabilities and the
+    kernels' own masks: the NT-Xent loss (abs <= 5e-3, the contract's bound: the head's BatchNorm sees 64 / 32 samples) and the
+    gradients of every parameter for a linear and for the pre-training loss, held to the precision budget measured on the batch.
 """
 import numpy as np
 import pytest
@@ -53,24 +53,27 @@ def test_full_batch_eval_forward_vs_oracle(name):
     ck.done()
 
 
-def test_ntxent_loss_and_gradients_at_32_pairs():
-    """c2 architecture, 32 pairs (BatchNorm of the projection head over 64 clouds / 32 images), dropout 0.1 / 0.5 with exported
-    masks.  Bounds: loss abs <= 5e-3 vs the fp32 oracle (measured 3e-5); NT-Xent gradients vs the bf16-emulating
-    oracle: all-parameter cosine >= 0.985, median per-tensor >= 0.98, lowest per-tensor >= 0.965 (measured 0.9924 / 0.9911 /
-    0.9856 -- against 0.65 - 0.85 for the 4-pair fixtures, whose head BatchNorm normalises over 8 samples -- and 0.9892 / 0.9897 /
-    0.9788 for the SAME kernels compiled without packed-fp32 instructions: a different last bit here and there moves these three
-    numbers by 0.003 - 0.007, which is the band the floors leave).  What is left is the
-    temperature: the projected features agree to 1.6e-2 (bf16 through 7 layers with p = 0.5 dropout scaling), the logits are
-    features / 0.1, so dL/dfeats turns by ~1e-1 in angle; every parameter's gradient inherits that one rotation, which is why the
-    per-tensor cosines sit in a narrow band (0.986 - 0.995) instead of a few outliers.  The backward KERNELS are checked to
-    >= 0.999 by the linear-loss comparisons of test_modules_gpu.py."""
+TRAIN_FULL = {"c1": 32, "c3": 32, "c4": 16}      # c1: half of configs[1]'s 64 pairs (the oracle's four backward passes stay in minutes)
+
+
+@pytest.mark.parametrize("name", ["c1", "c3", "c4"])
+def test_full_batch_train_step_loss_and_gradients(name):
+    """Train mode at BASELINE batch sizes (c2 architecture at 32 pairs, config 3 at its 32, config 4 at its 16 pairs per GPU),
+    dropout 0.1 / 0.5 with the kernels' own masks handed to the oracle.
+      * NT-Xent loss: abs <= 5e-3 against the fp32 oracle (SURVEY 8c) -- the projection head's BatchNorm sees 64 / 32 samples here;
+      * gradients of a loss linear in the backbone features AND of the pre-training loss, every parameter: held to the precision
+        budget measured on this very batch (test_modules_gpu.budget_check: deficit of the bf16-emulating oracle against fp32; HIP
+        within 3 x of it against fp32 and against the emulation).  No constant floors: tests/rounding_budget.py shows that bf16
+        operand WEIGHTS alone cost the gradient 0.2 - 0.4 % of its direction, so SURVEY 8c's 0.999 is a property of the data format
+        at these depths and dropout rates, not of the kernels."""
     from oracle import torch_oracle as O
     from vipformer_amd import ops
-    name, B = "c1", 32
+    from tests.test_modules_gpu import budget_check, clear, grads_of
+    B = TRAIN_FULL[name]
     ops.rng.seed(4321)
     with ops.rng.pinned():
         pc, im, a = build(name, (0.1, 0.5))
-        ck = Checks(f"ntxent-32[{name}]")
+        ck = Checks(f"fullsize-train[{name}, {B} pairs]")
         pts = Hh.synth_points(910, 2 * B, a["N"]); start = Hh.synth_start(910, 2 * B, a["N"])
         imgs = Hh.synth_images(911, B, a["img"], a["img"])
         pc.train(); im.train(); pc.zero_grad(); im.zero_grad()
@@ -79,6 +82,10 @@ def test_ntxent_loss_and_gradients_at_32_pairs():
         fi, bbi = im(imgs.cuda())
         f1, f2 = f[:B], f[B:]
         loss = ops.ntxent_loss(f1, f2, 0.1) + ops.ntxent_loss((f1 + f2) / 2, fi, 0.1)
+        Rb, Rbi = Hh.synth_like(700, bb.shape), Hh.synth_like(701, bbi.shape)
+        ((bb * Rb.cuda()).sum() + (bbi * Rbi.cuda()).sum()).backward(retain_graph=True)
+        lin_grads = {id(p): p.grad.clone() for m in (pc, im) for p in m.parameters() if p.grad is not None}
+        pc.zero_grad(); im.zero_grad()
         loss.backward()
         arch = O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"],
                       atten_drop=0.1, mlp_drop=0.5)
@@ -94,34 +101,32 @@ def test_ntxent_loss_and_gradients_at_32_pairs():
         for k in list(s):
             if "cross_attn_1." in k:
                 s[k] = s[k.replace("cross_attn_1.", "cross_attn_n.")]
-    with torch.no_grad():
-        fr, bbr = O.pc_forward(s1, pts, start, arch, True, pm, {})
-        fir, bbir = O.img_forward(s2, imgs, arch, True, imk, {})
-        lref = O.ntxent(fr[:B], fr[B:]) + O.ntxent((fr[:B] + fr[B:]) / 2, fir)
-    report(f"ntxent-32 loss hip {loss.item():.5f} fp32 oracle {lref.item():.5f}")
+    fr, bbr = O.pc_forward(s1, pts, start, arch, True, pm, {})
+    fir, bbir = O.img_forward(s2, imgs, arch, True, imk, {})
+    lref = O.ntxent(fr[:B], fr[B:]) + O.ntxent((fr[:B] + fr[B:]) / 2, fir)
+    report(f"fullsize-train[{name}] loss hip {loss.item():.5f} fp32 oracle {lref.item():.5f}")
+    ck.lt("pc backbone rel (fp32 oracle)", rel(bb, bbr), 2e-2)
+    ck.lt("img backbone rel (fp32 oracle)", rel(bbi, bbir), 2e-2)
     ck.lt("pc feats rel (fp32 oracle)", rel(f, fr), 2e-2)
     ck.lt("img feats rel (fp32 oracle)", rel(fi, fir), 2e-2)
-    ck.lt("loss abs diff vs fp32 oracle (|loss| ~ 9)", abs(loss.item() - lref.item()), 5e-3)
+    ck.lt("loss abs diff vs fp32 oracle (SURVEY 8c: 5e-3)", abs(loss.item() - lref.item()), 5e-3)
+    ((bbr * Rb).sum() + (bbir * Rbi).sum()).backward(retain_graph=True)
+    lin_f32 = grads_of((pcp, imp)); clear((pcp, imp))
+    lref.backward()
+    ntx_f32 = grads_of((pcp, imp)); clear((pcp, imp))
+    del fr, bbr, fir, bbir, lref
     with O.emulate_bf16():
         fe, bbe = O.pc_forward(s1, pts, start, arch, True, pm, {})
         fie, bbie = O.img_forward(s2, imgs, arch, True, imk, {})
         le = O.ntxent(fe[:B], fe[B:]) + O.ntxent((fe[:B] + fe[B:]) / 2, fie)
-    le.backward()
+    ck.lt("[emulated] pc backbone rel", rel(bb, bbe), 4e-3)
+    ck.lt("[emulated] img backbone rel", rel(bbi, bbie), 4e-3)
     ck.lt("[emulated] loss abs diff", abs(loss.item() - le.item()), 5e-3)
-    cosines = []
-    for model, ref in ((pc, pcp), (im, imp)):
-        for k, p in model.named_parameters():
-            r = ref[k].grad
-            if r is None or p.grad is None or k.endswith(("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias")):
-                continue
-            cosines.append((cosine(p.grad, r), k, float(r.norm())))
-    cosines.sort()
-    for cc, k, nr in cosines[:6]:
-        report(f"ntxent-32 lowest grad cosine {cc:.5f} {k} |ref| {nr:.2e}")
-    hip = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).cpu() for m in (pc, im) for _, p in m.named_parameters()])
-    refg = torch.cat([(r[k].grad if r[k].grad is not None else torch.zeros_like(r[k])).reshape(-1)
-                      for m, r in ((pc, pcp), (im, imp)) for k, _ in m.named_parameters()])
-    ck.gt("[emulated] NT-Xent all-parameter gradient cosine", cosine(hip, refg), 0.985)
-    ck.gt("[emulated] NT-Xent median per-tensor gradient cosine", float(np.median([c[0] for c in cosines])), 0.98)
-    ck.gt("[emulated] NT-Xent lowest per-tensor gradient cosine", cosines[0][0], 0.965)
+    ((bbe * Rb).sum() + (bbie * Rbi).sum()).backward(retain_graph=True)
+    lin_emu = grads_of((pcp, imp)); clear((pcp, imp))
+    le.backward()
+    ntx_emu = grads_of((pcp, imp)); clear((pcp, imp))
+    where = f"fullsize-train[{name}]"
+    budget_check(ck, where, "linear loss", pc, im, lambda p: lin_grads.get(id(p)), lin_emu, lin_f32, 2e-4, 2e-3)
+    budget_check(ck, where, "NT-Xent loss", pc, im, lambda p: p.grad, ntx_emu, ntx_f32, 1e-3, 5e-3)
     ck.done()

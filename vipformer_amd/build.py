@@ -22,7 +22,9 @@ ARCH = "gfx950"
 # mis-sampled whenever gemm_kernel workgroups shared its CU (the mechanism is not understood, so the
 # instruction class goes everywhere, not only from the bit-exact kernels) -- and the step is 0.03 ms FASTER without them (A/B on one
 # box, 4 alternating pairs: 4.296 vs 4.329 ms).
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
+# -fno-vectorize (round 3): the LOOP vectoriser formed the same instructions in 14 small kernels (BatchNorm pieces, LayerNorm taps ...);
+# check_no_packed_f32 below found them in the round-2 library that was believed to be free of them.
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize", "-fno-vectorize",
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # preproc.hip: bit-exact kernels -- no fused multiply-adds the source does not spell out
 PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
@@ -37,7 +39,7 @@ def source_hash() -> str:
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
-    h.update(" ".join(COMMON[:7] + sorted(sum(PER_FILE.values(), []))).encode())
+    h.update(" ".join(COMMON[:8] + sorted(sum(PER_FILE.values(), []))).encode())
     return h.hexdigest()
 
 
@@ -54,6 +56,51 @@ def _newest_header() -> float:
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(os.path.dirname(HERE), "include", "vipformer_hip.h"))
     return max(os.path.getmtime(h) for h in hs)
+
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def device_code_objects(path: str):
+    """The gfx950 code objects embedded in a host object / shared library: every AMDGPU ELF image found in the file."""
+    import struct
+    data = open(path, "rb").read()
+    at = 0
+    while True:
+        i = data.find(b"\x7fELF\x02\x01\x01", at)
+        if i < 0:
+            return
+        at = i + 4
+        if len(data) < i + 64 or struct.unpack_from("<H", data, i + 18)[0] != 224:        # e_machine: EM_AMDGPU
+            continue
+        e_shoff, = struct.unpack_from("<Q", data, i + 40)
+        e_shentsize, e_shnum = struct.unpack_from("<HH", data, i + 58)
+        yield data[i:i + e_shoff + e_shentsize * e_shnum]
+
+
+def check_no_packed_f32(lib_path: str) -> int:
+    """Fail the build if the library's device code contains a packed-fp32 VALU instruction (v_pk_add_f32 / v_pk_mul_f32 /
+    v_pk_fma_f32).  With them fps_kernel mis-sampled whenever gemm_kernel workgroups shared its CU: the
+    mechanism is not understood, so the instruction class is banned from the whole library -- -fno-slp-vectorize keeps the compiler
+    from forming them, this check keeps a hand-written one (inline asm, a builtin, a vector type) from re-opening the fault
+    silently.  Returns the number of code objects scanned."""
+    import re
+    import tempfile
+    n, bad = 0, []
+    for img in device_code_objects(lib_path):
+        n += 1
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(img); f.flush()
+            d = subprocess.run([OBJDUMP, "-d", f.name], capture_output=True, text=True).stdout
+        hits = re.findall(r"\bv_pk_(?:add|mul|fma)_f32\b", d)
+        if hits:
+            kernels = sorted(set(re.findall(r"^[0-9a-f]+ <([^>]+)>:", d, flags=re.M)))[:4]
+            bad.append(f"code object {n}: {len(hits)} ({', '.join(kernels)} ...)")
+    if n == 0:
+        raise RuntimeError(f"no gfx950 code object found in {lib_path}")
+    if bad:
+        raise RuntimeError("packed-fp32 instructions in the device code (the co-residency fault's trigger, DESIGN.md section 6): " + "; ".join(bad))
+    return n
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -94,8 +141,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
+        n = check_no_packed_f32(LIB)
         if verbose:
-            print("linked", LIB)
+            print(f"linked {LIB} ({n} code objects, no packed-fp32 instructions)")
     return LIB
 
 
