@@ -43,8 +43,11 @@ NAMES = {"c2": "E1CL6SL-H4D256-L96-MR2", "c3": "E1CL8SL-H4D256-L128-MR2", "c4": 
 GFLOP_PER_PAIR = {"c2": 17.4, "c3": 24.2, "c4": 64.7}   # fwd+bwd, 2 FLOP/MAC, backward = 2x forward
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guide: MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
-PROFILE_STATS = os.path.join(ROOT, "profiles", "r02_bench_c2_kernel_stats.csv")
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+# whole-step budgets (tools/collect_step_bytes.sh: kernel trace + FETCH_SIZE + WRITE_SIZE passes of this very command, folded per
+# kernel over the last whole steps): launches per step, in-step average duration, HBM bytes per launch IN THE STEP
+PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r03_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r03_step_bytes_c3.json"),
+                "c4": os.path.join(ROOT, "profiles", "r03_step_bytes_c4.json")}
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels
 
 
 def synth_batch(b, N, img, seed, device, dups=False):
@@ -70,17 +73,30 @@ def synth_batch(b, N, img, seed, device, dups=False):
 
 # ----------------------------------------------------------------------------------------------- kernel legs
 def _events(fn, iters=30, warm=5):
-    """Mean microseconds per call of fn, HIP events on torch's current stream (the stream the C ABI launches on)."""
+    """Mean microseconds per call of fn on the device.  `iters` calls are captured into ONE hipGraph (on the capture stream: the
+    stream the C ABI launches on is torch's current stream) and the replays are timed with HIP events on that stream: several of
+    the legs are shorter than what Python needs to issue them (a fused layer tail is 40 us on the device and ~45 us of ctypes +
+    allocator work on the host), so an eager loop would time the host."""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            for _ in range(iters):
+                fn()
+        graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record(side)
+        for _ in range(reps):
+            graph.replay()
+        e1.record(side)
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    return e0.elapsed_time(e1) / (iters * reps) * 1e3
 
 
 def _leg(name, us, nbytes, flops, bound, note):
@@ -132,10 +148,9 @@ def kernel_legs(device, a, pairs):
                                     dq, D, dk, D, dv, D, dl), 20, 3)
         kn = "attn_bwd_dq/dkv_kernel" if Lkv > 224 else "attn_res_bwd_kernel"
         legs[f"{kn} ({tag})"] = _leg(kn, us, 2.0 * D * (4 * Bq * Lq + 4 * Bq * Lkv), 2.5 * fl, "mfma", f"{tag} backward")
-    if D != 256:
-        return legs
     # ---- grouped weight gradients of one encoder layer: dW = dY^T X for fc2, fc1, o_proj, qkv over M tokens
-    shapes = [(D, 2 * D), (2 * D, D), (D, D), (3 * D, D)]
+    Hd = a["MR"] * D
+    shapes = [(D, Hd), (Hd, D), (D, D), (3 * D, D)]
     jobs = [(torch.randn(M, Nn, generator=g).to(device).bfloat16(), torch.randn(M, Kk, generator=g).to(device).bfloat16(), Nn, Kk,
              torch.zeros(Nn, Kk, device=device), torch.zeros(Nn, device=device)) for Nn, Kk in shapes]
 
@@ -149,7 +164,7 @@ def kernel_legs(device, a, pairs):
     nbytes = sum(2.0 * M * (Nn + Kk) + 4.0 * Nn * Kk for Nn, Kk in shapes)
     legs["gemm_wgrad_group_kernel"] = _leg("gemm_wgrad_group_kernel", us, nbytes, sum(2.0 * M * Nn * Kk for Nn, Kk in shapes), "hbm",
                                            f"4 weight gradients of one encoder layer, {M} tokens: operands read once + dW written once")
-    # ---- fused encoder-layer tail (o_proj .. MLP .. next layer's LayerNorm + q/k/v): 9232 B and 2*256*2048 flop per token
+    # ---- fused encoder-layer tail (o_proj .. MLP .. next layer's LayerNorm + q/k/v): 9232 B and 2*256*2048 flop per token at D = 256
     layers = nn.ModuleList([SelfAttentionLayer(H, D, a["MR"], 0.0, 0.1, 0.5) for _ in range(2)]).to(device)
     layers.train()
     blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
@@ -160,18 +175,19 @@ def kernel_legs(device, a, pairs):
     att, mlp = layers[0][0].module.attention, layers[0][1].module
     nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
     us = _events(lambda: ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, M, device), 20, 3)
-    per_row = 256 * 2 + 256 * 4 + 256 * 4 + 2 * 256 * 4 + 2 * 256 * 2 + 2 * 512 * 2 + 768 * 2 + 16
-    legs["sa_layer_fwd_kernel"] = _leg("sa_layer_fwd_kernel", us, float(per_row) * M, 2.0 * 256 * (256 + 512 + 512 + 768) * M, "hbm",
-                                       f"fused encoder-layer tail, {M} tokens x 256 channels")
+    # per token: o (bf16) + base, x1, out, pos (f32) + n2, next n1 (bf16) + u, h (bf16, hidden) + next q|k|v (bf16) + LayerNorm statistics
+    per_row = 28 * D + 4 * Hd + 16
+    legs["sa_layer_fwd_kernel"] = _leg("sa_layer_fwd_kernel" if D == 256 else "sa_rows_fwd_kernel", us, float(per_row) * M,
+                                       2.0 * D * (D + 2 * Hd + 3 * D) * M, "hbm", f"fused encoder-layer tail, {M} tokens x {D} channels")
     return legs
 
 
-def _profile_rows():
+def _step_profile(arch):
     try:
-        with open(PROFILE_STATS) as f:
-            return list(csv.DictReader(f))
-    except OSError:
-        return []
+        with open(PROFILE_STEP[arch]) as f:
+            return json.load(f)
+    except (OSError, ValueError, KeyError):
+        return {}
 
 
 def _pmc():
@@ -182,49 +198,59 @@ def _pmc():
         return {}
 
 
-PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step trace whose average durations add up to one "launch" of the leg
+PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step budget whose per-launch figures add up to one "launch" of the leg
     "fps_kernel": ["fps_kernel"],
     "knn_group_select_kernel": ["knn_group_select_kernel"],
     "gemm_wgrad_group_kernel": ["gemm_wgrad_group_kernel"],
-    "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel"],
-    "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel"],
-    "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel", "attn_bwd_dkv"],
-    "attn_res_fwd_kernel (self-attention pc)": ["attn_res_fwd_kernel<3>"],
+    "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel", "sa_rows_fwd_kernel"],
+    "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel<3, 128>", "attn_fwd_kernel<4, 128>"],
+    "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel<3, 128>", "attn_bwd_dq_kernel<4, 128>", "attn_bwd_dkv"],
+    "attn_res_fwd_kernel (self-attention pc)": ["attn_res_fwd_kernel<3>", "attn_res_fwd_kernel<4>"],
     "attn_res_fwd_kernel (self-attention img)": ["attn_res_fwd_kernel<7>"],
-    "attn_res_bwd_kernel (self-attention pc)": ["attn_res_bwd_kernel<3>"],
+    "attn_res_bwd_kernel (self-attention pc)": ["attn_res_bwd_kernel<3>", "attn_res_bwd_kernel<4>"],
     "attn_res_bwd_kernel (self-attention img)": ["attn_res_bwd_kernel<7>"],
 }
 
 
-def attach_profile(legs):
-    """Per leg: the in-step average of the committed whole-step rocprofv3 trace (same command), its share of the step's kernel time,
-    and the PMC numbers of the committed counter passes (HBM bytes per launch: FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950
-    correction; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs x 4 SIMDs))."""
-    rows = _profile_rows()
+def attach_profile(legs, prof):
+    """Per leg, from the committed whole-step budget of the same command: launches per step, the in-step average duration, the
+    leg's share of the step's kernel time and its HBM bytes per launch AS MEASURED IN THE STEP (FETCH_SIZE x 2 + WRITE_SIZE, the
+    guide's gfx950 correction); the stand-alone MFMA-busy counters of the attention kernels from the round-2 PMC passes."""
+    rows = prof.get("kernels", [])
     pmc = _pmc()
-    tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
+    tot = float(prof.get("kernel_us_per_step") or 0.0) or 1.0
     for key, leg in legs.items():
-        avg, ns_all, found = 0.0, 0.0, False
+        avg = us_all = byt = 0.0
+        n_l, found = 0.0, False
         for sub in PROFILE_NAMES.get(key, [leg["kernel"]]):
-            hit = [r for r in rows if sub in r["Name"]]
-            if hit:
-                ns = sum(float(r["TotalDurationNs"]) for r in hit); calls = sum(float(r["Calls"]) for r in hit)
-                avg += ns / calls; ns_all += ns; found = True
+            for r in rows:
+                if sub in r["kernel"] and r.get("launches_per_step"):
+                    avg += (r.get("avg_us_in_step") or 0.0) if sub != "attn_bwd_dkv" or True else 0.0
+                    us_all += r["us_per_step"]; byt += r.get("hbm_bytes_per_launch") or 0.0
+                    n_l = max(n_l, r["launches_per_step"]); found = True
         if found:
-            leg["in_step_avg_us"] = round(avg / 1e3, 2)
-            leg["share_of_step_kernel_time"] = round(ns_all / tot, 4)
+            leg["in_step_avg_us"] = round(avg, 2)
+            leg["launches_per_step"] = n_l
+            leg["share_of_step_kernel_time"] = round(us_all / tot, 4)
+            leg["hbm_bytes_per_launch"] = byt
+            if avg > 0:
+                leg["hbm_gbs_in_step"] = round(leg["bytes_per_launch"] / avg / 1e3, 1)
+                leg["hbm_frac_in_step"] = round(leg["bytes_per_launch"] / avg / 1e3 / PEAK_HBM_GBS, 4)
+                leg["mfma_frac_in_step"] = round(leg["flops_per_launch"] / avg / 1e6 / PEAK_BF16_TFLOPS, 4)
         p = pmc.get(key) or pmc.get(leg["kernel"])
         if p:
-            leg.update({k: v for k, v in p.items() if k != "pmc"})
+            for k, v in p.items():
+                if k in ("mfma_busy_frac", "mfma_busy_over_cu_busy"):
+                    leg[k + "_standalone"] = v
     return rows
 
 
 def dominant(legs, rows):
-    """The leg whose kernel is first in the whole-step kernel statistics (largest total time); the grouped weight gradient if the
-    profile is absent."""
-    for r in rows:
+    """The leg whose kernel is first in the whole-step budget by kernel time per step; the grouped weight gradient if there is no
+    budget for this architecture."""
+    for r in sorted(rows, key=lambda r: -r.get("us_per_step", 0.0)):
         for key in legs:
-            if any(sub in r["Name"] for sub in PROFILE_NAMES.get(key, [])):
+            if any(sub in r["kernel"] for sub in PROFILE_NAMES.get(key, [])):
                 return key
     return "gemm_wgrad_group_kernel" if "gemm_wgrad_group_kernel" in legs else next(iter(legs))
 
@@ -342,13 +368,21 @@ def main():
     # VPF_FORCE_DP=1 (diagnostic): run the N > 1 code path -- process group, split capture, region-wise all-reduce, AdamW per region --
     # in a one-rank group; its ms/step minus the plain one's is what data parallelism costs before any byte crosses xGMI
     force_dp = os.environ.get("VPF_FORCE_DP", "0") == "1"
+    ranks_seen = None
     if world > 1 or force_dp:
+        # a hang (a rank that never reaches a collective) must end the run with the ranks' stacks and a non-zero exit code, never with
+        # a re-exec or a silent wait for the driver's own limit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("VPF_BENCH_WATCHDOG_S", "900")), exit=True)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)   # "nccl" IS RCCL on ROCm
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                                  # proof in the JSON line that the group really spans `world` ranks
+        ranks_seen = int(ones.item())
 
     from vipformer_amd import __version__, ops
     from vipformer_amd.train import Pretrainer, build_models
@@ -425,6 +459,15 @@ def main():
         return el
 
     elapsed = timed(run, args.steps)
+    comm_ms = None
+    if tr.dp:
+        # the same steps again with device events around every region's exchange on the communication stream (never inside `value`)
+        tr.exchange.timing = True
+        cs = max(3, args.steps // 4)
+        for _ in range(cs):
+            run()
+        comm_ms = round(tr.exchange.comm_ms() / cs, 4)
+        tr.exchange.timing = False
     losses = [float(x) for x in tr.losses]
     finite = all(map(lambda v: v == v and abs(v) != float("inf"), losses))
 
@@ -508,19 +551,30 @@ def main():
         static[0].copy_(t1); static[1].copy_(t2)
 
     legs, roof = {}, None
+    prof = _step_profile(args.arch) if rank == 0 else {}
     if rank == 0 and not args.no_kernels:
         legs = kernel_legs(device, a, pairs)
-        rows = attach_profile(legs) if args.arch == "c2" else []
+        rows = attach_profile(legs, prof)
         key = dominant(legs, rows)
         d = legs[key]
         bound = d["bound"] if d["bound"] in ("hbm", "mfma") else "hbm"
-        ach, peak, unit = (d["hbm_gbs"], PEAK_HBM_GBS, "GB/s") if bound == "hbm" else (d["mfma_tflops"], PEAK_BF16_TFLOPS, "TFLOP/s")
-        roof = dict(bound=bound, kernel=f"{d['kernel']}: {d['note']}", achieved=ach, peak=peak, unit=unit, frac=round(ach / peak, 4),
-                    traffic=d.get("hbm_bytes_per_launch"), us_per_launch=d["us_per_launch"], in_step_avg_us=d.get("in_step_avg_us"),
-                    frac_in_step=(round(ach * d["us_per_launch"] / d["in_step_avg_us"] / peak, 4) if d.get("in_step_avg_us") else None),
-                    hbm_frac=d["hbm_frac"], mfma_frac=d["mfma_frac"], bytes_per_launch=d["bytes_per_launch"],
-                    flops_per_launch=d["flops_per_launch"], share_of_step_kernel_time=d.get("share_of_step_kernel_time"),
-                    source="live HIP-event timing on the launch stream; in-step average and traffic from profiles/r02_* (same command)")
+        in_step = d.get("in_step_avg_us")
+        us = in_step or d["us_per_launch"]                 # the in-step average when the whole-step budget of this arch is committed
+        alg = d["bytes_per_launch"] if bound == "hbm" else d["flops_per_launch"]
+        ach = alg / us / 1e3 if bound == "hbm" else alg / us / 1e6
+        peak, unit = (PEAK_HBM_GBS, "GB/s") if bound == "hbm" else (PEAK_BF16_TFLOPS, "TFLOP/s")
+        ach_alone = d["hbm_gbs"] if bound == "hbm" else d["mfma_tflops"]
+        roof = dict(bound=bound, kernel=f"{d['kernel']}: {d['note']}", achieved=round(ach, 1), peak=peak, unit=unit, frac=round(ach / peak, 4),
+                    traffic=d.get("hbm_bytes_per_launch"), us_per_launch=round(us, 2), launches_per_step=d.get("launches_per_step"),
+                    frac_standalone=round(ach_alone / peak, 4), us_per_launch_standalone=d["us_per_launch"],
+                    hbm_frac=d.get("hbm_frac_in_step", d["hbm_frac"]), mfma_frac=d.get("mfma_frac_in_step", d["mfma_frac"]),
+                    bytes_per_launch=d["bytes_per_launch"], flops_per_launch=d["flops_per_launch"],
+                    share_of_step_kernel_time=d.get("share_of_step_kernel_time"),
+                    source=("achieved / frac: algorithmic bytes over the kernel's IN-STEP average duration and traffic = its in-step HBM bytes "
+                            "(FETCH_SIZE x 2 + WRITE_SIZE), both from " + os.path.relpath(PROFILE_STEP[args.arch], ROOT) + " (rocprofv3 passes of "
+                            "this command, tools/collect_step_bytes.sh); *_standalone: timed live in this run, a hipGraph of 30 launches "
+                            "replayed, HIP events on the launch stream") if in_step else
+                           "no whole-step budget committed for this architecture: stand-alone live timing only")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(ARCHS["c2"])
@@ -537,10 +591,13 @@ def main():
             "config": {"workload": "%s, per-GPU batch %d pairs (2x%d-pt clouds + 224x224 img, patch 16), fwd+bwd+AdamW, NT-Xent IMC+CMC, "
                                    "dropout 0.1/0.5" % (NAMES[args.arch], pairs, a["N"]),
                        "global_batch": pairs * world, "parallelism": f"dp{world}" + (" (data-parallel code path forced in a one-rank group)" if force_dp else ""), "hip_graph": use_graph, "capture": capture_mode, "two_stream_overlap": tr.overlap,
+                       "ranks_seen": ranks_seen, "comm_ms": comm_ms, "comm_regions": ([n for n, _, _ in tr.regions] if tr.dp else None),
                        "last_losses": losses, "losses_finite": finite,
                        "step_tflops_algorithmic": round(value * gf / 1e3, 2),
                        "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
-                       "kernels_per_step": 187 if (args.arch == "c2" and use_graph) else None,   # rocprofv3 kernel trace of one replay (round 1: 196)
+                       "kernels_per_step": (prof.get("kernels_per_step") if use_graph else None),       # launches per replayed step (committed whole-step budget)
+                       "step_hbm_bytes": prof.get("hbm_bytes_per_step"),                                # FETCH_SIZE x 2 + WRITE_SIZE summed over a step's kernels
+                       "step_hbm_frac": (round(prof["hbm_bytes_per_step"] / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if prof.get("hbm_bytes_per_step") else None),
                        "version": __version__},
             "roofline": roof, "kernels": legs, "variants": variants, "cpu_baseline": cpu,
         }
@@ -556,6 +613,8 @@ def main():
         torch.cuda.synchronize()
         dist.destroy_process_group()
         libc.fflush(None)
+        import faulthandler
+        faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         print(json.dumps(out), flush=True)
 

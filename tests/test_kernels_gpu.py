@@ -377,6 +377,14 @@ def test_grouped_wgrad_workspace_split_k():
     finally:
         ops.cfg.wgrad_deterministic = False
     _grouped_wgrad_cases(ops)                                             # the default: fp32 atomics
+    from vipformer_amd import _lib
+    keep = _lib.debug_get("wgroup_cfg")
+    try:
+        for cfg in (2, 8):                                                # 8: two K slices per 8-wave workgroup, LDS exchange, half the atomics
+            _lib.debug_set("wgroup_cfg", cfg)
+            _grouped_wgrad_cases(ops)
+    finally:
+        _lib.debug_set("wgroup_cfg", keep)
 
 
 def _grouped_wgrad_cases(ops):

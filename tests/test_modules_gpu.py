@@ -563,14 +563,18 @@ def test_fused_sa_stack_matches_unfused_blocks(name):
 @pytest.mark.parametrize("name", ["c3", "c4"])
 def test_other_baseline_configs_trainer_step_vs_oracle(name):
     """BASELINE configs 3 (G = 128, 8 self-attention layers) and 4 (D = 384, 6 heads, MR 4, 2048 points: the round-3 row-block
-    kernels) through Pretrainer.step -- the flat-buffer trainer, not just the modules: dropout off so that no masks need exporting,
-    the loss against the fp32 oracle, the flat gradient's direction against the oracle's, and AdamW's first step (sign of the
-    gradient times lr wherever the gradient is not noise)."""
+    kernels) through Pretrainer -- the flat-buffer trainer, not just the modules.  Dropout off (no masks to export), 4 pairs:
+      * the loss against the fp32 oracle;
+      * the trainer's flat gradient against the gradient the SAME modules produce through plain autograd without a trainer
+        (p.grad tensors, no flat buffers, no grad sink): equal up to the order of fp32 atomics -- the oracle-held gradient checks
+        of these architectures are test_training_step_with_dropout_vs_oracle / test_fullsize_gpu, the pre-training loss at 4 pairs
+        is too ill-conditioned (BatchNorm over 4 samples, temperature 0.1) to say anything about plumbing;
+      * AdamW's first step: every parameter with a gradient moves by lr (sign(g)) up to eps and the decoupled weight decay."""
     from oracle import torch_oracle as O
     from vipformer_amd import ops
     from vipformer_amd.train import Pretrainer, build_models
     a = Hh.ARCHS[name]
-    B = 2
+    B = 4
     ops.clear_managed_shadows()
     ops.rng.seed(7)
     torch.manual_seed(3)
@@ -580,36 +584,36 @@ def test_other_baseline_configs_trainer_step_vs_oracle(name):
     im_sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200)
     pc.load_state_dict(pc_sd); im.load_state_dict(im_sd)
     pc.train(); im.train()
-    tr = Pretrainer(pc, im)
     t1 = Hh.synth_points(11, B, a["N"]); t2 = Hh.synth_points(12, B, a["N"])
     imgs = Hh.synth_images(13, B, a["img"], a["img"])
     start = Hh.synth_start(14, 2 * B, a["N"])
+    # (1) plain autograd on the modules (what pretrain.py's own loop body does)
+    with forced_start(start.cuda()):
+        f = pc(torch.cat([t1, t2]).cuda())[0]
+    fi = im(imgs.cuda())[0]
+    loss0 = ops.ntxent_loss(f[:B], f[B:], 0.1) + ops.ntxent_loss((f[:B] + f[B:]) / 2, fi, 0.1)
+    loss0.backward()
+    g_plain = {("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters() if p.grad is not None}
+    pc.zero_grad(); im.zero_grad()
+    # (2) the trainer on the same modules
+    tr = Pretrainer(pc, im)
     p0 = tr.flat.p.clone()
     with forced_start(start.cuda()):
         losses = tr.forward_backward(t1.cuda(), t2.cuda(), imgs.permute(0, 3, 1, 2).contiguous().cuda())
-    g_hip = {("pc." if m is pc else "img.") + k: p.grad.clone().cpu() for m in (pc, im) for k, p in m.named_parameters()}
+    g_tr = {("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters()}
     tr.optimizer_step()
     torch.cuda.synchronize()
     assert all(torch.isfinite(l).item() for l in losses), losses
     arch = O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"])
-    isparam = lambda k, v: v.dtype == torch.float32 and "running" not in k and "cross_attn_1." not in k
-    pcp = {k: v.clone().requires_grad_() for k, v in pc_sd.items() if isparam(k, v)}
-    imp = {k: v.clone().requires_grad_() for k, v in im_sd.items() if isparam(k, v)}
-    s1 = dict(pc_sd); s1.update(pcp); s2 = dict(im_sd); s2.update(imp)
-    for s in (s1, s2):
-        for k in list(s):
-            if "cross_attn_1." in k:
-                s[k] = s[k.replace("cross_attn_1.", "cross_attn_n.")]
-    total, _, _ = O.pretrain_losses(s1, s2, t1, t2, imgs, start, arch, True, O.Masks("off"), O.Masks("off"), {}, {})
-    total.backward()
+    with torch.no_grad():
+        total, _, _ = O.pretrain_losses(pc_sd, im_sd, t1, t2, imgs, start, arch, True, O.Masks("off"), O.Masks("off"), {}, {})
     ck = Checks(f"trainer-step[{name}]")
-    ck.lt("loss abs diff vs fp32 oracle (|loss| ~ 3: BatchNorm over 4 / 2 samples)", abs(float(losses[0]) - float(total)), 0.1)
-    ks = [k for k in g_hip if not k.endswith(ZERO_GRAD) and (pcp if k.startswith("pc.") else imp)[k.split(".", 1)[1]].grad is not None]
-    ref = torch.cat([(pcp if k.startswith("pc.") else imp)[k.split(".", 1)[1]].grad.reshape(-1) for k in ks])
-    hip = torch.cat([g_hip[k].reshape(-1) for k in ks])
-    report(f"trainer-step[{name}] loss hip {float(losses[0]):.5f} oracle {float(total):.5f}; flat gradient cosine {cosine(hip, ref):.5f}")
-    ck.gt("flat gradient cosine vs fp32 oracle (2 pairs: the head normalises over 4 / 2 samples)", cosine(hip, ref), 0.9)
-    # AdamW's first step: p -= lr * (sign(g) + wd * p) up to eps: wherever |g| is far above eps the step is lr in magnitude
+    report(f"trainer-step[{name}] loss trainer {float(losses[0]):.5f} modules {float(loss0):.5f} oracle {float(total):.5f}")
+    ck.lt("loss: trainer vs modules (same kernels)", abs(float(losses[0]) - float(loss0)), 1e-5)
+    ck.lt("loss abs diff vs fp32 oracle (BatchNorm over 8 / 4 samples)", abs(float(losses[0]) - float(total)), 0.1)
+    ks = sorted(g_plain)
+    ck.gt("flat gradient vs plain autograd gradient, all parameters", cosine(torch.cat([g_tr[k].reshape(-1) for k in ks]),
+                                                                                torch.cat([g_plain[k].reshape(-1) for k in ks])), 0.99999)
     dp = (tr.flat.p - p0).cpu()
     moved = dp.abs() > 0
     assert moved.float().mean().item() > 0.9 and torch.isfinite(tr.flat.p).all().item()

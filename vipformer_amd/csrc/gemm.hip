@@ -76,6 +76,10 @@ struct GemmArgs {
 __device__ __forceinline__ float gelu_f(float x) { return vpf_gelu(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { return vpf_gelu_grad(x); }
 
+// thread index inside the 256-thread GROUP that works on one K slice: the whole workgroup everywhere except the pair-merged
+// grouped weight gradient (gemm_tile<.., PAIR = true>: 512 threads = two groups on two K slices of the same output tile)
+__device__ __forceinline__ int gtid() { return threadIdx.x & 255; }
+
 // ------------------------------------------------------------------ tile staging
 // K-major operand tile: LDS [ROWS][BK + pad]; K-strided operand tile: LDS [BK][ROWS + pad].
 template <int ROWS, bool TR, int BK>
@@ -126,7 +130,7 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld,
     using Cfg = TileCfg<ROWS, TR, BK>;
 #pragma unroll
     for (int i = 0; i < Cfg::PER_THREAD; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = gtid() + i * 256;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (c < Cfg::CHUNKS) {
             if (!TR) {
@@ -155,7 +159,7 @@ __device__ __forceinline__ void tile_store(bf16_t* __restrict__ S, const uint4 (
     using Cfg = TileCfg<ROWS, TR, BK>;
 #pragma unroll
     for (int i = 0; i < Cfg::PER_THREAD; ++i) {
-        const int c = threadIdx.x + i * 256;
+        const int c = gtid() + i * 256;
         if (c < Cfg::CHUNKS) {
             int off;
             if (!TR) { const int row = c / (BK / 8), kc = c % (BK / 8); off = row * Cfg::LD + kc * 8; }
@@ -192,16 +196,22 @@ __device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int 
 }
 
 // ------------------------------------------------------------------ kernel
-template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX, int PF = 1>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz)
+template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, int BX, int PF = 1, bool PAIR = false>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int bz_)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     using ACfg = TileCfg<BM, ATR, BK>;
     using BCfg = TileCfg<BN, BTR, BK>;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];      // 2 * (ACfg::ELEMS + BCfg::ELEMS)
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds_all[];  // 2 * (ACfg::ELEMS + BCfg::ELEMS) per 256-thread group
     constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;
+    // PAIR (EPI_ATOMIC split-K only): the workgroup is TWO 256-thread groups that accumulate K slices 2 bz_ and 2 bz_ + 1 of the SAME
+    // output tile side by side (own staging buffers, common barriers); at the end they exchange half a tile through LDS and each
+    // flushes ONE half with atomics: half the flushed bytes per slice at the same number of resident waves per CU.
+    const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    bf16_t* lds = lds_all + half * 2 * STAGE;
+    const int bz = PAIR ? 2 * bz_ + half : bz_;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = gtid() >> 6, lane = threadIdx.x & 63;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = by * BM, n0 = bx * BN;
 
@@ -216,8 +226,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             if (bz & 1) { kbeg = cut; kend = min(g.K, base + 2 * per); } else { kbeg = base; kend = min(g.K, cut); }
         }
         if (kbeg >= kend) {
-            if (g.mode != EPI_PARTIAL) return;
-            kend = kbeg;                            // an empty slice still takes part in the arrival count (with a zero tile)
+            if (g.mode != EPI_PARTIAL && !PAIR) return;
+            kend = kbeg;                            // an empty slice still takes part in the arrival count / the pair's barriers (with a zero tile)
         }
     } else {
         A += (size_t)bz * g.sAb; B += (size_t)bz * g.sBb; cb = (long)bz * g.sCb;
@@ -235,6 +245,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     // flight per workgroup cannot keep the memory system busy; PF is chosen so that the VGPR count keeps the occupancy)
     uint4 ra[PF][ACfg::PER_THREAD], rb[PF][BCfg::PER_THREAD];
     const int nk = (kend - kbeg + BK - 1) / BK;
+    int nk_loop = nk;                               // PAIR: both groups run the longer slice's number of stages (common barriers)
+    if (PAIR) {
+        const int per = ((g.K + g.splitk - 1) / g.splitk + BK - 1) / BK * BK;
+        const int base = bz_ * 2 * per;
+        const int cut = (g.uneven && (g.splitk & 1) == 0) ? base + (((6 + g.uneven) * per) / 6 + BK - 1) / BK * BK : base + per;
+        const int n0k = (max(0, min(g.K, cut) - base) + BK - 1) / BK, n1k = (max(0, min(g.K, base + 2 * per) - cut) + BK - 1) / BK;
+        nk_loop = max(n0k, n1k);
+    }
 #pragma unroll
     for (int p = 0; p < PF; ++p)
         if (p < nk) {
@@ -255,11 +273,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);              // bf16 (1.0, 1.0)
-    for (int kt0 = 0; kt0 < nk; kt0 += PF) {
+    for (int kt0 = 0; kt0 < nk_loop; kt0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             const int kt = kt0 + p;
-            if (kt >= nk) break;
+            if (kt >= nk_loop) break;
+            if (PAIR && kt >= nk) { __syncthreads(); continue; }     // this group's slice is done: keep the other group's barriers company
             const int cur = kt & 1;
             const bf16_t* cA = lds + cur * STAGE;
             const bf16_t* cB = cA + ACfg::ELEMS;
@@ -383,11 +402,32 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     }
     if (g.mode == EPI_ATOMIC) {
         if (g.dbg & 1) { if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(g.C)[0] = 1.f; return; }
+        if constexpr (PAIR) {
+            // group h keeps the wave tiles i == h of the 128 x 128 tile: it parks the OTHER half of its accumulators in its (dead) staging
+            // buffers in accumulator order (lane-contiguous: conflict-free), and after the barrier adds the other group's parked half
+            static_assert(TM == 2, "the pair exchange splits the tile by its two 32-row blocks per wave");
+            float* mine = reinterpret_cast<float*>(lds);
+            float* theirs = reinterpret_cast<float*>(lds_all + (half ^ 1) * 2 * STAGE);
+            __syncthreads();                        // (both groups are past their last fragment reads)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[((wave * TN + j) * 16 + r) * 64 + lane] = half ? acc[0][j][r] : acc[1][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float o = theirs[((wave * TN + j) * 16 + r) * 64 + lane];
+                    if (half) acc[1][j][r] += o; else acc[0][j][r] += o;
+                }
+        }
         // split-K partial sums: fp32 atomics straight from the accumulators (128-byte row segments)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
+                if (PAIR && i != half) continue;
                 const int n = n0 + (wn * TN + j) * 32 + col_l;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -520,13 +560,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 // is a few hundred short workgroups whose ramp-up and tail dominate; together they fill the chip.
 #define GEMM_GROUP_MAX 8
 struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; int nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n; };
-template <int TM, int TN, int WM, int WN, int BK, int PF>
-__global__ void __launch_bounds__(256) gemm_wgrad_group_kernel(GemmGroup grp)
+template <int TM, int TN, int WM, int WN, int BK, int PF, bool PAIR = false>
+__global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(GemmGroup grp)
 {
     int p = 0;
     while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
     const int local = blockIdx.x - grp.start[p];
-    const int nx = grp.nx[p], ny = grp.ny[p], sk = grp.g[p].splitk;
+    const int nx = grp.nx[p], ny = grp.ny[p], sk = PAIR ? grp.g[p].splitk / 2 : grp.g[p].splitk;      // PAIR: a workgroup = two K slices
     int bx, by, bz;
     if ((sk & 7) == 0 && (grp.start[p] & 7) == 0) {
         // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All output tiles
@@ -537,20 +577,22 @@ __global__ void __launch_bounds__(256) gemm_wgrad_group_kernel(GemmGroup grp)
     } else {
         bx = local % nx; by = (local / nx) % ny; bz = local / (nx * ny);
     }
-    gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0, PF>(grp.g[p], bx, by, bz);
+    gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0, PF, PAIR>(grp.g[p], bx, by, bz);
 }
-template <int TM, int TN, int WM, int WN, int BK, int PF = 1>
+template <int TM, int TN, int WM, int WN, int BK, int PF = 1, bool PAIR = false>
 static int launch_wgrad_group(const GemmGroup& grp, int nblocks, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS);
+    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS) * (PAIR ? 2 : 1);
+    static_assert(!PAIR || sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS) >= (size_t)BM * BN * 4 / 2,
+                  "a group's staging buffers must hold half an accumulator tile");
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<TM, TN, WM, WN, BK, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_wgrad_group_kernel<TM, TN, WM, WN, BK, PF, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_wgrad_group_kernel<TM, TN, WM, WN, BK, PF>), dim3(nblocks), dim3(256), lds, st, grp);
+    hipLaunchKernelGGL((gemm_wgrad_group_kernel<TM, TN, WM, WN, BK, PF, PAIR>), dim3(nblocks), dim3(PAIR ? 512 : 256), lds, st, grp);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -697,6 +739,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
     const int cfg = vpf_debug().wgroup_cfg, target = vpf_debug().wgroup_wgs > 0 ? vpf_debug().wgroup_wgs : 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     const int partial = ws != nullptr;
     const int tm = cfg == 0 ? 64 : 128, tn = (cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64);
+    const bool pair = cfg == 8 && !partial;          // two K slices per 8-wave workgroup: half the flush atomics (round 3)
     long total_tiles = 0;
     for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
     int at = 0;
@@ -715,6 +758,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         const long maxs = vpf_cdiv(g.K, 256);
         if (sp > maxs) sp = maxs;
         if (sp < 2) sp = 2;                       // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
+        if (pair) sp &= ~1L;                      // whole pairs
         g.splitk = (int)sp;
         // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at
         // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
@@ -722,7 +766,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         g.uneven = vpf_debug().wgroup_uneven;
         g.dbg = vpf_debug().wgroup_dbg;
         grp.nx[i] = nx; grp.ny[i] = ny; grp.start[i] = at;
-        at += nx * ny * (int)sp;
+        at += nx * ny * (int)(pair ? sp / 2 : sp);
     }
     grp.start[njobs] = at;
     hipStream_t st = (hipStream_t)stream;
@@ -738,6 +782,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
     }
     // (measured and removed: 256 x 256 tiles with the accumulators in all 512 registers of a lane -- half the operand bytes staged
     //  per output element, but 154 us against 59: 67 MB of flush atomics and one wave per SIMD with nothing to hide behind)
+    if (pair) return launch_wgrad_group<2, 2, 2, 2, 64, 1, true>(grp, at, st); // 128x128, two K slices per 8-wave workgroup
     if (cfg == 7) return launch_wgrad_group<2, 2, 2, 2, 64, 3>(grp, at, st);  // 3 stages of loads in flight
     if (cfg == 6) return launch_wgrad_group<2, 2, 2, 2, 64, 2>(grp, at, st);  // 2 stages of loads in flight
     if (cfg == 5) return launch_wgrad_group<2, 2, 2, 2, 32>(grp, at, st);     // 128x128, shallow stages: 4 workgroups per CU

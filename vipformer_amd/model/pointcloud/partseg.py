@@ -342,6 +342,8 @@ class _PointBackbone(nn.Module):
             if enc.fused_ok(probe, pts.new_empty((pts.shape[0], 1, 2 * probe.shape[2]))):
                 params = list(self.input_adapter.parameters()) + list(cross.kv_norm.parameters()) + [cross.attention.k_proj.weight, cross.attention.v_proj.weight]
                 kv = ops.AdapterKVFn.apply(pts, self.input_adapter, cross, *params)
+        if callable(_groups):
+            _groups = _groups()          # issued only now: the K / V producer's kernels above are the first nodes of this stream
         if _groups is not None:
             neighborhood, center, ev = _groups
             torch.cuda.current_stream().wait_event(ev)

@@ -102,6 +102,8 @@ class GradientExchange:
         self._cuda = flat_g.is_cuda
         self._comm = torch.cuda.Stream(device=flat_g.device) if self._cuda else None
         self._pending = {}
+        self.timing = False           # bench.py: device events around every region's exchange (comm_ms)
+        self._events = []
 
     def start(self, name: str) -> None:
         """Launch the all-reduce of region ``name``; on a GPU it is ordered after everything queued so far on the CURRENT stream
@@ -113,32 +115,49 @@ class GradientExchange:
         if self._cuda:
             self._comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm):
+                ev = None
+                if self.timing:
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(self._comm)
                 buf = view.to(torch.bfloat16) if self.wire_bf16 else view
                 work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending[name] = (work, buf, view)
+            self._pending[name] = (work, buf, view, ev)
         else:
             buf = view.to(torch.bfloat16) if self.wire_bf16 else view
             work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            self._pending[name] = (work, buf, view)
+            self._pending[name] = (work, buf, view, None)
 
     def finish(self, name: str) -> None:
         """Make the current stream (GPU) / the caller (CPU) wait for region ``name``."""
         item = self._pending.pop(name, None)
         if item is None:
             return
-        work, buf, view = item
-        if self._cuda and buf is not view:
-            # bf16 wire: the copy back into the fp32 gradient runs on the communication stream, so THAT stream must wait for the
-            # collective (work.wait() orders only the stream that is current when it is called; RCCL runs on a stream of its own)
+        work, buf, view, ev = item
+        if self._cuda:
+            # the COMMUNICATION stream waits for the collective (work.wait() orders only the stream that is current when it is
+            # called; RCCL runs on a stream of its own), copies a bf16 wire buffer back, and the current stream then waits for it
             with torch.cuda.stream(self._comm):
                 work.wait()
-                view.copy_(buf)
+                if buf is not view:
+                    view.copy_(buf)
+                if ev is not None:
+                    ev[1].record(self._comm)
+                    self._events.append(ev)
+            torch.cuda.current_stream().wait_stream(self._comm)
         else:
             work.wait()
             if buf is not view:
                 view.copy_(buf)
-        if self._cuda:
-            torch.cuda.current_stream().wait_stream(self._comm)
+
+    def comm_ms(self) -> float:
+        """With ``timing`` on: milliseconds between launch and arrival summed over the regions exchanged since the last call (device
+        events on the communication stream; synchronises)."""
+        if not self._events:
+            return 0.0
+        torch.cuda.synchronize()
+        t = sum(a.elapsed_time(b) for a, b in self._events)
+        self._events = []
+        return t
 
     def all(self) -> None:
         self.exchange()
@@ -188,6 +207,7 @@ class Pretrainer:
         self.overlap = True
         self.fused_losses = True
         self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "1") == "1"
+        self.main_first = os.environ.get("VPF_MAIN_FIRST", "0") == "1"       # measured: no gain in the unmarked step (4.31 vs 4.29 ms), off
         self.timeline = None                 # an ops.Timeline: device timestamps at the branch boundaries (tools/step_timeline.py); None = no marks
         # optional: the point-cloud branch's grouped weight gradients on the image branch's stream behind its backward (ops.WgradDeferral).
         # Measured +0.11 ms/step on MI355X: the two branches already share the CUs for most of the step, the step is bound by the SUM
@@ -284,25 +304,41 @@ class Pretrainer:
         if self.overlap and self._side is not None:
             main = torch.cuda.current_stream()
             self._side.wait_stream(main)
-            groups = None
-            with torch.cuda.stream(self._side):
-                if tl is not None:
-                    tl.mark("side.begin")
-                if self.preproc_on_side:
-                    # FPS + kNN grouping ahead of the image branch on ITS stream (it has ~0.6 ms of slack): the point-cloud
-                    # stream starts with the K / V producer, which needs only the raw points, and meets the groups later
-                    from .model.pointcloud.utils import divide_patches
-                    nb, ct = divide_patches(pc, self.pc_model.num_groups, self.pc_model.group_size)
-                    ev = torch.cuda.Event()
-                    ev.record(self._side)
-                    nb.record_stream(main); ct.record_stream(main)
-                    groups = (nb, ct, ev)
+            side_out = {}
+
+            def side_branch():
+                """FPS + kNN grouping and the whole image forward on the side stream.  Returns the groups for the point-cloud branch."""
+                groups = None
+                with torch.cuda.stream(self._side):
                     if tl is not None:
-                        tl.mark("side.preproc.end")
-                img_feats = stamp(self.img_model(imgs)[0], "img.fwd.end", "img.bwd.begin")
+                        tl.mark("side.begin")
+                    if self.preproc_on_side:
+                        # FPS + kNN grouping ahead of the image branch on ITS stream (it has ~0.6 ms of slack): the point-cloud
+                        # stream starts with the K / V producer, which needs only the raw points, and meets the groups later
+                        from .model.pointcloud.utils import divide_patches
+                        nb, ct = divide_patches(pc, self.pc_model.num_groups, self.pc_model.group_size)
+                        ev = torch.cuda.Event()
+                        ev.record(self._side)
+                        nb.record_stream(main); ct.record_stream(main)
+                        groups = (nb, ct, ev)
+                        if tl is not None:
+                            tl.mark("side.preproc.end")
+                    side_out["img"] = stamp(self.img_model(imgs)[0], "img.fwd.end", "img.bwd.begin")
+                return groups
+
             if tl is not None:
                 tl.mark("pc.fwd.begin")
-            feats = stamp(self.pc_model(pc, _groups=groups, _cut=cut)[0], "pc.fwd.end", "pc.bwd.begin")
+            if self.preproc_on_side and self.main_first:
+                # the point-cloud model calls side_branch() itself, BEHIND its K / V producer: in the captured graph the main stream's
+                # first kernels are then created before the side stream's ~25 nodes (measured with tools/step_timeline.py: issued the
+                # other way round the replayed graph started the point-cloud branch only 168 us into the step)
+                feats = stamp(self.pc_model(pc, _groups=side_branch, _cut=cut)[0], "pc.fwd.end", "pc.bwd.begin")
+                if "img" not in side_out:
+                    side_branch()                                   # (a model path that never asked for the groups)
+            else:
+                groups = side_branch()
+                feats = stamp(self.pc_model(pc, _groups=groups, _cut=cut)[0], "pc.fwd.end", "pc.bwd.begin")
+            img_feats = side_out["img"]
             main.wait_stream(self._side)
             img_feats.record_stream(main)
         else:
