@@ -469,7 +469,7 @@ def test_sa_rows_fwd_equals_the_one_per_cu_kernel_bitwise(B, Lq, with_next, with
     from vipformer_amd import _lib
     run = _tail_case(B, Lq, with_next, with_pos, 40)
     outs = []
-    for wg2 in (0, 1, 1):
+    for wg2 in (0, 3, 3):
         _lib.debug_set("sa_wg2", wg2)
         try:
             outs.append(run())
@@ -527,7 +527,7 @@ def test_sa_rows_bwd_equals_the_one_per_cu_kernels_bitwise(M, with_dsum, dsum_in
         return out
 
     res = []
-    for wg2 in (0, 1, 1):
+    for wg2 in (0, 3, 3):
         _lib.debug_set("sa_wg2", wg2)
         try:
             res.append(run())

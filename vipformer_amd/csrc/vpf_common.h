@@ -42,7 +42,7 @@ struct VpfDebug {
     int sa_nj;              // VPF_SA_NJ             channel blocks per wave of the encoder row-block kernels (1: 8 waves, 2: 4 waves)
     int sa_bwd_rows;        // VPF_SA_BWD_ROWS       1: row-coalesced backward row-block kernels
     int smallk_rpb;         // VPF_SMALLK_RPB        rows per block of the K = 3 front kernels (0: default)
-    int sa_wg2;             // VPF_SA_WG2            1: the round-3 encoder row-block kernels (sa_rows.hip) also at D = 256 (measured slower in the step: 0)
+    int sa_wg2;             // VPF_SA_WG2            bit 0 / bit 1: the round-3 forward / backward row-block kernels (sa_rows.hip) also at D = 256 (measured slower in the step: 0)
     int sa_rb;              // VPF_SA_RB             geometry of those kernels at D = 256: 12 = 16 waves x 32 tokens each (default), 2 = 8 waves x 64, 1 = 8 waves x 32
 };
 VpfDebug& vpf_debug();
