@@ -380,6 +380,18 @@ typedef struct VpfSaLayerBwd {
 } VpfSaLayerBwd;
 int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* host_args, void* stream);
 int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);
+/* The front of the point-cloud branch's cross-attention layer in ONE kernel (D = 256): position_emb (partseg.py:498-501:
+ * Linear(3,128) GELU Linear(128,D)) on the group centres, base = tokens + pos (Encoder.forward, partseg.py:326), q_norm and the
+ * bias-free q projection (partseg.py:100-116, 48-51).  W1 / Wq = vpf_pack_wfrag of the bf16 weights [D,128] / [D,D].
+ * Outputs are what the separate kernels write: hpos bf16 [M,128] (GELU output), pos f32 [M,D], base f32 [M,D], mean / rstd f32 [M],
+ * nq bf16 [M,D], q bf16 [M,D]. */
+typedef struct VpfCaFront {
+    long M; int D, hidden, C;
+    const float* centers; const float* W0; const float* b0; const void* W1; const float* b1;
+    const float* x; const float* lnq_g; const float* lnq_b; const void* Wq;
+    void* hpos; float* pos; float* base; float* mean; float* rstd; void* nq; void* q;
+} VpfCaFront;
+int vpf_ca_front_fwd(const VpfCaFront* host_args, void* stream);
 typedef struct VpfPgradJob { const float* partials; int rows; int D; float* dgamma; float* dbeta; } VpfPgradJob;   /* D = 0 means 256 */
 #define VPF_PGRAD_MAX_JOBS 32
 int vpf_ln_pgrad_reduce(const VpfPgradJob* host_jobs, int njobs, void* stream);

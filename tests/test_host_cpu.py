@@ -67,7 +67,8 @@ def test_ctypes_structs_match_the_library_layout():
     from vipformer_amd import _lib, build
     build.build(verbose=False)
     lib = _lib.lib()
-    for which, cls in enumerate((_lib.PackJob, _lib.SaLayerFwd, _lib.WgradJob, _lib.SaLayerBwd, _lib.PgradJob, _lib.AdapterKv, _lib.AdapterKvBwd)):
+    for which, cls in enumerate((_lib.PackJob, _lib.SaLayerFwd, _lib.WgradJob, _lib.SaLayerBwd, _lib.PgradJob, _lib.AdapterKv, _lib.AdapterKvBwd,
+                                 _lib.CaFront)):
         assert lib.vpf_abi_sizeof(which) == ctypes.sizeof(cls), cls.__name__
     assert lib.vpf_abi_sizeof(99) == -1
 

@@ -538,3 +538,53 @@ def test_sa_rows_bwd_equals_the_one_per_cu_kernels_bitwise(M, with_dsum, dsum_in
         assert torch.equal(res[0][k], res[1][k]), (k, (res[0][k].float() - res[1][k].float()).abs().max().item())
     for k in ("pg1", "pg2"):
         assert rel(res[1][k], res[0][k]) < 1e-5, (k, rel(res[1][k], res[0][k]))
+
+
+@pytest.mark.parametrize("B,G", [(128, 96), (3, 50)])
+def test_ca_front_kernel_vs_the_separate_kernels(B, G):
+    """vpf_ca_front_fwd (position MLP + tokens + pos + q_norm + q projection in one row-block kernel) against the kernels it replaces
+    (vpf_smallk_fwd, vpf_gemm_bf16 with bias, vpf_layernorm_fwd with the positional term, vpf_gemm_bf16): same operands, same
+    rounding points (bf16 hidden layer, f32 pos / base, bf16 q_norm output and q), agreement to rounding."""
+    import torch.nn as nn
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.partseg import CrossAttentionLayer
+    D = 256
+    torch.manual_seed(11)
+    ca = CrossAttentionLayer(4, D, D, D, 2, 0.0, 0.1, 0.5).cuda()
+    seq = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, D)).cuda()
+    with torch.no_grad():
+        ca[0].module.q_norm.weight.copy_(rnd(1, D) * 0.2 + 1.0); ca[0].module.q_norm.bias.copy_(rnd(2, D) * 0.1)
+    centers = rnd(3, B, G, 3)
+    tokens = rnd(4, B, G, D)
+
+    class Enc:                      # what CaFrontFn / ca_front_supported look at
+        num_cross_attention_layers = 1
+        cross_attn_1 = ca
+        sa_layers = []
+    assert ops.ca_front_supported(seq, tokens, Enc)
+    pos = ops.CaFrontFn.apply(centers, seq, tokens, Enc, *seq.parameters())
+    st = ca.__dict__.pop("_vpf_front_stash")
+    torch.cuda.synchronize()
+    pos_ref = ops.PosMLPFn.apply(centers, seq, *seq.parameters())
+    lnq = ca[0].module.q_norm
+    nq, mq, rq, base = ops.layernorm_fwd(tokens.contiguous(), lnq.weight.data, lnq.bias.data, pos=pos_ref, want_sum=True)
+    catt = ca[0].module.attention
+    w16 = ops.shadow([catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight])
+    q = ops.linear_fwd(nq, w16[:D * D], D, D)
+    torch.cuda.synchronize()
+    # (the hidden layer's GELU inputs differ in the last bit -- the compiler contracts the three taps differently -- which flips a
+    #  bf16 rounding of the hidden activation here and there)
+    assert rel(pos, pos_ref) < 5e-4, rel(pos, pos_ref)
+    assert rel(st["base"].view(B, G, D), base.view(B, G, D)) < 5e-4
+    assert rel(st["mq"], mq) < 1e-5 and rel(st["rq"], rq) < 1e-5
+    assert rel(st["nq"].float(), nq.float()) < 2e-3, rel(st["nq"].float(), nq.float())
+    assert rel(st["q"].float(), q.float()) < 4e-3, rel(st["q"].float(), q.float())
+    # backward of the position MLP is PosMLPFn's own
+    seq.zero_grad()
+    R = rnd(5, B, G, D)
+    (pos * R).sum().backward()
+    g1 = [p.grad.clone() for p in seq.parameters()]
+    seq.zero_grad()
+    (pos_ref * R).sum().backward()
+    for a_, b_ in zip(g1, [p.grad for p in seq.parameters()]):
+        assert rel(a_, b_) < 1e-3          # (the same kernels on hidden activations that differ in a few bf16 roundings; fp32 atomics)

@@ -125,6 +125,7 @@ SIGS = {
     "vpf_pack_wfrag": [VP, I, VP],
     "vpf_sa_layer_fwd": [VP, VP],
     "vpf_abi_sizeof": [I],
+    "vpf_ca_front_fwd": [VP, VP],
     "vpf_wgrad_group": [VP, I, VP, L_, VP],
     "vpf_sa_layer_bwd_mlp": [VP, VP],
     "vpf_sa_layer_bwd_qkv": [VP, VP],
@@ -175,6 +176,14 @@ class SaLayerFwd(ctypes.Structure):
 class PgradJob(ctypes.Structure):
     """struct VpfPgradJob (include/vipformer_hip.h)."""
     _fields_ = [("partials", VP), ("rows", I), ("D", I), ("dgamma", VP), ("dbeta", VP)]
+
+
+class CaFront(ctypes.Structure):
+    """struct VpfCaFront (include/vipformer_hip.h)."""
+    _fields_ = [("M", L_), ("D", I), ("hidden", I), ("C", I),
+                ("centers", VP), ("W0", VP), ("b0", VP), ("W1", VP), ("b1", VP),
+                ("x", VP), ("lnq_g", VP), ("lnq_b", VP), ("Wq", VP),
+                ("hpos", VP), ("pos", VP), ("base", VP), ("mean", VP), ("rstd", VP), ("nq", VP), ("q", VP)]
 
 
 class AdapterKv(ctypes.Structure):

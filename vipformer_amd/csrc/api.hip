@@ -43,6 +43,7 @@ extern "C" int vpf_abi_sizeof(int which)
         case 4: return (int)sizeof(VpfPgradJob);
         case 5: return (int)sizeof(VpfAdapterKv);
         case 6: return (int)sizeof(VpfAdapterKvBwd);
+        case 7: return (int)sizeof(VpfCaFront);
         default: return -1;
     }
 }

@@ -871,6 +871,17 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     return VPF_ERR_UNSUPPORTED;
 }
 
+extern "C" int vpf_ca_front_fwd(const VpfCaFront* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfCaFront& a = *args;
+    if (!a.centers || !a.W0 || !a.b0 || !a.W1 || !a.b1 || !a.x || !a.lnq_g || !a.lnq_b || !a.Wq || !a.hpos || !a.pos || !a.base || !a.mean ||
+        !a.rstd || !a.nq || !a.q) return VPF_ERR_NULL;
+    if (a.M <= 0) return VPF_ERR_BADSHAPE;
+    return sa_rows_ca_front_launch(a, (hipStream_t)stream);
+}
+
 // ================================================================================================ backward
 // The dgrad chain of a self-attention layer in two row-block kernels around the attention backward:
 //   vpf_sa_layer_bwd_mlp : d(x2) -> dropout' -> [dz2] -> . W2 * gelu'(u) -> [du] -> . W1 -> LayerNorm-2' (+ d) -> [dx1]

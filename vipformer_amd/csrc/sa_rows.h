@@ -8,3 +8,4 @@ int sa_rows_bwd_mlp_launch(const VpfSaLayerBwd& a, hipStream_t st);
 int sa_rows_bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st);
 bool sa_rows_supported(int D, int hidden);
 int sa_rows_bwd_pgrad_tokens(int D);
+int sa_rows_ca_front_launch(const VpfCaFront& a, hipStream_t st);

@@ -613,6 +613,106 @@ int fwd_launch(const VpfSaLayerFwd& a, hipStream_t st, bool cut = false)
     return VPF_OK;
 }
 
+// ================================================================================================ cross-attention front
+// What sits between Group2Emb and the cross-attention of the point-cloud branch -- on the step's critical path, as five launches of
+// 20 - 36 us each (smallk_fwd, gemm, pack, layernorm_fwd, gemm: 112 us) -- as ONE row-block kernel:
+//   hpos = gelu(centres . W0^T + b0)          position_emb[0:2], partseg.py:498-501 (K = 3: VALU)
+//   pos  = hpos . W1^T + b1                   position_emb[2]
+//   base = x + pos                            Encoder.forward, partseg.py:326 (the residual base of the cross-attention layer)
+//   nq   = LayerNorm_q(base);  q = nq . Wq^T  CrossAttention / MultiHeadAttention, partseg.py:100-116, 48-51
+// Everything the backward passes of PosMLPFn / EncoderFusedFn read is written as the separate kernels write it.
+template <int D, int RB, int TH, int MINW>
+__global__ void __launch_bounds__(2 * D * TH, MINW) ca_front_fwd_kernel(VpfCaFront a)
+{
+    using C = Cfg<D, RB, TH>;
+    constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, PD = C::PD, HP = 128, HLD = HP + 8;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* actH = lds;                                               // [TOK][HLD]  hidden layer of the position MLP
+    bf16_t* actA = lds + TOK * HLD;                                   // [TOK][ALD]  nq
+    float2* sPair = reinterpret_cast<float2*>(actA + C::TILE);        // [TOK][NWV]
+    float* xded = reinterpret_cast<float*>(sPair + TOK * NWV);        // the transposition slices (a region of their own)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cw = wave % NWV, tb0 = (wave / NWV) * RB;
+    const long m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, a.M - m0);
+    float* slice = xded + wave * 1024;
+
+    WRing<PD> ring;
+    ring_fill<PD>((const bf16_t*)a.W1, HP / 16, 0, cw, ring);
+    float4 rb[RB][4];                                                 // the tokens' rows: consumed behind the first product
+#pragma unroll
+    for (int i = 0; i < RB; ++i) rows_load(a.x + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid), rb[i]);
+    // ---- hidden layer: thread -> (token, 16 consecutive hidden channels); whole 256-byte rows leave for HBM
+    {
+        const int tid_ = fresh_tid();
+        for (int e = tid_; e < TOK * (HP / 16); e += C::NT) {
+            const int row = e / (HP / 16), c0 = (e % (HP / 16)) * 16;
+            const bool ok = row < nvalid;
+            float cx[3] = {0.f, 0.f, 0.f};
+            if (ok) { const float* cp = a.centers + (size_t)(m0 + row) * a.C; cx[0] = cp[0]; cx[1] = cp[1]; cx[2] = cp[2]; }
+            uint32_t w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float u[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int ch = c0 + 2 * j + h;
+                    const float* wr = a.W0 + ch * a.C;
+                    // the order smallk_fwd_kernel adds in: bias, then the taps
+                    float t = a.b0[ch];
+                    t += wr[0] * cx[0]; t += wr[1] * cx[1]; t += wr[2] * cx[2];
+                    u[h] = vpf_gelu(t);
+                }
+                w[j] = pack_bf16x2(u[0], u[1]);
+            }
+            *reinterpret_cast<uint4*>(actH + row * HLD + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(actH + row * HLD + c0 + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+            if (ok) {
+                bf16_t* hp = (bf16_t*)a.hpos + (size_t)(m0 + row) * HP + c0;
+                *reinterpret_cast<uint4*>(hp) = make_uint4(w[0], w[1], w[2], w[3]);
+                *reinterpret_cast<uint4*>(hp + 8) = make_uint4(w[4], w[5], w[6], w[7]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- pos = hpos . W1^T + b1;  base = x + pos
+    f32x16_t acc[RB], xr[RB];
+    zero<RB>(acc);
+    gemm_unit<RB, HP / 16, PD>((const bf16_t*)a.W1, HP / 16, 0, cw, actH, HLD, tb0, acc, ring);
+    ring_fill<PD>((const bf16_t*)a.Wq, KS, 0, cw, ring);
+    {
+        const int lane = fresh_tid() & 63, hl = lane >> 5;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.b1 + 32 * cw + 8 * g + 4 * hl);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) { acc[i][4 * g + 0] += b4.x; acc[i][4 * g + 1] += b4.y; acc[i][4 * g + 2] += b4.z; acc[i][4 * g + 3] += b4.w; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const RowOff ro = row_offsets<D>(tb0 + i, cw, nvalid);
+        acc_to_slice(slice, acc[i]);
+        slice_store_rows(slice, a.pos + m0 * D, ro);                   // pos rows out
+        rows_to_slice(slice, rb[i]);
+        slice_to_acc<false>(slice, xr[i]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[i][r] += acc[i][r];             // base = x + pos
+        acc_to_slice(slice, xr[i]);
+        slice_store_rows(slice, a.base + m0 * D, ro);
+    }
+    layernorm<D, RB>(xr, a.lnq_g, a.lnq_b, sPair, a.mean + m0, a.rstd + m0, nvalid);
+    acc_to_tile<D, RB>(xr, actA, ALD);
+    __syncthreads();
+    tile_store_rows<C>(actA, (bf16_t*)a.nq + m0 * D, D, nvalid);
+    // ---- q = nq . Wq^T
+    zero<RB>(acc);
+    gemm_unit<RB, KS, PD>((const bf16_t*)a.Wq, KS, 0, cw, actA, ALD, tb0, acc, ring);
+    bf16_t* qslice = reinterpret_cast<bf16_t*>(slice);
+    acc_to_slice_bf16<RB>(qslice, acc);
+    slice_bf16_store_rows<RB>(qslice, (bf16_t*)a.q + (m0 + tb0 * 32) * D + 32 * cw, D, nvalid - tb0 * 32);
+}
+
 // ================================================================================================ backward
 // LayerNorm backward in place on the accumulator tile: acc = dL/dy -> dL/dx; x = the forward input of the LayerNorm in the same
 // layout (becomes x-hat).  The per-channel parameter gradients of this wave's tokens go to pgrad[0 .. D) (dgamma) / pgrad[D .. 2D)
@@ -976,4 +1076,19 @@ int sa_rows_bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st)
     if (a.D == 256) return bwd_qkv_launch<256, 1, 2, 4>(a, st);
     if (a.D == 384) return vpf_debug().sa_rb == 2 ? bwd_qkv_launch<384, 2, 1, 3>(a, st) : bwd_qkv_launch<384, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
+}
+
+int sa_rows_ca_front_launch(const VpfCaFront& a, hipStream_t st)
+{
+    if (a.D != 256 || a.hidden != 128 || a.C < 3) return VPF_ERR_UNSUPPORTED;
+    using C = Cfg<256, 1, 2>;                                           // 16 waves x 32 tokens each: 64-token blocks
+    const size_t lds = (size_t)C::TOK * 136 * 2 + (size_t)C::TILE * 2 + (size_t)C::TOK * C::NWV * 8 + (size_t)C::NW * 4096;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)ca_front_fwd_kernel<256, 1, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((ca_front_fwd_kernel<256, 1, 2, 4>), dim3(vpf_cdiv(a.M, C::TOK)), dim3(C::NT), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
 }

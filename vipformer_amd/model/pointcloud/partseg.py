@@ -350,7 +350,12 @@ class _PointBackbone(nn.Module):
         else:
             neighborhood, center = divide_patches(pts, self.num_groups, self.group_size)
         group_embs = self.group2emb(neighborhood)
-        pos_embs = ops.PosMLPFn.apply(center, self.position_emb, *self.position_emb.parameters())
+        if ops.ca_front_supported(self.position_emb, group_embs, enc) and self.training == enc.training:
+            # position MLP + (tokens + pos) + q_norm + q projection of the cross-attention layer in one kernel; the encoder picks up
+            # what it needs from a one-shot stash on the layer (and computes it itself if anything about its inputs differs)
+            pos_embs = ops.CaFrontFn.apply(center, self.position_emb, group_embs.detach(), enc, *self.position_emb.parameters())
+        else:
+            pos_embs = ops.PosMLPFn.apply(center, self.position_emb, *self.position_emb.parameters())
         if kv is not None:
             group_embs, pos_embs, kv = self._cut_here(_cut, group_embs, pos_embs, kv)
             return enc(group_embs, pos_embs, kv, layer_idx, kv_ready=True), center

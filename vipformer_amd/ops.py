@@ -43,7 +43,7 @@ class OpsConfig:
     The library's own launch-time knobs live in its VpfDebug struct (``_lib.debug_get`` / ``debug_set``)."""
     __slots__ = ("wgrad_async", "wgrad_group", "wgrad_group_async", "wgrad_deterministic", "wgrad_defer", "sa_debug", "sa_split_attn",
                  "sa_fused_bwd", "sa_fused", "enc_bwd_hook", "adapter_kv_fused", "adapter_kv_bwd_fused", "enc_fused", "g2e_bn_merged",
-                 "g2e_conv1_bwd_fused")
+                 "g2e_conv1_bwd_fused", "ca_front_fused")
 
     def __init__(self, env=os.environ):
         self.wgrad_async = False          # weight-gradient GEMMs on a side stream: measured slower (cross-stream event cost > overlap gain)
@@ -59,6 +59,7 @@ class OpsConfig:
         self.adapter_kv_fused = True      # point adapter + kv LayerNorm + K / V projections as one kernel
         self.adapter_kv_bwd_fused = True
         self.enc_fused = True             # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
+        self.ca_front_fused = env.get("VPF_CA_FRONT", "1") == "1"     # position MLP + (tokens + pos) + q_norm + q projection of the point-cloud branch as one kernel
         self.g2e_bn_merged = env.get("VPF_G2E_BN_MERGED", "1") != "0"          # BatchNorm bookkeeping of Group2Emb as single launches
         self.g2e_conv1_bwd_fused = env.get("VPF_G2E_CONV1_FUSED", "1") == "1"  # conv2 dgrad inside the first conv's backward (tests run both)
 
@@ -1083,15 +1084,17 @@ class SAStackFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------- fused encoder: cross-attention layer + self-attention stack
-def _pack_blocks(blocks, holder, dev):
+def _pack_blocks(blocks, holder, dev, front=None):
     """blocks: list of (attention module, MLP module, want_Wqkv_forward, want_WqkvT).  Returns per-block dicts of fragment-order
-    weight views (see _sa_packed)."""
+    weight views (see _sa_packed).  front = the position MLP's second Linear: its weight [D,128] is packed into views[0]["Wpos"] and
+    block 0's q projection into views[0]["Wq"] (vpf_ca_front_fwd), in the same launch."""
     D, Hd, _ = _block_dims(blocks[0][0], blocks[0][1])
     sizes = [("Wo", D * D), ("W1", Hd * D), ("W2", D * Hd), ("Wqkv", 3 * D * D), ("W2T", Hd * D), ("W1T", D * Hd), ("WoT", D * D), ("WqkvT", 3 * D * D)]
     per = sum(n for _, n in sizes)
+    extra = D * 128                                       # the position MLP's weight (always reserved: one buffer size per stack)
     buf = getattr(holder, "_vpf_packed_enc", None)
-    if buf is None or buf.device != dev or buf.numel() != per * len(blocks):
-        buf = torch.empty(per * len(blocks), dtype=BF16, device=dev)
+    if buf is None or buf.device != dev or buf.numel() != per * len(blocks) + extra:
+        buf = torch.empty(per * len(blocks) + extra, dtype=BF16, device=dev)
         holder._vpf_packed_enc = buf
     jobs = (L.PackJob * 64)()
     views, n = [], 0
@@ -1117,6 +1120,18 @@ def _pack_blocks(blocks, holder, dev):
             if n == 64:
                 L.call_struct("vpf_pack_wfrag", jobs, n)
                 n = 0
+    if front is not None:
+        assert not blocks[0][2], "block 0's Wqkv slot holds the packed q projection"
+        att0, v0 = blocks[0][0], views[0]
+        v0["Wq"] = v0["Wqkv"][:D * D]                      # (the cross-attention block's own Wqkv slot is otherwise unused)
+        v0["Wpos"] = buf[per * len(blocks):]
+        wq = shadow([att0.q_proj.weight, att0.k_proj.weight, att0.v_proj.weight])[:D * D]
+        for src, dst, N, K in ((wq, v0["Wq"], D, D), (shadow([front.weight]), v0["Wpos"], D, 128)):
+            if n == 64:
+                L.call_struct("vpf_pack_wfrag", jobs, n)
+                n = 0
+            jobs[n].src, jobs[n].dst, jobs[n].N, jobs[n].K, jobs[n].transposed = src.data_ptr(), dst.data_ptr(), N, K, 0
+            n += 1
     if n:
         L.call_struct("vpf_pack_wfrag", jobs, n)
     return views
@@ -1189,19 +1204,26 @@ class EncoderFusedFn(torch.autograd.Function):
         catt = cross.attention
         _, Hd, H = _block_dims(catt, cmlp)
         blocks = [(catt, cmlp, False, False)] + [(l[0].module.attention, l[1].module, True, True) for l in layers]
-        packed = _pack_blocks(blocks, ca, dev)
         pos_c = pos.contiguous().float() if pos is not None else None
         pos_rows = pos_c.numel() // D if pos_c is not None else 0
+        stash = ca.__dict__.pop("_vpf_front_stash", None)            # one-shot: CaFrontFn left base / q_norm / q for THESE tensors
+        if not (stash is not None and pos_c is not None and stash["tokens"] == x.data_ptr() and stash["pos"] == pos_c.data_ptr()
+                and stash["shape"] == (B, Lq, D) and stash["nblocks"] == len(blocks)):
+            stash = None
+        packed = stash["packed"] if stash is not None else _pack_blocks(blocks, ca, dev)
         # ---- cross-attention front (AttnBlockFn.forward up to the attention)
         lnq, lnkv = cross.q_norm, cross.kv_norm
-        nq, mq, rq, xsum = layernorm_fwd(x, lnq.weight.data, lnq.bias.data, pos=pos, want_sum=True)
-        base_ca = xsum if xsum is not None else x
+        qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
+        w16 = shadow(qkvw)
+        if stash is not None:
+            base_ca, mq, rq, nq, q = stash["base"], stash["mq"], stash["rq"], stash["nq"], stash["q"]
+        else:
+            nq, mq, rq, xsum = layernorm_fwd(x, lnq.weight.data, lnq.bias.data, pos=pos, want_sum=True)
+            base_ca = xsum if xsum is not None else x
+            q = linear_fwd(nq, w16[:D * D], D, D)
         xkv = xkv.contiguous()
         Lkv = xkv.shape[1]
         Mk = B * Lkv
-        qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
-        w16 = shadow(qkvw)
-        q = linear_fwd(nq, w16[:D * D], D, D)
         if kv_ready:
             kv = xkv.view(Mk, 2 * D)
             nk = mk = rk = xkv = torch.empty(0, device=dev)         # the kv side is AdapterKVFn's business
@@ -1783,6 +1805,64 @@ class PosMLPFn(torch.autograd.Function):
         dg = linear_dgrad(dy16, shadow([l2.weight]), D, Hd)
         L.call("vpf_smallk_bwd", x, dg, M, C, l0.weight.data, l0.bias.data, Hd, 1, grad_buf(l0.weight), grad_buf(l0.bias))
         return (None, None) + (None,) * ctx.nparams
+
+
+class CaFrontFn(torch.autograd.Function):
+    """position_emb AND the front of the cross-attention layer in one kernel (vpf_ca_front_fwd): pos = position_emb(centres) as
+    PosMLPFn computes it, plus -- for the encoder call that follows -- base = tokens + pos, q_norm(base) and the q projection, left
+    on the cross-attention layer as a one-shot stash that EncoderFusedFn.forward picks up instead of launching LayerNorm + GEMM
+    itself (together with the fragment-order weight copies of the whole encoder, which this call makes: one pack launch, as before).
+    Autograd sees exactly PosMLPFn: the tokens enter detached (their gradient flows through the encoder Function, which saves the
+    stashed tensors like its own), backward is PosMLPFn.backward."""
+
+    @staticmethod
+    def forward(ctx, centers, seq, tokens, enc, *params):
+        ctx.nparams, ctx.params = len(params), params
+        B, G, C = centers.shape
+        x = centers.contiguous().float().view(-1, C)
+        M = x.shape[0]
+        l0, l2 = seq[0], seq[2]
+        Hd, D = l0.weight.shape[0], l2.weight.shape[0]
+        dev = x.device
+        ca, layers = enc.cross_attn_1, enc.sa_layers
+        cross = ca[0].module
+        catt, lnq = cross.attention, cross.q_norm
+        blocks = [(catt, ca[1].module, False, False)] + [(l[0].module.attention, l[1].module, True, True) for l in layers]
+        packed = _pack_blocks(blocks, ca, dev, front=l2)
+        tok = tokens.contiguous().float()
+        hpos = torch.empty(M, Hd, dtype=BF16, device=dev)
+        pos = torch.empty(M, D, dtype=F32, device=dev)
+        base = torch.empty(M, D, dtype=F32, device=dev)
+        mq, rq = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+        nq, q = torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, D, dtype=BF16, device=dev)
+        a = L.CaFront()
+        a.M, a.D, a.hidden, a.C = M, D, Hd, C
+        a.centers, a.W0, a.b0 = x.data_ptr(), l0.weight.data.data_ptr(), l0.bias.data.data_ptr()
+        a.W1, a.b1 = packed[0]["Wpos"].data_ptr(), l2.bias.data.data_ptr()
+        a.x, a.lnq_g, a.lnq_b, a.Wq = tok.data_ptr(), lnq.weight.data.data_ptr(), lnq.bias.data.data_ptr(), packed[0]["Wq"].data_ptr()
+        a.hpos, a.pos, a.base, a.mean, a.rstd, a.nq, a.q = (hpos.data_ptr(), pos.data_ptr(), base.data_ptr(), mq.data_ptr(), rq.data_ptr(),
+                                                              nq.data_ptr(), q.data_ptr())
+        L.call_struct("vpf_ca_front_fwd", a)
+        ca._vpf_front_stash = dict(tokens=tok.data_ptr(), pos=pos.data_ptr(), shape=(B, G, D), base=base, mq=mq, rq=rq, nq=nq, q=q,
+                                   packed=packed, nblocks=len(blocks))
+        ctx.seq = seq
+        ctx.save_for_backward(x, hpos)
+        return pos.view(B, G, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = PosMLPFn.backward(ctx, dy)                     # (None, None, *parameter gradients): the same kernels, the same saved tensors
+        return g[:2] + (None, None) + g[2:]                # + the detached tokens and the encoder object
+
+
+def ca_front_supported(seq, tokens, enc) -> bool:
+    """vpf_ca_front_fwd: D = 256, Linear(3,128) position MLP, one cross-attention layer on the fused encoder path."""
+    if not (cfg.sa_fused and cfg.enc_fused and cfg.ca_front_fused) or not tokens.is_cuda or tokens.dim() != 3:
+        return False
+    l0, l2 = seq[0], seq[2]
+    if tokens.shape[-1] != 256 or tuple(l0.weight.shape) != (128, 3) or l2.weight.shape[1] != 128 or l2.weight.shape[0] != 256:
+        return False
+    return enc.num_cross_attention_layers == 1
 
 
 class PatchEmbedFn(torch.autograd.Function):
