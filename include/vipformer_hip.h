@@ -139,6 +139,19 @@ int vpf_attention_bwd(const void* q, long ldq, const void* k, long ldk, const vo
                       long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
                       int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
                       void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws, void* stream);
+/* The same pair with the key padding mask of partseg.py:54,73-76: pad_mask uint8 [B, Lkv], non-zero = padding key, shared by the
+ * H heads of a batch element (`repeat(pad_mask, "b j -> (b h) () j")`).  A padded key's score is replaced by the most negative
+ * finite float before the softmax, as masked_fill_(pad_mask, -finfo.max) does: it receives probability 0 beside any real key, a row
+ * whose keys are ALL padded attends uniformly to its Lkv keys, and no gradient reaches q / k through a padded score (dv still
+ * receives p * dout).  pad_mask must not be NULL (VPF_ERR_NULL); without a mask call the entry points above. */
+int vpf_attention_fwd_pad(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, int B, int H,
+                          int Lq, int Lkv, int head_dim, float scale, float dropout_p, const uint32_t* rng_state,
+                          uint32_t site, void* out, long ldo, float* lse, const uint8_t* pad_mask, void* stream);
+int vpf_attention_bwd_pad(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* out,
+                          long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
+                          int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                          void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws,
+                          const uint8_t* pad_mask, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm / dropout / residual
  * nn.LayerNorm of CrossAttention.q_norm/kv_norm, SelfAttention.norm, MLP[0] (partseg.py:100-101,

@@ -255,8 +255,8 @@ def pos_mlp(sd, pre: str, centers):
     return F.linear(h, Q(sd[pre + "2.weight"]), sd[pre + "2.bias"])
 
 
-def mha(sd, pre: str, xq, xkv, H: int, p: float, masks: Masks, site: str):
-    """partseg.py:53-86."""
+def mha(sd, pre: str, xq, xkv, H: int, p: float, masks: Masks, site: str, pad_mask=None):
+    """partseg.py:53-86.  pad_mask: bool [B, Lkv], True = padding key (:73-77)."""
     B, Lq, D = xq.shape
     Lk = xkv.shape[1]
     dh = D // H
@@ -265,6 +265,9 @@ def mha(sd, pre: str, xq, xkv, H: int, p: float, masks: Masks, site: str):
     k = QB(Q(F.linear(xkv, Q(sd[pre + "k_proj.weight"])), "qkv"), "dqkv").reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
     v = QB(Q(F.linear(xkv, Q(sd[pre + "v_proj.weight"])), "qkv"), "dqkv").reshape(B, Lk, H, dh).permute(0, 2, 1, 3).reshape(B * H, Lk, dh)
     a = QB(torch.bmm(q, k.transpose(1, 2)), "ds") * (dh ** -0.5)
+    if pad_mask is not None:
+        pm = pad_mask.bool()[:, None, None, :].expand(B, H, 1, Lk).reshape(B * H, 1, Lk)      # "b j -> (b h) () j"
+        a = a.masked_fill(pm, -torch.finfo(a.dtype).max)
     a = a.softmax(dim=-1)
     a = Q(masks.apply(a, site, p), "p")
     o = QB(Q(torch.bmm(a, v), "o"), "do").reshape(B, H, Lq, dh).permute(0, 2, 1, 3).reshape(B, Lq, D)
@@ -279,14 +282,14 @@ def mlp(sd, pre: str, x):
     return QB(F.linear(h, Q(sd[pre + "3.weight"]), sd[pre + "3.bias"]), "dz")
 
 
-def ca_layer(sd, pre: str, xq, xkv, a: Arch, masks: Masks, tag: str):
+def ca_layer(sd, pre: str, xq, xkv, a: Arch, masks: Masks, tag: str, pad_mask=None):
     """partseg.py:144-167 + Residual :201-213.  Residual dropout p = atten_drop for the
     attention branch (:165) and mlp_drop for the MLP branch (:166)."""
     D = xq.shape[-1]
     m = pre + "0.module."
     nq = F.layer_norm(xq, (D,), sd[m + "q_norm.weight"], sd[m + "q_norm.bias"], 1e-5)
     nk = F.layer_norm(xkv, (D,), sd[m + "kv_norm.weight"], sd[m + "kv_norm.bias"], 1e-5)
-    y = mha(sd, m + "attention.", nq, nk, a.H, a.atten_drop, masks, tag + ".attn")
+    y = mha(sd, m + "attention.", nq, nk, a.H, a.atten_drop, masks, tag + ".attn", pad_mask)
     x = masks.apply(y, tag + ".res1", a.atten_drop) + xq
     y = mlp(sd, pre + "1.module.", x)
     return masks.apply(y, tag + ".res2", a.mlp_drop) + x
@@ -303,14 +306,14 @@ def sa_layer(sd, pre: str, x, a: Arch, masks: Masks, tag: str):
     return masks.apply(y, tag + ".res2", a.mlp_drop) + x1
 
 
-def encoder(sd, pre: str, tokens, pos, kv, a: Arch, masks: Masks, taps=()):
+def encoder(sd, pre: str, tokens, pos, kv, a: Arch, masks: Masks, taps=(), pad_mask=None):
     """partseg.py:314-342.  pos is re-added before every layer and is part of the
-    residual base.  Returns (x, [tapped layer outputs])."""
-    x = ca_layer(sd, pre + "cross_attn_1.", tokens + pos, kv, a, masks, "ca")
+    residual base; pad_mask reaches the cross-attention layers only (:326,334).  Returns (x, [tapped layer outputs])."""
+    x = ca_layer(sd, pre + "cross_attn_1.", tokens + pos, kv, a, masks, "ca", pad_mask)
     feats = []
     for i in range(a.S):
         if i + 1 < a.n_ca:
-            x = ca_layer(sd, pre + "cross_attn_n.", x + pos, kv, a, masks, f"ca{i + 1}")
+            x = ca_layer(sd, pre + "cross_attn_n.", x + pos, kv, a, masks, f"ca{i + 1}", pad_mask)
         x = sa_layer(sd, pre + f"sa_layers.{i}.", x + pos, a, masks, f"sa{i}")
         if (i + 1) in taps:
             feats.append(x)

@@ -429,8 +429,59 @@ def make_ca2():
     save("model_tiny_ca2.npz", pc_eval_feats=f, pc_eval_backbone=bb, pc_train_backbone=bb2, pc_grad_norms=norms)
 
 
+def padmask_case():
+    """Inputs of the pad_mask fixture (shared with the tests through tests/helpers.py: only expected outputs are stored).
+    Ragged lengths (40 queries, 70 keys: neither a multiple of 32); batch row 0 pads its last 20 keys, row 1 a scattered half,
+    row 2 EVERY key (softmax of equal scores: uniform attention, no gradient to q / k)."""
+    return Hh.padmask_inputs()
+
+
+def make_padmask():
+    """Key padding mask of MultiHeadAttention (partseg.py:53-86) through the reference's CrossAttentionLayer, SelfAttention and Encoder
+    -> padmask.npz: outputs and every gradient for a linear loss, eval mode (dropout off)."""
+    c = padmask_case()
+    D, H = c["D"], c["H"]
+    out = {}
+    # (1) one cross-attention layer (LayerNorms, MHA with the mask, residual, MLP)
+    torch.manual_seed(0)
+    ca = RP.CrossAttentionLayer(H, D, D, D, widening_factor=2)
+    ca.load_state_dict(Hh.synth_state_dict(keyshapes(ca), 910, alias_ca=False))
+    ca.eval()
+    xq = c["xq"].clone().requires_grad_(); xkv = c["xkv"].clone().requires_grad_()
+    y = ca(xq, xkv, c["pad"])
+    (y * c["R"]).sum().backward()
+    out.update(ca_out=y.detach(), ca_dxq=xq.grad, ca_dxkv=xkv.grad)
+    for k, v in ca.named_parameters():
+        out["ca_g." + k] = v.grad
+    # (2) self-attention with a mask over its own tokens (SelfAttention.forward(x, pad_mask), partseg.py:138-141)
+    sa = RP.SelfAttention(H, D)
+    sa.load_state_dict(Hh.synth_state_dict(keyshapes(sa), 920, alias_ca=False))
+    sa.eval()
+    x = c["xq"].clone().requires_grad_()
+    y = sa(x, c["pad_self"])
+    (y * c["R"]).sum().backward()
+    out.update(sa_out=y.detach(), sa_dx=x.grad)
+    for k, v in sa.named_parameters():
+        out["sa_g." + k] = v.grad
+    # (3) Encoder.forward(group_embs, pos_embs, pts_embs, pad_mask=...) (partseg.py:314-342), 2 self-attention layers
+    enc = RP.Encoder(num_latent_channels=D, num_cross_attention_heads=H, cross_attention_widening_factor=2, num_self_attention_layers=2,
+                     num_self_attention_heads=H, self_attention_widening_factor=2, dpr_list=[0.0, 0.0], modal_prior=True)
+    json.dump(keyshapes(enc), open(os.path.join(HERE, "keys_enc_padmask.json"), "w"))
+    enc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_enc_padmask.json"), 930))
+    enc.eval()
+    tok = c["xq"].clone().requires_grad_(); kv = c["xkv"].clone().requires_grad_()
+    y = enc(tok, c["pos"], kv, pad_mask=c["pad"])
+    (y * c["R"]).sum().backward()
+    out.update(enc_out=y.detach(), enc_dtok=tok.grad, enc_dkv=kv.grad)
+    for k, v in enc.named_parameters():
+        out["enc_g." + k] = v.grad
+    save("padmask.npz", **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "ft":
+    if len(sys.argv) > 1 and sys.argv[1] == "padmask":
+        make_padmask()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ft":
         make_ft()
     elif len(sys.argv) > 1 and sys.argv[1] == "partseg":
         make_partseg()

@@ -93,6 +93,25 @@ def synth_like(seed: int, shape) -> torch.Tensor:
     return _uniform(rng, shape, -1.0, 1.0)
 
 
+def padmask_inputs():
+    """Inputs of the pad_mask fixture padmask.npz (tests/golden/make_golden.py make_padmask).  Ragged lengths (40 queries, 70 keys:
+    neither a multiple of 32); batch row 0 pads its last 20 keys, row 1 a scattered half, row 2 EVERY key (softmax of equal scores:
+    uniform attention, no gradient to q / k).  pad_self: the mask of a self-attention over the 40 query tokens."""
+    B, Lq, Lk, D, H = 3, 40, 70, 128, 2
+    rng = np.random.default_rng(4242)
+    pad = np.zeros((B, Lk), dtype=bool)
+    pad[0, 50:] = True
+    pad[1] = rng.random(Lk) < 0.5
+    pad[2] = True
+    pad_self = np.zeros((B, Lq), dtype=bool)
+    pad_self[0, 33:] = True
+    pad_self[1] = rng.random(Lq) < 0.4
+    pad_self[2] = True
+    return dict(B=B, Lq=Lq, Lk=Lk, D=D, H=H, xq=synth_like(900, (B, Lq, D)), xkv=synth_like(901, (B, Lk, D)),
+                pos=0.5 * synth_like(902, (B, Lq, D)), R=synth_like(903, (B, Lq, D)),
+                pad=torch.from_numpy(pad), pad_self=torch.from_numpy(pad_self))
+
+
 def load_keyshapes(name: str) -> List[Tuple[str, Tuple[int, ...]]]:
     with open(os.path.join(GOLDEN_DIR, name)) as f:
         return [(k, tuple(s)) for k, s in json.load(f)]

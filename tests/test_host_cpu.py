@@ -132,7 +132,7 @@ def test_error_behaviour_matches_reference_and_no_cpu_fallback():
     with pytest.raises(NotImplementedError):
         mha(x, x, attn_mask=torch.zeros(1))                       # partseg.py:64-65
     with pytest.raises(_lib.VpfError, match="pad_mask"):
-        mha(x, x, pad_mask=torch.zeros(1, 4, dtype=torch.bool))   # partseg.py:73-76 masks padded keys; never used on this path: loud, not silent
+        mha(x, x, pad_mask=torch.zeros(1, 5, dtype=torch.bool))   # partseg.py:73-76: [B, Lkv]; a mask of another shape is refused before any launch
     with pytest.raises(_lib.VpfError):
         mha(x, x)                                                 # CPU tensors: there is no eager fallback
     with pytest.raises(_lib.VpfError):

@@ -181,6 +181,75 @@ def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
         assert r < 1.5e-2, f"{name} rel {r}"                                 # bf16 P/dS operands + bf16 outputs
 
 
+@pytest.mark.parametrize("B,H,Lq,Lkv,p", [(3, 2, 40, 70, 0.0), (2, 2, 96, 1024, 0.1), (3, 4, 196, 196, 0.1), (2, 1, 33, 300, 0.5), (3, 2, 96, 96, 0.0)])
+def test_attention_pad_mask_fwd_bwd(B, H, Lq, Lkv, p):
+    """vpf_attention_fwd_pad / _bwd_pad (partseg.py:73-77: masked_fill_(pad_mask, -finfo.max) in front of the softmax) against torch
+    fp32 on the same bf16 operands and the kernel's own dropout mask: a tail mask, a scattered mask, and -- last batch row -- every
+    key padded (uniform attention; dq = dk = 0 there, dv = mean of dout).  Without a mask set the result is the unmasked kernels'."""
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    D = 64 * H
+    q, k, v, do = rnd(1, B, Lq, D), rnd(2, B, Lkv, D), rnd(3, B, Lkv, D), rnd(4, B, Lq, D)
+    q16, k16, v16, do16 = bf(q), bf(k), bf(v), bf(do)
+    g = torch.Generator().manual_seed(5)
+    pad = torch.zeros(B, Lkv, dtype=torch.bool)
+    pad[0, Lkv - Lkv // 3:] = True
+    if B > 2:
+        pad[1] = torch.rand(Lkv, generator=g) < 0.5
+    pad[B - 1] = True
+    pad8 = pad.to(torch.uint8).cuda()
+    site = ops.new_site()
+    scale = 64 ** -0.5
+    st = ops.rng.state("cuda")
+    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
+    L.call("vpf_attention_fwd_pad", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse, pad8)
+    keep = ops.dropout_keep_mask(site, p, (B, H, Lq, Lkv), "cuda").float() if p > 0 else None
+    split = lambda t, Lx: t.float().view(B, Lx, H, 64).permute(0, 2, 1, 3).contiguous().requires_grad_()
+    qr, kr, vr = split(q16, Lq), split(k16, Lkv), split(v16, Lkv)
+    s = torch.einsum("bhid,bhjd->bhij", qr, kr) * scale
+    s = s.masked_fill(pad.cuda()[:, None, None, :], -torch.finfo(torch.float32).max)
+    a = s.softmax(-1)
+    if keep is not None:
+        a = a * keep / (1 - p)
+    oref = torch.einsum("bhij,bhjd->bhid", a, vr)
+    og = o.float().view(B, Lq, H, 64).permute(0, 2, 1, 3)
+    assert rel(og, oref) < 8e-3, f"fwd rel {rel(og, oref)}"
+    lref = torch.logsumexp(s, -1)
+    part = ~pad.all(dim=1)                                     # rows with a real key: the log-sum-exp is an ordinary number
+    assert torch.allclose(lse.view(B, H, Lq)[part.cuda()], lref[part.cuda()], rtol=1e-4, atol=1e-4)
+    assert bool((lse.view(B, H, Lq)[B - 1] < -1e37).all())     # every key padded: ~ -finfo.max, recognised by the backward kernels
+    dq = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    dk = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+    dv = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+    L.call("vpf_attention_bwd_pad", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
+           dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"), pad8)
+    oref.backward(do16.float().view(B, Lq, H, 64).permute(0, 2, 1, 3))
+    unsplit = lambda t, Lx: t.permute(0, 2, 1, 3).reshape(B * Lx, D)
+    for name, got, ref in (("dq", dq, unsplit(qr.grad, Lq)), ("dk", dk, unsplit(kr.grad, Lkv)), ("dv", dv, unsplit(vr.grad, Lkv))):
+        assert torch.isfinite(got.float()).all(), name
+        r = rel(got.float(), ref)
+        assert r < 1.5e-2, f"{name} rel {r}"
+    # masked_fill_ overwrote the padded scores: no gradient through them
+    assert float(dq.view(B, Lq, D)[B - 1].float().abs().max()) == 0.0 and float(dk.view(B, Lkv, D)[B - 1].float().abs().max()) == 0.0
+    assert float(dk.view(B, Lkv, D)[0, Lkv - Lkv // 3:].float().abs().max()) == 0.0
+    assert float(dv.view(B, Lkv, D)[0, Lkv - Lkv // 3:].float().abs().max()) == 0.0      # p = 0 beside real keys
+    assert float(dv.view(B, Lkv, D)[B - 1].float().abs().max()) > 0.0                    # uniform attention still feeds v
+    # a NULL mask is refused (the unmasked entry points exist for that), and an all-zero mask reproduces the unmasked kernels bit for bit
+    o2 = torch.empty_like(o); lse2 = torch.empty_like(lse)
+    with pytest.raises(L.VpfError):
+        L.call("vpf_attention_fwd_pad", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o2, D, lse2, None)
+    L.call("vpf_attention_fwd_pad", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o2, D, lse2, torch.zeros_like(pad8))
+    o3 = torch.empty_like(o); lse3 = torch.empty_like(lse)
+    ops_res = L.debug_get("attn_resident")
+    L.debug_set("attn_resident", 0)                           # (the masked path never takes the LDS-resident self-attention kernels)
+    try:
+        L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o3, D, lse3)
+    finally:
+        L.debug_set("attn_resident", ops_res)
+    assert torch.equal(o2, o3) and torch.equal(lse2, lse3)
+
+
 def test_attention_strided_qkv_views():
     """q/k/v as column slices of one [M,3D] buffer (how the fused QKV projection hands them over)."""
     from vipformer_amd import _lib as L

@@ -264,3 +264,52 @@ def test_two_cross_attention_layers_vs_reference():
     with torch.no_grad():
         f, bb = O.pc_forward(sd, pts, start, arch, False)
     _close(f, g["pc_eval_feats"], 1e-4, 1e-4); _close(bb, g["pc_eval_backbone"], 1e-4, 1e-4)
+
+
+def _padmask_state(g, prefix, seed):
+    """State dict of one pad_mask fixture module: the key shapes are those of its stored gradients (the modules hold no buffers)."""
+    ks = [(k[len(prefix):], tuple(g[k].shape)) for k in g.files if k.startswith(prefix)]
+    return Hh.synth_state_dict(ks, seed, alias_ca=False), [k for k, _ in ks]
+
+
+def test_pad_mask_vs_reference():
+    """Key padding mask (partseg.py:53-86, 111-116, 138-141, 314-335; fixture: make_golden.py make_padmask): a cross-attention layer,
+    a self-attention and a whole Encoder with pad_mask -- ragged lengths, a scattered mask and a batch row whose keys are ALL padded
+    (uniform attention) -- outputs and every gradient of a linear loss against the reference run."""
+    c = Hh.padmask_inputs()
+    g = Hh.golden("padmask.npz")
+    arch = O.Arch(D=c["D"], H=c["H"], S=2, MR=2, atten_drop=0.0, mlp_drop=0.0)
+    off = O.Masks("off")
+    # (1) cross-attention layer
+    sd, names = _padmask_state(g, "ca_g.", 910)
+    sd = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    xq, xkv = c["xq"].clone().requires_grad_(), c["xkv"].clone().requires_grad_()
+    y = O.ca_layer(sd, "", xq, xkv, arch, off, "ca", c["pad"])
+    (y * c["R"]).sum().backward()
+    _close(y.detach(), g["ca_out"], 1e-4, 1e-4); _close(xq.grad, g["ca_dxq"], 1e-4, 2e-3); _close(xkv.grad, g["ca_dxkv"], 1e-4, 2e-3)
+    for k in names:
+        _close(sd[k].grad, g["ca_g." + k], 1e-4, 2e-3)
+    assert float(xkv.grad[2].abs().max()) > 0.0           # the all-padded row still feeds v (uniform attention) ...
+    # (2) self-attention with a mask over its own tokens
+    sd, names = _padmask_state(g, "sa_g.", 920)
+    sd = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    x = c["xq"].clone().requires_grad_()
+    n = torch.nn.functional.layer_norm(x, (c["D"],), sd["norm.weight"], sd["norm.bias"], 1e-5)
+    y = O.mha(sd, "attention.", n, n, c["H"], 0.0, off, "sa", c["pad_self"])
+    (y * c["R"]).sum().backward()
+    _close(y.detach(), g["sa_out"], 1e-4, 1e-4); _close(x.grad, g["sa_dx"], 1e-4, 2e-3)
+    for k in names:
+        _close(sd[k].grad, g["sa_g." + k], 1e-4, 2e-3)
+    # (3) Encoder.forward(..., pad_mask): the mask reaches the cross-attention layer only
+    sd = Hh.synth_state_dict(Hh.load_keyshapes("keys_enc_padmask.json"), 930)
+    sd = {k: (v.clone().requires_grad_() if "cross_attn_1." not in k else v) for k, v in sd.items()}
+    for k in list(sd):
+        if "cross_attn_1." in k:
+            sd[k] = sd[k.replace("cross_attn_1.", "cross_attn_n.")]
+    tok, kv = c["xq"].clone().requires_grad_(), c["xkv"].clone().requires_grad_()
+    y, _ = O.encoder(sd, "", tok, c["pos"], kv, arch, off, (), c["pad"])
+    (y * c["R"]).sum().backward()
+    _close(y.detach(), g["enc_out"], 1e-4, 1e-4); _close(tok.grad, g["enc_dtok"], 1e-4, 2e-3); _close(kv.grad, g["enc_dkv"], 1e-4, 2e-3)
+    for k in g.files:
+        if k.startswith("enc_g."):
+            _close(sd[k[6:]].grad, g[k], 1e-4, 2e-3)

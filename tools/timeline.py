@@ -1,22 +1,53 @@
 #!/usr/bin/env python3
-"""coarse per-queue timeline of the last full step in a rocprofv3 kernel trace of bench.py: tools/timeline.py <trace.csv> [window_us=400]"""
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-W = float(sys.argv[2]) * 1e3 if len(sys.argv) > 2 else 400e3
-ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"], r["Kernel_Name"]) for r in rows)
-starts = [i for i, k in enumerate(ks) if "fps_kernel" in k[3]]
-seg = ks[starts[-2]:starts[-1]]
-t0 = seg[0][0]
-n = int((seg[-1][1] - t0) / W) + 1
-for w in range(n):
-    a = t0 + w * W; b = a + W
-    d = collections.defaultdict(float); names = collections.defaultdict(collections.Counter)
-    for s, e, q, nm in seg:
-        o = max(0, min(e, b) - max(s, a))
-        if o > 0:
-            d[q] += o; names[q][nm.split('(')[0].replace('void ', '')[:28]] += o
-    line = f"{w*W/1e3:6.0f}us: "
-    for q in sorted(d):
-        top = ", ".join(f"{k}:{v/1e3:.0f}" for k, v in names[q].most_common(3))
-        line += f" q{q} {d[q]/1e3:4.0f} [{top}]"
-    print(line[:250])
+"""One steady-state step of a rocprofv3 --kernel-trace as a timeline: every dispatch with its start (us from the step's first
+kernel), duration, queue, and the number of kernels running at its start; then the busy / idle summary.
+
+    tools/timeline.py <kernel_trace.csv> [step_from_the_end=2] [--gaps-only]
+
+A step = the dispatches between two adamw_kernel launches.  "idle" = no kernel of this process running; "solo" = exactly one.
+"""
+import csv
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
+    depth, out = 0, []
+    for ch in name:
+        if ch == "(" and depth == 0:
+            break
+        out.append(ch)
+        depth += (ch == "<") - (ch == ">")
+    return "".join(out).strip()[:58]
+
+
+def main():
+    rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+    back = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 2
+    marks = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]).startswith("adamw_kernel")]
+    step = rows[marks[-1 - back] + 1:marks[-back] + 1]
+    t0 = int(step[0]["Start_Timestamp"])
+    ev = [((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3, r.get("Queue_Id", "?"), short(r["Kernel_Name"])) for r in step]
+    queues = {q: i for i, q in enumerate(sorted({e[2] for e in ev}))}
+    end = max(e[1] for e in ev)
+    # sweep
+    pts = sorted([(s, 1) for s, _, _, _ in ev] + [(e, -1) for _, e, _, _ in ev])
+    busy = {0: 0.0, 1: 0.0, 2: 0.0}
+    n, last = 0, 0.0
+    gaps = []
+    for t, d in pts:
+        busy[min(n, 2)] += t - last
+        if n == 0 and t - last > 1.0:
+            gaps.append((last, t))
+        last = t; n += d
+    if "--gaps-only" not in sys.argv:
+        for s, e, q, k in ev:
+            conc = sum(1 for s2, e2, _, _ in ev if s2 <= s < e2) - 1
+            print(f"{s:8.1f} {e - s:7.1f}  q{queues[q]}  +{conc}  {k}")
+    print(f"# step {end:.1f} us: idle {busy[0]:.1f}  solo {busy[1]:.1f}  overlapped {busy[2]:.1f}; {len(ev)} dispatches, sum of durations {sum(e - s for s, e, _, _ in ev):.1f}")
+    print("# idle gaps > 1 us:", " ".join(f"{a:.0f}-{b:.0f}" for a, b in gaps))
+
+
+if __name__ == "__main__":
+    main()

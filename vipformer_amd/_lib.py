@@ -101,6 +101,8 @@ SIGS = {
     "vpf_rowsum_mod_f32": [VP, L_, I, I, VP, VP],
     "vpf_attention_fwd": [VP, L_, VP, L_, VP, L_, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, VP],
     "vpf_attention_bwd": [VP, L_, VP, L_, VP, L_, VP, L_, VP, L_, VP, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, L_, VP, L_, VP, VP],
+    "vpf_attention_fwd_pad": [VP, L_, VP, L_, VP, L_, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, VP, VP],
+    "vpf_attention_bwd_pad": [VP, L_, VP, L_, VP, L_, VP, L_, VP, L_, VP, I, I, I, I, I, F, F, VP, U32, VP, L_, VP, L_, VP, L_, VP, VP, VP],
     "vpf_adapter_front_fwd": [VP, L_, I, VP, VP, VP, VP, VP, VP],
     "vpf_adapter_front_bwd": [VP, VP, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, L_, VP],
     "vpf_smallk_fwd": [VP, L_, I, VP, VP, I, I, VP, VP],

@@ -41,7 +41,15 @@ struct AttnArgs {
     // backward
     const bf16_t* dO; long lddo;
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; long lddq, lddk, lddv;
+    // optional key padding mask [B, Lkv], non-zero = padding key (partseg.py:73-76).  Only the tiled kernels read it.
+    const uint8_t* pad;
 };
+// A padded key's score is the most negative finite float, as masked_fill_(pad_mask, -finfo.max) leaves it: exp() of it is 0 beside any
+// real key, and a row whose keys are ALL padded comes out uniform over its Lkv keys.  Such a row's log-sum-exp (~ -2.4e38) cannot carry
+// log(Lkv) any more: the backward kernels recognise it by PAD_ROW_LSE2 and take p = 1 / Lkv.  No gradient reaches a padded score
+// (masked_fill_ overwrote it): dS = 0 there, dV still receives p * dO.
+#define PAD_SCORE (-3.402823466e+38f)
+#define PAD_ROW_LSE2 (-1.0e30f)
 
 __device__ __forceinline__ s16x4_t lds_tr16(const bf16_t* p)
 {
@@ -147,6 +155,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
     const bool drop = a.p > 0.f;
     const uint64_t rbase = ((uint64_t)bh * a.Lq + (uint64_t)(qok ? q : 0)) * (uint64_t)a.Lkv;
+    const uint8_t* padrow = a.pad ? a.pad + (size_t)b * a.Lkv : nullptr;
 
     uint4 rk[MAXC], rv[MAXC];
     const int nt = (a.Lkv + FWD_KT - 1) / FWD_KT;
@@ -179,6 +188,15 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
                 const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
                 s[r] = kv < a.Lkv ? s[r] * c : -INFINITY;
                 tmax = fmaxf(tmax, s[r]);
+            }
+            if (padrow) {                              // (block-uniform; the unmasked path is untouched)
+                tmax = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    if (kv < a.Lkv && padrow[kv]) s[r] = PAD_SCORE;
+                    tmax = fmaxf(tmax, s[r]);
+                }
             }
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float mn = fmaxf(m, tmax);           // finite: every sub-tile has >= 1 valid key
@@ -396,13 +414,14 @@ static int check_common(const AttnArgs& a)
     return VPF_OK;
 }
 
-extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, int B, int H,
-                                 int Lq, int Lkv, int head_dim, float scale, float dropout_p, const uint32_t* rng_state,
-                                 uint32_t site, void* out, long ldo, float* lse, void* stream)
+static int attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, int B, int H,
+                         int Lq, int Lkv, int head_dim, float scale, float dropout_p, const uint32_t* rng_state,
+                         uint32_t site, void* out, long ldo, float* lse, const uint8_t* pad, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (head_dim != DH) return VPF_ERR_UNSUPPORTED;
     AttnArgs a = {};
+    a.pad = pad;
     a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.O = (bf16_t*)out; a.ldo = ldo; a.LSE = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
     a.rng = rng_state; a.site = site; a.p = dropout_p;
@@ -413,7 +432,7 @@ extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ld
     hipStream_t st = (hipStream_t)stream;
     const int nqb = vpf_cdiv(Lq, 32);
     const int res = vpf_debug().attn_resident;
-    if (res && Lq == Lkv && k != q) {     // self-attention with the whole head resident in LDS
+    if (res && Lq == Lkv && k != q && !pad) {     // self-attention with the whole head resident in LDS
         if (nqb == 3) return launch_res_fwd<3>(a, st);
         if (nqb == 7) return launch_res_fwd<7>(a, st);
     }
@@ -425,6 +444,19 @@ extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ld
     if (nqb == 6) return launch_fwd<6>(a, st);
     if (nqb == 7) return launch_fwd<7>(a, st);
     return launch_fwd<8>(a, st);
+}
+extern "C" int vpf_attention_fwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, int B, int H,
+                                 int Lq, int Lkv, int head_dim, float scale, float dropout_p, const uint32_t* rng_state,
+                                 uint32_t site, void* out, long ldo, float* lse, void* stream)
+{
+    return attention_fwd(q, ldq, k, ldk, v, ldv, B, H, Lq, Lkv, head_dim, scale, dropout_p, rng_state, site, out, ldo, lse, nullptr, stream);
+}
+extern "C" int vpf_attention_fwd_pad(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, int B, int H,
+                                     int Lq, int Lkv, int head_dim, float scale, float dropout_p, const uint32_t* rng_state,
+                                     uint32_t site, void* out, long ldo, float* lse, const uint8_t* pad_mask, void* stream)
+{
+    if (!pad_mask) return VPF_ERR_NULL;
+    return attention_fwd(q, ldq, k, ldk, v, ldv, B, H, Lq, Lkv, head_dim, scale, dropout_p, rng_state, site, out, ldo, lse, pad_mask, stream);
 }
 
 // =============================================================================== backward
@@ -479,6 +511,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
     const bool drop = a.p > 0.f;
     const uint64_t rbase = ((uint64_t)bh * a.Lq + (uint64_t)(qok ? q : 0)) * (uint64_t)a.Lkv;
 
+    const uint8_t* padrow = a.pad ? a.pad + (size_t)b * a.Lkv : nullptr;
+
     f32x16_t dq[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
@@ -523,6 +557,13 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
                     const float pr = ok ? vpf_exp2(s[r] * c - lse2) : 0.f;
                     const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
                     ds[r] = pr * (dp[r] * keep - delta) * a.scale;
+                }
+            }
+            if (padrow) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kvs + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                    if (kv < a.Lkv && padrow[kv]) ds[r] = 0.f;
                 }
             }
 #pragma unroll
@@ -584,6 +625,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
     const float c = a.scale * LOG2E;
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
     const bool drop = a.p > 0.f;
+    const bool padded = a.pad && kvok && a.pad[(size_t)b * a.Lkv + kv];
 
     f32x16_t dk[2], dv[2];
 #pragma unroll
@@ -665,6 +707,10 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
                 }
                 pd[r] = pr * keep;
                 ds[r] = pr * (dp[r] * keep - sL[BWD_KT + qr]) * a.scale;
+                if (padded) {             // this lane's key is padding: p = 0, or 1 / Lkv in a row whose keys are all padded; dS = 0
+                    pd[r] = (ok && sL[qr] < PAD_ROW_LSE2) ? keep / (float)a.Lkv : 0.f;
+                    ds[r] = 0.f;
+                }
             }
         }
         // dV^T[d,kv] += dO^T[d,q] . P[q,kv] ; dK^T[d,kv] += Q^T[d,q] . dS[q,kv]
@@ -1080,9 +1126,9 @@ static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
         hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ, 32>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), sizeof(bf16_t) * 2 * 2 * 32 * KLD, st, a, delta);
     }
     const int res = vpf_debug().attn_resident;
-    if (res && a.Lq <= 96 && NWK == 4)
+    if (res && !a.pad && a.Lq <= 96 && NWK == 4)
         hipLaunchKernelGGL((attn_bwd_dkv_resq_kernel<NWK, 3>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
-    else if (res && a.Lq <= 128 && NWK == 4)
+    else if (res && !a.pad && a.Lq <= 128 && NWK == 4)
         hipLaunchKernelGGL((attn_bwd_dkv_resq_kernel<NWK, 4>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
     else
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<NWK>), dim3(a.B * a.H, vpf_cdiv(a.Lkv, 32 * NWK)), dim3(NWK * 64), 0, st, a, (const float*)delta);
@@ -1100,14 +1146,15 @@ static int launch_bwd_k(const AttnArgs& a, float* delta, hipStream_t st)
     return launch_bwd<NWQ, 4>(a, delta, st);
 }
 
-extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* out,
-                                 long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
-                                 int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
-                                 void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws, void* stream)
+static int attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* out,
+                         long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
+                         int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                         void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws, const uint8_t* pad, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (head_dim != DH) return VPF_ERR_UNSUPPORTED;
     AttnArgs a = {};
+    a.pad = pad;
     a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.O = (bf16_t*)out; a.ldo = ldo; a.LSE = (float*)lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
     a.rng = rng_state; a.site = site; a.p = dropout_p;
@@ -1121,7 +1168,7 @@ extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ld
     hipStream_t st = (hipStream_t)stream;
     const int nqb = vpf_cdiv(Lq, 32);
     const int res = vpf_debug().attn_resident;
-    if (res && Lq == Lkv && k != q) {
+    if (res && Lq == Lkv && k != q && !pad) {
         if (nqb == 3) return launch_res_bwd<3>(a, delta_ws, st);
         if (nqb == 7) return launch_res_bwd<7>(a, delta_ws, st);
     }
@@ -1130,4 +1177,22 @@ extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ld
     if (nqb == 3 || nqb == 6 || nqb == 9) return launch_bwd_k<3>(a, delta_ws, st);
     if (nqb == 7) return launch_bwd_k<7>(a, delta_ws, st);
     return launch_bwd_k<4>(a, delta_ws, st);
+}
+extern "C" int vpf_attention_bwd(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* out,
+                                 long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
+                                 int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                                 void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws, void* stream)
+{
+    return attention_bwd(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, B, H, Lq, Lkv, head_dim, scale, dropout_p, rng_state, site,
+                         dq, lddq, dk, lddk, dv, lddv, delta_ws, nullptr, stream);
+}
+extern "C" int vpf_attention_bwd_pad(const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, const void* out,
+                                     long ldo, const void* dout, long lddo, const float* lse, int B, int H, int Lq, int Lkv,
+                                     int head_dim, float scale, float dropout_p, const uint32_t* rng_state, uint32_t site,
+                                     void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* delta_ws,
+                                     const uint8_t* pad_mask, void* stream)
+{
+    if (!pad_mask) return VPF_ERR_NULL;
+    return attention_bwd(q, ldq, k, ldk, v, ldv, out, ldo, dout, lddo, lse, B, H, Lq, Lkv, head_dim, scale, dropout_p, rng_state, site,
+                         dq, lddq, dk, lddk, dv, lddv, delta_ws, pad_mask, stream);
 }

@@ -52,19 +52,23 @@ class MultiHeadAttention(nn.Module):
     def _check(self, pad_mask, attn_mask):
         if attn_mask is not None:
             raise NotImplementedError("attention masks not supported yet")
-        if pad_mask is not None:
-            raise L.VpfError("pad_mask is not supported by the fused attention kernel (unused on the pre-training path)")
         qi, ki, lat, out, ph = self._dims
         if not (qi == ki == lat == out) or ph != 64:
             raise L.VpfError("fused attention needs equal q/kv/latent/output channels and head dim 64")
 
-    def _run(self, x_q, x_kv, pos, ln_q, ln_kv, residual, p_res, site_res):
+    def _run(self, x_q, x_kv, pos, ln_q, ln_kv, residual, p_res, site_res, pad_mask=None):
         cfg = dict(ln_q=ln_q, ln_kv=ln_kv, residual=residual, p_res=p_res, site_res=site_res, training=self.training)
+        if pad_mask is not None:
+            # partseg.py:54,73-76: boolean [B, Lkv], True = padding key; the kernels read it as bytes (vpf_attention_fwd_pad)
+            lkv = (x_q if x_kv is None else x_kv).shape[1]
+            if pad_mask.dim() != 2 or tuple(pad_mask.shape) != (x_q.shape[0], lkv):
+                raise L.VpfError(f"pad_mask must be [B, Lkv] = {(x_q.shape[0], lkv)}, got {tuple(pad_mask.shape)}")
+            cfg["pad_mask"] = (pad_mask != 0).to(torch.uint8).contiguous()
         return ops.AttnBlockFn.apply(x_q, pos, x_kv, self, cfg, *(list(self.parameters()) + _ln_params(ln_q, ln_kv)))
 
     def forward(self, x_q, x_kv, pad_mask=None, attn_mask=None):
         self._check(pad_mask, attn_mask)
-        return self._run(x_q, None if x_kv is x_q else x_kv, None, None, None, False, 0.0, 0)
+        return self._run(x_q, None if x_kv is x_q else x_kv, None, None, None, False, 0.0, 0, pad_mask)
 
 
 class CrossAttention(nn.Module):
@@ -84,11 +88,11 @@ class CrossAttention(nn.Module):
         x_q, x_kv = args[0], args[1]
         pad_mask = args[2] if len(args) > 2 else None
         self.attention._check(pad_mask, None)
-        return self.attention._run(x_q, x_kv, pos, self.q_norm, self.kv_norm, residual, p_res, site_res)
+        return self.attention._run(x_q, x_kv, pos, self.q_norm, self.kv_norm, residual, p_res, site_res, pad_mask)
 
     def forward(self, x_q, x_kv, pad_mask=None, attn_mask=None):
         self.attention._check(pad_mask, attn_mask)
-        return self.attention._run(x_q, x_kv, None, self.q_norm, self.kv_norm, False, 0.0, 0)
+        return self.attention._run(x_q, x_kv, None, self.q_norm, self.kv_norm, False, 0.0, 0, pad_mask)
 
 
 class SelfAttention(nn.Module):
@@ -105,11 +109,11 @@ class SelfAttention(nn.Module):
     def _fused(self, args, pos, residual, p_res, site_res):
         pad_mask = args[1] if len(args) > 1 else None
         self.attention._check(pad_mask, None)
-        return self.attention._run(args[0], None, pos, self.norm, None, residual, p_res, site_res)
+        return self.attention._run(args[0], None, pos, self.norm, None, residual, p_res, site_res, pad_mask)
 
     def forward(self, x, pad_mask=None, attn_mask=None):
         self.attention._check(pad_mask, attn_mask)
-        return self.attention._run(x, None, None, self.norm, None, False, 0.0, 0)
+        return self.attention._run(x, None, None, self.norm, None, False, 0.0, 0, pad_mask)
 
 
 class MLP(Sequential):

@@ -647,8 +647,13 @@ class AttnBlockFn(torch.autograd.Function):
         o = torch.empty(Mq, D, dtype=BF16, device=dev)
         lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
         p_att = mod.dropout.p if training else 0.0
-        L.call("vpf_attention_fwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lkv, D // H, float(mod.dp_scale), float(p_att),
-               st, mod.site_attn, o, D, lse)
+        pad = ctx.pad = cfg.get("pad_mask")
+        if pad is None:
+            L.call("vpf_attention_fwd", q, ldq, k, ldk, v, ldv, B, H, Lq, Lkv, D // H, float(mod.dp_scale), float(p_att),
+                   st, mod.site_attn, o, D, lse)
+        else:
+            L.call("vpf_attention_fwd_pad", q, ldq, k, ldk, v, ldv, B, H, Lq, Lkv, D // H, float(mod.dp_scale), float(p_att),
+                   st, mod.site_attn, o, D, lse, pad)
         wo16 = shadow([mod.o_proj.weight])
         residual = cfg["residual"]
         p_res = cfg["p_res"] if training else 0.0
@@ -695,9 +700,14 @@ class AttnBlockFn(torch.autograd.Function):
             dkv = torch.empty(Mk, 2 * D, dtype=BF16, device=dev)
             q, k, v, ldq, ldk, ldv = qkv, kv, kv[:, D:], D, 2 * D, 2 * D
             dk, dv, lddq, lddk, lddv = dkv, dkv[:, D:], D, 2 * D, 2 * D
-        L.call("vpf_attention_bwd", q, ldq, k, ldk, v, ldv, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(mod.dp_scale),
-               float(p_att), ctx.rng_st, mod.site_attn, dq, lddq, dk, lddk, dv, lddv,
-               torch.empty(B * H * Lq, dtype=F32, device=dev))
+        if ctx.pad is None:
+            L.call("vpf_attention_bwd", q, ldq, k, ldk, v, ldv, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(mod.dp_scale),
+                   float(p_att), ctx.rng_st, mod.site_attn, dq, lddq, dk, lddk, dv, lddv,
+                   torch.empty(B * H * Lq, dtype=F32, device=dev))
+        else:
+            L.call("vpf_attention_bwd_pad", q, ldq, k, ldk, v, ldv, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(mod.dp_scale),
+                   float(p_att), ctx.rng_st, mod.site_attn, dq, lddq, dk, lddk, dv, lddv,
+                   torch.empty(B * H * Lq, dtype=F32, device=dev), ctx.pad)
         dxkv = None
         if is_self:
             wg.add(dqkv, nq, 3 * D, D, gW)
