@@ -153,6 +153,84 @@ def satail():
             print(f"   alone on a CU: median {dur[alone].median():.1f} us ({len(alone)}); sharing a CU: median {dur[shared].median():.1f} us ({len(shared)})")
 
 
+def satail2():
+    """Two encoder-layer tails side by side, as the step runs them: the point-cloud shape (128 x 96 tokens) on one stream and the image
+    shape (64 x 196) on another, six launches each, captured into ONE hipGraph and replayed -- with the round-2 kernels (one
+    workgroup per CU by LDS) and with the round-3 row-block kernels in every geometry (VPF_SA_WG2 / VPF_SA_RB as debug knobs).
+    Answers whether workgroups of two concurrent launches sharing CUs buy what the stand-alone numbers promise."""
+    import torch.nn as nn
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    D, H = 256, 4
+    shapes = [(128, 96), (64, 196)]
+    sets = []
+    for B, G in shapes:
+        M = B * G
+        layers = nn.ModuleList([SelfAttentionLayer(H, D, 2, 0.0, 0.1, 0.5) for _ in range(2)]).cuda()
+        layers.train()
+        blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
+        packed = ops._pack_blocks(blocks, layers[0], "cuda")
+        base = torch.randn(M, D, device="cuda"); pos = torch.randn(G, D, device="cuda")
+        o = torch.randn(M, D, device="cuda").to(torch.bfloat16)
+        lse = torch.zeros(B * H * G, device="cuda")
+        sets.append((B, G, M, layers, packed, base, pos, o, lse))
+    st = ops.rng.state("cuda")
+
+    def tail(s):
+        B, G, M, layers, packed, base, pos, o, lse = s
+        att, mlp = layers[0][0].module.attention, layers[0][1].module
+        nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
+        return ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, G, "cuda")
+
+    def run(which, n=6):
+        keep = []
+        main = torch.cuda.current_stream()
+        side = [torch.cuda.Stream() for _ in which]
+        for sd in side:
+            sd.wait_stream(main)
+        for sd, w in zip(side, which):
+            with torch.cuda.stream(sd):
+                for _ in range(n):
+                    keep.append(tail(sets[w]))
+        for sd in side:
+            main.wait_stream(sd)
+        return keep
+
+    def timed(which, label):
+        run(which); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        cs = torch.cuda.Stream()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            with torch.cuda.graph(g, stream=cs):
+                keep = run(which)
+        torch.cuda.current_stream().wait_stream(cs)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        print(f"   {label:34s} {us:8.1f} us per graph = {us / 6:6.1f} us per layer slot")
+        del keep
+        return us
+
+    for name, wg2, rb in (("round-2 kernels (1 WG/CU)", 0, 0), ("sa_rows <2,1> 64 tok, 76 KB", 1, 2), ("sa_rows <1,1> 32 tok cut to 2/CU", 1, 0),
+                          ("sa_rows <1,1> 32 tok whole", 1, 1), ("sa_rows <1,2> 64 tok 16 waves", 1, 12)):
+        L.debug_set("sa_wg2", wg2); L.debug_set("sa_rb", rb)
+        print(name)
+        a = timed([0], "pc alone (6 launches)")
+        b = timed([1], "img alone (6 launches)")
+        c = timed([0, 1], "pc || img (two streams)")
+        print(f"   -> side by side / (pc + img alone) = {c / (a + b):.3f}")
+    L.debug_set("sa_wg2", 0); L.debug_set("sa_rb", 0)
+
+
 def wgroup():
     """the grouped weight-gradient launch of one encoder layer (4 problems, M = 12288 tokens)"""
     from vipformer_amd import ops

@@ -24,10 +24,13 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-#ifndef LDS_PAD_TR
-#define LDS_PAD_TR 8
-#endif
-#define LDS_PAD 8   // bf16 elements (16 B) of row padding (K-major tiles); LDS_PAD_TR for K-strided tiles
+#define LDS_PAD 8   // bf16 elements (16 B) of row padding of a K-major tile: 16-byte fragment reads of 32 rows then touch every bank once
+// K-strided tiles ([BK][ROWS], read with ds_read_b64_tr_b16) carry NO padding: the transposing read addresses 4 consecutive k rows x
+// (2 x 16 rows) per 32-lane half, and a row pitch of ROWS * 2 bytes = a multiple of 256 B puts those 4 k rows on the same banks; a
+// pitch of ROWS + 8 elements (rounds 1 - 2) spread them by 4 banks where each needs 16: every transposing read took 8 LDS cycles
+// instead of 2 (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.60 on the grouped weight gradient, profiles/r03_step_issue.json; the
+// layout search is tools/lds_banks.py).  Instead the 32-row column blocks of k row k are XOR-permuted by k's low bits (tr_swz):
+// 16-byte staging stores stay contiguous, the four k rows of a read land on four different 64-byte bank groups, nothing is padded.
 
 enum {
     EPI_STORE = 0,       // C = acc (+bias)            -> bf16 or f32
@@ -84,8 +87,16 @@ __device__ __forceinline__ int gtid() { return threadIdx.x & 255; }
 // K-major operand tile: LDS [ROWS][BK + pad]; K-strided operand tile: LDS [BK][ROWS + pad].
 template <int ROWS, bool TR, int BK>
 struct TileCfg {
-    static constexpr int LD = TR ? (ROWS + LDS_PAD_TR) : (BK + LDS_PAD);
+    static_assert(!TR || ROWS == 32 || ROWS == 64 || ROWS % 128 == 0, "tr_swz permutes whole 32-row blocks inside 64 or 128 rows");
+    static constexpr int LD = TR ? ROWS : (BK + LDS_PAD);
     static constexpr int ELEMS = TR ? BK * LD : ROWS * LD;
+    // column of element (k, col) inside k row k of a K-strided tile
+    static __device__ __forceinline__ int tr_swz(int k, int col)
+    {
+        if constexpr (ROWS >= 128) return col ^ ((k & 3) << 5);
+        else if constexpr (ROWS == 64) return col ^ ((k & 2) << 4);
+        else return col;
+    }
     static constexpr int CHUNKS = ROWS * BK / 8;          // 16-byte chunks per tile
     static constexpr int PER_THREAD = (CHUNKS + 255) / 256;
 };
@@ -163,7 +174,7 @@ __device__ __forceinline__ void tile_store(bf16_t* __restrict__ S, const uint4 (
         if (c < Cfg::CHUNKS) {
             int off;
             if (!TR) { const int row = c / (BK / 8), kc = c % (BK / 8); off = row * Cfg::LD + kc * 8; }
-            else { const int krow = c / (ROWS / 8), rc = c % (ROWS / 8); off = krow * Cfg::LD + rc * 8; }
+            else { const int krow = c / (ROWS / 8), rc = c % (ROWS / 8); off = krow * Cfg::LD + Cfg::tr_swz(krow, rc * 8); }
             *reinterpret_cast<uint4*>(S + off) = regs[i];
         }
     }
@@ -184,7 +195,7 @@ __device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int 
         // columns 4p..4p+3; lane i receives column i of the 4 rows.
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
         const int h = g >> 1, roff = 16 * (g & 1);
-        const bf16_t* a0 = S + (s * 16 + 8 * h + q) * Cfg::LD + row0 + roff + 4 * p;
+        const bf16_t* a0 = S + (s * 16 + 8 * h + q) * Cfg::LD + Cfg::tr_swz(q, row0 + roff + 4 * p);      // (k & 3 = q; k + 4 swizzles alike)
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * Cfg::LD));
         typedef __attribute__((ext_vector_type(8))) short s16x8_t;
