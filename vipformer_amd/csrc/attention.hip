@@ -434,6 +434,7 @@ static int attention_fwd(const void* q, long ldq, const void* k, long ldk, const
     const int res = vpf_debug().attn_resident;
     if (res && Lq == Lkv && k != q && !pad) {     // self-attention with the whole head resident in LDS
         if (nqb == 3) return launch_res_fwd<3>(a, st);
+        if (nqb == 4) return launch_res_fwd<4>(a, st);       // 128 latents: BASELINE configs 3 and 4
         if (nqb == 7) return launch_res_fwd<7>(a, st);
     }
     if (nqb <= 1) return launch_fwd<1>(a, st);
@@ -1170,6 +1171,7 @@ static int attention_bwd(const void* q, long ldq, const void* k, long ldk, const
     const int res = vpf_debug().attn_resident;
     if (res && Lq == Lkv && k != q && !pad) {
         if (nqb == 3) return launch_res_bwd<3>(a, delta_ws, st);
+        if (nqb == 4) return launch_res_bwd<4>(a, delta_ws, st);
         if (nqb == 7) return launch_res_bwd<7>(a, delta_ws, st);
     }
     if (nqb <= 1) return launch_bwd_k<1>(a, delta_ws, st);
