@@ -609,6 +609,53 @@ def test_sa_rows_bwd_equals_the_one_per_cu_kernels_bitwise(M, with_dsum, dsum_in
         assert rel(res[1][k], res[0][k]) < 1e-5, (k, rel(res[1][k], res[0][k]))
 
 
+@pytest.mark.parametrize("B,N", [(8, 1024), (3, 333)])
+def test_adapter_kv_bwd_rows_kernel_equals_the_round2_kernel_bitwise(B, N):
+    """adapter_kv_bwd_rows_kernel (sa_rows.hip: two workgroups per CU) against adapter_kv_bwd_kernel (sa_layer.hip, VPF_SA_WG2 bit 2)
+    on the operands a real AdapterKVFn forward saved (ragged last block included): dxkv, da1 and the kv LayerNorm's
+    parameter-gradient partial rows must be BIT-identical -- same arithmetic, same rounding points, same 64-token grouping."""
+    from vipformer_amd import _lib, ops
+    from vipformer_amd.model.pointcloud import PointCloudInputAdapter
+    from vipformer_amd.model.pointcloud.partseg import CrossAttention
+    D = 256
+    torch.manual_seed(11)
+    adapter = PointCloudInputAdapter((N, 3), D).cuda()
+    cross = CrossAttention(4, D, D, D, 0.1).cuda()
+    with torch.no_grad():
+        cross.kv_norm.weight.copy_(rnd(7, D) * 0.2 + 1.0)
+    params = list(adapter.parameters()) + list(cross.kv_norm.parameters()) + [cross.attention.k_proj.weight, cross.attention.v_proj.weight]
+    ops.clear_managed_shadows()
+    kv = ops.AdapterKVFn.apply(rnd(1, B, N, 3) * 0.5, adapter, cross, *params)
+    x, a1, xkv, mk, rk, nk = kv.grad_fn.saved_tensors
+    pk = adapter._vpf_packed_kv
+    M, n2, nkv = B * N, D * 64, 2 * D * D
+    nwg = (M + 63) // 64
+    dkv = bf(rnd(2, M, 2 * D, scale=0.1))
+
+    def run(bit):
+        out = dict(dxkv=torch.zeros(M, D, dtype=torch.bfloat16, device="cuda"), da1=torch.zeros(M, 64, dtype=torch.bfloat16, device="cuda"),
+                   pg=torch.zeros(nwg, 2 * D, device="cuda"))
+        a = _lib.AdapterKvBwd()
+        a.M, a.C, a.D = M, 3, D
+        a.dkv, a.WkvT, a.xkv, a.mean, a.rstd, a.lnkv_g = dkv.data_ptr(), pk[2 * n2 + nkv:].data_ptr(), xkv.data_ptr(), mk.data_ptr(), rk.data_ptr(), cross.kv_norm.weight.data.data_ptr()
+        a.W2T = pk[n2 + nkv:].data_ptr()
+        a.dxkv, a.da1, a.pgrad_kv = out["dxkv"].data_ptr(), out["da1"].data_ptr(), out["pg"].data_ptr()
+        _lib.debug_set("sa_wg2", bit)
+        try:
+            _lib.call_struct("vpf_adapter_kv_bwd", a)
+            torch.cuda.synchronize()
+        finally:
+            _lib.debug_set("sa_wg2", 0)
+        return out
+
+    old, new, again = run(4), run(0), run(0)
+    assert float(old["dxkv"].float().abs().max()) > 0 and float(old["da1"].float().abs().max()) > 0
+    for k in ("dxkv", "da1", "pg"):
+        assert torch.equal(old[k], new[k]), (k, rel(new[k], old[k]))
+        assert torch.equal(new[k], again[k]), k
+    ops.clear_managed_shadows()
+
+
 @pytest.mark.parametrize("B,G", [(128, 96), (3, 50)])
 def test_ca_front_kernel_vs_the_separate_kernels(B, G):
     """vpf_ca_front_fwd (position MLP + tokens + pos + q_norm + q projection in one row-block kernel) against the kernels it replaces

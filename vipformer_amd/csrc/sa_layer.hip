@@ -1787,6 +1787,7 @@ extern "C" int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* args, void* stream)
     if (!a.dkv || !a.WkvT || !a.xkv || !a.mean || !a.rstd || !a.lnkv_g || !a.W2T || !a.dxkv || !a.da1 || !a.pgrad_kv) return VPF_ERR_NULL;
     if (a.M <= 0) return VPF_ERR_BADSHAPE;
     if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
+    if (!(vpf_debug().sa_wg2 & 4)) return sa_rows_adapter_kv_bwd_launch(a, (hipStream_t)stream);      // bit 2 set: the round-2 kernel below
     constexpr int TOK = 64;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2;
     static VpfPerDevice attr_dev; bool& attr = attr_dev();

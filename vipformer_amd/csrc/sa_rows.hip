@@ -717,7 +717,9 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) ca_front_fwd_kernel(VpfCaFro
 // LayerNorm backward in place on the accumulator tile: acc = dL/dy -> dL/dx; x = the forward input of the LayerNorm in the same
 // layout (becomes x-hat).  The per-channel parameter gradients of this wave's tokens go to pgrad[0 .. D) (dgamma) / pgrad[D .. 2D)
 // (dbeta).  Identical arithmetic to sa_layernorm_bwd of sa_layer.hip.
-template <int D, int RB>
+// EARLY: the parameter-gradient sums of each channel group are folded over the lanes and written as soon as they exist (8 live
+// registers instead of 32 across the exchange barrier; same sums, same order).
+template <int D, int RB, bool EARLY = false>
 __device__ __forceinline__ void layernorm_bwd(f32x16_t (&acc)[RB], f32x16_t (&x)[RB], const float* __restrict__ mean, const float* __restrict__ rstd,
                                               const float* __restrict__ gamma, float* sStat2, float* __restrict__ pgrad, int nvalid)
 {
@@ -756,6 +758,19 @@ __device__ __forceinline__ void layernorm_bwd(f32x16_t (&acc)[RB], f32x16_t (&x)
                 acc[i][4 * g + q] = gy;
                 x[i][4 * g + q] = xn;
             }
+        if constexpr (EARLY) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = dgam[g][q], b = dbet[g][q];
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (t == 0) {
+                    const int c = 32 * cw + 8 * g + 4 * hl + q;
+                    pgrad[c] = a;
+                    pgrad[D + c] = b;
+                }
+            }
+        }
     }
     // per-token sums over the channels: lane ^ 32, then the waves that share the token
 #pragma unroll
@@ -783,6 +798,7 @@ __device__ __forceinline__ void layernorm_bwd(f32x16_t (&acc)[RB], f32x16_t (&x)
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][4 * g + q] = rs[i] * (acc[i][4 * g + q] - s1[i] - x[i][4 * g + q] * s2[i]);
     // parameter gradients: sum over this wave's tokens = over the 32 lanes of each half
+    if constexpr (!EARLY)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1076,6 +1092,119 @@ int sa_rows_bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st)
     if (a.D == 256) return bwd_qkv_launch<256, 1, 2, 4>(a, st);
     if (a.D == 384) return vpf_debug().sa_rb == 2 ? bwd_qkv_launch<384, 2, 1, 3>(a, st) : bwd_qkv_launch<384, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
+}
+
+// ================================================================================================ K / V producer, backward
+// The same chain as adapter_kv_bwd_kernel (sa_layer.hip: dkv [M, 2D] -> . (Wk | Wv) -> kv LayerNorm' -> dxkv bf16 -> . W2 -> da1 bf16
+// [M, 64], identical arithmetic and rounding points) on this file's building blocks: two operand tiles instead of three (the LayerNorm's
+// input rows are staged into the dk tile once its product is done), a 4-deep weight ring instead of 16 k-steps of prefetch -- 128 VGPRs
+// and 72 KB of LDS, so TWO workgroups share a CU.  The launch has 2 048 workgroups (131 072 points): unlike the encoder's 192-workgroup
+// launches the second one is always there, and its products fill the first one's load / LayerNorm / store phases.
+template <int D, int RB>
+__device__ __forceinline__ void tile_to_acc(const bf16_t* sAct, int ald, f32x16_t (&x)[RB])
+{
+    const int tid_ = fresh_tid();
+    int cw, tb0;
+    who<D, RB>(tid_, cw, tb0);
+    const int lane = tid_ & 63, hl = lane >> 5, t = lane & 31;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const uint2 u = *reinterpret_cast<const uint2*>(sAct + ((tb0 + i) * 32 + t) * ald + 32 * cw + 8 * g + 4 * hl);
+            x[i][4 * g + 0] = __uint_as_float(u.x << 16);
+            x[i][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
+            x[i][4 * g + 2] = __uint_as_float(u.y << 16);
+            x[i][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
+        }
+}
+template <class C>
+__device__ __forceinline__ void rows_request(const bf16_t* __restrict__ Gu, int ld, int nvalid, uint4 (&r)[C::TOK * C::C8 / C::NT])
+{
+    const int tid_ = fresh_tid();
+#pragma unroll
+    for (int it = 0; it < C::TOK * C::C8 / C::NT; ++it) {
+        const int e = tid_ + it * C::NT, row = e / C::C8, ch = e - row * C::C8;
+        r[it] = row < nvalid ? *reinterpret_cast<const uint4*>(Gu + (unsigned)(row * ld + ch * 8)) : make_uint4(0, 0, 0, 0);
+    }
+}
+template <class C>
+__device__ __forceinline__ void rows_commit(bf16_t* sAct, const uint4 (&r)[C::TOK * C::C8 / C::NT])
+{
+    const int tid_ = fresh_tid();
+#pragma unroll
+    for (int it = 0; it < C::TOK * C::C8 / C::NT; ++it) {
+        const int e = tid_ + it * C::NT, row = e / C::C8, ch = e - row * C::C8;
+        *reinterpret_cast<uint4*>(sAct + row * C::ALD + ch * 8) = r[it];
+    }
+}
+template <int D, int RB, int TH, int MINW>
+__global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_bwd_rows_kernel(VpfAdapterKvBwd a)
+{
+    using C = Cfg<D, RB, TH>;
+    constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, PD = C::PD;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* buf0 = lds;                                               // dk rows, then the LayerNorm input rows, then the da1 slices
+    bf16_t* buf1 = lds + C::TILE;                                     // dv rows, then dxkv
+    float* sStat2 = reinterpret_cast<float*>(buf1 + C::TILE);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cw = wave % NWV, tb0 = (wave / NWV) * RB, th = wave / NWV;
+    const long M = a.M, m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, M - m0);
+    const bf16_t* dkv = (const bf16_t*)a.dkv + m0 * (2 * D);
+
+    WRing<PD> ring;
+    ring_fill<PD>((const bf16_t*)a.WkvT, 2 * KS, 0, cw, ring);
+    uint4 rr[TOK * C::C8 / C::NT];
+    rows_request<C>(dkv, 2 * D, nvalid, rr);
+    rows_commit<C>(buf0, rr);
+    rows_request<C>(dkv + D, 2 * D, nvalid, rr);                    // the dv rows travel while the dk rows settle
+    __syncthreads();
+    f32x16_t acc[RB];
+    zero<RB>(acc);
+    gemm_unit<RB, KS, PD>((const bf16_t*)a.WkvT, 2 * KS, 0, cw, buf0, ALD, tb0, acc, ring);
+    ring_fill<PD>((const bf16_t*)a.WkvT, 2 * KS, KS, cw, ring);
+    rows_commit<C>(buf1, rr);
+    rows_request<C>((const bf16_t*)a.xkv + m0 * D, D, nvalid, rr);  // the LayerNorm's input rows, behind the second product
+    __syncthreads();                                                  // (every wave is done with the dk tile)
+    gemm_unit<RB, KS, PD>((const bf16_t*)a.WkvT, 2 * KS, KS, cw, buf1, ALD, tb0, acc, ring);
+    rows_commit<C>(buf0, rr);
+    // the unfused path stores dnk as bf16 before the LayerNorm backward: round the same way
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = bf16_to_f32(f32_to_bf16(acc[i][r]));
+    __syncthreads();
+    f32x16_t xr[RB];
+    tile_to_acc<D, RB>(buf0, ALD, xr);
+    layernorm_bwd<D, RB, true>(acc, xr, a.mean + m0, a.rstd + m0, a.lnkv_g, sStat2, a.pgrad_kv + ((size_t)blockIdx.x * TH + th) * 2 * D, nvalid);
+    // (the barrier inside: every wave has finished the dv tile and read its x rows)
+    if (cw < 2) ring_fill<PD>((const bf16_t*)a.W2T, KS, 0, cw, ring);      // (not earlier: 16 more live registers across the LayerNorm spill)
+    acc_to_tile<D, RB>(acc, buf1, ALD);
+    __syncthreads();
+    tile_store_rows<C>(buf1, (bf16_t*)a.dxkv + m0 * D, D, nvalid);
+    // ---- da1 = dxkv . W2 (64 hidden channels: the waves of channel blocks 0 and 1), bf16 like the unfused dgrad output
+    if (cw < 2) {
+        zero<RB>(acc);
+        gemm_unit<RB, KS, PD>((const bf16_t*)a.W2T, KS, 0, cw, buf1, ALD, tb0, acc, ring);
+        bf16_t* slice = buf0 + wave * (RB * 1024);                   // wave-private; the x rows are in registers since the barriers above
+        acc_to_slice_bf16<RB>(slice, acc);
+        slice_bf16_store_rows<RB>(slice, (bf16_t*)a.da1 + (m0 + tb0 * 32) * 64 + 32 * cw, 64, nvalid - tb0 * 32);
+    }
+}
+int sa_rows_adapter_kv_bwd_launch(const VpfAdapterKvBwd& a, hipStream_t st)
+{
+    if (a.D != 256) return VPF_ERR_UNSUPPORTED;
+    using C = Cfg<256, 2, 1>;
+    const size_t lds = (size_t)2 * C::TILE * 2 + (size_t)C::TOK * C::NWV * 8;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)adapter_kv_bwd_rows_kernel<256, 2, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((adapter_kv_bwd_rows_kernel<256, 2, 1, 4>), dim3((int)vpf_cdiv(a.M, (long)C::TOK)), dim3(C::NT), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
 }
 
 int sa_rows_ca_front_launch(const VpfCaFront& a, hipStream_t st)
