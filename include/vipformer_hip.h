@@ -411,7 +411,7 @@ int vpf_ln_pgrad_reduce(const VpfPgradJob* host_jobs, int njobs, void* stream);
 /* number of partial rows (2 D floats each) the two backward kernels write for M tokens: size pgrad1 / pgrad2 and the reduce job with it */
 int vpf_sa_layer_pgrad_rows(long M, int D);
 /* PointCloudInputAdapter.point_mlp (classifier.py:31-36) + the cross-attention kv LayerNorm and K / V projections
- * (partseg.py:48-51,100-116) in one kernel, 64 points per workgroup, D = 256.  x f32 [M,C<=8]; W1 f32 [64,C];
+ * (partseg.py:48-51,100-116) in one kernel, 64 (D = 256) or 32 (D = 384) points per workgroup.  x f32 [M,C<=8]; W1 f32 [64,C];
  * W2 = vpf_pack_wfrag of the bf16 [D,64] weight; Wkv = vpf_pack_wfrag of the bf16 [2D,D] k|v weights.
  * Outputs (all also needed by the backward pass): a1 bf16 [M,64] (hidden layer), xkv bf16 [M,D] (the per-point
  * embedding), mean / rstd f32 [M] and nk bf16 [M,D] (kv LayerNorm), kv bf16 [M,2D]. */
@@ -434,6 +434,8 @@ typedef struct VpfAdapterKvBwd {
     void* dxkv; void* da1; float* pgrad_kv;
 } VpfAdapterKvBwd;
 int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* host_args, void* stream);
+/* number of partial rows vpf_adapter_kv_bwd writes to pgrad_kv for M points (one per workgroup: 64 points at D = 256, 32 at D = 384) */
+int vpf_adapter_kv_pgrad_rows(long M, int D);
 /* ------------------------------------------------------------------ part segmentation (BASELINE config 5)
  * CrossFormer_partseg.forward partseg.py:407-470 + PointNetFeaturePropagation.forward utils.py:205-242: everything that the
  * pre-training entry points above do not already cover (the 1x1 convolutions are vpf_gemm_bf16, BatchNorm the entries above). */

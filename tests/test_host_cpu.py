@@ -49,7 +49,7 @@ def test_ctypes_table_matches_header():
                 t = p.split()[1] if p.startswith("const") else p.split()[0]
                 want.append({"int": "i", "long": "l", "float": "f", "uint32_t": "u"}[t])
         assert [kind[t] for t in sig] == want, name
-    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id", "vpf_debug_set", "vpf_debug_get", "vpf_sa_layer_pgrad_rows"}
+    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id", "vpf_debug_set", "vpf_debug_get", "vpf_sa_layer_pgrad_rows", "vpf_adapter_kv_pgrad_rows"}
     # the launch-time knobs: one struct, read by name, environment consulted once (csrc/api.hip)
     assert _lib.debug_get("knn_select") == 1 and _lib.debug_get("wgroup_cfg") == 2
     _lib.debug_set("knn_select", 0)

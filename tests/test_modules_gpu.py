@@ -512,8 +512,8 @@ def test_fused_sa_stack_matches_unfused_blocks(name):
     start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
     results = []
     variants = ((False, False, None, False), (True, False, False, False), (True, False, True, False), (True, True, True, False), (True, True, True, True), (True, True, True, 2))
-    if name != "c1":          # attention inside the layer kernel and the fused K / V producer exist at D = 256 only
-        variants = ((False, False, None, False), (True, False, True, False), (True, True, True, False), (True, True, True, True))
+    if name != "c1":          # attention inside the layer kernel exists at D = 256 only
+        variants = ((False, False, None, False), (True, False, True, False), (True, True, True, False), (True, True, True, True), (True, True, True, 2))
     for fused, fused_bwd, split, enc in variants:
         ops.clear_managed_shadows()
         ops.rng.seed(99)

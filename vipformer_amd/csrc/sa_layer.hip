@@ -1689,7 +1689,7 @@ extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
     if (!a.x || !a.W1 || !a.b1 || !a.ln_g || !a.ln_b || !a.W2 || !a.b2 || !a.lnkv_g || !a.lnkv_b || !a.Wkv || !a.a1 || !a.xkv || !a.mean ||
         !a.rstd || !a.nk || !a.kv) return VPF_ERR_NULL;
     if (a.M <= 0 || a.C <= 0 || a.C > 8) return VPF_ERR_BADSHAPE;
-    if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
+    if (a.D != SA_D) return sa_rows_adapter_kv_fwd_launch(a, (hipStream_t)stream);       // D = 384; anything else: VPF_ERR_UNSUPPORTED
     constexpr int TOK = 64;
     const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2;
     static_assert(TOK * 72 * 2 + TOK * ALD * 2 + TOK * 8 * 2 * 4 + TOK * ALD * 2 <= 80 * 1024, "two workgroups per CU");
@@ -1779,6 +1779,12 @@ __global__ void __launch_bounds__(512) adapter_kv_bwd_kernel(VpfAdapterKvBwd a)
     }
 }
 
+// rows of kv-LayerNorm parameter-gradient partials (2 D floats each) vpf_adapter_kv_bwd writes for M points
+extern "C" int vpf_adapter_kv_pgrad_rows(long M, int D)
+{
+    const int tok = D == SA_D ? 64 : sa_rows_adapter_kv_tokens(D);
+    return (int)((M + tok - 1) / tok);
+}
 extern "C" int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* args, void* stream)
 {
     (void)hipGetLastError();
@@ -1786,7 +1792,7 @@ extern "C" int vpf_adapter_kv_bwd(const VpfAdapterKvBwd* args, void* stream)
     const VpfAdapterKvBwd& a = *args;
     if (!a.dkv || !a.WkvT || !a.xkv || !a.mean || !a.rstd || !a.lnkv_g || !a.W2T || !a.dxkv || !a.da1 || !a.pgrad_kv) return VPF_ERR_NULL;
     if (a.M <= 0) return VPF_ERR_BADSHAPE;
-    if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
+    if (a.D != SA_D) return sa_rows_adapter_kv_bwd_launch(a, (hipStream_t)stream);
     if (!(vpf_debug().sa_wg2 & 4)) return sa_rows_adapter_kv_bwd_launch(a, (hipStream_t)stream);      // bit 2 set: the round-2 kernel below
     constexpr int TOK = 64;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2;

@@ -1192,8 +1192,153 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_bwd_rows_kernel(V
         slice_bf16_store_rows<RB>(slice, (bf16_t*)a.da1 + (m0 + tb0 * 32) * 64 + 32 * cw, 64, nvalid - tb0 * 32);
     }
 }
+// ================================================================================================ K / V producer, forward (any D)
+// adapter_kv_fwd_kernel of sa_layer.hip (D = 256) on this file's building blocks, for the widths it does not cover (D = 384, BASELINE
+// config 4): Linear(C, 64) + LayerNorm(64) + ReLU in VALU (8 lanes per point) -> LDS -> . W2 (K = 64) + bias, rounded to bf16 as the
+// unfused path stores it -> kv LayerNorm -> LDS -> . Wk | . Wv; a1, xkv, nk and k | v leave as whole rows.  Same arithmetic, same
+// rounding points.
+template <int D, int RB, int TH, int MINW>
+__global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_fwd_rows_kernel(VpfAdapterKv a)
+{
+    using C = Cfg<D, RB, TH>;
+    constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, PD = C::PD, A1LD = 72;
+    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    bf16_t* sA1 = lds;                                               // [TOK][A1LD] hidden layer
+    bf16_t* sX = lds + TOK * A1LD;                                   // [TOK][ALD]  per-point embedding, then the k / v halves on their way out
+    bf16_t* actA = sX + C::TILE;                                     // [TOK][ALD]  normalised embedding
+    float2* sPair = reinterpret_cast<float2*>(actA + C::TILE);       // [TOK][NWV]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cw = wave % NWV, tb0 = (wave / NWV) * RB;
+    const long m0 = (long)blockIdx.x * TOK;
+    const int nvalid = (int)min((long)TOK, a.M - m0);
+    const int Cin = a.C;
+
+    WRing<PD> ring;
+    ring_fill<PD>((const bf16_t*)a.Wkv, KS, 0, cw, ring);
+    // ---- hidden layer: thread = (token, 8 of the 64 channels); LayerNorm over the token's 8 threads (lanes ^1 ^2 ^4)
+    {
+        const int tid_ = fresh_tid();
+        for (int e = tid_; e < TOK * 8; e += C::NT) {
+            const int tok = e >> 3, cg = (e & 7) * 8;
+            const bool ok = tok < nvalid;
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = (ok && j < Cin) ? a.x[(size_t)(m0 + tok) * Cin + j] : 0.f;
+            float h[8], sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float v = a.b1[cg + k];
+                for (int j = 0; j < Cin; ++j) v += a.W1[(cg + k) * Cin + j] * xv[j];
+                h[k] = v; sum += v;
+            }
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+            const float mu = sum * (1.f / 64.f);
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { h[k] -= mu; q += h[k] * h[k]; }
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+            const float rs = rsqrtf(q * (1.f / 64.f) + 1e-5f);
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float lo = fmaxf(h[2 * k] * rs * a.ln_g[cg + 2 * k] + a.ln_b[cg + 2 * k], 0.f);
+                const float hi = fmaxf(h[2 * k + 1] * rs * a.ln_g[cg + 2 * k + 1] + a.ln_b[cg + 2 * k + 1], 0.f);
+                w[k] = pack_bf16x2(lo, hi);
+            }
+            const uint4 v4 = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint4*>(sA1 + tok * A1LD + cg) = v4;
+            if (ok) *reinterpret_cast<uint4*>((bf16_t*)a.a1 + (size_t)(m0 + tok) * 64 + cg) = v4;
+        }
+    }
+    __syncthreads();
+    // ---- per-point embedding = hidden . W2^T + b2 (K = 64: four k-steps), rounded to bf16, then the kv LayerNorm
+    f32x16_t acc[RB];
+    zero<RB>(acc);
+    {
+        const unsigned lane = fresh_tid() & 63;
+        const uint4* w0 = reinterpret_cast<const uint4*>(a.W2) + (size_t)cw * 4 * 64 + lane;
+        const bf16_t* xrow = sA1 + (tb0 * 32 + (lane & 31)) * A1LD + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, w0[ks * 64]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xrow + i * 32 * A1LD + ks * 16)), acc[i], 0, 0, 0);
+        }
+    }
+    {
+        const int lane = fresh_tid() & 63, hl = lane >> 5, t = lane & 31;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 32 * cw + 8 * g + 4 * hl;
+            const float4 b2 = *reinterpret_cast<const float4*>(a.b2 + c);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                uint2 u;
+                u.x = pack_bf16x2(acc[i][4 * g + 0] + b2.x, acc[i][4 * g + 1] + b2.y);
+                u.y = pack_bf16x2(acc[i][4 * g + 2] + b2.z, acc[i][4 * g + 3] + b2.w);
+                *reinterpret_cast<uint2*>(sX + ((tb0 + i) * 32 + t) * ALD + c) = u;
+                acc[i][4 * g + 0] = __uint_as_float(u.x << 16); acc[i][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
+                acc[i][4 * g + 2] = __uint_as_float(u.y << 16); acc[i][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
+            }
+        }
+    }
+    layernorm<D, RB>(acc, a.lnkv_g, a.lnkv_b, sPair, a.mean + m0, a.rstd + m0, nvalid);
+    acc_to_tile<D, RB>(acc, actA, ALD);
+    __syncthreads();
+    tile_store_rows<C>(sX, (bf16_t*)a.xkv + m0 * D, D, nvalid);
+    tile_store_rows<C>(actA, (bf16_t*)a.nk + m0 * D, D, nvalid);
+    // ---- K | V = normalised . Wkv^T: two D-channel halves, each staged in sX and stored as whole half rows
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        zero<RB>(acc);
+        gemm_unit<RB, KS, PD>((const bf16_t*)a.Wkv, KS, 0, part * NWV + cw, actA, ALD, tb0, acc, ring);
+        if (part == 0) ring_fill<PD>((const bf16_t*)a.Wkv, KS, 0, NWV + cw, ring);
+        __syncthreads();                                             // the row pass that read sX last is done
+        acc_to_tile<D, RB>(acc, sX, ALD);
+        __syncthreads();
+        tile_store_rows<C>(sX, (bf16_t*)a.kv + m0 * (2 * D) + part * D, 2 * D, nvalid);
+    }
+}
+template <int D, int RB, int MINW>
+static int adapter_kv_fwd_rows_launch(const VpfAdapterKv& a, hipStream_t st)
+{
+    using C = Cfg<D, RB, 1>;
+    const size_t lds = (size_t)C::TOK * 72 * 2 + (size_t)2 * C::TILE * 2 + (size_t)C::TOK * C::NWV * 8;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)adapter_kv_fwd_rows_kernel<D, RB, 1, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((adapter_kv_fwd_rows_kernel<D, RB, 1, MINW>), dim3((int)vpf_cdiv(a.M, (long)C::TOK)), dim3(C::NT), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+int sa_rows_adapter_kv_fwd_launch(const VpfAdapterKv& a, hipStream_t st)
+{
+    if (a.D == 384) return vpf_debug().sa_rb == 2 ? adapter_kv_fwd_rows_launch<384, 2, 3>(a, st) : adapter_kv_fwd_rows_launch<384, 1, 3>(a, st);
+    if (a.D == 256) return adapter_kv_fwd_rows_launch<256, 2, 4>(a, st);
+    return VPF_ERR_UNSUPPORTED;
+}
+int sa_rows_adapter_kv_tokens(int D) { return (D == 384 && vpf_debug().sa_rb != 2) ? 32 : 64; }
+
+template <int D, int RB, int MINW>
+static int adapter_kv_bwd_rows_launch(const VpfAdapterKvBwd& a, hipStream_t st)
+{
+    using C = Cfg<D, RB, 1>;
+    const size_t lds = (size_t)2 * C::TILE * 2 + (size_t)C::TOK * C::NWV * 8;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)adapter_kv_bwd_rows_kernel<D, RB, 1, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((adapter_kv_bwd_rows_kernel<D, RB, 1, MINW>), dim3((int)vpf_cdiv(a.M, (long)C::TOK)), dim3(C::NT), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
 int sa_rows_adapter_kv_bwd_launch(const VpfAdapterKvBwd& a, hipStream_t st)
 {
+    if (a.D == 384) return vpf_debug().sa_rb == 2 ? adapter_kv_bwd_rows_launch<384, 2, 3>(a, st) : adapter_kv_bwd_rows_launch<384, 1, 3>(a, st);
     if (a.D != 256) return VPF_ERR_UNSUPPORTED;
     using C = Cfg<256, 2, 1>;
     const size_t lds = (size_t)2 * C::TILE * 2 + (size_t)C::TOK * C::NWV * 8;

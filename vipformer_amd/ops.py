@@ -56,7 +56,7 @@ class OpsConfig:
         self.sa_fused_bwd = True          # backward of the stack through vpf_sa_layer_bwd_mlp / _qkv instead of the block-by-block kernels
         self.sa_fused = True              # Encoder.forward uses the one-kernel-per-layer path when the shapes allow it
         self.enc_bwd_hook = None          # schedule experiments (tools/step_timeline.py): callable(cross_attention_layer, i)
-        self.adapter_kv_fused = True      # point adapter + kv LayerNorm + K / V projections as one kernel
+        self.adapter_kv_fused = env.get("VPF_ADAPTER_KV", "1") == "1"      # point adapter + kv LayerNorm + K / V projections as one kernel
         self.adapter_kv_bwd_fused = True
         self.enc_fused = True             # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
         self.ca_front_fused = env.get("VPF_CA_FRONT", "1") == "1"     # position MLP + (tokens + pos) + q_norm + q projection of the point-cloud branch as one kernel
@@ -1410,11 +1410,11 @@ class AdapterKVFn(torch.autograd.Function):
     def forward(ctx, pts, adapter, cross, *params):
         ctx.nparams, ctx.params = len(params), params
         B, N, C = pts.shape
-        D = 256
         dev = pts.device
         x = pts.contiguous().float().view(-1, C)
         M = x.shape[0]
         l0, ln, l3 = adapter.point_mlp[0], adapter.point_mlp[1], adapter.point_mlp[3]
+        D = l3.weight.shape[0]                                                # 256, or 384 (BASELINE config 4: the row-block kernels of sa_rows.hip)
         catt, lnkv = cross.attention, cross.kv_norm
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         pack_params(qkvw)
@@ -1454,7 +1454,7 @@ class AdapterKVFn(torch.autograd.Function):
         adapter, cross = ctx.mods
         l0, ln, l3 = adapter.point_mlp[0], adapter.point_mlp[1], adapter.point_mlp[3]
         catt, lnkv = cross.attention, cross.kv_norm
-        D = 256
+        D = l3.weight.shape[0]
         M, C = x.shape
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         w16, gKV = shadow(qkvw), packed_grad(qkvw[1:])
@@ -1462,7 +1462,9 @@ class AdapterKVFn(torch.autograd.Function):
         if cfg.adapter_kv_bwd_fused:
             pk = ctx.packed
             n2, nkv = D * 64, 2 * D * D
-            nwg = (M + 63) // 64
+            fn = L.lib().vpf_adapter_kv_pgrad_rows
+            fn.argtypes, fn.restype = [ctypes.c_long, ctypes.c_int], ctypes.c_int
+            nwg = fn(M, D)
             dy16 = torch.empty(M, D, dtype=BF16, device=x.device)
             pg = torch.empty(nwg * 2 * D, dtype=F32, device=x.device)
             da = torch.empty(M, 64, dtype=BF16, device=x.device)
@@ -1477,6 +1479,7 @@ class AdapterKVFn(torch.autograd.Function):
                    grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias), ws, ws.numel())
             pj = (L.PgradJob * 32)()
             pj[0].partials, pj[0].rows, pj[0].dgamma, pj[0].dbeta = pg.data_ptr(), nwg, grad_buf(lnkv.weight).data_ptr(), grad_buf(lnkv.bias).data_ptr()
+            pj[0].D = D
             L.call_struct("vpf_ln_pgrad_reduce", pj, 1)
             wg = WgradBatch()
             wg.add(dkv, nk, 2 * D, D, gKV)
@@ -1500,7 +1503,7 @@ def adapter_kv_supported(adapter, pts) -> bool:
     if not cfg.adapter_kv_fused or pts.dim() != 3 or pts.shape[-1] > 8:
         return False
     l3 = adapter.point_mlp[3]
-    return tuple(l3.weight.shape) == (256, 64)
+    return tuple(l3.weight.shape) in ((256, 64), (384, 64))
 
 
 def encoder_fused_supported(ca, layers, x, xkv) -> bool:
