@@ -1689,7 +1689,7 @@ extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
     if (!a.x || !a.W1 || !a.b1 || !a.ln_g || !a.ln_b || !a.W2 || !a.b2 || !a.lnkv_g || !a.lnkv_b || !a.Wkv || !a.a1 || !a.xkv || !a.mean ||
         !a.rstd || !a.nk || !a.kv) return VPF_ERR_NULL;
     if (a.M <= 0 || a.C <= 0 || a.C > 8) return VPF_ERR_BADSHAPE;
-    if (a.D != SA_D) return sa_rows_adapter_kv_fwd_launch(a, (hipStream_t)stream);       // D = 384; anything else: VPF_ERR_UNSUPPORTED
+    if (a.D != SA_D || (vpf_debug().sa_wg2 & 8)) return sa_rows_adapter_kv_fwd_launch(a, (hipStream_t)stream);       // D = 384 (bit 3: D = 256 too); anything else: VPF_ERR_UNSUPPORTED
     constexpr int TOK = 64;
     const size_t lds = (size_t)TOK * 72 * 2 + (size_t)TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * ALD * 2;
     static_assert(TOK * 72 * 2 + TOK * ALD * 2 + TOK * 8 * 2 * 4 + TOK * ALD * 2 <= 80 * 1024, "two workgroups per CU");

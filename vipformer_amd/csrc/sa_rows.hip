@@ -1316,8 +1316,8 @@ static int adapter_kv_fwd_rows_launch(const VpfAdapterKv& a, hipStream_t st)
 }
 int sa_rows_adapter_kv_fwd_launch(const VpfAdapterKv& a, hipStream_t st)
 {
-    if (a.D == 384) return vpf_debug().sa_rb == 2 ? adapter_kv_fwd_rows_launch<384, 2, 3>(a, st) : adapter_kv_fwd_rows_launch<384, 1, 3>(a, st);
-    if (a.D == 256) return adapter_kv_fwd_rows_launch<256, 2, 4>(a, st);
+    if (a.D == 384) return vpf_debug().sa_rb == 2 ? adapter_kv_fwd_rows_launch<384, 2, 3>(a, st) : adapter_kv_fwd_rows_launch<384, 1, 6>(a, st);
+    if (a.D == 256) return vpf_debug().sa_rb == 2 ? adapter_kv_fwd_rows_launch<256, 2, 4>(a, st) : adapter_kv_fwd_rows_launch<256, 1, 6>(a, st);
     return VPF_ERR_UNSUPPORTED;
 }
 int sa_rows_adapter_kv_tokens(int D) { return (D == 384 && vpf_debug().sa_rb != 2) ? 32 : 64; }
