@@ -389,7 +389,12 @@ def main():
 
     torch.manual_seed(1)                                   # parser.py:17 default seed; same init on every rank
     ops.rng.seed(1234 + rank)
-    pc, im = build_models(**a, device=device)
+    drops = os.environ.get("VPF_BENCH_DROPS")              # ablation only ("0,0.5"): the line then carries config.ablation and is not the metric
+    if drops:
+        ad, md = (float(v) for v in drops.split(","))
+        pc, im = build_models(**a, atten_drop=ad, mlp_drop=md, device=device)
+    else:
+        pc, im = build_models(**a, device=device)
     pc.train(); im.train()
     tr = Pretrainer(pc, im, world_size=world, force_data_parallel=force_dp)
     tr.overlap = not args.no_overlap
@@ -591,6 +596,7 @@ def main():
             "config": {"workload": "%s, per-GPU batch %d pairs (2x%d-pt clouds + 224x224 img, patch 16), fwd+bwd+AdamW, NT-Xent IMC+CMC, "
                                    "dropout 0.1/0.5" % (NAMES[args.arch], pairs, a["N"]),
                        "global_batch": pairs * world, "parallelism": f"dp{world}" + (" (data-parallel code path forced in a one-rank group)" if force_dp else ""), "hip_graph": use_graph, "capture": capture_mode, "two_stream_overlap": tr.overlap,
+                       **({"ablation": f"dropout probabilities overridden to {drops} (VPF_BENCH_DROPS): NOT the metric's workload"} if drops else {}),
                        "ranks_seen": ranks_seen, "comm_ms": comm_ms, "comm_regions": ([n for n, _, _ in tr.regions] if tr.dp else None),
                        "last_losses": losses, "losses_finite": finite,
                        "step_tflops_algorithmic": round(value * gf / 1e3, 2),
