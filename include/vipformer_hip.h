@@ -316,8 +316,8 @@ int vpf_pretrain_loss_bwd(const float* zn, const float* inv_norm, const float* P
 int vpf_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev,
                    int advance_step, void* stream);
 
-/* Up to 8 weight-gradient GEMMs in one launch (the backward of nn.Linear, e.g. the four of a transformer layer,
- * partseg.py:48-51,194-197): dW[N,K] += dy[M,N]^T x[M,K] (bf16 operands, fp32 atomics), dbias[N] += column sums of dy
+/* Up to 32 weight-gradient GEMMs in one launch (the backward of nn.Linear: the four of a transformer layer, or -- round 3 -- those
+ * of a whole encoder stack, so that the split-K flush is paid once per stack; partseg.py:48-51,194-197): dW[N,K] += dy[M,N]^T x[M,K] (bf16 operands, fp32 atomics), dbias[N] += column sums of dy
  * (dbias may be NULL).  host_jobs is a HOST array (copied into the kernel arguments: capturable). */
 typedef struct VpfWgradJob { const void* dy; const void* x; int M, N, K; float* dW; float* dbias; } VpfWgradJob;
 /* ws (nullable): >= 4096 + 65536 * (number of workgroups, <= ~640) bytes of scratch, 16-byte aligned, whose first 4096 bytes were

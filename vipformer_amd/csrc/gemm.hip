@@ -569,15 +569,28 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 
 // Several independent split-K weight-gradient GEMMs in ONE launch (the four of a transformer layer): each of them alone
 // is a few hundred short workgroups whose ramp-up and tail dominate; together they fill the chip.
-#define GEMM_GROUP_MAX 8
-struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; int nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n; };
+// Round 3: up to 32 problems -- the weight gradients of a whole encoder stack in one launch (ops.WgradBatch): with 7 x 32 output tiles
+// two K slices per tile already give ~450 workgroups, so the split-K flush (fp32 atomics at ~1.3 TB/s, 33 MB = 23 us of a 43 us
+// one-layer launch) is paid once per stack instead of once per layer.  The kernel argument holds compact descriptors (a GemmArgs
+// per problem would not fit the 4 KB argument segment); the workgroup builds the GemmArgs of its problem in registers.
+#define GEMM_GROUP_MAX 32
+struct WgDesc {
+    const bf16_t* A; const bf16_t* B; float* C; float* dbias; float* part; int* cnt;
+    int lda, ldb, ldc, M, N, K, splitk, ntx, mode;
+};
+struct GemmGroup { WgDesc d[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; short nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n, uneven, dbg; };
 template <int TM, int TN, int WM, int WN, int BK, int PF, bool PAIR = false>
 __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(GemmGroup grp)
 {
     int p = 0;
     while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
     const int local = blockIdx.x - grp.start[p];
-    const int nx = grp.nx[p], ny = grp.ny[p], sk = PAIR ? grp.g[p].splitk / 2 : grp.g[p].splitk;      // PAIR: a workgroup = two K slices
+    const WgDesc& d = grp.d[p];
+    GemmArgs g = {};
+    g.A = d.A; g.B = d.B; g.lda = d.lda; g.ldb = d.ldb; g.M = d.M; g.N = d.N; g.K = d.K; g.splitk = d.splitk; g.mode = d.mode;
+    g.C = d.C; g.ldc = d.ldc; g.c_f32 = 1; g.dbias = d.dbias; g.group = 1; g.uneven = grp.uneven; g.dbg = grp.dbg;
+    g.part = d.part; g.cnt = d.cnt; g.ntx = d.ntx;
+    const int nx = grp.nx[p], ny = grp.ny[p], sk = PAIR ? g.splitk / 2 : g.splitk;      // PAIR: a workgroup = two K slices
     int bx, by, bz;
     if ((sk & 7) == 0 && (grp.start[p] & 7) == 0) {
         // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All output tiles
@@ -588,7 +601,7 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(Gemm
     } else {
         bx = local % nx; by = (local / nx) % ny; bz = local / (nx * ny);
     }
-    gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0, PF, PAIR>(grp.g[p], bx, by, bz);
+    gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0, PF, PAIR>(g, bx, by, bz);
 }
 template <int TM, int TN, int WM, int WN, int BK, int PF = 1, bool PAIR = false>
 static int launch_wgrad_group(const GemmGroup& grp, int nblocks, hipStream_t st)
@@ -738,7 +751,7 @@ extern "C" int vpf_gemm_bf16_fused(const void* A, int a_kstrided, long lda, int 
 }
 
 
-// dW_i[N_i,K_i] += dY_i[M_i,N_i]^T . X_i[M_i,K_i]  (+ dbias_i[N_i] += column sums of dY_i) for up to 8 problems in one launch
+// dW_i[N_i,K_i] += dY_i[M_i,N_i]^T . X_i[M_i,K_i]  (+ dbias_i[N_i] += column sums of dY_i) for up to 32 problems in one launch
 #define WGROUP_CNT_INTS 1024        // arrival counters at the head of the workspace (zeroed ONCE by the caller; the kernel re-zeroes what it used)
 extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, long ws_bytes, void* stream)
 {
@@ -759,10 +772,10 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         if (!j.dy || !j.x || !j.dW) return VPF_ERR_NULL;
         if (j.M <= 0 || j.N <= 0 || j.K <= 0) return VPF_ERR_BADSHAPE;
         if ((j.N % 8) || (j.K % 8) || ((uintptr_t)j.dy & 15) || ((uintptr_t)j.x & 15)) return VPF_ERR_BADALIGN;
-        GemmArgs& g = grp.g[i];
+        WgDesc& g = grp.d[i];
         // C[m = n_out, n = k_in] += sum over tokens: A = dY read k-strided (rows = N), B = X read k-strided (rows = K)
         g.A = (const bf16_t*)j.dy; g.B = (const bf16_t*)j.x; g.lda = j.N; g.ldb = j.K;
-        g.M = j.N; g.N = j.K; g.K = j.M; g.mode = EPI_ATOMIC; g.C = j.dW; g.ldc = j.K; g.c_f32 = 1; g.dbias = j.dbias; g.group = 1;
+        g.M = j.N; g.N = j.K; g.K = j.M; g.mode = EPI_ATOMIC; g.C = j.dW; g.ldc = j.K; g.dbias = j.dbias;
         const int nx = vpf_cdiv(g.N, tn), ny = vpf_cdiv(g.M, tm);
         // ~`target` workgroups over the whole group, every K slice at least 256 tokens deep
         long sp = target / (total_tiles > 0 ? total_tiles : 1);
@@ -771,22 +784,22 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         if (sp < 2) sp = 2;                       // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
         if (pair) sp &= ~1L;                      // whole pairs
         g.splitk = (int)sp;
-        // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at
-        // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
-        // 512 workgroups flushing together at the end (-0.035 ms/step, 15 launches)
-        g.uneven = vpf_debug().wgroup_uneven;
-        g.dbg = vpf_debug().wgroup_dbg;
-        grp.nx[i] = nx; grp.ny[i] = ny; grp.start[i] = at;
+        grp.nx[i] = (short)nx; grp.ny[i] = (short)ny; grp.start[i] = at;
         at += nx * ny * (int)(pair ? sp / 2 : sp);
     }
     grp.start[njobs] = at;
+    // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at
+    // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
+    // 512 workgroups flushing together at the end (-0.035 ms/step, 15 launches)
+    grp.uneven = vpf_debug().wgroup_uneven;
+    grp.dbg = vpf_debug().wgroup_dbg;
     hipStream_t st = (hipStream_t)stream;
     // workspace split-K (EPI_PARTIAL) when the caller handed over enough scratch: [counters | one tm x tn f32 tile per workgroup]
     if (partial && ws && total_tiles <= WGROUP_CNT_INTS && ws_bytes >= (long)(WGROUP_CNT_INTS * 4 + (size_t)at * tm * tn * 4) && !((uintptr_t)ws & 15)) {
         float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + WGROUP_CNT_INTS * 4);
         int* cnt = reinterpret_cast<int*>(ws);
         for (int i = 0; i < njobs; ++i) {
-            GemmArgs& g = grp.g[i];
+            WgDesc& g = grp.d[i];
             g.mode = EPI_PARTIAL; g.part = part + (size_t)grp.start[i] * tm * tn; g.cnt = cnt; g.ntx = grp.nx[i];
             cnt += grp.nx[i] * grp.ny[i];
         }

@@ -43,7 +43,7 @@ class OpsConfig:
     The library's own launch-time knobs live in its VpfDebug struct (``_lib.debug_get`` / ``debug_set``)."""
     __slots__ = ("wgrad_async", "wgrad_group", "wgrad_group_async", "wgrad_deterministic", "wgrad_defer", "sa_debug", "sa_split_attn",
                  "sa_fused_bwd", "sa_fused", "enc_bwd_hook", "adapter_kv_fused", "adapter_kv_bwd_fused", "enc_fused", "g2e_bn_merged",
-                 "g2e_conv1_bwd_fused", "ca_front_fused")
+                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack")
 
     def __init__(self, env=os.environ):
         self.wgrad_async = False          # weight-gradient GEMMs on a side stream: measured slower (cross-stream event cost > overlap gain)
@@ -60,6 +60,7 @@ class OpsConfig:
         self.adapter_kv_bwd_fused = True
         self.enc_fused = True             # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
         self.ca_front_fused = env.get("VPF_CA_FRONT", "1") == "1"     # position MLP + (tokens + pos) + q_norm + q projection of the point-cloud branch as one kernel
+        self.wgrad_stack = env.get("VPF_WGRAD_STACK", "1") == "1"               # the weight gradients of a whole fused encoder stack as ONE grouped launch at the end of its backward
         self.g2e_bn_merged = env.get("VPF_G2E_BN_MERGED", "1") != "0"          # BatchNorm bookkeeping of Group2Emb as single launches
         self.g2e_conv1_bwd_fused = env.get("VPF_G2E_CONV1_FUSED", "1") == "1"  # conv2 dgrad inside the first conv's backward (tests run both)
 
@@ -529,21 +530,24 @@ class WgradDeferral:
 class WgradBatch:
     """Collects linear_wgrad calls of one layer and issues them as ONE grouped launch (vpf_wgrad_group)."""
 
-    def __init__(self):
+    CAP = 32                               # GEMM_GROUP_MAX of csrc/gemm.hip
+
+    def __init__(self, cap: int = 8):
         self.jobs = []
+        self.cap = min(cap, self.CAP)      # 8: one layer's launch; 32: a whole encoder stack's (cfg.wgrad_stack)
 
     def add(self, dy16, x16, N, K, dW, dbias=None):
         if not cfg.wgrad_group:
             linear_wgrad(dy16, x16, N, K, dW, dbias)
             return
         self.jobs.append((dy16, x16, dy16.numel() // N, N, K, dW, dbias))
-        if len(self.jobs) == 8:
+        if len(self.jobs) == self.cap:
             self.flush()
 
     def flush(self):
         if not self.jobs:
             return
-        arr = (L.WgradJob * 8)()
+        arr = (L.WgradJob * self.CAP)()
         for i, (dy, x, M, N, K, dW, db) in enumerate(self.jobs):
             arr[i].dy, arr[i].x, arr[i].M, arr[i].N, arr[i].K = dy.data_ptr(), x.data_ptr(), M, N, K
             arr[i].dW, arr[i].dbias = dW.data_ptr(), (db.data_ptr() if db is not None else None)
@@ -1289,6 +1293,10 @@ class EncoderFusedFn(torch.autograd.Function):
         npj = 0
         dsum = torch.empty(M, D, dtype=F32, device=dev) if want_pos else None      # written (not accumulated) by the first layer processed
         dsum_started = False
+        # the stack's weight gradients: one grouped launch per layer, or (wgrad_stack) ONE for the whole stack at the end -- 7 x 32
+        # output tiles fill the chip with 2 K slices each instead of 16, so the split-K flush is paid once (the operands of every
+        # layer stay alive until then: ~75 MB per layer at c2)
+        wg_all = WgradBatch(cap=WgradBatch.CAP) if (cfg.wgrad_stack and cfg.wgrad_group) else None      # (more than 32 jobs: a launch per 32)
 
         def bwd_mlp(a, blk, res_attn, res_mlp, pk, d, u, x1, m2, r2, slot):
             att, mlp = blk
@@ -1341,12 +1349,13 @@ class EncoderFusedFn(torch.autograd.Function):
             a.dsum_init = int(not dsum_started)
             dsum_started = True
             L.call_struct("vpf_sa_layer_bwd_qkv", a)
-            wg = WgradBatch()
+            wg = wg_all if wg_all is not None else WgradBatch()
             wg.add(dz2, h, D, Hd, grad_buf(mlp[3].weight), grad_buf(mlp[3].bias))
             wg.add(du, n2, Hd, D, grad_buf(mlp[1].weight), grad_buf(mlp[1].bias))
             wg.add(dz1, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
             wg.add(dqkv, n1, 3 * D, D, packed_grad([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]))
-            wg.flush()
+            if wg_all is None:
+                wg.flush()
             pgrad_job(i + 1, 1, mlp[0])
             pgrad_job(i + 1, 0, ln1)
             d = dbase
@@ -1368,14 +1377,15 @@ class EncoderFusedFn(torch.autograd.Function):
                torch.empty(B * H * Lq, dtype=F32, device=dev))
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         w16, gW = shadow(qkvw), packed_grad(qkvw[:1] if ctx.kv_ready else qkvw)      # (K / V weights: AdapterKVFn's business then)
-        wg = WgradBatch()
+        wg = wg_all if wg_all is not None else WgradBatch()
         wg.add(dz2, h, D, Hd, grad_buf(cmlp[3].weight), grad_buf(cmlp[3].bias))
         wg.add(du, n2, Hd, D, grad_buf(cmlp[1].weight), grad_buf(cmlp[1].bias))
         wg.add(dz1, o, D, D, grad_buf(catt.o_proj.weight), grad_buf(catt.o_proj.bias))
         wg.add(dq, nq, D, D, gW[:D * D])
         if not ctx.kv_ready:
             wg.add(dkv, nk, 2 * D, D, gW[D * D:])                      # (image branch: K / V weights' gradient in the same grouped launch)
-        wg.flush()
+        if wg_all is None:
+            wg.flush()
         dnq = linear_dgrad(dq, w16[:D * D], D, D)
         dxkv = None
         if ctx.kv_ready:
@@ -1398,6 +1408,8 @@ class EncoderFusedFn(torch.autograd.Function):
             else:
                 dpos = torch.zeros(ctx.pos_shape, dtype=F32, device=dev)
                 L.call("vpf_rowsum_mod_f32", dsum, M, D, Lq, dpos)
+        if wg_all is not None:
+            wg_all.flush()                                             # behind the dgrad chain: what follows this node waits for dx, not for the weight gradients
         return (dx.view(B, Lq, D), dpos, dxkv, None, None, None, None, None) + (None,) * ctx.nparams
 
 
