@@ -578,13 +578,34 @@ struct WgDesc {
     const bf16_t* A; const bf16_t* B; float* C; float* dbias; float* part; int* cnt;
     int lda, ldb, ldc, M, N, K, splitk, ntx, mode;
 };
-struct GemmGroup { WgDesc d[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; short nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n, uneven, dbg; };
+#define WGROUP_XLIST_MAX 96
+struct GemmGroup {
+    WgDesc d[GEMM_GROUP_MAX]; int start[GEMM_GROUP_MAX + 1]; short nx[GEMM_GROUP_MAX], ny[GEMM_GROUP_MAX]; int n, uneven, dbg;
+    // XCD lists (few K slices per tile -- a whole stack in one launch): every (problem, K slice) = "slab" is dealt to ONE XCD -- all its
+    // output tiles read the same dY / X rows, so its operands cross HBM once instead of once per XCD that holds one of its tiles
+    // (1 126 -> ~600 MB per stack launch).  Workgroup id -> XCD id % 8 (the dispatcher's round-robin), slot id / 8 -> walk the XCD's list.
+    int xmode;                                              // 1: the lists below are in use; grid = 8 x the longest list's tile count
+    unsigned char xp[WGROUP_XLIST_MAX], xz[WGROUP_XLIST_MAX], xoff[9];     // slab i: problem xp[i], slice xz[i]; XCD x owns slabs xoff[x] .. xoff[x + 1] - 1
+};
 template <int TM, int TN, int WM, int WN, int BK, int PF, bool PAIR = false>
 __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(GemmGroup grp)
 {
-    int p = 0;
-    while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
-    const int local = blockIdx.x - grp.start[p];
+    int p = 0, local = 0, xbz = 0;
+    if (grp.xmode) {
+        const int x = blockIdx.x & 7;
+        int slot = blockIdx.x >> 3, i = grp.xoff[x];
+        const int end = grp.xoff[x + 1];
+        for (; i < end; ++i) {
+            const int nt = grp.nx[grp.xp[i]] * grp.ny[grp.xp[i]];
+            if (slot < nt) break;
+            slot -= nt;
+        }
+        if (i >= end) return;                               // this XCD's list is shorter than the longest one
+        p = grp.xp[i]; xbz = grp.xz[i]; local = slot;
+    } else {
+        while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
+        local = blockIdx.x - grp.start[p];
+    }
     const WgDesc& d = grp.d[p];
     GemmArgs g = {};
     g.A = d.A; g.B = d.B; g.lda = d.lda; g.ldb = d.ldb; g.M = d.M; g.N = d.N; g.K = d.K; g.splitk = d.splitk; g.mode = d.mode;
@@ -592,7 +613,9 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(Gemm
     g.part = d.part; g.cnt = d.cnt; g.ntx = d.ntx;
     const int nx = grp.nx[p], ny = grp.ny[p], sk = PAIR ? g.splitk / 2 : g.splitk;      // PAIR: a workgroup = two K slices
     int bx, by, bz;
-    if ((sk & 7) == 0 && (grp.start[p] & 7) == 0) {
+    if (grp.xmode) {
+        bz = xbz; bx = local % nx; by = local / nx;
+    } else if ((sk & 7) == 0 && (grp.start[p] & 7) == 0) {
         // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2.  All output tiles
         // of one token slice read the same dY / X rows, so a slice's tiles are given ids that are congruent mod 8: the
         // slice's operands are fetched from HBM once per XCD instead of once per tile.
@@ -788,6 +811,44 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         at += nx * ny * (int)(pair ? sp / 2 : sp);
     }
     grp.start[njobs] = at;
+    {   // XCD lists: when no problem's slices can use the sk % 8 == 0 ordering of the kernel and the slabs fit the table
+        int nslab = 0; bool ok = vpf_debug().wgroup_xlist != 0;
+        for (int i = 0; i < njobs && ok; ++i) {
+            const int sk = pair ? grp.d[i].splitk / 2 : grp.d[i].splitk;
+            if ((sk & 7) == 0) ok = false;
+            if (grp.d[i].K / (sk > 0 ? sk : 1) < 4096) ok = false;      // short slabs (config 4: 2 048 tokens per slice) gain nothing: 4.40 vs 4.43 ms; c2 (6 144): 4.20 -> 4.10
+            nslab += sk;
+        }
+        if (ok && nslab <= WGROUP_XLIST_MAX && njobs > 1) {
+            // greedy: largest slabs first, each to the XCD with the fewest tiles so far
+            int order[WGROUP_XLIST_MAX], sp_[WGROUP_XLIST_MAX], sz_[WGROUP_XLIST_MAX], n = 0;
+            for (int i = 0; i < njobs; ++i) {
+                const int sk = pair ? grp.d[i].splitk / 2 : grp.d[i].splitk;
+                for (int z = 0; z < sk; ++z) { sp_[n] = i; sz_[n] = z; order[n] = n; ++n; }
+            }
+            auto tiles = [&](int k) { return (int)grp.nx[sp_[k]] * (int)grp.ny[sp_[k]]; };
+            for (int a = 1; a < n; ++a) {                   // insertion sort by tile count, descending (stable)
+                const int k = order[a]; int b = a - 1;
+                while (b >= 0 && tiles(order[b]) < tiles(k)) { order[b + 1] = order[b]; --b; }
+                order[b + 1] = k;
+            }
+            int load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, owner[WGROUP_XLIST_MAX];
+            for (int a = 0; a < n; ++a) {
+                int best = 0;
+                for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+                owner[order[a]] = best; load[best] += tiles(order[a]);
+            }
+            int w = 0, longest = 0;
+            for (int x = 0; x < 8; ++x) {
+                grp.xoff[x] = (unsigned char)w;
+                for (int k = 0; k < n; ++k) if (owner[k] == x) { grp.xp[w] = (unsigned char)sp_[k]; grp.xz[w] = (unsigned char)sz_[k]; ++w; }
+                if (load[x] > longest) longest = load[x];
+            }
+            grp.xoff[8] = (unsigned char)w;
+            grp.xmode = 1;
+            at = 8 * longest;
+        }
+    }
     // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at
     // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
     // 512 workgroups flushing together at the end (-0.035 ms/step, 15 launches)
