@@ -805,6 +805,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         const long maxs = vpf_cdiv(g.K, 256);
         if (sp > maxs) sp = maxs;
         if (sp < 2) sp = 2;                       // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
+        if (sp > 8 && vpf_debug().wgroup_xlist) sp &= ~7L;      // many slices: a multiple of 8, so that the kernel's XCD ordering applies (a slice's tiles on one XCD)
         if (pair) sp &= ~1L;                      // whole pairs
         g.splitk = (int)sp;
         grp.nx[i] = (short)nx; grp.ny[i] = (short)ny; grp.start[i] = at;
