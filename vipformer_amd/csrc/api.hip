@@ -53,7 +53,7 @@ struct VpfDebugKey { const char* name; const char* env; int VpfDebug::*field; in
 static const VpfDebugKey kDebugKeys[] = {
     {"attn_resident", "VPF_ATTN_RESIDENT", &VpfDebug::attn_resident, 1},
     {"g2e_grid", "VPF_G2E_GRID", &VpfDebug::g2e_grid, 256},
-    {"g2e_w4_grid", "VPF_G2E_W4_GRID", &VpfDebug::g2e_w4_grid, 256},
+    {"g2e_w4_grid", "VPF_G2E_W4_GRID", &VpfDebug::g2e_w4_grid, 0},
     {"wgrad_cfg", "VPF_WGRAD_CFG", &VpfDebug::wgrad_cfg, 0},
     {"wgrad_wgs", "VPF_WGRAD_WGS", &VpfDebug::wgrad_wgs, 0},
     {"gemm_cfg", "VPF_GEMM_CFG", &VpfDebug::gemm_cfg, -1},

@@ -415,6 +415,100 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
         }
     }
 }
+// Round 3: the same walk with the 256 input channels (k) split over FOUR workgroups per walker instead of the rows over 4 x as many
+// walkers: a workgroup owns [256 columns n] x [64 k] of dW4 (32 accumulators per thread) and stages the k quarter of FOUR groups per
+// step (the same 16 KB tile per step, the same number of steps), so the 256 workgroups of the launch flush 64 KB each instead of
+// 256 KB: 16.7 MB of fp32 atomics instead of 67 MB (at the atomic units' ~1.3 TB/s that flush was ~50 us of the kernel's 134).
+#define W4_G 4
+#define W4_KLD 72
+__global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
+{
+    __shared__ __attribute__((aligned(16))) bf16_t sA3[2][W4_G * 32 * W4_KLD];
+    __shared__ float sD[2][W4_G][256];
+    __shared__ uint8_t sR[2][W4_G][256];
+    const int t = threadIdx.x, nl = t & 255, kh = t >> 8;
+    const int nblk = blockIdx.y >> 2, kq = blockIdx.y & 3;
+    const int n = nblk * 256 + nl;
+    float aa[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { aa[j] = p.ab2[kq * 64 + (t & 7) * 8 + j]; bb[j] = p.ab2[256 + kq * 64 + (t & 7) * 8 + j]; }
+    float acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+    float accb = 0.f;
+    uint4 hv[2];
+    float dn[2];
+    uint8_t rn[2];
+    auto request = [&](long g0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + i * 512, j = c >> 8, row = (c >> 3) & 31, ch = c & 7;
+            const long gg = g0 + j;
+            hv[i] = gg < p.NG ? *reinterpret_cast<const uint4*>(p.h3 + ((size_t)gg * 32 + row) * 256 + kq * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+            const int col = c & 255, nn = nblk * 256 + col;
+            const bool ok = nn < p.Dm && gg < p.NG;
+            dn[i] = ok ? p.dout[(size_t)gg * p.Dm + nn] : 0.f;
+            rn[i] = ok ? p.arg4[(size_t)gg * p.Dm + nn] : 0;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = t + i * 512, j = c >> 8, row = (c >> 3) & 31, ch = c & 7;
+            uint32_t u[4] = {hv[i].x, hv[i].y, hv[i].z, hv[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                u[q] = pack_bf16x2(fmaxf(fmaf(aa[2 * q], __uint_as_float(u[q] << 16), bb[2 * q]), 0.f),
+                                   fmaxf(fmaf(aa[2 * q + 1], __uint_as_float(u[q] & 0xffff0000u), bb[2 * q + 1]), 0.f));
+            *reinterpret_cast<uint4*>(&sA3[buf][(j * 32 + row) * W4_KLD + ch * 8]) = make_uint4(u[0], u[1], u[2], u[3]);
+            sD[buf][j][c & 255] = dn[i]; sR[buf][j][c & 255] = rn[i];
+        }
+    };
+    long g0 = (long)blockIdx.x * W4_G;
+    const long gstep = (long)gridDim.x * W4_G;
+    int buf = 0;
+    if (g0 < p.NG) { request(g0); commit(0); }
+    __syncthreads();
+    for (; g0 < p.NG; g0 += gstep) {
+        const long gn = g0 + gstep;
+        if (gn < p.NG) request(gn);
+#pragma unroll
+        for (int j = 0; j < W4_G; ++j) {
+            const float d = sD[buf][j][nl];
+            const bf16_t* row = &sA3[buf][(j * 32 + (int)sR[buf][j][nl]) * W4_KLD + kh * 32];
+            if (kh == 0) accb += d;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + q * 8);
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[q * 8 + 2 * e] = fmaf(d, __uint_as_float(u[e] << 16), acc[q * 8 + 2 * e]);
+                    acc[q * 8 + 2 * e + 1] = fmaf(d, __uint_as_float(u[e] & 0xffff0000u), acc[q * 8 + 2 * e + 1]);
+                }
+            }
+        }
+        if (gn < p.NG) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // flush: [256 n] x [64 k] through LDS in two halves of 128 rows, added as 256-byte row segments (64 lanes = 64 consecutive k)
+    float* tile = reinterpret_cast<float*>(&sA3[0][0]);            // 128 x 64 f32 = 32 KB <= 2 x 128 x 72 x 2 B
+    static_assert(sizeof(bf16_t) * 2 * W4_G * 32 * W4_KLD >= 128 * 64 * 4, "flush tile must fit in the staging buffers");
+    if (kq == 0 && kh == 0 && n < p.Dm) atomicAdd(p.db4 + n, accb);
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if ((nl >> 7) == half) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) tile[(nl & 127) * 64 + kh * 32 + j] = acc[j];
+        }
+        __syncthreads();
+        for (int e = t; e < 128 * 64; e += 512) {
+            const int nn = nblk * 256 + half * 128 + (e >> 6);
+            if (nn < p.Dm) atomicAdd(p.dW4 + (size_t)nn * 256 + kq * 64 + (e & 63), tile[e]);
+        }
+    }
+}
 extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, const float* dout, const uint8_t* arg4, int Dm,
                               float* dW4, float* db4, void* stream)
 {
@@ -422,7 +516,14 @@ extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, co
     if (!h3_bf16 || !ab2 || !dout || !arg4 || !dW4 || !db4) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0) return VPF_ERR_BADSHAPE;
     G2eW4 p = {(const bf16_t*)h3_bf16, NG, ab2, dout, arg4, Dm, dW4, db4};
-    const int cap = vpf_debug().g2e_w4_grid < 1 ? 256 : vpf_debug().g2e_w4_grid;      // one workgroup per CU: twice the flush atomics of 128 workgroups, half the walk (168 -> ~110 us)
+    if (vpf_debug().g2e_w4_grid >= 0) {       // (VPF_G2E_W4_GRID < 0: the round-1 kernel below with -grid workgroups)
+        const int walkers = vpf_debug().g2e_w4_grid > 0 ? vpf_debug().g2e_w4_grid : 64;
+        long gx = vpf_cdiv(NG, (long)W4_G) < walkers ? vpf_cdiv(NG, (long)W4_G) : walkers;
+        hipLaunchKernelGGL(g2e_wgrad4_kq_kernel, dim3((unsigned)gx, 4 * vpf_cdiv(Dm, 256)), dim3(512), 0, (hipStream_t)stream, p);
+        VPF_CHECK_LAUNCH();
+        return VPF_OK;
+    }
+    const int cap = vpf_debug().g2e_w4_grid < -1 ? -vpf_debug().g2e_w4_grid : 256;      // one workgroup per CU: twice the flush atomics of 128 workgroups, half the walk (168 -> ~110 us)
     long gx = NG < cap ? NG : cap;
     hipLaunchKernelGGL(g2e_wgrad4_kernel, dim3((unsigned)gx, vpf_cdiv(Dm, 256)), dim3(512), 0, (hipStream_t)stream, p);
     VPF_CHECK_LAUNCH();

@@ -29,7 +29,7 @@ struct VpfPerDevice {
 struct VpfDebug {
     int attn_resident;      // VPF_ATTN_RESIDENT     1: whole-head resident attention kernels when the sequence fits (0: tiled ones)
     int g2e_grid;           // VPF_G2E_GRID          persistent Group2Emb workgroups
-    int g2e_w4_grid;        // VPF_G2E_W4_GRID       workgroups of the sparse dW4 walk
+    int g2e_w4_grid;        // VPF_G2E_W4_GRID       walkers of the sparse dW4 walk (0: 64, each x 4 k-quarter workgroups; < 0: the round-1 kernel, -value workgroups)
     int wgrad_cfg;          // VPF_WGRAD_CFG         tile configuration of the single weight-gradient GEMM (0: by shape)
     int wgrad_wgs;          // VPF_WGRAD_WGS         its target workgroup count (0: default)
     int gemm_cfg;           // VPF_GEMM_CFG          forced tile configuration of vpf_gemm_bf16 (-1: by shape)
