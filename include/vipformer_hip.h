@@ -393,6 +393,10 @@ typedef struct VpfSaLayerBwd {
 } VpfSaLayerBwd;
 int vpf_sa_layer_bwd_mlp(const VpfSaLayerBwd* host_args, void* stream);
 int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);
+/* Round 3: the qkv half of one layer and the mlp half of the layer BELOW it (mlp->d == qkv->dbase: the gradient leaving the upper
+ * layer enters the lower one) in ONE launch: a workgroup's gradient rows go from the first body to the second through LDS.  Where the
+ * fused kernel does not apply (D = 384, or mlp->d != qkv->dbase) the two launches above run back to back: same results either way. */
+int vpf_sa_layer_bwd_qkv_mlp(const VpfSaLayerBwd* qkv_of_layer, const VpfSaLayerBwd* mlp_of_layer_below, void* stream);
 /* The front of the point-cloud branch's cross-attention layer in ONE kernel (D = 256): position_emb (partseg.py:498-501:
  * Linear(3,128) GELU Linear(128,D)) on the group centres, base = tokens + pos (Encoder.forward, partseg.py:326), q_norm and the
  * bias-free q projection (partseg.py:100-116, 48-51).  W1 / Wq = vpf_pack_wfrag of the bf16 weights [D,128] / [D,D].

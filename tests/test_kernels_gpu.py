@@ -609,6 +609,62 @@ def test_sa_rows_bwd_equals_the_one_per_cu_kernels_bitwise(M, with_dsum, dsum_in
         assert rel(res[1][k], res[0][k]) < 1e-5, (k, rel(res[1][k], res[0][k]))
 
 
+@pytest.mark.parametrize("M", [12288, 200])
+def test_sa_bwd_qkv_mlp_one_launch_equals_two_bitwise(M):
+    """vpf_sa_layer_bwd_qkv_mlp (the qkv half of a layer and the MLP half of the layer below in one workgroup, the gradient rows handed
+    over through LDS) against the two launches it replaces (VPF_SA_BWD_FUSE = 0), dropout on, ragged last block: every output of both
+    halves and both LayerNorms' parameter-gradient partials must be bit-identical."""
+    import ctypes
+    import torch.nn as nn
+    from vipformer_amd import _lib, ops
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    D, Hd = 256, 512
+    torch.manual_seed(3)
+    layers = nn.ModuleList([SelfAttentionLayer(4, D, 2, 0.0, 0.1, 0.5) for _ in range(2)]).cuda()
+    layers.train()
+    pks = ops._pack_blocks([(l[0].module.attention, l[1].module, True, True) for l in layers], layers[0], "cuda")
+    st = ops.rng.state("cuda")
+    u = bf(rnd(2, M, Hd)); x1 = rnd(3, M, D); base = rnd(4, M, D); dqkv = bf(rnd(5, M, 3 * D, scale=0.1)); dx1_up = rnd(9, M, D)
+    m2 = x1.mean(1).contiguous(); r2 = (x1.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    m1 = base.mean(1).contiguous(); r1 = (base.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    dsum0 = rnd(6, M, D)
+    up, low = layers[1], layers[0]
+    nwg = ops.pgrad_rows(M, D)
+
+    def run(fuse):
+        out = dict(dbase=torch.empty(M, D, device="cuda"), dsum=dsum0.clone(),
+                   dz2=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"), du=torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda"),
+                   dx1=torch.empty(M, D, device="cuda"), dz1=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"),
+                   do=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"))
+        pg = torch.zeros(2, nwg * 2 * D, device="cuda")
+        a = _lib.SaLayerBwd()                                   # qkv half of the upper layer
+        a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
+        a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = (dqkv.data_ptr(), pks[1]["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(), r1.data_ptr(),
+                                                             up[0].module.norm.weight.data.data_ptr())
+        a.dx1, a.dbase, a.dsum, a.dsum_init, a.pgrad1 = dx1_up.data_ptr(), out["dbase"].data_ptr(), out["dsum"].data_ptr(), 0, pg[0].data_ptr()
+        b = _lib.SaLayerBwd()                                   # MLP half of the layer below: its d is the dbase above
+        b.M, b.D, b.hidden, b.rng = M, D, Hd, st.data_ptr()
+        b.p_res1, b.site_res1, b.p_res2, b.site_res2 = 0.5, low[0].site, 0.5, low[1].site
+        b.d, b.u, b.x1, b.mean2, b.rstd2, b.ln2_g = out["dbase"].data_ptr(), u.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), low[1].module[0].weight.data.data_ptr()
+        b.W2T, b.W1T, b.WoT = pks[0]["W2T"].data_ptr(), pks[0]["W1T"].data_ptr(), pks[0]["WoT"].data_ptr()
+        b.dz2, b.du, b.dx1, b.dz1, b.dout_attn = (out[k].data_ptr() for k in ("dz2", "du", "dx1", "dz1", "do"))
+        b.pgrad2 = pg[1].data_ptr()
+        _lib.debug_set("sa_bwd_fuse", fuse)
+        try:
+            _lib.call_struct("vpf_sa_layer_bwd_qkv_mlp", a, ctypes.addressof(b))
+            torch.cuda.synchronize()
+        finally:
+            _lib.debug_set("sa_bwd_fuse", 1)
+        out["pg"] = pg
+        return out
+
+    two, one, again = run(0), run(1), run(1)
+    assert float(two["dx1"].abs().max()) > 0 and float(two["do"].float().abs().max()) > 0
+    for k in two:
+        assert torch.equal(one[k], again[k]), ("not reproducible", k)
+        assert torch.equal(two[k], one[k]), (k, rel(one[k], two[k]))
+
+
 @pytest.mark.parametrize("B,N", [(8, 1024), (3, 333)])
 def test_adapter_kv_bwd_rows_kernel_equals_the_round2_kernel_bitwise(B, N):
     """adapter_kv_bwd_rows_kernel (sa_rows.hip: two workgroups per CU) against adapter_kv_bwd_kernel (sa_layer.hip, VPF_SA_WG2 bit 2)

@@ -696,6 +696,7 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
             long s = wtarget / (tiles > 0 ? tiles : 1);
             const long maxs = vpf_cdiv(g.K, 256);
             if (s > maxs) s = maxs;
+            if (s > 8) s &= ~7L;                  // a multiple of 8: the kernel's per-slice XCD ordering applies (a slice's tiles share one L2)
             if (s < 1) s = 1;
             g.splitk = (int)s;
         }

@@ -1143,8 +1143,11 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_mlp_kernel(VpfSaLayerBwd
 // The same with every HBM access but the u loads row-coalesced (8 waves x 32 channels).  d is only ever needed element-wise
 // (dropout', + d), so it is handled in the row layout; x1 (the LayerNorm-2 input) is staged into an f32 LDS tile at the start,
 // LayerNorm-2' leaves its result in that tile and a row pass turns it into dx1 (HBM) and dz1 (LDS operand tile + HBM).
-template <int RB>
-__global__ void __launch_bounds__(512) sa_bwd_mlp_rows_kernel(VpfSaLayerBwd a)
+// STAGED: dz2 (operand tile + HBM) and the x1 rows (xt) were put in place by the kernel body that ran in front of this one in the
+// same workgroup (sa_bwd_qkv_rows_body<.., true> of the layer above: one launch per layer boundary instead of two, and the
+// gradient rows cross HBM once instead of twice)
+template <int RB, bool STAGED>
+__device__ __forceinline__ void sa_bwd_mlp_rows_body(const VpfSaLayerBwd& a)
 {
     constexpr int NJ = 1, NT = 512, TOK = RB * 32, XPT = TOK * 64 / NT;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
@@ -1161,7 +1164,7 @@ __global__ void __launch_bounds__(512) sa_bwd_mlp_rows_kernel(VpfSaLayerBwd a)
     sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, NJ * wave, wpre);
     f32x16_t acc[NJ][RB], acc2[NJ][RB];
     // ---- dz2 = dropout'(d)  (row layout: operand tile + HBM);  x1 -> xt
-    {
+    if constexpr (!STAGED) {
         float4 dr[XPT], xr[XPT];
 #pragma unroll
         for (int it = 0; it < XPT; ++it) {
@@ -1265,6 +1268,11 @@ __global__ void __launch_bounds__(512) sa_bwd_mlp_rows_kernel(VpfSaLayerBwd a)
     __syncthreads();
     sa_tile_store_rows<TOK, NT>(actH, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
 }
+template <int RB>
+__global__ void __launch_bounds__(512) sa_bwd_mlp_rows_kernel(VpfSaLayerBwd a)
+{
+    sa_bwd_mlp_rows_body<RB, false>(a);
+}
 
 template <int RB, int NJ>
 __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
@@ -1347,8 +1355,10 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd
 
 // The same with every HBM access row-coalesced (8 waves x 32 channels): the LayerNorm input is staged into an f32 LDS tile at
 // the start, LayerNorm' leaves its result in that tile, and a row pass adds dx1 and writes dbase (and dsum).
-template <int RB>
-__global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
+// HANDOFF: the rows of dbase are also turned into the MLP backward's first operand of the layer BELOW (b: dz2 = dropout'(dbase) into
+// the operand tile and HBM, b's x1 rows into xt) -- sa_bwd_mlp_rows_body<.., true>(b) follows in the same workgroup.
+template <int RB, bool HANDOFF>
+__device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, const VpfSaLayerBwd& b)
 {
     constexpr int NJ = 1, NT = 512, TOK = RB * 32, CPT = TOK * 32 / NT, XPT = TOK * 64 / NT;
     extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
@@ -1425,16 +1435,61 @@ __global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
         if (a.dsum) sv[it] = a.dsum_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.dsum + off);
     }
     __syncthreads();
+    if constexpr (!HANDOFF) {
 #pragma unroll
-    for (int it = 0; it < XPT; ++it) {
-        const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
-        if (row >= nvalid) continue;
-        const size_t off = (size_t)(m0 + row) * SA_D + c4 * 4;
-        float4 v = *reinterpret_cast<const float4*>(xt + row * XLD + c4 * 4);
-        v.x += dv[it].x; v.y += dv[it].y; v.z += dv[it].z; v.w += dv[it].w;
-        *reinterpret_cast<float4*>(a.dbase + off) = v;
-        if (a.dsum) *reinterpret_cast<float4*>(a.dsum + off) = make_float4(sv[it].x + v.x, sv[it].y + v.y, sv[it].z + v.z, sv[it].w + v.w);
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            if (row >= nvalid) continue;
+            const size_t off = (size_t)(m0 + row) * SA_D + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(xt + row * XLD + c4 * 4);
+            v.x += dv[it].x; v.y += dv[it].y; v.z += dv[it].z; v.w += dv[it].w;
+            *reinterpret_cast<float4*>(a.dbase + off) = v;
+            if (a.dsum) *reinterpret_cast<float4*>(a.dsum + off) = make_float4(sv[it].x + v.x, sv[it].y + v.y, sv[it].z + v.z, sv[it].w + v.w);
+        }
+    } else {
+        // the same row pass, continued into the first pass of sa_bwd_mlp_rows_body of the layer below (identical arithmetic)
+        float4 xr[XPT];
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            xr[it] = *reinterpret_cast<const float4*>(b.x1 + (size_t)(m0 + (row < nvalid ? row : 0)) * SA_D + c4 * 4);
+        }
+        const VpfRng rng = vpf_rng_init(b.rng, b.site_res2, b.p_res2);
+        const bool drop = b.p_res2 > 0.f;
+        const float sc = drop ? rng.scale : 1.f;
+#pragma unroll
+        for (int it = 0; it < XPT; ++it) {
+            const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
+            const bool ok = row < nvalid;
+            const size_t off = (size_t)(m0 + (ok ? row : 0)) * SA_D + c4 * 4;
+            float4 v = *reinterpret_cast<const float4*>(xt + row * XLD + c4 * 4);
+            v.x += dv[it].x; v.y += dv[it].y; v.z += dv[it].z; v.w += dv[it].w;
+            if (ok) {
+                *reinterpret_cast<float4*>(a.dbase + off) = v;
+                if (a.dsum) *reinterpret_cast<float4*>(a.dsum + off) = make_float4(sv[it].x + v.x, sv[it].y + v.y, sv[it].z + v.z, sv[it].w + v.w);
+            }
+            const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u);
+            uint2 w;
+            w.x = pack_bf16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
+            w.y = pack_bf16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
+            *reinterpret_cast<uint2*>(actA + row * ALD + c4 * 4) = w;
+            if (ok) *reinterpret_cast<uint2*>((bf16_t*)b.dz2 + off) = w;
+            *reinterpret_cast<float4*>(xt + row * XLD + c4 * 4) = ok ? xr[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
+}
+template <int RB>
+__global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
+{
+    sa_bwd_qkv_rows_body<RB, false>(a, a);
+}
+// qkv backward of layer i and MLP backward of layer i - 1 (the layer below) in one workgroup: b.d == a.dbase
+template <int RB>
+__global__ void __launch_bounds__(512) sa_bwd_qkv_mlp_rows_kernel(VpfSaLayerBwd a, VpfSaLayerBwd b)
+{
+    sa_bwd_qkv_rows_body<RB, true>(a, b);
+    __syncthreads();                      // the operand tile and xt are complete; every wave's dbase rows are on their way to L2
+    sa_bwd_mlp_rows_body<RB, true>(b);
 }
 
 // dgamma[c] += sum_r partials[r][c], dbeta[c] += sum_r partials[r][256 + c]  (fixed order: deterministic) for a list of
@@ -1560,6 +1615,36 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else if (rows) hipLaunchKernelGGL((sa_bwd_qkv_rows_kernel<RB>), dim3(nwg), dim3(512), lds + (size_t)TOK * XLD * 4, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// qkv backward of one layer and the MLP backward of the layer BELOW it (mlp->d must be qkv->dbase: the gradient that leaves the
+// upper layer is the one that enters the lower one) as ONE launch where the fused row-block kernel exists (D = 256, the round-2
+// kernels); otherwise the two launches of vpf_sa_layer_bwd_qkv / vpf_sa_layer_bwd_mlp.  Same results either way.
+extern "C" int vpf_sa_layer_bwd_qkv_mlp(const VpfSaLayerBwd* qkv, const VpfSaLayerBwd* mlp, void* stream)
+{
+    (void)hipGetLastError();
+    if (!qkv || !mlp) return VPF_ERR_NULL;
+    const VpfSaLayerBwd& a = *qkv;
+    const VpfSaLayerBwd& b = *mlp;
+    const bool fusable = a.D == SA_D && a.hidden == SA_HID && b.D == SA_D && b.hidden == SA_HID && a.M == b.M && !sa_bwd_rows3(a) && !sa_bwd_rows3(b) &&
+                         sa_bwd_nj() != 2 && vpf_debug().sa_bwd_rows && vpf_debug().sa_bwd_fuse && (const void*)b.d == (const void*)a.dbase;
+    if (!fusable) {
+        const int rc = vpf_sa_layer_bwd_qkv(qkv, stream);
+        return rc ? rc : vpf_sa_layer_bwd_mlp(mlp, stream);
+    }
+    if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
+    if (!b.d || !b.rng || !b.u || !b.x1 || !b.mean2 || !b.rstd2 || !b.ln2_g || !b.W2T || !b.W1T || !b.WoT || !b.dz2 || !b.du || !b.dx1 ||
+        !b.dz1 || !b.dout_attn || !b.pgrad2) return VPF_ERR_NULL;
+    constexpr int RB = 2, TOK = RB * 32;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * XLD * 4;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)sa_bwd_qkv_mlp_rows_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((sa_bwd_qkv_mlp_rows_kernel<RB>), dim3(vpf_cdiv((long)a.M, TOK)), dim3(512), lds, (hipStream_t)stream, a, b);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

@@ -1298,6 +1298,9 @@ class EncoderFusedFn(torch.autograd.Function):
         # layer stay alive until then: ~75 MB per layer at c2)
         wg_all = WgradBatch(cap=WgradBatch.CAP) if (cfg.wgrad_stack and cfg.wgrad_group) else None      # (more than 32 jobs: a launch per 32)
 
+        pending = [None]      # the SaLayerBwd of the layer above whose qkv half is still to be launched: it goes out together with the
+                              # MLP half of the layer below (vpf_sa_layer_bwd_qkv_mlp: one launch per layer boundary)
+
         def bwd_mlp(a, blk, res_attn, res_mlp, pk, d, u, x1, m2, r2, slot):
             att, mlp = blk
             bufs = (torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, Hd, dtype=BF16, device=dev), torch.empty(M, D, dtype=F32, device=dev),
@@ -1310,7 +1313,11 @@ class EncoderFusedFn(torch.autograd.Function):
             a.W2T, a.W1T, a.WoT = pk["W2T"].data_ptr(), pk["W1T"].data_ptr(), pk["WoT"].data_ptr()
             a.dz2, a.du, a.dx1, a.dz1, a.dout_attn = dz2.data_ptr(), du.data_ptr(), dx1.data_ptr(), dz1.data_ptr(), do.data_ptr()
             a.pgrad2 = pg[slot, 1].data_ptr()
-            L.call_struct("vpf_sa_layer_bwd_mlp", a)
+            above, pending[0] = pending[0], None
+            if above is not None:
+                L.call_struct("vpf_sa_layer_bwd_qkv_mlp", above, ctypes.addressof(a))
+            else:
+                L.call_struct("vpf_sa_layer_bwd_mlp", a)
             return bufs
 
         def pgrad_job(slot, which, ln):
@@ -1348,7 +1355,10 @@ class EncoderFusedFn(torch.autograd.Function):
             a.dbase, a.dsum, a.pgrad1 = dbase.data_ptr(), (dsum.data_ptr() if dsum is not None else None), pg[i + 1, 0].data_ptr()
             a.dsum_init = int(not dsum_started)
             dsum_started = True
-            L.call_struct("vpf_sa_layer_bwd_qkv", a)
+            if tap_grad.get(i) is None:
+                pending[0] = a                              # launched with the MLP half of the layer below (its d is this dbase)
+            else:
+                L.call_struct("vpf_sa_layer_bwd_qkv", a)    # (a tapped boundary: the tap's gradient joins d first)
             wg = wg_all if wg_all is not None else WgradBatch()
             wg.add(dz2, h, D, Hd, grad_buf(mlp[3].weight), grad_buf(mlp[3].bias))
             wg.add(du, n2, Hd, D, grad_buf(mlp[1].weight), grad_buf(mlp[1].bias))
