@@ -397,6 +397,11 @@ int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* host_args, void* stream);
  * layer enters the lower one) in ONE launch: a workgroup's gradient rows go from the first body to the second through LDS.  Where the
  * fused kernel does not apply (D = 384, or mlp->d != qkv->dbase) the two launches above run back to back: same results either way. */
 int vpf_sa_layer_bwd_qkv_mlp(const VpfSaLayerBwd* qkv_of_layer, const VpfSaLayerBwd* mlp_of_layer_below, void* stream);
+/* Backward of a cross-attention layer's query side (CrossAttention.q_norm + q_proj, partseg.py:100-116, and the Residual around it) on
+ * the same struct: dqkv = dq bf16 [M, D]; WqkvT = vpf_pack_wfrag(transposed = 1) of the bf16 [D, D] q weight; base / mean1 / rstd1 / ln1_g =
+ * the q LayerNorm's input, statistics and scale; dx1 = the residual's gradient; out: dbase f32 [M, D] (+= into dsum if set), pgrad1.
+ * D = 256; VPF_ERR_UNSUPPORTED otherwise. */
+int vpf_ca_front_bwd(const VpfSaLayerBwd* host_args, void* stream);
 /* The front of the point-cloud branch's cross-attention layer in ONE kernel (D = 256): position_emb (partseg.py:498-501:
  * Linear(3,128) GELU Linear(128,D)) on the group centres, base = tokens + pos (Encoder.forward, partseg.py:326), q_norm and the
  * bias-free q projection (partseg.py:100-116, 48-51).  W1 / Wq = vpf_pack_wfrag of the bf16 weights [D,128] / [D,D].

@@ -1357,7 +1357,9 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd
 // the start, LayerNorm' leaves its result in that tile, and a row pass adds dx1 and writes dbase (and dsum).
 // HANDOFF: the rows of dbase are also turned into the MLP backward's first operand of the layer BELOW (b: dz2 = dropout'(dbase) into
 // the operand tile and HBM, b's x1 rows into xt) -- sa_bwd_mlp_rows_body<.., true>(b) follows in the same workgroup.
-template <int RB, bool HANDOFF>
+// NP: 256-wide parts of the incoming gradient (3: dq | dk | dv of a self-attention layer against Wqkv^T; 1: dq of a cross-attention
+// layer against Wq^T -- the same chain, vpf_ca_front_bwd)
+template <int RB, bool HANDOFF, int NP = 3>
 __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, const VpfSaLayerBwd& b)
 {
     constexpr int NJ = 1, NT = 512, TOK = RB * 32, CPT = TOK * 32 / NT, XPT = TOK * 64 / NT;
@@ -1371,13 +1373,13 @@ __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, con
     const int nvalid = (int)min((long)TOK, M - m0);
 
     SaWPre<NJ> wpre;
-    sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const bf16_t*)a.WqkvT, NP * SA_D / 16, 0, NJ * wave, wpre);
     uint4 r[CPT];
     auto load_part = [&](int part) {
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
-            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dqkv + (size_t)(m0 + row) * (3 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dqkv + (size_t)(m0 + row) * (NP * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_part = [&](int buf) {
@@ -1406,11 +1408,11 @@ __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, con
     f32x16_t acc[NJ][RB];
     sa_zero<RB, NJ>(acc);
 #pragma unroll
-    for (int part = 0; part < 3; ++part) {
-        if (part + 1 < 3) load_part(part + 1);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.WqkvT, 3 * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
-        if (part + 1 < 3) {
-            sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
+    for (int part = 0; part < NP; ++part) {
+        if (part + 1 < NP) load_part(part + 1);
+        sa_gemm_unit<RB, NJ>((const bf16_t*)a.WqkvT, NP * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
+        if (part + 1 < NP) {
+            sa_wprefetch((const bf16_t*)a.WqkvT, NP * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
             store_part((part + 1) & 1);
             __syncthreads();
         }
@@ -1482,6 +1484,12 @@ template <int RB>
 __global__ void __launch_bounds__(512) sa_bwd_qkv_rows_kernel(VpfSaLayerBwd a)
 {
     sa_bwd_qkv_rows_body<RB, false>(a, a);
+}
+// the front of a cross-attention layer, backward: dq . Wq -> q LayerNorm' -> + dx1 -> dx (and the running positional-gradient sum)
+template <int RB>
+__global__ void __launch_bounds__(512) ca_front_bwd_rows_kernel(VpfSaLayerBwd a)
+{
+    sa_bwd_qkv_rows_body<RB, false, 1>(a, a);
 }
 // qkv backward of layer i and MLP backward of layer i - 1 (the layer below) in one workgroup: b.d == a.dbase
 template <int RB>
@@ -1615,6 +1623,30 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
     if (sa_bwd_nj() == 2) hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 2>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, a);
     else if (rows) hipLaunchKernelGGL((sa_bwd_qkv_rows_kernel<RB>), dim3(nwg), dim3(512), lds + (size_t)TOK * XLD * 4, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((sa_bwd_qkv_kernel<RB, 1>), dim3(nwg), dim3(512), lds, (hipStream_t)stream, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// Backward of a cross-attention layer's query side (partseg.py:100-116,48-51 + the residual of :201-213) as one row-block kernel:
+// dq bf16 [M, D] (a->dqkv) . Wq (a->WqkvT = vpf_pack_wfrag(transposed) of the bf16 [D, D] q weight) -> q LayerNorm' (a->base = its
+// input, mean1 / rstd1 / ln1_g) -> + a->dx1 -> a->dbase (f32 [M, D]); a->dsum (nullable) accumulates it; the LayerNorm's parameter
+// gradients leave as partial rows (a->pgrad1).  D = 256 (else VPF_ERR_UNSUPPORTED: the caller keeps its GEMM + LayerNorm kernels).
+extern "C" int vpf_ca_front_bwd(const VpfSaLayerBwd* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfSaLayerBwd& a = *args;
+    if (a.M <= 0) return VPF_ERR_BADSHAPE;
+    if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
+    if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
+    constexpr int RB = 2, TOK = RB * 32;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * XLD * 4;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)ca_front_bwd_rows_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((ca_front_bwd_rows_kernel<RB>), dim3(vpf_cdiv((long)a.M, TOK)), dim3(512), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

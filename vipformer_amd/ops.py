@@ -43,7 +43,7 @@ class OpsConfig:
     The library's own launch-time knobs live in its VpfDebug struct (``_lib.debug_get`` / ``debug_set``)."""
     __slots__ = ("wgrad_async", "wgrad_group", "wgrad_group_async", "wgrad_deterministic", "wgrad_defer", "sa_debug", "sa_split_attn",
                  "sa_fused_bwd", "sa_fused", "enc_bwd_hook", "adapter_kv_fused", "adapter_kv_bwd_fused", "enc_fused", "g2e_bn_merged",
-                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack")
+                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack", "ca_front_bwd_fused")
 
     def __init__(self, env=os.environ):
         self.wgrad_async = False          # weight-gradient GEMMs on a side stream: measured slower (cross-stream event cost > overlap gain)
@@ -60,6 +60,7 @@ class OpsConfig:
         self.adapter_kv_bwd_fused = True
         self.enc_fused = True             # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
         self.ca_front_fused = env.get("VPF_CA_FRONT", "1") == "1"     # position MLP + (tokens + pos) + q_norm + q projection of the point-cloud branch as one kernel
+        self.ca_front_bwd_fused = env.get("VPF_CA_FRONT_BWD", "1") == "1"      # the cross-attention layer's query-side backward as one row-block kernel (vpf_ca_front_bwd)
         self.wgrad_stack = env.get("VPF_WGRAD_STACK", "1") == "1"               # the weight gradients of a whole fused encoder stack as ONE grouped launch at the end of its backward
         self.g2e_bn_merged = env.get("VPF_G2E_BN_MERGED", "1") != "0"          # BatchNorm bookkeeping of Group2Emb as single launches
         self.g2e_conv1_bwd_fused = env.get("VPF_G2E_CONV1_FUSED", "1") == "1"  # conv2 dgrad inside the first conv's backward (tests run both)
@@ -1128,6 +1129,10 @@ def _pack_blocks(blocks, holder, dev, front=None):
             todo.append((shadow(qkvw), v["Wqkv"], 3 * D, D, 0))
         if want_qkvT:
             todo.append((shadow(qkvw), v["WqkvT"], D, 3 * D, 1))
+        elif i == 0:
+            # the cross-attention block: its WqkvT slot holds the transposed q projection alone (vpf_ca_front_bwd)
+            v["WqT"] = v["WqkvT"][:D * D]
+            todo.append((shadow(qkvw)[:D * D], v["WqT"], D, D, 1))
         for src, dst, N, K, tr in todo:
             jobs[n].src, jobs[n].dst, jobs[n].N, jobs[n].K, jobs[n].transposed = src.data_ptr(), dst.data_ptr(), N, K, tr
             n += 1
@@ -1378,8 +1383,11 @@ class EncoderFusedFn(torch.autograd.Function):
         a = L.SaLayerBwd()
         dz2, du, dx1, dz1, do = bwd_mlp(a, (catt, cmlp), ca[0], ca[1], packed[0], d, u, x1, m2, r2, 0)
         pgrad_job(0, 1, cmlp[0])
-        if npj:
+        front_rows = (D == 256 and cfg.ca_front_bwd_fused and "WqT" in packed[0]       # the query side as one row-block kernel below
+                      and nwg == (M + 63) // 64)                                          # (its partial rows: one per 64 tokens)
+        if npj and not front_rows:
             L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
+            npj = 0
         dq = torch.empty(M, D, dtype=BF16, device=dev)
         dkv = torch.empty(Mk, 2 * D, dtype=BF16, device=dev)
         L.call("vpf_attention_bwd", q, D, kv, 2 * D, kv[:, D:], 2 * D, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(catt.dp_scale),
@@ -1396,7 +1404,7 @@ class EncoderFusedFn(torch.autograd.Function):
             wg.add(dkv, nk, 2 * D, D, gW[D * D:])                      # (image branch: K / V weights' gradient in the same grouped launch)
         if wg_all is None:
             wg.flush()
-        dnq = linear_dgrad(dq, w16[:D * D], D, D)
+        dnq = None if front_rows else linear_dgrad(dq, w16[:D * D], D, D)
         dxkv = None
         if ctx.kv_ready:
             dxkv = dkv.view(B, Lkv, 2 * D)                              # AdapterKVFn.backward takes it from here
@@ -1406,10 +1414,27 @@ class EncoderFusedFn(torch.autograd.Function):
                 dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16)).view(B, Lkv, D)
             else:
                 layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
-        dx = layernorm_bwd(dnq, base_ca, mq, rq, lnq.weight, lnq.bias, dx1).view(M, D)
+        if front_rows:
+            # dq . Wq -> q LayerNorm' -> + dx1 -> dx, the positional-gradient sum and the LayerNorm's parameter-gradient partials in one
+            # kernel (vpf_ca_front_bwd) instead of a GEMM, two LayerNorm launches and an add
+            dx = torch.empty(M, D, dtype=F32, device=dev)
+            a2 = L.SaLayerBwd()
+            a2.M, a2.D, a2.hidden = M, D, Hd
+            a2.dqkv, a2.WqkvT, a2.base, a2.mean1, a2.rstd1, a2.ln1_g = (dq.data_ptr(), packed[0]["WqT"].data_ptr(), base_ca.data_ptr(), mq.data_ptr(),
+                                                                     rq.data_ptr(), lnq.weight.data.data_ptr())
+            a2.dx1, a2.dbase, a2.pgrad1 = dx1.data_ptr(), dx.data_ptr(), pg[0, 0].data_ptr()
+            a2.dsum, a2.dsum_init = (dsum.data_ptr() if want_pos else None), int(not dsum_started)
+            L.call_struct("vpf_ca_front_bwd", a2)
+            pgrad_job(0, 0, lnq)
+            if npj:
+                L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
+        else:
+            dx = layernorm_bwd(dnq, base_ca, mq, rq, lnq.weight, lnq.bias, dx1).view(M, D)
         dpos = None
         if want_pos:
-            if dsum_started:
+            if front_rows:
+                pass                                                    # (dsum already holds the sum)
+            elif dsum_started:
                 dsum.add_(dx)
             else:
                 dsum = dx.clone()
