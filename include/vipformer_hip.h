@@ -402,6 +402,10 @@ int vpf_sa_layer_bwd_qkv_mlp(const VpfSaLayerBwd* qkv_of_layer, const VpfSaLayer
  * the q LayerNorm's input, statistics and scale; dx1 = the residual's gradient; out: dbase f32 [M, D] (+= into dsum if set), pgrad1.
  * D = 256; VPF_ERR_UNSUPPORTED otherwise. */
 int vpf_ca_front_bwd(const VpfSaLayerBwd* host_args, void* stream);
+/* ... and of its key / value side when the kv input is an f32 [M, D] tensor (CrossAttention.kv_norm + k_proj | v_proj; the image branch:
+ * the point-cloud branch's K / V producer has vpf_adapter_kv_bwd): dqkv = dk | dv bf16 [M, 2D]; WqkvT = vpf_pack_wfrag(transposed = 1) of
+ * the bf16 [2D, D] k | v weights; base / mean1 / rstd1 / ln1_g = the kv LayerNorm's; dx1 may be NULL; out: dbase = dxkv f32 [M, D], pgrad1. */
+int vpf_ca_kv_bwd(const VpfSaLayerBwd* host_args, void* stream);
 /* The front of the point-cloud branch's cross-attention layer in ONE kernel (D = 256): position_emb (partseg.py:498-501:
  * Linear(3,128) GELU Linear(128,D)) on the group centres, base = tokens + pos (Encoder.forward, partseg.py:326), q_norm and the
  * bias-free q projection (partseg.py:100-116, 48-51).  W1 / Wq = vpf_pack_wfrag of the bf16 weights [D,128] / [D,D].

@@ -133,6 +133,7 @@ SIGS = {
     "vpf_sa_layer_bwd_qkv": [VP, VP],
     "vpf_sa_layer_bwd_qkv_mlp": [VP, VP, VP],
     "vpf_ca_front_bwd": [VP, VP],
+    "vpf_ca_kv_bwd": [VP, VP],
     "vpf_ln_pgrad_reduce": [VP, I, VP],
     "vpf_adapter_kv_fwd": [VP, VP],
     "vpf_adapter_kv_bwd": [VP, VP],

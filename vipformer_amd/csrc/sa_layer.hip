@@ -1433,7 +1433,7 @@ __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, con
     for (int it = 0; it < XPT; ++it) {
         const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
         const size_t off = (size_t)(m0 + (row < nvalid ? row : 0)) * SA_D + c4 * 4;
-        dv[it] = *reinterpret_cast<const float4*>(a.dx1 + off);
+        dv[it] = a.dx1 ? *reinterpret_cast<const float4*>(a.dx1 + off) : make_float4(0.f, 0.f, 0.f, 0.f);      // (no residual: vpf_ca_kv_bwd)
         if (a.dsum) sv[it] = a.dsum_init ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(a.dsum + off);
     }
     __syncthreads();
@@ -1490,6 +1490,12 @@ template <int RB>
 __global__ void __launch_bounds__(512) ca_front_bwd_rows_kernel(VpfSaLayerBwd a)
 {
     sa_bwd_qkv_rows_body<RB, false, 1>(a, a);
+}
+// the key / value side of a cross-attention layer, backward: dk | dv . (Wk | Wv) -> kv LayerNorm' -> dxkv (no residual)
+template <int RB>
+__global__ void __launch_bounds__(512) ca_kv_bwd_rows_kernel(VpfSaLayerBwd a)
+{
+    sa_bwd_qkv_rows_body<RB, false, 2>(a, a);
 }
 // qkv backward of layer i and MLP backward of layer i - 1 (the layer below) in one workgroup: b.d == a.dbase
 template <int RB>
@@ -1647,6 +1653,29 @@ extern "C" int vpf_ca_front_bwd(const VpfSaLayerBwd* args, void* stream)
         attr = true;
     }
     hipLaunchKernelGGL((ca_front_bwd_rows_kernel<RB>), dim3(vpf_cdiv((long)a.M, TOK)), dim3(512), lds, (hipStream_t)stream, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// The key / value side of the same layer when its input is an f32 [M, D] tensor (the image branch's patch embeddings; the point-cloud
+// branch's K / V producer has vpf_adapter_kv_bwd): dqkv = dk | dv bf16 [M, 2D], WqkvT = vpf_pack_wfrag(transposed) of the bf16 [2D, D]
+// k | v weights, base / mean1 / rstd1 / ln1_g = the kv LayerNorm's input, statistics, scale; dx1 may be NULL (no residual); dbase = dxkv f32.
+extern "C" int vpf_ca_kv_bwd(const VpfSaLayerBwd* args, void* stream)
+{
+    (void)hipGetLastError();
+    if (!args) return VPF_ERR_NULL;
+    const VpfSaLayerBwd& a = *args;
+    if (a.M <= 0) return VPF_ERR_BADSHAPE;
+    if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
+    if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
+    constexpr int RB = 2, TOK = RB * 32;
+    const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * XLD * 4;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)ca_kv_bwd_rows_kernel<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((ca_kv_bwd_rows_kernel<RB>), dim3(vpf_cdiv((long)a.M, TOK)), dim3(512), lds, (hipStream_t)stream, a);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

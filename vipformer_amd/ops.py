@@ -43,7 +43,7 @@ class OpsConfig:
     The library's own launch-time knobs live in its VpfDebug struct (``_lib.debug_get`` / ``debug_set``)."""
     __slots__ = ("wgrad_async", "wgrad_group", "wgrad_group_async", "wgrad_deterministic", "wgrad_defer", "sa_debug", "sa_split_attn",
                  "sa_fused_bwd", "sa_fused", "enc_bwd_hook", "adapter_kv_fused", "adapter_kv_bwd_fused", "enc_fused", "g2e_bn_merged",
-                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack", "ca_front_bwd_fused")
+                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack", "ca_front_bwd_fused", "ca_kv_bwd_fused")
 
     def __init__(self, env=os.environ):
         self.wgrad_async = False          # weight-gradient GEMMs on a side stream: measured slower (cross-stream event cost > overlap gain)
@@ -61,6 +61,7 @@ class OpsConfig:
         self.enc_fused = True             # cross-attention layer tail fused as well (EncoderFusedFn) when the shapes allow it
         self.ca_front_fused = env.get("VPF_CA_FRONT", "1") == "1"     # position MLP + (tokens + pos) + q_norm + q projection of the point-cloud branch as one kernel
         self.ca_front_bwd_fused = env.get("VPF_CA_FRONT_BWD", "1") == "1"      # the cross-attention layer's query-side backward as one row-block kernel (vpf_ca_front_bwd)
+        self.ca_kv_bwd_fused = env.get("VPF_CA_KV_BWD", "0") == "1"            # ... and its key / value side where the kv input is an f32 tensor (image branch: vpf_ca_kv_bwd; measured: no gain, 3.93 vs 3.94 ms: off)
         self.wgrad_stack = env.get("VPF_WGRAD_STACK", "1") == "1"               # the weight gradients of a whole fused encoder stack as ONE grouped launch at the end of its backward
         self.g2e_bn_merged = env.get("VPF_G2E_BN_MERGED", "1") != "0"          # BatchNorm bookkeeping of Group2Emb as single launches
         self.g2e_conv1_bwd_fused = env.get("VPF_G2E_CONV1_FUSED", "1") == "1"  # conv2 dgrad inside the first conv's backward (tests run both)
@@ -1133,6 +1134,8 @@ def _pack_blocks(blocks, holder, dev, front=None):
             # the cross-attention block: its WqkvT slot holds the transposed q projection alone (vpf_ca_front_bwd)
             v["WqT"] = v["WqkvT"][:D * D]
             todo.append((shadow(qkvw)[:D * D], v["WqT"], D, D, 1))
+            v["WkvT"] = v["WqkvT"][D * D:]                  # ... and the transposed k | v projections (vpf_ca_kv_bwd)
+            todo.append((shadow(qkvw)[D * D:], v["WkvT"], D, 2 * D, 1))
         for src, dst, N, K, tr in todo:
             jobs[n].src, jobs[n].dst, jobs[n].N, jobs[n].K, jobs[n].transposed = src.data_ptr(), dst.data_ptr(), N, K, tr
             n += 1
@@ -1408,6 +1411,21 @@ class EncoderFusedFn(torch.autograd.Function):
         dxkv = None
         if ctx.kv_ready:
             dxkv = dkv.view(B, Lkv, 2 * D)                              # AdapterKVFn.backward takes it from here
+        elif front_rows and cfg.ca_kv_bwd_fused and "WkvT" in packed[0] and xkv.dtype == F32 and ctx.xkv_dtype == F32:
+            # dk | dv . (Wk | Wv) -> kv LayerNorm' -> dxkv in one row-block kernel (vpf_ca_kv_bwd) instead of a GEMM and two LayerNorm launches
+            dxkv = torch.empty(Mk, D, dtype=F32, device=dev)
+            nkw = (Mk + 63) // 64
+            pgkv = torch.empty(nkw * 2 * D, dtype=F32, device=dev)
+            a3 = L.SaLayerBwd()
+            a3.M, a3.D, a3.hidden = Mk, D, Hd
+            a3.dqkv, a3.WqkvT, a3.base, a3.mean1, a3.rstd1, a3.ln1_g = (dkv.data_ptr(), packed[0]["WkvT"].data_ptr(), xkv.data_ptr(), mk.data_ptr(),
+                                                                     rk.data_ptr(), lnkv.weight.data.data_ptr())
+            a3.dx1, a3.dbase, a3.pgrad1, a3.dsum = None, dxkv.data_ptr(), pgkv.data_ptr(), None
+            L.call_struct("vpf_ca_kv_bwd", a3)
+            pjobs[npj].partials, pjobs[npj].rows, pjobs[npj].D = pgkv.data_ptr(), nkw, D
+            pjobs[npj].dgamma, pjobs[npj].dbeta = grad_buf(lnkv.weight).data_ptr(), grad_buf(lnkv.bias).data_ptr()
+            npj += 1
+            dxkv = dxkv.view(B, Lkv, D) if ctx.needs_input_grad[2] else None
         else:
             dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
             if ctx.needs_input_grad[2]:
