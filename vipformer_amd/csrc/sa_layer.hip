@@ -1643,8 +1643,8 @@ extern "C" int vpf_ca_front_bwd(const VpfSaLayerBwd* args, void* stream)
     if (!args) return VPF_ERR_NULL;
     const VpfSaLayerBwd& a = *args;
     if (a.M <= 0) return VPF_ERR_BADSHAPE;
-    if (a.D != SA_D) return VPF_ERR_UNSUPPORTED;
     if (!a.dqkv || !a.WqkvT || !a.base || !a.mean1 || !a.rstd1 || !a.ln1_g || !a.dx1 || !a.dbase || !a.pgrad1) return VPF_ERR_NULL;
+    if (a.D != SA_D) return sa_rows_ca_front_bwd_launch(a, (hipStream_t)stream);      // D = 384; anything else: VPF_ERR_UNSUPPORTED
     constexpr int RB = 2, TOK = RB * 32;
     const size_t lds = (size_t)2 * TOK * ALD * 2 + (size_t)TOK * 8 * 2 * 4 + (size_t)TOK * XLD * 4;
     static VpfPerDevice attr_dev; bool& attr = attr_dev();

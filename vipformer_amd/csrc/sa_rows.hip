@@ -956,7 +956,8 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_mlp_kernel(VpfSa
 }
 
 //   [dqkv] . Wqkv -> LayerNorm-1' (+ dx1) -> [dbase] (+= dsum)
-template <int D, int RB, int TH, int MINW>
+// NP: D-wide parts of the incoming gradient (3: dq | dk | dv against Wqkv^T; 1: the cross-attention layer's dq against Wq^T, vpf_ca_front_bwd)
+template <int D, int RB, int TH, int MINW, int NP = 3>
 __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_qkv_kernel(VpfSaLayerBwd a)
 {
     using C = Cfg<D, RB, TH>;
@@ -973,18 +974,18 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_qkv_kernel(VpfSa
     float* slice = (C::XDED ? xded : reinterpret_cast<float*>(buf1)) + wave * 1024;      // buf1 is free once the last part is staged
 
     WRing<PD> ring;
-    ring_fill<PD>((const bf16_t*)a.WqkvT, 3 * KS, 0, cw, ring);
-    tile_load_rows<C>(buf0, (const bf16_t*)a.dqkv + m0 * (3 * D), 3 * D, nvalid);
+    ring_fill<PD>((const bf16_t*)a.WqkvT, NP * KS, 0, cw, ring);
+    tile_load_rows<C>(buf0, (const bf16_t*)a.dqkv + m0 * (NP * D), NP * D, nvalid);
     __syncthreads();
     f32x16_t acc[RB];
     zero<RB>(acc);
 #pragma unroll
-    for (int part = 0; part < 3; ++part) {
+    for (int part = 0; part < NP; ++part) {
         // (the next part is staged behind this part's product: the other buffer is free -- every wave passed the last barrier)
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.WqkvT, 3 * KS, part * KS, cw, (part & 1) ? buf1 : buf0, ALD, tb0, acc, ring);
-        if (part + 1 < 3) {
-            ring_fill<PD>((const bf16_t*)a.WqkvT, 3 * KS, (part + 1) * KS, cw, ring);
-            tile_load_rows<C>((part & 1) ? buf0 : buf1, (const bf16_t*)a.dqkv + m0 * (3 * D) + (part + 1) * D, 3 * D, nvalid);
+        gemm_unit<RB, KS, PD>((const bf16_t*)a.WqkvT, NP * KS, part * KS, cw, (part & 1) ? buf1 : buf0, ALD, tb0, acc, ring);
+        if (part + 1 < NP) {
+            ring_fill<PD>((const bf16_t*)a.WqkvT, NP * KS, (part + 1) * KS, cw, ring);
+            tile_load_rows<C>((part & 1) ? buf0 : buf1, (const bf16_t*)a.dqkv + m0 * (NP * D) + (part + 1) * D, NP * D, nvalid);
             __syncthreads();
         }
     }
@@ -1085,6 +1086,26 @@ int sa_rows_bwd_mlp_launch(const VpfSaLayerBwd& a, hipStream_t st)
 {
     if (a.D == 256 && a.hidden == 512) return bwd_mlp_launch<256, 512, 1, 2, 4>(a, st);      // 16 waves x 32 tokens each (the 8-wave x 64 shape spills at 128 registers)
     if (a.D == 384 && a.hidden == 1536) return vpf_debug().sa_rb == 2 ? bwd_mlp_launch<384, 1536, 2, 1, 3>(a, st) : bwd_mlp_launch<384, 1536, 1, 1, 3>(a, st);
+    return VPF_ERR_UNSUPPORTED;
+}
+template <int D, int RB, int TH, int MINW>
+static int ca_front_bwd_launch(const VpfSaLayerBwd& a, hipStream_t st)
+{
+    using C = Cfg<D, RB, TH>;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)sa_rows_bwd_qkv_kernel<D, RB, TH, MINW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    const size_t lds = bwd_lds<D, RB, TH>();
+    hipLaunchKernelGGL((sa_rows_bwd_qkv_kernel<D, RB, TH, MINW, 1>), dim3(vpf_cdiv((long)a.M, C::TOK)), dim3(C::NT), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+// the cross-attention layer's query-side backward at D = 384 (partial rows per 32 tokens, like the other D = 384 backward kernels)
+int sa_rows_ca_front_bwd_launch(const VpfSaLayerBwd& a, hipStream_t st)
+{
+    if (a.D == 384 && vpf_debug().sa_rb != 2) return ca_front_bwd_launch<384, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
 }
 int sa_rows_bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st)

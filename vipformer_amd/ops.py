@@ -1386,8 +1386,8 @@ class EncoderFusedFn(torch.autograd.Function):
         a = L.SaLayerBwd()
         dz2, du, dx1, dz1, do = bwd_mlp(a, (catt, cmlp), ca[0], ca[1], packed[0], d, u, x1, m2, r2, 0)
         pgrad_job(0, 1, cmlp[0])
-        front_rows = (D == 256 and cfg.ca_front_bwd_fused and "WqT" in packed[0]       # the query side as one row-block kernel below
-                      and nwg == (M + 63) // 64)                                          # (its partial rows: one per 64 tokens)
+        front_rows = (cfg.ca_front_bwd_fused and "WqT" in packed[0]                    # the query side as one row-block kernel below
+                      and ((D == 256 and nwg == (M + 63) // 64) or (D == 384 and nwg == (M + 31) // 32)))      # (its partial rows: one per 64 / 32 tokens)
         if npj and not front_rows:
             L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
             npj = 0
