@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long row0 = pr * 64;
         const long nrows = min((long)64, p.NG * 32 - row0);
+        const int nrows_i = (int)nrows;
         // ---- stage dh4 (virtual) : thread = (group gi, 8-channel chunk ch, slice of 4 members)
         {
             const int gi = t >> 8, ch = (t >> 3) & 31, sl = t & 7;
@@ -695,11 +696,15 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
                 const float xh = (bf16_to_f32(hraw[r]) - mean) * rstd;
                 float g = bf16_to_f32(f32_to_bf16(acc[rt][r]));            // da3 is a bf16 tensor in the unfused path
-                if (xh * ga + be <= 0.f || row >= nrows) g = 0.f;
+                // (one select on a 32-bit predicate: written as `a || b` with the 64-bit row count this was a branch, two exec-mask
+                // sequences, a 64-bit compare and a scratch reload of the count PER ELEMENT -- 862 of the kernel's 1 511 VALU instructions
+                // were moves)
+                const bool dead = (xh * ga + be <= 0.f) | (row >= nrows_i);
+                g = dead ? 0.f : g;
                 if (PASS == 0) { a0 += g; a1 += g * xh; }
                 else {
                     const float dv = p.training ? ga * rstd * (g - sg - xh * sgx) : ga * rstd * g;
-                    const bf16_t db = (row < nrows) ? f32_to_bf16(dv) : (bf16_t)0;
+                    const bf16_t db = (row < nrows_i) ? f32_to_bf16(dv) : (bf16_t)0;
                     dres[r] = db;
                     gsum[rt] += bf16_to_f32(db);
                 }
