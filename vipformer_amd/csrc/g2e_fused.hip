@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
     request(blockIdx.x);
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long row0 = pr * 64;                                   // first of 64 rows
-        const long nrows = min((long)64, p.NG * 32 - row0);          // 64, or 32 for an odd tail
+        const int nrows = (int)min((long)64, p.NG * 32 - row0);          // 64, or 32 for an odd tail
         // ---- conv1 + BN1 + ReLU -> a1 (LDS + HBM)
         {
             uint4 o = make_uint4(0, 0, 0, 0);
@@ -148,7 +148,8 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
                     const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
                     const bf16_t hb = f32_to_bf16(acc[rt][r] + b3v);
                     sH3[row * H3LD + w * 32 + l31] = hb;
-                    if (row < nrows) { const float hv = bf16_to_f32(hb); ssum += hv; ssq += hv * hv; }
+                    const float hv = row < nrows ? bf16_to_f32(hb) : 0.f;          // (a select, not a branch per element)
+                    ssum += hv; ssq += hv * hv;
                 }
         }
         __syncthreads();
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
     request(blockIdx.x);
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long row0 = pr * 64;
-        const long nrows = min((long)64, p.NG * 32 - row0);
+        const int nrows = (int)min((long)64, p.NG * 32 - row0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = t + i * 512, row = c >> 5, ch = c & 31;
@@ -631,8 +632,8 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     if (p.dbg) t0 = clock64();
     for (long pr = blockIdx.x; pr < npairs; pr += gridDim.x) {
         const long row0 = pr * 64;
-        const long nrows = min((long)64, p.NG * 32 - row0);
-        const int nrows_i = (int)nrows;
+        const int nrows = (int)min((long)64, p.NG * 32 - row0);
+        const int nrows_i = nrows;
         // ---- stage dh4 (virtual) : thread = (group gi, 8-channel chunk ch, slice of 4 members)
         {
             const int gi = t >> 8, ch = (t >> 3) & 31, sl = t & 7;
@@ -681,7 +682,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             }
         STAMP(1);
         load_d4(pr + gridDim.x);
-        if (PASS == 0) load_h3(pr + gridDim.x);
+        if (PASS == 0) load_h3(pr + gridDim.x);        // (requested in front of the MFMAs instead: 198 k -> 214 k cycles per workgroup, measured again in round 3)
         float gsum[2] = {0.f, 0.f};
         // one row tile at a time: its 16 h3 values of this lane first (independent LDS reads in flight together), then the
         // math, then the stores (both row tiles at once held 64 registers here and the kernel spilled)
