@@ -383,6 +383,15 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     const int L = a.L;
     const long mseq = (long)b * L;                    // first row of the sequence
     const long m0 = ATT ? mseq + (long)chunk * a.chunk_rows : (long)blockIdx.x * TOK;   // first row of this workgroup
+    // row of the positional table for block row r: (m0 + r) % pos_rows.  The 64-bit modulo is taken ONCE per workgroup (m0 is uniform);
+    // per row it is an add and -- the table has at least as many rows as a block in every shipped configuration -- one conditional
+    // subtraction (as `(m0 + row) % pos_rows` it was a 64-bit software division in front of each of a thread's 10 positional loads)
+    const int pos_m0 = a.pos ? (int)(m0 % (long)a.pos_rows) : 0;
+    auto pos_row = [&](int r) -> int {
+        int pr = pos_m0 + r;
+        if (a.pos_rows >= TOK) return pr >= a.pos_rows ? pr - a.pos_rows : pr;
+        return pr % a.pos_rows;
+    };
     const int nvalid = ATT ? min(a.chunk_rows, L - chunk * a.chunk_rows) : (int)min((long)TOK, (long)a.B * L - m0);
     const bf16_t* qkv = (const bf16_t*)a.qkv;
     long long t0_ = 0, t1_;
@@ -575,7 +584,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
         for (int it = 0; it < XPT; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
-            pv[it] = (a.pos && row < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)((m0 + row) % a.pos_rows) * SA_D + c4 * 4)
+            pv[it] = (a.pos && row < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)pos_row(row) * SA_D + c4 * 4)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
@@ -598,7 +607,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     float4 resx[XR ? 1 : NJ][XR ? 1 : 4][XR ? 1 : RB], resp[XR ? 1 : NJ][XR ? 1 : 4][XR ? 1 : RB];
     int prow[RB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) prow[i] = a.pos ? (int)((m0 + i * 32 + t) % a.pos_rows) : 0;
+    for (int i = 0; i < RB; ++i) prow[i] = a.pos ? pos_row(i * 32 + t) : 0;
     auto load_final = [&]() {
         if constexpr (XR) return;
         else {

@@ -705,7 +705,8 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* _
                 const float4 xr = sXrow[wave][row];
                 const float xh = wr[j][0] * xr.x + wr[j][1] * xr.y + wr[j][2] * xr.z + br[j];
                 float g = sAcc[r * 64 + lane];
-                if (xh * ga[j] + be[j] <= 0.f || row >= nrows) g = 0.f;
+                const bool dead = (xh * ga[j] + be[j] <= 0.f) | (row >= nrows);      // (one select; `a || b` is a branch per row here)
+                g = dead ? 0.f : g;
                 a0[j] += g; a1[j] += g * xh; aw[j][0] += g * xr.x; aw[j][1] += g * xr.y; aw[j][2] += g * xr.z;
             }
         }
