@@ -134,9 +134,15 @@ __device__ __forceinline__ RowOff pos_offsets(int tb, int cw, long m0, int pos_r
 {
     const unsigned lane = fresh_tid() & 63;
     RowOff po;
+    // one modulo per call on the (uniform) block start; per row an add and a conditional subtraction when the table has at least a
+    // block's rows (every shipped configuration), a 32-bit modulo otherwise
+    const uint32_t base = (uint32_t)((m0 + tb * 32) % (long)pos_rows), pr = (uint32_t)pos_rows;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
-        po.o[it] = ((uint32_t)(m0 + tb * 32 + 8 * it + (lane >> 3)) % (uint32_t)pos_rows) * D + 32 * cw + 4 * (lane & 7);
+    for (int it = 0; it < 4; ++it) {
+        uint32_t r = base + 8 * it + (lane >> 3);
+        r = pr >= 32u ? (r >= pr ? r - pr : r) : r % pr;
+        po.o[it] = r * D + 32 * cw + 4 * (lane & 7);
+    }
     po.ok = have ? ro.ok : 0u;
     return po;
 }
