@@ -181,6 +181,37 @@ def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
         assert r < 1.5e-2, f"{name} rel {r}"                                 # bf16 P/dS operands + bf16 outputs
 
 
+@pytest.mark.parametrize("B,H,Lq,Lkv", [(2, 4, 196, 196), (2, 2, 96, 1024), (1, 2, 300, 520), (2, 4, 128, 128)])
+def test_attention_dropout_32bit_group_index_equals_64bit_bitwise(B, H, Lq, Lkv):
+    """The attention kernels index the dropout hash with 32-bit group numbers when B*H*Lq*Lkv < 2^32 (VPF_ATTN_RNG32, default on);
+    the masks -- hence o, lse, dq, dk, dv -- must be bit-identical to the 64-bit indexing (which the exported mask uses)."""
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    D = 64 * H
+    q16, k16, v16, do16 = bf(rnd(1, B, Lq, D)), bf(rnd(2, B, Lkv, D)), bf(rnd(3, B, Lkv, D)), bf(rnd(4, B, Lq, D))
+    site, scale, p = ops.new_site(), 64 ** -0.5, 0.1
+    st = ops.rng.state("cuda")
+
+    def run(flag):
+        L.debug_set("attn_rng32", flag)
+        try:
+            o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+            lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
+            L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse)
+            dq = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+            dk = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+            dv = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+            L.call("vpf_attention_bwd", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
+                   dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"))
+            torch.cuda.synchronize()
+            return o, lse, dq, dk, dv
+        finally:
+            L.debug_set("attn_rng32", 1)
+
+    for name, a, b in zip(("o", "lse", "dq", "dk", "dv"), run(0), run(1)):
+        assert torch.equal(a, b), name
+
+
 @pytest.mark.parametrize("B,H,Lq,Lkv,p", [(3, 2, 40, 70, 0.0), (2, 2, 96, 1024, 0.1), (3, 4, 196, 196, 0.1), (2, 1, 33, 300, 0.5), (3, 2, 96, 96, 0.0)])
 def test_attention_pad_mask_fwd_bwd(B, H, Lq, Lkv, p):
     """vpf_attention_fwd_pad / _bwd_pad (partseg.py:73-77: masked_fill_(pad_mask, -finfo.max) in front of the softmax) against torch

@@ -43,6 +43,9 @@ struct AttnArgs {
     bf16_t* dQ; bf16_t* dK; bf16_t* dV; long lddq, lddk, lddv;
     // optional key padding mask [B, Lkv], non-zero = padding key (partseg.py:73-76).  Only the tiled kernels read it.
     const uint8_t* pad;
+    // 1: the score tensor has fewer than 2^32 elements and Lkv % 4 == 0 -- dropout groups are indexed in 32 bits and always aligned
+    // (vpf_keep4_32: the same masks as the 64-bit path, ~7 VALU instructions fewer per group of four scores)
+    int rng_fast;
 };
 // A padded key's score is the most negative finite float, as masked_fill_(pad_mask, -finfo.max) leaves it: exp() of it is 0 beside any
 // real key, and a row whose keys are ALL padded comes out uniform over its Lkv keys.  Such a row's log-sum-exp (~ -2.4e38) cannot carry
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
             float pv[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const uint32_t keep = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;   // keys kv0 + 8 g4 + 4 hl + 0..3
+                const uint32_t keep = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl))) : 15u;   // keys kv0 + 8 g4 + 4 hl + 0..3
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
@@ -341,7 +344,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
         float pv[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const uint32_t keep = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;
+            const uint32_t keep = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl))) : 15u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int r = 4 * g4 + e;
@@ -422,6 +425,7 @@ static int attention_fwd(const void* q, long ldq, const void* k, long ldk, const
     if (head_dim != DH) return VPF_ERR_UNSUPPORTED;
     AttnArgs a = {};
     a.pad = pad;
+    a.rng_fast = vpf_debug().attn_rng32 && ((unsigned long long)B * (unsigned long long)H * (unsigned long long)Lq * (unsigned long long)Lkv < (1ull << 32)) && (Lkv % 4 == 0);
     a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.O = (bf16_t*)out; a.ldo = ldo; a.LSE = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
     a.rng = rng_state; a.site = site; a.p = dropout_p;
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
             float ds[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const uint32_t kbits = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kvs + 8 * g4 + 4 * hl)) : 15u;
+                const uint32_t kbits = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kvs + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kvs + 8 * g4 + 4 * hl))) : 15u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
@@ -681,7 +685,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
             const bool quad_ok = (a.Lkv & 3) == 0;
             if (drop && quad_ok) {
                 const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
-                grp = vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
+                grp = a.rng_fast ? vpf_rand4x16_32(rng, (((uint32_t)bh * a.Lq + (uint32_t)qh) * (uint32_t)a.Lkv + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
             }
             uint32_t gw[4];
             {
@@ -857,7 +861,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             float ds[16];
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const uint32_t kbits = drop ? vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl)) : 15u;
+                const uint32_t kbits = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl))) : 15u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
@@ -915,7 +919,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                 uint2 grp = make_uint2(0u, 0u);
                 if (drop && quad_ok) {
                     const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
-                    grp = vpf_rand4x16(rng, (((uint64_t)bh * L + (uint64_t)qh) * (uint64_t)L + (uint64_t)kv) >> 2);
+                    grp = a.rng_fast ? vpf_rand4x16_32(rng, (((uint32_t)bh * L + (uint32_t)qh) * (uint32_t)L + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * L + (uint64_t)qh) * (uint64_t)L + (uint64_t)kv) >> 2);
                 }
                 uint32_t gw[4];
                 {
@@ -1057,7 +1061,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
             uint2 grp = make_uint2(0u, 0u);
             if (drop && quad_ok) {
                 const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
-                grp = vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
+                grp = a.rng_fast ? vpf_rand4x16_32(rng, (((uint32_t)bh * a.Lq + (uint32_t)qh) * (uint32_t)a.Lkv + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
             }
             uint32_t gw[4];
             {
@@ -1156,6 +1160,7 @@ static int attention_bwd(const void* q, long ldq, const void* k, long ldk, const
     if (head_dim != DH) return VPF_ERR_UNSUPPORTED;
     AttnArgs a = {};
     a.pad = pad;
+    a.rng_fast = vpf_debug().attn_rng32 && ((unsigned long long)B * (unsigned long long)H * (unsigned long long)Lq * (unsigned long long)Lkv < (1ull << 32)) && (Lkv % 4 == 0);
     a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
     a.O = (bf16_t*)out; a.ldo = ldo; a.LSE = (float*)lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
     a.rng = rng_state; a.site = site; a.p = dropout_p;

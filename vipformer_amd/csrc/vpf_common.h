@@ -43,6 +43,7 @@ struct VpfDebug {
     int sa_bwd_rows;        // VPF_SA_BWD_ROWS       1: row-coalesced backward row-block kernels
     int smallk_rpb;         // VPF_SMALLK_RPB        rows per block of the K = 3 front kernels (0: default)
     int sa_wg2;             // VPF_SA_WG2            bit 0 / bit 1: the round-3 forward / backward row-block kernels (sa_rows.hip) also at D = 256 (measured slower in the step: 0)
+    int attn_rng32;         // VPF_ATTN_RNG32        1: 32-bit dropout group indices in the attention kernels when the score tensor allows it (same masks)
     int sa_bwd_fuse;        // VPF_SA_BWD_FUSE       1: qkv backward of a layer + MLP backward of the layer below as one launch (vpf_sa_layer_bwd_qkv_mlp), 0: two
     int wgroup_xlist;       // VPF_WGROUP_XLIST      1: every (problem, K slice) of a grouped weight gradient on ONE XCD when the slices are few (0: plain order)
     int sa_rb;              // VPF_SA_RB             geometry of those kernels at D = 256: 12 = 16 waves x 32 tokens each (default), 2 = 8 waves x 64, 1 = 8 waves x 32
@@ -210,6 +211,20 @@ __device__ __forceinline__ uint2 vpf_rand4x16(const VpfRng& r, uint64_t g)
     uint32_t w0 = a * 0x9E3779B1u; w0 ^= w0 >> 15;
     uint32_t w1 = (a ^ 0x85ebca6bu) * 0xC2B2AE3Du; w1 ^= w1 >> 16;
     return make_uint2(w0, w1);
+}
+// the same four uniforms for a group index that fits 32 bits (hi = 0 in vpf_rand4x16: identical values, no 64-bit index arithmetic)
+__device__ __forceinline__ uint2 vpf_rand4x16_32(const VpfRng& r, uint32_t g)
+{
+    uint32_t a = vpf_hash32(g ^ r.k0) + r.k1;
+    uint32_t w0 = a * 0x9E3779B1u; w0 ^= w0 >> 15;
+    uint32_t w1 = (a ^ 0x85ebca6bu) * 0xC2B2AE3Du; w1 ^= w1 >> 16;
+    return make_uint2(w0, w1);
+}
+__device__ __forceinline__ uint32_t vpf_keep4_32(const VpfRng& r, uint32_t g)
+{
+    const uint2 w = vpf_rand4x16_32(r, g);
+    return ((w.x & 0xffffu) >= r.thresh ? 1u : 0u) | ((w.x >> 16) >= r.thresh ? 2u : 0u) |
+           ((w.y & 0xffffu) >= r.thresh ? 4u : 0u) | ((w.y >> 16) >= r.thresh ? 8u : 0u);
 }
 // bit e of the result = element 4g + e is KEPT
 __device__ __forceinline__ uint32_t vpf_keep4(const VpfRng& r, uint64_t g)
