@@ -146,7 +146,7 @@ def kernel_legs(device, a, pairs):
         legs[f"{kn} ({tag})"] = _leg(kn, us, io_f, fl, "mfma", f"{tag}: B {Bq} H {H} Lq {Lq} Lkv {Lkv} dh 64, dropout 0.1")
         us = _events(lambda: L.call("vpf_attention_bwd", q, D, k, D, v, D, o, D, do, D, lse, Bq, H, Lq, Lkv, 64, 0.125, 0.1, st, 7,
                                     dq, D, dk, D, dv, D, dl), 20, 3)
-        kn = "attn_bwd_dq/dkv_kernel" if Lkv > 224 else "attn_res_bwd_kernel"
+        kn = "attn_bwd_dq/dkv_kernel" if Lkv > 224 else "attn_res_bwd_kernel"      # (attn_bwd_ca_kernel when B * H >= 512)
         legs[f"{kn} ({tag})"] = _leg(kn, us, 2.0 * D * (4 * Bq * Lq + 4 * Bq * Lkv), 2.5 * fl, "mfma", f"{tag} backward")
     # ---- grouped weight gradients of one encoder layer: dW = dY^T X for fc2, fc1, o_proj, qkv over M tokens
     Hd = a["MR"] * D
@@ -179,7 +179,43 @@ def kernel_legs(device, a, pairs):
     per_row = 28 * D + 4 * Hd + 16
     legs["sa_layer_fwd_kernel"] = _leg("sa_layer_fwd_kernel" if D == 256 else "sa_rows_fwd_kernel", us, float(per_row) * M,
                                        2.0 * D * (D + 2 * Hd + 3 * D) * M, "hbm", f"fused encoder-layer tail, {M} tokens x {D} channels")
+    if D == 256:
+        legs["sa_bwd_qkv_mlp_rows_kernel"] = _bwd_rows_leg(device, layers, packed, st, M, D, Hd, g)
     return legs
+
+
+def _bwd_rows_leg(device, layers, packed, st, M, D, Hd, g):
+    """vpf_sa_layer_bwd_qkv_mlp stand-alone: the qkv half of layer 1's backward and the MLP half of layer 0's in one launch
+    (csrc/sa_layer.hip).  Per token it reads dqkv (bf16 3D), base, the upper dx1, the running positional sum and the lower x1 (f32 D
+    each), u (bf16 hidden) and four LayerNorm statistics; it writes dbase, dsum, dx1 (f32 D), dz2, dz1, dout (bf16 D) and du (bf16
+    hidden): 40 D + 4 hidden + 16 bytes.  Flops: dqkv.Wqkv (3D x D), d.W2 (D x hidden), du.W1 (hidden x D), dz1.Wo (D x D)."""
+    import ctypes
+    from vipformer_amd import _lib, ops
+    rn = lambda *sh: torch.randn(*sh, generator=g).to(device)
+    u = rn(M, Hd).bfloat16(); x1 = rn(M, D); base = rn(M, D); dqkv = (0.1 * rn(M, 3 * D)).bfloat16(); dx1_up = rn(M, D)
+    m2 = x1.mean(1).contiguous(); r2 = (x1.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    m1 = base.mean(1).contiguous(); r1 = (base.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    up, low = layers[1], layers[0]
+    f32 = lambda *sh: torch.empty(*sh, device=device)
+    b16 = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=device)
+    out = dict(dbase=f32(M, D), dsum=torch.zeros(M, D, device=device), dz2=b16(M, D), du=b16(M, Hd), dx1=f32(M, D), dz1=b16(M, D), do=b16(M, D))
+    pg = torch.zeros(2, ops.pgrad_rows(M, D) * 2 * D, device=device)
+    a = _lib.SaLayerBwd()
+    a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
+    a.dqkv, a.WqkvT, a.base, a.mean1, a.rstd1, a.ln1_g = (dqkv.data_ptr(), packed[1]["WqkvT"].data_ptr(), base.data_ptr(), m1.data_ptr(),
+                                                         r1.data_ptr(), up[0].module.norm.weight.data.data_ptr())
+    a.dx1, a.dbase, a.dsum, a.dsum_init, a.pgrad1 = dx1_up.data_ptr(), out["dbase"].data_ptr(), out["dsum"].data_ptr(), 0, pg[0].data_ptr()
+    b = _lib.SaLayerBwd()
+    b.M, b.D, b.hidden, b.rng = M, D, Hd, st.data_ptr()
+    b.p_res1, b.site_res1, b.p_res2, b.site_res2 = 0.5, low[0].site, 0.5, low[1].site
+    b.d, b.u, b.x1, b.mean2, b.rstd2, b.ln2_g = (out["dbase"].data_ptr(), u.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(),
+                                                 low[1].module[0].weight.data.data_ptr())
+    b.W2T, b.W1T, b.WoT = packed[0]["W2T"].data_ptr(), packed[0]["W1T"].data_ptr(), packed[0]["WoT"].data_ptr()
+    b.dz2, b.du, b.dx1, b.dz1, b.dout_attn = (out[k].data_ptr() for k in ("dz2", "du", "dx1", "dz1", "do"))
+    b.pgrad2 = pg[1].data_ptr()
+    us = _events(lambda: _lib.call_struct("vpf_sa_layer_bwd_qkv_mlp", a, ctypes.addressof(b)), 20, 3)
+    return _leg("sa_bwd_qkv_mlp_rows_kernel", us, float(40 * D + 4 * Hd + 16) * M, 2.0 * D * (3 * D + 2 * Hd + D) * M, "hbm",
+                f"fused encoder-layer backward (qkv half of layer l + MLP half of layer l-1), {M} tokens x {D} channels")
 
 
 def _step_profile(arch):
@@ -203,8 +239,9 @@ PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step budget
     "knn_group_select_kernel": ["knn_group_select_kernel"],
     "gemm_wgrad_group_kernel": ["gemm_wgrad_group_kernel"],
     "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel", "sa_rows_fwd_kernel"],
+    "sa_bwd_qkv_mlp_rows_kernel": ["sa_bwd_qkv_mlp_rows_kernel"],
     "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel<3, 128>", "attn_fwd_kernel<4, 128>"],
-    "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel<3, 128>", "attn_bwd_dq_kernel<4, 128>", "attn_bwd_dkv"],
+    "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel<3, 128>", "attn_bwd_dq_kernel<4, 128>", "attn_bwd_dkv", "attn_bwd_ca_kernel"],
     "attn_res_fwd_kernel (self-attention pc)": ["attn_res_fwd_kernel<3>", "attn_res_fwd_kernel<4>"],
     "attn_res_fwd_kernel (self-attention img)": ["attn_res_fwd_kernel<7>"],
     "attn_res_bwd_kernel (self-attention pc)": ["attn_res_bwd_kernel<3>", "attn_res_bwd_kernel<4>"],

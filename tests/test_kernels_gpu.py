@@ -181,6 +181,43 @@ def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
         assert r < 1.5e-2, f"{name} rel {r}"                                 # bf16 P/dS operands + bf16 outputs
 
 
+@pytest.mark.parametrize("B,H,Lq,Lkv,p", [(2, 2, 96, 1024, 0.1), (1, 2, 128, 1024, 0.1), (2, 1, 80, 1000, 0.1), (1, 1, 70, 518, 0.1),
+                                          (1, 2, 96, 512, 0.0), (3, 1, 33, 640, 0.5)])
+def test_attention_bwd_one_kernel_equals_two_bitwise(B, H, Lq, Lkv, p):
+    """attn_bwd_ca_kernel (few queries, many keys: dQ, dK, dV in one kernel, the queries resident, dQ accumulated over key tiles by the
+    wave that owns the query block) against attn_bwd_dq_kernel + attn_bwd_dkv_resq_kernel (VPF_ATTN_CA_MERGED = 0): same products in
+    the same order at the same rounding points -- bit-identical gradients, ragged query and key counts and the unaligned-dropout
+    fallback (Lkv % 4 != 0) included."""
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    D = 64 * H
+    q16, k16, v16, do16 = bf(rnd(1, B, Lq, D)), bf(rnd(2, B, Lkv, D)), bf(rnd(3, B, Lkv, D)), bf(rnd(4, B, Lq, D))
+    site, scale = ops.new_site(), 64 ** -0.5
+    st = ops.rng.state("cuda")
+    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
+    L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse)
+
+    def run(flag):
+        L.debug_set("attn_ca_merged", flag)
+        try:
+            dq = torch.full((B * Lq, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+            dk = torch.full((B * Lkv, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+            dv = torch.full((B * Lkv, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+            L.call("vpf_attention_bwd", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
+                   dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"))
+            torch.cuda.synchronize()
+            return dq, dk, dv
+        finally:
+            L.debug_set("attn_ca_merged", 512)
+
+    two, one, again = run(0), run(1), run(1)
+    for name, a, b, c in zip(("dq", "dk", "dv"), two, one, again):
+        assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 0, name
+        assert torch.equal(b, c), ("not reproducible", name)
+        assert torch.equal(a, b), (name, rel(b.float(), a.float()))
+
+
 @pytest.mark.parametrize("B,H,Lq,Lkv", [(2, 4, 196, 196), (2, 2, 96, 1024), (1, 2, 300, 520), (2, 4, 128, 128)])
 def test_attention_dropout_32bit_group_index_equals_64bit_bitwise(B, H, Lq, Lkv):
     """The attention kernels index the dropout hash with 32-bit group numbers when B*H*Lq*Lkv < 2^32 (VPF_ATTN_RNG32, default on);

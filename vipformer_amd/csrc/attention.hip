@@ -1115,9 +1115,238 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
     }
 }
 
+// dQ, dK and dV of a cross-attention with FEW queries and MANY keys in ONE kernel (96 / 128 latents against 1024 points): a
+// workgroup owns one (cloud, head), keeps its Q and dO tiles, lse and delta (computed here from dO and O) resident and walks the
+// keys in tiles of 128.  Phase A of a tile is attn_bwd_dkv_resq_kernel's body (a wave owns 32 keys; S and dP with the key on the
+// lane; dV^T += dO^T . P, dK^T += Q^T . dS), and leaves the tile's bf16 dS in LDS as [key][query] beside the K tile.  Phase B: wave w
+// owns query block w and adds K^T . dS^T over the tile's 128 keys into its dQ^T accumulators (both operands by transposing LDS reads,
+// in the k order attn_bwd_dq_kernel uses) -- no cross-wave reduction, no atomics; S, dP, the exponentials and the dropout hash are
+// computed once instead of twice and K / V cross HBM once.  Same arithmetic and rounding points as the two kernels it replaces.
+template <int QB>
+__global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
+{
+    constexpr int NW = 4, NT = NW * 64, QPT = QB * 32, KT = NW * 32, DLD = QPT + 8;
+    constexpr int NCH = 2 * QPT * 8, CPT = (NCH + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
+    bf16_t* sQ = sm;                                  // [QPT][KLD]
+    bf16_t* sD = sQ + QPT * KLD;                      // [QPT][KLD]  dO
+    bf16_t* sK = sD + QPT * KLD;                      // [KT][KLD]   this tile's keys
+    bf16_t* sT = sK + KT * KLD;                       // [KT][DLD]   this tile's dS, [key][query]
+    float* sL = reinterpret_cast<float*>(sT + KT * DLD);
+    float* sDel = sL + QPT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, kl = lane & 31;
+    const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
+    {
+        uint4 rr[CPT];
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % QPT, which = (e >> 3) / QPT;
+            rr[it] = make_uint4(0, 0, 0, 0);
+            if (e < NCH && row < a.Lq) {
+                const size_t gr = (size_t)b * a.Lq + row;
+                const bf16_t* src = which == 0 ? a.Q + gr * a.ldq : a.dO + gr * a.lddo;
+                rr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
+            }
+        }
+        if (wave < QB) {                               // delta[q] = rowsum(dO * O), summed as attn_bwd_dq_kernel sums it
+            const int q = wave * 32 + kl;
+            const bool qok = q < a.Lq;
+            const size_t row = (size_t)b * a.Lq + (qok ? q : 0);
+            const bf16_t* dp = a.dO + row * a.lddo + hd * DH + 8 * hl;
+            const bf16_t* op = a.O + row * a.ldo + hd * DH + 8 * hl;
+            float delta = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 ud = ld16_or_zero(dp + ks * 16, qok), uo = ld16_or_zero(op + ks * 16, qok);
+                const uint32_t dw[4] = {ud.x, ud.y, ud.z, ud.w}, ow[4] = {uo.x, uo.y, uo.z, uo.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    delta += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16);
+                    delta += __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+                }
+            }
+            delta += __shfl_xor(delta, 32, 64);
+            if (hl == 0) {
+                sDel[q] = qok ? delta : 0.f;
+                sL[q] = qok ? a.LSE[(size_t)bh * a.Lq + q] * LOG2E : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < CPT; ++it) {
+            const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % QPT, which = (e >> 3) / QPT;
+            if (e < NCH) *reinterpret_cast<uint4*>(sQ + (which * QPT + row) * KLD + ch * 8) = rr[it];
+        }
+    }
+    const float c = a.scale * LOG2E;
+    const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
+    const bool drop = a.p > 0.f;
+    const bool quad_ok = (a.Lkv & 3) == 0;
+    const int nt = (a.Lkv + KT - 1) / KT;
+    const bool bwave = wave < QB && wave * 32 < a.Lq;  // this wave owns a query block in phase B
+    f32x16_t dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    bf16x8_t kf[4], vf[4];
+    {
+        const int kv = wave * 32 + kl;
+        const bool kvok = kv < a.Lkv;
+        const size_t row = (size_t)b * a.Lkv + (kvok ? kv : 0);
+        const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+        const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, kvok));
+            vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, kvok));
+        }
+    }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int kv = t * KT + wave * 32 + kl;
+        const bool kvok = kv < a.Lkv;
+        bf16_t* myK = sK + (wave * 32 + kl) * KLD + 8 * hl;
+        bf16_t* myT = sT + (wave * 32 + kl) * DLD + 4 * hl;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<uint4*>(myK + ks * 16) = __builtin_bit_cast(uint4, kf[ks]);
+        f32x16_t dk[2], dv[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
+        // ---- phase A  (rolled: unrolled over the query blocks the live set passes 256 registers)
+#pragma unroll 1
+        for (int q0 = 0; q0 < QPT; q0 += 32) {
+            if (q0 >= a.Lq) break;
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp, 0, 0, 0);
+            }
+            float pd[16], ds[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                uint2 grp = make_uint2(0u, 0u);
+                if (drop && quad_ok) {
+                    const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
+                    grp = a.rng_fast ? vpf_rand4x16_32(rng, (((uint32_t)bh * a.Lq + (uint32_t)qh) * (uint32_t)a.Lkv + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
+                }
+                uint32_t gw[4];
+                {
+                    const uint32_t mine = (lane & 2) ? 1u : 0u;
+                    const uint32_t x0 = quad_bcast<0>(grp.x), x1 = quad_bcast<1>(grp.x), x2 = quad_bcast<2>(grp.x), x3 = quad_bcast<3>(grp.x);
+                    const uint32_t y0 = quad_bcast<0>(grp.y), y1 = quad_bcast<1>(grp.y), y2 = quad_bcast<2>(grp.y), y3 = quad_bcast<3>(grp.y);
+                    gw[0] = mine ? y0 : x0; gw[1] = mine ? y1 : x1; gw[2] = mine ? y2 : x2; gw[3] = mine ? y3 : x3;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const int qq = q0 + e + 8 * g4 + 4 * hl;
+                    const bool ok = kvok && qq < a.Lq;
+                    const float pr = ok ? vpf_exp2(s[r] * c - sL[qq]) : 0.f;
+                    float keep = 1.f;
+                    if (drop) {
+                        if (quad_ok) {
+                            const uint32_t word = gw[e];
+                            keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                        } else {
+                            keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
+                        }
+                    }
+                    pd[r] = pr * keep;
+                    ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
+                }
+                uint2 w;
+                w.x = pack_bf16x2(ds[4 * g4 + 0], ds[4 * g4 + 1]); w.y = pack_bf16x2(ds[4 * g4 + 2], ds[4 * g4 + 3]);
+                *reinterpret_cast<uint2*>(myT + q0 + 8 * g4) = w;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
+                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < nt) {                               // the next tile's keys / values travel behind the stores and phase B
+            const int kv2 = kv + KT;
+            const bool ok2 = kv2 < a.Lkv;
+            const size_t row = (size_t)b * a.Lkv + (ok2 ? kv2 : 0);
+            const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+            const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, ok2));
+                vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, ok2));
+            }
+        }
+        if (kvok) {
+            bf16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
+            bf16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    uint2 u, w;
+                    u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                    w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                    *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
+                    *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
+                }
+        }
+        __syncthreads();
+        // ---- phase B: dQ^T[dh][q] += K^T[dh][key] . dS^T[key][q] over the tile's keys
+        if (bwave) {
+#pragma unroll
+            for (int k16 = 0; k16 < KT / 16; ++k16) {
+                if (t * KT + k16 * 16 >= a.Lkv) break;
+                const bf16x8_t dsf = frag_tr_perm(sT, DLD, k16 * 16, wave * 32);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, k16 * 16, dt * 32), dsf, dq[dt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (bwave) {
+        const int q = wave * 32 + kl;
+        if (q < a.Lq) {
+            bf16_t* op = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + hd * DH;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    uint2 u;
+                    u.x = pack_bf16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
+                    u.y = pack_bf16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+                    *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
+                }
+        }
+    }
+}
+template <int QB>
+static int launch_bwd_ca(const AttnArgs& a, hipStream_t st)
+{
+    constexpr int QPT = QB * 32, KT = 128;
+    constexpr size_t lds = sizeof(bf16_t) * (2 * QPT * KLD + KT * KLD + KT * (QPT + 8)) + sizeof(float) * 2 * QPT;
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)attn_bwd_ca_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL((attn_bwd_ca_kernel<QB>), dim3(a.B * a.H), dim3(256), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 template <int NWQ, int NWK>
 static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
 {
+    // few queries, many keys, enough (cloud, head) pairs to fill the chip twice: one kernel for all three gradients
+    if (NWK == 4 && vpf_debug().attn_resident && vpf_debug().attn_ca_merged && !a.pad && a.Lq <= 128 && a.Lkv >= 512 &&
+        (long)a.B * a.H >= vpf_debug().attn_ca_merged)
+        return a.Lq <= 96 ? launch_bwd_ca<3>(a, st) : launch_bwd_ca<4>(a, st);
     if (a.Lkv >= 256) {
         constexpr int KT = 128;
         constexpr size_t lds = sizeof(bf16_t) * 2 * 2 * KT * KLD;
