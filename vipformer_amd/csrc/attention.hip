@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
                     const int r = 4 * g4 + e;
                     const float pr = vpf_exp2(s[r] - mn);
                     ps += pr;
-                    pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
+                    pv[r] = ((keep >> e) & 1u) ? pr * rng.scale : 0.f;        // p = 0: keep = 15, scale = 1
                 }
             }
             l = l * alpha + ps;
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
                 const int r = 4 * g4 + e;
                 const float pr = vpf_exp2(s[r] - mn);
                 ps += pr;
-                pv[r] = drop ? (((keep >> e) & 1u) ? pr * rng.scale : 0.f) : pr;
+                pv[r] = ((keep >> e) & 1u) ? pr * rng.scale : 0.f;        // p = 0: keep = 15, scale = 1
             }
         }
         l = l * alpha + ps;
@@ -559,8 +559,9 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
                     const int r = 4 * g4 + e;
                     const int kv = kvs + e + 8 * g4 + 4 * hl;
                     const bool ok = qok && kv < a.Lkv;
-                    const float pr = ok ? vpf_exp2(s[r] * c - lse2) : 0.f;
-                    const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
+                    const float ex = vpf_exp2(s[r] * c - lse2);                 // unconditional: a select, not an exec-mask branch per score
+                    const float pr = ok ? ex : 0.f;
+                    const float keep = ((kbits >> e) & 1u) ? rng.scale : 0.f;      // p = 0: kbits = 15, scale = 1
                     ds[r] = pr * (dp[r] * keep - delta) * a.scale;
                 }
             }
@@ -683,6 +684,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
             // exchanged with DPP quad broadcasts: one hash per 4 elements instead of one per element.
             uint2 grp = make_uint2(0u, 0u);
             const bool quad_ok = (a.Lkv & 3) == 0;
+            const bool slow_keep = drop && !quad_ok;
             if (drop && quad_ok) {
                 const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
                 grp = a.rng_fast ? vpf_rand4x16_32(rng, (((uint32_t)bh * a.Lq + (uint32_t)qh) * (uint32_t)a.Lkv + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
@@ -700,16 +702,11 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
                 const int qr = e + 8 * g4 + 4 * hl;
                 const int q = q0 + qr;
                 const bool ok = kvok && q < a.Lq;
-                const float pr = ok ? vpf_exp2(s[r] * c - sL[qr]) : 0.f;
-                float keep = 1.f;
-                if (drop) {
-                    if (quad_ok) {
-                        const uint32_t word = gw[e];                                 // this lane's half of quad lane e's group
-                        keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
-                    } else {
-                        keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)q) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
-                    }
-                }
+                const float ex = vpf_exp2(s[r] * c - sL[qr]);                 // unconditional: a select, not an exec-mask branch per score
+                    const float pr = ok ? ex : 0.f;
+                const uint32_t word = gw[e];                                   // this lane's half of quad lane e's group (p = 0: thresh 0, scale 1)
+                float keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                if (slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)q) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
                 pd[r] = pr * keep;
                 ds[r] = pr * (dp[r] * keep - sL[BWD_KT + qr]) * a.scale;
                 if (padded) {             // this lane's key is padding: p = 0, or 1 / Lkv in a row whose keys are all padded; dS = 0
@@ -867,8 +864,9 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                     const int r = 4 * g4 + e;
                     const int kv = kv0 + e + 8 * g4 + 4 * hl;
                     const bool ok = qok && kv < L;
-                    const float pr = ok ? vpf_exp2(s[r] * c - lse2) : 0.f;
-                    const float keep = drop ? (((kbits >> e) & 1u) ? rng.scale : 0.f) : 1.f;
+                    const float ex = vpf_exp2(s[r] * c - lse2);                 // unconditional: a select, not an exec-mask branch per score
+                    const float pr = ok ? ex : 0.f;
+                    const float keep = ((kbits >> e) & 1u) ? rng.scale : 0.f;      // p = 0: kbits = 15, scale = 1
                     ds[r] = pr * (dp[r] * keep - delta) * a.scale;
                 }
             }
@@ -902,6 +900,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
         const bool quad_ok = (L & 3) == 0;
+        const bool slow_keep = drop && !quad_ok;
 #pragma unroll
         for (int q0 = 0; q0 < LPT; q0 += 32) {
             if (q0 >= L) break;
@@ -934,16 +933,11 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                     const int qr = e + 8 * g4 + 4 * hl;
                     const int qq = q0 + qr;
                     const bool ok = kvok && qq < L;
-                    const float pr = ok ? vpf_exp2(s[r] * c - sL[qq]) : 0.f;
-                    float keep = 1.f;
-                    if (drop) {
-                        if (quad_ok) {
-                            const uint32_t word = gw[e];
-                            keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
-                        } else {
-                            keep = vpf_keep(rng, ((uint64_t)bh * L + (uint64_t)qq) * (uint64_t)L + (uint64_t)kv) ? rng.scale : 0.f;
-                        }
-                    }
+                    const float ex = vpf_exp2(s[r] * c - sL[qq]);                 // unconditional: a select, not an exec-mask branch per score
+                    const float pr = ok ? ex : 0.f;
+                    const uint32_t word = gw[e];                                   // this lane's half of quad lane e's group (p = 0: thresh 0, scale 1)
+                    float keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                    if (slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * L + (uint64_t)qq) * (uint64_t)L + (uint64_t)kv) ? rng.scale : 0.f;
                     pd[r] = pr * keep;
                     ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
                 }
@@ -1044,6 +1038,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
     const bool quad_ok = (a.Lkv & 3) == 0;
+    const bool slow_keep = drop && !quad_ok;
 #pragma unroll
     for (int q0 = 0; q0 < QPT; q0 += 32) {
         if (q0 >= a.Lq) break;
@@ -1075,16 +1070,11 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
                 const int r = 4 * g4 + e;
                 const int qq = q0 + e + 8 * g4 + 4 * hl;
                 const bool ok = kvok && qq < a.Lq;
-                const float pr = ok ? vpf_exp2(s[r] * c - sL[qq]) : 0.f;
-                float keep = 1.f;
-                if (drop) {
-                    if (quad_ok) {
-                        const uint32_t word = gw[e];
-                        keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
-                    } else {
-                        keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
-                    }
-                }
+                const float ex = vpf_exp2(s[r] * c - sL[qq]);                 // unconditional: a select, not an exec-mask branch per score
+                    const float pr = ok ? ex : 0.f;
+                const uint32_t word = gw[e];                                   // this lane's half of quad lane e's group (p = 0: thresh 0, scale 1)
+                float keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                if (slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
                 pd[r] = pr * keep;
                 ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
             }
@@ -1181,6 +1171,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
     const bool drop = a.p > 0.f;
     const bool quad_ok = (a.Lkv & 3) == 0;
+    const bool slow_keep = drop && !quad_ok;
     const int nt = (a.Lkv + KT - 1) / KT;
     const bool bwave = wave < QB && wave * 32 < a.Lq;  // this wave owns a query block in phase B
     f32x16_t dq[2];
@@ -1242,16 +1233,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
                     const int r = 4 * g4 + e;
                     const int qq = q0 + e + 8 * g4 + 4 * hl;
                     const bool ok = kvok && qq < a.Lq;
-                    const float pr = ok ? vpf_exp2(s[r] * c - sL[qq]) : 0.f;
-                    float keep = 1.f;
-                    if (drop) {
-                        if (quad_ok) {
-                            const uint32_t word = gw[e];
-                            keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
-                        } else {
-                            keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
-                        }
-                    }
+                    const float ex = vpf_exp2(s[r] * c - sL[qq]);                 // unconditional: a select, not an exec-mask branch per score
+                    const float pr = ok ? ex : 0.f;
+                    const uint32_t word = gw[e];                                   // this lane's half of quad lane e's group (p = 0: thresh 0, scale 1)
+                    float keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                    if (slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
                     pd[r] = pr * keep;
                     ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
                 }
