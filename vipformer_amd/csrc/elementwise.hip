@@ -906,6 +906,7 @@ __global__ void __launch_bounds__(512) bn_small_fwd_kernel(const float* __restri
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
     int r = rl;
+#pragma unroll 4                                     // 8 independent loads in flight per thread (the batch is 64 .. 256 rows: 8 dependent round trips otherwise)
     for (; r + 8 < M; r += 16) {
         const float a = x[(size_t)r * C + c], b = x[(size_t)(r + 8) * C + c];
         s0 += a; q0 += a * a; s1 += b; q1 += b * b;
@@ -932,6 +933,7 @@ __global__ void __launch_bounds__(512) bn_small_fwd_kernel(const float* __restri
     }
     __syncthreads();
     const float mu = smu[cl], rs = srs[cl], ga = gamma[c], be = beta[c];
+#pragma unroll 8
     for (r = rl; r < M; r += 8) {
         float v = (x[(size_t)r * C + c] - mu) * rs * ga + be;
         if (relu == 1) v = fmaxf(v, 0.f); else if (relu == 2) v = v > 0.f ? v : 0.2f * v;   // 2: LeakyReLU(0.2), partseg.py:393
@@ -963,6 +965,7 @@ __global__ void __launch_bounds__(512) bn_small_bwd_kernel(const float* __restri
     const float mu = stat[c], rs = stat[C + c], ga = gamma[c], be = beta[c];
     float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
     int r = rl;
+#pragma unroll 4
     for (; r + 8 < M; r += 16) {
         const float xa = (x[(size_t)r * C + c] - mu) * rs, xb = (x[(size_t)(r + 8) * C + c] - mu) * rs;
         float ga_ = dy[(size_t)r * C + c], gb_ = dy[(size_t)(r + 8) * C + c];
@@ -988,6 +991,7 @@ __global__ void __launch_bounds__(512) bn_small_bwd_kernel(const float* __restri
     __syncthreads();
     if (!dx) return;
     const float sm = ssum[cl] / (float)M, qm = sqsum[cl] / (float)M;
+#pragma unroll 8
     for (r = rl; r < M; r += 8) {
         const float xh = (x[(size_t)r * C + c] - mu) * rs;
         float g = dy[(size_t)r * C + c];
