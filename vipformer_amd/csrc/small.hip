@@ -64,6 +64,9 @@ extern "C" int vpf_adapter_front_fwd(const float* x, long M, int C, const float*
     return VPF_OK;
 }
 // da (bf16 [M,64]) -> dW[64,C] += , db[64] +=, dgamma[64] +=, dbeta[64] +=   (input needs no grad)
+// CT = the compile-time bound of the input-channel loops: 3 for xyz clouds (the loops over AD_MAXC = 8 channels with a run-time C spent
+// a fifth of the kernel's instructions on five channels that do not exist), AD_MAXC otherwise
+template <int CT>
 __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
                                                               const float* __restrict__ W, const float* __restrict__ b,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -71,21 +74,21 @@ __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __r
 {
     const int lane = threadIdx.x & 63;
     const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
-    float w[AD_MAXC], aw[AD_MAXC];
+    float w[CT], aw[CT];
 #pragma unroll
-    for (int j = 0; j < AD_MAXC; ++j) { w[j] = j < C ? W[lane * C + j] : 0.f; aw[j] = 0.f; }
+    for (int j = 0; j < CT; ++j) { w[j] = j < C ? W[lane * C + j] : 0.f; aw[j] = 0.f; }
     const float bb = b[lane], ga = gamma[lane], be = beta[lane];
     float adb = 0.f, adg = 0.f, adbe = 0.f;
     constexpr int U = 4;
     for (long r0 = wave0 * U; r0 < M; r0 += nw * U) {
-        float xv[U][AD_MAXC], h[U], gin[U];
+        float xv[U][CT], h[U], gin[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const bool ok = r0 + u < M;
             const long r = ok ? r0 + u : M - 1;
             h[u] = bb;
 #pragma unroll
-            for (int j = 0; j < AD_MAXC; ++j) { xv[u][j] = (j < C && ok) ? x[(size_t)r * C + j] : 0.f; h[u] += w[j] * xv[u][j]; }
+            for (int j = 0; j < CT; ++j) { xv[u][j] = ((CT < AD_MAXC || j < C) && ok) ? x[(size_t)r * C + j] : 0.f; h[u] += w[j] * xv[u][j]; }
             gin[u] = ok ? bf16_to_f32(da[(size_t)r * 64 + lane]) : 0.f;
         }
 #pragma unroll
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __r
             const float dh = (r0 + u < M) ? rs * (gx - m1 - xh * m2) : 0.f;
             adb += dh;
 #pragma unroll
-            for (int j = 0; j < AD_MAXC; ++j) aw[j] += dh * xv[u][j];
+            for (int j = 0; j < CT; ++j) aw[j] += dh * xv[u][j];
         }
     }
     // Thousands of waves adding into the same ~400 addresses serialise in L2 (this tail used to be most of the kernel):
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __r
     const int wv = threadIdx.x >> 6;
     fold[wv][lane] = adb; fold[wv][64 + lane] = adg; fold[wv][128 + lane] = adbe;
 #pragma unroll
-    for (int j = 0; j < AD_MAXC; ++j) fold[wv][192 + j * 64 + lane] = aw[j];
+    for (int j = 0; j < AD_MAXC; ++j) fold[wv][192 + j * 64 + lane] = j < CT ? aw[j < CT ? j : 0] : 0.f;
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * (3 + AD_MAXC); e += 256)
         partial[(size_t)blockIdx.x * 64 * (3 + AD_MAXC) + e] = (fold[0][e] + fold[1][e]) + (fold[2][e] + fold[3][e]);
@@ -161,8 +164,8 @@ extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M
     int nblk = grid_for(M, 64, 2048);
     if ((long)nblk * ROW > ws_floats) nblk = (int)(ws_floats / ROW);
     if (nblk < 1) return VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(adapter_front_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C,
-                       W, b, gamma, beta, ws);
+    if (C == 3) hipLaunchKernelGGL(adapter_front_bwd_kernel<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, gamma, beta, ws);
+    else hipLaunchKernelGGL(adapter_front_bwd_kernel<AD_MAXC>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, gamma, beta, ws);
     hipLaunchKernelGGL(adapter_front_fold_kernel, dim3(3 + AD_MAXC, 8), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
