@@ -27,7 +27,7 @@ LEGS = [  # (leg key of bench.py, kernel-name substring, predicate on (grid, fir
     ("attn_res_fwd_kernel (self-attention img)", "attn_res_fwd_kernel", "large"),
     ("attn_res_bwd_kernel (self-attention pc)", "attn_res_bwd_kernel", "small"),
     ("attn_res_bwd_kernel (self-attention img)", "attn_res_bwd_kernel", "large"),
-    ("attn_bwd_dq/dkv_kernel (cross-attention pc)", "attn_bwd_d", None),
+    ("attn_bwd_dq/dkv_kernel (cross-attention pc)", "attn_bwd_", None),      # dq + dkv, or the one attn_bwd_ca_kernel
 ]
 
 
@@ -48,7 +48,7 @@ def main():
         cands = [(k, d) for k, d in agg.items() if sub in k[0] and max(len(v) for v in d.values()) >= 3]
         if not cands:
             continue
-        if sub == "attn_bwd_d":          # two kernels (dq, dkv) per backward: sum them
+        if sub == "attn_bwd_":           # two kernels (dq, dkv) per backward: sum them (one when attn_bwd_ca_kernel runs)
             ctrs = collections.defaultdict(float)
             for k, d in cands:
                 for c, v in d.items():
