@@ -181,6 +181,28 @@ def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
         assert r < 1.5e-2, f"{name} rel {r}"                                 # bf16 P/dS operands + bf16 outputs
 
 
+@pytest.mark.parametrize("B,L,D", [(128, 96, 256), (3, 50, 384), (2, 7, 6), (2, 33, 1024), (5, 196, 256)])
+def test_pool_fwd_bwd_vs_torch(B, L, D):
+    """vpf_pool_fwd / vpf_pool_bwd (cat[max over tokens, mean over tokens], partseg.py:548): values, first-maximum argmax and the
+    backward (mean's share to every token + the maximum's to its winner) against the same formula in torch (one division and one addition
+    per element)."""
+    from vipformer_amd import _lib as L_
+    x = rnd(1, B, L, D).contiguous()
+    out = torch.empty(B, 2 * D, device="cuda")
+    arg = torch.empty(B, D, dtype=torch.int32, device="cuda")
+    L_.call("vpf_pool_fwd", x, B, L, D, out, arg)
+    xr = x.clone().requires_grad_()
+    ref = torch.cat([xr.max(dim=1)[0], xr.mean(dim=1)], dim=1)
+    assert torch.equal(out[:, :D], ref[:, :D].detach()) and torch.allclose(out[:, D:], ref[:, D:].detach(), rtol=1e-5, atol=1e-6)
+    assert torch.equal(arg.long(), x.argmax(dim=1))
+    dout = rnd(2, B, 2 * D).contiguous()
+    dx = torch.full((B, L, D), float("nan"), device="cuda")
+    L_.call("vpf_pool_bwd", dout, arg, B, L, D, dx)
+    want = (dout[:, None, D:] / float(L)).expand(B, L, D).clone()
+    want.scatter_add_(1, arg.long()[:, None, :], dout[:, None, :D])
+    assert torch.allclose(dx, want, rtol=2e-6, atol=1e-9), float((dx - want).abs().max())     # (the kernel's division is not IEEE-rounded)
+
+
 @pytest.mark.parametrize("B,H,Lq,Lkv,p", [(2, 2, 96, 1024, 0.1), (1, 2, 128, 1024, 0.1), (2, 1, 80, 1000, 0.1), (1, 1, 70, 518, 0.1),
                                           (1, 2, 96, 512, 0.0), (3, 1, 33, 640, 0.5)])
 def test_attention_bwd_one_kernel_equals_two_bitwise(B, H, Lq, Lkv, p):
