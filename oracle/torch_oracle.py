@@ -150,7 +150,7 @@ class _RoundBF16(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(torch.float32)
+        return x.to(_FWD_DTYPE[0]).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
@@ -167,6 +167,8 @@ class _RoundGradBF16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        if _BWD_DTYPE[0] is torch.float16:        # loss-scaled fp16 gradient operands (the reference's GradScaler arithmetic, pretrain.py:154,209)
+            return (g * _BWD_SCALE[0]).to(torch.float16).to(torch.float32) / _BWD_SCALE[0]
         return g.to(torch.bfloat16).to(torch.float32)
 
 
@@ -178,6 +180,9 @@ class _RoundGradBF16(torch.autograd.Function):
 FWD_TAGS = ("w", "adapter", "g2e", "pos", "ln", "qkv", "p", "o", "u", "h", "head")
 BWD_TAGS = ("dz", "du", "do", "dqkv", "ds")
 _EMULATE = [frozenset()]
+_BWD_DTYPE = [torch.bfloat16]
+_BWD_SCALE = [1.0]
+_FWD_DTYPE = [torch.bfloat16]        # the type forward operands are rounded to (emulate_fp16 switches it; gradients stay bf16)
 
 
 class emulate_bf16:
@@ -201,6 +206,30 @@ class emulate_bf16:
 
     def __exit__(self, *a):
         _EMULATE[0] = self.prev
+
+
+class emulate_fp16(emulate_bf16):
+    """The same rounding points with the FORWARD operands (weights + activations) rounded to IEEE fp16 -- the reference's own
+    autocast dtype (pretrain.py:154,176): 11 significant bits instead of bf16's 8, range 6e-8 .. 65504 (a value beyond it becomes
+    inf exactly as `v_cvt_f16_f32` would make it).  The gradients the backward kernels store stay bf16 (range).  Used by
+    tests/rounding_budget.py to measure what fp16 forward operands would buy against SURVEY 8c's tolerances."""
+
+    def __init__(self, only=None, backward=False, grad_scale=None):
+        """grad_scale: None -- gradient operands stay bf16; a number -- they are fp16 as well, rounded at ``grad_scale`` times their
+        value (GradScaler's loss scale: the gradients of the whole backward pass carry that factor)."""
+        super().__init__(only, backward)
+        self.grad_scale = grad_scale
+
+    def __enter__(self):
+        super().__enter__()
+        self.prev_dt = (_FWD_DTYPE[0], _BWD_DTYPE[0], _BWD_SCALE[0])
+        _FWD_DTYPE[0] = torch.float16
+        if self.grad_scale is not None:
+            _BWD_DTYPE[0], _BWD_SCALE[0] = torch.float16, float(self.grad_scale)
+
+    def __exit__(self, *a):
+        _FWD_DTYPE[0], _BWD_DTYPE[0], _BWD_SCALE[0] = self.prev_dt
+        super().__exit__(*a)
 
 
 def Q(x, tag="w"):

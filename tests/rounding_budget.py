@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-stage error budget of the bf16 rounding points -- oracle against oracle, CPU only.
 
-    python -m tests.rounding_budget [arch=c1] [pairs=4] > profiles/r03_rounding_budget_<arch>.txt
+    python -m tests.rounding_budget [arch=c1] [pairs=4] [bf16|fp16|fp16s|fp16s1] [quick] > profiles/r04_rounding_budget_<fwd>_<arch>.txt
 
 The fp32 oracle (pinned against the reference) is the baseline.  Each rounding point of the HIP path (oracle/torch_oracle.py:
 FWD_TAGS -- activations / weights stored as bf16 -- and BWD_TAGS -- gradients stored as bf16 operands of the backward products) is
@@ -40,7 +40,7 @@ def run(name, B, tags, backward, pts, start, imgs, masks, Rb, Rbi):
         for k in list(s):
             if "cross_attn_1." in k:
                 s[k] = s[k.replace("cross_attn_1.", "cross_attn_n.")]
-    with O.emulate_bf16(only=tags, backward=backward):
+    with EMU(only=tags, backward=backward):
         f, bb = O.pc_forward(s1, pts, start, arch, True, masks[0], {})
         fi, bbi = O.img_forward(s2, imgs, arch, True, masks[1], {})
         loss = O.ntxent(f[:B], f[B:]) + O.ntxent((f[:B] + f[B:]) / 2, fi)
@@ -54,9 +54,18 @@ def run(name, B, tags, backward, pts, start, imgs, masks, Rb, Rbi):
     return dict(bb=bb.detach(), bbi=bbi.detach(), loss=float(loss), lin=lin, ntx=ntx)
 
 
+EMU = O.emulate_bf16
+
+
 def main():
+    global EMU
     name = sys.argv[1] if len(sys.argv) > 1 else "c1"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    fwd = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+    import functools
+    EMU = {"bf16": O.emulate_bf16, "fp16": O.emulate_fp16, "fp16s": functools.partial(O.emulate_fp16, grad_scale=65536.0),
+           "fp16s1": functools.partial(O.emulate_fp16, grad_scale=1.0)}[fwd]
+    quick = len(sys.argv) > 4 and sys.argv[4] == "quick"        # only the combined rows
     a = Hh.ARCHS[name]
     torch.manual_seed(0)
     pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
@@ -78,8 +87,9 @@ def main():
     masks = (FixedMasks(1), FixedMasks(2))
     Rb, Rbi = Hh.synth_like(700, (2 * B, 2 * a["D"])), Hh.synth_like(701, (B, 2 * a["D"]))
     ref = run(name, B, (), False, pts, start, imgs, masks, Rb, Rbi)
-    variants = [(t, (t,), t in O.BWD_TAGS) for t in O.FWD_TAGS + O.BWD_TAGS]
+    variants = [] if quick else [(t, (t,), t in O.BWD_TAGS) for t in O.FWD_TAGS + O.BWD_TAGS]
     variants += [("all forward", O.FWD_TAGS, False), ("all backward", O.BWD_TAGS, True), ("all (the HIP data path)", O.FWD_TAGS + O.BWD_TAGS, True)]
+    print(f"# forward operands rounded to {fwd[:4]} (gradient operands: " + {"fp16s": "fp16 at loss scale 65536", "fp16s1": "fp16, no loss scale"}.get(fwd, "bf16") + ")")
     print(f"# rounding budget, arch {name}, {B} pairs, train mode, dropout 0.1 / 0.5 with fixed masks; baseline = fp32 oracle (loss {ref['loss']:.5f})")
     print(f"{'rounding point(s)':28s} {'pc bb rel':>10s} {'img bb rel':>10s} {'dloss':>9s} | linear loss: {'all cos':>9s} {'lowest':>8s} | NT-Xent: {'all cos':>9s} {'median':>8s} {'lowest':>8s}")
     for label, tags, bwd in variants:

@@ -498,6 +498,47 @@ def test_trainer_stream_and_graph_variants_agree():
         assert cosine(g, g0) > 0.999999, (tag, cosine(g, g0))      # gradients: fp32 atomic ordering only
 
 
+def test_ln_pgrad_reduce_flush_mid_stack_sees_written_partials():
+    """EncoderFusedFn.backward defers the qkv half of layer i to the MLP half of the layer below; the fold of its
+    LayerNorm partial rows must be queued BEHIND that launch.  With the flush threshold lowered to 2 jobs (a 16-layer stack
+    reaches the real threshold of 32 the same way) every mid-loop vpf_ln_pgrad_reduce fires while a qkv half is pending: the
+    LayerNorm gradients must equal the ones of a single flush at the end."""
+    from vipformer_amd import ops
+    from vipformer_amd.train import Pretrainer, build_models
+    a = Hh.ARCHS["c1"]
+    B = 2
+    t1 = Hh.synth_points(1, B, a["N"]).cuda(); t2 = Hh.synth_points(2, B, a["N"]).cuda()
+    imgs = Hh.synth_images(3, B, a["img"], a["img"]).permute(0, 3, 1, 2).contiguous().cuda()
+    start = Hh.synth_start(4, 2 * B, a["N"]).cuda()
+    res = []
+    try:
+        for flush in (32, 2, 1, 3):
+            ops.clear_managed_shadows()
+            ops.rng.seed(99)
+            torch.manual_seed(5)
+            pc, im = build_models(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], N=a["N"], img=a["img"], patch=a["patch"])
+            pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_pc_c1.json"), 100))
+            im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes("keys_img_c1.json"), 200))
+            pc.train(); im.train()
+            tr = Pretrainer(pc, im)
+            tr.overlap = False
+            ops.cfg.pgrad_flush = flush
+            with forced_start(start), ops.rng.pinned():
+                tr.forward_backward(t1, t2, imgs)
+            torch.cuda.synchronize()
+            res.append({("pc." if m is pc else "img.") + k: p.grad.clone() for m in (pc, im) for k, p in m.named_parameters()
+                        if ("norm" in k or ".module.0." in k) and "encoder" in k})
+    finally:
+        ops.cfg.pgrad_flush = 32
+        ops.clear_managed_shadows()
+    assert len(res[0]) >= 2 * (2 * a["S"] + 3) * 2
+    C = Checks("ln_pgrad flush threshold")
+    for r, flush in zip(res[1:], (2, 1, 3)):
+        for k in res[0]:
+            C.lt(f"[flush {flush}] {k} rel", rel(r[k], res[0][k]), 1e-6)
+    C.done()
+
+
 @pytest.mark.parametrize("name", ["c1", "c4"])
 def test_fused_sa_stack_matches_unfused_blocks(name):
     """vpf_sa_layer_fwd / vpf_sa_layer_bwd_* (fused self-attention layers) against the block-by-block kernels they

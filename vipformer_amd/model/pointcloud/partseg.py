@@ -264,6 +264,7 @@ class Encoder(nn.Module):
             outs = ops.EncoderFusedFn.apply(group_embs, pos_embs, pts_embs, self.cross_attn_1, self.sa_layers, self.training, kv_ready,
                                             taps, *params)
             return outs[0] if self.modal_prior else list(outs[1:])
+        self.cross_attn_1.__dict__.pop("_vpf_front_stash", None)        # a CaFrontFn stash is for the fused path only: never left behind
         if kv_ready:
             raise L.VpfError("kv_ready needs the fused encoder path")
         x = self.cross_attn_1(group_embs, pts_embs, pad_mask, pos=pos_embs)

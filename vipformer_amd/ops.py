@@ -43,7 +43,7 @@ class OpsConfig:
     The library's own launch-time knobs live in its VpfDebug struct (``_lib.debug_get`` / ``debug_set``)."""
     __slots__ = ("wgrad_async", "wgrad_group", "wgrad_group_async", "wgrad_deterministic", "wgrad_defer", "sa_debug", "sa_split_attn",
                  "sa_fused_bwd", "sa_fused", "enc_bwd_hook", "adapter_kv_fused", "adapter_kv_bwd_fused", "enc_fused", "g2e_bn_merged",
-                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack", "ca_front_bwd_fused", "ca_kv_bwd_fused")
+                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack", "ca_front_bwd_fused", "ca_kv_bwd_fused", "pgrad_flush")
 
     def __init__(self, env=os.environ):
         self.wgrad_async = False          # weight-gradient GEMMs on a side stream: measured slower (cross-stream event cost > overlap gain)
@@ -62,6 +62,7 @@ class OpsConfig:
         self.ca_front_fused = env.get("VPF_CA_FRONT", "1") == "1"     # position MLP + (tokens + pos) + q_norm + q projection of the point-cloud branch as one kernel
         self.ca_front_bwd_fused = env.get("VPF_CA_FRONT_BWD", "1") == "1"      # the cross-attention layer's query-side backward as one row-block kernel (vpf_ca_front_bwd)
         self.ca_kv_bwd_fused = env.get("VPF_CA_KV_BWD", "0") == "1"            # ... and its key / value side where the kv input is an f32 tensor (image branch: vpf_ca_kv_bwd; measured: no gain, 3.93 vs 3.94 ms: off)
+        self.pgrad_flush = 32             # LayerNorm parameter-gradient folds queued per vpf_ln_pgrad_reduce launch (tests lower it: ADVICE r03)
         self.wgrad_stack = env.get("VPF_WGRAD_STACK", "1") == "1"               # the weight gradients of a whole fused encoder stack as ONE grouped launch at the end of its backward
         self.g2e_bn_merged = env.get("VPF_G2E_BN_MERGED", "1") != "0"          # BatchNorm bookkeeping of Group2Emb as single launches
         self.g2e_conv1_bwd_fused = env.get("VPF_G2E_CONV1_FUSED", "1") == "1"  # conv2 dgrad inside the first conv's backward (tests run both)
@@ -1323,17 +1324,20 @@ class EncoderFusedFn(torch.autograd.Function):
             a.pgrad2 = pg[slot, 1].data_ptr()
             above, pending[0] = pending[0], None
             if above is not None:
-                L.call_struct("vpf_sa_layer_bwd_qkv_mlp", above, ctypes.addressof(a))
-            else:
+                L.call_struct("vpf_sa_layer_bwd_qkv_mlp", above[0], ctypes.addressof(a))
+                pgrad_job(*above[1])                        # its partial rows exist only now (queued at defer time, a mid-loop
+            else:                                           # flush of >= 32 jobs would have reduced unwritten memory)
                 L.call_struct("vpf_sa_layer_bwd_mlp", a)
             return bufs
 
-        def pgrad_job(slot, which, ln):
+        def pgrad_job(slot, which, ln, partials=None, rows=None):
+            """Queue the fold of one LayerNorm's parameter-gradient partial rows; ONLY behind the launch that writes them (a flush
+            happens as soon as ``cfg.pgrad_flush`` jobs are queued)."""
             nonlocal npj
-            pjobs[npj].partials, pjobs[npj].rows, pjobs[npj].D = pg[slot, which].data_ptr(), nwg, D
+            pjobs[npj].partials, pjobs[npj].rows, pjobs[npj].D = (pg[slot, which] if partials is None else partials).data_ptr(), (rows or nwg), D
             pjobs[npj].dgamma, pjobs[npj].dbeta = grad_buf(ln.weight).data_ptr(), grad_buf(ln.bias).data_ptr()
             npj += 1
-            if npj == 32:
+            if npj >= min(32, max(1, int(cfg.pgrad_flush))):
                 L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
                 npj = 0
 
@@ -1364,9 +1368,10 @@ class EncoderFusedFn(torch.autograd.Function):
             a.dsum_init = int(not dsum_started)
             dsum_started = True
             if tap_grad.get(i) is None:
-                pending[0] = a                              # launched with the MLP half of the layer below (its d is this dbase)
+                pending[0] = (a, (i + 1, 0, ln1))           # launched with the MLP half of the layer below (its d is this dbase)
             else:
                 L.call_struct("vpf_sa_layer_bwd_qkv", a)    # (a tapped boundary: the tap's gradient joins d first)
+                pgrad_job(i + 1, 0, ln1)
             wg = wg_all if wg_all is not None else WgradBatch()
             wg.add(dz2, h, D, Hd, grad_buf(mlp[3].weight), grad_buf(mlp[3].bias))
             wg.add(du, n2, Hd, D, grad_buf(mlp[1].weight), grad_buf(mlp[1].bias))
@@ -1375,7 +1380,6 @@ class EncoderFusedFn(torch.autograd.Function):
             if wg_all is None:
                 wg.flush()
             pgrad_job(i + 1, 1, mlp[0])
-            pgrad_job(i + 1, 0, ln1)
             d = dbase
         # ---- cross-attention layer
         if cfg.enc_bwd_hook is not None:
@@ -1422,9 +1426,7 @@ class EncoderFusedFn(torch.autograd.Function):
                                                                      rk.data_ptr(), lnkv.weight.data.data_ptr())
             a3.dx1, a3.dbase, a3.pgrad1, a3.dsum = None, dxkv.data_ptr(), pgkv.data_ptr(), None
             L.call_struct("vpf_ca_kv_bwd", a3)
-            pjobs[npj].partials, pjobs[npj].rows, pjobs[npj].D = pgkv.data_ptr(), nkw, D
-            pjobs[npj].dgamma, pjobs[npj].dbeta = grad_buf(lnkv.weight).data_ptr(), grad_buf(lnkv.bias).data_ptr()
-            npj += 1
+            pgrad_job(0, 0, lnkv, partials=pgkv, rows=nkw)
             dxkv = dxkv.view(B, Lkv, D) if ctx.needs_input_grad[2] else None
         else:
             dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
@@ -1926,8 +1928,9 @@ class CaFrontFn(torch.autograd.Function):
         a.hpos, a.pos, a.base, a.mean, a.rstd, a.nq, a.q = (hpos.data_ptr(), pos.data_ptr(), base.data_ptr(), mq.data_ptr(), rq.data_ptr(),
                                                               nq.data_ptr(), q.data_ptr())
         L.call_struct("vpf_ca_front_fwd", a)
+        # (the stash HOLDS tok / pos: a recycled allocation can then never alias the pointers it is matched by)
         ca._vpf_front_stash = dict(tokens=tok.data_ptr(), pos=pos.data_ptr(), shape=(B, G, D), base=base, mq=mq, rq=rq, nq=nq, q=q,
-                                   packed=packed, nblocks=len(blocks))
+                                   packed=packed, nblocks=len(blocks), keep=(tok, pos))
         ctx.seq = seq
         ctx.save_for_backward(x, hpos)
         return pos.view(B, G, D)
@@ -1945,7 +1948,11 @@ def ca_front_supported(seq, tokens, enc) -> bool:
     l0, l2 = seq[0], seq[2]
     if tokens.shape[-1] != 256 or tuple(l0.weight.shape) != (128, 3) or l2.weight.shape[1] != 128 or l2.weight.shape[0] != 256:
         return False
-    return enc.num_cross_attention_layers == 1
+    if enc.num_cross_attention_layers != 1:
+        return False
+    # the stash is only ever consumed by EncoderFusedFn: the encoder call that follows must take the fused path
+    probe = tokens.new_empty((tokens.shape[0], 1, 2 * tokens.shape[2]))
+    return bool(enc.fused_ok(tokens, probe))
 
 
 class PatchEmbedFn(torch.autograd.Function):
