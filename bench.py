@@ -32,22 +32,36 @@ import time
 import torch
 import torch.distributed as dist
 
+H16 = torch.float16          # the library's 16-bit operand dtype (vipformer_amd._lib.H16)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ARCHS = {"c2": dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=1024, img=224, patch=16),      # configs[1] (and configs[0])
          "c3": dict(D=256, H=4, G=128, K=32, S=8, MR=2, N=1024, img=224, patch=16),     # configs[2]: 32 pairs / GPU
          "c4": dict(D=384, H=6, G=128, K=32, S=8, MR=4, N=2048, img=224, patch=16)}     # configs[3]: 16 pairs / GPU
-PAIRS = {"c2": 64, "c3": 32, "c4": 16}
-NAMES = {"c2": "E1CL6SL-H4D256-L96-MR2", "c3": "E1CL8SL-H4D256-L128-MR2", "c4": "E1CL8SL-H6D384-L128-MR4"}
-GFLOP_PER_PAIR = {"c2": 17.4, "c3": 24.2, "c4": 64.7}   # fwd+bwd, 2 FLOP/MAC, backward = 2x forward
-PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (guide: MI355X_MICROARCH.md)
+# the geometry the reference's own training scripts ship (scripts/pretrain/pt-E1CL6SL-H4D256-L96-MR2-0.sh:10-16 + parser.py:112): 2048-pt
+# clouds, 144 x 144 images, patch 12 -> 144 tokens of 432 values; a side line like c3 / c4
+ARCHS["ref144"] = dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=2048, img=144, patch=12)
+PAIRS = {"c2": 64, "c3": 32, "c4": 16, "ref144": 64}
+NAMES = {"c2": "E1CL6SL-H4D256-L96-MR2", "c3": "E1CL8SL-H4D256-L128-MR2", "c4": "E1CL8SL-H6D384-L128-MR4",
+         "ref144": "E1CL6SL-H4D256-L96-MR2, the reference scripts' 2048 pts + 144x144 img / patch 12"}
+def _gflop_per_pair(a):
+    """SURVEY 8d's formula (MAC counts x 2 FLOP, backward = 2 x forward): two clouds + one image."""
+    D, G, K, S, MR, N = a["D"], a["G"], a["K"], a["S"], a["MR"], a["N"]
+    T, p = (a["img"] // a["patch"]) ** 2, a["patch"]
+    cloud = (N * (192 + 64 * D) + 3 * G * N + G * K * (192 + 8192 + 65536 + 256 * D) + G * (384 + 128 * D)
+             + 2 * G * D * D + 2 * N * D * D + 2 * G * N * D + 2 * G * MR * D * D + S * (4 * G * D * D + 2 * G * G * D + 2 * G * MR * D * D) + 3 * D * D)
+    image = T * 3 * p * p * D + (S + 1) * (4 * T * D * D + 2 * T * T * D + 2 * T * MR * D * D) + 3 * D * D
+    return round(3 * 2 * (2 * cloud + image) / 1e9, 1)
+GFLOP_PER_PAIR = {"c2": 17.4, "c3": 24.2, "c4": 64.7, "ref144": _gflop_per_pair(ARCHS["ref144"])}   # SURVEY 8d: fwd+bwd, 2 FLOP/MAC, backward = 2x forward
+PEAK_H16_TFLOPS = 2500.0      # MI355X dense h16 MFMA (guide: MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
 # whole-step budgets (tools/collect_step_bytes.sh: kernel trace + FETCH_SIZE + WRITE_SIZE passes of this very command, folded per
 # kernel over the last whole steps): launches per step, in-step average duration, HBM bytes per launch IN THE STEP
-PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r03_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r03_step_bytes_c3.json"),
-                "c4": os.path.join(ROOT, "profiles", "r03_step_bytes_c4.json")}
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels (tools/collect_profiles.sh)
+PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r04_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r04_step_bytes_c3.json"),
+                "c4": os.path.join(ROOT, "profiles", "r04_step_bytes_c4.json"), "ref144": os.path.join(ROOT, "profiles", "r04_step_bytes_ref144.json")}
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels (tools/collect_profiles.sh)
 
 
 def synth_batch(b, N, img, seed, device, dups=False):
@@ -103,7 +117,7 @@ def _leg(name, us, nbytes, flops, bound, note):
     gbs, tf = nbytes / us / 1e3, flops / us / 1e6
     d = dict(kernel=name, us_per_launch=round(us, 2), bytes_per_launch=float(nbytes), flops_per_launch=float(flops),
              hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4), mfma_tflops=round(tf, 1),
-             mfma_frac=round(tf / PEAK_BF16_TFLOPS, 4), bound=bound, note=note)
+             mfma_frac=round(tf / PEAK_H16_TFLOPS, 4), bound=bound, note=note)
     return d
 
 
@@ -134,8 +148,8 @@ def kernel_legs(device, a, pairs):
     st = ops.rng.state(device)
     T = (a["img"] // a["patch"]) ** 2
     for tag, (Bq, Lq, Lkv) in (("cross-attention pc", (B, G, N)), ("self-attention pc", (B, G, G)), ("self-attention img", (pairs, T, T))):
-        q = torch.randn(Bq * Lq, D, generator=g).to(device).bfloat16(); k = torch.randn(Bq * Lkv, D, generator=g).to(device).bfloat16()
-        v = torch.randn(Bq * Lkv, D, generator=g).to(device).bfloat16(); do = torch.randn(Bq * Lq, D, generator=g).to(device).bfloat16()
+        q = torch.randn(Bq * Lq, D, generator=g).to(device).to(H16); k = torch.randn(Bq * Lkv, D, generator=g).to(device).to(H16)
+        v = torch.randn(Bq * Lkv, D, generator=g).to(device).to(H16); do = torch.randn(Bq * Lq, D, generator=g).to(device).to(H16)
         o = torch.empty_like(q); lse = torch.empty(Bq * H * Lq, device=device)
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dl = torch.empty(Bq * H * Lq, dtype=torch.float32, device=device)
@@ -151,7 +165,7 @@ def kernel_legs(device, a, pairs):
     # ---- grouped weight gradients of one encoder layer: dW = dY^T X for fc2, fc1, o_proj, qkv over M tokens
     Hd = a["MR"] * D
     shapes = [(D, Hd), (Hd, D), (D, D), (3 * D, D)]
-    jobs = [(torch.randn(M, Nn, generator=g).to(device).bfloat16(), torch.randn(M, Kk, generator=g).to(device).bfloat16(), Nn, Kk,
+    jobs = [(torch.randn(M, Nn, generator=g).to(device).to(H16), torch.randn(M, Kk, generator=g).to(device).to(H16), Nn, Kk,
              torch.zeros(Nn, Kk, device=device), torch.zeros(Nn, device=device)) for Nn, Kk in shapes]
 
     def wgroup():
@@ -162,20 +176,38 @@ def kernel_legs(device, a, pairs):
 
     us = _events(wgroup, 50, 5)
     nbytes = sum(2.0 * M * (Nn + Kk) + 4.0 * Nn * Kk for Nn, Kk in shapes)
-    legs["gemm_wgrad_group_kernel"] = _leg("gemm_wgrad_group_kernel", us, nbytes, sum(2.0 * M * Nn * Kk for Nn, Kk in shapes), "hbm",
-                                           f"4 weight gradients of one encoder layer, {M} tokens: operands read once + dW written once")
+    legs["gemm_wgrad_group_kernel (one layer)"] = _leg("gemm_wgrad_group_kernel", us, nbytes, sum(2.0 * M * Nn * Kk for Nn, Kk in shapes), "hbm",
+                                                       f"4 weight gradients of one encoder layer, {M} tokens: operands read once + dW written once")
+    # ... and the launch the STEP makes: the weight gradients of the point-cloud branch's whole encoder stack in one grouped launch
+    # (EncoderFusedFn.backward's job list: the cross-attention layer's fc2, fc1, o_proj, q_proj + fc2, fc1, o_proj, q|k|v of every
+    # self-attention layer); operands of every layer distinct, as in the step
+    stack_shapes = [(D, Hd), (Hd, D), (D, D), (D, D)] + [sh for _ in range(a["S"]) for sh in shapes]
+    sjobs = [(torch.randn(M, Nn, generator=g).to(device).to(H16), torch.randn(M, Kk, generator=g).to(device).to(H16), Nn, Kk,
+              torch.zeros(Nn, Kk, device=device), (torch.zeros(Nn, device=device) if i % 4 != 3 else None)) for i, (Nn, Kk) in enumerate(stack_shapes)]
+
+    def wstack():
+        wg = ops.WgradBatch(cap=ops.WgradBatch.CAP)
+        for dy, x, Nn, Kk, dW, db in sjobs:
+            wg.add(dy, x, Nn, Kk, dW, db)
+        wg.flush()
+
+    us = _events(wstack, 10, 3)
+    sbytes = sum(2.0 * M * (Nn + Kk) + 4.0 * Nn * Kk for Nn, Kk in stack_shapes)
+    legs["gemm_wgrad_group_kernel"] = _leg("gemm_wgrad_group_kernel", us, sbytes, sum(2.0 * M * Nn * Kk for Nn, Kk in stack_shapes), "hbm",
+                                           f"{len(stack_shapes)} weight gradients of the point-cloud encoder stack in ONE launch (what the step "
+                                           f"launches), {M} tokens: operands read once + dW written once")
     # ---- fused encoder-layer tail (o_proj .. MLP .. next layer's LayerNorm + q/k/v): 9232 B and 2*256*2048 flop per token at D = 256
     layers = nn.ModuleList([SelfAttentionLayer(H, D, a["MR"], 0.0, 0.1, 0.5) for _ in range(2)]).to(device)
     layers.train()
     blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
     packed = ops._pack_blocks(blocks, layers[0], device)
     base = torch.randn(M, D, device=device); pos = torch.randn(M, D, device=device)
-    o = torch.randn(M, D, device=device).to(torch.bfloat16)
+    o = torch.randn(M, D, device=device).to(H16)
     lse = torch.zeros(B * H * G, device=device)
     att, mlp = layers[0][0].module.attention, layers[0][1].module
     nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
     us = _events(lambda: ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, M, device), 20, 3)
-    # per token: o (bf16) + base, x1, out, pos (f32) + n2, next n1 (bf16) + u, h (bf16, hidden) + next q|k|v (bf16) + LayerNorm statistics
+    # per token: o (h16) + base, x1, out, pos (f32) + n2, next n1 (h16) + u, h (h16, hidden) + next q|k|v (h16) + LayerNorm statistics
     per_row = 28 * D + 4 * Hd + 16
     legs["sa_layer_fwd_kernel"] = _leg("sa_layer_fwd_kernel" if D == 256 else "sa_rows_fwd_kernel", us, float(per_row) * M,
                                        2.0 * D * (D + 2 * Hd + 3 * D) * M, "hbm", f"fused encoder-layer tail, {M} tokens x {D} channels")
@@ -186,18 +218,18 @@ def kernel_legs(device, a, pairs):
 
 def _bwd_rows_leg(device, layers, packed, st, M, D, Hd, g):
     """vpf_sa_layer_bwd_qkv_mlp stand-alone: the qkv half of layer 1's backward and the MLP half of layer 0's in one launch
-    (csrc/sa_layer.hip).  Per token it reads dqkv (bf16 3D), base, the upper dx1, the running positional sum and the lower x1 (f32 D
-    each), u (bf16 hidden) and four LayerNorm statistics; it writes dbase, dsum, dx1 (f32 D), dz2, dz1, dout (bf16 D) and du (bf16
+    (csrc/sa_layer.hip).  Per token it reads dqkv (h16 3D), base, the upper dx1, the running positional sum and the lower x1 (f32 D
+    each), u (h16 hidden) and four LayerNorm statistics; it writes dbase, dsum, dx1 (f32 D), dz2, dz1, dout (h16 D) and du (h16
     hidden): 40 D + 4 hidden + 16 bytes.  Flops: dqkv.Wqkv (3D x D), d.W2 (D x hidden), du.W1 (hidden x D), dz1.Wo (D x D)."""
     import ctypes
     from vipformer_amd import _lib, ops
     rn = lambda *sh: torch.randn(*sh, generator=g).to(device)
-    u = rn(M, Hd).bfloat16(); x1 = rn(M, D); base = rn(M, D); dqkv = (0.1 * rn(M, 3 * D)).bfloat16(); dx1_up = rn(M, D)
+    u = rn(M, Hd).to(H16); x1 = rn(M, D); base = rn(M, D); dqkv = (0.1 * rn(M, 3 * D)).to(H16); dx1_up = rn(M, D)
     m2 = x1.mean(1).contiguous(); r2 = (x1.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
     m1 = base.mean(1).contiguous(); r1 = (base.var(1, unbiased=False) + 1e-5).rsqrt().contiguous()
     up, low = layers[1], layers[0]
     f32 = lambda *sh: torch.empty(*sh, device=device)
-    b16 = lambda *sh: torch.empty(*sh, dtype=torch.bfloat16, device=device)
+    b16 = lambda *sh: torch.empty(*sh, dtype=H16, device=device)
     out = dict(dbase=f32(M, D), dsum=torch.zeros(M, D, device=device), dz2=b16(M, D), du=b16(M, Hd), dx1=f32(M, D), dz1=b16(M, D), do=b16(M, D))
     pg = torch.zeros(2, ops.pgrad_rows(M, D) * 2 * D, device=device)
     a = _lib.SaLayerBwd()
@@ -218,12 +250,27 @@ def _bwd_rows_leg(device, layers, packed, st, M, D, Hd, g):
                 f"fused encoder-layer backward (qkv half of layer l + MLP half of layer l-1), {M} tokens x {D} channels")
 
 
+def _build_id():
+    import ctypes
+    from vipformer_amd import _lib
+    fn = _lib.lib().vpf_build_id
+    fn.restype = ctypes.c_char_p
+    return fn().decode().replace("VPF_BUILD_ID=", "")
+
+
 def _step_profile(arch):
+    """The committed whole-step budget of this architecture -- ONLY if it was collected with the library that is loaded now (the
+    budget's `build_id` is vpf_build_id() of the run that produced it): a budget of another build says nothing about these kernels
+    (ADVICE r03), so it is dropped and the line carries the live stand-alone figures alone."""
     try:
         with open(PROFILE_STEP[arch]) as f:
-            return json.load(f)
+            prof = json.load(f)
     except (OSError, ValueError, KeyError):
         return {}
+    if prof.get("build_id") != _build_id():
+        return {"stale": f"{os.path.relpath(PROFILE_STEP[arch], ROOT)} was collected with build {str(prof.get('build_id'))[:12]}, "
+                         f"this library is {_build_id()[:12]}: in-step figures omitted"}
+    return prof
 
 
 def _pmc():
@@ -241,7 +288,9 @@ PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step budget
     "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel", "sa_rows_fwd_kernel"],
     "sa_bwd_qkv_mlp_rows_kernel": ["sa_bwd_qkv_mlp_rows_kernel"],
     "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel<3, 128>", "attn_fwd_kernel<4, 128>"],
-    "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel<3, 128>", "attn_bwd_dq_kernel<4, 128>", "attn_bwd_dkv", "attn_bwd_ca_kernel"],
+    # (one "launch" of the leg = the merged kernel, or the dq + dk/dv pair of the same shape where the merged one is not used)
+    "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel<3, 128>", "attn_bwd_dq_kernel<4, 128>", "attn_bwd_dkv_resq_kernel<4, 3>",
+                                                    "attn_bwd_dkv_resq_kernel<4, 4>", "attn_bwd_ca_kernel"],
     "attn_res_fwd_kernel (self-attention pc)": ["attn_res_fwd_kernel<3>", "attn_res_fwd_kernel<4>"],
     "attn_res_fwd_kernel (self-attention img)": ["attn_res_fwd_kernel<7>"],
     "attn_res_bwd_kernel (self-attention pc)": ["attn_res_bwd_kernel<3>", "attn_res_bwd_kernel<4>"],
@@ -262,7 +311,7 @@ def attach_profile(legs, prof):
         for sub in PROFILE_NAMES.get(key, [leg["kernel"]]):
             for r in rows:
                 if sub in r["kernel"] and r.get("launches_per_step"):
-                    avg += (r.get("avg_us_in_step") or 0.0) if sub != "attn_bwd_dkv" or True else 0.0
+                    avg += r.get("avg_us_in_step") or 0.0
                     us_all += r["us_per_step"]; byt += r.get("hbm_bytes_per_launch") or 0.0
                     n_l = max(n_l, r["launches_per_step"]); found = True
         if found:
@@ -273,7 +322,7 @@ def attach_profile(legs, prof):
             if avg > 0:
                 leg["hbm_gbs_in_step"] = round(leg["bytes_per_launch"] / avg / 1e3, 1)
                 leg["hbm_frac_in_step"] = round(leg["bytes_per_launch"] / avg / 1e3 / PEAK_HBM_GBS, 4)
-                leg["mfma_frac_in_step"] = round(leg["flops_per_launch"] / avg / 1e6 / PEAK_BF16_TFLOPS, 4)
+                leg["mfma_frac_in_step"] = round(leg["flops_per_launch"] / avg / 1e6 / PEAK_H16_TFLOPS, 4)
         p = pmc.get(key) or pmc.get(leg["kernel"])
         if p:
             for k, v in p.items():
@@ -372,13 +421,125 @@ def cpu_baseline(a, pairs=8, timed_steps=3):
                 torch=torch.__version__, logical_cpus=os.cpu_count())
 
 
+# ----------------------------------------------------------------------------------------------- BASELINE configs[4]: the part-segmentation fine-tune step
+def partseg_line(args, device):
+    """`--arch c5`: one fine-tune step of CrossFormer_partseg on the pre-training backbone of configs[2] (E1CL8SL-H4D256-L128-MR2),
+    ft_partseg.py:145-176 as it stands: zero_grad(set_to_none=True), forward(points, one-hot object label), CrossEntropyLoss(
+    label_smoothing 0.2), backward, clip_grad_norm_(10), torch.optim.AdamW -- eager, no Pretrainer (the reference's fine-tune loops have
+    none), parser.py's defaults (batch 16, 1024 points, 16 object / 50 part classes).  A side line with its own metric; never `value`
+    of the pre-training metric."""
+    from vipformer_amd import ops_seg as S
+    from vipformer_amd.model.pointcloud import CrossFormer_partseg, PointCloudInputAdapter
+    a = ARCHS["c3"]
+    B, N = args.pairs or 16, 1024
+    torch.manual_seed(1)
+    ad = PointCloudInputAdapter((N, 3), a["D"])
+    m = CrossFormer_partseg(ad, a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.1, 0.5, [2, 5, 8], 50).to(device)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    pts = torch.randn(B, N, 3, generator=g)
+    pts = ((pts - pts.mean(1, keepdim=True)) / pts.norm(dim=2).max(dim=1)[0].view(B, 1, 1)).to(device)
+    onehot = torch.zeros(B, 16, device=device)
+    onehot[torch.arange(B), torch.arange(B) % 16] = 1.0
+    target = torch.randint(0, 50, (B, N), generator=g).to(device)
+    last = [0.0]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = m(pts, onehot)
+        loss = S.cross_entropy_smooth(pred.reshape(-1, 50), target.reshape(-1), 0.2)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 10, norm_type=2)
+        opt.step()
+        last[0] = loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.steps
+    return {"metric": "part-segmentation fine-tune clouds/sec (ShapeNetPart-shaped, E1CL8SL-H4D256-L128-MR2 backbone)", "value": round(B / el, 2),
+            "unit": "clouds/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: CrossFormer_partseg fine-tune step, {B} clouds x {N} points, 16 object / 50 part classes, "
+                                   "CE(label_smoothing 0.2) + clip_grad_norm_(10) + torch AdamW, eager (ft_partseg.py:145-176)",
+                       "last_loss": float(last[0]), "hip_graph": False,
+                       "note": "side line: the reference's fine-tune loop body unchanged on the mirrored CrossFormer_partseg; not the pre-training metric"},
+            "roofline": None, "cpu_baseline": None}
+
+
+# ----------------------------------------------------------------------------------------------- the drop-in path (INTEGRATION.md section 1)
+def modules_ddp_eager(a, pairs, t1, t2, imgs, device, steps):
+    """What a reference maintainer gets WITHOUT the Pretrainer fast path: pretrain.py:104-124,173-211 as it stands -- the mirrored
+    modules in DistributedDataParallel (a one-rank RCCL group), ONE torch.optim.AdamW over both models, torch's GradScaler, autocast,
+    zero_grad(set_to_none=True), eager launches from Python, the three loss `.item()` reads of the reference's logging -- no flat
+    buffers, no fused AdamW, no hipGraph.  A side line (never `value`): the cost of the drop-in as a number."""
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from vipformer_amd import ops
+    from vipformer_amd.train import build_models
+    created = not dist.is_initialized()
+    if created:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)              # "nccl" IS RCCL on ROCm
+    try:
+        torch.manual_seed(1)
+        pc, im = build_models(**a, device=device)
+        pc_ddp = DDP(pc, device_ids=[device.index], find_unused_parameters=False)            # pretrain.py:104-105
+        im_ddp = DDP(im, device_ids=[device.index], find_unused_parameters=False)
+        opt = torch.optim.AdamW(list(pc_ddp.parameters()) + list(im_ddp.parameters()), lr=1e-3)      # pretrain.py:106,121-124
+        scaler = torch.amp.GradScaler("cuda")                                                # pretrain.py:154
+        pc_ddp.train(); im_ddp.train()
+        imgs_nhwc = imgs
+        b = t1.shape[0]
+        last = [None]
+
+        def step():
+            opt.zero_grad(set_to_none=True)                                                  # pretrain.py:174
+            with torch.autocast("cuda", dtype=torch.float16):                                # pretrain.py:176
+                x = torch.permute(imgs_nhwc, (0, 2, 3, 1))                                   # :179
+                pcs = torch.cat([t1, t2], dim=0)                                             # :183
+                feats = pc_ddp(pcs)[0]
+                f1, f2 = feats[:b, :], feats[b:, :]
+                loss_imid = ops.ntxent_loss(f1, f2, 0.1)                                     # :196 (lightly's NTXentLoss, restated)
+                img_feats = im_ddp(x)[0]
+                loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, 0.1)                   # :197-202
+                total = loss_imid + 1.0 * loss_cmid
+            scaler.scale(total).backward()                                                   # :209
+            scaler.step(opt)                                                                 # :210
+            scaler.update()                                                                  # :211
+            last[0] = (loss_imid.item(), loss_cmid.item(), total.item())                     # :213-216 (the reference's loss meters)
+
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        return dict(value=round(pairs / el, 2), ms_per_step=round(el * 1e3, 3), steps=steps, last_losses=list(last[0]),
+                    grad_scale=float(scaler.get_scale()),
+                    note="pretrain.py:104-124,173-211 unchanged on the mirrored modules: DistributedDataParallel (one-rank RCCL group), "
+                         "torch.optim.AdamW over both models, torch GradScaler + autocast, eager launches, per-step loss .item() reads; "
+                         "no Pretrainer, no hipGraph (INTEGRATION.md section 1)")
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 # ----------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--arch", choices=sorted(ARCHS), default="c2", help="c2 = BASELINE configs[1] (the metric's workload)")
+    ap.add_argument("--arch", choices=sorted(ARCHS) + ["c5"], default="c2",
+                    help="c2 = BASELINE configs[1] (the metric's workload); c3 / c4 / ref144: side lines; c5: the part-segmentation fine-tune step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the stand-alone kernel legs (profiling runs)")
@@ -387,6 +548,12 @@ def main():
     ap.add_argument("--wgrad-async", action="store_true", help="grouped weight-gradient launches on a side stream")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the configuration's per-GPU batch)")
     args = ap.parse_args()
+    if args.arch == "c5":
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("--arch c5 is a one-GPU side line")
+        torch.cuda.set_device(0)
+        print(json.dumps(partseg_line(args, torch.device("cuda", 0))), flush=True)
+        return
     a = ARCHS[args.arch]
     pairs = args.pairs or PAIRS[args.arch]
 
@@ -501,6 +668,20 @@ def main():
         return el
 
     elapsed = timed(run, args.steps)
+    # SURVEY 8d quotes the metric on the MEDIAN step of >= 100: `value` stays on the driver's --steps (a mean), the median of 200 more
+    # steps -- HIP events between consecutive steps on the launch stream -- goes to config.median_ms_200
+    median_ms = None
+    if use_graph and os.environ.get("VPF_BENCH_MEDIAN", "1") == "1":
+        n_med = 200
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_med + 1)]
+        fence()
+        evs[0].record()
+        for i in range(n_med):
+            run()
+            evs[i + 1].record()
+        fence()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_med))
+        median_ms = dict(median=round(per[n_med // 2], 4), p10=round(per[n_med // 10], 4), p90=round(per[(9 * n_med) // 10], 4), steps=n_med)
     comm_ms = None
     if tr.dp:
         # the same steps again with device events around every region's exchange on the communication stream (never inside `value`)
@@ -592,6 +773,12 @@ def main():
                                                        "point 0): what FPS / kNN see on augmented ShapeNetRender data")
         static[0].copy_(t1); static[1].copy_(t2)
 
+    if world == 1 and not force_dp and not args.no_variants:
+        try:
+            variants["modules_ddp_eager"] = modules_ddp_eager(a, pairs, t1, t2, imgs, device, max(5, args.steps // 2))
+        except Exception as e:                                       # noqa: BLE001 -- a side line must never cost the metric
+            variants["modules_ddp_eager"] = dict(error=repr(e))
+
     legs, roof = {}, None
     prof = _step_profile(args.arch) if rank == 0 else {}
     if rank == 0 and not args.no_kernels:
@@ -600,23 +787,28 @@ def main():
         key = dominant(legs, rows)
         d = legs[key]
         bound = d["bound"] if d["bound"] in ("hbm", "mfma") else "hbm"
-        in_step = d.get("in_step_avg_us")
-        us = in_step or d["us_per_launch"]                 # the in-step average when the whole-step budget of this arch is committed
+        peak, unit = (PEAK_HBM_GBS, "GB/s") if bound == "hbm" else (PEAK_H16_TFLOPS, "TFLOP/s")
         alg = d["bytes_per_launch"] if bound == "hbm" else d["flops_per_launch"]
-        ach = alg / us / 1e3 if bound == "hbm" else alg / us / 1e6
-        peak, unit = (PEAK_HBM_GBS, "GB/s") if bound == "hbm" else (PEAK_BF16_TFLOPS, "TFLOP/s")
-        ach_alone = d["hbm_gbs"] if bound == "hbm" else d["mfma_tflops"]
-        roof = dict(bound=bound, kernel=f"{d['kernel']}: {d['note']}", achieved=round(ach, 1), peak=peak, unit=unit, frac=round(ach / peak, 4),
+        rate = lambda us: alg / us / 1e3 if bound == "hbm" else alg / us / 1e6
+        in_step = d.get("in_step_avg_us")
+        # achieved / frac: when the whole-step budget committed under profiles/ was collected with THIS build of the library (its
+        # build_id == vpf_build_id()), the kernel's IN-STEP average duration of that rocprofv3 trace of this very command; otherwise
+        # the live stand-alone timing of this run.  Both are always in the line under explicit names.
+        us = in_step or d["us_per_launch"]
+        roof = dict(bound=bound, kernel=f"{d['kernel']}: {d['note']}", achieved=round(rate(us), 1), peak=peak, unit=unit, frac=round(rate(us) / peak, 4),
                     traffic=d.get("hbm_bytes_per_launch"), us_per_launch=round(us, 2), launches_per_step=d.get("launches_per_step"),
-                    frac_standalone=round(ach_alone / peak, 4), us_per_launch_standalone=d["us_per_launch"],
+                    frac_is="in_step_profiled" if in_step else "standalone_live",
+                    frac_standalone_live=round(rate(d["us_per_launch"]) / peak, 4), us_per_launch_standalone_live=d["us_per_launch"],
+                    frac_in_step_profiled=(round(rate(in_step) / peak, 4) if in_step else None), us_per_launch_in_step_profiled=in_step,
                     hbm_frac=d.get("hbm_frac_in_step", d["hbm_frac"]), mfma_frac=d.get("mfma_frac_in_step", d["mfma_frac"]),
                     bytes_per_launch=d["bytes_per_launch"], flops_per_launch=d["flops_per_launch"],
-                    share_of_step_kernel_time=d.get("share_of_step_kernel_time"),
-                    source=("achieved / frac: algorithmic bytes over the kernel's IN-STEP average duration and traffic = its in-step HBM bytes "
-                            "(FETCH_SIZE x 2 + WRITE_SIZE), both from " + os.path.relpath(PROFILE_STEP[args.arch], ROOT) + " (rocprofv3 passes of "
-                            "this command, tools/collect_step_bytes.sh); *_standalone: timed live in this run, a hipGraph of 30 launches "
-                            "replayed, HIP events on the launch stream") if in_step else
-                           "no whole-step budget committed for this architecture: stand-alone live timing only")
+                    share_of_step_kernel_time=d.get("share_of_step_kernel_time"), profile_build_id=prof.get("build_id"),
+                    source=("frac = algorithmic bytes over the kernel's IN-STEP average duration, traffic = its in-step HBM bytes (FETCH_SIZE x 2 + "
+                            "WRITE_SIZE), both from " + os.path.relpath(PROFILE_STEP[args.arch], ROOT) + " (rocprofv3 passes of this command with "
+                            "this build of the library, tools/collect_step_bytes.sh); *_standalone_live: timed in this run, a hipGraph of "
+                            "launches replayed, HIP events on the launch stream") if in_step else
+                           ("stand-alone live timing only (a hipGraph of launches replayed, HIP events on the launch stream): "
+                            + prof.get("stale", "no whole-step budget committed for this architecture")))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(ARCHS["c2"])
@@ -629,15 +821,17 @@ def main():
             "metric": "pretrain pairs/sec (1024 pts + 224^2 img, L96 H4D256)" if args.arch == "c2" else f"pretrain pairs/sec ({NAMES[args.arch]})",
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "%s, per-GPU batch %d pairs (2x%d-pt clouds + 224x224 img, patch 16), fwd+bwd+AdamW, NT-Xent IMC+CMC, "
-                                   "dropout 0.1/0.5" % (NAMES[args.arch], pairs, a["N"]),
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "%s, per-GPU batch %d pairs (2x%d-pt clouds + %dx%d img, patch %d), fwd+bwd+AdamW, NT-Xent IMC+CMC, "
+                                   "dropout 0.1/0.5" % (NAMES[args.arch], pairs, a["N"], a["img"], a["img"], a["patch"]),
                        "global_batch": pairs * world, "parallelism": f"dp{world}" + (" (data-parallel code path forced in a one-rank group)" if force_dp else ""), "hip_graph": use_graph, "capture": capture_mode, "two_stream_overlap": tr.overlap,
                        **({"ablation": f"dropout probabilities overridden to {drops} (VPF_BENCH_DROPS): NOT the metric's workload"} if drops else {}),
                        "ranks_seen": ranks_seen, "comm_ms": comm_ms, "comm_regions": ([n for n, _, _ in tr.regions] if tr.dp else None),
                        "last_losses": losses, "losses_finite": finite,
+                       "median_ms_200": median_ms,
+                       "loss_scale": tr.loss_scale, "overflow_skipped_steps": tr.skipped_steps,      # GradScaler state after the run (device-resident)
                        "step_tflops_algorithmic": round(value * gf / 1e3, 2),
-                       "step_mfma_frac": round(value * gf / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+                       "step_mfma_frac": round(value * gf / 1e3 / (PEAK_H16_TFLOPS * world), 4),
                        "kernels_per_step": (prof.get("kernels_per_step") if use_graph else None),       # launches per replayed step (committed whole-step budget)
                        "step_hbm_bytes": prof.get("hbm_bytes_per_step"),                                # FETCH_SIZE x 2 + WRITE_SIZE summed over a step's kernels
                        "step_hbm_frac": (round(prof["hbm_bytes_per_step"] / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if prof.get("hbm_bytes_per_step") else None),

@@ -111,9 +111,25 @@ def grad_summary(model):
     return names, np.array(norms), np.stack(heads)
 
 
+def make_keys(names):
+    """state-dict key lists + shapes of the reference's two models for architectures added after round 1 (keys_*_<name>.json)."""
+    for name in names:
+        pc, im = build_ref(Hh.ARCHS[name])
+        json.dump(keyshapes(pc), open(os.path.join(HERE, f"keys_pc_{name}.json"), "w"))
+        json.dump(keyshapes(im), open(os.path.join(HERE, f"keys_img_{name}.json"), "w"))
+        cpath = os.path.join(HERE, "param_counts.json")
+        counts = json.load(open(cpath))
+        counts[name] = dict(pc_params=sum(p.numel() for p in pc.parameters()), img_params=sum(p.numel() for p in im.parameters()),
+                            pc_state=len(pc.state_dict()), img_state=len(im.state_dict()),
+                            pc_named=[k for k, _ in pc.named_parameters()], img_named=[k for k, _ in im.named_parameters()])
+        json.dump(counts, open(cpath, "w"))
+        print("keys", name, counts[name]["pc_params"], counts[name]["img_params"])
+
+
 def main(only_models=None):
     torch.set_num_threads(8)
     if only_models:
+        make_keys([n for n in only_models if not os.path.exists(os.path.join(HERE, f"keys_pc_{n}.json"))])
         return make_models(only_models)
     # ------------------------------------------------------------ key lists / param counts
     counts = {}
@@ -165,11 +181,12 @@ def main(only_models=None):
              sqdist_bits=(d.numpy().view(np.uint32) if small else d[:, :4, :].contiguous().numpy().view(np.uint32)),
              knn_dist=torch.gather(d, 2, can), meta=np.array([seed, B, N, C, G, K]))
 
-    make_models(("tiny", "tiny2", "c1", "c3", "c4"))
+    make_keys(Hh.REF_ARCHS)
+    make_models(("tiny", "tiny2", "c1", "c3", "c4") + Hh.REF_ARCHS)
     print("done")
 
 
-SLICED = ("c1", "c3", "c4")      # full-size architectures: stage outputs / big gradients are stored as slices
+SLICED = Hh.FULLSIZE      # full-size architectures: stage outputs / big gradients are stored as slices
 
 
 def make_models(names):
@@ -274,7 +291,7 @@ def make_models(names):
         json.dump(dict(pc=n, img=n2), open(os.path.join(HERE, f"grad_names_{name}.json"), "w"))
 
         # ---- dropout placement pin (oracle-only test): train mode, real p, torch RNG stream
-        if name not in SLICED:
+        if name not in ("c1", "c3", "c4"):
             pcd, imd = build_ref(a, drops=(0.1, 0.5))
             pcd.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100))
             imd.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200))

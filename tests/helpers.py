@@ -14,6 +14,9 @@ from typing import Dict, Iterable, List, Tuple
 import numpy as np
 import torch
 
+TEST_LOSS_SCALE = 256.0       # = tests/conftest.py's VPF_LOSS_SCALE: GradScaler's scale after it has backed off on the tests' tiny batches
+H16 = torch.float16          # the library's 16-bit operand dtype (vipformer_amd._lib.H16; a GPU test checks they agree)
+
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -130,10 +133,16 @@ ARCHS = {
     "c3": dict(D=256, H=4, G=128, K=32, S=8, MR=2, N=1024, img=224, patch=16),
     "c4": dict(D=384, H=6, G=128, K=32, S=8, MR=4, N=2048, img=224, patch=16),
     "tinyseg": dict(D=64, H=1, G=16, K=8, S=3, MR=2, N=256, img=32, patch=8),       # CrossFormer_partseg needs >= 3 layers to tap
+    # the geometry the reference's own training scripts ship (scripts/pretrain/pt-E1CL6SL-H4D256-L96-MR2-0.sh:10-16 with parser.py:112's
+    # default patch_size 12): 2048-point clouds at D = 256, 144 x 144 images -> T = 144 tokens, patch row K = 432 (not a multiple of 64)
+    "ref144": dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=2048, img=144, patch=12),
+    "ref144m4": dict(D=256, H=4, G=96, K=32, S=6, MR=4, N=2048, img=144, patch=12),  # ...-MR4-0.sh: hidden 1024 at D = 256
 }
+REF_ARCHS = ("ref144", "ref144m4")
+FULLSIZE = ("c1", "c3", "c4") + REF_ARCHS          # fixtures of these hold slices
 
 # pairs per batch used by the model_* / dropout-step fixtures and tests
-MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4, "c3": 4, "c4": 4, "tinyseg": 8}
+MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4, "c3": 4, "c4": 4, "tinyseg": 8, "ref144": 4, "ref144m4": 4}
 
 # CrossFormer_partseg taps (1-based self-attention layer numbers; the reference needs 3 or 4 of them, partseg.py:430-435)
 PARTSEG_LAYERS = {"tinyseg": [1, 2, 3], "c3": [2, 5, 8]}

@@ -4,7 +4,7 @@
     AccumulateGrad runs, ``p.grad`` is populated and the reducer's hooks fire;
   * a torch optimizer + the loop body of pretrain.py:174-211: parameters move, dropout masks are fresh every forward pass and the
     backward pass regenerates the masks of ITS forward pass even if other forward passes ran in between;
-  * writes to parameters that bump ``p._version`` (load_state_dict, optimizers) reach the bf16 MFMA operands, also for parameters
+  * writes to parameters that bump ``p._version`` (load_state_dict, optimizers) reach the h16 MFMA operands, also for parameters
     a Pretrainer owns.
 """
 import os
@@ -93,21 +93,23 @@ def test_ddp_wrapped_models_populate_grads_and_fire_reducer_hooks():
                 mod.p = 0.0
     pc.zero_grad(); im.zero_grad()
     loss = _loop_body(pc, im, t1, t2, imgs, start)
-    loss.backward()
+    SCALE = Hh.TEST_LOSS_SCALE
+    (loss * SCALE).backward()                            # scaler.scale(loss).backward() (pretrain.py:209)
     with forced_start(start):
         tr.forward_backward(t1, t2, imgs.permute(0, 3, 1, 2))
+    tr.unscale_()
     torch.cuda.synchronize()
     for m_a, m_b in ((pc, pc2), (im, im2)):
         for (k, p), (_, q) in zip(m_a.named_parameters(), m_b.named_parameters()):
             if k in zero_ok or float(q.grad.norm()) < 1e-6:
                 continue
             assert cosine(p.grad, q.grad) > 0.9999, k
-            assert rel(p.grad, q.grad) < 1e-2, k
+            assert rel(p.grad / SCALE, q.grad) < 1e-2, k
 
 
 def test_torch_optimizer_loop_trains_with_fresh_dropout_masks():
     """pretrain.py:174-211 with torch.optim.AdamW and no Pretrainer: two consecutive training-mode forward passes draw different
-    masks, the parameters move, and the bf16 operands follow the optimizer's in-place updates."""
+    masks, the parameters move, and the h16 operands follow the optimizer's in-place updates."""
     pc, im, a = build("tiny", (0.1, 0.5))
     pc.train(); im.train()
     opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3)
@@ -158,7 +160,7 @@ def test_backward_regenerates_the_masks_of_its_own_forward():
 
 
 def test_load_state_dict_after_pretrainer_reaches_the_mfma_operands():
-    """the trainer-owned bf16 shadow must follow load_state_dict (--resume, best checkpoint before eval)."""
+    """the trainer-owned h16 shadow must follow load_state_dict (--resume, best checkpoint before eval)."""
     from vipformer_amd.train import Pretrainer
     pc, im, a = build("tiny")
     tr = Pretrainer(pc, im)                                                  # noqa: F841  (owns the parameters from here on)
@@ -388,3 +390,29 @@ def test_replayed_step_is_bitwise_reproducible():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.main("c2", 8, 150) == 1
+
+
+def test_pretrainer_loss_scale_backs_off_on_overflow_inside_the_captured_graph():
+    """GradScaler semantics on the device (pretrain.py:154,209-211), followed by a REPLAYED hipGraph: started at a loss scale that
+    overflows fp16 (2 ** 30), the first replays find inf / NaN in the flat gradient, skip AdamW (parameters, moments and the
+    bias-correction counter stay put) and halve the scale; once the gradients fit, the steps train (the loss falls) and the scale stays."""
+    from vipformer_amd.train import Pretrainer
+    pc, im, a = build("tiny", (0.1, 0.5))
+    pc.train(); im.train()
+    tr = Pretrainer(pc, im, loss_scale=2.0 ** 30, growth_interval=1000)
+    t1, t2, imgs, start = _batch(a, 8)
+    tr.capture(t1, t2, imgs.permute(0, 3, 1, 2).contiguous(), warmup=2)
+    assert tr.loss_scale == 2.0 ** 30 and tr.skipped_steps == 0 and float(tr.hyper[6]) == 0.0      # the warm-ups changed nothing
+    p0 = tr.flat.p.clone()
+    scales, losses = [], []
+    for it in range(40):
+        l = tr.replay()
+        scales.append(tr.loss_scale); losses.append(float(l[0]))
+        if it == 0:
+            assert tr.skipped_steps == 1 and torch.equal(tr.flat.p, p0) and float(tr.hyper[6]) == 0.0, "an overflowed step must change nothing"
+    skipped = tr.skipped_steps
+    assert 1 <= skipped < 30, skipped
+    assert scales[-1] == 2.0 ** 30 * 0.5 ** skipped and scales[-1] == scales[-5]                     # halved once per skipped step, then stable
+    assert float(tr.hyper[6]) == 40 - skipped                                                       # AdamW's step counter counts the good steps only
+    assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.5, (losses[0], losses[-1])     # and those steps train
+    assert torch.isfinite(tr.flat.p).all().item()

@@ -2,11 +2,11 @@
 the HIP path runs configs 2, 3 and 4 at their per-GPU batch (64 / 32 / 16 pairs) against the oracle run live on the host
 (the oracle itself is pinned against the reference for all three architectures by tests/test_oracle_golden.py).
 
-  * eval-mode forward of both models: backbone and projected features, rel-L2 <= 2e-2 (a whole network of bf16 operand rounding,
-    the bound test_models_vs_reference_golden uses);
-  * the c2 architecture at 32 pairs, config 3 at 32 and config 4 at 16 pairs, train mode with the real dropout probabilities and the
-    kernels' own masks: the NT-Xent loss (abs <= 5e-3, the contract's bound: the head's BatchNorm sees 64 / 32 samples) and the
-    gradients of every parameter for a linear and for the pre-training loss, held to the precision budget measured on the batch.
+  * eval-mode forward of both models: backbone and projected features, rel-L2 <= 2e-3 (SURVEY 8c's bound for fp16 operands);
+  * the c2 architecture at 32 pairs, config 3 at 32 and config 4 at 16 pairs, the reference scripts' own geometry (2048 points,
+    144 x 144 / patch 12) at 32, train mode with the real dropout probabilities and the kernels' own masks: the NT-Xent loss
+    (abs <= 5e-3, the contract's bound), features behind the BatchNorm head <= 1e-2, and the gradients of every parameter for a
+    linear and for the pre-training loss against the fp32 oracle with constant floors (test_modules_gpu.FLOORS).
 """
 import numpy as np
 import pytest
@@ -17,7 +17,7 @@ from tests.test_modules_gpu import Checks, _site_masks, build, cosine, forced_st
 
 pytestmark = pytest.mark.gpu
 
-FULL = {"c1": 64, "c3": 32, "c4": 16}          # pairs per GPU of BASELINE configs[1], [2], [3]
+FULL = {"c1": 64, "c3": 32, "c4": 16, "ref144": 64}          # pairs per GPU of BASELINE configs[1], [2], [3]; the reference scripts' geometry
 
 
 def _oracle_sd(name):
@@ -26,7 +26,7 @@ def _oracle_sd(name):
     return pc_sd, im_sd
 
 
-@pytest.mark.parametrize("name", ["c1", "c3", "c4"])
+@pytest.mark.parametrize("name", ["c1", "c3", "c4", "ref144"])
 def test_full_batch_eval_forward_vs_oracle(name):
     from oracle import torch_oracle as O
     pc, im, a = build(name)
@@ -43,29 +43,28 @@ def test_full_batch_eval_forward_vs_oracle(name):
     with torch.no_grad():
         fr, bbr = O.pc_forward(pc_sd, pts, start, arch, False)
         fir, bbir = O.img_forward(im_sd, imgs, arch, False)
-    ck.lt("pc backbone rel", rel(bb, bbr), 2e-2)
-    ck.lt("pc feats rel", rel(f, fr), 2e-2)
-    ck.lt("img backbone rel", rel(bbi, bbir), 2e-2)
-    ck.lt("img feats rel", rel(fi, fir), 2e-2)
+    ck.lt("pc backbone rel", rel(bb, bbr), 2e-3)           # SURVEY 8c, fp16 operands: forward activations rel-L2 <= 2e-3 (measured 4 - 5e-4)
+    ck.lt("pc feats rel", rel(f, fr), 2e-3)
+    ck.lt("img backbone rel", rel(bbi, bbir), 2e-3)
+    ck.lt("img feats rel", rel(fi, fir), 2e-3)
     # per-sample worst case (a single bad cloud must not hide in the batch norm of the error)
     per = ((bb.cpu().double() - bbr.double()).norm(dim=1) / bbr.double().norm(dim=1)).max().item()
-    ck.lt("pc backbone worst-sample rel", per, 4e-2)
+    ck.lt("pc backbone worst-sample rel", per, 4e-3)
     ck.done()
 
 
-TRAIN_FULL = {"c1": 32, "c3": 32, "c4": 16}      # c1: half of configs[1]'s 64 pairs (the oracle's four backward passes stay in minutes)
+TRAIN_FULL = {"c1": 32, "c3": 32, "c4": 16, "ref144": 32}      # c1: half of configs[1]'s 64 pairs (the oracle's four backward passes stay in minutes)
 
 
-@pytest.mark.parametrize("name", ["c1", "c3", "c4"])
+@pytest.mark.parametrize("name", ["c1", "c3", "c4", "ref144"])
 def test_full_batch_train_step_loss_and_gradients(name):
     """Train mode at BASELINE batch sizes (c2 architecture at 32 pairs, config 3 at its 32, config 4 at its 16 pairs per GPU),
     dropout 0.1 / 0.5 with the kernels' own masks handed to the oracle.
       * NT-Xent loss: abs <= 5e-3 against the fp32 oracle (SURVEY 8c) -- the projection head's BatchNorm sees 64 / 32 samples here;
-      * gradients of a loss linear in the backbone features AND of the pre-training loss, every parameter: held to the precision
-        budget measured on this very batch (test_modules_gpu.budget_check: deficit of the bf16-emulating oracle against fp32; HIP
-        within 3 x of it against fp32 and against the emulation).  No constant floors: tests/rounding_budget.py shows that bf16
-        operand WEIGHTS alone cost the gradient 0.2 - 0.4 % of its direction, so SURVEY 8c's 0.999 is a property of the data format
-        at these depths and dropout rates, not of the kernels."""
+      * gradients of a loss linear in the backbone features AND of the pre-training loss, every parameter, against the fp32 oracle
+        with constant floors (test_modules_gpu.FLOORS: all-parameter cosine >= 0.998 / 0.996, worst tensor >= 0.99 / 0.98; measured
+        0.9990 - 0.9994 / 0.9983 - 0.9995 with fp16 operands, where bf16 operands gave 0.9855 - 0.9947); the deficit of the
+        fp16-emulating oracle on the same batch is reported beside it."""
     from oracle import torch_oracle as O
     from vipformer_amd import ops
     from tests.test_modules_gpu import budget_check, clear, grads_of
@@ -105,17 +104,17 @@ def test_full_batch_train_step_loss_and_gradients(name):
     fir, bbir = O.img_forward(s2, imgs, arch, True, imk, {})
     lref = O.ntxent(fr[:B], fr[B:]) + O.ntxent((fr[:B] + fr[B:]) / 2, fir)
     report(f"fullsize-train[{name}] loss hip {loss.item():.5f} fp32 oracle {lref.item():.5f}")
-    ck.lt("pc backbone rel (fp32 oracle)", rel(bb, bbr), 2e-2)
-    ck.lt("img backbone rel (fp32 oracle)", rel(bbi, bbir), 2e-2)
-    ck.lt("pc feats rel (fp32 oracle)", rel(f, fr), 2e-2)
-    ck.lt("img feats rel (fp32 oracle)", rel(fi, fir), 2e-2)
+    ck.lt("pc backbone rel (fp32 oracle)", rel(bb, bbr), 2e-3)          # train mode, dropout 0.1 / 0.5 (measured 3 - 4e-4)
+    ck.lt("img backbone rel (fp32 oracle)", rel(bbi, bbir), 2e-3)
+    ck.lt("pc feats rel (fp32 oracle)", rel(f, fr), 1e-2)               # behind the BatchNorm head (<= 1e-2; measured 2e-3)
+    ck.lt("img feats rel (fp32 oracle)", rel(fi, fir), 1e-2)
     ck.lt("loss abs diff vs fp32 oracle (SURVEY 8c: 5e-3)", abs(loss.item() - lref.item()), 5e-3)
     ((bbr * Rb).sum() + (bbir * Rbi).sum()).backward(retain_graph=True)
     lin_f32 = grads_of((pcp, imp)); clear((pcp, imp))
     lref.backward()
     ntx_f32 = grads_of((pcp, imp)); clear((pcp, imp))
     del fr, bbr, fir, bbir, lref
-    with O.emulate_bf16():
+    with O.emulate_fp16():
         fe, bbe = O.pc_forward(s1, pts, start, arch, True, pm, {})
         fie, bbie = O.img_forward(s2, imgs, arch, True, imk, {})
         le = O.ntxent(fe[:B], fe[B:]) + O.ntxent((fe[:B] + fe[B:]) / 2, fie)

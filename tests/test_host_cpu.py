@@ -49,7 +49,11 @@ def test_ctypes_table_matches_header():
                 t = p.split()[1] if p.startswith("const") else p.split()[0]
                 want.append({"int": "i", "long": "l", "float": "f", "uint32_t": "u"}[t])
         assert [kind[t] for t in sig] == want, name
-    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id", "vpf_debug_set", "vpf_debug_get", "vpf_sa_layer_pgrad_rows", "vpf_adapter_kv_pgrad_rows"}
+    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id", "vpf_operand_dtype", "vpf_debug_set", "vpf_debug_get", "vpf_sa_layer_pgrad_rows", "vpf_adapter_kv_pgrad_rows"}
+    # the 16-bit operand type the library was built for is the one the Python side allocates (fp16: the reference's autocast dtype)
+    import torch as _t
+    from tests import helpers as _Hh
+    assert _lib.lib().vpf_operand_dtype() == 1 and _lib.H16 == _t.float16 == _Hh.H16
     # the launch-time knobs: one struct, read by name, environment consulted once (csrc/api.hip)
     assert _lib.debug_get("knn_select") == 1 and _lib.debug_get("wgroup_cfg") == 2
     _lib.debug_set("knn_select", 0)
@@ -80,7 +84,7 @@ def _build(name):
                         device="cpu")
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4"])
+@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4", "ref144", "ref144m4"])
 def test_state_dict_keys_shapes_and_counts_match_reference(name):
     pc, im = _build(name)
     assert [(k, tuple(v.shape)) for k, v in pc.state_dict().items()] == Hh.load_keyshapes(f"keys_pc_{name}.json")

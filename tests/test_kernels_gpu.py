@@ -1,5 +1,5 @@
 """GPU parity of the individual HIP kernels (through the C ABI) against plain torch fp32
-references of the same op on the same bf16-rounded operands.  Tolerances are stated per test."""
+references of the same op on the same h16-rounded operands.  Tolerances are stated per test."""
 import math
 
 import numpy as np
@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from tests import helpers as Hh
+from tests.helpers import H16
 
 pytestmark = pytest.mark.gpu
 
@@ -21,7 +22,7 @@ def rnd(seed, *shape, scale=1.0):
 
 
 def bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(H16)
 
 
 # ------------------------------------------------------------------------------------------ GEMM
@@ -50,11 +51,11 @@ def test_gemm_epilogues_and_splitk():
     A16, W16 = bf(A), bf(W)
     ref = A16.float() @ W16.float().t() + bias
     y = ops.linear_fwd(A16, W16, N, K, bias)
-    assert rel(y.float(), ref) < 4e-3          # bf16 output rounding
+    assert rel(y.float(), ref) < 4e-3          # h16 output rounding
     y32 = ops.linear_fwd(A16, W16, N, K, bias, out_f32=True)
     assert rel(y32, ref) < 1e-5                # fp32 accumulate, only summation order differs
     # GELU epilogue (+ pre-activation), GELU' dgrad epilogue
-    u = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    u = torch.empty(M, N, dtype=H16, device="cuda")
     h = ops.linear_fwd(A16, W16, N, K, bias, mode=ops.EPI_GELU, C2=u, ldc2=N)
     assert rel(u.float(), ref) < 4e-3
     assert rel(h.float(), torch.nn.functional.gelu(u.float())) < 4e-3
@@ -110,7 +111,7 @@ def test_layernorm_fwd_bwd(rows, D):
     dx = ops.layernorm_bwd(dy, xsum, mean, rstd, gamma, beta, dres)
     yr.backward(dy.float())
     assert rel(dx, xr.grad + dres) < 1e-4 and rel(gamma.grad, g2.grad) < 1e-4 and rel(beta.grad, b2.grad) < 1e-4
-    # broadcast pos ([T,D] over the batch) and bf16 input
+    # broadcast pos ([T,D] over the batch) and h16 input
     T = rows // 4 if rows % 4 == 0 else rows
     y2, _, _, xs2 = ops.layernorm_fwd(x, gamma.data, beta.data, pos=pos[:T].contiguous(), want_sum=True)
     assert torch.equal(xs2, x + pos[:T].repeat(rows // T, 1))
@@ -148,7 +149,8 @@ def attn_ref(q, k, v, scale, keep, p):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lkv,p", [(2, 2, 96, 1024, 0.0), (2, 4, 196, 196, 0.0), (1, 1, 16, 8, 0.0), (2, 1, 33, 70, 0.0),
-                                          (2, 2, 96, 96, 0.1), (2, 4, 128, 128, 0.1), (3, 2, 120, 120, 0.0), (1, 2, 128, 1024, 0.1), (2, 4, 196, 196, 0.1), (3, 1, 50, 200, 0.5), (1, 2, 300, 520, 0.1), (2, 1, 160, 96, 0.0)])
+                                          (2, 2, 96, 96, 0.1), (2, 4, 128, 128, 0.1), (3, 2, 120, 120, 0.0), (1, 2, 128, 1024, 0.1), (2, 4, 196, 196, 0.1), (3, 1, 50, 200, 0.5), (1, 2, 300, 520, 0.1), (2, 1, 160, 96, 0.0),
+                                          (2, 4, 144, 144, 0.1), (1, 2, 150, 150, 0.0), (2, 4, 96, 2048, 0.1)])      # 144: the reference scripts' 144 x 144 / patch 12 image (resident <5>); 96 x 2048: their clouds
 def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
     from vipformer_amd import _lib as L
     from vipformer_amd import ops
@@ -158,7 +160,7 @@ def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
     q16, k16, v16, do16 = bf(q), bf(k), bf(v), bf(do)
     site = ops.new_site()
     scale = 64 ** -0.5
-    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B * Lq, D, dtype=H16, device="cuda")
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
     st = ops.rng.state("cuda")
     L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse)
@@ -167,18 +169,18 @@ def test_attention_fwd_bwd(B, H, Lq, Lkv, p):
     qr, kr, vr = split(q16, Lq), split(k16, Lkv), split(v16, Lkv)
     oref, lref = attn_ref(qr, kr, vr, scale, keep, p)
     og = o.float().view(B, Lq, H, 64).permute(0, 2, 1, 3)
-    assert rel(og, oref) < 8e-3, f"fwd rel {rel(og, oref)}"            # bf16 P and bf16 output
+    assert rel(og, oref) < 8e-3, f"fwd rel {rel(og, oref)}"            # h16 P and h16 output
     assert torch.allclose(lse.view(B, H, Lq), lref, rtol=1e-4, atol=1e-4)
-    dq = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
-    dk = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
-    dv = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+    dq = torch.empty(B * Lq, D, dtype=H16, device="cuda")
+    dk = torch.empty(B * Lkv, D, dtype=H16, device="cuda")
+    dv = torch.empty(B * Lkv, D, dtype=H16, device="cuda")
     L.call("vpf_attention_bwd", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
            dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"))
     oref.backward(do16.float().view(B, Lq, H, 64).permute(0, 2, 1, 3))
     unsplit = lambda t, Lx: t.permute(0, 2, 1, 3).reshape(B * Lx, D)
     for name, got, ref in (("dq", dq, unsplit(qr.grad, Lq)), ("dk", dk, unsplit(kr.grad, Lkv)), ("dv", dv, unsplit(vr.grad, Lkv))):
         r = rel(got.float(), ref)
-        assert r < 1.5e-2, f"{name} rel {r}"                                 # bf16 P/dS operands + bf16 outputs
+        assert r < 1.5e-2, f"{name} rel {r}"                                 # h16 P/dS operands + h16 outputs
 
 
 @pytest.mark.parametrize("B,L,D", [(128, 96, 256), (3, 50, 384), (2, 7, 6), (2, 33, 1024), (5, 196, 256)])
@@ -216,16 +218,16 @@ def test_attention_bwd_one_kernel_equals_two_bitwise(B, H, Lq, Lkv, p):
     q16, k16, v16, do16 = bf(rnd(1, B, Lq, D)), bf(rnd(2, B, Lkv, D)), bf(rnd(3, B, Lkv, D)), bf(rnd(4, B, Lq, D))
     site, scale = ops.new_site(), 64 ** -0.5
     st = ops.rng.state("cuda")
-    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B * Lq, D, dtype=H16, device="cuda")
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
     L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse)
 
     def run(flag):
         L.debug_set("attn_ca_merged", flag)
         try:
-            dq = torch.full((B * Lq, D), float("nan"), dtype=torch.bfloat16, device="cuda")
-            dk = torch.full((B * Lkv, D), float("nan"), dtype=torch.bfloat16, device="cuda")
-            dv = torch.full((B * Lkv, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+            dq = torch.full((B * Lq, D), float("nan"), dtype=H16, device="cuda")
+            dk = torch.full((B * Lkv, D), float("nan"), dtype=H16, device="cuda")
+            dv = torch.full((B * Lkv, D), float("nan"), dtype=H16, device="cuda")
             L.call("vpf_attention_bwd", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
                    dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"))
             torch.cuda.synchronize()
@@ -240,7 +242,7 @@ def test_attention_bwd_one_kernel_equals_two_bitwise(B, H, Lq, Lkv, p):
         assert torch.equal(a, b), (name, rel(b.float(), a.float()))
 
 
-@pytest.mark.parametrize("B,H,Lq,Lkv", [(2, 4, 196, 196), (2, 2, 96, 1024), (1, 2, 300, 520), (2, 4, 128, 128)])
+@pytest.mark.parametrize("B,H,Lq,Lkv", [(2, 4, 196, 196), (2, 2, 96, 1024), (1, 2, 300, 520), (2, 4, 128, 128), (2, 4, 144, 144)])
 def test_attention_dropout_32bit_group_index_equals_64bit_bitwise(B, H, Lq, Lkv):
     """The attention kernels index the dropout hash with 32-bit group numbers when B*H*Lq*Lkv < 2^32 (VPF_ATTN_RNG32, default on);
     the masks -- hence o, lse, dq, dk, dv -- must be bit-identical to the 64-bit indexing (which the exported mask uses)."""
@@ -254,12 +256,12 @@ def test_attention_dropout_32bit_group_index_equals_64bit_bitwise(B, H, Lq, Lkv)
     def run(flag):
         L.debug_set("attn_rng32", flag)
         try:
-            o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+            o = torch.empty(B * Lq, D, dtype=H16, device="cuda")
             lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
             L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse)
-            dq = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
-            dk = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
-            dv = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+            dq = torch.empty(B * Lq, D, dtype=H16, device="cuda")
+            dk = torch.empty(B * Lkv, D, dtype=H16, device="cuda")
+            dv = torch.empty(B * Lkv, D, dtype=H16, device="cuda")
             L.call("vpf_attention_bwd", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
                    dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"))
             torch.cuda.synchronize()
@@ -274,7 +276,7 @@ def test_attention_dropout_32bit_group_index_equals_64bit_bitwise(B, H, Lq, Lkv)
 @pytest.mark.parametrize("B,H,Lq,Lkv,p", [(3, 2, 40, 70, 0.0), (2, 2, 96, 1024, 0.1), (3, 4, 196, 196, 0.1), (2, 1, 33, 300, 0.5), (3, 2, 96, 96, 0.0)])
 def test_attention_pad_mask_fwd_bwd(B, H, Lq, Lkv, p):
     """vpf_attention_fwd_pad / _bwd_pad (partseg.py:73-77: masked_fill_(pad_mask, -finfo.max) in front of the softmax) against torch
-    fp32 on the same bf16 operands and the kernel's own dropout mask: a tail mask, a scattered mask, and -- last batch row -- every
+    fp32 on the same h16 operands and the kernel's own dropout mask: a tail mask, a scattered mask, and -- last batch row -- every
     key padded (uniform attention; dq = dk = 0 there, dv = mean of dout).  Without a mask set the result is the unmasked kernels'."""
     from vipformer_amd import _lib as L
     from vipformer_amd import ops
@@ -291,7 +293,7 @@ def test_attention_pad_mask_fwd_bwd(B, H, Lq, Lkv, p):
     site = ops.new_site()
     scale = 64 ** -0.5
     st = ops.rng.state("cuda")
-    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B * Lq, D, dtype=H16, device="cuda")
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
     L.call("vpf_attention_fwd_pad", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse, pad8)
     keep = ops.dropout_keep_mask(site, p, (B, H, Lq, Lkv), "cuda").float() if p > 0 else None
@@ -309,9 +311,9 @@ def test_attention_pad_mask_fwd_bwd(B, H, Lq, Lkv, p):
     part = ~pad.all(dim=1)                                     # rows with a real key: the log-sum-exp is an ordinary number
     assert torch.allclose(lse.view(B, H, Lq)[part.cuda()], lref[part.cuda()], rtol=1e-4, atol=1e-4)
     assert bool((lse.view(B, H, Lq)[B - 1] < -1e37).all())     # every key padded: ~ -finfo.max, recognised by the backward kernels
-    dq = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
-    dk = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
-    dv = torch.empty(B * Lkv, D, dtype=torch.bfloat16, device="cuda")
+    dq = torch.empty(B * Lq, D, dtype=H16, device="cuda")
+    dk = torch.empty(B * Lkv, D, dtype=H16, device="cuda")
+    dv = torch.empty(B * Lkv, D, dtype=H16, device="cuda")
     L.call("vpf_attention_bwd_pad", q16, D, k16, D, v16, D, o, D, do16, D, lse, B, H, Lq, Lkv, 64, scale, p, st, site,
            dq, D, dk, D, dv, D, torch.empty(B * H * Lq, dtype=torch.float32, device="cuda"), pad8)
     oref.backward(do16.float().view(B, Lq, H, 64).permute(0, 2, 1, 3))
@@ -347,7 +349,7 @@ def test_attention_strided_qkv_views():
     B, H, Lq = 2, 2, 96
     D = 128
     qkv = bf(rnd(1, B * Lq, 3 * D))
-    o = torch.empty(B * Lq, D, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B * Lq, D, dtype=H16, device="cuda")
     lse = torch.empty(B * H * Lq, dtype=torch.float32, device="cuda")
     L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, 64, 0.125, 0.0,
            ops.rng.state("cuda"), 1, o, D, lse)
@@ -386,7 +388,7 @@ def test_batchnorm_pieces():
 @pytest.mark.parametrize("M,C", [(128, 256), (37, 64), (1, 64), (256, 512)])
 def test_batchnorm_small_batch_one_kernel(M, C):
     """vpf_bn_small_fwd / vpf_bn_small_bwd (projection heads, partseg.py:519-525: BatchNorm1d + ReLU in training mode on a
-    batch of 64 .. 256 rows as ONE kernel each way) against torch.nn.BatchNorm1d fp32.  Tolerances: the output is bf16
+    batch of 64 .. 256 rows as ONE kernel each way) against torch.nn.BatchNorm1d fp32.  Tolerances: the output is h16
     (2^-8 relative per element -> 3e-3 on the norm), statistics and gradients are fp32 sums (1e-4)."""
     from vipformer_amd import _lib as L
     x = rnd(11, M, C, scale=2.0) + 0.3
@@ -394,7 +396,7 @@ def test_batchnorm_small_batch_one_kernel(M, C):
     bn.weight.data = rnd(12, C) * 0.2 + 1; bn.bias.data = rnd(13, C) * 0.1
     ref = torch.nn.BatchNorm1d(C).cuda()
     ref.load_state_dict(bn.state_dict())
-    stat = torch.empty(2 * C, device="cuda"); y = torch.empty(M, C, dtype=torch.bfloat16, device="cuda")
+    stat = torch.empty(2 * C, device="cuda"); y = torch.empty(M, C, dtype=H16, device="cuda")
     L.call("vpf_bn_small_fwd", x, M, C, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), bn.running_mean, bn.running_var,
            bn.num_batches_tracked, stat, y, 1)
     xr = x.clone().requires_grad_()
@@ -403,18 +405,18 @@ def test_batchnorm_small_batch_one_kernel(M, C):
         assert rel(y.float(), yr) < 3e-3
         assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-5) and torch.allclose(bn.running_var, ref.running_var, rtol=1e-4, atol=1e-6)
     else:       # torch refuses a single row in training mode; the kernel follows the formula (var = 0 -> y = relu(beta))
-        assert torch.allclose(y.float()[0], torch.relu(bn.bias.data).to(torch.bfloat16).float(), atol=1e-6)
+        assert torch.allclose(y.float()[0], torch.relu(bn.bias.data).to(H16).float(), atol=1e-6)
         return
     assert int(bn.num_batches_tracked) == 1
     assert torch.allclose(stat[:C], x.mean(0), atol=1e-5)
     dy = rnd(14, M, C)
-    for out_bf16 in (0, 1):
-        dx = torch.empty(M, C, dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+    for out_h16 in (0, 1):
+        dx = torch.empty(M, C, dtype=H16 if out_h16 else torch.float32, device="cuda")
         dg = torch.zeros(C, device="cuda"); db = torch.zeros(C, device="cuda")
-        L.call("vpf_bn_small_bwd", dy, x, stat, bn.weight.data, bn.bias.data, M, C, 1, dx, out_bf16, dg, db)
-        if out_bf16 == 0:
+        L.call("vpf_bn_small_bwd", dy, x, stat, bn.weight.data, bn.bias.data, M, C, 1, dx, out_h16, dg, db)
+        if out_h16 == 0:
             yr.backward(dy)
-        assert rel(dx.float(), xr.grad) < (3e-3 if out_bf16 else 2e-4)
+        assert rel(dx.float(), xr.grad) < (3e-3 if out_h16 else 2e-4)
         assert rel(dg, ref.weight.grad) < 2e-4 and rel(db, ref.bias.grad) < 2e-4
     # shapes the kernel does not take are refused loudly
     with pytest.raises(RuntimeError):
@@ -431,16 +433,16 @@ def test_group_max_concat_pool():
     assert torch.equal(out, mv)
     assert torch.equal(torch.gather(h.float().view(NG, K, C), 1, arg.long().unsqueeze(1)).squeeze(1), mv)
     dout = rnd(2, NG, C)
-    dh = torch.empty(NG * K, C, dtype=torch.bfloat16, device="cuda")
+    dh = torch.empty(NG * K, C, dtype=H16, device="cuda")
     L.call("vpf_group_max_bwd", dout, 0, arg, NG, K, C, dh)
     ref = torch.zeros(NG, K, C, device="cuda").scatter_(1, arg.long().unsqueeze(1), bf(dout).float().unsqueeze(1))
     assert torch.equal(dh.float().view(NG, K, C), ref)
     g16 = bf(out)
-    feat = torch.empty(NG * K, 2 * C, dtype=torch.bfloat16, device="cuda")
+    feat = torch.empty(NG * K, 2 * C, dtype=H16, device="cuda")
     L.call("vpf_g2e_concat_fwd", g16, h, NG * K, K, C, feat)
     assert torch.equal(feat.view(NG, K, 2 * C)[:, :, :C], g16.unsqueeze(1).expand(NG, K, C)) and torch.equal(feat[:, C:], h)
     dfeat = bf(rnd(3, NG * K, 2 * C))
-    dh2 = torch.empty(NG * K, C, dtype=torch.bfloat16, device="cuda")
+    dh2 = torch.empty(NG * K, C, dtype=H16, device="cuda")
     L.call("vpf_g2e_concat_bwd", dfeat, arg, NG, K, C, dh2)
     dfv = dfeat.float().view(NG, K, 2 * C)
     ref2 = dfv[:, :, C:] + torch.zeros(NG, K, C, device="cuda").scatter_(1, arg.long().unsqueeze(1), dfv[:, :, :C].sum(1, keepdim=True))
@@ -478,14 +480,62 @@ def test_adamw_matches_torch():
     ref = torch.nn.Parameter(p0.clone())
     opt = torch.optim.AdamW([ref], lr=1e-3)
     p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    sh = torch.empty(n, dtype=torch.bfloat16, device="cuda")
-    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0.0, 0.0], device="cuda")
+    sh = torch.empty(n, dtype=H16, device="cuda")
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0.0, 0.0] + [0.0] * 8, device="cuda")        # no loss scale
     for it in range(3):
         gi = g * (it + 1)
         ref.grad = gi.clone(); opt.step()
         L.call("vpf_adamw_step", p, gi, m, v, sh, n, hyper, 1)
     assert torch.allclose(p, ref.data, rtol=1e-5, atol=1e-7) and hyper[6].item() == 3.0
-    assert torch.equal(sh, p.to(torch.bfloat16))
+    assert torch.equal(sh, p.to(H16))
+
+
+def test_adamw_follows_gradscaler_step_and_update():
+    """torch.cuda.amp.GradScaler's step / update on the device (pretrain.py:154,209-211; include/vipformer_hip.h vpf_adamw_step):
+    gradients carry the loss scale and are divided by it; vpf_grad_check finds an inf / NaN anywhere in the flat gradient, that
+    step changes nothing (parameters, moments, bias-correction counter) and halves the scale; `growth interval` good steps in a
+    row double it; GradScaler.unscale_ (hyper[15]) hands AdamW gradients that are already unscaled."""
+    from vipformer_amd import _lib as L
+    n = 100003
+    S = 1024.0
+    p0, g = rnd(1, n), rnd(2, n, scale=0.01)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda", init_scale=S, growth_interval=3)
+    scaler.scale(torch.zeros(1, device="cuda"))            # (GradScaler creates its device-side scale lazily, at the first scale())
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    sh = torch.empty(n, dtype=H16, device="cuda")
+    #                      lr    b1   b2     eps   wd   gs   step skip  S  tracker interval found growth backoff skipped unscaled
+    hyper = torch.tensor([1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0.0, 0.0, S, 0.0, 3.0, 0.0, 2.0, 0.5, 0.0, 0.0], device="cuda")
+    bad_at = {2: float("inf"), 5: float("nan")}
+    for it in range(9):
+        scale_now = hyper[8].item()
+        assert scale_now == scaler.get_scale(), (it, scale_now, scaler.get_scale())
+        gi = g * (it + 1) * scale_now                      # what backward leaves behind scaler.scale(loss)
+        if it in bad_at:
+            gi[n - 2] = bad_at[it]                         # (the last float4 group's tail: the check's remainder path)
+        ref.grad = gi.clone()
+        scaler.step(opt); scaler.update()
+        gk = gi.clone()
+        if it == 7:                                        # GradScaler.unscale_ before the step (gradient clipping would sit here)
+            gk /= scale_now; hyper[15] = 1.0
+        L.call("vpf_grad_check", gk, n, hyper)
+        assert hyper[11].item() == (1.0 if it in bad_at else 0.0)
+        L.call("vpf_adamw_step", p, gk, m, v, sh, n, hyper, 1)
+        assert hyper[11].item() == 0.0 and hyper[15].item() == 0.0
+        assert torch.allclose(p, ref.data, rtol=1e-5, atol=1e-7), it
+    assert hyper[6].item() == 7.0 and hyper[14].item() == 2.0          # 9 steps, 2 skipped
+    assert torch.equal(sh, p.to(H16))
+    # a clean flat gradient of a length that is not a multiple of 4, and one whose only bad value sits in the remainder
+    for bad in (False, True):
+        x = torch.ones(4099, device="cuda")[:4098 + 0]
+        x = x[:4098].clone()
+        if bad:
+            x[4097] = float("-inf")
+        hyper[11] = 0.0
+        L.call("vpf_grad_check", x, x.numel(), hyper)
+        assert hyper[11].item() == float(bad)
+    hyper[11] = 0.0
 
 
 def test_patchify_on_permuted_nchw_view():
@@ -493,7 +543,7 @@ def test_patchify_on_permuted_nchw_view():
     from vipformer_amd import _lib as L
     imgs = Hh.synth_images(3, 2, 32, 48).cuda()                     # [B,H,W,3] view of NCHW
     assert not imgs.is_contiguous()
-    out = torch.empty(2 * (32 // 8) * (48 // 8), 8 * 8 * 3, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(2 * (32 // 8) * (48 // 8), 8 * 8 * 3, dtype=H16, device="cuda")
     sb, sh, sw, sc = imgs.stride()
     L.call("vpf_patchify", imgs, sb, sh, sw, sc, 2, 32, 48, 3, 8, out)
     assert torch.equal(out.view(2, -1, 192), bf(O.patchify(imgs.cpu(), 8)).cuda())
@@ -526,7 +576,7 @@ def test_fused_pretrain_losses_match_the_two_ntxent_calls():
 def test_grouped_wgrad_workspace_split_k():
     """vpf_wgrad_group with the split-K workspace (partial tiles + last-arriver reduction, no atomics on dW): the four weight
     gradients of an encoder layer at the benchmark's token count and at ragged sizes, accumulated INTO non-zero buffers, launched
-    twice in a row (the arrival counters must come back to zero), against fp32 matmuls of the same bf16 operands."""
+    twice in a row (the arrival counters must come back to zero), against fp32 matmuls of the same h16 operands."""
     from vipformer_amd import ops
     ops.cfg.wgrad_deterministic = True
     try:
@@ -666,9 +716,9 @@ def test_sa_rows_bwd_equals_the_one_per_cu_kernels_bitwise(M, with_dsum, dsum_in
 
     def run():
         nwg = ops.pgrad_rows(M, D)
-        out = dict(dz2=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"), du=torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda"),
-                   dx1=torch.empty(M, D, device="cuda"), dz1=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"),
-                   do=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"), dbase=torch.empty(M, D, device="cuda"), dsum=dsum0.clone())
+        out = dict(dz2=torch.empty(M, D, dtype=H16, device="cuda"), du=torch.empty(M, Hd, dtype=H16, device="cuda"),
+                   dx1=torch.empty(M, D, device="cuda"), dz1=torch.empty(M, D, dtype=H16, device="cuda"),
+                   do=torch.empty(M, D, dtype=H16, device="cuda"), dbase=torch.empty(M, D, device="cuda"), dsum=dsum0.clone())
         pg = torch.zeros(2, nwg * 2 * D, device="cuda")
         a = _lib.SaLayerBwd()
         a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
@@ -723,9 +773,9 @@ def test_sa_bwd_qkv_mlp_one_launch_equals_two_bitwise(M):
 
     def run(fuse):
         out = dict(dbase=torch.empty(M, D, device="cuda"), dsum=dsum0.clone(),
-                   dz2=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"), du=torch.empty(M, Hd, dtype=torch.bfloat16, device="cuda"),
-                   dx1=torch.empty(M, D, device="cuda"), dz1=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"),
-                   do=torch.empty(M, D, dtype=torch.bfloat16, device="cuda"))
+                   dz2=torch.empty(M, D, dtype=H16, device="cuda"), du=torch.empty(M, Hd, dtype=H16, device="cuda"),
+                   dx1=torch.empty(M, D, device="cuda"), dz1=torch.empty(M, D, dtype=H16, device="cuda"),
+                   do=torch.empty(M, D, dtype=H16, device="cuda"))
         pg = torch.zeros(2, nwg * 2 * D, device="cuda")
         a = _lib.SaLayerBwd()                                   # qkv half of the upper layer
         a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
@@ -779,7 +829,7 @@ def test_adapter_kv_bwd_rows_kernel_equals_the_round2_kernel_bitwise(B, N):
     dkv = bf(rnd(2, M, 2 * D, scale=0.1))
 
     def run(bit):
-        out = dict(dxkv=torch.zeros(M, D, dtype=torch.bfloat16, device="cuda"), da1=torch.zeros(M, 64, dtype=torch.bfloat16, device="cuda"),
+        out = dict(dxkv=torch.zeros(M, D, dtype=H16, device="cuda"), da1=torch.zeros(M, 64, dtype=H16, device="cuda"),
                    pg=torch.zeros(nwg, 2 * D, device="cuda"))
         a = _lib.AdapterKvBwd()
         a.M, a.C, a.D = M, 3, D
@@ -805,8 +855,8 @@ def test_adapter_kv_bwd_rows_kernel_equals_the_round2_kernel_bitwise(B, N):
 @pytest.mark.parametrize("B,G", [(128, 96), (3, 50)])
 def test_ca_front_kernel_vs_the_separate_kernels(B, G):
     """vpf_ca_front_fwd (position MLP + tokens + pos + q_norm + q projection in one row-block kernel) against the kernels it replaces
-    (vpf_smallk_fwd, vpf_gemm_bf16 with bias, vpf_layernorm_fwd with the positional term, vpf_gemm_bf16): same operands, same
-    rounding points (bf16 hidden layer, f32 pos / base, bf16 q_norm output and q), agreement to rounding."""
+    (vpf_smallk_fwd, vpf_gemm_h16 with bias, vpf_layernorm_fwd with the positional term, vpf_gemm_h16): same operands, same
+    rounding points (h16 hidden layer, f32 pos / base, h16 q_norm output and q), agreement to rounding."""
     import torch.nn as nn
     from vipformer_amd import ops
     from vipformer_amd.model.pointcloud.partseg import CrossAttentionLayer
@@ -835,7 +885,7 @@ def test_ca_front_kernel_vs_the_separate_kernels(B, G):
     q = ops.linear_fwd(nq, w16[:D * D], D, D)
     torch.cuda.synchronize()
     # (the hidden layer's GELU inputs differ in the last bit -- the compiler contracts the three taps differently -- which flips a
-    #  bf16 rounding of the hidden activation here and there)
+    #  h16 rounding of the hidden activation here and there)
     assert rel(pos, pos_ref) < 5e-4, rel(pos, pos_ref)
     assert rel(st["base"].view(B, G, D), base.view(B, G, D)) < 5e-4
     assert rel(st["mq"], mq) < 1e-5 and rel(st["rq"], rq) < 1e-5
@@ -849,4 +899,4 @@ def test_ca_front_kernel_vs_the_separate_kernels(B, G):
     seq.zero_grad()
     (pos_ref * R).sum().backward()
     for a_, b_ in zip(g1, [p.grad for p in seq.parameters()]):
-        assert rel(a_, b_) < 1e-3          # (the same kernels on hidden activations that differ in a few bf16 roundings; fp32 atomics)
+        assert rel(a_, b_) < 1e-3          # (the same kernels on hidden activations that differ in a few h16 roundings; fp32 atomics)

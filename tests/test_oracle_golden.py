@@ -47,7 +47,7 @@ def _close(x, ref, rtol=2e-5, atol=2e-5):
     np.testing.assert_allclose(x, ref, rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4"])
+@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4", "ref144", "ref144m4"])
 def test_models_vs_reference(name):
     arch, a = _arch(name)
     g = Hh.golden(f"model_{name}.npz")
@@ -92,7 +92,7 @@ def test_models_vs_reference(name):
         _close(bufs[k], g["pc_buf." + k])
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4"])
+@pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4", "ref144", "ref144m4"])
 def test_stages_vs_reference(name):
     arch, a = _arch(name)
     g = Hh.golden(f"stages_{name}.npz")
@@ -108,7 +108,7 @@ def test_stages_vs_reference(name):
     y = O.group2emb(s2, pre, nb, True, bufs)
     R = Hh.synth_like(500, y.shape)
     (y * R).sum().backward()
-    c1 = name in ("c1", "c3", "c4")          # full-size fixtures hold slices
+    c1 = name in Hh.FULLSIZE          # full-size fixtures hold slices
     _close(y[:, :8] if c1 else y, g["g2e_train"], 1e-4, 1e-4)
     _close(bufs[pre + "first_conv.1.running_mean"], g["g2e_rm1"]); _close(bufs[pre + "first_conv.1.running_var"], g["g2e_rv1"])
     _close(bufs[pre + "second_conv.1.running_mean"], g["g2e_rm2"]); _close(bufs[pre + "second_conv.1.running_var"], g["g2e_rv2"])
@@ -138,7 +138,7 @@ def test_stages_vs_reference(name):
     _close(ysa[sl], g["sa_out"], 1e-4, 1e-4); _close(x2.grad[sl], g["sa_dx"], 1e-3, 1e-4)
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny2"])
+@pytest.mark.parametrize("name", ["tiny", "tiny2", "ref144", "ref144m4"])
 def test_dropout_placement_vs_reference(name):
     """Train mode with the real probabilities: the oracle draws its masks from torch's
     RNG in the reference's call order, so equal seeds must give equal outputs.  Pins

@@ -1,7 +1,7 @@
 """GPU parity of CrossFormer_partseg + PointNetFeaturePropagation (BASELINE config 5 = the c3 architecture) against the
 reference fixtures (tests/golden/partseg_*.npz, make_golden.py make_partseg) and the oracle:
   * 3-NN indices and inverse-distance weights: BIT-exact (integer / IEEE work);
-  * logits eval / train: rel-L2 <= 2e-2 / 4e-2 (bf16 MFMA operands through the whole network + five BatchNorms over B*N rows);
+  * logits eval / train: rel-L2 <= 2e-2 / 4e-2 (h16 MFMA operands through the whole network + five BatchNorms over B*N rows);
   * label-smoothed cross entropy value, gradient norms per parameter, BatchNorm running statistics;
   * the head's Dropout(0.5) with the kernels' own mask handed to the oracle;
   * the ft_partseg.py:145-176 step (strict=False load of a pre-training checkpoint, CE(label_smoothing=0.2), clip_grad_norm_(10),
@@ -91,7 +91,7 @@ def test_partseg_vs_reference_golden(name):
                       "propagation.mlp_convs.0.bias", "propagation.mlp_convs.1.bias")
     # tensors that carry >= 3 % of the largest gradient norm: within 8 %.  The small ones (1e-3 .. 3e-2 of the largest: e.g. the q / k
     # projections of the last tapped layer, whose softmax gradient P * (dP - delta) is a difference of nearly equal numbers) carry the
-    # bf16 rounding of P / dO / O as noise of their own size; the bf16-emulating oracle reproduces them to cosine > 0.98 (next test).
+    # h16 rounding of P / dO / O as noise of their own size; the h16-emulating oracle reproduces them to cosine > 0.98 (next test).
     for lo, hi, bound, tag in ((3e-2, 2.0, 0.08, "large"), (1e-3, 3e-2, 0.30, "small")):
         sel = np.array([(lo * refn.max() < refn[i] <= hi * refn.max()) and (k not in zero_before_bn) for i, k in enumerate(names)])
         ratio = norms[sel] / refn[sel]
@@ -106,7 +106,7 @@ def test_partseg_vs_reference_golden(name):
 @pytest.mark.parametrize("name", ["tinyseg", "c3"])
 def test_partseg_training_step_with_dropout_vs_oracle(name):
     """Train mode, encoder dropouts 0.1 / 0.5 and the head's Dropout(0.5), every keep mask exported from the kernels and handed to
-    the oracle: logits and every parameter gradient against the bf16-emulating oracle (kernel logic) and the fp32 oracle."""
+    the oracle: logits and every parameter gradient against the h16-emulating oracle (kernel logic) and the fp32 oracle."""
     from oracle import torch_oracle as O
     from vipformer_amd import ops
     from tests.test_modules_gpu import _site_masks
@@ -134,7 +134,7 @@ def test_partseg_training_step_with_dropout_vs_oracle(name):
     with torch.no_grad():
         yr = O.partseg_forward(s2, pts, start, cls, arch, lidx, True, masks, {}, head_mask=head_mask)
     ck.lt("logits rel (fp32 oracle)", rel(y, yr), 4e-2)
-    with O.emulate_bf16():
+    with O.emulate_fp16():
         ye = O.partseg_forward(s2, pts, start, cls, arch, lidx, True, masks, {}, head_mask=head_mask)
     # (dropout p = 0.5 in every encoder layer and in the head scales activations by 2 ahead of five training-mode BatchNorms: the
     #  dropout-free comparison above sits at 5e-3, this one at ~1.1e-2)
@@ -177,7 +177,7 @@ def test_feature_propagation_module_vs_oracle():
         R = Hh.synth_like(4, (B, N, 64))
         (y.permute(0, 2, 1) * R.cuda()).sum().backward()
         fr = feat.clone().requires_grad_()
-        with O.emulate_bf16():
+        with O.emulate_fp16():
             yr = O.feature_propagation(sd, "p.", xyz1, xyz2, xyz1 if with_p1 else None, fr, True, {})
         (yr * R).sum().backward()
         assert rel(y.permute(0, 2, 1), yr) < 1e-2, rel(y.permute(0, 2, 1), yr)

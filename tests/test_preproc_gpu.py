@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from tests import helpers as Hh
+from tests.helpers import H16
 
 pytestmark = pytest.mark.gpu
 PRE = ["u1024", "u2048", "d1024", "g1024", "c6_1000", "u256", "u512"]
@@ -92,8 +93,8 @@ def test_fps_is_stable_beside_gemms_on_another_stream():
     want = O.fps_indices(pts, start, 96)
     pts_d, start_d = pts.cuda(), start.cuda()
     M, N, K = 12288, 512, 256
-    dY = torch.randn(M, N, device="cuda").bfloat16()
-    W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    dY = torch.randn(M, N, device="cuda").to(H16)
+    W = (torch.randn(N, K, device="cuda") * 0.05).to(H16)
     side = torch.cuda.Stream()
     torch.cuda.synchronize()
     bad = 0

@@ -64,7 +64,7 @@ def test_loss_curve_tracks_the_fp32_oracle():
     report("trajectory hip " + " ".join(f"{v:.3f}" for v in hip))
     report("trajectory ref " + " ".join(f"{v:.3f}" for v in ref))
     # measured (profiles/r02_parity_report.txt): 9.156 6.006 3.003 1.698 ... 0.020 against 9.170 5.975 2.943 1.749 ... 0.021
-    assert abs(hip[0] - ref[0]) < 5e-2                                    # same starting point (bf16 vs fp32 forward)
+    assert abs(hip[0] - ref[0]) < 5e-2                                    # same starting point (h16 vs fp32 forward)
     assert np.abs(hip - ref).max() < 0.15, np.abs(hip - ref).max()        # the whole curve within 0.15 (largest gap 0.06, on the steep part)
     assert hip[-1] < 0.01 * hip[0] and ref[-1] < 0.01 * ref[0]            # both overfit the fixed batch: 9.2 -> 0.02
     assert abs(hip[-1] - ref[-1]) < 0.25 * ref[-1], (hip[-1], ref[-1])    # and end at the same loss

@@ -6,6 +6,7 @@ such workgroups.  usage: python tools/diag_beside_gemms.py [runs=300] [pairs=8]"
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+H16 = torch.float16
 
 
 def main(runs=300, pairs=8):
@@ -22,7 +23,7 @@ def main(runs=300, pairs=8):
     start = torch.randint(0, A["N"], (2 * pairs,), device=dev)
     torch.randint = lambda *a, **k: start.clone()
     M, N, K = 12288, 512, 256
-    dY = torch.randn(M, N, device=dev).bfloat16(); W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    dY = torch.randn(M, N, device=dev).to(H16); W = (torch.randn(N, K, device=dev) * 0.05).to(H16)
     side = torch.cuda.Stream()
     seen = {"pc feats": collections.Counter(), "pc backbone": collections.Counter(), "img feats": collections.Counter(), "img backbone": collections.Counter()}
     h = lambda t: hash(t.detach().float().cpu().numpy().tobytes())

@@ -1,4 +1,4 @@
-"""Stage-by-stage comparison of the part-segmentation head (HIP) against the bf16-emulating oracle (diagnostic, GPU box)."""
+"""Stage-by-stage comparison of the part-segmentation head (HIP) against the h16-emulating oracle (diagnostic, GPU box)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

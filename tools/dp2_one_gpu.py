@@ -84,12 +84,13 @@ def run_mode(overlap, rank, world, pairs, steps, dev):
             local = tr.flat.g.clone()
             p_before, m_before, v_before = tr.flat.p.clone(), tr.flat.m.clone(), tr.flat.v.clone()
             step_no = float(tr.hyper[6])
+            scale = tr.loss_scale                                # the gradients carry GradScaler's loss scale; AdamW divides it out
             tr.exchange_and_step()
             torch.cuda.synchronize()
             both = [torch.empty_like(local) for _ in range(world)]
             dist.all_gather(both, local)
             err = float((tr.flat.g - (both[0] + both[1])).abs().max())
-            gm = (both[0] + both[1]) / world                     # single-process AdamW (torch formulas, fp32) on the MEAN gradient
+            gm = (both[0] + both[1]) / world / scale             # single-process AdamW (torch formulas, fp32) on the MEAN gradient
             b1, b2, lr, eps, wd = 0.9, 0.999, 1e-3, 1e-8, 0.01
             t = step_no + 1
             m = b1 * m_before + (1 - b1) * gm

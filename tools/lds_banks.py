@@ -28,11 +28,11 @@ if __name__ == "__main__":
     for it in range(4):
         f = lambda l: (8 * it + (l >> 3)) * 128 + ((l & 7) ^ swz(8 * it + (l >> 3))) * 16
         print("row-side write f32 it", it, cycles("write_b128", f), " read", cycles("read_b128", f))
-    # bf16 [64 tok][4 chunks x 16 B], 8 B per lane on the acc side
+    # h16 [64 tok][4 chunks x 16 B], 8 B per lane on the acc side
     for name, s2 in (("(t>>1)&3", lambda t: (t >> 1) & 3), ("t&3", lambda t: t & 3), ("(t>>1)&3 ^ (t&1)<<1", lambda t: ((t >> 1) & 3) ^ ((t & 1) << 1)), ("(t>>2)&3", lambda t: (t >> 2) & 3)):
         for i in range(1):
             for g in range(4):
-                print(name, "acc-side write bf16 g", g, cycles("write_b64", lambda l: (i * 32 + (l & 31)) * 64 + (g ^ s2(l & 31)) * 16 + 8 * (l >> 5)))
+                print(name, "acc-side write h16 g", g, cycles("write_b64", lambda l: (i * 32 + (l & 31)) * 64 + (g ^ s2(l & 31)) * 16 + 8 * (l >> 5)))
         for it in range(1):
             f = lambda l: (16 * it + (l >> 2)) * 64 + ((l & 3) ^ s2(16 * it + (l >> 2))) * 16
-            print(name, "row-side read bf16 it", it, cycles("read_b128", f))
+            print(name, "row-side read h16 it", it, cycles("read_b128", f))

@@ -3,6 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tests import helpers as Hh
+from tests.helpers import H16
 
 
 def timeit(fn, iters=50, warm=5):
@@ -36,8 +37,8 @@ def attn():
     st = ops.rng.state("cuda")
     for (B, H, Lq, Lkv, p, tag) in [(64, 4, 196, 196, 0.1, "img"), (128, 4, 96, 96, 0.1, "pc-SA"), (128, 4, 96, 1024, 0.1, "pc-CA")]:
         D = 64 * H
-        q = torch.randn(B * Lq, D, device="cuda").bfloat16(); k = torch.randn(B * Lkv, D, device="cuda").bfloat16()
-        v = torch.randn(B * Lkv, D, device="cuda").bfloat16(); do = torch.randn(B * Lq, D, device="cuda").bfloat16()
+        q = torch.randn(B * Lq, D, device="cuda").to(H16); k = torch.randn(B * Lkv, D, device="cuda").to(H16)
+        v = torch.randn(B * Lkv, D, device="cuda").to(H16); do = torch.randn(B * Lq, D, device="cuda").to(H16)
         o = torch.empty_like(q); lse = torch.empty(B * H * Lq, device="cuda")
         dq = torch.empty_like(q); dk = torch.empty_like(k); dv = torch.empty_like(v)
         f = lambda: L.call("vpf_attention_fwd", q, D, k, D, v, D, B, H, Lq, Lkv, 64, 0.125, p, st, 7, o, D, lse)
@@ -51,8 +52,8 @@ def gemm():
     from vipformer_amd import ops
     for (M, N, K, tag) in [(393216, 256, 256, "g2e conv3"), (393216, 128, 64, "g2e conv2"), (131072, 512, 256, "CA kv proj"),
                            (12288, 768, 256, "SA qkv"), (12288, 512, 256, "fc1"), (12288, 256, 512, "fc2"), (12544, 256, 768, "patch")]:
-        A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
-        dY = torch.randn(M, N, device="cuda").bfloat16(); dW = torch.zeros(N, K, device="cuda")
+        A = torch.randn(M, K, device="cuda").to(H16); W = (torch.randn(N, K, device="cuda") * 0.05).to(H16)
+        dY = torch.randn(M, N, device="cuda").to(H16); dW = torch.zeros(N, K, device="cuda")
         bias = torch.zeros(N, device="cuda")
         t1 = timeit(lambda: ops.linear_fwd(A, W, N, K, bias), 20, 3)
         t2 = timeit(lambda: ops.linear_dgrad(dY, W, N, K), 20, 3)
@@ -65,8 +66,8 @@ def wgrad():
     from vipformer_amd import ops
     for (M, N, K, tag) in [(12288, 256, 512, "fc2"), (12288, 512, 256, "fc1"), (12288, 256, 256, "proj"), (12288, 768, 256, "qkv"),
                            (131072, 512, 256, "CA kv")]:
-        A = torch.randn(M, K, device="cuda").bfloat16()
-        dY = torch.randn(M, N, device="cuda").bfloat16(); dW = torch.zeros(N, K, device="cuda")
+        A = torch.randn(M, K, device="cuda").to(H16)
+        dY = torch.randn(M, N, device="cuda").to(H16); dW = torch.zeros(N, K, device="cuda")
         t3 = timeit(lambda: ops.linear_wgrad(dY, A, N, K, dW), 300, 10)
         fl = 2.0 * M * N * K
         print(f"wgrad {tag} M={M} N={N} K={K}: {t3:.1f} us ({fl/t3/1e6:.0f} TF/s)")
@@ -117,7 +118,7 @@ def satail():
     packed = ops._pack_blocks(blocks, layers[0], "cuda")
     st = ops.rng.state("cuda")
     base = torch.randn(M, D, device="cuda"); pos = torch.randn(M, D, device="cuda")
-    o = torch.randn(M, D, device="cuda").to(torch.bfloat16)
+    o = torch.randn(M, D, device="cuda").to(H16)
     lse = torch.zeros(B * H * G, device="cuda")
     att, mlp = layers[0][0].module.attention, layers[0][1].module
     nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
@@ -172,7 +173,7 @@ def satail2():
         blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
         packed = ops._pack_blocks(blocks, layers[0], "cuda")
         base = torch.randn(M, D, device="cuda"); pos = torch.randn(G, D, device="cuda")
-        o = torch.randn(M, D, device="cuda").to(torch.bfloat16)
+        o = torch.randn(M, D, device="cuda").to(H16)
         lse = torch.zeros(B * H * G, device="cuda")
         sets.append((B, G, M, layers, packed, base, pos, o, lse))
     st = ops.rng.state("cuda")
@@ -238,7 +239,7 @@ def wgroup():
     shapes = [(256, 512), (512, 256), (256, 256), (768, 256)]
     ts = []
     for (N, K) in shapes:
-        ts.append((torch.randn(M, N, device="cuda").bfloat16(), torch.randn(M, K, device="cuda").bfloat16(), N, K,
+        ts.append((torch.randn(M, N, device="cuda").to(H16), torch.randn(M, K, device="cuda").to(H16), N, K,
                    torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")))
     def run():
         wg = ops.WgradBatch()
@@ -279,13 +280,13 @@ def gemmk():
     from vipformer_amd import ops
     M, N = 12288, 256
     for K in (32, 64, 128, 256, 512, 1024, 2048):
-        A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
-        y16 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda"); y32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        A = torch.randn(M, K, device="cuda").to(H16); W = (torch.randn(N, K, device="cuda") * 0.05).to(H16)
+        y16 = torch.empty(M, N, dtype=H16, device="cuda"); y32 = torch.empty(M, N, dtype=torch.float32, device="cuda")
         t1 = timeit(lambda: ops.gemm(A, 0, K, W, 0, K, M, N, K, y16, N, c_f32=False), 30, 5)
         t2 = timeit(lambda: ops.gemm(A, 0, K, W, 0, K, M, N, K, y32, N, c_f32=True), 30, 5)
-        print(f"gemmk K={K}: bf16-out {t1:.1f} us  f32-out {t2:.1f} us")
+        print(f"gemmk K={K}: h16-out {t1:.1f} us  f32-out {t2:.1f} us")
     e = torch.empty(8, device="cuda")
-    print("empty launch (cast of 8 elems): %.1f us" % timeit(lambda: ops.to_bf16(e), 50, 5))
+    print("empty launch (cast of 8 elems): %.1f us" % timeit(lambda: ops.to_h16(e), 50, 5))
 
 
 if __name__ == "__main__":
@@ -298,8 +299,8 @@ def _one_gemm(kind):
     """neighbour loads for tools/diag_fps_shared.py: one GEMM flavour in a loop"""
     from vipformer_amd import ops
     M, N, K = 12288, 512, 256
-    A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
-    dY = torch.randn(M, N, device="cuda").bfloat16(); dW = torch.zeros(N, K, device="cuda")
+    A = torch.randn(M, K, device="cuda").to(H16); W = (torch.randn(N, K, device="cuda") * 0.05).to(H16)
+    dY = torch.randn(M, N, device="cuda").to(H16); dW = torch.zeros(N, K, device="cuda")
     for _ in range(200):
         if kind == "fwd": ops.linear_fwd(A, W, N, K, None)
         elif kind == "dgrad": ops.linear_dgrad(dY, W, N, K)

@@ -7,7 +7,7 @@ profiles/<round>_pmc_summary.json, keyed by the kernel legs of bench.py.
 Per kernel (name prefix + launch grid) the MEDIAN of every counter over its dispatches; then
   hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE   (KiB -> bytes; gfx950 tallies a wide coalesced read at half its bytes)
   mfma_busy_frac       = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 256 CUs * 4 SIMDs)
-                         (SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_bf16 summed over every SIMD -- checked against
+                         (SQ_VALU_MFMA_BUSY_CYCLES = 32 cycles per v_mfma_f32_32x32x16_f16 summed over every SIMD -- checked against
                          the algorithmic MFMA count of the grouped weight gradient: 12 582 912 = 32 x 393 216; GRBM_GUI_ACTIVE is summed
                          over the 8 XCDs: 1.25 M for a 59 us kernel at 2.4 GHz)
   mfma_busy_over_cu_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES   (as recorded; units of the latter uncalibrated)

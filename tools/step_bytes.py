@@ -88,6 +88,14 @@ def main():
         res["ms_per_step_unprofiled"] = ms_step
         res["step_tb_per_s"] = round(tot_b / (ms_step * 1e-3) / 1e12, 3)
         res["step_hbm_frac_of_8tbs"] = round(tot_b / (ms_step * 1e-3) / 8e12, 4)
+    try:            # the library build the budget belongs to: bench.py drops a budget whose id is not the loaded library's
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from vipformer_amd import build as _b
+        res["build_id"] = _b.built_hash()
+    except Exception as e:                                  # noqa: BLE001
+        res["build_id"] = None
+        print("no build id:", e)
     json.dump(res, open(out, "w"), indent=1)
     print(f"steps f/w/t {steps_f}/{steps_w}/{steps_t}  kernels/step {res['kernels_per_step']}  kernel us/step {tot_us:.0f}  "
           f"HBM GB/step {tot_b / 1e9:.2f} (fetch {tot_f / 1e9:.2f} + write {tot_w / 1e9:.2f})"

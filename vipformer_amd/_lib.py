@@ -25,6 +25,12 @@ class VpfError(RuntimeError):
     pass
 
 
+# The storage dtype of every 16-bit tensor that crosses the C ABI (weights' shadow, activations, gradient operands): IEEE fp16 -- the
+# reference's autocast dtype (pretrain.py:154,176); csrc/vpf_common.h VPF_OPERAND_FP16.  VPF_OPERAND=bf16 + a library built with
+# `python -m vipformer_amd.build --bf16` is the A/B switch back to rounds 1-3's bf16 (lib() refuses a mismatch).
+H16 = torch.bfloat16 if os.environ.get("VPF_OPERAND", "f16") == "bf16" else torch.float16
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
@@ -35,6 +41,10 @@ def lib() -> ctypes.CDLL:
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.vpf_strerror.restype = ctypes.c_char_p
         _lib.vpf_strerror.argtypes = [I]
+        _lib.vpf_operand_dtype.restype = I
+        built = torch.float16 if _lib.vpf_operand_dtype() == 1 else torch.bfloat16
+        if built != H16:
+            raise VpfError(f"{LIB_PATH} computes with {built} operands but this process expects {H16} (VPF_OPERAND / build --bf16 mismatch)")
     return _lib
 
 
@@ -67,10 +77,10 @@ SIGS = {
     "vpf_index_points_f32": [VP, I, I, I, VP, I, VP, VP],
     "vpf_square_distance_f32": [VP, I, VP, I, I, I, I, VP, VP],
     "vpf_knn_group_f32": [VP, I, I, I, VP, I, I, I, I, VP, VP, VP, VP],
-    "vpf_gemm_bf16": [VP, I, L_, VP, I, L_, I, I, I, I, L_, L_, L_, VP, L_, I, I, VP, VP, L_, VP, L_, VP, L_, VP, I, VP, U32, F, I, VP, VP],
-    "vpf_gemm_bf16_fused": [VP, I, L_, I, VP, VP, VP, VP, I, L_, VP, I, L_, I, VP, VP, I, I, I, VP, L_, I, I, VP, VP, L_, I, I, VP, VP],
-    "vpf_cast_f32_bf16": [VP, VP, L_, VP],
-    "vpf_cast_bf16_f32": [VP, VP, L_, VP],
+    "vpf_gemm_h16": [VP, I, L_, VP, I, L_, I, I, I, I, L_, L_, L_, VP, L_, I, I, VP, VP, L_, VP, L_, VP, L_, VP, I, VP, U32, F, I, VP, VP],
+    "vpf_gemm_h16_fused": [VP, I, L_, I, VP, VP, VP, VP, I, L_, VP, I, L_, I, VP, VP, I, I, I, VP, L_, I, I, VP, VP, L_, I, I, VP, VP],
+    "vpf_cast_f32_h16": [VP, VP, L_, VP],
+    "vpf_cast_h16_f32": [VP, VP, L_, VP],
     "vpf_layernorm_fwd": [VP, I, VP, I, VP, VP, VP, VP, VP, VP, L_, I, F, VP],
     "vpf_layernorm_bwd": [VP, VP, I, VP, VP, VP, VP, VP, I, VP, VP, VP, L_, L_, I, VP],
     "vpf_dropout_add_fwd": [VP, VP, VP, L_, VP, U32, F, VP],
@@ -89,7 +99,8 @@ SIGS = {
     "vpf_g2e_fwd_b": [VP, L_, VP, VP, VP, I, VP, VP, VP],
     "vpf_g2e_wgrad4": [VP, L_, VP, VP, VP, I, VP, VP, VP],
     "vpf_g2e_bwd": [VP, VP, I, L_, VP, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, VP, VP],
-    "vpf_transpose_bf16": [VP, L_, I, I, VP, VP],
+    "vpf_grad_check": [VP, L_, VP, VP],
+    "vpf_transpose_h16": [VP, L_, I, I, VP, VP],
     "vpf_group_max_fwd": [VP, L_, I, I, VP, I, VP, VP],
     "vpf_group_max_bwd": [VP, I, VP, L_, I, I, VP, VP],
     "vpf_g2e_concat_fwd": [VP, VP, L_, I, I, VP, VP],
@@ -142,7 +153,7 @@ SIGS = {
     "vpf_ln_taps_bwd": [VP, VP, VP, VP, VP, I, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP],
     "vpf_interp_rows_fwd": [VP, VP, I, I, I, I, I, VP, VP, I, VP, VP],
     "vpf_interp_rows_bwd": [VP, I, I, I, I, I, VP, VP, I, VP, VP],
-    "vpf_pad_bf16": [VP, I, L_, I, L_, L_, I, VP, VP],
+    "vpf_pad_h16": [VP, I, L_, I, L_, L_, I, VP, VP],
     "vpf_ce_smooth": [VP, L_, VP, L_, I, F, VP, VP, VP, L_, VP],
     "vpf_augment_points": [VP, I, I, I, VP, U32, VP, VP, VP],
     "vpf_image_u8_normalize": [VP, I, I, I, VP, VP, VP, U32, F, VP, VP, VP],

@@ -28,6 +28,10 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
           "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # preproc.hip: bit-exact kernels -- no fused multiply-adds the source does not spell out
 PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
+# `python -m vipformer_amd.build --bf16` (or VPF_OPERAND=bf16 in the environment): the A/B build with bf16 MFMA operands (rounds 1-3)
+# instead of fp16 -- csrc/vpf_common.h VPF_OPERAND_FP16; vipformer_amd._lib refuses a library that does not match VPF_OPERAND.
+if os.environ.get("VPF_OPERAND", "f16") == "bf16" or "--bf16" in sys.argv:
+    COMMON = COMMON[:8] + ["-DVPF_OPERAND_FP16=0"] + COMMON[8:]
 
 
 def source_hash() -> str:
@@ -39,7 +43,7 @@ def source_hash() -> str:
     for f in files:
         h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
-    h.update(" ".join(COMMON[:8] + sorted(sum(PER_FILE.values(), []))).encode())
+    h.update(" ".join([c for c in COMMON if not c.startswith("-I")] + sorted(sum(PER_FILE.values(), []))).encode())
     return h.hexdigest()
 
 

@@ -85,6 +85,7 @@ VpfDebug& vpf_debug()
     }();
     return d;
 }
+extern "C" int vpf_operand_dtype(void) { return VPF_OPERAND_FP16 ? 1 : 0; }
 extern "C" int vpf_debug_set(const char* key, int value)
 {
     if (!key) return VPF_ERR_NULL;

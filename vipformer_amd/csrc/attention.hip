@@ -7,7 +7,7 @@
 // counter-based function of (rng state, site, (bh, q, kv)) so backward regenerates the mask.
 //
 // Layout ("swapped" products, key/value index in registers, query on the lane):
-//   S^T[kv,q] = K[kv,:] . Q[q,:]      v_mfma_f32_32x32x16_bf16, A = K tile rows (LDS, ds_read_b128),
+//   S^T[kv,q] = K[kv,:] . Q[q,:]      v_mfma_f32_32x32x16_f16, A = K tile rows (LDS, ds_read_b128),
 //                                     B = Q fragment (registers, loaded once)
 //   softmax statistics are per-lane scalars (query = lane & 31; partner lane ^ 32 holds the other
 //   16 keys of a 32-key sub-tile), P^T accumulators are re-used in place as the B operand of
@@ -19,28 +19,27 @@
 #include "vpf_common.h"
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 #define DH 64
-#define KLD 72          // LDS row stride (bf16) of the K / V / Q / dO tiles: 64 + 8 pad
-#define TLD 40          // LDS row stride (bf16) of the per-wave P / dS scratch: 32 + 8 pad
+#define KLD 72          // LDS row stride (h16) of the K / V / Q / dO tiles: 64 + 8 pad
+#define TLD 40          // LDS row stride (h16) of the per-wave P / dS scratch: 32 + 8 pad
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
 struct AttnArgs {
-    const bf16_t* Q; const bf16_t* K; const bf16_t* V;
+    const h16_t* Q; const h16_t* K; const h16_t* V;
     long ldq, ldk, ldv;           // row strides (elements); head h starts at column h*64
-    bf16_t* O; long ldo;
+    h16_t* O; long ldo;
     float* LSE;                   // [B,H,Lq]
     int B, H, Lq, Lkv;
     float scale;
     const uint32_t* rng; uint32_t site; float p;
     // backward
-    const bf16_t* dO; long lddo;
-    bf16_t* dQ; bf16_t* dK; bf16_t* dV; long lddq, lddk, lddv;
+    const h16_t* dO; long lddo;
+    h16_t* dQ; h16_t* dK; h16_t* dV; long lddq, lddk, lddv;
     // optional key padding mask [B, Lkv], non-zero = padding key (partseg.py:73-76).  Only the tiled kernels read it.
     const uint8_t* pad;
     // 1: the score tensor has fewer than 2^32 elements and Lkv % 4 == 0 -- dropout groups are indexed in 32 bits and always aligned
@@ -54,47 +53,47 @@ struct AttnArgs {
 #define PAD_SCORE (-3.402823466e+38f)
 #define PAD_ROW_LSE2 (-1.0e30f)
 
-__device__ __forceinline__ s16x4_t lds_tr16(const bf16_t* p)
+__device__ __forceinline__ s16x4_t lds_tr16(const h16_t* p)
 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
 }
 // A-operand fragment (rows = 32 consecutive columns c0.. of a natural [k][col] LDS tile, k-slots in the
 // PERMUTED order of an accumulator-as-operand chain): slot (h,j) <-> k = kbase + 8*(j>>2) + 4h + (j&3)
-__device__ __forceinline__ bf16x8_t frag_tr_perm(const bf16_t* S, int ld, int kbase, int c0)
+__device__ __forceinline__ h16x8_t frag_tr_perm(const h16_t* S, int ld, int kbase, int c0)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int h = g >> 1, coff = 16 * (g & 1);
-    const bf16_t* a = S + (kbase + 4 * h + q) * ld + c0 + coff + 4 * p;
+    const h16_t* a = S + (kbase + 4 * h + q) * ld + c0 + coff + 4 * p;
     const s16x4_t lo = lds_tr16(a), hi = lds_tr16(a + 8 * ld);
     s16x8_t v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(h16x8_t, v);
 }
 // natural k order: slot (h,j) <-> k = kbase + 8h + j   (operand element (k, c0 + (lane&31)))
-__device__ __forceinline__ bf16x8_t frag_tr_nat(const bf16_t* S, int ld, int kbase, int c0)
+__device__ __forceinline__ h16x8_t frag_tr_nat(const h16_t* S, int ld, int kbase, int c0)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int h = g >> 1, coff = 16 * (g & 1);
-    const bf16_t* a = S + (kbase + 8 * h + q) * ld + c0 + coff + 4 * p;
+    const h16_t* a = S + (kbase + 8 * h + q) * ld + c0 + coff + 4 * p;
     const s16x4_t lo = lds_tr16(a), hi = lds_tr16(a + 4 * ld);
     s16x8_t v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(h16x8_t, v);
 }
 // row fragment: element (row0 + (lane&31), kbase + 8h + j) of a [row][k] LDS tile
-__device__ __forceinline__ bf16x8_t frag_row(const bf16_t* S, int ld, int row0, int kbase)
+__device__ __forceinline__ h16x8_t frag_row(const h16_t* S, int ld, int row0, int kbase)
 {
     const int lane = threadIdx.x & 63;
     const uint4 v = *reinterpret_cast<const uint4*>(S + (row0 + (lane & 31)) * ld + kbase + 8 * (lane >> 5));
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(h16x8_t, v);
 }
-__device__ __forceinline__ bf16x8_t pack8(const float* f)
+__device__ __forceinline__ h16x8_t pack8(const float* f)
 {
     uint4 u;
-    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]); u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
-    return __builtin_bit_cast(bf16x8_t, u);
+    u.x = pack_h16x2(f[0], f[1]); u.y = pack_h16x2(f[2], f[3]); u.z = pack_h16x2(f[4], f[5]); u.w = pack_h16x2(f[6], f[7]);
+    return __builtin_bit_cast(h16x8_t, u);
 }
-__device__ __forceinline__ uint4 ld16_or_zero(const bf16_t* p, bool ok)
+__device__ __forceinline__ uint4 ld16_or_zero(const h16_t* p, bool ok)
 {
     return ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
 }
@@ -106,9 +105,9 @@ __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, E | (E << 2) | (E << 4) | (E << 6), 0xF, 0xF, true);
 }
 
-// cooperative stage of a [ROWS x 64] bf16 tile (rows r0.. of a [L, ld] matrix, head column offset applied by caller)
+// cooperative stage of a [ROWS x 64] h16 tile (rows r0.. of a [L, ld] matrix, head column offset applied by caller)
 template <int ROWS, int MAXC>
-__device__ __forceinline__ void kv_load(const bf16_t* __restrict__ G, long ld, int L, int r0, uint4 (&regs)[MAXC], int nthreads)
+__device__ __forceinline__ void kv_load(const h16_t* __restrict__ G, long ld, int L, int r0, uint4 (&regs)[MAXC], int nthreads)
 {
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
@@ -119,7 +118,7 @@ __device__ __forceinline__ void kv_load(const bf16_t* __restrict__ G, long ld, i
     }
 }
 template <int ROWS, int MAXC>
-__device__ __forceinline__ void kv_store(bf16_t* __restrict__ S, const uint4 (&regs)[MAXC], int nthreads)
+__device__ __forceinline__ void kv_store(h16_t* __restrict__ S, const uint4 (&regs)[MAXC], int nthreads)
 {
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
@@ -136,19 +135,19 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
 {
     constexpr int NT = NW * 64;
     constexpr int MAXC = (FWD_KT * 8 + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];               // [2 buf][K,V][FWD_KT][KLD]
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];               // [2 buf][K,V][FWD_KT][KLD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
     const int q = (blockIdx.y * NW + wave) * 32 + (lane & 31);
     const bool qok = q < a.Lq;
-    const bf16_t* Kg = a.K + (size_t)b * a.Lkv * a.ldk + hd * DH;
-    const bf16_t* Vg = a.V + (size_t)b * a.Lkv * a.ldv + hd * DH;
+    const h16_t* Kg = a.K + (size_t)b * a.Lkv * a.ldk + hd * DH;
+    const h16_t* Vg = a.V + (size_t)b * a.Lkv * a.ldv + hd * DH;
 
-    bf16x8_t qf[4];
+    h16x8_t qf[4];
     {
-        const bf16_t* qp = a.Q + ((size_t)b * a.Lq + (qok ? q : 0)) * a.ldq + hd * DH + 8 * hl;
+        const h16_t* qp = a.Q + ((size_t)b * a.Lq + (qok ? q : 0)) * a.ldq + hd * DH + 8 * hl;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(qp + ks * 16, qok));
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(qp + ks * 16, qok));
     }
     f32x16_t o[2];
 #pragma unroll
@@ -169,8 +168,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const bf16_t* sK = lds + (t & 1) * 2 * FWD_KT * KLD;
-        const bf16_t* sV = sK + FWD_KT * KLD;
+        const h16_t* sK = lds + (t & 1) * 2 * FWD_KT * KLD;
+        const h16_t* sV = sK + FWD_KT * KLD;
         if (t + 1 < nt) {
             kv_load<FWD_KT, MAXC>(Kg, a.ldk, a.Lkv, (t + 1) * FWD_KT, rk, NT);
             kv_load<FWD_KT, MAXC>(Vg, a.ldv, a.Lkv, (t + 1) * FWD_KT, rv, NT);
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, sub * 32, ks * 16), qf[ks], s, 0, 0, 0);
+                s = vpf_mfma32(frag_row(sK, KLD, sub * 32, ks * 16), qf[ks], s);
             float tmax = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -223,14 +222,14 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
             for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t pf = pack8(pv + 8 * s2);
+                const h16x8_t pf = pack8(pv + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sV, KLD, sub * 32 + 16 * s2, dt * 32), pf, o[dt], 0, 0, 0);
+                    o[dt] = vpf_mfma32(frag_tr_perm(sV, KLD, sub * 32 + 16 * s2, dt * 32), pf, o[dt]);
             }
         }
         if (t + 1 < nt) {
-            bf16_t* nK = lds + ((t + 1) & 1) * 2 * FWD_KT * KLD;
+            h16_t* nK = lds + ((t + 1) & 1) * 2 * FWD_KT * KLD;
             kv_store<FWD_KT, MAXC>(nK, rk, NT);
             kv_store<FWD_KT, MAXC>(nK + FWD_KT * KLD, rv, NT);
         }
@@ -239,14 +238,14 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = 1.f / lt;
     if (qok) {
-        bf16_t* op = a.O + ((size_t)b * a.Lq + q) * a.ldo + hd * DH;
+        h16_t* op = a.O + ((size_t)b * a.Lq + q) * a.ldo + hd * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 u;
-                u.x = pack_bf16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
-                u.y = pack_bf16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
+                u.x = pack_h16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
+                u.y = pack_h16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
                 *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
             }
         if (hl == 0 && a.LSE) a.LSE[(size_t)bh * a.Lq + q] = (m + log2f(lt)) * LN2;
@@ -259,7 +258,7 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st)
     dim3 grid(a.B * a.H, vpf_cdiv(a.Lq, 32 * NW));
     if (a.Lkv >= 256) {
         constexpr int KT = 128;
-        constexpr size_t lds = sizeof(bf16_t) * 2 * 2 * KT * KLD;
+        constexpr size_t lds = sizeof(h16_t) * 2 * 2 * KT * KLD;
         static VpfPerDevice attr_dev; bool& attr = attr_dev();
         if (!attr) {
             if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
@@ -267,7 +266,7 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st)
         }
         hipLaunchKernelGGL((attn_fwd_kernel<NW, KT>), grid, dim3(NW * 64), lds, st, a);
     } else {
-        hipLaunchKernelGGL((attn_fwd_kernel<NW, 64>), grid, dim3(NW * 64), sizeof(bf16_t) * 2 * 2 * 64 * KLD, st, a);
+        hipLaunchKernelGGL((attn_fwd_kernel<NW, 64>), grid, dim3(NW * 64), sizeof(h16_t) * 2 * 2 * 64 * KLD, st, a);
     }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
@@ -282,9 +281,9 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
 {
     constexpr int NT = NW * 64, LPT = NW * 32;
     constexpr int NCH = 2 * LPT * 8, CPT = (NCH + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) bf16_t rlds[];
-    bf16_t* sK = rlds;
-    bf16_t* sV = rlds + LPT * KLD;
+    extern __shared__ __attribute__((aligned(16))) h16_t rlds[];
+    h16_t* sK = rlds;
+    h16_t* sV = rlds + LPT * KLD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H, L = a.Lq;
     const int q = wave * 32 + (lane & 31);
@@ -295,15 +294,15 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
         const int e = threadIdx.x + it * NT, ch = e & 7, row = (e >> 3) % LPT, kv = (e >> 3) / LPT;
         kvr[it] = make_uint4(0, 0, 0, 0);
         if (e < NCH && row < L) {
-            const bf16_t* src = kv ? a.V + ((size_t)b * L + row) * a.ldv : a.K + ((size_t)b * L + row) * a.ldk;
+            const h16_t* src = kv ? a.V + ((size_t)b * L + row) * a.ldv : a.K + ((size_t)b * L + row) * a.ldk;
             kvr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
         }
     }
-    bf16x8_t qf[4];
+    h16x8_t qf[4];
     {
-        const bf16_t* qp = a.Q + ((size_t)b * L + (qok ? q : 0)) * a.ldq + hd * DH + 8 * hl;
+        const h16_t* qp = a.Q + ((size_t)b * L + (qok ? q : 0)) * a.ldq + hd * DH + 8 * hl;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(qp + ks * 16, qok));
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(qp + ks * 16, qok));
     }
 #pragma unroll
     for (int it = 0; it < CPT; ++it) {
@@ -328,7 +327,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, kv0, ks * 16), qf[ks], s, 0, 0, 0);
+            s = vpf_mfma32(frag_row(sK, KLD, kv0, ks * 16), qf[ks], s);
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -358,10 +357,10 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8_t pf = pack8(pv + 8 * s2);
+            const h16x8_t pf = pack8(pv + 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sV, KLD, kv0 + 16 * s2, dt * 32), pf, o[dt], 0, 0, 0);
+                o[dt] = vpf_mfma32(frag_tr_perm(sV, KLD, kv0 + 16 * s2, dt * 32), pf, o[dt]);
         }
     }
     const float lt = l + __shfl_xor(l, 32, 64);
@@ -372,14 +371,14 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
         // (the staging rows take over the K tile once every wave is past its last Q K^T: 2 instead of 3 tiles of LDS -- 64 KB at 196
         // patches, so two workgroups share a CU)
         __syncthreads();
-        bf16_t* sO = rlds + wave * 32 * KLD;
+        h16_t* sO = rlds + wave * 32 * KLD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 u;
-                u.x = pack_bf16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
-                u.y = pack_bf16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
+                u.x = pack_h16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
+                u.y = pack_h16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
                 *reinterpret_cast<uint2*>(sO + (lane & 31) * KLD + dt * 32 + 8 * gq + 4 * hl) = u;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave: LDS operations complete in order
@@ -397,7 +396,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
 template <int NW>
 static int launch_res_fwd(const AttnArgs& a, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)2 * NW * 32 * KLD * sizeof(bf16_t);      // K and V (the per-wave output staging rows reuse K)
+    constexpr size_t lds = (size_t)2 * NW * 32 * KLD * sizeof(h16_t);      // K and V (the per-wave output staging rows reuse K)
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
@@ -426,8 +425,8 @@ static int attention_fwd(const void* q, long ldq, const void* k, long ldk, const
     AttnArgs a = {};
     a.pad = pad;
     a.rng_fast = vpf_debug().attn_rng32 && ((unsigned long long)B * (unsigned long long)H * (unsigned long long)Lq * (unsigned long long)Lkv < (1ull << 32)) && (Lkv % 4 == 0);
-    a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-    a.O = (bf16_t*)out; a.ldo = ldo; a.LSE = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
+    a.Q = (const h16_t*)q; a.K = (const h16_t*)k; a.V = (const h16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+    a.O = (h16_t*)out; a.ldo = ldo; a.LSE = lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
     a.rng = rng_state; a.site = site; a.p = dropout_p;
     int rc = check_common(a);
     if (rc) return rc;
@@ -439,6 +438,7 @@ static int attention_fwd(const void* q, long ldq, const void* k, long ldk, const
     if (res && Lq == Lkv && k != q && !pad) {     // self-attention with the whole head resident in LDS
         if (nqb == 3) return launch_res_fwd<3>(a, st);
         if (nqb == 4) return launch_res_fwd<4>(a, st);       // 128 latents: BASELINE configs 3 and 4
+        if (nqb == 5) return launch_res_fwd<5>(a, st);       // 144 tokens: the reference's shipped 144 x 144 / patch 12 image geometry
         if (nqb == 7) return launch_res_fwd<7>(a, st);
     }
     if (nqb <= 1) return launch_fwd<1>(a, st);
@@ -481,30 +481,30 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
 {
     constexpr int NT = NW * 64;
     constexpr int MAXC = (KT * 8 + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) bf16_t sKV[];                  // [2 buf][K,V][KT][KLD]
+    extern __shared__ __attribute__((aligned(16))) h16_t sKV[];                  // [2 buf][K,V][KT][KLD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, ql = lane & 31;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
     const int q = (blockIdx.y * NW + wave) * 32 + ql;
     const bool qok = q < a.Lq;
-    const bf16_t* Kg = a.K + (size_t)b * a.Lkv * a.ldk + hd * DH;
-    const bf16_t* Vg = a.V + (size_t)b * a.Lkv * a.ldv + hd * DH;
+    const h16_t* Kg = a.K + (size_t)b * a.Lkv * a.ldk + hd * DH;
+    const h16_t* Vg = a.V + (size_t)b * a.Lkv * a.ldv + hd * DH;
 
-    bf16x8_t qf[4], dof[4];
+    h16x8_t qf[4], dof[4];
     float delta = 0.f;
     {
         const size_t row = (size_t)b * a.Lq + (qok ? q : 0);
-        const bf16_t* qp = a.Q + row * a.ldq + hd * DH + 8 * hl;
-        const bf16_t* dp = a.dO + row * a.lddo + hd * DH + 8 * hl;
-        const bf16_t* op = a.O + row * a.ldo + hd * DH + 8 * hl;
+        const h16_t* qp = a.Q + row * a.ldq + hd * DH + 8 * hl;
+        const h16_t* dp = a.dO + row * a.lddo + hd * DH + 8 * hl;
+        const h16_t* op = a.O + row * a.ldo + hd * DH + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const uint4 uq = ld16_or_zero(qp + ks * 16, qok), ud = ld16_or_zero(dp + ks * 16, qok), uo = ld16_or_zero(op + ks * 16, qok);
-            qf[ks] = __builtin_bit_cast(bf16x8_t, uq); dof[ks] = __builtin_bit_cast(bf16x8_t, ud);
+            qf[ks] = __builtin_bit_cast(h16x8_t, uq); dof[ks] = __builtin_bit_cast(h16x8_t, ud);
             const uint32_t dw[4] = {ud.x, ud.y, ud.z, ud.w}, ow[4] = {uo.x, uo.y, uo.z, uo.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                delta += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16);
-                delta += __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+                delta += h16_lo(dw[j]) * h16_lo(ow[j]);
+                delta += h16_hi(dw[j]) * h16_hi(ow[j]);
             }
         }
     }
@@ -531,8 +531,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const bf16_t* sK = sKV + (t & 1) * 2 * KT * KLD;
-        const bf16_t* sV = sK + KT * KLD;
+        const h16_t* sK = sKV + (t & 1) * 2 * KT * KLD;
+        const h16_t* sV = sK + KT * KLD;
         const int kv0 = t * KT;
         if (t + 1 < nt) {
             kv_load<KT, MAXC>(Kg, a.ldk, a.Lkv, (t + 1) * KT, rk, NT);
@@ -547,8 +547,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, sub * 32, ks * 16), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sV, KLD, sub * 32, ks * 16), dof[ks], dp, 0, 0, 0);
+                s = vpf_mfma32(frag_row(sK, KLD, sub * 32, ks * 16), qf[ks], s);
+                dp = vpf_mfma32(frag_row(sV, KLD, sub * 32, ks * 16), dof[ks], dp);
             }
             float ds[16];
 #pragma unroll
@@ -574,28 +574,28 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dq_kernel(AttnArgs a, float*
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t dsf = pack8(ds + 8 * s2);
+                const h16x8_t dsf = pack8(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, sub * 32 + 16 * s2, dt * 32), dsf, dq[dt], 0, 0, 0);
+                    dq[dt] = vpf_mfma32(frag_tr_perm(sK, KLD, sub * 32 + 16 * s2, dt * 32), dsf, dq[dt]);
             }
         }
         if (t + 1 < nt) {
-            bf16_t* nK = sKV + ((t + 1) & 1) * 2 * KT * KLD;
+            h16_t* nK = sKV + ((t + 1) & 1) * 2 * KT * KLD;
             kv_store<KT, MAXC>(nK, rk, NT);
             kv_store<KT, MAXC>(nK + KT * KLD, rv, NT);
         }
         __syncthreads();
     }
     if (qok) {
-        bf16_t* op = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + hd * DH;
+        h16_t* op = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + hd * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 u;
-                u.x = pack_bf16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
-                u.y = pack_bf16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+                u.x = pack_h16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
+                u.y = pack_h16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
                 *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
             }
     }
@@ -606,26 +606,26 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
 {
     constexpr int NT = NW * 64;
     constexpr int MAXC = (BWD_KT * 8 + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) bf16_t sQD[2 * 2 * BWD_KT * KLD];     // [2 buf][Q,dO][32][KLD]
+    __shared__ __attribute__((aligned(16))) h16_t sQD[2 * 2 * BWD_KT * KLD];     // [2 buf][Q,dO][32][KLD]
     __shared__ float sStat[2 * 2 * BWD_KT];                                        // [2 buf][lse*log2e, delta][32]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, kl = lane & 31;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
     const int kv = (blockIdx.y * NW + wave) * 32 + kl;
     const bool kvok = kv < a.Lkv;
-    const bf16_t* Qg = a.Q + (size_t)b * a.Lq * a.ldq + hd * DH;
-    const bf16_t* Dg = a.dO + (size_t)b * a.Lq * a.lddo + hd * DH;
+    const h16_t* Qg = a.Q + (size_t)b * a.Lq * a.ldq + hd * DH;
+    const h16_t* Dg = a.dO + (size_t)b * a.Lq * a.lddo + hd * DH;
     const float* lseg = a.LSE + (size_t)bh * a.Lq;
     const float* delg = delta_in + (size_t)bh * a.Lq;
 
-    bf16x8_t kf[4], vf[4];
+    h16x8_t kf[4], vf[4];
     {
         const size_t row = (size_t)b * a.Lkv + (kvok ? kv : 0);
-        const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
-        const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+        const h16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+        const h16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, kvok));
-            vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, kvok));
+            kf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(kp + ks * 16, kvok));
+            vf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(vp + ks * 16, kvok));
         }
     }
     const float c = a.scale * LOG2E;
@@ -658,8 +658,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const bf16_t* sQ = sQD + (t & 1) * 2 * BWD_KT * KLD;
-        const bf16_t* sD = sQ + BWD_KT * KLD;
+        const h16_t* sQ = sQD + (t & 1) * 2 * BWD_KT * KLD;
+        const h16_t* sD = sQ + BWD_KT * KLD;
         const float* sL = sStat + (t & 1) * 2 * BWD_KT;
         const int q0 = t * BWD_KT;
         if (t + 1 < nt) {
@@ -673,8 +673,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, 0, ks * 16), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, 0, ks * 16), vf[ks], dp, 0, 0, 0);
+            s = vpf_mfma32(frag_row(sQ, KLD, 0, ks * 16), kf[ks], s);
+            dp = vpf_mfma32(frag_row(sD, KLD, 0, ks * 16), vf[ks], dp);
         }
         float pd[16], ds[16];
 #pragma unroll
@@ -718,15 +718,15 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
         // dV^T[d,kv] += dO^T[d,q] . P[q,kv] ; dK^T[d,kv] += Q^T[d,q] . dS[q,kv]
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+            const h16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+                dv[dt] = vpf_mfma32(frag_tr_perm(sD, KLD, 16 * s2, dt * 32), pf, dv[dt]);
+                dk[dt] = vpf_mfma32(frag_tr_perm(sQ, KLD, 16 * s2, dt * 32), sf, dk[dt]);
             }
         }
         if (t + 1 < nt) {
-            bf16_t* nQ = sQD + ((t + 1) & 1) * 2 * BWD_KT * KLD;
+            h16_t* nQ = sQD + ((t + 1) & 1) * 2 * BWD_KT * KLD;
             kv_store<BWD_KT, MAXC>(nQ, rq, NT);
             kv_store<BWD_KT, MAXC>(nQ + BWD_KT * KLD, rd, NT);
             if (threadIdx.x < 64) sStat[((t + 1) & 1) * 2 * BWD_KT + threadIdx.x] = st0;
@@ -734,15 +734,15 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
         __syncthreads();
     }
     if (kvok) {
-        bf16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
-        bf16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
+        h16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
+        h16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 u, w;
-                u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
-                w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                u.x = pack_h16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_h16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                w.x = pack_h16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_h16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
                 *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
                 *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
             }
@@ -760,11 +760,11 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
 {
     constexpr int NT = NW * 64, LPT = NW * 32;
     constexpr int NCH = 4 * LPT * 8, CPT = (NCH + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) bf16_t rlds[];
-    bf16_t* sQ = rlds;
-    bf16_t* sK = sQ + LPT * KLD;
-    bf16_t* sV = sK + LPT * KLD;
-    bf16_t* sD = sV + LPT * KLD;
+    extern __shared__ __attribute__((aligned(16))) h16_t rlds[];
+    h16_t* sQ = rlds;
+    h16_t* sK = sQ + LPT * KLD;
+    h16_t* sV = sK + LPT * KLD;
+    h16_t* sD = sV + LPT * KLD;
     float* sL = reinterpret_cast<float*>(sD + LPT * KLD);        // [LPT] lse * log2e
     float* sDel = sL + LPT;                                      // [LPT] delta
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, ql = lane & 31;
@@ -779,14 +779,14 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             rr[it] = make_uint4(0, 0, 0, 0);
             if (e < NCH && row < L) {
                 const size_t gr = (size_t)b * L + row;
-                const bf16_t* src = which == 0 ? a.Q + gr * a.ldq : which == 1 ? a.K + gr * a.ldk : which == 2 ? a.V + gr * a.ldv : a.dO + gr * a.lddo;
+                const h16_t* src = which == 0 ? a.Q + gr * a.ldq : which == 1 ? a.K + gr * a.ldk : which == 2 ? a.V + gr * a.ldv : a.dO + gr * a.lddo;
                 rr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
             }
         }
         // O fragments of this lane's query (only needed for delta) and its log-sum-exp
         uint4 of[4];
         {
-            const bf16_t* op = a.O + ((size_t)b * L + (qok ? q : 0)) * a.ldo + hd * DH + 8 * hl;
+            const h16_t* op = a.O + ((size_t)b * L + (qok ? q : 0)) * a.ldo + hd * DH + 8 * hl;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) of[ks] = ld16_or_zero(op + ks * 16, qok);
         }
@@ -805,8 +805,8 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             const uint32_t dw[4] = {ud.x, ud.y, ud.z, ud.w}, ow[4] = {of[ks].x, of[ks].y, of[ks].z, of[ks].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                delta += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16);
-                delta += __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+                delta += h16_lo(dw[j]) * h16_lo(ow[j]);
+                delta += h16_hi(dw[j]) * h16_hi(ow[j]);
             }
         }
         delta += __shfl_xor(delta, 32, 64);
@@ -820,7 +820,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
     // phase B has its fragments in registers: the accumulator layout would store 8 bytes per lane into 32 different rows,
     // from LDS the same tile goes out as 128-byte rows (16 bytes per lane, 8 rows per wave-instruction).
     uint2 dqp[2][4];
-    auto tile_out = [&](bf16_t* S, const uint2 (&tp)[2][4], bf16_t* G, long ld) {
+    auto tile_out = [&](h16_t* S, const uint2 (&tp)[2][4], h16_t* G, long ld) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -836,7 +836,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
     };
     // ------------------------------------------------------------------ phase A: dQ (lane = query)
     {
-        bf16x8_t qf[4], dof[4];
+        h16x8_t qf[4], dof[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row(sQ, KLD, wave * 32, ks * 16); dof[ks] = frag_row(sD, KLD, wave * 32, ks * 16); }
         const float lse2 = sL[q], delta = sDel[q];       // written by this very lane (hl == 0) or its partner: same wave, in order
@@ -852,8 +852,8 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sK, KLD, kv0, ks * 16), qf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sV, KLD, kv0, ks * 16), dof[ks], dp, 0, 0, 0);
+                s = vpf_mfma32(frag_row(sK, KLD, kv0, ks * 16), qf[ks], s);
+                dp = vpf_mfma32(frag_row(sV, KLD, kv0, ks * 16), dof[ks], dp);
             }
             float ds[16];
 #pragma unroll
@@ -872,18 +872,18 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t dsf = pack8(ds + 8 * s2);
+                const h16x8_t dsf = pack8(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, kv0 + 16 * s2, dt * 32), dsf, dq[dt], 0, 0, 0);
+                    dq[dt] = vpf_mfma32(frag_tr_perm(sK, KLD, kv0 + 16 * s2, dt * 32), dsf, dq[dt]);
             }
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                dqp[dt][gq].x = pack_bf16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
-                dqp[dt][gq].y = pack_bf16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+                dqp[dt][gq].x = pack_h16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
+                dqp[dt][gq].y = pack_h16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
             }
     }
     __syncthreads();                      // sL / sDel of every query are in LDS; no wave reads K / V rows of another wave any more
@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
     {
         const int kv = q;
         const bool kvok = qok;
-        bf16x8_t kf[4], vf[4];
+        h16x8_t kf[4], vf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(sK, KLD, wave * 32, ks * 16); vf[ks] = frag_row(sV, KLD, wave * 32, ks * 16); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers before the rows are reused
@@ -909,8 +909,8 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp, 0, 0, 0);
+                s = vpf_mfma32(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s);
+                dp = vpf_mfma32(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp);
             }
             float pd[16], ds[16];
 #pragma unroll
@@ -944,11 +944,11 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+                const h16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+                    dv[dt] = vpf_mfma32(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt]);
+                    dk[dt] = vpf_mfma32(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt]);
                 }
             }
         }
@@ -959,8 +959,8 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    tk[dt][gq].x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); tk[dt][gq].y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
-                    tv[dt][gq].x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); tv[dt][gq].y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                    tk[dt][gq].x = pack_h16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); tk[dt][gq].y = pack_h16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                    tv[dt][gq].x = pack_h16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); tv[dt][gq].y = pack_h16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
                 }
             tile_out(sK, tk, a.dK, a.lddk);
             tile_out(sV, tv, a.dV, a.lddv);
@@ -970,7 +970,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
 template <int NW>
 static int launch_res_bwd(const AttnArgs& a, float* delta, hipStream_t st)
 {
-    constexpr size_t lds = (size_t)4 * NW * 32 * KLD * sizeof(bf16_t) + (size_t)2 * NW * 32 * sizeof(float);
+    constexpr size_t lds = (size_t)4 * NW * 32 * KLD * sizeof(h16_t) + (size_t)2 * NW * 32 * sizeof(float);
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_bwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
@@ -989,10 +989,10 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
 {
     constexpr int NT = NW * 64, QPT = QB * 32;
     constexpr int NCH = 2 * QPT * 8, CPT = (NCH + NT - 1) / NT;
-    __shared__ __attribute__((aligned(16))) bf16_t sQD[2 * QPT * KLD];
+    __shared__ __attribute__((aligned(16))) h16_t sQD[2 * QPT * KLD];
     __shared__ float sL[QPT], sDel[QPT];
-    bf16_t* sQ = sQD;
-    bf16_t* sD = sQD + QPT * KLD;
+    h16_t* sQ = sQD;
+    h16_t* sD = sQD + QPT * KLD;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, kl = lane & 31;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
     const int kv = (blockIdx.y * NW + wave) * 32 + kl;
@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
             rr[it] = make_uint4(0, 0, 0, 0);
             if (e < NCH && row < a.Lq) {
                 const size_t gr = (size_t)b * a.Lq + row;
-                const bf16_t* src = which == 0 ? a.Q + gr * a.ldq : a.dO + gr * a.lddo;
+                const h16_t* src = which == 0 ? a.Q + gr * a.ldq : a.dO + gr * a.lddo;
                 rr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
             }
         }
@@ -1019,15 +1019,15 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
             if (e < NCH) *reinterpret_cast<uint4*>(sQD + (which * QPT + row) * KLD + ch * 8) = rr[it];
         }
     }
-    bf16x8_t kf[4], vf[4];
+    h16x8_t kf[4], vf[4];
     {
         const size_t row = (size_t)b * a.Lkv + (kvok ? kv : 0);
-        const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
-        const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+        const h16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+        const h16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, kvok));
-            vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, kvok));
+            kf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(kp + ks * 16, kvok));
+            vf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(vp + ks * 16, kvok));
         }
     }
     __syncthreads();
@@ -1047,8 +1047,8 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp, 0, 0, 0);
+            s = vpf_mfma32(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s);
+            dp = vpf_mfma32(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp);
         }
         float pd[16], ds[16];
 #pragma unroll
@@ -1081,24 +1081,24 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
         }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+            const h16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+                dv[dt] = vpf_mfma32(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt]);
+                dk[dt] = vpf_mfma32(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt]);
             }
         }
     }
     if (kvok) {
-        bf16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
-        bf16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
+        h16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
+        h16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 uint2 u, w;
-                u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
-                w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                u.x = pack_h16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_h16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                w.x = pack_h16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_h16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
                 *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
                 *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
             }
@@ -1108,7 +1108,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
 // dQ, dK and dV of a cross-attention with FEW queries and MANY keys in ONE kernel (96 / 128 latents against 1024 points): a
 // workgroup owns one (cloud, head), keeps its Q and dO tiles, lse and delta (computed here from dO and O) resident and walks the
 // keys in tiles of 128.  Phase A of a tile is attn_bwd_dkv_resq_kernel's body (a wave owns 32 keys; S and dP with the key on the
-// lane; dV^T += dO^T . P, dK^T += Q^T . dS), and leaves the tile's bf16 dS in LDS as [key][query] beside the K tile.  Phase B: wave w
+// lane; dV^T += dO^T . P, dK^T += Q^T . dS), and leaves the tile's h16 dS in LDS as [key][query] beside the K tile.  Phase B: wave w
 // owns query block w and adds K^T . dS^T over the tile's 128 keys into its dQ^T accumulators (both operands by transposing LDS reads,
 // in the k order attn_bwd_dq_kernel uses) -- no cross-wave reduction, no atomics; S, dP, the exponentials and the dropout hash are
 // computed once instead of twice and K / V cross HBM once.  Same arithmetic and rounding points as the two kernels it replaces.
@@ -1117,11 +1117,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
 {
     constexpr int NW = 4, NT = NW * 64, QPT = QB * 32, KT = NW * 32, DLD = QPT + 8;
     constexpr int NCH = 2 * QPT * 8, CPT = (NCH + NT - 1) / NT;
-    extern __shared__ __attribute__((aligned(16))) bf16_t sm[];
-    bf16_t* sQ = sm;                                  // [QPT][KLD]
-    bf16_t* sD = sQ + QPT * KLD;                      // [QPT][KLD]  dO
-    bf16_t* sK = sD + QPT * KLD;                      // [KT][KLD]   this tile's keys
-    bf16_t* sT = sK + KT * KLD;                       // [KT][DLD]   this tile's dS, [key][query]
+    extern __shared__ __attribute__((aligned(16))) h16_t sm[];
+    h16_t* sQ = sm;                                  // [QPT][KLD]
+    h16_t* sD = sQ + QPT * KLD;                      // [QPT][KLD]  dO
+    h16_t* sK = sD + QPT * KLD;                      // [KT][KLD]   this tile's keys
+    h16_t* sT = sK + KT * KLD;                       // [KT][DLD]   this tile's dS, [key][query]
     float* sL = reinterpret_cast<float*>(sT + KT * DLD);
     float* sDel = sL + QPT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, kl = lane & 31;
@@ -1134,7 +1134,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
             rr[it] = make_uint4(0, 0, 0, 0);
             if (e < NCH && row < a.Lq) {
                 const size_t gr = (size_t)b * a.Lq + row;
-                const bf16_t* src = which == 0 ? a.Q + gr * a.ldq : a.dO + gr * a.lddo;
+                const h16_t* src = which == 0 ? a.Q + gr * a.ldq : a.dO + gr * a.lddo;
                 rr[it] = *reinterpret_cast<const uint4*>(src + hd * DH + ch * 8);
             }
         }
@@ -1142,8 +1142,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
             const int q = wave * 32 + kl;
             const bool qok = q < a.Lq;
             const size_t row = (size_t)b * a.Lq + (qok ? q : 0);
-            const bf16_t* dp = a.dO + row * a.lddo + hd * DH + 8 * hl;
-            const bf16_t* op = a.O + row * a.ldo + hd * DH + 8 * hl;
+            const h16_t* dp = a.dO + row * a.lddo + hd * DH + 8 * hl;
+            const h16_t* op = a.O + row * a.ldo + hd * DH + 8 * hl;
             float delta = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -1151,8 +1151,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
                 const uint32_t dw[4] = {ud.x, ud.y, ud.z, ud.w}, ow[4] = {uo.x, uo.y, uo.z, uo.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    delta += __uint_as_float(dw[j] << 16) * __uint_as_float(ow[j] << 16);
-                    delta += __uint_as_float(dw[j] & 0xffff0000u) * __uint_as_float(ow[j] & 0xffff0000u);
+                    delta += h16_lo(dw[j]) * h16_lo(ow[j]);
+                    delta += h16_hi(dw[j]) * h16_hi(ow[j]);
                 }
             }
             delta += __shfl_xor(delta, 32, 64);
@@ -1177,25 +1177,25 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
     f32x16_t dq[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
-    bf16x8_t kf[4], vf[4];
+    h16x8_t kf[4], vf[4];
     {
         const int kv = wave * 32 + kl;
         const bool kvok = kv < a.Lkv;
         const size_t row = (size_t)b * a.Lkv + (kvok ? kv : 0);
-        const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
-        const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+        const h16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+        const h16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, kvok));
-            vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, kvok));
+            kf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(kp + ks * 16, kvok));
+            vf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(vp + ks * 16, kvok));
         }
     }
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int kv = t * KT + wave * 32 + kl;
         const bool kvok = kv < a.Lkv;
-        bf16_t* myK = sK + (wave * 32 + kl) * KLD + 8 * hl;
-        bf16_t* myT = sT + (wave * 32 + kl) * DLD + 4 * hl;
+        h16_t* myK = sK + (wave * 32 + kl) * KLD + 8 * hl;
+        h16_t* myT = sT + (wave * 32 + kl) * DLD + 4 * hl;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) *reinterpret_cast<uint4*>(myK + ks * 16) = __builtin_bit_cast(uint4, kf[ks]);
         f32x16_t dk[2], dv[2];
@@ -1210,8 +1210,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp, 0, 0, 0);
+                s = vpf_mfma32(frag_row(sQ, KLD, q0, ks * 16), kf[ks], s);
+                dp = vpf_mfma32(frag_row(sD, KLD, q0, ks * 16), vf[ks], dp);
             }
             float pd[16], ds[16];
 #pragma unroll
@@ -1242,16 +1242,16 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
                     ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
                 }
                 uint2 w;
-                w.x = pack_bf16x2(ds[4 * g4 + 0], ds[4 * g4 + 1]); w.y = pack_bf16x2(ds[4 * g4 + 2], ds[4 * g4 + 3]);
+                w.x = pack_h16x2(ds[4 * g4 + 0], ds[4 * g4 + 1]); w.y = pack_h16x2(ds[4 * g4 + 2], ds[4 * g4 + 3]);
                 *reinterpret_cast<uint2*>(myT + q0 + 8 * g4) = w;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
+                const h16x8_t pf = pack8(pd + 8 * s2), sf = pack8(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt], 0, 0, 0);
-                    dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt], 0, 0, 0);
+                    dv[dt] = vpf_mfma32(frag_tr_perm(sD, KLD, q0 + 16 * s2, dt * 32), pf, dv[dt]);
+                    dk[dt] = vpf_mfma32(frag_tr_perm(sQ, KLD, q0 + 16 * s2, dt * 32), sf, dk[dt]);
                 }
             }
         }
@@ -1259,24 +1259,24 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
             const int kv2 = kv + KT;
             const bool ok2 = kv2 < a.Lkv;
             const size_t row = (size_t)b * a.Lkv + (ok2 ? kv2 : 0);
-            const bf16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
-            const bf16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
+            const h16_t* kp = a.K + row * a.ldk + hd * DH + 8 * hl;
+            const h16_t* vp = a.V + row * a.ldv + hd * DH + 8 * hl;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                kf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(kp + ks * 16, ok2));
-                vf[ks] = __builtin_bit_cast(bf16x8_t, ld16_or_zero(vp + ks * 16, ok2));
+                kf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(kp + ks * 16, ok2));
+                vf[ks] = __builtin_bit_cast(h16x8_t, ld16_or_zero(vp + ks * 16, ok2));
             }
         }
         if (kvok) {
-            bf16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
-            bf16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
+            h16_t* kp = a.dK + ((size_t)b * a.Lkv + kv) * a.lddk + hd * DH;
+            h16_t* vp = a.dV + ((size_t)b * a.Lkv + kv) * a.lddv + hd * DH;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     uint2 u, w;
-                    u.x = pack_bf16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_bf16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
-                    w.x = pack_bf16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_bf16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
+                    u.x = pack_h16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); u.y = pack_h16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
+                    w.x = pack_h16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); w.y = pack_h16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
                     *reinterpret_cast<uint2*>(kp + dt * 32 + 8 * gq + 4 * hl) = u;
                     *reinterpret_cast<uint2*>(vp + dt * 32 + 8 * gq + 4 * hl) = w;
                 }
@@ -1287,10 +1287,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
 #pragma unroll
             for (int k16 = 0; k16 < KT / 16; ++k16) {
                 if (t * KT + k16 * 16 >= a.Lkv) break;
-                const bf16x8_t dsf = frag_tr_perm(sT, DLD, k16 * 16, wave * 32);
+                const h16x8_t dsf = frag_tr_perm(sT, DLD, k16 * 16, wave * 32);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr_perm(sK, KLD, k16 * 16, dt * 32), dsf, dq[dt], 0, 0, 0);
+                    dq[dt] = vpf_mfma32(frag_tr_perm(sK, KLD, k16 * 16, dt * 32), dsf, dq[dt]);
             }
         }
         __syncthreads();
@@ -1298,14 +1298,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
     if (bwave) {
         const int q = wave * 32 + kl;
         if (q < a.Lq) {
-            bf16_t* op = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + hd * DH;
+            h16_t* op = a.dQ + ((size_t)b * a.Lq + q) * a.lddq + hd * DH;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     uint2 u;
-                    u.x = pack_bf16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
-                    u.y = pack_bf16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
+                    u.x = pack_h16x2(dq[dt][4 * gq + 0], dq[dt][4 * gq + 1]);
+                    u.y = pack_h16x2(dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]);
                     *reinterpret_cast<uint2*>(op + dt * 32 + 8 * gq + 4 * hl) = u;
                 }
         }
@@ -1315,7 +1315,7 @@ template <int QB>
 static int launch_bwd_ca(const AttnArgs& a, hipStream_t st)
 {
     constexpr int QPT = QB * 32, KT = 128;
-    constexpr size_t lds = sizeof(bf16_t) * (2 * QPT * KLD + KT * KLD + KT * (QPT + 8)) + sizeof(float) * 2 * QPT;
+    constexpr size_t lds = sizeof(h16_t) * (2 * QPT * KLD + KT * KLD + KT * (QPT + 8)) + sizeof(float) * 2 * QPT;
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)attn_bwd_ca_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
@@ -1335,7 +1335,7 @@ static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
         return a.Lq <= 96 ? launch_bwd_ca<3>(a, st) : launch_bwd_ca<4>(a, st);
     if (a.Lkv >= 256) {
         constexpr int KT = 128;
-        constexpr size_t lds = sizeof(bf16_t) * 2 * 2 * KT * KLD;
+        constexpr size_t lds = sizeof(h16_t) * 2 * 2 * KT * KLD;
         static VpfPerDevice attr_dev; bool& attr = attr_dev();
         if (!attr) {
             if (hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<NWQ, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
@@ -1343,7 +1343,7 @@ static int launch_bwd(const AttnArgs& a, float* delta, hipStream_t st)
         }
         hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ, KT>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), lds, st, a, delta);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ, 32>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), sizeof(bf16_t) * 2 * 2 * 32 * KLD, st, a, delta);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NWQ, 32>), dim3(a.B * a.H, vpf_cdiv(a.Lq, 32 * NWQ)), dim3(NWQ * 64), sizeof(h16_t) * 2 * 2 * 32 * KLD, st, a, delta);
     }
     const int res = vpf_debug().attn_resident;
     if (res && !a.pad && a.Lq <= 96 && NWK == 4)
@@ -1376,10 +1376,10 @@ static int attention_bwd(const void* q, long ldq, const void* k, long ldk, const
     AttnArgs a = {};
     a.pad = pad;
     a.rng_fast = vpf_debug().attn_rng32 && ((unsigned long long)B * (unsigned long long)H * (unsigned long long)Lq * (unsigned long long)Lkv < (1ull << 32)) && (Lkv % 4 == 0);
-    a.Q = (const bf16_t*)q; a.K = (const bf16_t*)k; a.V = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
-    a.O = (bf16_t*)out; a.ldo = ldo; a.LSE = (float*)lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
+    a.Q = (const h16_t*)q; a.K = (const h16_t*)k; a.V = (const h16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
+    a.O = (h16_t*)out; a.ldo = ldo; a.LSE = (float*)lse; a.B = B; a.H = H; a.Lq = Lq; a.Lkv = Lkv; a.scale = scale;
     a.rng = rng_state; a.site = site; a.p = dropout_p;
-    a.dO = (const bf16_t*)dout; a.lddo = lddo; a.dQ = (bf16_t*)dq; a.dK = (bf16_t*)dk; a.dV = (bf16_t*)dv;
+    a.dO = (const h16_t*)dout; a.lddo = lddo; a.dQ = (h16_t*)dq; a.dK = (h16_t*)dk; a.dV = (h16_t*)dv;
     a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
     int rc = check_common(a);
     if (rc) return rc;
@@ -1392,6 +1392,7 @@ static int attention_bwd(const void* q, long ldq, const void* k, long ldk, const
     if (res && Lq == Lkv && k != q && !pad) {
         if (nqb == 3) return launch_res_bwd<3>(a, delta_ws, st);
         if (nqb == 4) return launch_res_bwd<4>(a, delta_ws, st);
+        if (nqb == 5) return launch_res_bwd<5>(a, delta_ws, st);
         if (nqb == 7) return launch_res_bwd<7>(a, delta_ws, st);
     }
     if (nqb <= 1) return launch_bwd_k<1>(a, delta_ws, st);

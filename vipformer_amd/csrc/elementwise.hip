@@ -7,10 +7,10 @@
 
 template <typename T> __device__ __forceinline__ float ld_f(const T* p, size_t i);
 template <> __device__ __forceinline__ float ld_f<float>(const float* p, size_t i) { return p[i]; }
-template <> __device__ __forceinline__ float ld_f<bf16_t>(const bf16_t* p, size_t i) { return bf16_to_f32(p[i]); }
+template <> __device__ __forceinline__ float ld_f<h16_t>(const h16_t* p, size_t i) { return h16_to_f32(p[i]); }
 template <typename T> __device__ __forceinline__ void st_f(T* p, size_t i, float v);
 template <> __device__ __forceinline__ void st_f<float>(float* p, size_t i, float v) { p[i] = v; }
-template <> __device__ __forceinline__ void st_f<bf16_t>(bf16_t* p, size_t i, float v) { p[i] = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void st_f<h16_t>(h16_t* p, size_t i, float v) { p[i] = f32_to_h16(v); }
 
 static inline int grid_for(long n, int per_block, int cap = 4096)
 {
@@ -21,38 +21,38 @@ static inline int grid_for(long n, int per_block, int cap = 4096)
 }
 
 // =============================================================================== cast
-__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n)
+__global__ void cast_f32_h16_kernel(const float* __restrict__ x, h16_t* __restrict__ y, long n)
 {
     const long n4 = n / 4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
-        uint2 o; o.x = pack_bf16x2(v.x, v.y); o.y = pack_bf16x2(v.z, v.w);
+        uint2 o; o.x = pack_h16x2(v.x, v.y); o.y = pack_h16x2(v.z, v.w);
         reinterpret_cast<uint2*>(y)[i] = o;
     }
     for (long i = n4 * 4 + blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        y[i] = f32_to_bf16(x[i]);
+        y[i] = f32_to_h16(x[i]);
 }
-extern "C" int vpf_cast_f32_bf16(const float* x, void* y, long n, void* stream)
+extern "C" int vpf_cast_f32_h16(const float* x, void* y, long n, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !y) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 7)) return VPF_ERR_BADALIGN;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+    hipLaunchKernelGGL(cast_f32_h16_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, x, (h16_t*)y, n);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 
-__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n)
+__global__ void cast_h16_f32_kernel(const h16_t* __restrict__ x, float* __restrict__ y, long n)
 {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = bf16_to_f32(x[i]);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = h16_to_f32(x[i]);
 }
-extern "C" int vpf_cast_bf16_f32(const void* x, float* y, long n, void* stream)
+extern "C" int vpf_cast_h16_f32(const void* x, float* y, long n, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !y) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, y, n);
+    hipLaunchKernelGGL(cast_h16_f32_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, y, n);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -63,7 +63,7 @@ extern "C" int vpf_cast_bf16_f32(const void* x, float* y, long n, void* stream)
 template <typename TIN>
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const TIN* __restrict__ x, const float* __restrict__ pos, int pos_rows,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          bf16_t* __restrict__ y, float* __restrict__ xsum,
+                                                          h16_t* __restrict__ y, float* __restrict__ xsum,
                                                           float* __restrict__ mean, float* __restrict__ rstd, long rows, int D, float eps)
 {
     const int lane = threadIdx.x & 63;
@@ -90,33 +90,33 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const TIN* __restric
 #pragma unroll
         for (int i = 0; i < LN_MAXI; ++i) {
             const int c = lane + 64 * i;
-            if (c < D) y[(size_t)r * D + c] = f32_to_bf16((v[i] - mu) * rs * gamma[c] + beta[c]);
+            if (c < D) y[(size_t)r * D + c] = f32_to_h16((v[i] - mu) * rs * gamma[c] + beta[c]);
         }
         if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
     }
 }
-extern "C" int vpf_layernorm_fwd(const void* x, int x_is_bf16, const float* pos, int pos_rows, const float* gamma,
-                                 const float* beta, void* y_bf16, float* xsum, float* mean, float* rstd, long rows, int D,
+extern "C" int vpf_layernorm_fwd(const void* x, int x_is_h16, const float* pos, int pos_rows, const float* gamma,
+                                 const float* beta, void* y_h16, float* xsum, float* mean, float* rstd, long rows, int D,
                                  float eps, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !gamma || !beta || !y_bf16 || !mean || !rstd) return VPF_ERR_NULL;
+    if (!x || !gamma || !beta || !y_h16 || !mean || !rstd) return VPF_ERR_NULL;
     if (rows < 0 || D <= 0 || D > 64 * LN_MAXI || (pos && pos_rows <= 0)) return VPF_ERR_BADSHAPE;
     if (rows == 0) return VPF_OK;
     const int grid = grid_for(rows, 4);
-    if (x_is_bf16)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, pos, pos_rows,
-                           gamma, beta, (bf16_t*)y_bf16, xsum, mean, rstd, rows, D, eps);
+    if (x_is_h16)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x, pos, pos_rows,
+                           gamma, beta, (h16_t*)y_h16, xsum, mean, rstd, rows, D, eps);
     else
         hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, pos, pos_rows,
-                           gamma, beta, (bf16_t*)y_bf16, xsum, mean, rstd, rows, D, eps);
+                           gamma, beta, (h16_t*)y_h16, xsum, mean, rstd, rows, D, eps);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 
 // dx = (dres ? dres : 0) + rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)); dgamma += dy*xhat; dbeta += dy
 template <typename TX, typename TDX>
-__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const TX* __restrict__ x,
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const h16_t* __restrict__ dy, const TX* __restrict__ x,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ gamma, const float* __restrict__ dres,
                                                           TDX* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const bf16_t* __rest
             const int c = lane + 64 * i;
             xh[i] = g[i] = 0.f;
             if (c < D) {
-                const float d = bf16_to_f32(dy[(size_t)r * D + c]);
+                const float d = h16_to_f32(dy[(size_t)r * D + c]);
                 xh[i] = (ld_f<TX>(x, (size_t)r * D + c) - mu) * rs;
                 ag[i] += d * xh[i]; ab[i] += d;
                 g[i] = d * gm[i];
@@ -184,12 +184,12 @@ __global__ void layernorm_bwd_finish_kernel(const float* __restrict__ ws, int nb
     for (; r < r1; ++r) s0 += ws[((size_t)which * nblk + r) * D + cc];
     atomicAdd((which ? dbeta : dgamma) + cc, (s0 + s1) + (s2 + s3));
 }
-extern "C" int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf16, const float* mean, const float* rstd,
-                                 const float* gamma, const float* dres, void* dx, int dx_is_bf16, float* dgamma, float* dbeta,
+extern "C" int vpf_layernorm_bwd(const void* dy_h16, const void* x, int x_is_h16, const float* mean, const float* rstd,
+                                 const float* gamma, const float* dres, void* dx, int dx_is_h16, float* dgamma, float* dbeta,
                                  float* ws, long ws_floats, long rows, int D, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!dy_bf16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return VPF_ERR_NULL;
+    if (!dy_h16 || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta) return VPF_ERR_NULL;
     if (rows < 0 || D <= 0 || D > 64 * LN_MAXI) return VPF_ERR_BADSHAPE;
     if (rows == 0) return VPF_OK;
     int grid = grid_for(rows, rows >= 65536 ? 16 : 4, 1024);      // a wave per row for the encoder-sized inputs (4 k .. 12 k rows): the row loop is a latency chain
@@ -197,11 +197,11 @@ extern "C" int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf
     // workspace of 2 * grid * D floats -> per-block partial sums + a finishing pass; without it: fp32 atomics
     float* wsp = (ws && ws_floats >= 2L * grid * D && grid > 8) ? ws : nullptr;
     if (!wsp && grid > 64) grid = 64;            // atomic fallback: keep the contention on the 2D addresses low
-#define LNB(TX, TDX) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDX>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dy_bf16, (const TX*)x, \
+#define LNB(TX, TDX) hipLaunchKernelGGL((layernorm_bwd_kernel<TX, TDX>), dim3(grid), dim3(256), 0, st, (const h16_t*)dy_h16, (const TX*)x, \
                                         mean, rstd, gamma, dres, (TDX*)dx, dgamma, dbeta, wsp, rows, D)
-    if (x_is_bf16 && dx_is_bf16) LNB(bf16_t, bf16_t);
-    else if (x_is_bf16) LNB(bf16_t, float);
-    else if (dx_is_bf16) LNB(float, bf16_t);
+    if (x_is_h16 && dx_is_h16) LNB(h16_t, h16_t);
+    else if (x_is_h16) LNB(h16_t, float);
+    else if (dx_is_h16) LNB(float, h16_t);
     else LNB(float, float);
 #undef LNB
     if (wsp) hipLaunchKernelGGL(layernorm_bwd_finish_kernel, dim3(vpf_cdiv(2 * D, 256), 32), dim3(256), 0, st, wsp, grid, D, dgamma, dbeta);
@@ -210,7 +210,7 @@ extern "C" int vpf_layernorm_bwd(const void* dy_bf16, const void* x, int x_is_bf
 }
 
 // =============================================================================== dropout (+ residual)
-__global__ void dropout_add_fwd_kernel(const bf16_t* __restrict__ y, const float* __restrict__ res, float* __restrict__ out,
+__global__ void dropout_add_fwd_kernel(const h16_t* __restrict__ y, const float* __restrict__ res, float* __restrict__ out,
                                        long n, const uint32_t* __restrict__ rng_state, uint32_t site, float p)
 {
     const VpfRng rng = vpf_rng_init(rng_state, site, p);
@@ -218,24 +218,24 @@ __global__ void dropout_add_fwd_kernel(const bf16_t* __restrict__ y, const float
         const uint32_t keep = vpf_keep4(rng, (uint64_t)g);
         for (int e = 0; e < 4 && g * 4 + e < n; ++e) {
             const long i = g * 4 + e;
-            const float v = bf16_to_f32(y[i]);
+            const float v = h16_to_f32(y[i]);
             out[i] = (res ? res[i] : 0.f) + (((keep >> e) & 1u) ? v * rng.scale : 0.f);
         }
     }
 }
-extern "C" int vpf_dropout_add_fwd(const void* y_bf16, const float* res, float* out, long n, const uint32_t* rng_state,
+extern "C" int vpf_dropout_add_fwd(const void* y_h16, const float* res, float* out, long n, const uint32_t* rng_state,
                                    uint32_t site, float p, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!y_bf16 || !out || !rng_state) return VPF_ERR_NULL;
+    if (!y_h16 || !out || !rng_state) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(dropout_add_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y_bf16, res, out, n,
+    hipLaunchKernelGGL(dropout_add_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)y_h16, res, out, n,
                        rng_state, site, p);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-// dy(bf16) = keep ? dout * scale : 0
-__global__ void dropout_bwd_kernel(const float* __restrict__ dout, bf16_t* __restrict__ dy, long n,
+// dy(h16) = keep ? dout * scale : 0
+__global__ void dropout_bwd_kernel(const float* __restrict__ dout, h16_t* __restrict__ dy, long n,
                                    const uint32_t* __restrict__ rng_state, uint32_t site, float p)
 {
     const VpfRng rng = vpf_rng_init(rng_state, site, p);
@@ -245,22 +245,22 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dout, bf16_t* __res
         if (vec) {
             const float4 d = *reinterpret_cast<const float4*>(dout + g * 4);
             uint2 w;
-            w.x = pack_bf16x2((keep & 1u) ? d.x * rng.scale : 0.f, (keep & 2u) ? d.y * rng.scale : 0.f);
-            w.y = pack_bf16x2((keep & 4u) ? d.z * rng.scale : 0.f, (keep & 8u) ? d.w * rng.scale : 0.f);
+            w.x = pack_h16x2((keep & 1u) ? d.x * rng.scale : 0.f, (keep & 2u) ? d.y * rng.scale : 0.f);
+            w.y = pack_h16x2((keep & 4u) ? d.z * rng.scale : 0.f, (keep & 8u) ? d.w * rng.scale : 0.f);
             *reinterpret_cast<uint2*>(dy + g * 4) = w;
         } else {
             for (int e = 0; e < 4 && g * 4 + e < n; ++e)
-                dy[g * 4 + e] = f32_to_bf16(((keep >> e) & 1u) ? dout[g * 4 + e] * rng.scale : 0.f);
+                dy[g * 4 + e] = f32_to_h16(((keep >> e) & 1u) ? dout[g * 4 + e] * rng.scale : 0.f);
         }
     }
 }
-extern "C" int vpf_dropout_bwd(const float* dout, void* dy_bf16, long n, const uint32_t* rng_state, uint32_t site, float p,
+extern "C" int vpf_dropout_bwd(const float* dout, void* dy_h16, long n, const uint32_t* rng_state, uint32_t site, float p,
                                void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!dout || !dy_bf16 || !rng_state) return VPF_ERR_NULL;
+    if (!dout || !dy_h16 || !rng_state) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, (bf16_t*)dy_bf16, n, rng_state, site, p);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, dout, (h16_t*)dy_h16, n, rng_state, site, p);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -313,7 +313,7 @@ extern "C" int vpf_rng_advance(uint32_t* rng_state, void* stream)
 
 // =============================================================================== column sums (bias grads, BN stats)
 // x [M,C] -> acc[c] += sum_m x ; acc2[c] += sum_m x^2 (optional).  A block owns a slab of rows; every thread
-// streams 8 consecutive columns (16-byte loads for bf16) of one row per step; the block's row-lanes meet in
+// streams 8 consecutive columns (16-byte loads for h16) of one row per step; the block's row-lanes meet in
 // LDS and ONE fp32 atomic per column and block leaves the CU.
 // small M: block = 64 columns (8 groups of 8) x 32 row lanes; fixed-order fold
 template <typename T>
@@ -328,10 +328,10 @@ __global__ void __launch_bounds__(256) colsum_small_kernel(const T* __restrict__
     for (long r = rl; r < M; r += 32) {
         float v[8];
         if (sizeof(T) == 2) {
-            const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + (size_t)r * C + c0);
+            const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const h16_t*>(x) + (size_t)r * C + c0);
             const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+            for (int j = 0; j < 4; ++j) { v[2 * j] = h16_lo(w[j]); v[2 * j + 1] = h16_hi(w[j]); }
         } else {
             const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + c0);
             const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + c0 + 4);
@@ -371,10 +371,10 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ x, lo
             for (long r = r0 + rl; r < r1; r += rlanes) {
                 float v[8];
                 if (sizeof(T) == 2) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(x) + (size_t)r * C + cg * 8);
+                    const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const h16_t*>(x) + (size_t)r * C + cg * 8);
                     const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+                    for (int j = 0; j < 4; ++j) { v[2 * j] = h16_lo(w[j]); v[2 * j + 1] = h16_hi(w[j]); }
                 } else {
                     const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + cg * 8);
                     const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + (size_t)r * C + cg * 8 + 4);
@@ -412,7 +412,7 @@ __global__ void colsum_generic_kernel(const T* __restrict__ x, long M, int C, fl
     atomicAdd(acc + c, s);
     if (acc2) atomicAdd(acc2 + c, q);
 }
-extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* acc, float* acc2, void* stream)
+extern "C" int vpf_colsum(const void* x, int x_is_h16, long M, int C, float* acc, float* acc2, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !acc) return VPF_ERR_NULL;
@@ -425,7 +425,7 @@ extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* ac
             // a batch of samples (BatchNorm of the projection heads): every column is summed by ONE block in a fixed order
             // (deterministic), but the columns are spread over C/64 blocks and the rows over 32 lanes, so that no thread walks
             // more than M/32 rows
-            if (x_is_bf16) hipLaunchKernelGGL(colsum_small_kernel<bf16_t>, dim3(C / 64), dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2);
+            if (x_is_h16) hipLaunchKernelGGL(colsum_small_kernel<h16_t>, dim3(C / 64), dim3(256), 0, st, (const h16_t*)x, M, C, acc, acc2);
             else hipLaunchKernelGGL(colsum_small_kernel<float>, dim3(C / 64), dim3(256), 0, st, (const float*)x, M, C, acc, acc2);
             VPF_CHECK_LAUNCH();
             return VPF_OK;
@@ -433,13 +433,13 @@ extern "C" int vpf_colsum(const void* x, int x_is_bf16, long M, int C, float* ac
         if (M <= 2048) rpb = (int)M;                        // one block: a deterministic sum
         while ((M + rpb - 1) / rpb > 512) rpb *= 2;      // <= 512 blocks -> <= 512 atomics per column
         const int grid = (int)((M + rpb - 1) / rpb);
-        if (x_is_bf16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2, rpb);
+        if (x_is_h16) hipLaunchKernelGGL(colsum_kernel<h16_t>, dim3(grid), dim3(256), 0, st, (const h16_t*)x, M, C, acc, acc2, rpb);
         else hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, M, C, acc, acc2, rpb);
     } else {
         int rpb = 128;
         while ((M + rpb - 1) / rpb > 16384) rpb *= 2;
         dim3 grid(vpf_cdiv(C, 256), (unsigned)((M + rpb - 1) / rpb));
-        if (x_is_bf16) hipLaunchKernelGGL(colsum_generic_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, M, C, acc, acc2, rpb);
+        if (x_is_h16) hipLaunchKernelGGL(colsum_generic_kernel<h16_t>, grid, dim3(256), 0, st, (const h16_t*)x, M, C, acc, acc2, rpb);
         else hipLaunchKernelGGL(colsum_generic_kernel<float>, grid, dim3(256), 0, st, (const float*)x, M, C, acc, acc2, rpb);
     }
     VPF_CHECK_LAUNCH();
@@ -544,8 +544,8 @@ __global__ void bn_act_fwd_kernel(const TIN* __restrict__ x, const float* __rest
         st_f<TOUT>(y, i, v);
     }
 }
-extern "C" int vpf_bn_act_fwd(const void* x, int x_is_bf16, const float* stat, const float* gamma, const float* beta, void* y,
-                              int y_is_bf16, long M, int C, int relu, void* stream)
+extern "C" int vpf_bn_act_fwd(const void* x, int x_is_h16, const float* stat, const float* gamma, const float* beta, void* y,
+                              int y_is_h16, long M, int C, int relu, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!x || !stat || !gamma || !beta || !y) return VPF_ERR_NULL;
@@ -555,9 +555,9 @@ extern "C" int vpf_bn_act_fwd(const void* x, int x_is_bf16, const float* stat, c
     const int grid = grid_for(total, 256);
     hipStream_t st = (hipStream_t)stream;
 #define BNF(TI, TO) hipLaunchKernelGGL((bn_act_fwd_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)x, stat, gamma, beta, (TO*)y, total, C, relu)
-    if (x_is_bf16 && y_is_bf16) BNF(bf16_t, bf16_t);
-    else if (x_is_bf16) BNF(bf16_t, float);
-    else if (y_is_bf16) BNF(float, bf16_t);
+    if (x_is_h16 && y_is_h16) BNF(h16_t, h16_t);
+    else if (x_is_h16) BNF(h16_t, float);
+    else if (y_is_h16) BNF(float, h16_t);
     else BNF(float, float);
 #undef BNF
     VPF_CHECK_LAUNCH();
@@ -616,8 +616,8 @@ __global__ void bn_bwd_apply_kernel(const TDY* __restrict__ dy, const TX* __rest
     if (blockIdx.x == 0 && dgamma)
         for (int c = threadIdx.x; c < C; c += blockDim.x) { atomicAdd(dgamma + c, tmp[C + c]); atomicAdd(dbeta + c, tmp[c]); }
 }
-extern "C" int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_is_bf16, const float* stat, const float* gamma,
-                          const float* beta, long M, int C, int relu, int training, float* tmp2C_zeroed, void* dx, int dx_is_bf16,
+extern "C" int vpf_bn_bwd(const void* dy, int dy_is_h16, const void* x, int x_is_h16, const float* stat, const float* gamma,
+                          const float* beta, long M, int C, int relu, int training, float* tmp2C_zeroed, void* dx, int dx_is_h16,
                           float* dgamma, float* dbeta, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
@@ -632,10 +632,10 @@ extern "C" int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_i
     const int g2 = grid_for(M * C, 256);
 #define BNR(TX, TDY) hipLaunchKernelGGL((bn_bwd_reduce_kernel<TX, TDY>), g1, dim3(256), 0, st, (const TDY*)dy, (const TX*)x, stat, gamma, beta, M, C, relu, tmp2C_zeroed, rpb)
 #define BNA(TX, TDY, TDX) hipLaunchKernelGGL((bn_bwd_apply_kernel<TX, TDY, TDX>), dim3(g2), dim3(256), 0, st, (const TDY*)dy, (const TX*)x, stat, gamma, beta, tmp2C_zeroed, M, C, relu, training, (TDX*)dx, dgamma, dbeta)
-    if (x_is_bf16 && dy_is_bf16) { BNR(bf16_t, bf16_t); if (dx_is_bf16) BNA(bf16_t, bf16_t, bf16_t); else BNA(bf16_t, bf16_t, float); }
-    else if (x_is_bf16 && !dy_is_bf16) { BNR(bf16_t, float); if (dx_is_bf16) BNA(bf16_t, float, bf16_t); else BNA(bf16_t, float, float); }
-    else if (!x_is_bf16 && dy_is_bf16) { BNR(float, bf16_t); if (dx_is_bf16) BNA(float, bf16_t, bf16_t); else BNA(float, bf16_t, float); }
-    else { BNR(float, float); if (dx_is_bf16) BNA(float, float, bf16_t); else BNA(float, float, float); }
+    if (x_is_h16 && dy_is_h16) { BNR(h16_t, h16_t); if (dx_is_h16) BNA(h16_t, h16_t, h16_t); else BNA(h16_t, h16_t, float); }
+    else if (x_is_h16 && !dy_is_h16) { BNR(h16_t, float); if (dx_is_h16) BNA(h16_t, float, h16_t); else BNA(h16_t, float, float); }
+    else if (!x_is_h16 && dy_is_h16) { BNR(float, h16_t); if (dx_is_h16) BNA(float, h16_t, h16_t); else BNA(float, h16_t, float); }
+    else { BNR(float, float); if (dx_is_h16) BNA(float, float, h16_t); else BNA(float, float, float); }
 #undef BNR
 #undef BNA
     VPF_CHECK_LAUNCH();
@@ -643,56 +643,56 @@ extern "C" int vpf_bn_bwd(const void* dy, int dy_is_bf16, const void* x, int x_i
 }
 
 // =============================================================================== max over group members
-// h [NG, K, C] bf16 -> out [NG, C] (f32 or bf16), arg [NG, C] (uint8, first max)
+// h [NG, K, C] h16 -> out [NG, C] (f32 or h16), arg [NG, C] (uint8, first max)
 template <typename TOUT>
-__global__ void group_max_fwd_kernel(const bf16_t* __restrict__ h, long NG, int K, int C, TOUT* __restrict__ out, uint8_t* __restrict__ arg)
+__global__ void group_max_fwd_kernel(const h16_t* __restrict__ h, long NG, int K, int C, TOUT* __restrict__ out, uint8_t* __restrict__ arg)
 {
     const long total = NG * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long g = i / C; const int c = (int)(i % C);
         float best = -INFINITY; int bi = 0;
-        for (int k = 0; k < K; ++k) { const float v = bf16_to_f32(h[((size_t)g * K + k) * C + c]); if (v > best) { best = v; bi = k; } }
+        for (int k = 0; k < K; ++k) { const float v = h16_to_f32(h[((size_t)g * K + k) * C + c]); if (v > best) { best = v; bi = k; } }
         st_f<TOUT>(out, i, best);
         if (arg) arg[i] = (uint8_t)bi;
     }
 }
-extern "C" int vpf_group_max_fwd(const void* h_bf16, long NG, int K, int C, void* out, int out_is_bf16, uint8_t* arg, void* stream)
+extern "C" int vpf_group_max_fwd(const void* h_h16, long NG, int K, int C, void* out, int out_is_h16, uint8_t* arg, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!h_bf16 || !out) return VPF_ERR_NULL;
+    if (!h_h16 || !out) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || K > 255 || C <= 0) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
     const int grid = grid_for(NG * C, 256);
-    if (out_is_bf16) hipLaunchKernelGGL(group_max_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, NG, K, C, (bf16_t*)out, arg);
-    else hipLaunchKernelGGL(group_max_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)h_bf16, NG, K, C, (float*)out, arg);
+    if (out_is_h16) hipLaunchKernelGGL(group_max_fwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h16_t*)h_h16, NG, K, C, (h16_t*)out, arg);
+    else hipLaunchKernelGGL(group_max_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h16_t*)h_h16, NG, K, C, (float*)out, arg);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-// dh [NG,K,C] bf16 = (k == arg) ? dout : 0
+// dh [NG,K,C] h16 = (k == arg) ? dout : 0
 template <typename TIN>
-__global__ void group_max_bwd_kernel(const TIN* __restrict__ dout, const uint8_t* __restrict__ arg, long NG, int K, int C, bf16_t* __restrict__ dh)
+__global__ void group_max_bwd_kernel(const TIN* __restrict__ dout, const uint8_t* __restrict__ arg, long NG, int K, int C, h16_t* __restrict__ dh)
 {
     const long total = NG * K * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C); const long gk = i / C; const int k = (int)(gk % K); const long g = gk / K;
-        dh[i] = (arg[g * C + c] == k) ? f32_to_bf16(ld_f<TIN>(dout, (size_t)g * C + c)) : (bf16_t)0;
+        dh[i] = (arg[g * C + c] == k) ? f32_to_h16(ld_f<TIN>(dout, (size_t)g * C + c)) : (h16_t)0;
     }
 }
-extern "C" int vpf_group_max_bwd(const void* dout, int dout_is_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
+extern "C" int vpf_group_max_bwd(const void* dout, int dout_is_h16, const uint8_t* arg, long NG, int K, int C, void* dh_h16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!dout || !arg || !dh_bf16) return VPF_ERR_NULL;
+    if (!dout || !arg || !dh_h16) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
     const int grid = grid_for(NG * K * C, 256);
-    if (dout_is_bf16) hipLaunchKernelGGL(group_max_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dout, arg, NG, K, C, (bf16_t*)dh_bf16);
-    else hipLaunchKernelGGL(group_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dout, arg, NG, K, C, (bf16_t*)dh_bf16);
+    if (dout_is_h16) hipLaunchKernelGGL(group_max_bwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h16_t*)dout, arg, NG, K, C, (h16_t*)dh_h16);
+    else hipLaunchKernelGGL(group_max_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)dout, arg, NG, K, C, (h16_t*)dh_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 
 // Group2Emb concat (utils.py:183): feat[m, 0:C] = gmax[m / K, :], feat[m, C:2C] = h[m, :]
-__global__ void g2e_concat_fwd_kernel(const bf16_t* __restrict__ gmax, const bf16_t* __restrict__ h, long M, int K, int C, bf16_t* __restrict__ feat)
+__global__ void g2e_concat_fwd_kernel(const h16_t* __restrict__ gmax, const h16_t* __restrict__ h, long M, int K, int C, h16_t* __restrict__ feat)
 {
     const long total = M * 2 * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -700,45 +700,45 @@ __global__ void g2e_concat_fwd_kernel(const bf16_t* __restrict__ gmax, const bf1
         feat[i] = c < C ? gmax[(m / K) * C + c] : h[m * C + (c - C)];
     }
 }
-extern "C" int vpf_g2e_concat_fwd(const void* gmax_bf16, const void* h_bf16, long M, int K, int C, void* feat_bf16, void* stream)
+extern "C" int vpf_g2e_concat_fwd(const void* gmax_h16, const void* h_h16, long M, int K, int C, void* feat_h16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!gmax_bf16 || !h_bf16 || !feat_bf16) return VPF_ERR_NULL;
+    if (!gmax_h16 || !h_h16 || !feat_h16) return VPF_ERR_NULL;
     if (M < 0 || K <= 0 || C <= 0 || (M % K)) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
-    hipLaunchKernelGGL(g2e_concat_fwd_kernel, dim3(grid_for(M * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)gmax_bf16,
-                       (const bf16_t*)h_bf16, M, K, C, (bf16_t*)feat_bf16);
+    hipLaunchKernelGGL(g2e_concat_fwd_kernel, dim3(grid_for(M * 2 * C, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)gmax_h16,
+                       (const h16_t*)h_h16, M, K, C, (h16_t*)feat_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 // dh[m,c] = dfeat[m, C+c] + (k == arg[g,c] ? sum_k' dfeat[(g,k'), c] : 0)
-__global__ void g2e_concat_bwd_kernel(const bf16_t* __restrict__ dfeat, const uint8_t* __restrict__ arg, long NG, int K, int C, bf16_t* __restrict__ dh)
+__global__ void g2e_concat_bwd_kernel(const h16_t* __restrict__ dfeat, const uint8_t* __restrict__ arg, long NG, int K, int C, h16_t* __restrict__ dh)
 {
     const long total = NG * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long g = i / C; const int c = (int)(i % C);
         float s = 0.f;
-        for (int k = 0; k < K; ++k) s += bf16_to_f32(dfeat[((size_t)g * K + k) * 2 * C + c]);
+        for (int k = 0; k < K; ++k) s += h16_to_f32(dfeat[((size_t)g * K + k) * 2 * C + c]);
         const int a = arg[i];
         for (int k = 0; k < K; ++k) {
-            const float v = bf16_to_f32(dfeat[((size_t)g * K + k) * 2 * C + C + c]) + (k == a ? s : 0.f);
-            dh[((size_t)g * K + k) * C + c] = f32_to_bf16(v);
+            const float v = h16_to_f32(dfeat[((size_t)g * K + k) * 2 * C + C + c]) + (k == a ? s : 0.f);
+            dh[((size_t)g * K + k) * C + c] = f32_to_h16(v);
         }
     }
 }
-extern "C" int vpf_g2e_concat_bwd(const void* dfeat_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
+extern "C" int vpf_g2e_concat_bwd(const void* dfeat_h16, const uint8_t* arg, long NG, int K, int C, void* dh_h16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!dfeat_bf16 || !arg || !dh_bf16) return VPF_ERR_NULL;
+    if (!dfeat_h16 || !arg || !dh_h16) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
-    hipLaunchKernelGGL(g2e_concat_bwd_kernel, dim3(grid_for(NG * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dfeat_bf16, arg, NG, K, C, (bf16_t*)dh_bf16);
+    hipLaunchKernelGGL(g2e_concat_bwd_kernel, dim3(grid_for(NG * C, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)dfeat_h16, arg, NG, K, C, (h16_t*)dh_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 
-// sum over the K group members: x bf16 [NG,K,C] -> out f32 [NG,C]   (gradient of the broadcast "global" feature, utils.py:183)
-__global__ void group_sum_kernel(const bf16_t* __restrict__ x, long NG, int K, int C, float* __restrict__ out)
+// sum over the K group members: x h16 [NG,K,C] -> out f32 [NG,C]   (gradient of the broadcast "global" feature, utils.py:183)
+__global__ void group_sum_kernel(const h16_t* __restrict__ x, long NG, int K, int C, float* __restrict__ out)
 {
     const long total = NG * (C / 2);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -746,38 +746,38 @@ __global__ void group_sum_kernel(const bf16_t* __restrict__ x, long NG, int K, i
         float s0 = 0.f, s1 = 0.f;
         for (int k = 0; k < K; ++k) {
             const uint32_t u = *reinterpret_cast<const uint32_t*>(x + ((size_t)g * K + k) * C + 2 * c2);
-            s0 += __uint_as_float(u << 16); s1 += __uint_as_float(u & 0xffff0000u);
+            s0 += h16_lo(u); s1 += h16_hi(u);
         }
         out[g * C + 2 * c2] = s0; out[g * C + 2 * c2 + 1] = s1;
     }
 }
-extern "C" int vpf_group_sum(const void* x_bf16, long NG, int K, int C, float* out, void* stream)
+extern "C" int vpf_group_sum(const void* x_h16, long NG, int K, int C, float* out, void* stream)
 {
     (void)hipGetLastError();
-    if (!x_bf16 || !out) return VPF_ERR_NULL;
+    if (!x_h16 || !out) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || C <= 0 || (C & 1)) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
-    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(NG * (C / 2), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, NG, K, C, out);
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid_for(NG * (C / 2), 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)x_h16, NG, K, C, out);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 // dh[g, arg[g,c], c] += dg[g,c]   (max-pool backward added onto an existing gradient; one writer per element)
-__global__ void group_max_scatter_add_kernel(const bf16_t* __restrict__ dg, const uint8_t* __restrict__ arg, long NG, int K, int C, bf16_t* __restrict__ dh)
+__global__ void group_max_scatter_add_kernel(const h16_t* __restrict__ dg, const uint8_t* __restrict__ arg, long NG, int K, int C, h16_t* __restrict__ dh)
 {
     const long total = NG * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long g = i / C; const int c = (int)(i % C);
         const size_t o = ((size_t)g * K + arg[i]) * C + c;
-        dh[o] = f32_to_bf16(bf16_to_f32(dh[o]) + bf16_to_f32(dg[i]));
+        dh[o] = f32_to_h16(h16_to_f32(dh[o]) + h16_to_f32(dg[i]));
     }
 }
-extern "C" int vpf_group_max_scatter_add(const void* dg_bf16, const uint8_t* arg, long NG, int K, int C, void* dh_bf16, void* stream)
+extern "C" int vpf_group_max_scatter_add(const void* dg_h16, const uint8_t* arg, long NG, int K, int C, void* dh_h16, void* stream)
 {
     (void)hipGetLastError();
-    if (!dg_bf16 || !arg || !dh_bf16) return VPF_ERR_NULL;
+    if (!dg_h16 || !arg || !dh_h16) return VPF_ERR_NULL;
     if (NG < 0 || K <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
     if (NG == 0) return VPF_OK;
-    hipLaunchKernelGGL(group_max_scatter_add_kernel, dim3(grid_for(NG * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dg_bf16, arg, NG, K, C, (bf16_t*)dh_bf16);
+    hipLaunchKernelGGL(group_max_scatter_add_kernel, dim3(grid_for(NG * C, 256)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)dg_h16, arg, NG, K, C, (h16_t*)dh_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -899,7 +899,7 @@ __global__ void __launch_bounds__(512) bn_small_fwd_kernel(const float* __restri
                                                           const float* __restrict__ beta, float eps, float momentum,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           long long* __restrict__ num_batches, float* __restrict__ stat,
-                                                          bf16_t* __restrict__ y, int relu)
+                                                          h16_t* __restrict__ y, int relu)
 {
     __shared__ float fs[8][64], fq[8][64];
     __shared__ float smu[64], srs[64];
@@ -937,18 +937,18 @@ __global__ void __launch_bounds__(512) bn_small_fwd_kernel(const float* __restri
     for (r = rl; r < M; r += 8) {
         float v = (x[(size_t)r * C + c] - mu) * rs * ga + be;
         if (relu == 1) v = fmaxf(v, 0.f); else if (relu == 2) v = v > 0.f ? v : 0.2f * v;   // 2: LeakyReLU(0.2), partseg.py:393
-        y[(size_t)r * C + c] = f32_to_bf16(v);
+        y[(size_t)r * C + c] = f32_to_h16(v);
     }
 }
 extern "C" int vpf_bn_small_fwd(const float* x, int M, int C, const float* gamma, const float* beta, float eps, float momentum,
-                                float* running_mean, float* running_var, long long* num_batches, float* stat, void* y_bf16, int relu,
+                                float* running_mean, float* running_var, long long* num_batches, float* stat, void* y_h16, int relu,
                                 void* stream)
 {
     (void)hipGetLastError();
-    if (!x || !gamma || !beta || !stat || !y_bf16) return VPF_ERR_NULL;
+    if (!x || !gamma || !beta || !stat || !y_h16) return VPF_ERR_NULL;
     if (M <= 0 || M > 4096 || C <= 0 || (C % 64)) return VPF_ERR_BADSHAPE;
     hipLaunchKernelGGL(bn_small_fwd_kernel, dim3(C / 64), dim3(512), 0, (hipStream_t)stream, x, M, C, gamma, beta, eps, momentum, running_mean,
-                       running_var, num_batches, stat, (bf16_t*)y_bf16, relu);
+                       running_var, num_batches, stat, (h16_t*)y_h16, relu);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -1000,12 +1000,12 @@ __global__ void __launch_bounds__(512) bn_small_bwd_kernel(const float* __restri
     }
 }
 extern "C" int vpf_bn_small_bwd(const float* dy, const float* x, const float* stat, const float* gamma, const float* beta, int M, int C,
-                                int relu, void* dx, int dx_is_bf16, float* dgamma, float* dbeta, void* stream)
+                                int relu, void* dx, int dx_is_h16, float* dgamma, float* dbeta, void* stream)
 {
     (void)hipGetLastError();
     if (!dy || !x || !stat || !gamma || !beta) return VPF_ERR_NULL;
     if (M <= 0 || M > 4096 || C <= 0 || (C % 64)) return VPF_ERR_BADSHAPE;
-    if (dx_is_bf16) hipLaunchKernelGGL(bn_small_bwd_kernel<bf16_t>, dim3(C / 64), dim3(512), 0, (hipStream_t)stream, dy, x, stat, gamma, beta, M, C, relu, (bf16_t*)dx, dgamma, dbeta);
+    if (dx_is_h16) hipLaunchKernelGGL(bn_small_bwd_kernel<h16_t>, dim3(C / 64), dim3(512), 0, (hipStream_t)stream, dy, x, stat, gamma, beta, M, C, relu, (h16_t*)dx, dgamma, dbeta);
     else hipLaunchKernelGGL(bn_small_bwd_kernel<float>, dim3(C / 64), dim3(512), 0, (hipStream_t)stream, dy, x, stat, gamma, beta, M, C, relu, (float*)dx, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;

@@ -5,7 +5,7 @@
 // M = batch*groups*32 = 393 216 rows at the benchmark size).  Here one workgroup (8 waves) walks pairs of
 // groups (64 rows); the conv weights live in REGISTERS as MFMA B-fragments (each wave owns fixed output
 // columns), activations of the pair stay in LDS, and only what BatchNorm's batch statistics force out
-// (the pre-BN2 activation h3, bf16) plus what backward needs (a1, h2, max-pool winners) goes to HBM.
+// (the pre-BN2 activation h3, h16) plus what backward needs (a1, h2, max-pool winners) goes to HBM.
 //
 //   g2e_fwd_a:  x --conv1+BN1+ReLU (BN folded into the 3-tap weights)--> a1 --conv2 (MFMA)--> h2
 //               --max over the 32 members--> gmax --conv3 on [gmax | h2] (MFMA, gmax read as an LDS broadcast,
@@ -14,32 +14,31 @@
 #include "vpf_common.h"
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-#define A1LD 72      // a1 tile row stride (bf16): 64 + 8
+#define A1LD 72      // a1 tile row stride (h16): 64 + 8
 #define H2LD 136     // h2 tile row stride: 128 + 8
 #define H3LD 264     // h3 / a3 tile row stride: 256 + 8
 
-__device__ __forceinline__ bf16x8_t ldfrag(const bf16_t* p) { return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(p)); }
-__device__ __forceinline__ uint32_t bf16_sortable(bf16_t v) { return (v & 0x8000u) ? (uint32_t)(uint16_t)~v : (uint32_t)(v | 0x8000u); }
-__device__ __forceinline__ bf16_t bf16_unsortable(uint32_t s) { return (s & 0x8000u) ? (bf16_t)(s & 0x7fffu) : (bf16_t)~s; }
+__device__ __forceinline__ h16x8_t ldfrag(const h16_t* p) { return __builtin_bit_cast(h16x8_t, *reinterpret_cast<const uint4*>(p)); }
+__device__ __forceinline__ uint32_t h16_sortable(h16_t v) { return (v & 0x8000u) ? (uint32_t)(uint16_t)~v : (uint32_t)(v | 0x8000u); }
+__device__ __forceinline__ h16_t h16_unsortable(uint32_t s) { return (s & 0x8000u) ? (h16_t)(s & 0x7fffu) : (h16_t)~s; }
 
 struct G2eA {
     const float* x; long NG; int C;                 // x [NG*32, C] fp32
     const float* w1e; const float* b1e;              // BN1 folded into conv1: [64,C], [64]
-    const bf16_t* w2; const float* b2;               // [128,64] bf16, [128]
-    const bf16_t* w3; const float* b3;               // [256,256] bf16 ([global | local] columns), [256]
-    bf16_t* a1; bf16_t* h2; bf16_t* gmax; uint8_t* arg2; bf16_t* h3;   // outputs
+    const h16_t* w2; const float* b2;               // [128,64] h16, [128]
+    const h16_t* w3; const float* b3;               // [256,256] h16 ([global | local] columns), [256]
+    h16_t* a1; h16_t* h2; h16_t* gmax; uint8_t* arg2; h16_t* h3;   // outputs
     float* sums;                                     // [gridDim.x][512] = per-workgroup sum | sumsq of h3 per column
 };
 
 __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
 {
-    __shared__ __attribute__((aligned(16))) bf16_t sA1[64 * A1LD];
-    __shared__ __attribute__((aligned(16))) bf16_t sH2[64 * H2LD];
-    __shared__ __attribute__((aligned(16))) bf16_t sG[2 * 128];
-    __shared__ __attribute__((aligned(16))) bf16_t sH3[64 * H3LD];
+    __shared__ __attribute__((aligned(16))) h16_t sA1[64 * A1LD];
+    __shared__ __attribute__((aligned(16))) h16_t sH2[64 * H2LD];
+    __shared__ __attribute__((aligned(16))) h16_t sG[2 * 128];
+    __shared__ __attribute__((aligned(16))) h16_t sH3[64 * H3LD];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hl = lane >> 5, l31 = lane & 31;
 
     // ---- per-thread constants: conv1 (BN folded) for 8 channels of one row
@@ -52,12 +51,12 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
     // ---- weight-stationary MFMA B fragments
     // conv2: wave w -> row tile rt2 = w >> 2, column tile ct2 = w & 3 ; B[k][n] = W2[n][k], lane holds n = ct2*32 + l31, k = ks*16 + 8h + j
     const int rt2 = w >> 2, ct2 = w & 3;
-    bf16x8_t w2f[4];
+    h16x8_t w2f[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) w2f[ks] = ldfrag(p.w2 + (size_t)(ct2 * 32 + l31) * 64 + ks * 16 + 8 * hl);
     const float b2v = p.b2[ct2 * 32 + l31];
     // conv3: wave w -> column tile w (32 of 256 columns), both row tiles
-    bf16x8_t w3f[16];
+    h16x8_t w3f[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) w3f[ks] = ldfrag(p.w3 + (size_t)(w * 32 + l31) * 256 + ks * 16 + 8 * hl);
     const float b3v = p.b3[w * 32 + l31];
@@ -87,33 +86,33 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float4 wv = sW1[c1ch + j]; v[j] = fmaxf(wv.x * x0 + wv.y * x1 + wv.z * x2 + wv.w, 0.f); }
-                o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                o.x = pack_h16x2(v[0], v[1]); o.y = pack_h16x2(v[2], v[3]); o.z = pack_h16x2(v[4], v[5]); o.w = pack_h16x2(v[6], v[7]);
                 *reinterpret_cast<uint4*>(p.a1 + (size_t)(row0 + c1row) * 64 + c1ch) = o;
             }
             *reinterpret_cast<uint4*>(sA1 + c1row * A1LD + c1ch) = o;
         }
         __syncthreads();
-        // ---- conv2 (K = 64) -> h2 tile [32 x 32] of this wave, + bias, bf16 ; group max over the 32 rows
+        // ---- conv2 (K = 64) -> h2 tile [32 x 32] of this wave, + bias, h16 ; group max over the 32 rows
         {
             f32x16_t acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sA1 + (rt2 * 32 + l31) * A1LD + ks * 16 + 8 * hl), w2f[ks], acc, 0, 0, 0);
+                acc = vpf_mfma32(ldfrag(sA1 + (rt2 * 32 + l31) * A1LD + ks * 16 + 8 * hl), w2f[ks], acc);
             uint32_t best = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;
-                const bf16_t hb = f32_to_bf16(acc[r] + b2v);
+                const h16_t hb = f32_to_h16(acc[r] + b2v);
                 sH2[(rt2 * 32 + row) * H2LD + ct2 * 32 + l31] = hb;
-                const uint32_t key = (bf16_sortable(hb) << 8) | (uint32_t)(31 - row);      // max value, ties -> first row
+                const uint32_t key = (h16_sortable(hb) << 8) | (uint32_t)(31 - row);      // max value, ties -> first row
                 best = key > best ? key : best;
             }
             const uint32_t other = __shfl_xor(best, 32, 64);
             best = other > best ? other : best;
             if (hl == 0) {
-                const bf16_t gv = bf16_unsortable(best >> 8);
+                const h16_t gv = h16_unsortable(best >> 8);
                 sG[rt2 * 128 + ct2 * 32 + l31] = gv;
                 const long g = pr * 2 + rt2;
                 if (g < p.NG) {
@@ -136,9 +135,9 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
             for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const bf16_t* ap = ks < 8 ? (sG + rt * 128 + ks * 16 + 8 * hl)                                   // same global feature for all rows
+                    const h16_t* ap = ks < 8 ? (sG + rt * 128 + ks * 16 + 8 * hl)                                   // same global feature for all rows
                                               : (sH2 + (rt * 32 + l31) * H2LD + (ks - 8) * 16 + 8 * hl);
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(ap), w3f[ks], acc[rt], 0, 0, 0);
+                    acc[rt] = vpf_mfma32(ldfrag(ap), w3f[ks], acc[rt]);
                 }
             }
 #pragma unroll
@@ -146,9 +145,9 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                    const bf16_t hb = f32_to_bf16(acc[rt][r] + b3v);
+                    const h16_t hb = f32_to_h16(acc[rt][r] + b3v);
                     sH3[row * H3LD + w * 32 + l31] = hb;
-                    const float hv = row < nrows ? bf16_to_f32(hb) : 0.f;          // (a select, not a branch per element)
+                    const float hv = row < nrows ? h16_to_f32(hb) : 0.f;          // (a select, not a branch per element)
                     ssum += hv; ssq += hv * hv;
                 }
         }
@@ -164,9 +163,9 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
 }
 
 struct G2eB {
-    const bf16_t* h3; long NG;                       // [NG*32, 256]
+    const h16_t* h3; long NG;                       // [NG*32, 256]
     const float* ab2;                                // BN2 as an affine: a[256] | b[256]
-    const bf16_t* w4; const float* b4; int Dm;       // [Dm,256] bf16, [Dm]
+    const h16_t* w4; const float* b4; int Dm;       // [Dm,256] h16, [Dm]
     float* out; uint8_t* arg4;                       // [NG,Dm]
 };
 
@@ -174,9 +173,9 @@ struct G2eB {
 template <int NT>
 __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
 {
-    __shared__ __attribute__((aligned(16))) bf16_t sA3[64 * H3LD];
+    __shared__ __attribute__((aligned(16))) h16_t sA3[64 * H3LD];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hl = lane >> 5, l31 = lane & 31;
-    bf16x8_t w4f[NT][16];
+    h16x8_t w4f[NT][16];
     float b4v[NT];
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
         b4v[q] = n < p.Dm ? p.b4[n] : 0.f;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
-            w4f[q][ks] = n < p.Dm ? ldfrag(p.w4 + (size_t)n * 256 + ks * 16 + 8 * hl) : __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+            w4f[q][ks] = n < p.Dm ? ldfrag(p.w4 + (size_t)n * 256 + ks * 16 + 8 * hl) : __builtin_bit_cast(h16x8_t, make_uint4(0, 0, 0, 0));
     }
     // staging: thread owns 16-byte chunk column (t & 31) -> BN2 affine for those 8 channels
     float aa[8], bb[8];
@@ -216,8 +215,8 @@ __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
                 uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    u[j] = pack_bf16x2(fmaxf(fmaf(aa[2 * j], __uint_as_float(u[j] << 16), bb[2 * j]), 0.f),
-                                       fmaxf(fmaf(aa[2 * j + 1], __uint_as_float(u[j] & 0xffff0000u), bb[2 * j + 1]), 0.f));
+                    u[j] = pack_h16x2(fmaxf(fmaf(aa[2 * j], h16_lo(u[j]), bb[2 * j]), 0.f),
+                                       fmaxf(fmaf(aa[2 * j + 1], h16_hi(u[j]), bb[2 * j + 1]), 0.f));
                 v = make_uint4(u[0], u[1], u[2], u[3]);
             }
             *reinterpret_cast<uint4*>(sA3 + row * H3LD + ch * 8) = v;
@@ -234,21 +233,21 @@ __global__ void __launch_bounds__(512) g2e_fwd_b_kernel(G2eB p)
             for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sA3 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[q][ks], acc[rt], 0, 0, 0);
+                    acc[rt] = vpf_mfma32(ldfrag(sA3 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[q][ks], acc[rt]);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 uint32_t best = 0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * hl;
-                    const uint32_t key = (bf16_sortable(f32_to_bf16(acc[rt][r] + b4v[q])) << 8) | (uint32_t)(31 - row);
+                    const uint32_t key = (h16_sortable(f32_to_h16(acc[rt][r] + b4v[q])) << 8) | (uint32_t)(31 - row);
                     best = key > best ? key : best;
                 }
                 const uint32_t other = __shfl_xor(best, 32, 64);
                 best = other > best ? other : best;
                 const long g = pr * 2 + rt;
                 if (hl == 0 && g < p.NG && n < p.Dm) {
-                    p.out[(size_t)g * p.Dm + n] = bf16_to_f32(bf16_unsortable(best >> 8));
+                    p.out[(size_t)g * p.Dm + n] = h16_to_f32(h16_unsortable(best >> 8));
                     p.arg4[(size_t)g * p.Dm + n] = (uint8_t)(31 - (best & 0xff));
                 }
             }
@@ -283,18 +282,18 @@ extern "C" int vpf_g2e_fold_bn1(const float* W1, const float* b1, const float* a
     return VPF_OK;
 }
 
-// x [NG*32, C] -> a1 [M,64], h2 [M,128], gmax [NG,128], arg2 [NG,128], h3 [M,256] (all bf16 / u8); partials [256][512] receives one
-// row of column sum | sum^2 of h3 per workgroup (rows >= *nrows_out are not written): fold with vpf_sum_rows_f32 (deterministic).  w1e/b1e: first conv with BatchNorm-1 folded in (fp32); w2 [128,64], w3 [256,256] bf16.
-extern "C" int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, const float* b1e, const void* w2_bf16, const float* b2,
-                             const void* w3_bf16, const float* b3, void* a1, void* h2, void* gmax, uint8_t* arg2, void* h3,
+// x [NG*32, C] -> a1 [M,64], h2 [M,128], gmax [NG,128], arg2 [NG,128], h3 [M,256] (all h16 / u8); partials [256][512] receives one
+// row of column sum | sum^2 of h3 per workgroup (rows >= *nrows_out are not written): fold with vpf_sum_rows_f32 (deterministic).  w1e/b1e: first conv with BatchNorm-1 folded in (fp32); w2 [128,64], w3 [256,256] h16.
+extern "C" int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, const float* b1e, const void* w2_h16, const float* b2,
+                             const void* w3_h16, const float* b3, void* a1, void* h2, void* gmax, uint8_t* arg2, void* h3,
                              float* partials_256x512, int* nrows_out, void* stream)
 {
     (void)hipGetLastError();
-    if (!x || !w1e || !b1e || !w2_bf16 || !b2 || !w3_bf16 || !b3 || !a1 || !h2 || !gmax || !arg2 || !h3 || !partials_256x512 || !nrows_out) return VPF_ERR_NULL;
+    if (!x || !w1e || !b1e || !w2_h16 || !b2 || !w3_h16 || !b3 || !a1 || !h2 || !gmax || !arg2 || !h3 || !partials_256x512 || !nrows_out) return VPF_ERR_NULL;
     if (NG <= 0 || C < 3 || C > 3) return VPF_ERR_BADSHAPE;       // xyz groups only (the pre-training path)
-    if (((uintptr_t)w2_bf16 & 15) || ((uintptr_t)w3_bf16 & 15) || ((uintptr_t)a1 & 15) || ((uintptr_t)h2 & 15) || ((uintptr_t)h3 & 15)) return VPF_ERR_BADALIGN;
-    G2eA p = {x, NG, C, w1e, b1e, (const bf16_t*)w2_bf16, b2, (const bf16_t*)w3_bf16, b3, (bf16_t*)a1, (bf16_t*)h2, (bf16_t*)gmax, arg2,
-              (bf16_t*)h3, partials_256x512};
+    if (((uintptr_t)w2_h16 & 15) || ((uintptr_t)w3_h16 & 15) || ((uintptr_t)a1 & 15) || ((uintptr_t)h2 & 15) || ((uintptr_t)h3 & 15)) return VPF_ERR_BADALIGN;
+    G2eA p = {x, NG, C, w1e, b1e, (const h16_t*)w2_h16, b2, (const h16_t*)w3_h16, b3, (h16_t*)a1, (h16_t*)h2, (h16_t*)gmax, arg2,
+              (h16_t*)h3, partials_256x512};
     long grid = (NG + 1) / 2; if (grid > g2e_max_grid()) grid = g2e_max_grid();
     *nrows_out = (int)grid;
     hipLaunchKernelGGL(g2e_fwd_a_kernel, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
@@ -302,15 +301,15 @@ extern "C" int vpf_g2e_fwd_a(const float* x, long NG, int C, const float* w1e, c
     return VPF_OK;
 }
 
-// h3 [NG*32,256] bf16, ab2 = BN2 affine (a | b) -> out f32 [NG,Dm] = max over the 32 members of conv4(relu(bn(h3))), arg4 u8
-extern "C" int vpf_g2e_fwd_b(const void* h3_bf16, long NG, const float* ab2, const void* w4_bf16, const float* b4, int Dm, float* out,
+// h3 [NG*32,256] h16, ab2 = BN2 affine (a | b) -> out f32 [NG,Dm] = max over the 32 members of conv4(relu(bn(h3))), arg4 u8
+extern "C" int vpf_g2e_fwd_b(const void* h3_h16, long NG, const float* ab2, const void* w4_h16, const float* b4, int Dm, float* out,
                              uint8_t* arg4, void* stream)
 {
     (void)hipGetLastError();
-    if (!h3_bf16 || !ab2 || !w4_bf16 || !b4 || !out || !arg4) return VPF_ERR_NULL;
+    if (!h3_h16 || !ab2 || !w4_h16 || !b4 || !out || !arg4) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0 || Dm > 512 || (Dm % 32)) return VPF_ERR_BADSHAPE;
-    if (((uintptr_t)h3_bf16 & 15) || ((uintptr_t)w4_bf16 & 15)) return VPF_ERR_BADALIGN;
-    G2eB p = {(const bf16_t*)h3_bf16, NG, ab2, (const bf16_t*)w4_bf16, b4, Dm, out, arg4};
+    if (((uintptr_t)h3_h16 & 15) || ((uintptr_t)w4_h16 & 15)) return VPF_ERR_BADALIGN;
+    G2eB p = {(const h16_t*)h3_h16, NG, ab2, (const h16_t*)w4_h16, b4, Dm, out, arg4};
     long grid = (NG + 1) / 2; if (grid > g2e_max_grid()) grid = g2e_max_grid();
     if (Dm <= 256) hipLaunchKernelGGL(g2e_fwd_b_kernel<1>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(g2e_fwd_b_kernel<2>, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, p);
@@ -324,13 +323,13 @@ extern "C" int vpf_g2e_fwd_b(const void* h3_bf16, long NG, const float* ab2, con
 // over all 32*NG rows does 32x the necessary work; here each thread owns 128 entries of one row of dW4 in registers
 // and walks the groups, fetching the winning row of a3 = relu(bn(h3)) from an LDS tile.
 struct G2eW4 {
-    const bf16_t* h3; long NG; const float* ab2;
+    const h16_t* h3; long NG; const float* ab2;
     const float* dout; const uint8_t* arg4; int Dm;
     float* dW4; float* db4;                     // [Dm,256], [Dm]
 };
 __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
 {
-    __shared__ __attribute__((aligned(16))) bf16_t sA3[2][32 * H3LD];
+    __shared__ __attribute__((aligned(16))) h16_t sA3[2][32 * H3LD];
     __shared__ float sD[2][256];
     __shared__ uint8_t sR[2][256];
     const int t = threadIdx.x, nl = t & 255, kh = t >> 8;
@@ -368,8 +367,8 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
             uint32_t u[4] = {hv[i].x, hv[i].y, hv[i].z, hv[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                u[j] = pack_bf16x2(fmaxf(fmaf(aa[2 * j], __uint_as_float(u[j] << 16), bb[2 * j]), 0.f),
-                                   fmaxf(fmaf(aa[2 * j + 1], __uint_as_float(u[j] & 0xffff0000u), bb[2 * j + 1]), 0.f));
+                u[j] = pack_h16x2(fmaxf(fmaf(aa[2 * j], h16_lo(u[j]), bb[2 * j]), 0.f),
+                                   fmaxf(fmaf(aa[2 * j + 1], h16_hi(u[j]), bb[2 * j + 1]), 0.f));
             *reinterpret_cast<uint4*>(&sA3[buf][row * H3LD + ch * 8]) = make_uint4(u[0], u[1], u[2], u[3]);
         }
         if (t < 256) { sD[buf][t] = dn; sR[buf][t] = rn; }
@@ -382,7 +381,7 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
         const long gn = g + gridDim.x;
         if (gn < p.NG) request(gn);
         const float d = sD[buf][nl];
-        const bf16_t* row = &sA3[buf][(int)sR[buf][nl] * H3LD + kh * 128];
+        const h16_t* row = &sA3[buf][(int)sR[buf][nl] * H3LD + kh * 128];
         if (kh == 0) accb += d;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -390,8 +389,8 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
             const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[q * 8 + 2 * j] = fmaf(d, __uint_as_float(u[j] << 16), acc[q * 8 + 2 * j]);
-                acc[q * 8 + 2 * j + 1] = fmaf(d, __uint_as_float(u[j] & 0xffff0000u), acc[q * 8 + 2 * j + 1]);
+                acc[q * 8 + 2 * j] = fmaf(d, h16_lo(u[j]), acc[q * 8 + 2 * j]);
+                acc[q * 8 + 2 * j + 1] = fmaf(d, h16_hi(u[j]), acc[q * 8 + 2 * j + 1]);
             }
         }
         if (gn < p.NG) commit(buf ^ 1);
@@ -401,7 +400,7 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
     // flush: a wave-wide atomic must cover contiguous bytes (64 lanes in 64 different rows run ~17x slower), so the
     // per-thread rows are transposed through LDS 64 rows of dW4 at a time and added as 256-byte row segments
     float* tile = reinterpret_cast<float*>(&sA3[0][0]);            // 32 x 256 fp32 = 32 KB <= 2 x 32 x H3LD x 2 B
-    static_assert(sizeof(bf16_t) * 2 * 32 * H3LD >= 32 * 256 * 4, "flush tile must fit in the staging buffers");
+    static_assert(sizeof(h16_t) * 2 * 32 * H3LD >= 32 * 256 * 4, "flush tile must fit in the staging buffers");
     if (kh == 0 && n < p.Dm) atomicAdd(p.db4 + n, accb);
     for (int rr = 0; rr < 8; ++rr) {
         __syncthreads();
@@ -424,7 +423,7 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kernel(G2eW4 p)
 #define W4_KLD 72
 __global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
 {
-    __shared__ __attribute__((aligned(16))) bf16_t sA3[2][W4_G * 32 * W4_KLD];
+    __shared__ __attribute__((aligned(16))) h16_t sA3[2][W4_G * 32 * W4_KLD];
     __shared__ float sD[2][W4_G][256];
     __shared__ uint8_t sR[2][W4_G][256];
     const int t = threadIdx.x, nl = t & 255, kh = t >> 8;
@@ -459,8 +458,8 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
             uint32_t u[4] = {hv[i].x, hv[i].y, hv[i].z, hv[i].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                u[q] = pack_bf16x2(fmaxf(fmaf(aa[2 * q], __uint_as_float(u[q] << 16), bb[2 * q]), 0.f),
-                                   fmaxf(fmaf(aa[2 * q + 1], __uint_as_float(u[q] & 0xffff0000u), bb[2 * q + 1]), 0.f));
+                u[q] = pack_h16x2(fmaxf(fmaf(aa[2 * q], h16_lo(u[q]), bb[2 * q]), 0.f),
+                                   fmaxf(fmaf(aa[2 * q + 1], h16_hi(u[q]), bb[2 * q + 1]), 0.f));
             *reinterpret_cast<uint4*>(&sA3[buf][(j * 32 + row) * W4_KLD + ch * 8]) = make_uint4(u[0], u[1], u[2], u[3]);
             sD[buf][j][c & 255] = dn[i]; sR[buf][j][c & 255] = rn[i];
         }
@@ -476,7 +475,7 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
 #pragma unroll
         for (int j = 0; j < W4_G; ++j) {
             const float d = sD[buf][j][nl];
-            const bf16_t* row = &sA3[buf][(j * 32 + (int)sR[buf][j][nl]) * W4_KLD + kh * 32];
+            const h16_t* row = &sA3[buf][(j * 32 + (int)sR[buf][j][nl]) * W4_KLD + kh * 32];
             if (kh == 0) accb += d;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -484,8 +483,8 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
                 const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[q * 8 + 2 * e] = fmaf(d, __uint_as_float(u[e] << 16), acc[q * 8 + 2 * e]);
-                    acc[q * 8 + 2 * e + 1] = fmaf(d, __uint_as_float(u[e] & 0xffff0000u), acc[q * 8 + 2 * e + 1]);
+                    acc[q * 8 + 2 * e] = fmaf(d, h16_lo(u[e]), acc[q * 8 + 2 * e]);
+                    acc[q * 8 + 2 * e + 1] = fmaf(d, h16_hi(u[e]), acc[q * 8 + 2 * e + 1]);
                 }
             }
         }
@@ -495,7 +494,7 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
     }
     // flush: [256 n] x [64 k] through LDS in two halves of 128 rows, added as 256-byte row segments (64 lanes = 64 consecutive k)
     float* tile = reinterpret_cast<float*>(&sA3[0][0]);            // 128 x 64 f32 = 32 KB <= 2 x 128 x 72 x 2 B
-    static_assert(sizeof(bf16_t) * 2 * W4_G * 32 * W4_KLD >= 128 * 64 * 4, "flush tile must fit in the staging buffers");
+    static_assert(sizeof(h16_t) * 2 * W4_G * 32 * W4_KLD >= 128 * 64 * 4, "flush tile must fit in the staging buffers");
     if (kq == 0 && kh == 0 && n < p.Dm) atomicAdd(p.db4 + n, accb);
     for (int half = 0; half < 2; ++half) {
         __syncthreads();
@@ -510,13 +509,13 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
         }
     }
 }
-extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, const float* dout, const uint8_t* arg4, int Dm,
+extern "C" int vpf_g2e_wgrad4(const void* h3_h16, long NG, const float* ab2, const float* dout, const uint8_t* arg4, int Dm,
                               float* dW4, float* db4, void* stream)
 {
     (void)hipGetLastError();
-    if (!h3_bf16 || !ab2 || !dout || !arg4 || !dW4 || !db4) return VPF_ERR_NULL;
+    if (!h3_h16 || !ab2 || !dout || !arg4 || !dW4 || !db4) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0) return VPF_ERR_BADSHAPE;
-    G2eW4 p = {(const bf16_t*)h3_bf16, NG, ab2, dout, arg4, Dm, dW4, db4};
+    G2eW4 p = {(const h16_t*)h3_h16, NG, ab2, dout, arg4, Dm, dW4, db4};
     if (vpf_debug().g2e_w4_grid >= 0) {       // (VPF_G2E_W4_GRID < 0: the round-1 kernel below with -grid workgroups)
         const int walkers = vpf_debug().g2e_w4_grid > 0 ? vpf_debug().g2e_w4_grid : 64;
         long gx = vpf_cdiv(NG, (long)W4_G) < walkers ? vpf_cdiv(NG, (long)W4_G) : walkers;
@@ -531,21 +530,21 @@ extern "C" int vpf_g2e_wgrad4(const void* h3_bf16, long NG, const float* ab2, co
     return VPF_OK;
 }
 
-// dst[c][r] = src[r][c]  (bf16; k-strided weight operands of the persistent backward kernels are read from a transposed shadow)
-__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, long lds_, int R, int C, bf16_t* __restrict__ dst)
+// dst[c][r] = src[r][c]  (h16; k-strided weight operands of the persistent backward kernels are read from a transposed shadow)
+__global__ void transpose_h16_kernel(const h16_t* __restrict__ src, long lds_, int R, int C, h16_t* __restrict__ dst)
 {
-    __shared__ bf16_t tile[32][33];
+    __shared__ h16_t tile[32][33];
     const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-    for (int i = threadIdx.y; i < 32; i += blockDim.y) { const int r = r0 + i, c = c0 + threadIdx.x; tile[i][threadIdx.x] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : (bf16_t)0; }
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) { const int r = r0 + i, c = c0 + threadIdx.x; tile[i][threadIdx.x] = (r < R && c < C) ? src[(size_t)r * lds_ + c] : (h16_t)0; }
     __syncthreads();
     for (int i = threadIdx.y; i < 32; i += blockDim.y) { const int c = c0 + i, r = r0 + threadIdx.x; if (c < C && r < R) dst[(size_t)c * R + r] = tile[threadIdx.x][i]; }
 }
-extern "C" int vpf_transpose_bf16(const void* src, long ld, int R, int C, void* dst, void* stream)
+extern "C" int vpf_transpose_h16(const void* src, long ld, int R, int C, void* dst, void* stream)
 {
     (void)hipGetLastError();
     if (!src || !dst) return VPF_ERR_NULL;
     if (R <= 0 || C <= 0) return VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(vpf_cdiv(C, 32), vpf_cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, (const bf16_t*)src, ld, R, C, (bf16_t*)dst);
+    hipLaunchKernelGGL(transpose_h16_kernel, dim3(vpf_cdiv(C, 32), vpf_cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, (const h16_t*)src, ld, R, C, (h16_t*)dst);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -555,27 +554,27 @@ extern "C" int vpf_transpose_bf16(const void* src, long ld, int R, int C, void* 
 // (dout, arg4), da3 = dh4 . W4 runs on MFMA with W4^T fragments held in registers, and BatchNorm-2's backward is
 // applied in the accumulator layout (column = lane, so the per-channel statistics are per-lane scalars):
 //   PASS 0: tmp[c] += sum g, tmp[256+c] += sum g*xhat          (g = da3 * relu'(bn(h3)))
-//   PASS 1: dh3 = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M) -> HBM (bf16), dgb[g,:] = sum over the 32 members of dh3,
-//           dh2 = dh3 . W3[:,128:]  (W3b^T fragments in registers) -> HBM (bf16), without the max-pool term of the
+//   PASS 1: dh3 = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M) -> HBM (h16), dgb[g,:] = sum over the 32 members of dh3,
+//           dh2 = dh3 . W3[:,128:]  (W3b^T fragments in registers) -> HBM (h16), without the max-pool term of the
 //           global feature (added afterwards by vpf_group_max_scatter_add)
 struct G2eBwd {
     const float* dout; const uint8_t* arg4; int Dm; long NG;
-    const bf16_t* h3; const float* stat2; const float* gamma2; const float* beta2;
-    const bf16_t* w4t;            // [256][Dm]  (W4 transposed)
-    const bf16_t* w3bt;           // [128][256] (W3[:,128:] transposed)
+    const h16_t* h3; const float* stat2; const float* gamma2; const float* beta2;
+    const h16_t* w4t;            // [256][Dm]  (W4 transposed)
+    const h16_t* w3bt;           // [128][256] (W3[:,128:] transposed)
     float* tmp;                   // [512]
     float invM; int training;
-    bf16_t* dh3; float* dgb; bf16_t* dh2;
+    h16_t* dh3; float* dgb; h16_t* dh2;
     long long* dbg;               // diagnostic: per-phase cycle sums of wave 0 of every workgroup (nullable)
 };
 
 template <int PASS>
 __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
 {
-    extern __shared__ __attribute__((aligned(16))) bf16_t smem[];
-    bf16_t* sD4 = smem;                         // [64][H3LD]  dh4 tile (Dm <= 256), later dh2 staging
-    bf16_t* sH3 = smem + 64 * H3LD;             // [64][H3LD]  h3, overwritten by dh3
-    bf16_t* sW3 = sH3 + 64 * H3LD;              // PASS 1: W3b^T in MFMA fragment order, [4 column tiles][16 k-steps][64 lanes] x 16 B = 64 KB
+    extern __shared__ __attribute__((aligned(16))) h16_t smem[];
+    h16_t* sD4 = smem;                         // [64][H3LD]  dh4 tile (Dm <= 256), later dh2 staging
+    h16_t* sH3 = smem + 64 * H3LD;             // [64][H3LD]  h3, overwritten by dh3
+    h16_t* sW3 = sH3 + 64 * H3LD;              // PASS 1: W3b^T in MFMA fragment order, [4 column tiles][16 k-steps][64 lanes] x 16 B = 64 KB
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hl = lane >> 5, l31 = lane & 31;
     if (PASS == 1) {
         // (64 more live registers would spill, and fetched from L2 inside the loop every pair paid that latency in front of
@@ -589,10 +588,10 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
         // (visible to every wave after the first barrier of the loop)
     }
     const int KS4 = p.Dm / 16;                  // k-steps of the dh4 . W4 product (<= 16)
-    bf16x8_t w4f[16];
+    h16x8_t w4f[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-        w4f[ks] = ks < KS4 ? ldfrag(p.w4t + (size_t)(w * 32 + l31) * p.Dm + ks * 16 + 8 * hl) : __builtin_bit_cast(bf16x8_t, make_uint4(0, 0, 0, 0));
+        w4f[ks] = ks < KS4 ? ldfrag(p.w4t + (size_t)(w * 32 + l31) * p.Dm + ks * 16 + 8 * hl) : __builtin_bit_cast(h16x8_t, make_uint4(0, 0, 0, 0));
     const int col = w * 32 + l31;
     const float mean = p.stat2[col], rstd = p.stat2[256 + col], ga = p.gamma2[col], be = p.beta2[col];
     float sg = 0.f, sgx = 0.f;
@@ -644,10 +643,10 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                 // and used at once they cost one HBM latency per pair)
                 uint32_t aw[2] = {nar.x, nar.y};
                 float dd[8] = {nd0.x, nd0.y, nd0.z, nd0.w, nd1.x, nd1.y, nd1.z, nd1.w};
-                // the 8 gradients as bf16 pairs once; every member row then keeps a pair element iff it won the max
+                // the 8 gradients as h16 pairs once; every member row then keeps a pair element iff it won the max
                 uint32_t dp[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) dp[j] = pack_bf16x2(dd[2 * j], dd[2 * j + 1]);
+                for (int j = 0; j < 4; ++j) dp[j] = pack_h16x2(dd[2 * j], dd[2 * j + 1]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint32_t k = (uint32_t)(sl * 4 + i);
@@ -678,7 +677,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             if (ks < KS4) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sD4 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[ks], acc[rt], 0, 0, 0);
+                    acc[rt] = vpf_mfma32(ldfrag(sD4 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[ks], acc[rt]);
             }
         STAMP(1);
         load_d4(pr + gridDim.x);
@@ -688,15 +687,15 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
         // math, then the stores (both row tiles at once held 64 registers here and the kernel spilled)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            bf16_t hraw[16];
+            h16_t hraw[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) hraw[r] = sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col];
-            bf16_t dres[16];
+            h16_t dres[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                const float xh = (bf16_to_f32(hraw[r]) - mean) * rstd;
-                float g = bf16_to_f32(f32_to_bf16(acc[rt][r]));            // da3 is a bf16 tensor in the unfused path
+                const float xh = (h16_to_f32(hraw[r]) - mean) * rstd;
+                float g = h16_to_f32(f32_to_h16(acc[rt][r]));            // da3 is a h16 tensor in the unfused path
                 // (one select on a 32-bit predicate: written as `a || b` with the 64-bit row count this was a branch, two exec-mask
                 // sequences, a 64-bit compare and a scratch reload of the count PER ELEMENT -- 862 of the kernel's 1 511 VALU instructions
                 // were moves)
@@ -705,9 +704,9 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                 if (PASS == 0) { a0 += g; a1 += g * xh; }
                 else {
                     const float dv = p.training ? ga * rstd * (g - sg - xh * sgx) : ga * rstd * g;
-                    const bf16_t db = (row < nrows_i) ? f32_to_bf16(dv) : (bf16_t)0;
+                    const h16_t db = (row < nrows_i) ? f32_to_h16(dv) : (h16_t)0;
                     dres[r] = db;
-                    gsum[rt] += bf16_to_f32(db);
+                    gsum[rt] += h16_to_f32(db);
                 }
             }
             if (PASS == 1) {
@@ -736,12 +735,12 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             // W3b^T fragments from the LDS copy (conflict-free 16-byte reads, lane-contiguous)
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks)
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ldfrag(sH3 + (rt2 * 32 + l31) * H3LD + ks * 16 + 8 * hl),
-                                                             ldfrag(sW3 + ((size_t)(ct2 * 16 + ks) * 64 + lane) * 8), a2, 0, 0, 0);
+                a2 = vpf_mfma32(ldfrag(sH3 + (rt2 * 32 + l31) * H3LD + ks * 16 + 8 * hl),
+                                ldfrag(sW3 + ((size_t)(ct2 * 16 + ks) * 64 + lane) * 8), a2);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rt2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                sD4[row * H2LD + ct2 * 32 + l31] = f32_to_bf16(a2[r]);
+                sD4[row * H2LD + ct2 * 32 + l31] = f32_to_h16(a2[r]);
             }
             __syncthreads();
             STAMP(4);
@@ -768,18 +767,18 @@ __global__ void g2e_bn2_param_grad_kernel(const float* __restrict__ tmp, float* 
     const int c = threadIdx.x;
     if (c < 256) { atomicAdd(dgamma + c, tmp[256 + c]); atomicAdd(dbeta + c, tmp[c]); }
 }
-extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_bf16, const float* stat2,
-                           const float* gamma2, const float* beta2, const void* w4t_bf16, const void* w3bt_bf16, int training,
-                           float* tmp512_zeroed, void* dh3_bf16, float* dgb, void* dh2_bf16, float* dgamma2, float* dbeta2, long long* dbg,
+extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_h16, const float* stat2,
+                           const float* gamma2, const float* beta2, const void* w4t_h16, const void* w3bt_h16, int training,
+                           float* tmp512_zeroed, void* dh3_h16, float* dgb, void* dh2_h16, float* dgamma2, float* dbeta2, long long* dbg,
                            void* stream)
 {
     (void)hipGetLastError();
-    if (!dout || !arg4 || !h3_bf16 || !stat2 || !gamma2 || !beta2 || !w4t_bf16 || !w3bt_bf16 || !tmp512_zeroed || !dh3_bf16 || !dgb || !dh2_bf16 ||
+    if (!dout || !arg4 || !h3_h16 || !stat2 || !gamma2 || !beta2 || !w4t_h16 || !w3bt_h16 || !tmp512_zeroed || !dh3_h16 || !dgb || !dh2_h16 ||
         !dgamma2 || !dbeta2) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0 || Dm > 256 || (Dm % 16)) return VPF_ERR_BADSHAPE;
-    G2eBwd p = {dout, arg4, Dm, NG, (const bf16_t*)h3_bf16, stat2, gamma2, beta2, (const bf16_t*)w4t_bf16, (const bf16_t*)w3bt_bf16, tmp512_zeroed,
-                1.0f / (float)(NG * 32), training, (bf16_t*)dh3_bf16, dgb, (bf16_t*)dh2_bf16, dbg};
-    const size_t lds = sizeof(bf16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
+    G2eBwd p = {dout, arg4, Dm, NG, (const h16_t*)h3_h16, stat2, gamma2, beta2, (const h16_t*)w4t_h16, (const h16_t*)w3bt_h16, tmp512_zeroed,
+                1.0f / (float)(NG * 32), training, (h16_t*)dh3_h16, dgb, (h16_t*)dh2_h16, dbg};
+    const size_t lds = sizeof(h16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;

@@ -1,4 +1,4 @@
-// gemm.hip -- bf16 MFMA GEMM family for gfx950:  C[m,n] (+)= sum_k A(m,k) * B(n,k)
+// gemm.hip -- h16 MFMA GEMM family for gfx950:  C[m,n] (+)= sum_k A(m,k) * B(n,k)
 //
 // Replaces the aten linear / conv1d(k=1) / mm / bmm calls of the reference's encoder, MLP,
 // projections and Group2Emb (vipformer/model/pointcloud/partseg.py:48-51,67-86,191-198;
@@ -6,12 +6,12 @@
 //
 // One kernel template covers forward (A=[M,K], B=W[N,K]), dgrad (B = W read "k-strided") and
 // wgrad (both operands k-strided, split-K with fp32 atomics into the gradient buffer):
-//   * operands are bf16 in HBM; an operand is either K-MAJOR (contraction index contiguous)
+//   * operands are h16 in HBM; an operand is either K-MAJOR (contraction index contiguous)
 //     or K-STRIDED (stored [K][rows]).  Tiles are staged in LDS in their natural HBM
 //     orientation with 16-byte coalesced loads; K-major fragments are read with ds_read_b128,
 //     K-strided fragments with the gfx950 transposing read ds_read_b64_tr_b16, so no operand
 //     is ever transposed in memory.
-//   * 64-lane wavefronts, v_mfma_f32_32x32x16_bf16, fp32 accumulate; 256 threads = 4 waves per
+//   * 64-lane wavefronts, v_mfma_f32_32x32x16_f16, fp32 accumulate; 256 threads = 4 waves per
 //     workgroup, wave tile = TM x TN MFMA tiles; LDS double-buffered with register prefetch
 //     (global loads of tile t+1 are in flight while tile t is on the matrix cores).
 //   * fused epilogues: bias, GELU (+ pre-activation for backward), dropout + residual add,
@@ -19,12 +19,11 @@
 #include "vpf_common.h"
 #include <stdlib.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-#define LDS_PAD 8   // bf16 elements (16 B) of row padding of a K-major tile: 16-byte fragment reads of 32 rows then touch every bank once
+#define LDS_PAD 8   // h16 elements (16 B) of row padding of a K-major tile: 16-byte fragment reads of 32 rows then touch every bank once
 // K-strided tiles ([BK][ROWS], read with ds_read_b64_tr_b16) carry NO padding: the transposing read addresses 4 consecutive k rows x
 // (2 x 16 rows) per 32-lane half, and a row pitch of ROWS * 2 bytes = a multiple of 256 B puts those 4 k rows on the same banks; a
 // pitch of ROWS + 8 elements (rounds 1 - 2) spread them by 4 banks where each needs 16: every transposing read took 8 LDS cycles
@@ -33,14 +32,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // 16-byte staging stores stay contiguous, the four k rows of a read land on four different 64-byte bank groups, nothing is padded.
 
 enum {
-    EPI_STORE = 0,       // C = acc (+bias)            -> bf16 or f32
-    EPI_GELU = 1,        // u = acc + bias; C2 = u (bf16, pre-activation), C = gelu(u) (bf16)
+    EPI_STORE = 0,       // C = acc (+bias)            -> h16 or f32
+    EPI_GELU = 1,        // u = acc + bias; C2 = u (h16, pre-activation), C = gelu(u) (h16)
     EPI_DROP_RES = 2,    // C(f32) = res(f32) + dropout(acc + bias)
-    EPI_GELU_BWD = 3,    // C(bf16) = acc * gelu'(aux_u(bf16))
+    EPI_GELU_BWD = 3,    // C(h16) = acc * gelu'(aux_u(h16))
     EPI_ATOMIC = 4,      // C(f32) += acc   (split-K)
     EPI_RELU = 5,        // C = relu(acc + bias)
-    EPI_GROUPBIAS = 6,   // C = acc + gbias[(m / group) * N + n]   (f32 row-group bias), bf16/f32 out
-    EPI_GROUPMAX = 7,    // C(f32)[m / group, n] = max over the group's rows of bf16(acc + bias); C2(u8) = first arg-max
+    EPI_GROUPBIAS = 6,   // C = acc + gbias[(m / group) * N + n]   (f32 row-group bias), h16/f32 out
+    EPI_GROUPMAX = 7,    // C(f32)[m / group, n] = max over the group's rows of h16(acc + bias); C2(u8) = first arg-max
     EPI_PARTIAL = 8,     // split-K without atomics: partial tiles to a workspace, the last-arriving slice of a tile adds them up (grouped wgrad)
 };
 
@@ -56,17 +55,17 @@ struct OpXform {
 };
 
 struct GemmArgs {
-    const bf16_t* A; const bf16_t* B;
+    const h16_t* A; const h16_t* B;
     long lda, ldb;              // leading dimension (elements) of the stored matrices
     long sAb, sBb, sCb;         // batch strides (elements); 0 = shared
     int M, N, K;
     int splitk;                 // >1: blockIdx.z = k-slice (EPI_ATOMIC), else blockIdx.z = batch
     int mode;
     void* C; long ldc; int c_f32;
-    void* C2; long ldc2;        // EPI_GELU: pre-activation (bf16)
+    void* C2; long ldc2;        // EPI_GELU: pre-activation (h16)
     const float* bias;          // [N] or null
     const float* res; long ldres;      // EPI_DROP_RES
-    const bf16_t* aux; long ldaux;     // EPI_GELU_BWD: u
+    const h16_t* aux; long ldaux;     // EPI_GELU_BWD: u
     const float* gbias; int group;     // EPI_GROUPBIAS
     const uint32_t* rng; uint32_t site; float p;   // dropout
     float* dbias;                                   // EPI_ATOMIC with a k-strided A: dbias[m] += sum_k A(m,k)
@@ -111,9 +110,9 @@ __device__ __forceinline__ uint4 xform_chunk(const OpXform& xf, uint4 v, int tok
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float lo = fmaxf(fmaf(aa[2 * j], __uint_as_float(w[j] << 16), bb[2 * j]), 0.f);
-            const float hi = fmaxf(fmaf(aa[2 * j + 1], __uint_as_float(w[j] & 0xffff0000u), bb[2 * j + 1]), 0.f);
-            w[j] = pack_bf16x2(lo, hi);
+            const float lo = fmaxf(fmaf(aa[2 * j], h16_lo(w[j]), bb[2 * j]), 0.f);
+            const float hi = fmaxf(fmaf(aa[2 * j + 1], h16_hi(w[j]), bb[2 * j + 1]), 0.f);
+            w[j] = pack_h16x2(lo, hi);
         }
         return make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -129,13 +128,13 @@ __device__ __forceinline__ uint4 xform_chunk(const OpXform& xf, uint4 v, int tok
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e0 = (aw[(2 * j) >> 2] >> (8 * ((2 * j) & 3))) & 0xff, e1 = (aw[(2 * j + 1) >> 2] >> (8 * ((2 * j + 1) & 3))) & 0xff;
-        w[j] = pack_bf16x2(e0 == k ? dd[2 * j] : 0.f, e1 == k ? dd[2 * j + 1] : 0.f);
+        w[j] = pack_h16x2(e0 == k ? dd[2 * j] : 0.f, e1 == k ? dd[2 * j + 1] : 0.f);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 template <int ROWS, bool TR, int BK, int XK>
-__device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld, int R, int K, int r0, int k0, int kend,
+__device__ __forceinline__ void tile_load(const h16_t* __restrict__ G, long ld, int R, int K, int r0, int k0, int kend,
                                           uint4 (&regs)[TileCfg<ROWS, TR, BK>::PER_THREAD], const OpXform& xf)
 {
     using Cfg = TileCfg<ROWS, TR, BK>;
@@ -165,7 +164,7 @@ __device__ __forceinline__ void tile_load(const bf16_t* __restrict__ G, long ld,
 }
 
 template <int ROWS, bool TR, int BK>
-__device__ __forceinline__ void tile_store(bf16_t* __restrict__ S, const uint4 (&regs)[TileCfg<ROWS, TR, BK>::PER_THREAD])
+__device__ __forceinline__ void tile_store(h16_t* __restrict__ S, const uint4 (&regs)[TileCfg<ROWS, TR, BK>::PER_THREAD])
 {
     using Cfg = TileCfg<ROWS, TR, BK>;
 #pragma unroll
@@ -182,27 +181,27 @@ __device__ __forceinline__ void tile_store(bf16_t* __restrict__ S, const uint4 (
 
 // fragment for one 32x32x16 MFMA: rows [row0, row0+32), k-step s (16 wide) of the BK-deep tile
 template <int ROWS, bool TR, int BK>
-__device__ __forceinline__ bf16x8_t frag_read(const bf16_t* __restrict__ S, int row0, int s)
+__device__ __forceinline__ h16x8_t frag_read(const h16_t* __restrict__ S, int row0, int s)
 {
     using Cfg = TileCfg<ROWS, TR, BK>;
     const int lane = threadIdx.x & 63;
     if (!TR) {
         const int r = lane & 31, h = lane >> 5;
         const uint4 v = *reinterpret_cast<const uint4*>(S + (row0 + r) * Cfg::LD + s * 16 + 8 * h);
-        return __builtin_bit_cast(bf16x8_t, v);
+        return __builtin_bit_cast(h16x8_t, v);
     } else {
         // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p addresses row q,
         // columns 4p..4p+3; lane i receives column i of the 4 rows.
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
         const int h = g >> 1, roff = 16 * (g & 1);
-        const bf16_t* a0 = S + (s * 16 + 8 * h + q) * Cfg::LD + Cfg::tr_swz(q, row0 + roff + 4 * p);      // (k & 3 = q; k + 4 swizzles alike)
+        const h16_t* a0 = S + (s * 16 + 8 * h + q) * Cfg::LD + Cfg::tr_swz(q, row0 + roff + 4 * p);      // (k & 3 = q; k + 4 swizzles alike)
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0 + 4 * Cfg::LD));
         typedef __attribute__((ext_vector_type(8))) short s16x8_t;
         s16x8_t v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        return __builtin_bit_cast(bf16x8_t, v);
+        return __builtin_bit_cast(h16x8_t, v);
     }
 }
 
@@ -213,13 +212,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     using ACfg = TileCfg<BM, ATR, BK>;
     using BCfg = TileCfg<BN, BTR, BK>;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds_all[];  // 2 * (ACfg::ELEMS + BCfg::ELEMS) per 256-thread group
+    extern __shared__ __attribute__((aligned(16))) h16_t lds_all[];  // 2 * (ACfg::ELEMS + BCfg::ELEMS) per 256-thread group
     constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;
     // PAIR (EPI_ATOMIC split-K only): the workgroup is TWO 256-thread groups that accumulate K slices 2 bz_ and 2 bz_ + 1 of the SAME
     // output tile side by side (own staging buffers, common barriers); at the end they exchange half a tile through LDS and each
     // flushes ONE half with atomics: half the flushed bytes per slice at the same number of resident waves per CU.
     const int half = PAIR ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
-    bf16_t* lds = lds_all + half * 2 * STAGE;
+    h16_t* lds = lds_all + half * 2 * STAGE;
     const int bz = PAIR ? 2 * bz_ + half : bz_;
 
     const int wave = gtid() >> 6, lane = threadIdx.x & 63;
@@ -227,7 +226,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     const int m0 = by * BM, n0 = bx * BN;
 
     int kbeg = 0, kend = g.K;
-    const bf16_t* A = g.A; const bf16_t* B = g.B;
+    const h16_t* A = g.A; const h16_t* B = g.B;
     long cb = 0;
     if (g.splitk > 1) {
         const int per = ((g.K + g.splitk - 1) / g.splitk + BK - 1) / BK * BK;
@@ -275,15 +274,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     __syncthreads();
 
     // fused bias gradient (wgrad): the waves that own the first column of wave tiles in the first column of workgroups also sum their
-    // dY fragments over the tokens.  A lane's fragment holds 8 tokens of ONE output row: four v_dot2c_f32_bf16 against (1, 1) add them
+    // dY fragments over the tokens.  A lane's fragment holds 8 tokens of ONE output row: four v_dot2c_f32_f16 against (1, 1) add them
     // to a per-lane partial; lanes r and r + 32 (the two token halves of row r) meet in the epilogue.  The scalar LDS column sums this
     // replaces (32 two-byte LDS reads per thread and stage) cost 11 us of the 59 us grouped launch.
     const bool do_bias = ATR && g.dbias != nullptr && bx == 0 && wn == 0;
     float bsum[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3F803F80u);              // bf16 (1.0, 1.0)
     for (int kt0 = 0; kt0 < nk_loop; kt0 += PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
@@ -291,10 +288,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             if (kt >= nk_loop) break;
             if (PAIR && kt >= nk) { __syncthreads(); continue; }     // this group's slice is done: keep the other group's barriers company
             const int cur = kt & 1;
-            const bf16_t* cA = lds + cur * STAGE;
-            const bf16_t* cB = cA + ACfg::ELEMS;
-            bf16_t* nA = lds + (cur ^ 1) * STAGE;
-            bf16_t* nB = nA + ACfg::ELEMS;
+            const h16_t* cA = lds + cur * STAGE;
+            const h16_t* cB = cA + ACfg::ELEMS;
+            h16_t* nA = lds + (cur ^ 1) * STAGE;
+            h16_t* nB = nA + ACfg::ELEMS;
             // register set p held stage kt, which is in LDS by now: refill it with stage kt + PF
             if (kt + PF < nk) {
                 tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg + (kt + PF) * BK, kend, ra[p], g.xa);
@@ -303,7 +300,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             if (!(g.dbg & 2)) {
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
-                bf16x8_t fa[TM], fb[TN];
+                h16x8_t fa[TM], fb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, (g.dbg & 4) ? 0 : s);
 #pragma unroll
@@ -312,15 +309,15 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = vpf_mfma32(fa[i], fb[j], acc[i][j]);
                 if (ATR && do_bias) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         const uint4 w = __builtin_bit_cast(uint4, fa[i]);
-                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), ones2, bsum[i], false);
-                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), ones2, bsum[i], false);
-                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), ones2, bsum[i], false);
-                        bsum[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), ones2, bsum[i], false);
+                        bsum[i] = h16_dot2(w.x, VPF_H16_ONES2, bsum[i]);
+                        bsum[i] = h16_dot2(w.y, VPF_H16_ONES2, bsum[i]);
+                        bsum[i] = h16_dot2(w.z, VPF_H16_ONES2, bsum[i]);
+                        bsum[i] = h16_dot2(w.w, VPF_H16_ONES2, bsum[i]);
                     }
                 }
             }
@@ -486,7 +483,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
                 const float vv[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float t = bf16_to_f32(f32_to_bf16(vv[q]));
+                    const float t = h16_to_f32(f32_to_h16(vv[q]));
                     if (t > best[q]) { best[q] = t; bi[q] = k; }
                 }
             }
@@ -506,10 +503,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
         const int nv = min(4, g.N - n);
         const size_t co = (size_t)cb + (size_t)m * g.ldc + n;
         if (g.mode == EPI_GELU) {
-            bf16_t ub[4];
+            h16_t ub[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { ub[q] = f32_to_bf16(v[q]); v[q] = gelu_f(bf16_to_f32(ub[q])); }
-            bf16_t* u = reinterpret_cast<bf16_t*>(g.C2) + (size_t)m * g.ldc2 + n;
+            for (int q = 0; q < 4; ++q) { ub[q] = f32_to_h16(v[q]); v[q] = gelu_f(h16_to_f32(ub[q])); }
+            h16_t* u = reinterpret_cast<h16_t*>(g.C2) + (size_t)m * g.ldc2 + n;
             if (vec) { uint2 w; w.x = ub[0] | ((uint32_t)ub[1] << 16); w.y = ub[2] | ((uint32_t)ub[3] << 16); *reinterpret_cast<uint2*>(u) = w; }
             else { for (int q = 0; q < nv; ++q) u[q] = ub[q]; }
         } else if (g.mode == EPI_DROP_RES) {
@@ -522,12 +519,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = rr[q] + (((keep >> q) & 1u) ? v[q] * rng.scale : 0.f);
         } else if (g.mode == EPI_GELU_BWD) {
-            const bf16_t* ap = g.aux + (size_t)m * g.ldaux + n;
-            bf16_t ab[4] = {0, 0, 0, 0};
+            const h16_t* ap = g.aux + (size_t)m * g.ldaux + n;
+            h16_t ab[4] = {0, 0, 0, 0};
             if (vec) { const uint2 t = *reinterpret_cast<const uint2*>(ap); ab[0] = t.x & 0xffff; ab[1] = t.x >> 16; ab[2] = t.y & 0xffff; ab[3] = t.y >> 16; }
             else { for (int q = 0; q < nv; ++q) ab[q] = ap[q]; }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] *= gelu_grad_f(bf16_to_f32(ab[q]));
+            for (int q = 0; q < 4; ++q) v[q] *= gelu_grad_f(h16_to_f32(ab[q]));
         } else if (g.mode == EPI_RELU) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -541,9 +538,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             if (vec) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
             else { for (int q = 0; q < nv; ++q) o[q] = v[q]; }
         } else {
-            bf16_t* o = reinterpret_cast<bf16_t*>(g.C) + co;
-            if (vec) { uint2 w; w.x = pack_bf16x2(v[0], v[1]); w.y = pack_bf16x2(v[2], v[3]); *reinterpret_cast<uint2*>(o) = w; }
-            else { for (int q = 0; q < nv; ++q) o[q] = f32_to_bf16(v[q]); }
+            h16_t* o = reinterpret_cast<h16_t*>(g.C) + co;
+            if (vec) { uint2 w; w.x = pack_h16x2(v[0], v[1]); w.y = pack_h16x2(v[2], v[3]); *reinterpret_cast<uint2*>(o) = w; }
+            else { for (int q = 0; q < nv; ++q) o[q] = f32_to_h16(v[q]); }
         }
     }
 }
@@ -575,7 +572,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g)
 // per problem would not fit the 4 KB argument segment); the workgroup builds the GemmArgs of its problem in registers.
 #define GEMM_GROUP_MAX 32
 struct WgDesc {
-    const bf16_t* A; const bf16_t* B; float* C; float* dbias; float* part; int* cnt;
+    const h16_t* A; const h16_t* B; float* C; float* dbias; float* part; int* cnt;
     int lda, ldb, ldc, M, N, K, splitk, ntx, mode;
 };
 #define WGROUP_XLIST_MAX 96
@@ -630,8 +627,8 @@ template <int TM, int TN, int WM, int WN, int BK, int PF = 1, bool PAIR = false>
 static int launch_wgrad_group(const GemmGroup& grp, int nblocks, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS) * (PAIR ? 2 : 1);
-    static_assert(!PAIR || sizeof(bf16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS) >= (size_t)BM * BN * 4 / 2,
+    constexpr size_t lds = sizeof(h16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS) * (PAIR ? 2 : 1);
+    static_assert(!PAIR || sizeof(h16_t) * 2 * (TileCfg<BM, true, BK>::ELEMS + TileCfg<BN, true, BK>::ELEMS) >= (size_t)BM * BN * 4 / 2,
                   "a group's staging buffers must hold half an accumulator tile");
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
@@ -648,7 +645,7 @@ template <int TM, int TN, int WM, int WN, int BK, bool ATR, bool BTR, int AX, in
 static int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st)
 {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    constexpr size_t lds = sizeof(bf16_t) * 2 * (TileCfg<BM, ATR, BK>::ELEMS + TileCfg<BN, BTR, BK>::ELEMS);
+    constexpr size_t lds = sizeof(h16_t) * 2 * (TileCfg<BM, ATR, BK>::ELEMS + TileCfg<BN, BTR, BK>::ELEMS);
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         if (lds > 65536 && hipFuncSetAttribute((const void*)gemm_kernel<TM, TN, WM, WN, BK, ATR, BTR, AX, BX>,
@@ -720,7 +717,7 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
 }
 
 // ------------------------------------------------------------------ C ABI
-extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void* B, int b_kstrided, long ldb,
+extern "C" int vpf_gemm_h16(const void* A, int a_kstrided, long lda, const void* B, int b_kstrided, long ldb,
                              int M, int N, int K, int batch, long sAb, long sBb, long sCb,
                              void* C, long ldc, int c_is_f32, int mode, const float* bias,
                              void* C2, long ldc2, const float* res, long ldres, const void* aux, long ldaux,
@@ -729,14 +726,14 @@ extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     GemmArgs g;
-    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb;
+    g.A = (const h16_t*)A; g.B = (const h16_t*)B; g.lda = lda; g.ldb = ldb;
     g.sAb = sAb; g.sBb = sBb; g.sCb = sCb; g.M = M; g.N = N; g.K = K; g.splitk = splitk; g.mode = mode;
     g.C = C; g.ldc = ldc; g.c_f32 = c_is_f32; g.C2 = C2; g.ldc2 = ldc2; g.bias = bias; g.res = res; g.ldres = ldres;
-    g.aux = (const bf16_t*)aux; g.ldaux = ldaux; g.gbias = gbias; g.group = group > 0 ? group : 1;
+    g.aux = (const h16_t*)aux; g.ldaux = ldaux; g.gbias = gbias; g.group = group > 0 ? group : 1;
     g.rng = rng_state; g.site = site; g.p = p; g.dbias = dbias;
     g.xa.kind = 0; g.xb.kind = 0; g.uneven = 0; g.dbg = 0;
     if (dbias && !(mode == EPI_ATOMIC && a_kstrided)) return VPF_ERR_UNSUPPORTED;
-    if (mode < 0 || mode > EPI_GROUPBIAS) return VPF_ERR_UNSUPPORTED;   // EPI_GROUPMAX: vpf_gemm_bf16_fused
+    if (mode < 0 || mode > EPI_GROUPBIAS) return VPF_ERR_UNSUPPORTED;   // EPI_GROUPMAX: vpf_gemm_h16_fused
     if (mode == EPI_GELU && !C2) return VPF_ERR_NULL;
     if (mode == EPI_DROP_RES && (!res || !rng_state || !c_is_f32)) return VPF_ERR_NULL;
     if (mode == EPI_GELU_BWD && !aux) return VPF_ERR_NULL;
@@ -748,7 +745,7 @@ extern "C" int vpf_gemm_bf16(const void* A, int a_kstrided, long lda, const void
 //   a_kind / b_kind: 0 none | 1 relu(a[c]*x + b[c]) on the fly (xa = a, xb = b: f32 [channels]) |
 //                    2 (A only) virtual max-pool gradient from (dout f32 [tokens/group, ncols], arg u8), A pointer ignored
 //   mode: VPF_EPI_STORE / VPF_EPI_ATOMIC (+dbias) / 7 = group max: C f32 [M/group, N] (ldc), C2 u8 arg (ldc2)
-extern "C" int vpf_gemm_bf16_fused(const void* A, int a_kstrided, long lda, int a_kind, const float* a_scale, const float* a_shift,
+extern "C" int vpf_gemm_h16_fused(const void* A, int a_kstrided, long lda, int a_kind, const float* a_scale, const float* a_shift,
                                    const float* a_dout, const uint8_t* a_arg, int a_group, long a_ncols,
                                    const void* B, int b_kstrided, long ldb, int b_kind, const float* b_scale, const float* b_shift,
                                    int M, int N, int K, void* C, long ldc, int c_is_f32, int mode, const float* bias,
@@ -756,7 +753,7 @@ extern "C" int vpf_gemm_bf16_fused(const void* A, int a_kstrided, long lda, int 
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     GemmArgs g = {};
-    g.A = (const bf16_t*)(a_kind == 2 ? (const void*)a_dout : A); g.B = (const bf16_t*)B; g.lda = lda; g.ldb = ldb;
+    g.A = (const h16_t*)(a_kind == 2 ? (const void*)a_dout : A); g.B = (const h16_t*)B; g.lda = lda; g.ldb = ldb;
     g.M = M; g.N = N; g.K = K; g.splitk = splitk; g.mode = mode; g.C = C; g.ldc = ldc; g.c_f32 = c_is_f32; g.C2 = C2; g.ldc2 = ldc2;
     g.bias = bias; g.group = group > 0 ? group : 1; g.dbias = dbias;
     g.xa.kind = a_kind; g.xa.a = a_scale; g.xa.b = a_shift; g.xa.dout = a_dout; g.xa.arg = a_arg; g.xa.group = a_group > 0 ? a_group : 1; g.xa.ncols = a_ncols;
@@ -798,7 +795,7 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         if ((j.N % 8) || (j.K % 8) || ((uintptr_t)j.dy & 15) || ((uintptr_t)j.x & 15)) return VPF_ERR_BADALIGN;
         WgDesc& g = grp.d[i];
         // C[m = n_out, n = k_in] += sum over tokens: A = dY read k-strided (rows = N), B = X read k-strided (rows = K)
-        g.A = (const bf16_t*)j.dy; g.B = (const bf16_t*)j.x; g.lda = j.N; g.ldb = j.K;
+        g.A = (const h16_t*)j.dy; g.B = (const h16_t*)j.x; g.lda = j.N; g.ldb = j.K;
         g.M = j.N; g.N = j.K; g.K = j.M; g.mode = EPI_ATOMIC; g.C = j.dW; g.ldc = j.K; g.dbias = j.dbias;
         const int nx = vpf_cdiv(g.N, tn), ny = vpf_cdiv(g.M, tm);
         // ~`target` workgroups over the whole group, every K slice at least 256 tokens deep

@@ -5,31 +5,31 @@
 // (The 3-NN search itself lives in preproc.hip next to the exact square_distance recipe it shares.)
 #include "vpf_common.h"
 
-// ------------------------------------------------------------------ zero-padded bf16 operand copy
-// dst bf16 [rows_out, Kp] = src [rows, K] (f32 or bf16, row stride ld) in the top-left corner, zeros elsewhere.
+// ------------------------------------------------------------------ zero-padded h16 operand copy
+// dst h16 [rows_out, Kp] = src [rows, K] (f32 or h16, row stride ld) in the top-left corner, zeros elsewhere.
 template <typename T>
-__global__ void pad_bf16_kernel(const T* __restrict__ src, long rows, int K, long ld, long rows_out, int Kp, bf16_t* __restrict__ dst)
+__global__ void pad_h16_kernel(const T* __restrict__ src, long rows, int K, long ld, long rows_out, int Kp, h16_t* __restrict__ dst)
 {
     const long total = rows_out * (long)Kp;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / Kp; const int c = (int)(i % Kp);
         float v = 0.f;
         if (r < rows && c < K) {
-            if constexpr (sizeof(T) == 2) v = bf16_to_f32(src[r * ld + c]); else v = src[r * ld + c];
+            if constexpr (sizeof(T) == 2) v = h16_to_f32(src[r * ld + c]); else v = src[r * ld + c];
         }
-        dst[i] = f32_to_bf16(v);
+        dst[i] = f32_to_h16(v);
     }
 }
-extern "C" int vpf_pad_bf16(const void* src, int src_is_bf16, long rows, int K, long ld, long rows_out, int Kp, void* dst_bf16, void* stream)
+extern "C" int vpf_pad_h16(const void* src, int src_is_h16, long rows, int K, long ld, long rows_out, int Kp, void* dst_h16, void* stream)
 {
     (void)hipGetLastError();
-    if (!src || !dst_bf16) return VPF_ERR_NULL;
+    if (!src || !dst_h16) return VPF_ERR_NULL;
     if (rows < 0 || K <= 0 || rows_out < rows || Kp < K || ld < K) return VPF_ERR_BADSHAPE;
     if (rows_out == 0) return VPF_OK;
     const long total = rows_out * (long)Kp;
     int grid = vpf_cdiv(total, 256); if (grid > 4096) grid = 4096;
-    if (src_is_bf16) hipLaunchKernelGGL(pad_bf16_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, rows, K, ld, rows_out, Kp, (bf16_t*)dst_bf16);
-    else hipLaunchKernelGGL(pad_bf16_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, rows, K, ld, rows_out, Kp, (bf16_t*)dst_bf16);
+    if (src_is_h16) hipLaunchKernelGGL(pad_h16_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const h16_t*)src, rows, K, ld, rows_out, Kp, (h16_t*)dst_h16);
+    else hipLaunchKernelGGL(pad_h16_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, rows, K, ld, rows_out, Kp, (h16_t*)dst_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -134,12 +134,12 @@ extern "C" int vpf_ln_taps_bwd(const float* dxcat, const float* x0, const float*
 }
 
 // ------------------------------------------------------------------ interpolation rows (utils.py:230-236)
-// A[b*N + n, :] = [ points1 = xyz[b, n, 0:C]  |  sum_k w[n, k] * feat[b, idx[n, k], 0:F]  |  zero pad to Kp ]   (bf16): the operand
+// A[b*N + n, :] = [ points1 = xyz[b, n, 0:C]  |  sum_k w[n, k] * feat[b, idx[n, k], 0:F]  |  zero pad to Kp ]   (h16): the operand
 // of mlp_convs[0] -- cat([points1, interpolated_points]) -- written once, directly in the GEMM's layout.  One wave per point; the
 // three source rows are read as whole contiguous rows (F * 4 bytes each), products and sum in the reference's order.
 __global__ void __launch_bounds__(256) interp_rows_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ xyz, int C,
                                                              const int* __restrict__ idx, const float* __restrict__ w, int N, int S,
-                                                             int F, int Kp, long rows, bf16_t* __restrict__ A)
+                                                             int F, int Kp, long rows, h16_t* __restrict__ A)
 {
     const int lane = threadIdx.x & 63;
     const long r = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
@@ -150,31 +150,31 @@ __global__ void __launch_bounds__(256) interp_rows_fwd_kernel(const float* __res
     const float* f0 = feat + (b * S + i0) * (long)F;
     const float* f1 = feat + (b * S + i1) * (long)F;
     const float* f2 = feat + (b * S + i2) * (long)F;
-    bf16_t* a = A + r * (long)Kp;
-    if (lane < C) a[lane] = f32_to_bf16(xyz[r * C + lane]);
+    h16_t* a = A + r * (long)Kp;
+    if (lane < C) a[lane] = f32_to_h16(xyz[r * C + lane]);
     for (int c = lane; c < F; c += 64) {
         float v = f0[c] * w0 + f1[c] * w1;
         v = v + f2[c] * w2;
-        a[C + c] = f32_to_bf16(v);
+        a[C + c] = f32_to_h16(v);
     }
     for (int c = C + F + lane; c < Kp; c += 64) a[c] = 0;
 }
 extern "C" int vpf_interp_rows_fwd(const float* feat, const float* xyz, int B, int N, int C, int S, int F, const int* idx,
-                                   const float* weight, int Kp, void* A_bf16, void* stream)
+                                   const float* weight, int Kp, void* A_h16, void* stream)
 {
     (void)hipGetLastError();
-    if (!feat || !xyz || !idx || !weight || !A_bf16) return VPF_ERR_NULL;
+    if (!feat || !xyz || !idx || !weight || !A_h16) return VPF_ERR_NULL;
     if (B < 0 || N < 0 || S <= 0 || F <= 0 || C < 0 || C > 64 || Kp < C + F) return VPF_ERR_BADSHAPE;
     const long rows = (long)B * N;
     if (rows == 0) return VPF_OK;
     hipLaunchKernelGGL(interp_rows_fwd_kernel, dim3(vpf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, feat, xyz, C, idx, weight, N, S, F, Kp,
-                       rows, (bf16_t*)A_bf16);
+                       rows, (h16_t*)A_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 // backward: dfeat[b, idx[n, k], :] += w[n, k] * dA[b*N + n, C : C + F]   (fp32 atomics into a zeroed buffer: a centre collects from
 // every point that has it among its three nearest, ~3N/S points on average)
-__global__ void __launch_bounds__(256) interp_rows_bwd_kernel(const bf16_t* __restrict__ dA, int C, const int* __restrict__ idx,
+__global__ void __launch_bounds__(256) interp_rows_bwd_kernel(const h16_t* __restrict__ dA, int C, const int* __restrict__ idx,
                                                              const float* __restrict__ w, int N, int S, int F, int Kp, long rows,
                                                              float* __restrict__ dfeat)
 {
@@ -182,23 +182,23 @@ __global__ void __launch_bounds__(256) interp_rows_bwd_kernel(const bf16_t* __re
     const long r = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     if (r >= rows) return;
     const long b = r / N;
-    const bf16_t* a = dA + r * (long)Kp + C;
+    const h16_t* a = dA + r * (long)Kp + C;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float wk = w[r * 3 + k];
         float* d = dfeat + (b * S + idx[r * 3 + k]) * (long)F;
-        for (int c = lane; c < F; c += 64) atomicAdd(d + c, wk * bf16_to_f32(a[c]));
+        for (int c = lane; c < F; c += 64) atomicAdd(d + c, wk * h16_to_f32(a[c]));
     }
 }
-extern "C" int vpf_interp_rows_bwd(const void* dA_bf16, int B, int N, int C, int S, int F, const int* idx, const float* weight, int Kp,
+extern "C" int vpf_interp_rows_bwd(const void* dA_h16, int B, int N, int C, int S, int F, const int* idx, const float* weight, int Kp,
                                    float* dfeat, void* stream)
 {
     (void)hipGetLastError();
-    if (!dA_bf16 || !idx || !weight || !dfeat) return VPF_ERR_NULL;
+    if (!dA_h16 || !idx || !weight || !dfeat) return VPF_ERR_NULL;
     if (B < 0 || N < 0 || S <= 0 || F <= 0 || C < 0 || Kp < C + F) return VPF_ERR_BADSHAPE;
     const long rows = (long)B * N;
     if (rows == 0) return VPF_OK;
-    hipLaunchKernelGGL(interp_rows_bwd_kernel, dim3(vpf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dA_bf16, C, idx, weight, N,
+    hipLaunchKernelGGL(interp_rows_bwd_kernel, dim3(vpf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const h16_t*)dA_h16, C, idx, weight, N,
                        S, F, Kp, rows, dfeat);
     VPF_CHECK_LAUNCH();
     return VPF_OK;

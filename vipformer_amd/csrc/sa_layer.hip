@@ -23,7 +23,6 @@
 #include "vipformer_hip.h"
 #include "sa_rows.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -32,44 +31,44 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 #define SA_HID 512
 #define SA_H 4
 #define SA_DH 64
-#define ALD 264         // LDS row stride (bf16) of a [tokens][256] activation tile (256 + 8 pad)
+#define ALD 264         // LDS row stride (h16) of a [tokens][256] activation tile (256 + 8 pad)
 #define XLD 260         // LDS row stride (f32) of the [tokens][256] residual tile (256 + 4 pad)
-#define QLD 776         // LDS row stride (bf16) of the [tokens][768] q | k | v staging tile (768 + 8 pad)
-#define KLD 72          // LDS row stride (bf16) of a [tokens][64] K / V tile
+#define QLD 776         // LDS row stride (h16) of the [tokens][768] q | k | v staging tile (768 + 8 pad)
+#define KLD 72          // LDS row stride (h16) of a [tokens][64] K / V tile
 #define LOG2E 1.4426950408889634f
 #define LN2F 0.6931471805599453f
 
-__device__ __forceinline__ s16x4_t sa_lds_tr16(const bf16_t* p)
+__device__ __forceinline__ s16x4_t sa_lds_tr16(const h16_t* p)
 {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(p));
 }
 // see attention.hip: A-operand fragment of V^T with the k slots in accumulator order
-__device__ __forceinline__ bf16x8_t sa_frag_tr_perm(const bf16_t* S, int ld, int kbase, int c0)
+__device__ __forceinline__ h16x8_t sa_frag_tr_perm(const h16_t* S, int ld, int kbase, int c0)
 {
     const int lane = threadIdx.x & 63, g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const int h = g >> 1, coff = 16 * (g & 1);
-    const bf16_t* a = S + (kbase + 4 * h + q) * ld + c0 + coff + 4 * p;
+    const h16_t* a = S + (kbase + 4 * h + q) * ld + c0 + coff + 4 * p;
     const s16x4_t lo = sa_lds_tr16(a), hi = sa_lds_tr16(a + 8 * ld);
     s16x8_t v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(h16x8_t, v);
 }
-__device__ __forceinline__ bf16x8_t sa_frag_row(const bf16_t* S, int ld, int row0, int kbase)
+__device__ __forceinline__ h16x8_t sa_frag_row(const h16_t* S, int ld, int row0, int kbase)
 {
     const int lane = threadIdx.x & 63;
     const uint4 v = *reinterpret_cast<const uint4*>(S + (row0 + (lane & 31)) * ld + kbase + 8 * (lane >> 5));
-    return __builtin_bit_cast(bf16x8_t, v);
+    return __builtin_bit_cast(h16x8_t, v);
 }
-__device__ __forceinline__ bf16x8_t sa_pack8(const float* f)
+__device__ __forceinline__ h16x8_t sa_pack8(const float* f)
 {
     uint4 u;
-    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]); u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
-    return __builtin_bit_cast(bf16x8_t, u);
+    u.x = pack_h16x2(f[0], f[1]); u.y = pack_h16x2(f[2], f[3]); u.z = pack_h16x2(f[4], f[5]); u.w = pack_h16x2(f[6], f[7]);
+    return __builtin_bit_cast(h16x8_t, u);
 }
 __device__ __forceinline__ float sa_gelu(float x) { return vpf_gelu(x); }
 
 // ------------------------------------------------------------------------------------------------ weight packing
-// natural W[N][K] (bf16, row-major)  ->  fragment order: frag(cb, ks) = 64 lanes x 8 values,
+// natural W[N][K] (h16, row-major)  ->  fragment order: frag(cb, ks) = 64 lanes x 8 values,
 //   lane l holds W[cb*32 + (l & 31)][ks*16 + 8*(l >> 5) + 0..7];   offset ((cb * (K/16) + ks) * 64 + l) * 8
 struct PackJobs { VpfPackJob job[VPF_PACK_MAX_JOBS]; int n; };
 __global__ void pack_wfrag_kernel(PackJobs jobs)
@@ -88,7 +87,7 @@ __global__ void pack_wfrag_kernel(PackJobs jobs)
             dst[e] = src[(row * j.K + col) >> 3];
         } else {
             // logical A[row][col] = src[col * N + row]  (src stored [K][N]: the transposed view of a natural weight)
-            const bf16_t* s16 = reinterpret_cast<const bf16_t*>(j.src);
+            const h16_t* s16 = reinterpret_cast<const h16_t*>(j.src);
             uint32_t w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -121,7 +120,7 @@ extern "C" int vpf_pack_wfrag(const VpfPackJob* jobs, int njobs, void* stream)
 template <int NJ>
 struct SaWPre { uint4 w[NJ][8]; };            // groups 0 and 1 (k-steps 0..7) of the wave's NJ channel blocks
 template <int NJ>
-__device__ __forceinline__ void sa_wprefetch(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb0, SaWPre<NJ>& w)
+__device__ __forceinline__ void sa_wprefetch(const h16_t* __restrict__ Wp, int ksn, int ks0, int cb0, SaWPre<NJ>& w)
 {
     const int lane = threadIdx.x & 63;
     const uint4* w0 = reinterpret_cast<const uint4*>(Wp) + ((size_t)cb0 * ksn + ks0) * 64 + lane;
@@ -135,7 +134,7 @@ __device__ __forceinline__ void sa_wprefetch(const bf16_t* __restrict__ Wp, int 
 // prefetch); the compiler barriers keep the loads from being hoisted further (register pressure next to two live
 // accumulator sets).
 template <int RB, int NJ>
-__device__ __forceinline__ void sa_gemm_unit(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb0, const bf16_t* act,
+__device__ __forceinline__ void sa_gemm_unit(const h16_t* __restrict__ Wp, int ksn, int ks0, int cb0, const h16_t* act,
                                              f32x16_t (&acc)[NJ][RB], const SaWPre<NJ>& pre)
 {
     const int lane = threadIdx.x & 63;
@@ -148,14 +147,14 @@ __device__ __forceinline__ void sa_gemm_unit(const bf16_t* __restrict__ Wp, int 
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-        bf16x8_t af[NJ];
+        h16x8_t af[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) af[j] = __builtin_bit_cast(bf16x8_t, ks < 8 ? pre.w[j][ks & 7] : wl[j][ks & 7]);
+        for (int j = 0; j < NJ; ++j) af[j] = __builtin_bit_cast(h16x8_t, ks < 8 ? pre.w[j][ks & 7] : wl[j][ks & 7]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const bf16x8_t x = sa_frag_row(act, ALD, i * 32, ks * 16);
+            const h16x8_t x = sa_frag_row(act, ALD, i * 32, ks * 16);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], x, acc[j][i], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[j][i] = vpf_mfma32(af[j], x, acc[j][i]);
         }
     }
 }
@@ -253,10 +252,10 @@ __device__ __forceinline__ void sa_layernorm(f32x16_t (&acc)[NJ][RB], const floa
         }
 }
 
-// store the accumulator tile as bf16 into an LDS activation tile [tokens][ALD] (column offset col0) and, for valid tokens,
+// store the accumulator tile as h16 into an LDS activation tile [tokens][ALD] (column offset col0) and, for valid tokens,
 // to a global [M][ld] matrix (column offset gcol0)
 template <int RB, int NJ>
-__device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[NJ][RB], bf16_t* sAct, int col0, bf16_t* __restrict__ G, long ld,
+__device__ __forceinline__ void sa_store_h16(const f32x16_t (&acc)[NJ][RB], h16_t* sAct, int col0, h16_t* __restrict__ G, long ld,
                                               int gcol0, long m0, int nvalid)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
@@ -267,8 +266,8 @@ __device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[NJ][RB], bf1
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 u;
-                u.x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
-                u.y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                u.x = pack_h16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
+                u.y = pack_h16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
                 const int c = 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
                 const int tok = i * 32 + t;
                 if (sAct) *reinterpret_cast<uint2*>(sAct + tok * ALD + col0 + c) = u;
@@ -279,7 +278,7 @@ __device__ __forceinline__ void sa_store_bf16(const f32x16_t (&acc)[NJ][RB], bf1
 // The same tile, row-coalesced: every thread moves 16 B (8 channels) of a row, a wave-instruction writes two whole 512-byte rows.
 // (The accumulator layout above makes a wave-instruction touch 32 rows with 16 bytes each: ~5x the cycles in the address unit.)
 template <int TOK, int NT>
-__device__ __forceinline__ void sa_tile_store_rows(const bf16_t* sAct, bf16_t* __restrict__ G, long ld, int gcol0, long m0, int nvalid)
+__device__ __forceinline__ void sa_tile_store_rows(const h16_t* sAct, h16_t* __restrict__ G, long ld, int gcol0, long m0, int nvalid)
 {
 #pragma unroll
     for (int it = 0; it < TOK * 32 / NT; ++it) {
@@ -292,7 +291,7 @@ __device__ __forceinline__ void sa_tile_store_rows(const bf16_t* sAct, bf16_t* _
 // ------------------------------------------------------------------------------------------------ the layer kernel
 // one (head, 32-query block) attention unit of a wave; K / V tiles of the head are in LDS, LPT = padded sequence length
 template <int LPT>
-__device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV, const bf16x8_t (&qf)[4], int L, float c, const VpfRng& rng,
+__device__ __forceinline__ void sa_attn_unit(const h16_t* sK, const h16_t* sV, const h16x8_t (&qf)[4], int L, float c, const VpfRng& rng,
                                              bool drop, uint64_t rbase, f32x16_t (&o)[2], float& m, float& l)
 {
     const int hl = (threadIdx.x & 63) >> 5;
@@ -307,7 +306,7 @@ __device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV,
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa_frag_row(sK, KLD, kv0, ks * 16), qf[ks], s, 0, 0, 0);
+            s = vpf_mfma32(sa_frag_row(sK, KLD, kv0, ks * 16), qf[ks], s);
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -337,10 +336,10 @@ __device__ __forceinline__ void sa_attn_unit(const bf16_t* sK, const bf16_t* sV,
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            const bf16x8_t pf = sa_pack8(pv + 8 * s2);
+            const h16x8_t pf = sa_pack8(pv + 8 * s2);
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa_frag_tr_perm(sV, KLD, kv0 + 16 * s2, dt * 32), pf, o[dt], 0, 0, 0);
+                o[dt] = vpf_mfma32(sa_frag_tr_perm(sV, KLD, kv0 + 16 * s2, dt * 32), pf, o[dt]);
         }
     }
 }
@@ -352,13 +351,13 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 {
     constexpr int NWV = 8 / NJ, NT = 64 * NWV;          // waves per workgroup: each owns NJ blocks of 32 channels per 256-wide chunk
     static_assert(!ATT || NJ == 2, "the in-kernel attention distributes its units over 4 waves");
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
     constexpr int TOK = RB * 32;
     constexpr int UPW = HPR * RB / 4;                 // attention units per wave and round
     static_assert(HPR * RB % 4 == 0, "units must divide over the 4 waves");
-    bf16_t* actA = lds;                               // [TOK][ALD]   o -> n2 -> next n1
-    bf16_t* reg1 = lds + TOK * ALD;                   // K/V tiles during attention, then actH + LayerNorm exchange
-    bf16_t* actH = reg1;                              // [TOK][ALD]   one 256-wide chunk of the hidden activation
+    h16_t* actA = lds;                               // [TOK][ALD]   o -> n2 -> next n1
+    h16_t* reg1 = lds + TOK * ALD;                   // K/V tiles during attention, then actH + LayerNorm exchange
+    h16_t* actH = reg1;                              // [TOK][ALD]   one 256-wide chunk of the hidden activation
     float* sStatA = reinterpret_cast<float*>(reg1 + TOK * ALD);   // [TOK][NWV]
     float* sStatB = sStatA + TOK * NWV;
     // XR (no attention inside, one channel block per wave): the f32 residual stream of the workgroup's rows lives in LDS
@@ -393,7 +392,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
         return pr % a.pos_rows;
     };
     const int nvalid = ATT ? min(a.chunk_rows, L - chunk * a.chunk_rows) : (int)min((long)TOK, (long)a.B * L - m0);
-    const bf16_t* qkv = (const bf16_t*)a.qkv;
+    const h16_t* qkv = (const h16_t*)a.qkv;
     long long t0_ = 0, t1_;
     int ph_ = 0;
 #define SA_STAMP() do { if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { t1_ = clock64(); a.dbg[ph_++] = t1_ - t0_; t0_ = t1_; } } while (0)
@@ -402,13 +401,13 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
     SaWPre<NJ> wpre;
     if constexpr (!ATT) {
         // stage this workgroup's rows of the attention output (coalesced 16-byte loads)
-        sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, NJ * wave, wpre);
+        sa_wprefetch((const h16_t*)a.Wo, SA_D / 16, 0, NJ * wave, wpre);
         constexpr int CPT = TOK * 32 / NT;
         uint4 r[CPT];
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
-            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.o + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const h16_t*)a.o + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
         if constexpr (XR) {                                        // the residual base, row-coalesced, into xres
             constexpr int XPT = TOK * 64 / NT;
@@ -457,16 +456,16 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                 if (e < NCH && row < L) kvr[it] = *reinterpret_cast<const uint4*>(qkv + (size_t)(mseq + row) * (3 * SA_D) + (1 + kv) * SA_D + hd * SA_DH + ch * 8);
             }
             // the query fragments of this wave's units
-            bf16x8_t qf[UPW][4];
+            h16x8_t qf[UPW][4];
 #pragma unroll
             for (int uu = 0; uu < UPW; ++uu) {
                 const int u = wave + 4 * uu, slot = u / RB, rb = u % RB, hd = round * HPR + slot;
                 const int tok = rb * 32 + t;
                 const bool qok = tok < nvalid;
-                const bf16_t* qp = qkv + (size_t)(m0 + (qok ? tok : 0)) * (3 * SA_D) + hd * SA_DH + 8 * hl;
+                const h16_t* qp = qkv + (size_t)(m0 + (qok ? tok : 0)) * (3 * SA_D) + hd * SA_DH + 8 * hl;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
-                    qf[uu][ks] = __builtin_bit_cast(bf16x8_t, qok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0));
+                    qf[uu][ks] = __builtin_bit_cast(h16x8_t, qok ? *reinterpret_cast<const uint4*>(qp + ks * 16) : make_uint4(0, 0, 0, 0));
             }
 #pragma unroll
             for (int it = 0; it < CPT; ++it) {
@@ -475,12 +474,12 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                 if (e < NCH) *reinterpret_cast<uint4*>(reg1 + ((slot * 2 + kv) * LPT + row) * KLD + ch * 8) = kvr[it];
             }
             __syncthreads();
-            if (round + 1 == SA_H / HPR) sa_wprefetch((const bf16_t*)a.Wo, SA_D / 16, 0, NJ * wave, wpre);   // ahead of the o stores
+            if (round + 1 == SA_H / HPR) sa_wprefetch((const h16_t*)a.Wo, SA_D / 16, 0, NJ * wave, wpre);   // ahead of the o stores
 #pragma unroll
             for (int uu = 0; uu < UPW; ++uu) {
                 const int u = wave + 4 * uu, slot = u / RB, rb = u % RB, hd = round * HPR + slot;
-                const bf16_t* sK = reg1 + (slot * 2) * LPT * KLD;
-                const bf16_t* sV = sK + LPT * KLD;
+                const h16_t* sK = reg1 + (slot * 2) * LPT * KLD;
+                const h16_t* sV = sK + LPT * KLD;
                 const int tok = rb * 32 + t;
                 const bool qok = tok < nvalid;
                 const int q = chunk * a.chunk_rows + tok;             // query index inside the sequence
@@ -496,11 +495,11 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         uint2 w;
-                        w.x = pack_bf16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
-                        w.y = pack_bf16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
+                        w.x = pack_h16x2(o[dt][4 * gq + 0] * inv, o[dt][4 * gq + 1] * inv);
+                        w.y = pack_h16x2(o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv);
                         const int cc = hd * SA_DH + dt * 32 + 8 * gq + 4 * hl;
                         *reinterpret_cast<uint2*>(actA + tok * ALD + cc) = w;
-                        if (qok) *reinterpret_cast<uint2*>((bf16_t*)a.o + (size_t)(m0 + tok) * SA_D + cc) = w;
+                        if (qok) *reinterpret_cast<uint2*>((h16_t*)a.o + (size_t)(m0 + tok) * SA_D + cc) = w;
                     }
                 if (qok && hl == 0) a.lse[(size_t)bh * L + q] = (m + log2f(lt)) * LN2F;
             }
@@ -528,8 +527,8 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                 }
         }
         sa_zero<RB, NJ>(acc);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wo, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
-        sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, NJ * wave, wpre);           // fc1 chunk 0, ahead of the x1 / n2 stores
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.Wo, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const h16_t*)a.W1, SA_D / 16, 0, NJ * wave, wpre);           // fc1 chunk 0, ahead of the x1 / n2 stores
         SA_STAMP();     // 1: o_proj MFMA
         const VpfRng rng = vpf_rng_init(a.rng, a.site_res1, a.p_res1);
         const bool drop = a.p_res1 > 0.f;
@@ -573,7 +572,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                 if (i * 32 + t < nvalid) { a.mean2[m0 + i * 32 + t] = mean[i]; a.rstd2[m0 + i * 32 + t] = rstd[i]; }
         }
         // (the LayerNorm exchange barriers guarantee every wave has finished reading o from actA)
-        sa_store_bf16<RB, NJ>(acc, actA, 0, XR ? nullptr : (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
+        sa_store_h16<RB, NJ>(acc, actA, 0, XR ? nullptr : (h16_t*)a.n2, SA_D, 0, m0, nvalid);
         SA_STAMP();     // 3b: n2 stores
     }
     __syncthreads();                                           // n2 complete in actA
@@ -587,7 +586,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
             pv[it] = (a.pos && row < nvalid) ? *reinterpret_cast<const float4*>(a.pos + (size_t)pos_row(row) * SA_D + c4 * 4)
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.n2, SA_D, 0, m0, nvalid);
+        sa_tile_store_rows<TOK, NT>(actA, (h16_t*)a.n2, SA_D, 0, m0, nvalid);
 #pragma unroll
         for (int it = 0; it < XPT; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 6, c4 = e & 63;
@@ -629,11 +628,11 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
     for (int hc = 0; hc < SA_HID / SA_D; ++hc) {
         sa_zero<RB, NJ>(acc);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
-        sa_wprefetch((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, wpre);   // this chunk's fc2 slice, ahead of the u / h stores
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.W1, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const h16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, wpre);   // this chunk's fc2 slice, ahead of the u / h stores
         if (hc == 1) SA_STAMP();    // 4a: (chunk 0 and) fc1 of chunk 1
         if constexpr (XR) {
-            // u = bf16(acc + b1) goes to actH in the accumulator layout; a row-coalesced pass then sends u to HBM, turns it into
+            // u = h16(acc + b1) goes to actH in the accumulator layout; a row-coalesced pass then sends u to HBM, turns it into
             // h = gelu(u) in place and sends h to HBM (16 bytes per lane, whole rows per wave-instruction)
             if (hc) __syncthreads();                           // every wave is done reading the previous chunk from actH
 #pragma unroll
@@ -643,8 +642,8 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     uint2 w;
-                    w.x = pack_bf16x2(acc[0][i][4 * g + 0] + b1.x, acc[0][i][4 * g + 1] + b1.y);
-                    w.y = pack_bf16x2(acc[0][i][4 * g + 2] + b1.z, acc[0][i][4 * g + 3] + b1.w);
+                    w.x = pack_h16x2(acc[0][i][4 * g + 0] + b1.x, acc[0][i][4 * g + 1] + b1.y);
+                    w.y = pack_h16x2(acc[0][i][4 * g + 2] + b1.z, acc[0][i][4 * g + 3] + b1.w);
                     *reinterpret_cast<uint2*>(actH + (i * 32 + t) * ALD + cl) = w;
                 }
             }
@@ -654,19 +653,19 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                 const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
                 const uint4 v = *reinterpret_cast<const uint4*>(actH + row * ALD + ch * 8);
                 const size_t go = (size_t)(m0 + row) * SA_HID + hc * SA_D + ch * 8;
-                if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.u + go) = v;
+                if (row < nvalid) *reinterpret_cast<uint4*>((h16_t*)a.u + go) = v;
                 const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
                 uint32_t hh[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    hh[q] = pack_bf16x2(sa_gelu(__uint_as_float(vv[q] << 16)), sa_gelu(__uint_as_float(vv[q] & 0xffff0000u)));
+                    hh[q] = pack_h16x2(sa_gelu(h16_lo(vv[q])), sa_gelu(h16_hi(vv[q])));
                 const uint4 hv = make_uint4(hh[0], hh[1], hh[2], hh[3]);
                 *reinterpret_cast<uint4*>(actH + row * ALD + ch * 8) = hv;
-                if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.h + go) = hv;
+                if (row < nvalid) *reinterpret_cast<uint4*>((h16_t*)a.h + go) = hv;
             }
             __syncthreads();
         } else {
-        // u = bf16(acc + b1) (saved), h = gelu(u)
+        // u = h16(acc + b1) (saved), h = gelu(u)
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -681,30 +680,30 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
                     for (int q = 0; q < 4; ++q) uu[q] = acc[j][i][4 * g + q] + bb[q];
                     uint2 w;
-                    w.x = pack_bf16x2(uu[0], uu[1]); w.y = pack_bf16x2(uu[2], uu[3]);
-                    if (tok < nvalid) *reinterpret_cast<uint2*>((bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + cch) = w;
-                    acc[j][i][4 * g + 0] = sa_gelu(__uint_as_float(w.x << 16));
-                    acc[j][i][4 * g + 1] = sa_gelu(__uint_as_float(w.x & 0xffff0000u));
-                    acc[j][i][4 * g + 2] = sa_gelu(__uint_as_float(w.y << 16));
-                    acc[j][i][4 * g + 3] = sa_gelu(__uint_as_float(w.y & 0xffff0000u));
+                    w.x = pack_h16x2(uu[0], uu[1]); w.y = pack_h16x2(uu[2], uu[3]);
+                    if (tok < nvalid) *reinterpret_cast<uint2*>((h16_t*)a.u + (size_t)(m0 + tok) * SA_HID + cch) = w;
+                    acc[j][i][4 * g + 0] = sa_gelu(h16_lo(w.x));
+                    acc[j][i][4 * g + 1] = sa_gelu(h16_hi(w.x));
+                    acc[j][i][4 * g + 2] = sa_gelu(h16_lo(w.y));
+                    acc[j][i][4 * g + 3] = sa_gelu(h16_hi(w.y));
                 }
             }
         if (hc == 1) SA_STAMP();    // 4b: bias + u store + GELU
         if (hc) __syncthreads();                               // every wave is done reading the previous chunk from actH
         if (hc == 1) SA_STAMP();    // 4c: barrier
-        sa_store_bf16<RB, NJ>(acc, actH, 0, (bf16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
+        sa_store_h16<RB, NJ>(acc, actH, 0, (h16_t*)a.h, SA_HID, hc * SA_D, m0, nvalid);
         if (hc == 1) SA_STAMP();    // 4d: h stores
         __syncthreads();
         }
         if (hc == 1) SA_STAMP();    // 4e: barrier
         if (NJ == 1 && hc + 1 == SA_HID / SA_D) load_final();
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
-        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W1, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.W2, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const h16_t*)a.W1, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
         if (hc == 1) SA_STAMP();    // 4f: fc2 of chunk 1
     }
     if (NJ != 1) load_final();
     const bool nxt = a.qkv_next != nullptr;
-    if (nxt) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, NJ * wave, wpre);
+    if (nxt) sa_wprefetch((const h16_t*)a.Wqkv_next, SA_D / 16, 0, NJ * wave, wpre);
     SA_STAMP();     // 4: MLP (fc1 + GELU + fc2)
 
     // ============================================================ x2 = x1 + dropout(h . W2^T + b2)  [+ pos -> next base, LN1, qkv]
@@ -766,27 +765,27 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                 if (i * 32 + t < nvalid) { a.mean1n[m0 + i * 32 + t] = mean[i]; a.rstd1n[m0 + i * 32 + t] = rstd[i]; }
         }
         store_out();                  // (the LayerNorm exchange barrier: every wave's part of out is in xres)
-        sa_store_bf16<RB, NJ>(acc2, actA, 0, XR ? nullptr : (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
+        sa_store_h16<RB, NJ>(acc2, actA, 0, XR ? nullptr : (h16_t*)a.n1n, SA_D, 0, m0, nvalid);     // n2 is dead: every wave passed the last fc1 barrier
     }
     __syncthreads();                  // n1n complete in actA; actH, the LayerNorm exchange and xres are dead
-    if constexpr (XR) sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.n1n, SA_D, 0, m0, nvalid);
+    if constexpr (XR) sa_tile_store_rows<TOK, NT>(actA, (h16_t*)a.n1n, SA_D, 0, m0, nvalid);
     SA_STAMP();     // 6: next LayerNorm 1
-    // q | k | v of the next layer: the results are held (packed bf16) and stored after the last unit, so that no weight load
+    // q | k | v of the next layer: the results are held (packed h16) and stored after the last unit, so that no weight load
     // ever queues behind a batch of stores
     if constexpr (XR) {
-        bf16_t* qst = reg1;                                   // [TOK][QLD] over actH | exchange | xres
+        h16_t* qst = reg1;                                   // [TOK][QLD] over actH | exchange | xres
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
             sa_zero<RB, NJ>(acc);
-            sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
-            if (part + 1 < 3) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + NJ * wave, wpre);
+            sa_gemm_unit<RB, NJ>((const h16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
+            if (part + 1 < 3) sa_wprefetch((const h16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + NJ * wave, wpre);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     uint2 w;
-                    w.x = pack_bf16x2(acc[0][i][4 * g + 0], acc[0][i][4 * g + 1]);
-                    w.y = pack_bf16x2(acc[0][i][4 * g + 2], acc[0][i][4 * g + 3]);
+                    w.x = pack_h16x2(acc[0][i][4 * g + 0], acc[0][i][4 * g + 1]);
+                    w.y = pack_h16x2(acc[0][i][4 * g + 2], acc[0][i][4 * g + 3]);
                     *reinterpret_cast<uint2*>(qst + (i * 32 + t) * QLD + part * SA_D + 32 * wave + 8 * g + 4 * hl) = w;
                 }
         }
@@ -795,7 +794,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
         for (int it = 0; it < TOK * 96 / NT; ++it) {
             const int e = threadIdx.x + it * NT, row = e / 96, ch = e - row * 96;
             const uint4 v = *reinterpret_cast<const uint4*>(qst + row * QLD + ch * 8);
-            if (row < nvalid) *reinterpret_cast<uint4*>((bf16_t*)a.qkv_next + (size_t)(m0 + row) * (3 * SA_D) + ch * 8) = v;
+            if (row < nvalid) *reinterpret_cast<uint4*>((h16_t*)a.qkv_next + (size_t)(m0 + row) * (3 * SA_D) + ch * 8) = v;
         }
         SA_STAMP();     // 7: next q/k/v projection
         return;
@@ -804,16 +803,16 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
         sa_zero<RB, NJ>(acc);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
-        if (part + 1 < 3) sa_wprefetch((const bf16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + NJ * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.Wqkv_next, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
+        if (part + 1 < 3) sa_wprefetch((const h16_t*)a.Wqkv_next, SA_D / 16, 0, (part + 1) * 8 + NJ * wave, wpre);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    held[part][j][i][g].x = pack_bf16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
-                    held[part][j][i][g].y = pack_bf16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+                    held[part][j][i][g].x = pack_h16x2(acc[j][i][4 * g + 0], acc[j][i][4 * g + 1]);
+                    held[part][j][i][g].y = pack_h16x2(acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
                 }
     }
 #pragma unroll
@@ -826,7 +825,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_layer_fwd_kernel(VpfSaLayerF
                 for (int g = 0; g < 4; ++g) {
                     const int tok = i * 32 + t;
                     if (tok < nvalid)
-                        *reinterpret_cast<uint2*>((bf16_t*)a.qkv_next + (size_t)(m0 + tok) * (3 * SA_D) + part * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) = held[part][j][i][g];
+                        *reinterpret_cast<uint2*>((h16_t*)a.qkv_next + (size_t)(m0 + tok) * (3 * SA_D) + part * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl) = held[part][j][i][g];
                 }
     SA_STAMP();     // 7: next q/k/v projection
 #undef SA_STAMP
@@ -896,7 +895,7 @@ extern "C" int vpf_ca_front_fwd(const VpfCaFront* args, void* stream)
 //   vpf_sa_layer_bwd_mlp : d(x2) -> dropout' -> [dz2] -> . W2 * gelu'(u) -> [du] -> . W1 -> LayerNorm-2' (+ d) -> [dx1]
 //                          -> dropout' -> [dz1] -> . Wo -> [do]
 //   vpf_sa_layer_bwd_qkv : [dqkv] . Wqkv -> LayerNorm-1' (+ dx1) -> [dbase]
-// ([..] = written to HBM: the bf16 ones are the operands of the weight-gradient GEMMs / the attention backward.)
+// ([..] = written to HBM: the h16 ones are the operands of the weight-gradient GEMMs / the attention backward.)
 // Same layout as the forward: swapped products, a lane owns a token, weights in (transposed) fragment order.
 
 // LayerNorm backward in place on the accumulator tile: acc = dL/dy -> dL/dx;  x (the forward input) from HBM.
@@ -925,14 +924,14 @@ __device__ __forceinline__ void sa_layernorm_bwd(f32x16_t (&acc)[NJ][RB], const 
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
                 const size_t off = (size_t)(m0 + (tok < nvalid ? tok : 0)) * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl;
-                if constexpr (XLDS && XBF) {  // a bf16 LDS tile [tokens][ALD]
-                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + tok * ALD + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl);
-                    xh[j][g][i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                if constexpr (XLDS && XBF) {  // a h16 LDS tile [tokens][ALD]
+                    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const h16_t*>(x) + tok * ALD + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl);
+                    xh[j][g][i] = make_float4(h16_lo(u.x), h16_hi(u.x), h16_lo(u.y), h16_hi(u.y));
                 } else if constexpr (XLDS) {
                     xh[j][g][i] = *reinterpret_cast<const float4*>(x + tok * XLD + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl);
-                } else if constexpr (XBF) {   // the LayerNorm input was stored as bf16 (x points at bf16 data)
-                    const uint2 u = tok < nvalid ? *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + off) : make_uint2(0u, 0u);
-                    xh[j][g][i] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+                } else if constexpr (XBF) {   // the LayerNorm input was stored as h16 (x points at h16 data)
+                    const uint2 u = tok < nvalid ? *reinterpret_cast<const uint2*>(reinterpret_cast<const h16_t*>(x) + off) : make_uint2(0u, 0u);
+                    xh[j][g][i] = make_float4(h16_lo(u.x), h16_hi(u.x), h16_lo(u.y), h16_hi(u.y));
                 } else {
                     xh[j][g][i] = tok < nvalid ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -1051,10 +1050,10 @@ __device__ __forceinline__ void sa_load_dropout_bwd(f32x16_t (&acc)[NJ][RB], con
 template <int RB, int NJ>
 __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_mlp_kernel(VpfSaLayerBwd a)
 {
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
     constexpr int TOK = RB * 32;
-    bf16_t* actA = lds;                               // dz2 -> dz1
-    bf16_t* actH = lds + TOK * ALD;                   // one 256-wide chunk of du
+    h16_t* actA = lds;                               // dz2 -> dz1
+    h16_t* actH = lds + TOK * ALD;                   // one 256-wide chunk of du
     float* sStat2 = reinterpret_cast<float*>(actH + TOK * ALD);   // [TOK][4] float2
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const long M = (long)a.M;
@@ -1062,13 +1061,13 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_mlp_kernel(VpfSaLayerBwd
     const int nvalid = (int)min((long)TOK, M - m0);
 
     SaWPre<NJ> wpre;
-    sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const h16_t*)a.W2T, SA_D / 16, 0, NJ * wave, wpre);
     f32x16_t acc[NJ][RB], acc2[NJ][RB];
     // ---- dz2 = dropout'(d)
     {
         const VpfRng rng = vpf_rng_init(a.rng, a.site_res2, a.p_res2);
         sa_load_dropout_bwd<RB, NJ>(acc, a.d, rng, a.p_res2 > 0.f, m0, nvalid);
-        sa_store_bf16<RB, NJ>(acc, actA, 0, (bf16_t*)a.dz2, SA_D, 0, m0, nvalid);
+        sa_store_h16<RB, NJ>(acc, actA, 0, (h16_t*)a.dz2, SA_D, 0, m0, nvalid);
     }
     __syncthreads();
     // ---- du = (dz2 . W2) * gelu'(u) ;  dn = du . W1
@@ -1083,30 +1082,30 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_mlp_kernel(VpfSaLayerBwd
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
                     const int tok = i * 32 + t;
-                    uu[j][g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
+                    uu[j][g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const h16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 32 * NJ * wave + 32 * j + 8 * g + 4 * hl)
                                                : make_uint2(0u, 0u);
                 }
         sa_zero<RB, NJ>(acc);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2T, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
-        sa_wprefetch((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.W2T, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const h16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, wpre);
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int i = 0; i < RB; ++i) {
-                    acc[j][i][4 * g + 0] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].x << 16));
-                    acc[j][i][4 * g + 1] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].x & 0xffff0000u));
-                    acc[j][i][4 * g + 2] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].y << 16));
-                    acc[j][i][4 * g + 3] *= vpf_gelu_grad(__uint_as_float(uu[j][g][i].y & 0xffff0000u));
+                    acc[j][i][4 * g + 0] *= vpf_gelu_grad(h16_lo(uu[j][g][i].x));
+                    acc[j][i][4 * g + 1] *= vpf_gelu_grad(h16_hi(uu[j][g][i].x));
+                    acc[j][i][4 * g + 2] *= vpf_gelu_grad(h16_lo(uu[j][g][i].y));
+                    acc[j][i][4 * g + 3] *= vpf_gelu_grad(h16_hi(uu[j][g][i].y));
                 }
         if (hc) __syncthreads();
-        sa_store_bf16<RB, NJ>(acc, actH, 0, (bf16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
+        sa_store_h16<RB, NJ>(acc, actH, 0, (h16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
         __syncthreads();
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
-        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const h16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
     }
-    sa_wprefetch((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const h16_t*)a.WoT, SA_D / 16, 0, NJ * wave, wpre);
     // ---- dx1 = LayerNorm-2'(dn) + d
     sa_layernorm_bwd<RB, NJ>(acc2, a.x1, a.mean2, a.rstd2, a.ln2_g, sStat2, a.pgrad2 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
     {
@@ -1141,12 +1140,12 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_mlp_kernel(VpfSaLayerBwd
                 }
     }
     // (the barriers of the hidden-chunk loop guarantee every wave has finished reading dz2 from actA)
-    sa_store_bf16<RB, NJ>(acc2, actA, 0, (bf16_t*)a.dz1, SA_D, 0, m0, nvalid);
+    sa_store_h16<RB, NJ>(acc2, actA, 0, (h16_t*)a.dz1, SA_D, 0, m0, nvalid);
     __syncthreads();
     // ---- do = dz1 . Wo
     sa_zero<RB, NJ>(acc);
-    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
-    sa_store_bf16<RB, NJ>(acc, nullptr, 0, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
+    sa_gemm_unit<RB, NJ>((const h16_t*)a.WoT, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
+    sa_store_h16<RB, NJ>(acc, nullptr, 0, (h16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
 }
 
 // The same with every HBM access but the u loads row-coalesced (8 waves x 32 channels).  d is only ever needed element-wise
@@ -1159,9 +1158,9 @@ template <int RB, bool STAGED>
 __device__ __forceinline__ void sa_bwd_mlp_rows_body(const VpfSaLayerBwd& a)
 {
     constexpr int NJ = 1, NT = 512, TOK = RB * 32, XPT = TOK * 64 / NT;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* actA = lds;                               // dz2 -> dz1
-    bf16_t* actH = lds + TOK * ALD;                   // one 256-wide chunk of du, then do
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* actA = lds;                               // dz2 -> dz1
+    h16_t* actH = lds + TOK * ALD;                   // one 256-wide chunk of du, then do
     float* sStat2 = reinterpret_cast<float*>(actH + TOK * ALD);   // [TOK][8] float2
     float* xt = sStat2 + TOK * 8 * 2;                 // [TOK][XLD] f32: x1, then LayerNorm-2'(dn)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
@@ -1170,7 +1169,7 @@ __device__ __forceinline__ void sa_bwd_mlp_rows_body(const VpfSaLayerBwd& a)
     const int nvalid = (int)min((long)TOK, M - m0);
 
     SaWPre<NJ> wpre;
-    sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const h16_t*)a.W2T, SA_D / 16, 0, NJ * wave, wpre);
     f32x16_t acc[NJ][RB], acc2[NJ][RB];
     // ---- dz2 = dropout'(d)  (row layout: operand tile + HBM);  x1 -> xt
     if constexpr (!STAGED) {
@@ -1192,10 +1191,10 @@ __device__ __forceinline__ void sa_bwd_mlp_rows_body(const VpfSaLayerBwd& a)
             const size_t off = (size_t)(m0 + (ok ? row : 0)) * SA_D + c4 * 4;
             const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u);
             uint2 w;
-            w.x = pack_bf16x2((keep & 1u) ? dr[it].x * sc : 0.f, (keep & 2u) ? dr[it].y * sc : 0.f);
-            w.y = pack_bf16x2((keep & 4u) ? dr[it].z * sc : 0.f, (keep & 8u) ? dr[it].w * sc : 0.f);
+            w.x = pack_h16x2((keep & 1u) ? dr[it].x * sc : 0.f, (keep & 2u) ? dr[it].y * sc : 0.f);
+            w.y = pack_h16x2((keep & 4u) ? dr[it].z * sc : 0.f, (keep & 8u) ? dr[it].w * sc : 0.f);
             *reinterpret_cast<uint2*>(actA + row * ALD + c4 * 4) = w;
-            if (ok) *reinterpret_cast<uint2*>((bf16_t*)a.dz2 + off) = w;
+            if (ok) *reinterpret_cast<uint2*>((h16_t*)a.dz2 + off) = w;
             *reinterpret_cast<float4*>(xt + row * XLD + c4 * 4) = ok ? xr[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -1210,29 +1209,29 @@ __device__ __forceinline__ void sa_bwd_mlp_rows_body(const VpfSaLayerBwd& a)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 const int tok = i * 32 + t;
-                uu[g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const bf16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 32 * wave + 8 * g + 4 * hl)
+                uu[g][i] = tok < nvalid ? *reinterpret_cast<const uint2*>((const h16_t*)a.u + (size_t)(m0 + tok) * SA_HID + hc * SA_D + 32 * wave + 8 * g + 4 * hl)
                                         : make_uint2(0u, 0u);
             }
         sa_zero<RB, NJ>(acc);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2T, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
-        sa_wprefetch((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.W2T, SA_D / 16, 0, hc * 8 + NJ * wave, actA, acc, wpre);
+        sa_wprefetch((const h16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, wpre);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                acc[0][i][4 * g + 0] *= vpf_gelu_grad(__uint_as_float(uu[g][i].x << 16));
-                acc[0][i][4 * g + 1] *= vpf_gelu_grad(__uint_as_float(uu[g][i].x & 0xffff0000u));
-                acc[0][i][4 * g + 2] *= vpf_gelu_grad(__uint_as_float(uu[g][i].y << 16));
-                acc[0][i][4 * g + 3] *= vpf_gelu_grad(__uint_as_float(uu[g][i].y & 0xffff0000u));
+                acc[0][i][4 * g + 0] *= vpf_gelu_grad(h16_lo(uu[g][i].x));
+                acc[0][i][4 * g + 1] *= vpf_gelu_grad(h16_hi(uu[g][i].x));
+                acc[0][i][4 * g + 2] *= vpf_gelu_grad(h16_lo(uu[g][i].y));
+                acc[0][i][4 * g + 3] *= vpf_gelu_grad(h16_hi(uu[g][i].y));
             }
         if (hc) __syncthreads();
-        sa_store_bf16<RB, NJ>(acc, actH, 0, nullptr, SA_HID, hc * SA_D, m0, nvalid);
+        sa_store_h16<RB, NJ>(acc, actH, 0, nullptr, SA_HID, hc * SA_D, m0, nvalid);
         __syncthreads();
-        sa_tile_store_rows<TOK, NT>(actH, (bf16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
-        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
+        sa_tile_store_rows<TOK, NT>(actH, (h16_t*)a.du, SA_HID, hc * SA_D, m0, nvalid);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.W1T, SA_HID / 16, hc * 16, NJ * wave, actH, acc2, wpre);
+        if (hc + 1 < SA_HID / SA_D) sa_wprefetch((const h16_t*)a.W2T, SA_D / 16, 0, (hc + 1) * 8 + NJ * wave, wpre);
     }
-    sa_wprefetch((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const h16_t*)a.WoT, SA_D / 16, 0, NJ * wave, wpre);
     // ---- LayerNorm-2'(dn) -> xt (the slots this lane read its x1 from)
     sa_layernorm_bwd<RB, NJ, false, true>(acc2, xt, a.mean2, a.rstd2, a.ln2_g, sStat2, a.pgrad2 + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
 #pragma unroll
@@ -1263,19 +1262,19 @@ __device__ __forceinline__ void sa_bwd_mlp_rows_body(const VpfSaLayerBwd& a)
             if (ok) *reinterpret_cast<float4*>(a.dx1 + off) = v;
             const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u);
             uint2 w;
-            w.x = pack_bf16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
-            w.y = pack_bf16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
+            w.x = pack_h16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
+            w.y = pack_h16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
             *reinterpret_cast<uint2*>(actA + row * ALD + c4 * 4) = w;
-            if (ok) *reinterpret_cast<uint2*>((bf16_t*)a.dz1 + off) = w;
+            if (ok) *reinterpret_cast<uint2*>((h16_t*)a.dz1 + off) = w;
         }
     }
     __syncthreads();
     // ---- do = dz1 . Wo   (staged through actH: the last du chunk is dead)
     sa_zero<RB, NJ>(acc);
-    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WoT, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
-    sa_store_bf16<RB, NJ>(acc, actH, 0, nullptr, SA_D, 0, m0, nvalid);
+    sa_gemm_unit<RB, NJ>((const h16_t*)a.WoT, SA_D / 16, 0, NJ * wave, actA, acc, wpre);
+    sa_store_h16<RB, NJ>(acc, actH, 0, nullptr, SA_D, 0, m0, nvalid);
     __syncthreads();
-    sa_tile_store_rows<TOK, NT>(actH, (bf16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
+    sa_tile_store_rows<TOK, NT>(actH, (h16_t*)a.dout_attn, SA_D, 0, m0, nvalid);
 }
 template <int RB>
 __global__ void __launch_bounds__(512) sa_bwd_mlp_rows_kernel(VpfSaLayerBwd a)
@@ -1287,9 +1286,9 @@ template <int RB, int NJ>
 __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd a)
 {
     constexpr int NT = 64 * (8 / NJ);
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
     constexpr int TOK = RB * 32;
-    bf16_t* actA = lds;                                // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
+    h16_t* actA = lds;                                // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
     float* sStat2 = reinterpret_cast<float*>(lds + 2 * TOK * ALD);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const long M = (long)a.M;
@@ -1298,13 +1297,13 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd
     constexpr int CPT = TOK * 32 / NT;
 
     SaWPre<NJ> wpre;
-    sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const h16_t*)a.WqkvT, 3 * SA_D / 16, 0, NJ * wave, wpre);
     uint4 r[CPT];
     auto load_part = [&](int part) {
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
-            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dqkv + (size_t)(m0 + row) * (3 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const h16_t*)a.dqkv + (size_t)(m0 + row) * (3 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_part = [&](int buf) {
@@ -1322,9 +1321,9 @@ __global__ void __launch_bounds__(64 * (8 / NJ)) sa_bwd_qkv_kernel(VpfSaLayerBwd
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
         if (part + 1 < 3) load_part(part + 1);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.WqkvT, 3 * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.WqkvT, 3 * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
         if (part + 1 < 3) {
-            sa_wprefetch((const bf16_t*)a.WqkvT, 3 * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
+            sa_wprefetch((const h16_t*)a.WqkvT, 3 * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
             store_part((part + 1) & 1);
             __syncthreads();
         }
@@ -1372,8 +1371,8 @@ template <int RB, bool HANDOFF, int NP = 3>
 __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, const VpfSaLayerBwd& b)
 {
     constexpr int NJ = 1, NT = 512, TOK = RB * 32, CPT = TOK * 32 / NT, XPT = TOK * 64 / NT;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* actA = lds;                                // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* actA = lds;                                // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
     float* sStat2 = reinterpret_cast<float*>(lds + 2 * TOK * ALD);
     float* xt = sStat2 + TOK * 8 * 2;                  // [TOK][XLD] f32: base, then LayerNorm-1'(dn1)
     const int wave = threadIdx.x >> 6;
@@ -1382,13 +1381,13 @@ __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, con
     const int nvalid = (int)min((long)TOK, M - m0);
 
     SaWPre<NJ> wpre;
-    sa_wprefetch((const bf16_t*)a.WqkvT, NP * SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const h16_t*)a.WqkvT, NP * SA_D / 16, 0, NJ * wave, wpre);
     uint4 r[CPT];
     auto load_part = [&](int part) {
 #pragma unroll
         for (int it = 0; it < CPT; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
-            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dqkv + (size_t)(m0 + row) * (NP * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const h16_t*)a.dqkv + (size_t)(m0 + row) * (NP * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_part = [&](int buf) {
@@ -1419,9 +1418,9 @@ __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, con
 #pragma unroll
     for (int part = 0; part < NP; ++part) {
         if (part + 1 < NP) load_part(part + 1);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.WqkvT, NP * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.WqkvT, NP * SA_D / 16, part * 16, NJ * wave, actA + (part & 1) * TOK * ALD, acc, wpre);
         if (part + 1 < NP) {
-            sa_wprefetch((const bf16_t*)a.WqkvT, NP * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
+            sa_wprefetch((const h16_t*)a.WqkvT, NP * SA_D / 16, (part + 1) * 16, NJ * wave, wpre);
             store_part((part + 1) & 1);
             __syncthreads();
         }
@@ -1481,10 +1480,10 @@ __device__ __forceinline__ void sa_bwd_qkv_rows_body(const VpfSaLayerBwd& a, con
             }
             const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u);
             uint2 w;
-            w.x = pack_bf16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
-            w.y = pack_bf16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
+            w.x = pack_h16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
+            w.y = pack_h16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
             *reinterpret_cast<uint2*>(actA + row * ALD + c4 * 4) = w;
-            if (ok) *reinterpret_cast<uint2*>((bf16_t*)b.dz2 + off) = w;
+            if (ok) *reinterpret_cast<uint2*>((h16_t*)b.dz2 + off) = w;
             *reinterpret_cast<float4*>(xt + row * XLD + c4 * 4) = ok ? xr[it] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -1643,7 +1642,7 @@ extern "C" int vpf_sa_layer_bwd_qkv(const VpfSaLayerBwd* args, void* stream)
 }
 
 // Backward of a cross-attention layer's query side (partseg.py:100-116,48-51 + the residual of :201-213) as one row-block kernel:
-// dq bf16 [M, D] (a->dqkv) . Wq (a->WqkvT = vpf_pack_wfrag(transposed) of the bf16 [D, D] q weight) -> q LayerNorm' (a->base = its
+// dq h16 [M, D] (a->dqkv) . Wq (a->WqkvT = vpf_pack_wfrag(transposed) of the h16 [D, D] q weight) -> q LayerNorm' (a->base = its
 // input, mean1 / rstd1 / ln1_g) -> + a->dx1 -> a->dbase (f32 [M, D]); a->dsum (nullable) accumulates it; the LayerNorm's parameter
 // gradients leave as partial rows (a->pgrad1).  D = 256 (else VPF_ERR_UNSUPPORTED: the caller keeps its GEMM + LayerNorm kernels).
 extern "C" int vpf_ca_front_bwd(const VpfSaLayerBwd* args, void* stream)
@@ -1667,7 +1666,7 @@ extern "C" int vpf_ca_front_bwd(const VpfSaLayerBwd* args, void* stream)
 }
 
 // The key / value side of the same layer when its input is an f32 [M, D] tensor (the image branch's patch embeddings; the point-cloud
-// branch's K / V producer has vpf_adapter_kv_bwd): dqkv = dk | dv bf16 [M, 2D], WqkvT = vpf_pack_wfrag(transposed) of the bf16 [2D, D]
+// branch's K / V producer has vpf_adapter_kv_bwd): dqkv = dk | dv h16 [M, 2D], WqkvT = vpf_pack_wfrag(transposed) of the h16 [2D, D]
 // k | v weights, base / mean1 / rstd1 / ln1_g = the kv LayerNorm's input, statistics, scale; dx1 may be NULL (no residual); dbase = dxkv f32.
 extern "C" int vpf_ca_kv_bwd(const VpfSaLayerBwd* args, void* stream)
 {
@@ -1723,17 +1722,17 @@ extern "C" int vpf_sa_layer_bwd_qkv_mlp(const VpfSaLayerBwd* qkv, const VpfSaLay
 // PointCloudInputAdapter.point_mlp (classifier.py:31-36: Linear(C,64) -> LayerNorm(64) -> ReLU -> Linear(64,D)), the
 // cross-attention kv LayerNorm (partseg.py:100-116) and the bias-free K / V projections (partseg.py:48-51) for 64 points
 // per workgroup in ONE kernel: the per-point embedding [B*N, D] -- the largest activation of the step -- goes from the
-// 64-wide hidden layer to K / V through LDS and registers.  It is still written once (bf16, with the hidden layer and the
+// 64-wide hidden layer to K / V through LDS and registers.  It is still written once (h16, with the hidden layer and the
 // normalised rows) because the backward pass reads it, but it is never read back in the forward pass.
 template <int NJ>
 __global__ void __launch_bounds__(64 * (8 / NJ), 4) adapter_kv_fwd_kernel(VpfAdapterKv a)
 {
     constexpr int RB = 2, TOK = RB * 32, NT = 64 * (8 / NJ), NWV = 8 / NJ, A1LD = 72;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* sA1 = lds;                                  // [TOK][A1LD]  hidden layer (bf16)
-    bf16_t* actA = lds + TOK * A1LD;                    // [TOK][ALD]   normalised per-point embedding
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* sA1 = lds;                                  // [TOK][A1LD]  hidden layer (h16)
+    h16_t* actA = lds + TOK * A1LD;                    // [TOK][ALD]   normalised per-point embedding
     float* sStat = reinterpret_cast<float*>(actA + TOK * ALD);      // [TOK][NWV] float2
-    bf16_t* sX = reinterpret_cast<bf16_t*>(sStat + TOK * NWV * 2);  // [TOK][ALD]   per-point embedding before the LayerNorm, then the K rows, then
+    h16_t* sX = reinterpret_cast<h16_t*>(sStat + TOK * NWV * 2);  // [TOK][ALD]   per-point embedding before the LayerNorm, then the K rows, then
                                                                     //              the V rows (staging for HBM).  79 KB in all: two workgroups share a
                                                                     //              CU and one's MFMA phases fill the other's LayerNorm / store phases
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
@@ -1742,7 +1741,7 @@ __global__ void __launch_bounds__(64 * (8 / NJ), 4) adapter_kv_fwd_kernel(VpfAda
     const int C = a.C;
 
     SaWPre<NJ> wpre;
-    sa_wprefetch((const bf16_t*)a.Wkv, SA_D / 16, 0, NJ * wave, wpre);
+    sa_wprefetch((const h16_t*)a.Wkv, SA_D / 16, 0, NJ * wave, wpre);
     // ---- hidden layer: thread = (token, 8 of the 64 channels); LayerNorm over the token's 8 threads (lanes ^1 ^2 ^4)
     for (int e = threadIdx.x; e < TOK * 8; e += NT) {
         const int tok = e >> 3, cg = (e & 7) * 8;
@@ -1769,28 +1768,28 @@ __global__ void __launch_bounds__(64 * (8 / NJ), 4) adapter_kv_fwd_kernel(VpfAda
         for (int k = 0; k < 4; ++k) {
             const float lo = fmaxf(h[2 * k] * rs * a.ln_g[cg + 2 * k] + a.ln_b[cg + 2 * k], 0.f);
             const float hi = fmaxf(h[2 * k + 1] * rs * a.ln_g[cg + 2 * k + 1] + a.ln_b[cg + 2 * k + 1], 0.f);
-            w[k] = pack_bf16x2(lo, hi);
+            w[k] = pack_h16x2(lo, hi);
         }
         const uint4 v4 = make_uint4(w[0], w[1], w[2], w[3]);
         *reinterpret_cast<uint4*>(sA1 + tok * A1LD + cg) = v4;
-        if (ok) *reinterpret_cast<uint4*>((bf16_t*)a.a1 + (size_t)(m0 + tok) * 64 + cg) = v4;
+        if (ok) *reinterpret_cast<uint4*>((h16_t*)a.a1 + (size_t)(m0 + tok) * 64 + cg) = v4;
     }
     __syncthreads();
-    // ---- per-point embedding = hidden . W2^T + b2 (K = 64), rounded to bf16 as the unfused path stores it, then kv LayerNorm
+    // ---- per-point embedding = hidden . W2^T + b2 (K = 64), rounded to h16 as the unfused path stores it, then kv LayerNorm
     f32x16_t acc[NJ][RB];
     sa_zero<RB, NJ>(acc);
     {
         const uint4* w0 = reinterpret_cast<const uint4*>(a.W2) + ((size_t)(NJ * wave) * 4) * 64 + lane;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t af[NJ];
+            h16x8_t af[NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) af[j] = __builtin_bit_cast(bf16x8_t, w0[((size_t)j * 4 + ks) * 64]);
+            for (int j = 0; j < NJ; ++j) af[j] = __builtin_bit_cast(h16x8_t, w0[((size_t)j * 4 + ks) * 64]);
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                const bf16x8_t x = sa_frag_row(sA1, A1LD, i * 32, ks * 16);
+                const h16x8_t x = sa_frag_row(sA1, A1LD, i * 32, ks * 16);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j], x, acc[j][i], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[j][i] = vpf_mfma32(af[j], x, acc[j][i]);
             }
         }
     }
@@ -1804,12 +1803,12 @@ __global__ void __launch_bounds__(64 * (8 / NJ), 4) adapter_kv_fwd_kernel(VpfAda
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 uint2 u;
-                u.x = pack_bf16x2(acc[j][i][4 * g + 0] + bb[0], acc[j][i][4 * g + 1] + bb[1]);
-                u.y = pack_bf16x2(acc[j][i][4 * g + 2] + bb[2], acc[j][i][4 * g + 3] + bb[3]);
+                u.x = pack_h16x2(acc[j][i][4 * g + 0] + bb[0], acc[j][i][4 * g + 1] + bb[1]);
+                u.y = pack_h16x2(acc[j][i][4 * g + 2] + bb[2], acc[j][i][4 * g + 3] + bb[3]);
                 const int tok = i * 32 + t;
                 *reinterpret_cast<uint2*>(sX + tok * ALD + c) = u;       // to HBM in the row pass below (whole rows per wave-instruction)
-                acc[j][i][4 * g + 0] = __uint_as_float(u.x << 16); acc[j][i][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
-                acc[j][i][4 * g + 2] = __uint_as_float(u.y << 16); acc[j][i][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
+                acc[j][i][4 * g + 0] = h16_lo(u.x); acc[j][i][4 * g + 1] = h16_hi(u.x);
+                acc[j][i][4 * g + 2] = h16_lo(u.y); acc[j][i][4 * g + 3] = h16_hi(u.y);
             }
         }
     float mean[RB], rstd[RB];
@@ -1819,20 +1818,20 @@ __global__ void __launch_bounds__(64 * (8 / NJ), 4) adapter_kv_fwd_kernel(VpfAda
         for (int i = 0; i < RB; ++i)
             if (i * 32 + t < nvalid) { a.mean[m0 + i * 32 + t] = mean[i]; a.rstd[m0 + i * 32 + t] = rstd[i]; }
     }
-    sa_store_bf16<RB, NJ>(acc, actA, 0, nullptr, SA_D, 0, m0, nvalid);
+    sa_store_h16<RB, NJ>(acc, actA, 0, nullptr, SA_D, 0, m0, nvalid);
     __syncthreads();
-    sa_tile_store_rows<TOK, NT>(sX, (bf16_t*)a.xkv, SA_D, 0, m0, nvalid);
-    sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.nk, SA_D, 0, m0, nvalid);
+    sa_tile_store_rows<TOK, NT>(sX, (h16_t*)a.xkv, SA_D, 0, m0, nvalid);
+    sa_tile_store_rows<TOK, NT>(actA, (h16_t*)a.nk, SA_D, 0, m0, nvalid);
     // ---- K | V = normalised . Wkv^T   (two 256-channel halves, each staged in LDS and stored as whole 512-byte half rows)
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
         sa_zero<RB, NJ>(acc);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.Wkv, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
-        if (part == 0) sa_wprefetch((const bf16_t*)a.Wkv, SA_D / 16, 0, 8 + NJ * wave, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.Wkv, SA_D / 16, 0, part * 8 + NJ * wave, actA, acc, wpre);
+        if (part == 0) sa_wprefetch((const h16_t*)a.Wkv, SA_D / 16, 0, 8 + NJ * wave, wpre);
         __syncthreads();                                             // the row pass that read sX last is done
-        sa_store_bf16<RB, NJ>(acc, sX, 0, nullptr, SA_D, 0, m0, nvalid);
+        sa_store_h16<RB, NJ>(acc, sX, 0, nullptr, SA_D, 0, m0, nvalid);
         __syncthreads();
-        sa_tile_store_rows<TOK, NT>(sX, (bf16_t*)a.kv, 2 * SA_D, part * SA_D, m0, nvalid);
+        sa_tile_store_rows<TOK, NT>(sX, (h16_t*)a.kv, 2 * SA_D, part * SA_D, m0, nvalid);
     }
 }
 
@@ -1860,29 +1859,29 @@ extern "C" int vpf_adapter_kv_fwd(const VpfAdapterKv* args, void* stream)
 
 
 // ================================================================================================ K / V producer, backward
-// dkv [M, 2D] -> (. Wk | Wv) -> kv LayerNorm' -> dxkv (bf16, also the operand of the adapter's weight gradient) -> . W2 -> da1
-// (bf16 [M, 64]), 64 points per workgroup.  The kv LayerNorm's parameter gradients leave as per-workgroup partial rows
+// dkv [M, 2D] -> (. Wk | Wv) -> kv LayerNorm' -> dxkv (h16, also the operand of the adapter's weight gradient) -> . W2 -> da1
+// (h16 [M, 64]), 64 points per workgroup.  The kv LayerNorm's parameter gradients leave as per-workgroup partial rows
 // (folded by vpf_ln_pgrad_reduce); the two weight-gradient GEMMs (dkv x nk, dxkv x a1) stay GEMMs and the 3 -> 64 front's
 // backward stays vpf_adapter_front_bwd (a per-workgroup fold of its 704 parameter-gradient sums costs more than it saves).
 __global__ void __launch_bounds__(512) adapter_kv_bwd_kernel(VpfAdapterKvBwd a)
 {
     constexpr int RB = 2, NJ = 1, TOK = 64, NT = 512;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* actA = lds;                                 // two [TOK][ALD] buffers: dk | dv rows, then dxkv in buffer 0
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* actA = lds;                                 // two [TOK][ALD] buffers: dk | dv rows, then dxkv in buffer 0
     float* sStat2 = reinterpret_cast<float*>(lds + 2 * TOK * ALD);  // [TOK][8] float2
-    bf16_t* sX = reinterpret_cast<bf16_t*>(sStat2 + TOK * 8 * 2);   // [TOK][ALD] the kv LayerNorm's input rows
+    h16_t* sX = reinterpret_cast<h16_t*>(sStat2 + TOK * 8 * 2);   // [TOK][ALD] the kv LayerNorm's input rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5, t = lane & 31;
     const long M = a.M, m0 = (long)blockIdx.x * TOK;
     const int nvalid = (int)min((long)TOK, M - m0);
 
     SaWPre<NJ> wpre;
-    sa_wprefetch((const bf16_t*)a.WkvT, 2 * SA_D / 16, 0, wave, wpre);
+    sa_wprefetch((const h16_t*)a.WkvT, 2 * SA_D / 16, 0, wave, wpre);
     {   // stage both halves of the dkv rows and the LayerNorm input rows (coalesced 16-byte loads, all in flight together)
         uint4 rx[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int e = threadIdx.x + it * NT, row = e >> 5, ch = e & 31;
-            rx[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.xkv + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+            rx[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const h16_t*)a.xkv + (size_t)(m0 + row) * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -1893,7 +1892,7 @@ __global__ void __launch_bounds__(512) adapter_kv_bwd_kernel(VpfAdapterKvBwd a)
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int e = threadIdx.x + it * NT, part = e >> 11, row = (e >> 5) & 63, ch = e & 31;
-            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const bf16_t*)a.dkv + (size_t)(m0 + row) * (2 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
+            r[it] = row < nvalid ? *reinterpret_cast<const uint4*>((const h16_t*)a.dkv + (size_t)(m0 + row) * (2 * SA_D) + part * SA_D + ch * 8) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
@@ -1904,32 +1903,32 @@ __global__ void __launch_bounds__(512) adapter_kv_bwd_kernel(VpfAdapterKvBwd a)
     __syncthreads();
     f32x16_t acc[NJ][RB];
     sa_zero<RB, NJ>(acc);
-    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WkvT, 2 * SA_D / 16, 0, wave, actA, acc, wpre);
-    sa_wprefetch((const bf16_t*)a.WkvT, 2 * SA_D / 16, 16, wave, wpre);
-    sa_gemm_unit<RB, NJ>((const bf16_t*)a.WkvT, 2 * SA_D / 16, 16, wave, actA + TOK * ALD, acc, wpre);
-    if (wave < 2) sa_wprefetch((const bf16_t*)a.W2T, SA_D / 16, 0, wave, wpre);
-    // the unfused path stores dnk as bf16 before the LayerNorm backward: round the same way
+    sa_gemm_unit<RB, NJ>((const h16_t*)a.WkvT, 2 * SA_D / 16, 0, wave, actA, acc, wpre);
+    sa_wprefetch((const h16_t*)a.WkvT, 2 * SA_D / 16, 16, wave, wpre);
+    sa_gemm_unit<RB, NJ>((const h16_t*)a.WkvT, 2 * SA_D / 16, 16, wave, actA + TOK * ALD, acc, wpre);
+    if (wave < 2) sa_wprefetch((const h16_t*)a.W2T, SA_D / 16, 0, wave, wpre);
+    // the unfused path stores dnk as h16 before the LayerNorm backward: round the same way
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][i][r] = bf16_to_f32(f32_to_bf16(acc[0][i][r]));
+        for (int r = 0; r < 16; ++r) acc[0][i][r] = h16_to_f32(f32_to_h16(acc[0][i][r]));
     sa_layernorm_bwd<RB, NJ, true, true>(acc, reinterpret_cast<const float*>(sX), a.mean, a.rstd, a.lnkv_g, sStat2, a.pgrad_kv + (size_t)blockIdx.x * 2 * SA_D, m0, nvalid);
     // (the exchange barrier inside guarantees every wave has finished reading the dk / dv rows)
-    sa_store_bf16<RB, NJ>(acc, actA, 0, nullptr, SA_D, 0, m0, nvalid);
+    sa_store_h16<RB, NJ>(acc, actA, 0, nullptr, SA_D, 0, m0, nvalid);
     __syncthreads();
-    sa_tile_store_rows<TOK, NT>(actA, (bf16_t*)a.dxkv, SA_D, 0, m0, nvalid);
-    // ---- da1 = dxkv . W2   (64 hidden channels: waves 0 and 1), stored as bf16 like the unfused dgrad output
+    sa_tile_store_rows<TOK, NT>(actA, (h16_t*)a.dxkv, SA_D, 0, m0, nvalid);
+    // ---- da1 = dxkv . W2   (64 hidden channels: waves 0 and 1), stored as h16 like the unfused dgrad output
     if (wave < 2) {
         sa_zero<RB, NJ>(acc);
-        sa_gemm_unit<RB, NJ>((const bf16_t*)a.W2T, SA_D / 16, 0, wave, actA, acc, wpre);
+        sa_gemm_unit<RB, NJ>((const h16_t*)a.W2T, SA_D / 16, 0, wave, actA, acc, wpre);
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 u;
-                u.x = pack_bf16x2(acc[0][i][4 * g + 0], acc[0][i][4 * g + 1]);
-                u.y = pack_bf16x2(acc[0][i][4 * g + 2], acc[0][i][4 * g + 3]);
-                if (i * 32 + t < nvalid) *reinterpret_cast<uint2*>((bf16_t*)a.da1 + (size_t)(m0 + i * 32 + t) * 64 + 32 * wave + 8 * g + 4 * hl) = u;
+                u.x = pack_h16x2(acc[0][i][4 * g + 0], acc[0][i][4 * g + 1]);
+                u.y = pack_h16x2(acc[0][i][4 * g + 2], acc[0][i][4 * g + 3]);
+                if (i * 32 + t < nvalid) *reinterpret_cast<uint2*>((h16_t*)a.da1 + (size_t)(m0 + i * 32 + t) * 64 + 32 * wave + 8 * g + 4 * hl) = u;
             }
     }
 }

@@ -23,7 +23,6 @@
 //   <1, 1>  D = 384 (BASELINE config 4: 6 heads, hidden 1536): 12 waves, 32-token blocks.
 #include "sa_rows.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 namespace {
@@ -31,7 +30,7 @@ namespace {
 template <int D, int RB, int TH>
 struct Cfg {
     static constexpr int NWV = D / 32, NW = NWV * TH, NT = 64 * NW, TOK = 32 * RB * TH, ALD = D + 8, KS = D / 16, C8 = D / 8;
-    static constexpr int TILE = TOK * ALD;                               // bf16 elements of one operand tile
+    static constexpr int TILE = TOK * ALD;                               // h16 elements of one operand tile
     static constexpr bool XDED = (NW * 4096 > TILE * 2);                 // the transposition slices need a region of their own
     static constexpr int PD = RB == 1 ? 8 : 4;                           // weight ring depth (k-steps in flight per wave)
     static constexpr bool KEEPX = RB == 1;                               // the residual rows stay in registers across the MLP
@@ -59,7 +58,7 @@ __device__ __forceinline__ void who(int tid_, int& cw, int& tb0)
 template <int PD> struct WRing { uint4 w[PD]; };
 
 template <int PD>
-__device__ __forceinline__ void ring_fill(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb, WRing<PD>& r)
+__device__ __forceinline__ void ring_fill(const h16_t* __restrict__ Wp, int ksn, int ks0, int cb, WRing<PD>& r)
 {
     const unsigned lane = fresh_tid() & 63;
     const uint4* w0 = reinterpret_cast<const uint4*>(Wp) + ((size_t)cb * ksn + ks0) * 64;      // wave-uniform (cb is): scalar base + lane
@@ -71,13 +70,13 @@ __device__ __forceinline__ void ring_fill(const bf16_t* __restrict__ Wp, int ksn
 // front of the MFMAs of k-step ks, and a scheduling fence per k-step keeps the compiler from hoisting all RB KSU LDS reads of the
 // unrolled loop to the top (that is what it does on its own: 128 registers of fragments, spills everywhere else).
 template <int RB, int KSU, int PD>
-__device__ __forceinline__ void gemm_unit(const bf16_t* __restrict__ Wp, int ksn, int ks0, int cb, const bf16_t* act, int ald, int tb0,
+__device__ __forceinline__ void gemm_unit(const h16_t* __restrict__ Wp, int ksn, int ks0, int cb, const h16_t* act, int ald, int tb0,
                                           f32x16_t (&acc)[RB], WRing<PD>& r)
 {
     constexpr int XD = 2;                                  // activation fragments: k-steps in flight
     const unsigned lane = fresh_tid() & 63;
     const uint4* w0 = reinterpret_cast<const uint4*>(Wp) + ((size_t)cb * ksn + ks0) * 64;
-    const bf16_t* xrow = act + (tb0 * 32 + (lane & 31)) * ald + 8 * (lane >> 5);
+    const h16_t* xrow = act + (tb0 * 32 + (lane & 31)) * ald + 8 * (lane >> 5);
     uint4 xb[XD][RB];
 #pragma unroll
     for (int p = 0; p < XD - 1; ++p)
@@ -89,11 +88,11 @@ __device__ __forceinline__ void gemm_unit(const bf16_t* __restrict__ Wp, int ksn
 #pragma unroll
             for (int i = 0; i < RB; ++i) xb[(ks + XD - 1) % XD][i] = *reinterpret_cast<const uint4*>(xrow + i * 32 * ald + (ks + XD - 1) * 16);
         }
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, r.w[ks % PD]);
+        const h16x8_t af = __builtin_bit_cast(h16x8_t, r.w[ks % PD]);
         if (ks + PD < KSU) r.w[ks % PD] = w0[(ks + PD) * 64 + lane];
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, xb[ks % XD][i]), acc[i], 0, 0, 0);
+            acc[i] = vpf_mfma32(af, __builtin_bit_cast(h16x8_t, xb[ks % XD][i]), acc[i]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -191,11 +190,11 @@ __device__ __forceinline__ void acc_to_slice(float* slice, const f32x16_t& v)
     for (int g = 0; g < 4; ++g)
         *reinterpret_cast<float4*>(slice + t * 32 + (((2 * g + hl) ^ swz(t)) << 2)) = make_float4(v[4 * g + 0], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
 }
-// bf16: [32 RB tokens][4 chunks of 16 B] (the wave's 32 channels of one GEMM result): accumulator side writes 8 B, row side moves
+// h16: [32 RB tokens][4 chunks of 16 B] (the wave's 32 channels of one GEMM result): accumulator side writes 8 B, row side moves
 // 16 tokens x 64 B per wave-instruction
 __device__ __forceinline__ int swz2(int t) { return (t >> 1) & 3; }
 template <int RB>
-__device__ __forceinline__ void acc_to_slice_bf16(bf16_t* slice, const f32x16_t (&v)[RB])
+__device__ __forceinline__ void acc_to_slice_h16(h16_t* slice, const f32x16_t (&v)[RB])
 {
     const int lane = fresh_tid() & 63, t = lane & 31, hl = lane >> 5;
 #pragma unroll
@@ -203,15 +202,15 @@ __device__ __forceinline__ void acc_to_slice_bf16(bf16_t* slice, const f32x16_t 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 w;
-            w.x = pack_bf16x2(v[i][4 * g + 0], v[i][4 * g + 1]);
-            w.y = pack_bf16x2(v[i][4 * g + 2], v[i][4 * g + 3]);
+            w.x = pack_h16x2(v[i][4 * g + 0], v[i][4 * g + 1]);
+            w.y = pack_h16x2(v[i][4 * g + 2], v[i][4 * g + 3]);
             const int tok = i * 32 + t;
             *reinterpret_cast<uint2*>(slice + tok * 32 + ((g ^ swz2(tok)) << 3) + 4 * hl) = w;
         }
 }
 // rows of the slice -> Gu[tok * ld + 8 chunk ..] (Gu = the matrix at the wave's first token and first column) for tok < nv
 template <int RB>
-__device__ __forceinline__ void slice_bf16_store_rows(const bf16_t* slice, bf16_t* __restrict__ Gu, int ld, int nv)
+__device__ __forceinline__ void slice_h16_store_rows(const h16_t* slice, h16_t* __restrict__ Gu, int ld, int nv)
 {
     const int lane = fresh_tid() & 63, tl = lane >> 2, ch = lane & 3;
 #pragma unroll
@@ -223,9 +222,9 @@ __device__ __forceinline__ void slice_bf16_store_rows(const bf16_t* slice, bf16_
 }
 
 // ------------------------------------------------------------------ operand tiles
-// accumulator tile -> bf16 operand tile [tokens][ALD] (this wave's 32 columns of its token blocks)
+// accumulator tile -> h16 operand tile [tokens][ALD] (this wave's 32 columns of its token blocks)
 template <int D, int RB>
-__device__ __forceinline__ void acc_to_tile(const f32x16_t (&acc)[RB], bf16_t* sAct, int ald)
+__device__ __forceinline__ void acc_to_tile(const f32x16_t (&acc)[RB], h16_t* sAct, int ald)
 {
     const int tid_ = fresh_tid();
     int cw, tb0;
@@ -236,14 +235,14 @@ __device__ __forceinline__ void acc_to_tile(const f32x16_t (&acc)[RB], bf16_t* s
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 u;
-            u.x = pack_bf16x2(acc[i][4 * g + 0], acc[i][4 * g + 1]);
-            u.y = pack_bf16x2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
+            u.x = pack_h16x2(acc[i][4 * g + 0], acc[i][4 * g + 1]);
+            u.y = pack_h16x2(acc[i][4 * g + 2], acc[i][4 * g + 3]);
             *reinterpret_cast<uint2*>(sAct + ((tb0 + i) * 32 + t) * ald + 32 * cw + 8 * g + 4 * hl) = u;
         }
 }
-// u = bf16(acc + bias) -> operand tile in the accumulator layout
+// u = h16(acc + bias) -> operand tile in the accumulator layout
 template <int D, int RB>
-__device__ __forceinline__ void bias_to_tile(const f32x16_t (&acc)[RB], const float* bias, bf16_t* sAct, int ald)
+__device__ __forceinline__ void bias_to_tile(const f32x16_t (&acc)[RB], const float* bias, h16_t* sAct, int ald)
 {
     const int tid_ = fresh_tid();
     int cw, tb0;
@@ -256,15 +255,15 @@ __device__ __forceinline__ void bias_to_tile(const f32x16_t (&acc)[RB], const fl
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             uint2 w;
-            w.x = pack_bf16x2(acc[i][4 * g + 0] + b1.x, acc[i][4 * g + 1] + b1.y);
-            w.y = pack_bf16x2(acc[i][4 * g + 2] + b1.z, acc[i][4 * g + 3] + b1.w);
+            w.x = pack_h16x2(acc[i][4 * g + 0] + b1.x, acc[i][4 * g + 1] + b1.y);
+            w.y = pack_h16x2(acc[i][4 * g + 2] + b1.z, acc[i][4 * g + 3] + b1.w);
             *reinterpret_cast<uint2*>(sAct + ((tb0 + i) * 32 + t) * ald + cl) = w;
         }
     }
 }
 // the whole tile, row-coalesced: every thread moves 16 B of a row
 template <class C>
-__device__ __forceinline__ void tile_store_rows(const bf16_t* sAct, bf16_t* __restrict__ Gu /* row 0, column 0 of the block */, int ld, int nvalid)
+__device__ __forceinline__ void tile_store_rows(const h16_t* sAct, h16_t* __restrict__ Gu /* row 0, column 0 of the block */, int ld, int nvalid)
 {
     const int tid_ = fresh_tid();
 #pragma unroll
@@ -275,7 +274,7 @@ __device__ __forceinline__ void tile_store_rows(const bf16_t* sAct, bf16_t* __re
     }
 }
 template <class C>
-__device__ __forceinline__ void tile_load_rows(bf16_t* sAct, const bf16_t* __restrict__ Gu, int ld, int nvalid)
+__device__ __forceinline__ void tile_load_rows(h16_t* sAct, const h16_t* __restrict__ Gu, int ld, int nvalid)
 {
     const int tid_ = fresh_tid();
     uint4 r[C::TOK * C::C8 / C::NT];
@@ -292,7 +291,7 @@ __device__ __forceinline__ void tile_load_rows(bf16_t* sAct, const bf16_t* __res
 }
 // row pass over the hidden chunk in sAct: u -> HBM, h = gelu(u) in place and -> HBM (16 B per lane, whole rows per wave-instruction)
 template <class C>
-__device__ __forceinline__ void gelu_rows_pass(bf16_t* sAct, bf16_t* __restrict__ u_u, bf16_t* __restrict__ h_u, int ldh, int nvalid)
+__device__ __forceinline__ void gelu_rows_pass(h16_t* sAct, h16_t* __restrict__ u_u, h16_t* __restrict__ h_u, int ldh, int nvalid)
 {
     const int tid_ = fresh_tid();
 #pragma unroll
@@ -306,7 +305,7 @@ __device__ __forceinline__ void gelu_rows_pass(bf16_t* sAct, bf16_t* __restrict_
         uint32_t hh[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            hh[q] = pack_bf16x2(vpf_gelu(__uint_as_float(vv[q] << 16)), vpf_gelu(__uint_as_float(vv[q] & 0xffff0000u)));
+            hh[q] = pack_h16x2(vpf_gelu(h16_lo(vv[q])), vpf_gelu(h16_hi(vv[q])));
         const uint4 hv = make_uint4(hh[0], hh[1], hh[2], hh[3]);
         *reinterpret_cast<uint4*>(sAct + row * C::ALD + ch * 8) = hv;
         if (row < nvalid) *reinterpret_cast<uint4*>(h_u + go) = hv;
@@ -415,9 +414,9 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
 {
     using C = Cfg<D, RB, TH>;
     constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, HC = HID / D, PD = C::PD;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* actA = lds;                                               // [TOK][ALD]  o -> n2 -> (slices) out, q|k|v staging
-    bf16_t* actH = lds + C::TILE;                                     // [TOK][ALD]  (slices) base, x1, pos -> hidden chunk -> next n1
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* actA = lds;                                               // [TOK][ALD]  o -> n2 -> (slices) out, q|k|v staging
+    h16_t* actH = lds + C::TILE;                                     // [TOK][ALD]  (slices) base, x1, pos -> hidden chunk -> next n1
     float2* sPair = reinterpret_cast<float2*>(actH + C::TILE);        // [TOK][NWV]  LayerNorm exchange
     float* sPar = reinterpret_cast<float*>(sPair + TOK * NWV);        // bo | ln2 g | ln2 b | b2 | next ln1 g | b | b1[HID]
     float* xded = sPar + 6 * D + HID;                                 // XDED: the slices' own region
@@ -447,20 +446,20 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
         }
     };
     WRing<PD> ring;
-    ring_fill<PD>((const bf16_t*)a.Wo, KS, 0, cw, ring);
+    ring_fill<PD>((const h16_t*)a.Wo, KS, 0, cw, ring);
     // ---- residual base rows (consumed behind the first product), o rows -> actA, per-channel vectors -> sPar
     float4 rb[RB][4];
 #pragma unroll
     for (int i = 0; i < RB; ++i) rows_load(a.base + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid), rb[i]);
     stage_params<D, HID, C::NW>(sPar, a.bo, a.ln2_g, a.ln2_b, a.b2, a.ln1n_g, a.ln1n_b, a.b1);
-    tile_load_rows<C>(actA, (const bf16_t*)a.o + m0 * D, D, nvalid);
+    tile_load_rows<C>(actA, (const h16_t*)a.o + m0 * D, D, nvalid);
     __syncthreads();                                                  // o in actA, parameters in sPar
     R_STAMP();      // 0: loads (o, parameters) + barrier
     // ============================================================ x1 = base + dropout(o . Wo^T + bo);  n2 = LN2(x1)
     f32x16_t acc[RB];
     zero<RB>(acc);
-    gemm_unit<RB, KS, PD>((const bf16_t*)a.Wo, KS, 0, cw, actA, ALD, tb0, acc, ring);
-    ring_fill<PD>((const bf16_t*)a.W1, KS, 0, cw, ring);              // fc1 chunk 0
+    gemm_unit<RB, KS, PD>((const h16_t*)a.Wo, KS, 0, cw, actA, ALD, tb0, acc, ring);
+    ring_fill<PD>((const h16_t*)a.W1, KS, 0, cw, ring);              // fc1 chunk 0
     R_STAMP();      // 1: o_proj MFMA
     f32x16_t xr[RB];                                                  // the residual rows: rows -> slice -> accumulator layout
 #pragma unroll
@@ -486,7 +485,7 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
     acc_to_tile<D, RB>(acc, actA, ALD);                                // (the LayerNorm barrier: every wave is done reading o)
     __syncthreads();                                                  // n2 complete in actA; every wave's x1 slices are drained
     R_STAMP();      // 3: LayerNorm 2 + n2 tile + barrier
-    tile_store_rows<C>(actA, (bf16_t*)a.n2 + m0 * D, D, nvalid);
+    tile_store_rows<C>(actA, (h16_t*)a.n2 + m0 * D, D, nvalid);
     R_STAMP();      // 4: n2 rows out
 
     // ============================================================ MLP: HC chunks of D hidden channels
@@ -496,13 +495,13 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
 #pragma unroll
     for (int hc = 0; hc < HC; ++hc) {
         zero<RB>(acc);
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.W1, KS, 0, hc * NWV + cw, actA, ALD, tb0, acc, ring);
-        ring_fill<PD>((const bf16_t*)a.W2, HID / 16, hc * KS, cw, ring);   // this chunk's fc2 slice
+        gemm_unit<RB, KS, PD>((const h16_t*)a.W1, KS, 0, hc * NWV + cw, actA, ALD, tb0, acc, ring);
+        ring_fill<PD>((const h16_t*)a.W2, HID / 16, hc * KS, cw, ring);   // this chunk's fc2 slice
         if (hc == 0) R_STAMP();      // 5: fc1 MFMA (chunk 0)
         if (hc) __syncthreads();                                      // every wave is done reading the previous chunk from actH
-        bias_to_tile<D, RB>(acc, b1_p + hc * D, actH, ALD);             // u = bf16(acc + b1), accumulator layout
+        bias_to_tile<D, RB>(acc, b1_p + hc * D, actH, ALD);             // u = h16(acc + b1), accumulator layout
         __syncthreads();
-        gelu_rows_pass<C>(actH, (bf16_t*)a.u + m0 * HID + hc * D, (bf16_t*)a.h + m0 * HID + hc * D, HID, nvalid);
+        gelu_rows_pass<C>(actH, (h16_t*)a.u + m0 * HID + hc * D, (h16_t*)a.h + m0 * HID + hc * D, HID, nvalid);
         if (hc == 0) R_STAMP();      // 6: u tile + barrier + gelu row pass (chunk 0)
         __syncthreads();
         if (hc == 0) R_STAMP();          // 7: barrier
@@ -534,11 +533,11 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
             }
             R_STAMP();     // 8 (last chunk): fc1 .. gelu of the last chunk + the x1 / pos row requests
         }
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.W2, HID / 16, hc * KS, cw, actH, ALD, tb0, acc2, ring);
-        if (hc + 1 < HC) ring_fill<PD>((const bf16_t*)a.W1, KS, 0, (hc + 1) * NWV + cw, ring);
+        gemm_unit<RB, KS, PD>((const h16_t*)a.W2, HID / 16, hc * KS, cw, actH, ALD, tb0, acc2, ring);
+        if (hc + 1 < HC) ring_fill<PD>((const h16_t*)a.W1, KS, 0, (hc + 1) * NWV + cw, ring);
         if (hc == 0 && HC > 1) R_STAMP();          // 8 (first chunk): fc2 MFMA (chunk 0)
     }
-    if (nxt) ring_fill<PD>((const bf16_t*)a.Wqkv_next, KS, 0, cw, ring);
+    if (nxt) ring_fill<PD>((const h16_t*)a.Wqkv_next, KS, 0, cw, ring);
     R_STAMP();      // fc2 MFMA (last chunk)
 
     // ============================================================ x2 = x1 + dropout(h . W2^T + b2)  [+ pos -> next base, LN1, q|k|v]
@@ -563,17 +562,17 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
     acc_to_tile<D, RB>(xr, actH, ALD);                                 // (the LayerNorm barrier: every wave is done with the hidden chunk)
     __syncthreads();                                                  // next n1 complete in actH
     R_STAMP();      // next LayerNorm 1 + tile + barrier
-    tile_store_rows<C>(actH, (bf16_t*)a.n1n + m0 * D, D, nvalid);
+    tile_store_rows<C>(actH, (h16_t*)a.n1n + m0 * D, D, nvalid);
     R_STAMP();      // n1 rows out
     // q | k | v of the next layer: each wave's [32 RB x 32] result leaves through its slice as 64-byte row pieces
-    bf16_t* qslice = reinterpret_cast<bf16_t*>(sliceA);
+    h16_t* qslice = reinterpret_cast<h16_t*>(sliceA);
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
         zero<RB>(acc);
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.Wqkv_next, KS, 0, part * NWV + cw, actH, ALD, tb0, acc, ring);
-        if (part + 1 < 3) ring_fill<PD>((const bf16_t*)a.Wqkv_next, KS, 0, (part + 1) * NWV + cw, ring);
-        acc_to_slice_bf16<RB>(qslice, acc);
-        slice_bf16_store_rows<RB>(qslice, (bf16_t*)a.qkv_next + (m0 + tb0 * 32) * (3 * D) + part * D + 32 * cw, 3 * D, nvalid - tb0 * 32);
+        gemm_unit<RB, KS, PD>((const h16_t*)a.Wqkv_next, KS, 0, part * NWV + cw, actH, ALD, tb0, acc, ring);
+        if (part + 1 < 3) ring_fill<PD>((const h16_t*)a.Wqkv_next, KS, 0, (part + 1) * NWV + cw, ring);
+        acc_to_slice_h16<RB>(qslice, acc);
+        slice_h16_store_rows<RB>(qslice, (h16_t*)a.qkv_next + (m0 + tb0 * 32) * (3 * D) + part * D + 32 * cw, 3 * D, nvalid - tb0 * 32);
     }
     R_STAMP();      // q | k | v
     wg_record();
@@ -632,9 +631,9 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) ca_front_fwd_kernel(VpfCaFro
 {
     using C = Cfg<D, RB, TH>;
     constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, PD = C::PD, HP = 128, HLD = HP + 8;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* actH = lds;                                               // [TOK][HLD]  hidden layer of the position MLP
-    bf16_t* actA = lds + TOK * HLD;                                   // [TOK][ALD]  nq
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* actH = lds;                                               // [TOK][HLD]  hidden layer of the position MLP
+    h16_t* actA = lds + TOK * HLD;                                   // [TOK][ALD]  nq
     float2* sPair = reinterpret_cast<float2*>(actA + C::TILE);        // [TOK][NWV]
     float* xded = reinterpret_cast<float*>(sPair + TOK * NWV);        // the transposition slices (a region of their own)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -644,7 +643,7 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) ca_front_fwd_kernel(VpfCaFro
     float* slice = xded + wave * 1024;
 
     WRing<PD> ring;
-    ring_fill<PD>((const bf16_t*)a.W1, HP / 16, 0, cw, ring);
+    ring_fill<PD>((const h16_t*)a.W1, HP / 16, 0, cw, ring);
     float4 rb[RB][4];                                                 // the tokens' rows: consumed behind the first product
 #pragma unroll
     for (int i = 0; i < RB; ++i) rows_load(a.x + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid), rb[i]);
@@ -669,12 +668,12 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) ca_front_fwd_kernel(VpfCaFro
                     t += wr[0] * cx[0]; t += wr[1] * cx[1]; t += wr[2] * cx[2];
                     u[h] = vpf_gelu(t);
                 }
-                w[j] = pack_bf16x2(u[0], u[1]);
+                w[j] = pack_h16x2(u[0], u[1]);
             }
             *reinterpret_cast<uint4*>(actH + row * HLD + c0) = make_uint4(w[0], w[1], w[2], w[3]);
             *reinterpret_cast<uint4*>(actH + row * HLD + c0 + 8) = make_uint4(w[4], w[5], w[6], w[7]);
             if (ok) {
-                bf16_t* hp = (bf16_t*)a.hpos + (size_t)(m0 + row) * HP + c0;
+                h16_t* hp = (h16_t*)a.hpos + (size_t)(m0 + row) * HP + c0;
                 *reinterpret_cast<uint4*>(hp) = make_uint4(w[0], w[1], w[2], w[3]);
                 *reinterpret_cast<uint4*>(hp + 8) = make_uint4(w[4], w[5], w[6], w[7]);
             }
@@ -684,8 +683,8 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) ca_front_fwd_kernel(VpfCaFro
     // ---- pos = hpos . W1^T + b1;  base = x + pos
     f32x16_t acc[RB], xr[RB];
     zero<RB>(acc);
-    gemm_unit<RB, HP / 16, PD>((const bf16_t*)a.W1, HP / 16, 0, cw, actH, HLD, tb0, acc, ring);
-    ring_fill<PD>((const bf16_t*)a.Wq, KS, 0, cw, ring);
+    gemm_unit<RB, HP / 16, PD>((const h16_t*)a.W1, HP / 16, 0, cw, actH, HLD, tb0, acc, ring);
+    ring_fill<PD>((const h16_t*)a.Wq, KS, 0, cw, ring);
     {
         const int lane = fresh_tid() & 63, hl = lane >> 5;
 #pragma unroll
@@ -710,13 +709,13 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) ca_front_fwd_kernel(VpfCaFro
     layernorm<D, RB>(xr, a.lnq_g, a.lnq_b, sPair, a.mean + m0, a.rstd + m0, nvalid);
     acc_to_tile<D, RB>(xr, actA, ALD);
     __syncthreads();
-    tile_store_rows<C>(actA, (bf16_t*)a.nq + m0 * D, D, nvalid);
+    tile_store_rows<C>(actA, (h16_t*)a.nq + m0 * D, D, nvalid);
     // ---- q = nq . Wq^T
     zero<RB>(acc);
-    gemm_unit<RB, KS, PD>((const bf16_t*)a.Wq, KS, 0, cw, actA, ALD, tb0, acc, ring);
-    bf16_t* qslice = reinterpret_cast<bf16_t*>(slice);
-    acc_to_slice_bf16<RB>(qslice, acc);
-    slice_bf16_store_rows<RB>(qslice, (bf16_t*)a.q + (m0 + tb0 * 32) * D + 32 * cw, D, nvalid - tb0 * 32);
+    gemm_unit<RB, KS, PD>((const h16_t*)a.Wq, KS, 0, cw, actA, ALD, tb0, acc, ring);
+    h16_t* qslice = reinterpret_cast<h16_t*>(slice);
+    acc_to_slice_h16<RB>(qslice, acc);
+    slice_h16_store_rows<RB>(qslice, (h16_t*)a.q + (m0 + tb0 * 32) * D + 32 * cw, D, nvalid - tb0 * 32);
 }
 
 // ================================================================================================ backward
@@ -820,10 +819,10 @@ __device__ __forceinline__ void layernorm_bwd(f32x16_t (&acc)[RB], f32x16_t (&x)
         }
 }
 
-// cooperative row pass: dst tile (bf16, [TOK][ALD]) and HBM (bf16 rows, ld = D) = dropout'(src f32 rows) -- the operand of the next
+// cooperative row pass: dst tile (h16, [TOK][ALD]) and HBM (h16 rows, ld = D) = dropout'(src f32 rows) -- the operand of the next
 // product and of the weight-gradient GEMM
 template <class C, int D>
-__device__ __forceinline__ void dropout_bwd_rows(const float* __restrict__ src_u, bf16_t* sAct, bf16_t* __restrict__ dst_u, const VpfRng& rng, bool drop,
+__device__ __forceinline__ void dropout_bwd_rows(const float* __restrict__ src_u, h16_t* sAct, h16_t* __restrict__ dst_u, const VpfRng& rng, bool drop,
                                                  long m0, int nvalid)
 {
     constexpr int XPT = C::TOK * (D / 4) / C::NT;
@@ -842,8 +841,8 @@ __device__ __forceinline__ void dropout_bwd_rows(const float* __restrict__ src_u
         const size_t off = (size_t)(m0 + (ok ? row : 0)) * D + c4 * 4;
         const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, (uint64_t)off >> 2) : 15u);
         uint2 w;
-        w.x = pack_bf16x2((keep & 1u) ? dr[it].x * sc : 0.f, (keep & 2u) ? dr[it].y * sc : 0.f);
-        w.y = pack_bf16x2((keep & 4u) ? dr[it].z * sc : 0.f, (keep & 8u) ? dr[it].w * sc : 0.f);
+        w.x = pack_h16x2((keep & 1u) ? dr[it].x * sc : 0.f, (keep & 2u) ? dr[it].y * sc : 0.f);
+        w.y = pack_h16x2((keep & 4u) ? dr[it].z * sc : 0.f, (keep & 8u) ? dr[it].w * sc : 0.f);
         *reinterpret_cast<uint2*>(sAct + row * C::ALD + c4 * 4) = w;
         if (ok) *reinterpret_cast<uint2*>(dst_u + (unsigned)(row * D + c4 * 4)) = w;
     }
@@ -855,9 +854,9 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_mlp_kernel(VpfSa
 {
     using C = Cfg<D, RB, TH>;
     constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, HC = HID / D, PD = C::PD;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* actA = lds;                                               // dz2 -> (slices: x1, LayerNorm-2' result, do)
-    bf16_t* actH = lds + C::TILE;                                     // one D-wide chunk of du, then dz1
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* actA = lds;                                               // dz2 -> (slices: x1, LayerNorm-2' result, do)
+    h16_t* actH = lds + C::TILE;                                     // one D-wide chunk of du, then dz1
     float* sStat2 = reinterpret_cast<float*>(actH + C::TILE);         // [TOK][NWV] float2
     float* xded = sStat2 + TOK * NWV * 2;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -867,11 +866,11 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_mlp_kernel(VpfSa
     float* slice = (C::XDED ? xded : reinterpret_cast<float*>(actA)) + wave * 1024;
 
     WRing<PD> ring;
-    ring_fill<PD>((const bf16_t*)a.W2T, KS, 0, cw, ring);
+    ring_fill<PD>((const h16_t*)a.W2T, KS, 0, cw, ring);
     // ---- dz2 = dropout'(d): operand tile + HBM, in the row layout
     {
         const VpfRng rng = vpf_rng_init(a.rng, a.site_res2, a.p_res2);
-        dropout_bwd_rows<C, D>(a.d + m0 * D, actA, (bf16_t*)a.dz2 + m0 * D, rng, a.p_res2 > 0.f, m0, nvalid);
+        dropout_bwd_rows<C, D>(a.d + m0 * D, actA, (h16_t*)a.dz2 + m0 * D, rng, a.p_res2 > 0.f, m0, nvalid);
     }
     __syncthreads();
     // ---- du = (dz2 . W2) * gelu'(u) ;  dn = du . W1
@@ -882,7 +881,7 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_mlp_kernel(VpfSa
         uint2 uu[4][RB];                                               // the pre-GELU values of this lane's elements (accumulator layout)
         {
             const int lane = fresh_tid() & 63, hl = lane >> 5, t = lane & 31;
-            const bf16_t* u_u = (const bf16_t*)a.u + m0 * HID + hc * D + 32 * cw;
+            const h16_t* u_u = (const h16_t*)a.u + m0 * HID + hc * D + 32 * cw;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -892,25 +891,25 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_mlp_kernel(VpfSa
                 }
         }
         zero<RB>(acc);
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.W2T, KS, 0, hc * NWV + cw, actA, ALD, tb0, acc, ring);
-        ring_fill<PD>((const bf16_t*)a.W1T, HID / 16, hc * KS, cw, ring);
+        gemm_unit<RB, KS, PD>((const h16_t*)a.W2T, KS, 0, hc * NWV + cw, actA, ALD, tb0, acc, ring);
+        ring_fill<PD>((const h16_t*)a.W1T, HID / 16, hc * KS, cw, ring);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
-                acc[i][4 * g + 0] *= vpf_gelu_grad(__uint_as_float(uu[g][i].x << 16));
-                acc[i][4 * g + 1] *= vpf_gelu_grad(__uint_as_float(uu[g][i].x & 0xffff0000u));
-                acc[i][4 * g + 2] *= vpf_gelu_grad(__uint_as_float(uu[g][i].y << 16));
-                acc[i][4 * g + 3] *= vpf_gelu_grad(__uint_as_float(uu[g][i].y & 0xffff0000u));
+                acc[i][4 * g + 0] *= vpf_gelu_grad(h16_lo(uu[g][i].x));
+                acc[i][4 * g + 1] *= vpf_gelu_grad(h16_hi(uu[g][i].x));
+                acc[i][4 * g + 2] *= vpf_gelu_grad(h16_lo(uu[g][i].y));
+                acc[i][4 * g + 3] *= vpf_gelu_grad(h16_hi(uu[g][i].y));
             }
         if (hc) __syncthreads();                                      // every wave is done reading the previous chunk from actH
         acc_to_tile<D, RB>(acc, actH, ALD);
         __syncthreads();
-        tile_store_rows<C>(actH, (bf16_t*)a.du + m0 * HID + hc * D, HID, nvalid);
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.W1T, HID / 16, hc * KS, cw, actH, ALD, tb0, acc2, ring);
-        if (hc + 1 < HC) ring_fill<PD>((const bf16_t*)a.W2T, KS, 0, (hc + 1) * NWV + cw, ring);
+        tile_store_rows<C>(actH, (h16_t*)a.du + m0 * HID + hc * D, HID, nvalid);
+        gemm_unit<RB, KS, PD>((const h16_t*)a.W1T, HID / 16, hc * KS, cw, actH, ALD, tb0, acc2, ring);
+        if (hc + 1 < HC) ring_fill<PD>((const h16_t*)a.W2T, KS, 0, (hc + 1) * NWV + cw, ring);
     }
-    ring_fill<PD>((const bf16_t*)a.WoT, KS, 0, cw, ring);
+    ring_fill<PD>((const h16_t*)a.WoT, KS, 0, cw, ring);
     // ---- LayerNorm-2'(dn): x1 comes in row segments through the slices (dz2 in actA is dead: every wave has left the chunk loop's
     //      last W2 product behind a barrier)
     f32x16_t xr[RB];
@@ -945,20 +944,20 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_mlp_kernel(VpfSa
                 if (ok) *reinterpret_cast<float4*>(a.dx1 + m0 * D + ro.o[it]) = v;
                 const uint32_t keep = !ok ? 0u : (drop ? vpf_keep4(rng, ((uint64_t)m0 * D + ro.o[it]) >> 2) : 15u);
                 uint2 w;
-                w.x = pack_bf16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
-                w.y = pack_bf16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
+                w.x = pack_h16x2((keep & 1u) ? v.x * sc : 0.f, (keep & 2u) ? v.y * sc : 0.f);
+                w.y = pack_h16x2((keep & 4u) ? v.z * sc : 0.f, (keep & 8u) ? v.w * sc : 0.f);
                 *reinterpret_cast<uint2*>(actH + row * ALD + 32 * cw + 4 * ch) = w;
-                if (ok) *reinterpret_cast<uint2*>((bf16_t*)a.dz1 + m0 * D + ro.o[it]) = w;
+                if (ok) *reinterpret_cast<uint2*>((h16_t*)a.dz1 + m0 * D + ro.o[it]) = w;
             }
         }
     }
     __syncthreads();                                                  // dz1 complete in actH
     // ---- do = dz1 . Wo: leaves through the wave's slice as 64-byte row pieces
     zero<RB>(acc);
-    gemm_unit<RB, KS, PD>((const bf16_t*)a.WoT, KS, 0, cw, actH, ALD, tb0, acc, ring);
-    bf16_t* qslice = reinterpret_cast<bf16_t*>(slice);
-    acc_to_slice_bf16<RB>(qslice, acc);
-    slice_bf16_store_rows<RB>(qslice, (bf16_t*)a.dout_attn + (m0 + tb0 * 32) * D + 32 * cw, D, nvalid - tb0 * 32);
+    gemm_unit<RB, KS, PD>((const h16_t*)a.WoT, KS, 0, cw, actH, ALD, tb0, acc, ring);
+    h16_t* qslice = reinterpret_cast<h16_t*>(slice);
+    acc_to_slice_h16<RB>(qslice, acc);
+    slice_h16_store_rows<RB>(qslice, (h16_t*)a.dout_attn + (m0 + tb0 * 32) * D + 32 * cw, D, nvalid - tb0 * 32);
 }
 
 //   [dqkv] . Wqkv -> LayerNorm-1' (+ dx1) -> [dbase] (+= dsum)
@@ -968,9 +967,9 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_qkv_kernel(VpfSa
 {
     using C = Cfg<D, RB, TH>;
     constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, PD = C::PD;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* buf0 = lds;                                               // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
-    bf16_t* buf1 = lds + C::TILE;
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* buf0 = lds;                                               // two buffers of [TOK][ALD]: the q | k | v slices of dqkv
+    h16_t* buf1 = lds + C::TILE;
     float* sStat2 = reinterpret_cast<float*>(buf1 + C::TILE);
     float* xded = sStat2 + TOK * NWV * 2;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -980,18 +979,18 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_bwd_qkv_kernel(VpfSa
     float* slice = (C::XDED ? xded : reinterpret_cast<float*>(buf1)) + wave * 1024;      // buf1 is free once the last part is staged
 
     WRing<PD> ring;
-    ring_fill<PD>((const bf16_t*)a.WqkvT, NP * KS, 0, cw, ring);
-    tile_load_rows<C>(buf0, (const bf16_t*)a.dqkv + m0 * (NP * D), NP * D, nvalid);
+    ring_fill<PD>((const h16_t*)a.WqkvT, NP * KS, 0, cw, ring);
+    tile_load_rows<C>(buf0, (const h16_t*)a.dqkv + m0 * (NP * D), NP * D, nvalid);
     __syncthreads();
     f32x16_t acc[RB];
     zero<RB>(acc);
 #pragma unroll
     for (int part = 0; part < NP; ++part) {
         // (the next part is staged behind this part's product: the other buffer is free -- every wave passed the last barrier)
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.WqkvT, NP * KS, part * KS, cw, (part & 1) ? buf1 : buf0, ALD, tb0, acc, ring);
+        gemm_unit<RB, KS, PD>((const h16_t*)a.WqkvT, NP * KS, part * KS, cw, (part & 1) ? buf1 : buf0, ALD, tb0, acc, ring);
         if (part + 1 < NP) {
-            ring_fill<PD>((const bf16_t*)a.WqkvT, NP * KS, (part + 1) * KS, cw, ring);
-            tile_load_rows<C>((part & 1) ? buf0 : buf1, (const bf16_t*)a.dqkv + m0 * (NP * D) + (part + 1) * D, NP * D, nvalid);
+            ring_fill<PD>((const h16_t*)a.WqkvT, NP * KS, (part + 1) * KS, cw, ring);
+            tile_load_rows<C>((part & 1) ? buf0 : buf1, (const h16_t*)a.dqkv + m0 * (NP * D) + (part + 1) * D, NP * D, nvalid);
             __syncthreads();
         }
     }
@@ -1122,13 +1121,13 @@ int sa_rows_bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st)
 }
 
 // ================================================================================================ K / V producer, backward
-// The same chain as adapter_kv_bwd_kernel (sa_layer.hip: dkv [M, 2D] -> . (Wk | Wv) -> kv LayerNorm' -> dxkv bf16 -> . W2 -> da1 bf16
+// The same chain as adapter_kv_bwd_kernel (sa_layer.hip: dkv [M, 2D] -> . (Wk | Wv) -> kv LayerNorm' -> dxkv h16 -> . W2 -> da1 h16
 // [M, 64], identical arithmetic and rounding points) on this file's building blocks: two operand tiles instead of three (the LayerNorm's
 // input rows are staged into the dk tile once its product is done), a 4-deep weight ring instead of 16 k-steps of prefetch -- 128 VGPRs
 // and 72 KB of LDS, so TWO workgroups share a CU.  The launch has 2 048 workgroups (131 072 points): unlike the encoder's 192-workgroup
 // launches the second one is always there, and its products fill the first one's load / LayerNorm / store phases.
 template <int D, int RB>
-__device__ __forceinline__ void tile_to_acc(const bf16_t* sAct, int ald, f32x16_t (&x)[RB])
+__device__ __forceinline__ void tile_to_acc(const h16_t* sAct, int ald, f32x16_t (&x)[RB])
 {
     const int tid_ = fresh_tid();
     int cw, tb0;
@@ -1139,14 +1138,14 @@ __device__ __forceinline__ void tile_to_acc(const bf16_t* sAct, int ald, f32x16_
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const uint2 u = *reinterpret_cast<const uint2*>(sAct + ((tb0 + i) * 32 + t) * ald + 32 * cw + 8 * g + 4 * hl);
-            x[i][4 * g + 0] = __uint_as_float(u.x << 16);
-            x[i][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
-            x[i][4 * g + 2] = __uint_as_float(u.y << 16);
-            x[i][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
+            x[i][4 * g + 0] = h16_lo(u.x);
+            x[i][4 * g + 1] = h16_hi(u.x);
+            x[i][4 * g + 2] = h16_lo(u.y);
+            x[i][4 * g + 3] = h16_hi(u.y);
         }
 }
 template <class C>
-__device__ __forceinline__ void rows_request(const bf16_t* __restrict__ Gu, int ld, int nvalid, uint4 (&r)[C::TOK * C::C8 / C::NT])
+__device__ __forceinline__ void rows_request(const h16_t* __restrict__ Gu, int ld, int nvalid, uint4 (&r)[C::TOK * C::C8 / C::NT])
 {
     const int tid_ = fresh_tid();
 #pragma unroll
@@ -1156,7 +1155,7 @@ __device__ __forceinline__ void rows_request(const bf16_t* __restrict__ Gu, int 
     }
 }
 template <class C>
-__device__ __forceinline__ void rows_commit(bf16_t* sAct, const uint4 (&r)[C::TOK * C::C8 / C::NT])
+__device__ __forceinline__ void rows_commit(h16_t* sAct, const uint4 (&r)[C::TOK * C::C8 / C::NT])
 {
     const int tid_ = fresh_tid();
 #pragma unroll
@@ -1170,18 +1169,18 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_bwd_rows_kernel(V
 {
     using C = Cfg<D, RB, TH>;
     constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, PD = C::PD;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* buf0 = lds;                                               // dk rows, then the LayerNorm input rows, then the da1 slices
-    bf16_t* buf1 = lds + C::TILE;                                     // dv rows, then dxkv
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* buf0 = lds;                                               // dk rows, then the LayerNorm input rows, then the da1 slices
+    h16_t* buf1 = lds + C::TILE;                                     // dv rows, then dxkv
     float* sStat2 = reinterpret_cast<float*>(buf1 + C::TILE);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cw = wave % NWV, tb0 = (wave / NWV) * RB, th = wave / NWV;
     const long M = a.M, m0 = (long)blockIdx.x * TOK;
     const int nvalid = (int)min((long)TOK, M - m0);
-    const bf16_t* dkv = (const bf16_t*)a.dkv + m0 * (2 * D);
+    const h16_t* dkv = (const h16_t*)a.dkv + m0 * (2 * D);
 
     WRing<PD> ring;
-    ring_fill<PD>((const bf16_t*)a.WkvT, 2 * KS, 0, cw, ring);
+    ring_fill<PD>((const h16_t*)a.WkvT, 2 * KS, 0, cw, ring);
     uint4 rr[TOK * C::C8 / C::NT];
     rows_request<C>(dkv, 2 * D, nvalid, rr);
     rows_commit<C>(buf0, rr);
@@ -1189,39 +1188,39 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_bwd_rows_kernel(V
     __syncthreads();
     f32x16_t acc[RB];
     zero<RB>(acc);
-    gemm_unit<RB, KS, PD>((const bf16_t*)a.WkvT, 2 * KS, 0, cw, buf0, ALD, tb0, acc, ring);
-    ring_fill<PD>((const bf16_t*)a.WkvT, 2 * KS, KS, cw, ring);
+    gemm_unit<RB, KS, PD>((const h16_t*)a.WkvT, 2 * KS, 0, cw, buf0, ALD, tb0, acc, ring);
+    ring_fill<PD>((const h16_t*)a.WkvT, 2 * KS, KS, cw, ring);
     rows_commit<C>(buf1, rr);
-    rows_request<C>((const bf16_t*)a.xkv + m0 * D, D, nvalid, rr);  // the LayerNorm's input rows, behind the second product
+    rows_request<C>((const h16_t*)a.xkv + m0 * D, D, nvalid, rr);  // the LayerNorm's input rows, behind the second product
     __syncthreads();                                                  // (every wave is done with the dk tile)
-    gemm_unit<RB, KS, PD>((const bf16_t*)a.WkvT, 2 * KS, KS, cw, buf1, ALD, tb0, acc, ring);
+    gemm_unit<RB, KS, PD>((const h16_t*)a.WkvT, 2 * KS, KS, cw, buf1, ALD, tb0, acc, ring);
     rows_commit<C>(buf0, rr);
-    // the unfused path stores dnk as bf16 before the LayerNorm backward: round the same way
+    // the unfused path stores dnk as h16 before the LayerNorm backward: round the same way
 #pragma unroll
     for (int i = 0; i < RB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = bf16_to_f32(f32_to_bf16(acc[i][r]));
+        for (int r = 0; r < 16; ++r) acc[i][r] = h16_to_f32(f32_to_h16(acc[i][r]));
     __syncthreads();
     f32x16_t xr[RB];
     tile_to_acc<D, RB>(buf0, ALD, xr);
     layernorm_bwd<D, RB, true>(acc, xr, a.mean + m0, a.rstd + m0, a.lnkv_g, sStat2, a.pgrad_kv + ((size_t)blockIdx.x * TH + th) * 2 * D, nvalid);
     // (the barrier inside: every wave has finished the dv tile and read its x rows)
-    if (cw < 2) ring_fill<PD>((const bf16_t*)a.W2T, KS, 0, cw, ring);      // (not earlier: 16 more live registers across the LayerNorm spill)
+    if (cw < 2) ring_fill<PD>((const h16_t*)a.W2T, KS, 0, cw, ring);      // (not earlier: 16 more live registers across the LayerNorm spill)
     acc_to_tile<D, RB>(acc, buf1, ALD);
     __syncthreads();
-    tile_store_rows<C>(buf1, (bf16_t*)a.dxkv + m0 * D, D, nvalid);
-    // ---- da1 = dxkv . W2 (64 hidden channels: the waves of channel blocks 0 and 1), bf16 like the unfused dgrad output
+    tile_store_rows<C>(buf1, (h16_t*)a.dxkv + m0 * D, D, nvalid);
+    // ---- da1 = dxkv . W2 (64 hidden channels: the waves of channel blocks 0 and 1), h16 like the unfused dgrad output
     if (cw < 2) {
         zero<RB>(acc);
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.W2T, KS, 0, cw, buf1, ALD, tb0, acc, ring);
-        bf16_t* slice = buf0 + wave * (RB * 1024);                   // wave-private; the x rows are in registers since the barriers above
-        acc_to_slice_bf16<RB>(slice, acc);
-        slice_bf16_store_rows<RB>(slice, (bf16_t*)a.da1 + (m0 + tb0 * 32) * 64 + 32 * cw, 64, nvalid - tb0 * 32);
+        gemm_unit<RB, KS, PD>((const h16_t*)a.W2T, KS, 0, cw, buf1, ALD, tb0, acc, ring);
+        h16_t* slice = buf0 + wave * (RB * 1024);                   // wave-private; the x rows are in registers since the barriers above
+        acc_to_slice_h16<RB>(slice, acc);
+        slice_h16_store_rows<RB>(slice, (h16_t*)a.da1 + (m0 + tb0 * 32) * 64 + 32 * cw, 64, nvalid - tb0 * 32);
     }
 }
 // ================================================================================================ K / V producer, forward (any D)
 // adapter_kv_fwd_kernel of sa_layer.hip (D = 256) on this file's building blocks, for the widths it does not cover (D = 384, BASELINE
-// config 4): Linear(C, 64) + LayerNorm(64) + ReLU in VALU (8 lanes per point) -> LDS -> . W2 (K = 64) + bias, rounded to bf16 as the
+// config 4): Linear(C, 64) + LayerNorm(64) + ReLU in VALU (8 lanes per point) -> LDS -> . W2 (K = 64) + bias, rounded to h16 as the
 // unfused path stores it -> kv LayerNorm -> LDS -> . Wk | . Wv; a1, xkv, nk and k | v leave as whole rows.  Same arithmetic, same
 // rounding points.
 template <int D, int RB, int TH, int MINW>
@@ -1229,10 +1228,10 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_fwd_rows_kernel(V
 {
     using C = Cfg<D, RB, TH>;
     constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, PD = C::PD, A1LD = 72;
-    extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-    bf16_t* sA1 = lds;                                               // [TOK][A1LD] hidden layer
-    bf16_t* sX = lds + TOK * A1LD;                                   // [TOK][ALD]  per-point embedding, then the k / v halves on their way out
-    bf16_t* actA = sX + C::TILE;                                     // [TOK][ALD]  normalised embedding
+    extern __shared__ __attribute__((aligned(16))) h16_t lds[];
+    h16_t* sA1 = lds;                                               // [TOK][A1LD] hidden layer
+    h16_t* sX = lds + TOK * A1LD;                                   // [TOK][ALD]  per-point embedding, then the k / v halves on their way out
+    h16_t* actA = sX + C::TILE;                                     // [TOK][ALD]  normalised embedding
     float2* sPair = reinterpret_cast<float2*>(actA + C::TILE);       // [TOK][NWV]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cw = wave % NWV, tb0 = (wave / NWV) * RB;
@@ -1241,7 +1240,7 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_fwd_rows_kernel(V
     const int Cin = a.C;
 
     WRing<PD> ring;
-    ring_fill<PD>((const bf16_t*)a.Wkv, KS, 0, cw, ring);
+    ring_fill<PD>((const h16_t*)a.Wkv, KS, 0, cw, ring);
     // ---- hidden layer: thread = (token, 8 of the 64 channels); LayerNorm over the token's 8 threads (lanes ^1 ^2 ^4)
     {
         const int tid_ = fresh_tid();
@@ -1270,27 +1269,27 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_fwd_rows_kernel(V
             for (int k = 0; k < 4; ++k) {
                 const float lo = fmaxf(h[2 * k] * rs * a.ln_g[cg + 2 * k] + a.ln_b[cg + 2 * k], 0.f);
                 const float hi = fmaxf(h[2 * k + 1] * rs * a.ln_g[cg + 2 * k + 1] + a.ln_b[cg + 2 * k + 1], 0.f);
-                w[k] = pack_bf16x2(lo, hi);
+                w[k] = pack_h16x2(lo, hi);
             }
             const uint4 v4 = make_uint4(w[0], w[1], w[2], w[3]);
             *reinterpret_cast<uint4*>(sA1 + tok * A1LD + cg) = v4;
-            if (ok) *reinterpret_cast<uint4*>((bf16_t*)a.a1 + (size_t)(m0 + tok) * 64 + cg) = v4;
+            if (ok) *reinterpret_cast<uint4*>((h16_t*)a.a1 + (size_t)(m0 + tok) * 64 + cg) = v4;
         }
     }
     __syncthreads();
-    // ---- per-point embedding = hidden . W2^T + b2 (K = 64: four k-steps), rounded to bf16, then the kv LayerNorm
+    // ---- per-point embedding = hidden . W2^T + b2 (K = 64: four k-steps), rounded to h16, then the kv LayerNorm
     f32x16_t acc[RB];
     zero<RB>(acc);
     {
         const unsigned lane = fresh_tid() & 63;
         const uint4* w0 = reinterpret_cast<const uint4*>(a.W2) + (size_t)cw * 4 * 64 + lane;
-        const bf16_t* xrow = sA1 + (tb0 * 32 + (lane & 31)) * A1LD + 8 * (lane >> 5);
+        const h16_t* xrow = sA1 + (tb0 * 32 + (lane & 31)) * A1LD + 8 * (lane >> 5);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, w0[ks * 64]);
+            const h16x8_t af = __builtin_bit_cast(h16x8_t, w0[ks * 64]);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xrow + i * 32 * A1LD + ks * 16)), acc[i], 0, 0, 0);
+                acc[i] = vpf_mfma32(af, __builtin_bit_cast(h16x8_t, *reinterpret_cast<const uint4*>(xrow + i * 32 * A1LD + ks * 16)), acc[i]);
         }
     }
     {
@@ -1302,29 +1301,29 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) adapter_kv_fwd_rows_kernel(V
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
                 uint2 u;
-                u.x = pack_bf16x2(acc[i][4 * g + 0] + b2.x, acc[i][4 * g + 1] + b2.y);
-                u.y = pack_bf16x2(acc[i][4 * g + 2] + b2.z, acc[i][4 * g + 3] + b2.w);
+                u.x = pack_h16x2(acc[i][4 * g + 0] + b2.x, acc[i][4 * g + 1] + b2.y);
+                u.y = pack_h16x2(acc[i][4 * g + 2] + b2.z, acc[i][4 * g + 3] + b2.w);
                 *reinterpret_cast<uint2*>(sX + ((tb0 + i) * 32 + t) * ALD + c) = u;
-                acc[i][4 * g + 0] = __uint_as_float(u.x << 16); acc[i][4 * g + 1] = __uint_as_float(u.x & 0xffff0000u);
-                acc[i][4 * g + 2] = __uint_as_float(u.y << 16); acc[i][4 * g + 3] = __uint_as_float(u.y & 0xffff0000u);
+                acc[i][4 * g + 0] = h16_lo(u.x); acc[i][4 * g + 1] = h16_hi(u.x);
+                acc[i][4 * g + 2] = h16_lo(u.y); acc[i][4 * g + 3] = h16_hi(u.y);
             }
         }
     }
     layernorm<D, RB>(acc, a.lnkv_g, a.lnkv_b, sPair, a.mean + m0, a.rstd + m0, nvalid);
     acc_to_tile<D, RB>(acc, actA, ALD);
     __syncthreads();
-    tile_store_rows<C>(sX, (bf16_t*)a.xkv + m0 * D, D, nvalid);
-    tile_store_rows<C>(actA, (bf16_t*)a.nk + m0 * D, D, nvalid);
+    tile_store_rows<C>(sX, (h16_t*)a.xkv + m0 * D, D, nvalid);
+    tile_store_rows<C>(actA, (h16_t*)a.nk + m0 * D, D, nvalid);
     // ---- K | V = normalised . Wkv^T: two D-channel halves, each staged in sX and stored as whole half rows
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
         zero<RB>(acc);
-        gemm_unit<RB, KS, PD>((const bf16_t*)a.Wkv, KS, 0, part * NWV + cw, actA, ALD, tb0, acc, ring);
-        if (part == 0) ring_fill<PD>((const bf16_t*)a.Wkv, KS, 0, NWV + cw, ring);
+        gemm_unit<RB, KS, PD>((const h16_t*)a.Wkv, KS, 0, part * NWV + cw, actA, ALD, tb0, acc, ring);
+        if (part == 0) ring_fill<PD>((const h16_t*)a.Wkv, KS, 0, NWV + cw, ring);
         __syncthreads();                                             // the row pass that read sX last is done
         acc_to_tile<D, RB>(acc, sX, ALD);
         __syncthreads();
-        tile_store_rows<C>(sX, (bf16_t*)a.kv + m0 * (2 * D) + part * D, 2 * D, nvalid);
+        tile_store_rows<C>(sX, (h16_t*)a.kv + m0 * (2 * D) + part * D, 2 * D, nvalid);
     }
 }
 template <int D, int RB, int MINW>

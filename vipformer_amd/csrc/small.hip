@@ -21,11 +21,11 @@ __device__ __forceinline__ float gelu_grad_f(float x)
 }
 
 // =============================================================================== adapter front: Linear(C,64) -> LN(64) -> ReLU
-// wave per row (grid-stride), lane = channel.  out bf16 [M,64] feeds the 64->D MFMA GEMM.
+// wave per row (grid-stride), lane = channel.  out h16 [M,64] feeds the 64->D MFMA GEMM.
 #define AD_MAXC 8
 __global__ void __launch_bounds__(256) adapter_front_fwd_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W,
                                                               const float* __restrict__ b, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, bf16_t* __restrict__ out)
+                                                              const float* __restrict__ beta, h16_t* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
@@ -48,26 +48,26 @@ __global__ void __launch_bounds__(256) adapter_front_fwd_kernel(const float* __r
             const float mu = wave_sum(h[u]) * (1.f / 64.f);
             const float d = h[u] - mu;
             const float rs = rsqrtf(wave_sum(d * d) * (1.f / 64.f) + 1e-5f);
-            if (r0 + u < M) out[(size_t)(r0 + u) * 64 + lane] = f32_to_bf16(fmaxf(d * rs * ga + be, 0.f));
+            if (r0 + u < M) out[(size_t)(r0 + u) * 64 + lane] = f32_to_h16(fmaxf(d * rs * ga + be, 0.f));
         }
     }
 }
 extern "C" int vpf_adapter_front_fwd(const float* x, long M, int C, const float* W, const float* b, const float* gamma,
-                                     const float* beta, void* out_bf16, void* stream)
+                                     const float* beta, void* out_h16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !W || !b || !gamma || !beta || !out_bf16) return VPF_ERR_NULL;
+    if (!x || !W || !b || !gamma || !beta || !out_h16) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
-    hipLaunchKernelGGL(adapter_front_fwd_kernel, dim3(grid_for(M, 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, gamma, beta, (bf16_t*)out_bf16);
+    hipLaunchKernelGGL(adapter_front_fwd_kernel, dim3(grid_for(M, 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, gamma, beta, (h16_t*)out_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-// da (bf16 [M,64]) -> dW[64,C] += , db[64] +=, dgamma[64] +=, dbeta[64] +=   (input needs no grad)
+// da (h16 [M,64]) -> dW[64,C] += , db[64] +=, dgamma[64] +=, dbeta[64] +=   (input needs no grad)
 // CT = the compile-time bound of the input-channel loops: 3 for xyz clouds (the loops over AD_MAXC = 8 channels with a run-time C spent
 // a fifth of the kernel's instructions on five channels that do not exist), AD_MAXC otherwise
 template <int CT>
-__global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
+__global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __restrict__ x, const h16_t* __restrict__ da, long M, int C,
                                                               const float* __restrict__ W, const float* __restrict__ b,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               float* __restrict__ partial)
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) adapter_front_bwd_kernel(const float* __r
             h[u] = bb;
 #pragma unroll
             for (int j = 0; j < CT; ++j) { xv[u][j] = ((CT < AD_MAXC || j < C) && ok) ? x[(size_t)r * C + j] : 0.f; h[u] += w[j] * xv[u][j]; }
-            gin[u] = ok ? bf16_to_f32(da[(size_t)r * 64 + lane]) : 0.f;
+            gin[u] = ok ? h16_to_f32(da[(size_t)r * 64 + lane]) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -152,53 +152,53 @@ int vpf_adapter_front_fold(const float* partial, int nblk, int C, float* dW, flo
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b,
+extern "C" int vpf_adapter_front_bwd(const float* x, const void* da_h16, long M, int C, const float* W, const float* b,
                                      const float* gamma, const float* beta, float* dW, float* db, float* dgamma, float* dbeta,
                                      float* ws, long ws_floats, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !da_bf16 || !W || !b || !gamma || !beta || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
+    if (!x || !da_h16 || !W || !b || !gamma || !beta || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
     constexpr int ROW = 64 * (3 + AD_MAXC);
     int nblk = grid_for(M, 64, 2048);
     if ((long)nblk * ROW > ws_floats) nblk = (int)(ws_floats / ROW);
     if (nblk < 1) return VPF_ERR_BADSHAPE;
-    if (C == 3) hipLaunchKernelGGL(adapter_front_bwd_kernel<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, gamma, beta, ws);
-    else hipLaunchKernelGGL(adapter_front_bwd_kernel<AD_MAXC>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const bf16_t*)da_bf16, M, C, W, b, gamma, beta, ws);
+    if (C == 3) hipLaunchKernelGGL(adapter_front_bwd_kernel<3>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const h16_t*)da_h16, M, C, W, b, gamma, beta, ws);
+    else hipLaunchKernelGGL(adapter_front_bwd_kernel<AD_MAXC>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, (const h16_t*)da_h16, M, C, W, b, gamma, beta, ws);
     hipLaunchKernelGGL(adapter_front_fold_kernel, dim3(3 + AD_MAXC, 8), dim3(1024), 0, (hipStream_t)stream, (const float*)ws, nblk, C, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 
 // =============================================================================== generic tiny-K front: y = act(x W^T + b), x f32 [M,C<=8], W [N,C]
-// act 0 = none, 1 = GELU.  out bf16 [M,N].  (position_emb[0:2]: C=3, N=128, GELU)
+// act 0 = none, 1 = GELU.  out h16 [M,N].  (position_emb[0:2]: C=3, N=128, GELU)
 __global__ void smallk_fwd_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W, const float* __restrict__ b,
-                                  int N, int act, bf16_t* __restrict__ out)
+                                  int N, int act, h16_t* __restrict__ out)
 {
     const long total = M * N;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int n = (int)(i % N); const long m = i / N;
         float u = b[n];
         for (int j = 0; j < C; ++j) u += W[n * C + j] * x[(size_t)m * C + j];
-        out[i] = f32_to_bf16(act == 1 ? gelu_f(u) : u);
+        out[i] = f32_to_h16(act == 1 ? gelu_f(u) : u);
     }
 }
-extern "C" int vpf_smallk_fwd(const float* x, long M, int C, const float* W, const float* b, int N, int act, void* out_bf16, void* stream)
+extern "C" int vpf_smallk_fwd(const float* x, long M, int C, const float* W, const float* b, int N, int act, void* out_h16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !W || !b || !out_bf16) return VPF_ERR_NULL;
+    if (!x || !W || !b || !out_h16) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > 8 || N <= 0) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
-    hipLaunchKernelGGL(smallk_fwd_kernel, dim3(grid_for(M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, N, act, (bf16_t*)out_bf16);
+    hipLaunchKernelGGL(smallk_fwd_kernel, dim3(grid_for(M * N, 256)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, N, act, (h16_t*)out_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-// dy bf16 [M,N] -> dW[N,C] +=, db[N] +=.   thread = output channel n, block = row slab
+// dy h16 [M,N] -> dW[N,C] +=, db[N] +=.   thread = output channel n, block = row slab
 // block = bx output channels x 8 row lanes (blockDim = (bx, 8)); a block owns `rows_per_block` rows, row lane rl walks rows
 // r0 + rl, r0 + rl + 8, ... four at a time; the 8 row lanes meet in LDS and ONE atomic per value and block leaves the CU
 // (one thread per channel walking the whole slab, and hundreds of blocks adding into the same addresses, was 10x slower)
-__global__ void __launch_bounds__(1024) smallk_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, long M, int C,
+__global__ void __launch_bounds__(1024) smallk_bwd_kernel(const float* __restrict__ x, const h16_t* __restrict__ dy, long M, int C,
                                                          const float* __restrict__ W, const float* __restrict__ b, int N, int act,
                                                          float* __restrict__ dW, float* __restrict__ db, int rows_per_block)
 {
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(1024) smallk_bwd_kernel(const float* __restric
     for (long r = r0 + rl; r < r1; r += 32) {
         float gv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gv[q] = (nok && r + 8 * q < r1) ? bf16_to_f32(dy[(size_t)(r + 8 * q) * N + n]) : 0.f;
+        for (int q = 0; q < 4; ++q) gv[q] = (nok && r + 8 * q < r1) ? h16_to_f32(dy[(size_t)(r + 8 * q) * N + n]) : 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long rr = r + 8 * q < r1 ? r + 8 * q : r1 - 1;
@@ -249,11 +249,11 @@ __global__ void __launch_bounds__(1024) smallk_bwd_kernel(const float* __restric
         for (int j = 0; j < 8; ++j) if (j < C) atomicAdd(dW + n * C + j, tw[j]);
     }
 }
-extern "C" int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C, const float* W, const float* b, int N, int act,
+extern "C" int vpf_smallk_bwd(const float* x, const void* dy_h16, long M, int C, const float* W, const float* b, int N, int act,
                               float* dW, float* db, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !dy_bf16 || !W || !b || !dW || !db) return VPF_ERR_NULL;
+    if (!x || !dy_h16 || !W || !b || !dW || !db) return VPF_ERR_NULL;
     if (M < 0 || C <= 0 || C > 8 || N <= 0) return VPF_ERR_BADSHAPE;
     if (M == 0) return VPF_OK;
     // ~100 row blocks: with 24 (512 rows each) the kernel ran on 24 CUs and took 51 us for 12 k rows; with many more the
@@ -264,7 +264,7 @@ extern "C" int vpf_smallk_bwd(const float* x, const void* dy_bf16, long M, int C
     while ((M + rpb - 1) / rpb > 4096) rpb *= 2;
     const int bx = N >= 128 ? 128 : 64;
     dim3 grid(vpf_cdiv(N, bx), (unsigned)((M + rpb - 1) / rpb));
-    hipLaunchKernelGGL(smallk_bwd_kernel, grid, dim3(bx, 8), 0, (hipStream_t)stream, x, (const bf16_t*)dy_bf16, M, C, W, b, N, act, dW, db, rpb);
+    hipLaunchKernelGGL(smallk_bwd_kernel, grid, dim3(bx, 8), 0, (hipStream_t)stream, x, (const h16_t*)dy_h16, M, C, W, b, N, act, dW, db, rpb);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -516,7 +516,7 @@ extern "C" int vpf_bn_partials_finalize(const float* partials, int nrows, int C,
 
 __global__ void __launch_bounds__(256) g2e_conv1_apply_kernel(const float* __restrict__ x, long M, int C, const float* __restrict__ W,
                                                             const float* __restrict__ b, const float* __restrict__ stat,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ out)
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, h16_t* __restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const long wave0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
@@ -536,16 +536,16 @@ __global__ void __launch_bounds__(256) g2e_conv1_apply_kernel(const float* __res
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (r0 + u < M) out[(size_t)(r0 + u) * 64 + lane] = f32_to_bf16(fmaxf((h[u] - mu) * rs * ga + be, 0.f));
+            if (r0 + u < M) out[(size_t)(r0 + u) * 64 + lane] = f32_to_h16(fmaxf((h[u] - mu) * rs * ga + be, 0.f));
     }
 }
 extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W, const float* b, const float* stat, const float* gamma,
-                                   const float* beta, void* out_bf16, void* stream)
+                                   const float* beta, void* out_h16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !W || !b || !stat || !gamma || !beta || !out_bf16) return VPF_ERR_NULL;
+    if (!x || !W || !b || !stat || !gamma || !beta || !out_h16) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > AD_MAXC) return VPF_ERR_BADSHAPE;
-    hipLaunchKernelGGL(g2e_conv1_apply_kernel, dim3(grid_for(M, 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, stat, gamma, beta, (bf16_t*)out_bf16);
+    hipLaunchKernelGGL(g2e_conv1_apply_kernel, dim3(grid_for(M, 64, 2048)), dim3(256), 0, (hipStream_t)stream, x, M, C, W, b, stat, gamma, beta, (h16_t*)out_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -557,7 +557,7 @@ extern "C" int vpf_g2e_conv1_apply(const float* x, long M, int C, const float* W
 //   dW_ci = gamma_c rs_c (S_gx[i] - S_g / M S1[i] - S_gxh / M sum_r xh_c x_i),   db_c = 0,   dgamma_c = S_gxh,   dbeta_c = S_g.
 // (The two-pass form -- statistics, then dh -- read the 50 MB gradient twice: 2 x 117 us of the point-cloud branch's tail.)
 // thread = (row, 8 channels): 16-byte loads of the incoming gradient, four rows in flight, per-thread partial sums, LDS fold per block.
-__global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ da, long M, int C,
+__global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restrict__ x, const h16_t* __restrict__ da, long M, int C,
                                                           const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ stat,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ partial)
@@ -582,7 +582,7 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restr
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xh = wr[j][0] * x0 + wr[j][1] * x1 + wr[j][2] * x2 + br[j];
-            float g = (j & 1) ? __uint_as_float(uw[j >> 1] & 0xffff0000u) : __uint_as_float(uw[j >> 1] << 16);
+            float g = (j & 1) ? h16_hi(uw[j >> 1]) : h16_lo(uw[j >> 1]);
             if (xh * ga[j] + be[j] <= 0.f) g = 0.f;
             a0[j] += g; a1[j] += g * xh; aw[j][0] += g * x0; aw[j][1] += g * x1; aw[j][2] += g * x2;
         }
@@ -623,20 +623,20 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_kernel(const float* __restr
     }
 }
 // The same sums with the second conv's input gradient folded in: da = dh2 . W2 (Conv1d(64, 128) backward, K = 128) is produced on the
-// matrix cores from dh2 rows read straight from HBM in A-fragment layout and consumed in the accumulator registers -- the 50 MB bf16
+// matrix cores from dh2 rows read straight from HBM in A-fragment layout and consumed in the accumulator registers -- the 50 MB h16
 // da tensor is neither written nor read (a 42 us GEMM + a 55 us sums pass -> one pass over dh2).  A wave owns 32 rows x 64 channels per
 // iteration; in the accumulator layout a lane owns ONE channel per 32-channel tile (column = lane & 31) and 16 of the 32 rows, so the
 // five per-channel sums are plain per-lane accumulations; the rows' inputs x sit in a wave-private LDS slot.
-typedef __attribute__((ext_vector_type(8))) __bf16 g2e_bf16x8_t;
+typedef h16x8_t g2e_h16x8_t;
 typedef __attribute__((ext_vector_type(16))) float g2e_f32x16_t;
-__global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dh2, long M, int C,
+__global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* __restrict__ x, const h16_t* __restrict__ dh2, long M, int C,
                                                                 const float* __restrict__ W, const float* __restrict__ b,
                                                                 const float* __restrict__ stat, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, const bf16_t* __restrict__ W2,
+                                                                const float* __restrict__ beta, const h16_t* __restrict__ W2,
                                                                 float* __restrict__ partial)
 {
     __shared__ float redf[4 * 320];              // [4 waves][5 values][64 channels]
-    __shared__ __attribute__((aligned(16))) bf16_t sW2[128 * 72];     // W2 [128 out][64 in], rows padded to 72
+    __shared__ __attribute__((aligned(16))) h16_t sW2[128 * 72];     // W2 [128 out][64 in], rows padded to 72
     __shared__ float sAccAll[4 * 16 * 64];                            // per wave: the accumulator tile [16][64] f32
     __shared__ float4 sXrow[4][32];                                   // per wave: the current tile's input rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cl = lane & 31, hl = lane >> 5;
@@ -649,14 +649,14 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* _
     typedef __attribute__((ext_vector_type(4))) short s16x4_t;
     typedef __attribute__((ext_vector_type(8))) short s16x8_t;
     const int g16 = lane >> 4, i16 = lane & 15;
-    const bf16_t* wfrag = sW2 + (8 * (g16 >> 1) + (i16 >> 2)) * 72 + 16 * (g16 & 1) + 4 * (i16 & 3);
+    const h16_t* wfrag = sW2 + (8 * (g16 >> 1) + (i16 >> 2)) * 72 + 16 * (g16 & 1) + 4 * (i16 & 3);
     auto bfrag = [&](int j, int ks) {
-        const bf16_t* a0p = wfrag + ks * 16 * 72 + 32 * j;
+        const h16_t* a0p = wfrag + ks * 16 * 72 + 32 * j;
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0p));
         const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(a0p + 4 * 72));
         s16x8_t v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        return __builtin_bit_cast(g2e_bf16x8_t, v);
+        return __builtin_bit_cast(g2e_h16x8_t, v);
     };
     float* sAcc = sAccAll + wave * 16 * 64;
     float wr[2][3], br[2], ga[2], be[2];
@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* _
     uint4 af[8]; float4 xr0;
     auto load_tile = [&](long tile) {                             // A fragments straight from HBM: row = lane & 31, 8 values at k = 16 ks + 8 hl
         const long rr = min(min(tile, ntiles - 1) * 32 + cl, M - 1);      // (rows / tiles past the end: clamped loads, their gradient is zeroed below)
-        const bf16_t* src = dh2 + (size_t)rr * 128 + 8 * hl;
+        const h16_t* src = dh2 + (size_t)rr * 128 + 8 * hl;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) af[ks] = *reinterpret_cast<const uint4*>(src + ks * 16);
         const float* xp = x + (size_t)rr * C;
@@ -691,9 +691,9 @@ __global__ void __launch_bounds__(256) g2e_conv1_bwd_fused_kernel(const float* _
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const g2e_bf16x8_t a = __builtin_bit_cast(g2e_bf16x8_t, af[ks]);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag(0, ks), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag(1, ks), acc[1], 0, 0, 0);
+            const g2e_h16x8_t a = __builtin_bit_cast(g2e_h16x8_t, af[ks]);
+            acc[0] = vpf_mfma32(a, bfrag(0, ks), acc[0]);
+            acc[1] = vpf_mfma32(a, bfrag(1, ks), acc[1]);
         }
         load_tile(tile + tstep);                                  // the next tile's rows travel under this tile's per-row arithmetic
 #pragma unroll
@@ -772,12 +772,12 @@ __global__ void g2e_conv1_grads_kernel(const float* __restrict__ sums, const flo
         dW[c * C + i] += (float)(ga * rs * v);
     }
 }
-extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, int C, const float* W, const float* b, const float* stat,
+extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_h16, long M, int C, const float* W, const float* b, const float* stat,
                                  const float* gamma, const float* beta, int training, const float* mom, float* dW, float* db,
                                  float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!x || !da_bf16 || !W || !b || !stat || !gamma || !beta || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
+    if (!x || !da_h16 || !W || !b || !stat || !gamma || !beta || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
     if (training && !mom) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > 3) return VPF_ERR_BADSHAPE;
     int grid = grid_for(M, 32 * 4, 1024);
@@ -785,29 +785,29 @@ extern "C" int vpf_g2e_conv1_bwd(const float* x, const void* da_bf16, long M, in
     if (grid < 1) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
     float* sums = ws + (size_t)grid * 320;
-    hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(256), 0, st, x, (const bf16_t*)da_bf16, M, C, W, b, stat, gamma, beta, ws);
+    hipLaunchKernelGGL(g2e_conv1_bwd_kernel, dim3(grid), dim3(256), 0, st, x, (const h16_t*)da_h16, M, C, W, b, stat, gamma, beta, ws);
     hipLaunchKernelGGL(g2e_conv1_fold_kernel, dim3(10), dim3(1024), 0, st, (const float*)ws, grid, sums);
     hipLaunchKernelGGL(g2e_conv1_grads_kernel, dim3(1), dim3(64), 0, st, (const float*)sums, mom, M, C, W, b, stat, gamma, training, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
 
-extern "C" int vpf_g2e_conv1_bwd_fused(const float* x, const void* dh2_bf16, long M, int C, const float* W, const float* b, const float* stat,
-                                       const float* gamma, const float* beta, int training, const float* mom, const void* W2_bf16,
+extern "C" int vpf_g2e_conv1_bwd_fused(const float* x, const void* dh2_h16, long M, int C, const float* W, const float* b, const float* stat,
+                                       const float* gamma, const float* beta, int training, const float* mom, const void* W2_h16,
                                        float* dW, float* db, float* dgamma, float* dbeta, float* ws, long ws_floats, void* stream)
 {
     (void)hipGetLastError();
-    if (!x || !dh2_bf16 || !W || !b || !stat || !gamma || !beta || !W2_bf16 || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
+    if (!x || !dh2_h16 || !W || !b || !stat || !gamma || !beta || !W2_h16 || !dW || !db || !dgamma || !dbeta || !ws) return VPF_ERR_NULL;
     if (training && !mom) return VPF_ERR_NULL;
     if (M <= 0 || C <= 0 || C > 3) return VPF_ERR_BADSHAPE;
-    if ((uintptr_t)dh2_bf16 & 15) return VPF_ERR_BADALIGN;
+    if ((uintptr_t)dh2_h16 & 15) return VPF_ERR_BADALIGN;
     int grid = grid_for(M, 32 * 4 * 3, 1024);
     if ((long)(grid + 1) * 320 > ws_floats) grid = (int)(ws_floats / 320) - 1;
     if (grid < 1) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
     float* sums = ws + (size_t)grid * 320;
-    hipLaunchKernelGGL(g2e_conv1_bwd_fused_kernel, dim3(grid), dim3(256), 0, st, x, (const bf16_t*)dh2_bf16, M, C, W, b, stat, gamma, beta,
-                       (const bf16_t*)W2_bf16, ws);
+    hipLaunchKernelGGL(g2e_conv1_bwd_fused_kernel, dim3(grid), dim3(256), 0, st, x, (const h16_t*)dh2_h16, M, C, W, b, stat, gamma, beta,
+                       (const h16_t*)W2_h16, ws);
     hipLaunchKernelGGL(g2e_conv1_fold_kernel, dim3(10), dim3(1024), 0, st, (const float*)ws, grid, sums);
     hipLaunchKernelGGL(g2e_conv1_grads_kernel, dim3(1), dim3(64), 0, st, (const float*)sums, mom, M, C, W, b, stat, gamma, training, dW, db, dgamma, dbeta);
     VPF_CHECK_LAUNCH();
@@ -815,9 +815,9 @@ extern "C" int vpf_g2e_conv1_bwd_fused(const float* x, const void* dh2_bf16, lon
 }
 
 // =============================================================================== patchify  'b (h p1) (w p2) c -> b (h w) (p1 p2 c)'
-// imgs is an arbitrary-stride [B,H,W,3] view (pretrain.py:179 hands a permuted NCHW tensor); out bf16 [B*T, p*p*3]
+// imgs is an arbitrary-stride [B,H,W,3] view (pretrain.py:179 hands a permuted NCHW tensor); out h16 [B*T, p*p*3]
 __global__ void patchify_kernel(const float* __restrict__ img, long sb, long sh, long sw, long sc, int B, int Hh, int Ww, int Cc, int p,
-                                bf16_t* __restrict__ out)
+                                h16_t* __restrict__ out)
 {
     const int wp = Ww / p, hp = Hh / p, pd = p * p * Cc;
     const long total = (long)B * hp * wp * pd;
@@ -825,16 +825,16 @@ __global__ void patchify_kernel(const float* __restrict__ img, long sb, long sh,
         const int e = (int)(i % pd); const long tok = i / pd;
         const int c = e % Cc, p2 = (e / Cc) % p, p1 = e / (Cc * p);
         const int tw = (int)(tok % wp), th = (int)((tok / wp) % hp); const long b = tok / ((long)wp * hp);
-        out[i] = f32_to_bf16(img[b * sb + (long)(th * p + p1) * sh + (long)(tw * p + p2) * sw + c * sc]);
+        out[i] = f32_to_h16(img[b * sb + (long)(th * p + p1) * sh + (long)(tw * p + p2) * sw + c * sc]);
     }
 }
 // One block per (image, row of patches): the p image rows x W x C slab is read with the thread on the w axis (contiguous
 // in the NCHW memory the loader hands over), re-ordered in LDS into the token-major output order and written back with
 // 16-byte stores (the slab's tokens are one contiguous piece of the output).  8 loads in flight per thread.
 __global__ void __launch_bounds__(256) patchify_rows_kernel(const float* __restrict__ img, long sb, long sh, long sw, long sc, int Hh, int Ww,
-                                                           int Cc, int p, bf16_t* __restrict__ out)
+                                                           int Cc, int p, h16_t* __restrict__ out)
 {
-    extern __shared__ bf16_t tile[];                 // [wp][p*p*Cc]
+    extern __shared__ h16_t tile[];                 // [wp][p*p*Cc]
     const int wp = Ww / p, hp = Hh / p, pd = p * p * Cc;
     const int b = blockIdx.x / hp, th = blockIdx.x % hp;
     const float* base = img + (long)b * sb + (long)(th * p) * sh;
@@ -851,7 +851,7 @@ __global__ void __launch_bounds__(256) patchify_rows_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int pl = pl0 + u;
-                if (pl < npl) { const int c = pl / p, p1 = pl % p; tile[tw * pd + (p1 * p + p2) * Cc + c] = f32_to_bf16(v[u]); }
+                if (pl < npl) { const int c = pl / p, p1 = pl % p; tile[tw * pd + (p1 * p + p2) * Cc + c] = f32_to_h16(v[u]); }
             }
         }
     }
@@ -861,17 +861,17 @@ __global__ void __launch_bounds__(256) patchify_rows_kernel(const float* __restr
     const uint4* src = reinterpret_cast<const uint4*>(tile);
     for (int e = threadIdx.x; e < nchunk; e += blockDim.x) dst[e] = src[e];
 }
-extern "C" int vpf_patchify(const float* img, long sb, long sh, long sw, long sc, int B, int H, int W, int C, int p, void* out_bf16, void* stream)
+extern "C" int vpf_patchify(const float* img, long sb, long sh, long sw, long sc, int B, int H, int W, int C, int p, void* out_h16, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
-    if (!img || !out_bf16) return VPF_ERR_NULL;
+    if (!img || !out_h16) return VPF_ERR_NULL;
     if (B < 0 || H <= 0 || W <= 0 || C <= 0 || p <= 0 || (H % p) || (W % p)) return VPF_ERR_BADSHAPE;
     if (B == 0) return VPF_OK;
-    const size_t lds = sizeof(bf16_t) * (size_t)(W / p) * p * p * C;
-    if ((p * p * C) % 8 == 0 && lds <= 64 * 1024 && (((uintptr_t)out_bf16) & 15) == 0)
-        hipLaunchKernelGGL(patchify_rows_kernel, dim3(B * (H / p)), dim3(256), lds, (hipStream_t)stream, img, sb, sh, sw, sc, H, W, C, p, (bf16_t*)out_bf16);
+    const size_t lds = sizeof(h16_t) * (size_t)(W / p) * p * p * C;
+    if ((p * p * C) % 8 == 0 && lds <= 64 * 1024 && (((uintptr_t)out_h16) & 15) == 0)
+        hipLaunchKernelGGL(patchify_rows_kernel, dim3(B * (H / p)), dim3(256), lds, (hipStream_t)stream, img, sb, sh, sw, sc, H, W, C, p, (h16_t*)out_h16);
     else
-        hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, img, sb, sh, sw, sc, B, H, W, C, p, (bf16_t*)out_bf16);
+        hipLaunchKernelGGL(patchify_kernel, dim3(grid_for((long)B * H * W * C, 256)), dim3(256), 0, (hipStream_t)stream, img, sb, sh, sw, sc, B, H, W, C, p, (h16_t*)out_h16);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -1028,14 +1028,23 @@ extern "C" int vpf_ntxent_bwd(const float* zn, const float* inv_norm, const floa
     return VPF_OK;
 }
 
-// =============================================================================== fused AdamW over a flat buffer (+ bf16 shadow)
-// torch.optim.AdamW semantics (decoupled weight decay, bias correction).  hyper (device, 8 floats):
-// {lr, beta1, beta2, eps, weight_decay, grad_scale, step (float, incremented here), skip_flag}
+// =============================================================================== fused AdamW over a flat buffer (+ h16 shadow)
+// torch.optim.AdamW semantics (decoupled weight decay, bias correction) + torch.cuda.amp.GradScaler's step / update
+// (pretrain.py:154,209-211: scaler.scale(loss).backward(); scaler.step(opt); scaler.update()).  hyper (device, 16 floats):
+//   [0] lr  [1] beta1  [2] beta2  [3] eps  [4] weight_decay  [5] grad_scale (1 / world size)  [6] step (float, incremented here)
+//   [7] skip flag (caller-owned: capture warm-ups)
+//   [8] loss scale S (0: no loss scaling -- gradients are taken as they are)   [9] growth tracker (good steps since the last change)
+//   [10] growth interval (2000)   [11] found_inf (set by vpf_grad_check, cleared here)   [12] growth factor (2)   [13] backoff (0.5)
+//   [14] number of skipped (overflowed) steps so far   [15] 1: g has been unscaled already (GradScaler.unscale_; cleared here)
+// The gradients in `g` carry the factor S; AdamW divides it out.  A step whose gradients hold an inf / NaN is skipped (parameters,
+// moments and the step counter stay put) and S is halved; after `growth interval` good steps in a row S doubles.
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                             bf16_t* __restrict__ shadow, long n, const float* __restrict__ hyper, int zero_grad)
+                             h16_t* __restrict__ shadow, long n, const float* __restrict__ hyper, int zero_grad)
 {
-    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], gs = hyper[5], step = hyper[6] + 1.f;
-    const bool skip = hyper[7] != 0.f;
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], step = hyper[6] + 1.f;
+    const float S = hyper[8];
+    const float gs = (S > 0.f && hyper[15] == 0.f) ? hyper[5] / S : hyper[5];
+    const bool skip = hyper[7] != 0.f || hyper[11] != 0.f;
     const float bc1 = 1.f - powf(b1, step), bc2 = 1.f - powf(b2, step);
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -1049,20 +1058,61 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
             pv -= step_size * mv / (sqrtf(vv) * inv_sqrt_bc2 + eps);
             p[i] = pv;
         }
-        if (shadow) shadow[i] = f32_to_bf16(pv);
+        if (shadow) shadow[i] = f32_to_h16(pv);
         if (zero_grad) g[i] = 0.f;          // optimizer.zero_grad() of the NEXT step (pretrain.py:174) folded in: no 33 MB fill launch
     }
 }
-__global__ void adamw_step_kernel(float* hyper) { if (threadIdx.x == 0 && hyper[7] == 0.f) hyper[6] += 1.f; }
-extern "C" int vpf_adamw_step(float* p, float* g, float* m, float* v, void* shadow_bf16, long n, float* hyper_dev, int advance_step,
+// behind the last AdamW launch of a step: the bias-correction counter and GradScaler.update()
+__global__ void adamw_step_kernel(float* hyper)
+{
+    if (threadIdx.x != 0 || hyper[7] != 0.f) return;                 // (a caller-skipped step changes nothing)
+    const bool inf = hyper[11] != 0.f;
+    if (!inf) hyper[6] += 1.f;
+    if (hyper[8] > 0.f) {
+        if (inf) { hyper[8] *= hyper[13]; hyper[9] = 0.f; hyper[14] += 1.f; }
+        else {
+            hyper[9] += 1.f;
+            if (hyper[9] >= hyper[10]) { hyper[8] *= hyper[12]; hyper[9] = 0.f; }
+        }
+    }
+    hyper[11] = 0.f;
+    hyper[15] = 0.f;
+}
+extern "C" int vpf_adamw_step(float* p, float* g, float* m, float* v, void* shadow_h16, long n, float* hyper_dev, int advance_step,
                               void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!p || !g || !m || !v || !hyper_dev) return VPF_ERR_NULL;
     if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, p, g, m, v, (bf16_t*)shadow_bf16, n, hyper_dev, (advance_step >> 1) & 1);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, p, g, m, v, (h16_t*)shadow_h16, n, hyper_dev, (advance_step >> 1) & 1);
     if (advance_step & 1) hipLaunchKernelGGL(adamw_step_kernel, dim3(1), dim3(64), 0, st, hyper_dev);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
+// GradScaler's overflow check (torch._amp_foreach_non_finite_check_and_unscale_, pretrain.py:210) over the flat gradient: hyper[11] = 1
+// if any element is inf / NaN.  One streaming read (33 MB at c2: ~8 us); every thread that sees one writes the same 1.0f.
+__global__ void grad_check_kernel(const float* __restrict__ g, long n, float* __restrict__ hyper)
+{
+    const long n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    bool bad = false;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 x = g4[i];
+        // |x| < inf is false for inf and NaN alike
+        bad = bad || !(fabsf(x.x) < INFINITY) || !(fabsf(x.y) < INFINITY) || !(fabsf(x.z) < INFINITY) || !(fabsf(x.w) < INFINITY);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) bad = bad || !(fabsf(g[n4 * 4 + threadIdx.x]) < INFINITY);
+    if (bad) hyper[11] = 1.f;
+}
+extern "C" int vpf_grad_check(const float* g, long n, float* hyper_dev, void* stream)
+{
+    (void)hipGetLastError();
+    if (!g || !hyper_dev) return VPF_ERR_NULL;
+    if (n <= 0) return n == 0 ? VPF_OK : VPF_ERR_BADSHAPE;
+    if ((uintptr_t)g & 15) return VPF_ERR_BADALIGN;
+    hipLaunchKernelGGL(grad_check_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, g, n, hyper_dev);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

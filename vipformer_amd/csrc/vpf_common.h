@@ -51,25 +51,83 @@ struct VpfDebug {
 };
 VpfDebug& vpf_debug();
 
-// ------------------------------------------------------------------ bf16 helpers
-typedef uint16_t bf16_t;
+// ------------------------------------------------------------------ the 16-bit MFMA operand type ("h16") -- ONE switch
+// Every 16-bit tensor of the library (weights' shadow, activations, gradient operands) and every matrix-core product uses ONE type:
+//   VPF_OPERAND_FP16 = 1 (default, round 4): IEEE fp16 -- the reference's own autocast dtype (pretrain.py:154,176): 11 significant
+//     bits; the gradients of the backward pass carry GradScaler's loss scale (train.Pretrainer / torch.cuda.amp.GradScaler) to stay
+//     inside fp16's range.  tests/rounding_budget.py (profiles/r04_rounding_budget_*): gradient cosine 0.9995 against the fp32 oracle
+//     where bf16 operands give 0.994, features 4e-4 instead of 3e-3 (c1, 16 pairs, train mode).
+//   VPF_OPERAND_FP16 = 0: bf16 (rounds 1-3), kept for A/B runs of the same kernels (python -m vipformer_amd.build --bf16).
+// v_mfma_f32_32x32x16_f16 and _bf16 issue at the same rate; conversions cost the same (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 per pair
+// in, one v_cvt_f32_f16 [sdwa] / one shift-or-mask per element out).  Storage is uint16_t either way; vpf_operand_dtype() reports it.
+#ifndef VPF_OPERAND_FP16
+#define VPF_OPERAND_FP16 1
+#endif
+typedef uint16_t h16_t;
+typedef __attribute__((ext_vector_type(2))) float vpf_f32x2_t;
+#if VPF_OPERAND_FP16
+typedef _Float16 h16_scalar_t;
+#define vpf_mfma32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#else
+typedef __bf16 h16_scalar_t;
+#define vpf_mfma32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef __attribute__((ext_vector_type(8))) h16_scalar_t h16x8_t;          // one MFMA operand fragment (8 consecutive k per lane)
+typedef __attribute__((ext_vector_type(2))) h16_scalar_t h16x2_t;
 
-__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even; NaN stays NaN.  A plain cast lowers to the hardware v_cvt_pk_bf16_f32 on gfx950
-// (one instruction per PAIR instead of ~8 integer ops per value).
-__device__ __forceinline__ bf16_t f32_to_bf16(float f)
+// the two halves of a packed pair as f32 (element 0 = low half)
+__device__ __forceinline__ float h16_lo(uint32_t w)
 {
-    const __bf16 b = (__bf16)f;
-    return __builtin_bit_cast(bf16_t, b);
+#if VPF_OPERAND_FP16
+    return (float)__builtin_bit_cast(h16x2_t, w)[0];
+#else
+    return __uint_as_float(w << 16);
+#endif
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi)
+__device__ __forceinline__ float h16_hi(uint32_t w)
 {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-    const f32x2_t v = {lo, hi};
-    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+#if VPF_OPERAND_FP16
+    return (float)__builtin_bit_cast(h16x2_t, w)[1];
+#else
+    return __uint_as_float(w & 0xffff0000u);
+#endif
+}
+__device__ __forceinline__ float h16_to_f32(h16_t v)
+{
+#if VPF_OPERAND_FP16
+    return (float)__builtin_bit_cast(_Float16, v);
+#else
+    return __uint_as_float(((uint32_t)v) << 16);
+#endif
+}
+// round-to-nearest-even; NaN stays NaN, a value beyond the type's range becomes inf (what GradScaler's overflow check looks for).
+// A plain cast lowers to the hardware v_cvt_pk_{f16,bf16}_f32 on gfx950 (one instruction per PAIR).
+__device__ __forceinline__ h16_t f32_to_h16(float f)
+{
+    const h16_scalar_t b = (h16_scalar_t)f;
+    return __builtin_bit_cast(h16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi)
+{
+    const vpf_f32x2_t v = {lo, hi};
+    const h16x2_t b = __builtin_convertvector(v, h16x2_t);
     return __builtin_bit_cast(uint32_t, b);
 }
+// acc += a.lo * b.lo + a.hi * b.hi on the packed pairs (v_dot2c_f32_f16 / v_dot2c_f32_bf16)
+__device__ __forceinline__ float h16_dot2(uint32_t a, uint32_t b, float acc)
+{
+#if VPF_OPERAND_FP16
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2_t, a), __builtin_bit_cast(h16x2_t, b), acc, false);
+#else
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(h16x2_t, a), __builtin_bit_cast(h16x2_t, b), acc, false);
+#endif
+}
+// the packed pair (1, 1)
+#if VPF_OPERAND_FP16
+#define VPF_H16_ONES2 0x3c003c00u
+#else
+#define VPF_H16_ONES2 0x3f803f80u
+#endif
 
 // ------------------------------------------------------------------ wave-level reductions (64 lanes)
 // DPP (data-parallel primitives) cross-lane moves stay in the VALU: quad permutes, row (16-lane) mirrors,

@@ -30,7 +30,7 @@ class PointCloudInputAdapter(InputAdapter):
     """Per-point MLP Linear(C,64) -> LayerNorm(64) -> ReLU -> Linear(64,D)  (classifier.py:31-36).
 
     forward([B,N,C]) -> [B,N,D].  The result is the key/value source of the encoder's
-    cross-attention and nothing else, so it is produced in bf16 (MFMA operand precision)."""
+    cross-attention and nothing else, so it is produced in h16 (MFMA operand precision)."""
 
     def __init__(self, pointcloud_shape: Tuple[int, ...], num_input_channels: int):
         super().__init__(num_input_channels=num_input_channels)

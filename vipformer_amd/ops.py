@@ -4,7 +4,7 @@ Everything numerical happens in the HIP kernels; this file owns buffers, autogra
 (torch.autograd.Function with hand-written backward sequences) and the small amount of
 parameter bookkeeping the fused kernels need:
 
-  * bf16 "shadow" copies of fp32 master weights (MFMA operands), refreshed when the
+  * h16 "shadow" copies of fp32 master weights (MFMA operands), refreshed when the
     parameter changes, or owned by the trainer's fused AdamW (which writes them directly);
   * packed q/k/v weights and gradients (one [3D,D] GEMM instead of three);
   * weight gradients: the wgrad kernels accumulate with fp32 atomics (split over the token
@@ -14,8 +14,8 @@ parameter bookkeeping the fused kernels need:
     other parameter, so ``p.grad`` is populated the standard way and DistributedDataParallel's
     reducer hooks fire (pretrain.py:104-105,209).
 
-Precision contract: fp32 master weights, fp32 residual stream, bf16 MFMA operands with fp32
-accumulation, bf16 activations between fused ops, fp32 statistics (LayerNorm/BatchNorm/softmax).
+Precision contract: fp32 master weights, fp32 residual stream, h16 MFMA operands with fp32
+accumulation, h16 activations between fused ops, fp32 statistics (LayerNorm/BatchNorm/softmax).
 """
 from __future__ import annotations
 
@@ -31,7 +31,7 @@ import torch
 
 from . import _lib as L
 
-BF16 = torch.bfloat16
+H16 = L.H16              # the library's 16-bit operand dtype (fp16; _lib.H16)
 F32 = torch.float32
 
 EPI_STORE, EPI_GELU, EPI_DROP_RES, EPI_GELU_BWD, EPI_ATOMIC, EPI_RELU, EPI_GROUPBIAS = range(7)
@@ -173,11 +173,11 @@ def dropout_keep_mask(site: int, p: float, shape, device, state: Optional[torch.
 # --------------------------------------------------------------------------- parameter packing / shadows / gradient sinks
 class ManagedFlat:
     """What a trainer registers for parameters it owns (train.FlatParams): flat fp32 values, flat fp32 gradients the weight-
-    gradient kernels accumulate into DIRECTLY, and the bf16 shadow its fused AdamW rewrites.  Parameters carry a weak reference
+    gradient kernels accumulate into DIRECTLY, and the h16 shadow its fused AdamW rewrites.  Parameters carry a weak reference
     (``p._vpf_managed``) -- no process-wide registry, two trainers in one process never alias, a dead trainer costs nothing."""
 
-    def __init__(self, flat_f32: torch.Tensor, flat_bf16: torch.Tensor, flat_grad: Optional[torch.Tensor] = None):
-        self.p, self.s, self.g = flat_f32, flat_bf16, flat_grad
+    def __init__(self, flat_f32: torch.Tensor, flat_h16: torch.Tensor, flat_grad: Optional[torch.Tensor] = None):
+        self.p, self.s, self.g = flat_f32, flat_h16, flat_grad
 
     def grad_view(self, param: torch.nn.Parameter, offset: int) -> torch.Tensor:
         """``param.grad`` as the view of the flat gradient buffer it must be -- re-installed if somebody dropped it
@@ -197,7 +197,7 @@ class ManagedFlat:
 
     def recast(self, param: torch.nn.Parameter, offset: int) -> None:
         n = param.numel()
-        L.call("vpf_cast_f32_bf16", self.p[offset:offset + n], self.s[offset:offset + n], n)
+        L.call("vpf_cast_f32_h16", self.p[offset:offset + n], self.s[offset:offset + n], n)
         param._vpf_ver = param._version
 
 
@@ -345,7 +345,7 @@ def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:
 
 
 def shadow(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
-    """bf16 copy of the (adjacent) parameters as one flat tensor.  Trainer-owned parameters: a slice of the trainer's shadow
+    """h16 copy of the (adjacent) parameters as one flat tensor.  Trainer-owned parameters: a slice of the trainer's shadow
     (rewritten by its fused AdamW), re-cast here if somebody else wrote the parameter since (load_state_dict, an external
     optimizer: anything that bumps ``p._version``; raw ``p.data`` writes do not -- call FlatParams.refresh_shadow() then).
     Other parameters: a cached cast keyed on (version, pointer)."""
@@ -371,23 +371,23 @@ def shadow(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
     if hit is not None and hit[0] == ver and hit[1].numel() == n:
         return hit[1]
     src = torch.as_strided(p0.data, (n,), (1,), p0.data.storage_offset()) if len(params) > 1 else p0.data.reshape(-1)
-    out = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == p0.device) else torch.empty(n, dtype=BF16, device=p0.device)
+    out = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == p0.device) else torch.empty(n, dtype=H16, device=p0.device)
     if (src.data_ptr() & 15) == 0:
-        L.call("vpf_cast_f32_bf16", src, out, n)
+        L.call("vpf_cast_f32_h16", src, out, n)
     else:   # unaligned view: stage through an aligned copy
-        L.call("vpf_cast_f32_bf16", src.clone(), out, n)
+        L.call("vpf_cast_f32_h16", src.clone(), out, n)
     p0._vpf_shadow = (ver, out)
     return out
 
 
 # --------------------------------------------------------------------------- thin kernel wrappers
-def to_bf16(x: torch.Tensor) -> torch.Tensor:
-    if x.dtype == BF16:
+def to_h16(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype == H16:
         return x.contiguous()
     x = x.contiguous().float()
-    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    out = torch.empty(x.shape, dtype=H16, device=x.device)
     if x.numel():
-        L.call("vpf_cast_f32_bf16", x, out, x.numel())
+        L.call("vpf_cast_f32_h16", x, out, x.numel())
     return out
 
 
@@ -397,7 +397,7 @@ def to_f32(x: torch.Tensor) -> torch.Tensor:
     x = x.contiguous()
     out = torch.empty(x.shape, dtype=F32, device=x.device)
     if x.numel():
-        L.call("vpf_cast_bf16_f32", x, out, x.numel())
+        L.call("vpf_cast_h16_f32", x, out, x.numel())
     return out
 
 
@@ -405,16 +405,16 @@ def gemm(A, a_tr, lda, Bm, b_tr, ldb, M, N, K, C, ldc, *, c_f32, mode=EPI_STORE,
          ldres=0, aux=None, ldaux=0, gbias=None, group=1, site=0, p=0.0, splitk=0, batch=1, sAb=0, sBb=0, sCb=0, dbias=None,
          rng_state=None):
     st = (rng_state if rng_state is not None else rng.state(C.device)) if mode == EPI_DROP_RES else None
-    L.call("vpf_gemm_bf16", A, int(a_tr), lda, Bm, int(b_tr), ldb, M, N, K, batch, sAb, sBb, sCb, C, ldc, int(c_f32), mode,
+    L.call("vpf_gemm_h16", A, int(a_tr), lda, Bm, int(b_tr), ldb, M, N, K, batch, sAb, sBb, sCb, C, ldc, int(c_f32), mode,
            bias, C2, ldc2, res, ldres, aux, ldaux, gbias, group, st, site, float(p), splitk, dbias)
 
 
 def gemm_fused(A, a_tr, lda, Bm, b_tr, ldb, M, N, K, C, ldc, *, c_f32, mode=EPI_STORE, a_kind=0, a_ab=None, a_dout=None, a_arg=None,
                a_group=1, a_ncols=0, b_kind=0, b_ab=None, bias=None, C2=None, ldc2=0, group=1, splitk=0, dbias=None):
-    """vpf_gemm_bf16_fused: operand prologues (BatchNorm+ReLU affine / virtual max-pool gradient) + group-max epilogue."""
+    """vpf_gemm_h16_fused: operand prologues (BatchNorm+ReLU affine / virtual max-pool gradient) + group-max epilogue."""
     nch_a = a_ab.numel() // 2 if a_ab is not None else 0
     nch_b = b_ab.numel() // 2 if b_ab is not None else 0
-    L.call("vpf_gemm_bf16_fused", A, int(a_tr), lda, a_kind, a_ab, a_ab[nch_a:] if a_ab is not None else None, a_dout, a_arg,
+    L.call("vpf_gemm_h16_fused", A, int(a_tr), lda, a_kind, a_ab, a_ab[nch_a:] if a_ab is not None else None, a_dout, a_arg,
            a_group, a_ncols, Bm, int(b_tr), ldb, b_kind, b_ab, b_ab[nch_b:] if b_ab is not None else None, M, N, K, C, ldc,
            int(c_f32), mode, bias, C2, ldc2, group, splitk, dbias)
 
@@ -425,7 +425,7 @@ EPI_GROUPMAX = 7
 def linear_fwd(x16, w16, N, K, bias=None, *, out_f32=False, mode=EPI_STORE, **kw):
     """y[M,N] = x16[M,K] @ w16[N,K]^T (+bias, epilogue)."""
     M = x16.numel() // K
-    y = torch.empty(M, N, dtype=F32 if out_f32 else BF16, device=x16.device)
+    y = torch.empty(M, N, dtype=F32 if out_f32 else H16, device=x16.device)
     gemm(x16, 0, K, w16, 0, K, M, N, K, y, N, c_f32=out_f32, mode=mode, bias=bias, **kw)
     return y
 
@@ -433,7 +433,7 @@ def linear_fwd(x16, w16, N, K, bias=None, *, out_f32=False, mode=EPI_STORE, **kw
 def linear_dgrad(dy16, w16, N, K, *, out_f32=False, mode=EPI_STORE, **kw):
     """dx[M,K] = dy16[M,N] @ w16[N,K]   (W read k-strided: no transposed copy)."""
     M = dy16.numel() // N
-    dx = torch.empty(M, K, dtype=F32 if out_f32 else BF16, device=dy16.device)
+    dx = torch.empty(M, K, dtype=F32 if out_f32 else H16, device=dy16.device)
     gemm(dy16, 0, N, w16, 1, K, M, K, N, dx, K, c_f32=out_f32, mode=mode, **kw)
     return dx
 
@@ -575,27 +575,27 @@ class WgradBatch:
 
 def colsum(x, C, acc, acc2=None):
     M = x.numel() // C
-    L.call("vpf_colsum", x, int(x.dtype == BF16), M, C, acc, acc2)
+    L.call("vpf_colsum", x, int(x.dtype == H16), M, C, acc, acc2)
 
 
 def layernorm_fwd(x, gamma, beta, pos=None, want_sum=False):
     D = x.shape[-1]
     rows = x.numel() // D
-    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    y = torch.empty(x.shape, dtype=H16, device=x.device)
     mean = torch.empty(rows, dtype=F32, device=x.device)
     rstd = torch.empty(rows, dtype=F32, device=x.device)
     xsum = torch.empty(x.shape, dtype=F32, device=x.device) if (pos is not None and want_sum) else None
     pos_rows = (pos.numel() // D) if pos is not None else 0
-    L.call("vpf_layernorm_fwd", x, int(x.dtype == BF16), pos, pos_rows, gamma, beta, y, xsum, mean, rstd, rows, D, 1e-5)
+    L.call("vpf_layernorm_fwd", x, int(x.dtype == H16), pos, pos_rows, gamma, beta, y, xsum, mean, rstd, rows, D, 1e-5)
     return y, mean, rstd, xsum
 
 
-def layernorm_bwd(dy16, x, mean, rstd, gamma_p, beta_p, dres=None, out_bf16=False):
+def layernorm_bwd(dy16, x, mean, rstd, gamma_p, beta_p, dres=None, out_h16=False):
     D = x.shape[-1]
     rows = x.numel() // D
-    dx = torch.empty(x.shape, dtype=BF16 if out_bf16 else F32, device=x.device)
+    dx = torch.empty(x.shape, dtype=H16 if out_h16 else F32, device=x.device)
     ws = torch.empty(2 * 1024 * D, dtype=F32, device=x.device)      # per-block dgamma/dbeta partials
-    L.call("vpf_layernorm_bwd", dy16, x, int(x.dtype == BF16), mean, rstd, gamma_p.data, dres, dx, int(out_bf16),
+    L.call("vpf_layernorm_bwd", dy16, x, int(x.dtype == H16), mean, rstd, gamma_p.data, dres, dx, int(out_h16),
            grad_buf(gamma_p), grad_buf(beta_p), ws, ws.numel(), rows, D)
     return dx
 
@@ -628,7 +628,7 @@ class AttnBlockFn(torch.autograd.Function):
         else:
             if pos is not None:
                 raise L.VpfError("pos requires a query LayerNorm")
-            nq = to_bf16(xq)
+            nq = to_h16(xq)
         mk = rk = None
         if is_self:
             nk, Lkv = nq, Lq
@@ -638,10 +638,10 @@ class AttnBlockFn(torch.autograd.Function):
             if lnkv is not None:
                 nk, mk, rk, _ = layernorm_fwd(xkv, lnkv.weight.data, lnkv.bias.data)
             else:
-                nk = to_bf16(xkv)
+                nk = to_h16(xkv)
         qkvw = [mod.q_proj.weight, mod.k_proj.weight, mod.v_proj.weight]
         pack_params(qkvw)
-        w16 = shadow(qkvw)                      # [3D, D] bf16
+        w16 = shadow(qkvw)                      # [3D, D] h16
         Mq, Mk = B * Lq, B * Lkv
         if is_self:
             qkv = linear_fwd(nq, w16, 3 * D, D)                                  # [Mq, 3D]
@@ -651,7 +651,7 @@ class AttnBlockFn(torch.autograd.Function):
             qkv = linear_fwd(nq, w16[:D * D], D, D)                              # [Mq, D]
             kv = linear_fwd(nk, w16[D * D:], 2 * D, D)                           # [Mk, 2D]
             q, k, v, ldq, ldk, ldv = qkv, kv, kv[:, D:], D, 2 * D, 2 * D
-        o = torch.empty(Mq, D, dtype=BF16, device=dev)
+        o = torch.empty(Mq, D, dtype=H16, device=dev)
         lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
         p_att = mod.dropout.p if training else 0.0
         pad = ctx.pad = cfg.get("pad_mask")
@@ -688,10 +688,10 @@ class AttnBlockFn(torch.autograd.Function):
         Mq, Mk = B * Lq, B * Lkv
         residual = cfg["residual"]
         if residual and p_res > 0.0:
-            dz = torch.empty(Mq, D, dtype=BF16, device=dev)
+            dz = torch.empty(Mq, D, dtype=H16, device=dev)
             L.call("vpf_dropout_bwd", dout, dz, dout.numel(), ctx.rng_st, cfg["site_res"], float(p_res))
         else:
-            dz = to_bf16(dout).view(Mq, D)
+            dz = to_h16(dout).view(Mq, D)
         wg = WgradBatch()                      # the block's weight gradients as ONE grouped launch at the end (they are off the dgrad chain)
         wg.add(dz, o, D, D, grad_buf(mod.o_proj.weight), grad_buf(mod.o_proj.bias))
         do = linear_dgrad(dz, shadow([mod.o_proj.weight]), D, D)
@@ -699,12 +699,12 @@ class AttnBlockFn(torch.autograd.Function):
         w16 = shadow(qkvw)
         gW = packed_grad(qkvw)
         if is_self:
-            dqkv = torch.empty(Mq, 3 * D, dtype=BF16, device=dev)
+            dqkv = torch.empty(Mq, 3 * D, dtype=H16, device=dev)
             q, k, v, ldq, ldk, ldv = qkv, qkv[:, D:], qkv[:, 2 * D:], 3 * D, 3 * D, 3 * D
             dq, dk, dv, lddq, lddk, lddv = dqkv, dqkv[:, D:], dqkv[:, 2 * D:], 3 * D, 3 * D, 3 * D
         else:
-            dq = torch.empty(Mq, D, dtype=BF16, device=dev)
-            dkv = torch.empty(Mk, 2 * D, dtype=BF16, device=dev)
+            dq = torch.empty(Mq, D, dtype=H16, device=dev)
+            dkv = torch.empty(Mk, 2 * D, dtype=H16, device=dev)
             q, k, v, ldq, ldk, ldv = qkv, kv, kv[:, D:], D, 2 * D, 2 * D
             dk, dv, lddq, lddk, lddv = dkv, dkv[:, D:], D, 2 * D, 2 * D
         if ctx.pad is None:
@@ -727,15 +727,15 @@ class AttnBlockFn(torch.autograd.Function):
                 dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
                 lnkv = cfg["ln_kv"]
                 if lnkv is not None:
-                    dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16))
+                    dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_h16=(ctx.xkv_dtype == H16))
                     dxkv = dxkv.view(B, Lkv, D)
                 else:
-                    dxkv = (dnk if ctx.xkv_dtype == BF16 else to_f32(dnk)).view(B, Lkv, D)
+                    dxkv = (dnk if ctx.xkv_dtype == H16 else to_f32(dnk)).view(B, Lkv, D)
             elif cfg["ln_kv"] is not None:
                 # kv input needs no grad but the kv LayerNorm affine does
                 dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
                 lnkv = cfg["ln_kv"]
-                layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
+                layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_h16=True)
         wg.flush()
         lnq = cfg["ln_q"]
         if lnq is not None:
@@ -769,7 +769,7 @@ class MLPBlockFn(torch.autograd.Function):
         Hd = fc1.weight.shape[0]
         n, mean, rstd, _ = layernorm_fwd(x, ln.weight.data, ln.bias.data)
         M = x.numel() // D
-        u = torch.empty(M, Hd, dtype=BF16, device=x.device)
+        u = torch.empty(M, Hd, dtype=H16, device=x.device)
         h = linear_fwd(n, shadow([fc1.weight]), Hd, D, fc1.bias.data, mode=EPI_GELU, C2=u, ldc2=Hd)
         training, residual = cfg["training"], cfg["residual"]
         p_res = cfg["p_res"] if training else 0.0
@@ -795,10 +795,10 @@ class MLPBlockFn(torch.autograd.Function):
         dout = dout.contiguous().float()
         residual = cfg["residual"]
         if residual and p_res > 0.0:
-            dz = torch.empty(M, D, dtype=BF16, device=x.device)
+            dz = torch.empty(M, D, dtype=H16, device=x.device)
             L.call("vpf_dropout_bwd", dout, dz, dout.numel(), ctx.rng_st, cfg["site_res"], float(p_res))
         else:
-            dz = to_bf16(dout).view(M, D)
+            dz = to_h16(dout).view(M, D)
         wg = WgradBatch()
         wg.add(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
         du = linear_dgrad(dz, shadow([fc2.weight]), D, Hd, mode=EPI_GELU_BWD, aux=u, ldaux=Hd)
@@ -847,7 +847,7 @@ def pgrad_rows(M: int, D: int) -> int:
 
 def _sa_packed(layers, dev):
     """Fragment-order copies of the stack's weights -- forward: Wo, W1, W2 (and Wqkv of layers >= 1); backward (dgrad):
-    the transposed views W2T, W1T, WoT, WqkvT -- rewritten from the bf16 shadow on every call (the shadow changes every
+    the transposed views W2T, W1T, WoT, WqkvT -- rewritten from the h16 shadow on every call (the shadow changes every
     optimizer step; the copy is one small kernel)."""
     holder = layers[0]
     D, Hd, _ = _block_dims(layers[0][0].module.attention, layers[0][1].module)
@@ -855,7 +855,7 @@ def _sa_packed(layers, dev):
     per_layer = sum(n for _, n in sizes)
     buf = getattr(holder, "_vpf_packed", None)
     if buf is None or buf.device != dev or buf.numel() != per_layer * len(layers):
-        buf = torch.empty(per_layer * len(layers), dtype=BF16, device=dev)
+        buf = torch.empty(per_layer * len(layers), dtype=H16, device=dev)
         holder._vpf_packed = buf
     jobs = (L.PackJob * 64)()
     views = []
@@ -919,14 +919,14 @@ class SAStackFn(torch.autograd.Function):
             att, mlp = layer[0].module.attention, layer[1].module
             ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
             last = i + 1 == nl
-            o = torch.empty(M, D, dtype=BF16, device=dev)
+            o = torch.empty(M, D, dtype=H16, device=dev)
             lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
             x1 = torch.empty(M, D, dtype=F32, device=dev)
             m2 = torch.empty(M, dtype=F32, device=dev)
             r2 = torch.empty(M, dtype=F32, device=dev)
-            n2 = torch.empty(M, D, dtype=BF16, device=dev)
-            u = torch.empty(M, Hd, dtype=BF16, device=dev)
-            h = torch.empty(M, Hd, dtype=BF16, device=dev)
+            n2 = torch.empty(M, D, dtype=H16, device=dev)
+            u = torch.empty(M, Hd, dtype=H16, device=dev)
+            h = torch.empty(M, Hd, dtype=H16, device=dev)
             out = torch.empty(M, D, dtype=F32, device=dev)
             a = L.SaLayerFwd()
             a.B, a.L, a.chunk_rows, a.D, a.H, a.hidden = B, Lq, chunk_rows, D, H, Hd
@@ -949,7 +949,7 @@ class SAStackFn(torch.autograd.Function):
             if not last:
                 lnn = layers[i + 1][0].module.norm
                 nxt = (torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev),
-                       torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, 3 * D, dtype=BF16, device=dev))
+                       torch.empty(M, D, dtype=H16, device=dev), torch.empty(M, 3 * D, dtype=H16, device=dev))
                 a.pos, a.pos_rows = (pos_c.data_ptr() if pos_c is not None else None), pos_rows
                 a.ln1n_g, a.ln1n_b, a.Wqkv_next = lnn.weight.data.data_ptr(), lnn.bias.data.data_ptr(), packed[i + 1]["Wqkv"].data_ptr()
                 a.mean1n, a.rstd1n, a.n1n, a.qkv_next = nxt[0].data_ptr(), nxt[1].data_ptr(), nxt[2].data_ptr(), nxt[3].data_ptr()
@@ -989,10 +989,10 @@ class SAStackFn(torch.autograd.Function):
             # ---- MLP residual block (MLPBlockFn.backward)
             p2 = layer[1].dropout.p if training else 0.0
             if p2 > 0.0:
-                dz = torch.empty(M, D, dtype=BF16, device=dev)
+                dz = torch.empty(M, D, dtype=H16, device=dev)
                 L.call("vpf_dropout_bwd", d, dz, d.numel(), st, layer[1].site, float(p2))
             else:
-                dz = to_bf16(d).view(M, D)
+                dz = to_h16(d).view(M, D)
             wg.add(dz, h, D, Hd, grad_buf(fc2.weight), grad_buf(fc2.bias))
             du = linear_dgrad(dz, shadow([fc2.weight]), D, Hd, mode=EPI_GELU_BWD, aux=u, ldaux=Hd)
             wg.add(du, n2, Hd, D, grad_buf(fc1.weight), grad_buf(fc1.bias))
@@ -1001,15 +1001,15 @@ class SAStackFn(torch.autograd.Function):
             # ---- attention residual block (AttnBlockFn.backward, self-attention branch)
             p1 = layer[0].dropout.p if training else 0.0
             if p1 > 0.0:
-                dz = torch.empty(M, D, dtype=BF16, device=dev)
+                dz = torch.empty(M, D, dtype=H16, device=dev)
                 L.call("vpf_dropout_bwd", dx1, dz, dx1.numel(), st, layer[0].site, float(p1))
             else:
-                dz = to_bf16(dx1).view(M, D)
+                dz = to_h16(dx1).view(M, D)
             wg.add(dz, o, D, D, grad_buf(att.o_proj.weight), grad_buf(att.o_proj.bias))
             do = linear_dgrad(dz, shadow([att.o_proj.weight]), D, D)
             qkvw = [att.q_proj.weight, att.k_proj.weight, att.v_proj.weight]
             w16 = shadow(qkvw)
-            dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+            dqkv = torch.empty(M, 3 * D, dtype=H16, device=dev)
             p_att = att.dropout.p if training else 0.0
             L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
                    float(att.dp_scale), float(p_att), st, att.site_attn, dqkv, 3 * D, dqkv[:, D:], 3 * D, dqkv[:, 2 * D:], 3 * D,
@@ -1049,12 +1049,12 @@ class SAStackFn(torch.autograd.Function):
             sa, mlp = layer[0].module, layer[1].module
             att, ln1 = sa.attention, sa.norm
             ln2, fc1, fc2 = mlp[0], mlp[1], mlp[3]
-            dz2 = torch.empty(M, D, dtype=BF16, device=dev)
-            du = torch.empty(M, Hd, dtype=BF16, device=dev)
+            dz2 = torch.empty(M, D, dtype=H16, device=dev)
+            du = torch.empty(M, Hd, dtype=H16, device=dev)
             dx1 = torch.empty(M, D, dtype=F32, device=dev)
-            dz1 = torch.empty(M, D, dtype=BF16, device=dev)
-            do = torch.empty(M, D, dtype=BF16, device=dev)
-            dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+            dz1 = torch.empty(M, D, dtype=H16, device=dev)
+            do = torch.empty(M, D, dtype=H16, device=dev)
+            dqkv = torch.empty(M, 3 * D, dtype=H16, device=dev)
             dbase = torch.empty(M, D, dtype=F32, device=dev)
             a = L.SaLayerBwd()
             a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
@@ -1111,7 +1111,7 @@ def _pack_blocks(blocks, holder, dev, front=None):
     extra = D * 128                                       # the position MLP's weight (always reserved: one buffer size per stack)
     buf = getattr(holder, "_vpf_packed_enc", None)
     if buf is None or buf.device != dev or buf.numel() != per * len(blocks) + extra:
-        buf = torch.empty(per * len(blocks) + extra, dtype=BF16, device=dev)
+        buf = torch.empty(per * len(blocks) + extra, dtype=H16, device=dev)
         holder._vpf_packed_enc = buf
     jobs = (L.PackJob * 64)()
     views, n = [], 0
@@ -1169,9 +1169,9 @@ def _tail_fwd(att, mlp, res_attn, res_mlp, pk, training, st, B, Lq, qkv_dummy, b
     x1 = torch.empty(M, D, dtype=F32, device=dev)
     m2 = torch.empty(M, dtype=F32, device=dev)
     r2 = torch.empty(M, dtype=F32, device=dev)
-    n2 = torch.empty(M, D, dtype=BF16, device=dev)
-    u = torch.empty(M, Hd, dtype=BF16, device=dev)
-    h = torch.empty(M, Hd, dtype=BF16, device=dev)
+    n2 = torch.empty(M, D, dtype=H16, device=dev)
+    u = torch.empty(M, Hd, dtype=H16, device=dev)
+    h = torch.empty(M, Hd, dtype=H16, device=dev)
     out = torch.empty(M, D, dtype=F32, device=dev)
     a = L.SaLayerFwd()
     a.B, a.L, a.chunk_rows, a.D, a.H, a.hidden = B, Lq, 64, D, H, Hd
@@ -1192,7 +1192,7 @@ def _tail_fwd(att, mlp, res_attn, res_mlp, pk, training, st, B, Lq, qkv_dummy, b
     if nxt is not None:
         lnn, wqkv = nxt
         head = (torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev),
-                torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, 3 * D, dtype=BF16, device=dev))
+                torch.empty(M, D, dtype=H16, device=dev), torch.empty(M, 3 * D, dtype=H16, device=dev))
         a.pos, a.pos_rows = (pos_c.data_ptr() if pos_c is not None else None), pos_rows
         a.ln1n_g, a.ln1n_b, a.Wqkv_next = lnn.weight.data.data_ptr(), lnn.bias.data.data_ptr(), wqkv.data_ptr()
         a.mean1n, a.rstd1n, a.n1n, a.qkv_next = head[0].data_ptr(), head[1].data_ptr(), head[2].data_ptr(), head[3].data_ptr()
@@ -1211,7 +1211,7 @@ class EncoderFusedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, xkv, ca, layers, training, kv_ready, taps, *params):
-        """kv_ready: ``xkv`` already holds the cross-attention K | V projections (bf16 [B, Lkv, 2D], AdapterKVFn).
+        """kv_ready: ``xkv`` already holds the cross-attention K | V projections (h16 [B, Lkv, 2D], AdapterKVFn).
         taps: ascending 1-based self-attention layer numbers whose output is returned as well (Encoder.forward's ``layer_idx``,
         partseg.py:336-337).  Returns (x after the last layer, *tapped layer outputs)."""
         ctx.nparams, ctx.params = len(params), params
@@ -1253,7 +1253,7 @@ class EncoderFusedFn(torch.autograd.Function):
         else:
             nk, mk, rk, _ = layernorm_fwd(xkv, lnkv.weight.data, lnkv.bias.data)
             kv = linear_fwd(nk, w16[D * D:], 2 * D, D)
-        o = torch.empty(M, D, dtype=BF16, device=dev)
+        o = torch.empty(M, D, dtype=H16, device=dev)
         lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
         L.call("vpf_attention_fwd", q, D, kv, 2 * D, kv[:, D:], 2 * D, B, H, Lq, Lkv, D // H, float(catt.dp_scale),
                float(catt.dropout.p if training else 0.0), st, catt.site_attn, o, D, lse)
@@ -1265,7 +1265,7 @@ class EncoderFusedFn(torch.autograd.Function):
         for i, layer in enumerate(layers):
             att, mlp = layer[0].module.attention, layer[1].module
             base, (m1, r1, n1, qkv) = out, head
-            o = torch.empty(M, D, dtype=BF16, device=dev)
+            o = torch.empty(M, D, dtype=H16, device=dev)
             lse = torch.empty(B * H * Lq, dtype=F32, device=dev)
             L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, D // H, float(att.dp_scale),
                    float(att.dropout.p if training else 0.0), st, att.site_attn, o, D, lse)
@@ -1279,7 +1279,7 @@ class EncoderFusedFn(torch.autograd.Function):
         ctx.ca, ctx.layers, ctx.training, ctx.packed = ca, layers, training, packed
         ctx.dims = (B, Lq, Lkv, D, Hd, H)
         ctx.pos_shape = tuple(pos.shape) if pos is not None else None
-        ctx.xkv_dtype = BF16 if kv_ready else xkv.dtype
+        ctx.xkv_dtype = H16 if kv_ready else xkv.dtype
         ctx.save_for_backward(*flat)
         return (out.view(B, Lq, D),) + tuple(tapped)
 
@@ -1312,8 +1312,8 @@ class EncoderFusedFn(torch.autograd.Function):
 
         def bwd_mlp(a, blk, res_attn, res_mlp, pk, d, u, x1, m2, r2, slot):
             att, mlp = blk
-            bufs = (torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, Hd, dtype=BF16, device=dev), torch.empty(M, D, dtype=F32, device=dev),
-                    torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, D, dtype=BF16, device=dev))
+            bufs = (torch.empty(M, D, dtype=H16, device=dev), torch.empty(M, Hd, dtype=H16, device=dev), torch.empty(M, D, dtype=F32, device=dev),
+                    torch.empty(M, D, dtype=H16, device=dev), torch.empty(M, D, dtype=H16, device=dev))
             dz2, du, dx1, dz1, do = bufs
             a.M, a.D, a.hidden, a.rng = M, D, Hd, st.data_ptr()
             a.p_res1, a.site_res1 = float(res_attn.dropout.p if training else 0.0), res_attn.site
@@ -1357,7 +1357,7 @@ class EncoderFusedFn(torch.autograd.Function):
             pk = packed[i + 1]
             a = L.SaLayerBwd()
             dz2, du, dx1, dz1, do = bwd_mlp(a, (att, mlp), layer[0], layer[1], pk, d, u, x1, m2, r2, i + 1)
-            dqkv = torch.empty(M, 3 * D, dtype=BF16, device=dev)
+            dqkv = torch.empty(M, 3 * D, dtype=H16, device=dev)
             dbase = torch.empty(M, D, dtype=F32, device=dev)
             L.call("vpf_attention_bwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, o, D, do, D, lse, B, H, Lq, Lq, D // H,
                    float(att.dp_scale), float(att.dropout.p if training else 0.0), st, att.site_attn, dqkv, 3 * D, dqkv[:, D:], 3 * D,
@@ -1395,8 +1395,8 @@ class EncoderFusedFn(torch.autograd.Function):
         if npj and not front_rows:
             L.call_struct("vpf_ln_pgrad_reduce", pjobs, npj)
             npj = 0
-        dq = torch.empty(M, D, dtype=BF16, device=dev)
-        dkv = torch.empty(Mk, 2 * D, dtype=BF16, device=dev)
+        dq = torch.empty(M, D, dtype=H16, device=dev)
+        dkv = torch.empty(Mk, 2 * D, dtype=H16, device=dev)
         L.call("vpf_attention_bwd", q, D, kv, 2 * D, kv[:, D:], 2 * D, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(catt.dp_scale),
                float(catt.dropout.p if training else 0.0), st, catt.site_attn, dq, D, dkv, 2 * D, dkv[:, D:], 2 * D,
                torch.empty(B * H * Lq, dtype=F32, device=dev))
@@ -1431,9 +1431,9 @@ class EncoderFusedFn(torch.autograd.Function):
         else:
             dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
             if ctx.needs_input_grad[2]:
-                dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=(ctx.xkv_dtype == BF16)).view(B, Lkv, D)
+                dxkv = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_h16=(ctx.xkv_dtype == H16)).view(B, Lkv, D)
             else:
-                layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True)
+                layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_h16=True)
         if front_rows:
             # dq . Wq -> q LayerNorm' -> + dx1 -> dx, the positional-gradient sum and the LayerNorm's parameter-gradient partials in one
             # kernel (vpf_ca_front_bwd) instead of a GEMM, two LayerNorm launches and an add
@@ -1470,7 +1470,7 @@ class EncoderFusedFn(torch.autograd.Function):
 
 class AdapterKVFn(torch.autograd.Function):
     """PointCloudInputAdapter (classifier.py:31-50) + the cross-attention kv LayerNorm and K / V projections
-    (partseg.py:48-51,100-116) as ONE forward kernel (vpf_adapter_kv_fwd): pts [B,N,C] -> kv bf16 [B,N,2D].
+    (partseg.py:48-51,100-116) as ONE forward kernel (vpf_adapter_kv_fwd): pts [B,N,C] -> kv h16 [B,N,2D].
     Backward: the block-by-block kernels on what the forward saved."""
 
     @staticmethod
@@ -1489,7 +1489,7 @@ class AdapterKVFn(torch.autograd.Function):
         pk = getattr(adapter, "_vpf_packed_kv", None)
         n2, nkv = D * 64, 2 * D * D
         if pk is None or pk.device != dev:
-            pk = torch.empty(2 * (n2 + nkv), dtype=BF16, device=dev)        # W2 | Wkv | W2T | WkvT  (fragment order)
+            pk = torch.empty(2 * (n2 + nkv), dtype=H16, device=dev)        # W2 | Wkv | W2T | WkvT  (fragment order)
             adapter._vpf_packed_kv = pk
         jobs = (L.PackJob * 64)()
         w2 = shadow([l3.weight])
@@ -1497,12 +1497,12 @@ class AdapterKVFn(torch.autograd.Function):
                                                            (w2, n2 + nkv, 64, D, 1), (w16[D * D:], 2 * n2 + nkv, D, 2 * D, 1))):
             jobs[i].src, jobs[i].dst, jobs[i].N, jobs[i].K, jobs[i].transposed = src.data_ptr(), pk[off:].data_ptr(), rows_, depth_, tr
         L.call_struct("vpf_pack_wfrag", jobs, 4)
-        a1 = torch.empty(M, 64, dtype=BF16, device=dev)
-        xkv = torch.empty(M, D, dtype=BF16, device=dev)
+        a1 = torch.empty(M, 64, dtype=H16, device=dev)
+        xkv = torch.empty(M, D, dtype=H16, device=dev)
         mk = torch.empty(M, dtype=F32, device=dev)
         rk = torch.empty(M, dtype=F32, device=dev)
-        nk = torch.empty(M, D, dtype=BF16, device=dev)
-        kv = torch.empty(M, 2 * D, dtype=BF16, device=dev)
+        nk = torch.empty(M, D, dtype=H16, device=dev)
+        kv = torch.empty(M, 2 * D, dtype=H16, device=dev)
         a = L.AdapterKv()
         a.M, a.C, a.D = M, C, D
         a.x, a.W1, a.b1, a.ln_g, a.ln_b = x.data_ptr(), l0.weight.data.data_ptr(), l0.bias.data.data_ptr(), ln.weight.data.data_ptr(), ln.bias.data.data_ptr()
@@ -1525,16 +1525,16 @@ class AdapterKVFn(torch.autograd.Function):
         M, C = x.shape
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         w16, gKV = shadow(qkvw), packed_grad(qkvw[1:])
-        dkv = to_bf16(dkv).view(M, 2 * D)
+        dkv = to_h16(dkv).view(M, 2 * D)
         if cfg.adapter_kv_bwd_fused:
             pk = ctx.packed
             n2, nkv = D * 64, 2 * D * D
             fn = L.lib().vpf_adapter_kv_pgrad_rows
             fn.argtypes, fn.restype = [ctypes.c_long, ctypes.c_int], ctypes.c_int
             nwg = fn(M, D)
-            dy16 = torch.empty(M, D, dtype=BF16, device=x.device)
+            dy16 = torch.empty(M, D, dtype=H16, device=x.device)
             pg = torch.empty(nwg * 2 * D, dtype=F32, device=x.device)
-            da = torch.empty(M, 64, dtype=BF16, device=x.device)
+            da = torch.empty(M, 64, dtype=H16, device=x.device)
             a = L.AdapterKvBwd()
             a.M, a.C, a.D = M, C, D
             a.dkv, a.WkvT, a.xkv, a.mean, a.rstd, a.lnkv_g = dkv.data_ptr(), pk[2 * n2 + nkv:].data_ptr(), xkv.data_ptr(), mk.data_ptr(), rk.data_ptr(), lnkv.weight.data.data_ptr()
@@ -1555,7 +1555,7 @@ class AdapterKVFn(torch.autograd.Function):
             return (None, None, None) + (None,) * ctx.nparams
         linear_wgrad(dkv, nk, 2 * D, D, gKV)
         dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
-        dy16 = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_bf16=True).view(M, D)
+        dy16 = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_h16=True).view(M, D)
         linear_wgrad(dy16, a1, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
         da = linear_dgrad(dy16, shadow([l3.weight]), D, 64)
         ws = torch.empty(2048 * 64 * 11, dtype=F32, device=x.device)
@@ -1591,7 +1591,7 @@ def encoder_fused_supported(ca, layers, x, xkv) -> bool:
 class DropoutAddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, res, p, site):
-        y16 = to_bf16(y)
+        y16 = to_h16(y)
         res = res.contiguous().float()
         out = torch.empty(res.shape, dtype=F32, device=res.device)
         ctx.rng_st = rng.acquire(res.device, p > 0.0)
@@ -1602,9 +1602,9 @@ class DropoutAddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         dout = dout.contiguous().float()
-        dy = torch.empty(dout.shape, dtype=BF16, device=dout.device)
+        dy = torch.empty(dout.shape, dtype=H16, device=dout.device)
         L.call("vpf_dropout_bwd", dout, dy, dout.numel(), ctx.rng_st, ctx.site, float(ctx.p))
-        return (dy if ctx.ydt == BF16 else to_f32(dy)), dout, None, None
+        return (dy if ctx.ydt == H16 else to_f32(dy)), dout, None, None
 
 
 # --------------------------------------------------------------------------- BatchNorm helper (channels-last [M,C])
@@ -1624,19 +1624,19 @@ def _bn_stat(x, C, bn, training):
     return stat
 
 
-def _bn_act(x, C, stat, bn, relu, out_bf16):
+def _bn_act(x, C, stat, bn, relu, out_h16):
     M = x.numel() // C
-    y = torch.empty(M, C, dtype=BF16 if out_bf16 else F32, device=x.device)
-    L.call("vpf_bn_act_fwd", x, int(x.dtype == BF16), stat, bn.weight.data, bn.bias.data, y, int(out_bf16), M, C, int(relu))
+    y = torch.empty(M, C, dtype=H16 if out_h16 else F32, device=x.device)
+    L.call("vpf_bn_act_fwd", x, int(x.dtype == H16), stat, bn.weight.data, bn.bias.data, y, int(out_h16), M, C, int(relu))
     return y
 
 
-def _bn_bwd(dy, x, C, stat, bn, relu, training, out_bf16, want_dx=True):
+def _bn_bwd(dy, x, C, stat, bn, relu, training, out_h16, want_dx=True):
     M = x.numel() // C
     tmp = torch.zeros(2 * C, dtype=F32, device=x.device)
-    dx = torch.empty(M, C, dtype=BF16 if out_bf16 else F32, device=x.device) if want_dx else None
-    L.call("vpf_bn_bwd", dy, int(dy.dtype == BF16), x, int(x.dtype == BF16), stat, bn.weight.data, bn.bias.data, M, C,
-           int(relu), int(training), tmp, dx, int(out_bf16), grad_buf(bn.weight), grad_buf(bn.bias))
+    dx = torch.empty(M, C, dtype=H16 if out_h16 else F32, device=x.device) if want_dx else None
+    L.call("vpf_bn_bwd", dy, int(dy.dtype == H16), x, int(x.dtype == H16), stat, bn.weight.data, bn.bias.data, M, C,
+           int(relu), int(training), tmp, dx, int(out_h16), grad_buf(bn.weight), grad_buf(bn.bias))
     return dx
 
 
@@ -1691,11 +1691,11 @@ class Group2EmbFn(torch.autograd.Function):
                 L.call("vpf_bn_affine", stat1, bn1.weight.data, bn1.bias.data, 64, ab1)
                 w1e = torch.empty(64 * C + 64, dtype=F32, device=dev)
                 L.call("vpf_g2e_fold_bn1", w1, c1.bias.data, ab1, C, w1e, w1e[64 * C:])
-            a1 = torch.empty(M, 64, dtype=BF16, device=dev)
-            h2 = torch.empty(M, 128, dtype=BF16, device=dev)
-            gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
+            a1 = torch.empty(M, 64, dtype=H16, device=dev)
+            h2 = torch.empty(M, 128, dtype=H16, device=dev)
+            gmax = torch.empty(NG, 128, dtype=H16, device=dev)
             arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
-            h3 = torch.empty(M, 256, dtype=BF16, device=dev)
+            h3 = torch.empty(M, 256, dtype=H16, device=dev)
             part = torch.empty(256 * 512, dtype=F32, device=dev)
             nwg = ctypes.c_int(0)
             L.call("vpf_g2e_fwd_a", x, NG, C, w1e, w1e[64 * C:], shadow([c2.weight]), c2.bias.data, shadow([c3.weight]), c3.bias.data,
@@ -1721,16 +1721,16 @@ class Group2EmbFn(torch.autograd.Function):
             L.call("vpf_g2e_fwd_b", h3, NG, ab2, shadow([c4.weight]), c4.bias.data, Dm, out, arg4)
             fused = True
         else:
-            a1 = torch.empty(M, 64, dtype=BF16, device=dev)
+            a1 = torch.empty(M, 64, dtype=H16, device=dev)
             L.call("vpf_g2e_conv1_apply", x, M, C, w1, c1.bias.data, stat1, bn1.weight.data, bn1.bias.data, a1)
             h2 = linear_fwd(a1, shadow([c2.weight]), 128, 64, c2.bias.data)                      # [M,128]
-            gmax = torch.empty(NG, 128, dtype=BF16, device=dev)
+            gmax = torch.empty(NG, 128, dtype=H16, device=dev)
             arg2 = torch.empty(NG, 128, dtype=torch.uint8, device=dev)
             L.call("vpf_group_max_fwd", h2, NG, K, 128, gmax, 1, arg2)
             w3 = shadow([c3.weight])                                                              # [256, 256] = [global | local]
             gb = torch.empty(NG, 256, dtype=F32, device=dev)
             gemm(gmax, 0, 128, w3, 0, 256, NG, 256, 128, gb, 256, c_f32=True, bias=c3.bias.data)  # global . W[:, :128]^T + b
-            h3 = torch.empty(M, 256, dtype=BF16, device=dev)
+            h3 = torch.empty(M, 256, dtype=H16, device=dev)
             gemm(h2, 0, 128, w3[128:], 0, 256, M, 256, 128, h3, 256, c_f32=False, mode=EPI_GROUPBIAS, gbias=gb, group=K)
             stat2 = _bn_stat(h3, 256, bn2, training)
             ab2 = torch.empty(512, dtype=F32, device=dev)
@@ -1766,15 +1766,15 @@ class Group2EmbFn(torch.autograd.Function):
         if ctx.fused and K == 32 and C == 3 and Dm <= 256 and Dm % 16 == 0:
             # persistent fused path: sparse wgrad of the last conv, then dgrad + BatchNorm-2 backward + conv3 dgrad on MFMA
             # with transposed weight fragments in registers; only dh3 / dh2 reach HBM
-            w4t = torch.empty(256 * Dm, dtype=BF16, device=dev)
-            L.call("vpf_transpose_bf16", shadow([c4.weight]), 256, Dm, 256, w4t)
-            w3bt = torch.empty(128 * 256, dtype=BF16, device=dev)
-            L.call("vpf_transpose_bf16", w3[128:], 256, 256, 128, w3bt)
+            w4t = torch.empty(256 * Dm, dtype=H16, device=dev)
+            L.call("vpf_transpose_h16", shadow([c4.weight]), 256, Dm, 256, w4t)
+            w3bt = torch.empty(128 * 256, dtype=H16, device=dev)
+            L.call("vpf_transpose_h16", w3[128:], 256, 256, 128, w3bt)
             L.call("vpf_g2e_wgrad4", h3, NG, ab2, dout, arg4, Dm, grad_buf(c4.weight), grad_buf(c4.bias))
             tmp2 = torch.zeros(512, dtype=F32, device=dev)
-            dh3 = torch.empty(M, 256, dtype=BF16, device=dev)
+            dh3 = torch.empty(M, 256, dtype=H16, device=dev)
             dgb = torch.empty(NG, 256, dtype=F32, device=dev)
-            dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
+            dh2 = torch.empty(M, 128, dtype=H16, device=dev)
             L.call("vpf_g2e_bwd", dout, arg4, Dm, NG, h3, stat2, bn2.weight.data, bn2.bias.data, w4t, w3bt, int(training), tmp2, dh3,
                    dgb, dh2, grad_buf(bn2.weight), grad_buf(bn2.bias), G2E_DEBUG.get("dbg"))
         else:
@@ -1788,12 +1788,12 @@ class Group2EmbFn(torch.autograd.Function):
                 else:
                     gemm_fused(dout, 1, Dm, h3, 1, 256, Dm, 256, M, grad_buf(c4.weight), 256, c_f32=True, mode=EPI_ATOMIC, a_kind=2,
                                a_dout=dout, a_arg=arg4, a_group=K, a_ncols=Dm, b_kind=1, b_ab=ab2, dbias=grad_buf(c4.bias))
-                da3 = torch.empty(M, 256, dtype=BF16, device=dev)
+                da3 = torch.empty(M, 256, dtype=H16, device=dev)
                 gemm_fused(dout, 0, Dm, shadow([c4.weight]), 1, 256, M, 256, Dm, da3, 256, c_f32=False, a_kind=2, a_dout=dout,
                            a_arg=arg4, a_group=K, a_ncols=Dm)
             else:
                 a3 = _bn_act(h3, 256, stat2, bn2, True, True)
-                dh4 = torch.empty(M, Dm, dtype=BF16, device=dev)
+                dh4 = torch.empty(M, Dm, dtype=H16, device=dev)
                 L.call("vpf_group_max_bwd", dout, 0, arg4, NG, K, Dm, dh4)
                 linear_wgrad(dh4, a3, Dm, 256, grad_buf(c4.weight), grad_buf(c4.bias))
                 da3 = linear_dgrad(dh4, shadow([c4.weight]), Dm, 256)
@@ -1801,13 +1801,13 @@ class Group2EmbFn(torch.autograd.Function):
             # conv(256,256) on [global | local]: per-group part and per-point part
             dgb = torch.empty(NG, 256, dtype=F32, device=dev)
             L.call("vpf_group_sum", dh3, NG, K, 256, dgb)                                        # d(per-group bias)
-            dh2 = torch.empty(M, 128, dtype=BF16, device=dev)
+            dh2 = torch.empty(M, 128, dtype=H16, device=dev)
             gemm(dh3, 0, 256, w3[128:], 1, 256, M, 128, 256, dh2, 128, c_f32=False)                            # dlocal
         colsum(dgb, 256, grad_buf(c3.bias))
-        dgb16 = to_bf16(dgb)
+        dgb16 = to_h16(dgb)
         gemm(dgb16, 1, 256, gmax, 1, 128, 256, 128, NG, gW3, 256, c_f32=True, mode=EPI_ATOMIC)            # dW[:, :128]
         gemm(dh3, 1, 256, h2, 1, 128, 256, 128, M, gW3[:, 128:], 256, c_f32=True, mode=EPI_ATOMIC)        # dW[:, 128:]
-        dgmax = torch.empty(NG, 128, dtype=BF16, device=dev)
+        dgmax = torch.empty(NG, 128, dtype=H16, device=dev)
         gemm(dgb16, 0, 256, w3, 1, 256, NG, 128, 256, dgmax, 128, c_f32=False)                             # dglobal
         L.call("vpf_group_max_scatter_add", dgmax, arg2, NG, K, 128, dh2)
         linear_wgrad(dh2, a1, 128, 64, grad_buf(c2.weight), grad_buf(c2.bias))
@@ -1826,7 +1826,7 @@ class Group2EmbFn(torch.autograd.Function):
 
 # --------------------------------------------------------------------------- adapter / position MLP / patch embedding
 class AdapterFn(torch.autograd.Function):
-    """PointCloudInputAdapter.point_mlp (classifier.py:31-36): Linear(C,64) LN ReLU Linear(64,D) -> bf16 [B,N,D]."""
+    """PointCloudInputAdapter.point_mlp (classifier.py:31-36): Linear(C,64) LN ReLU Linear(64,D) -> h16 [B,N,D]."""
 
     @staticmethod
     def forward(ctx, pts, mod, *params):
@@ -1836,7 +1836,7 @@ class AdapterFn(torch.autograd.Function):
         M = x.shape[0]
         l0, ln, l3 = mod.point_mlp[0], mod.point_mlp[1], mod.point_mlp[3]
         D = l3.weight.shape[0]
-        a = torch.empty(M, 64, dtype=BF16, device=x.device)
+        a = torch.empty(M, 64, dtype=H16, device=x.device)
         L.call("vpf_adapter_front_fwd", x, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data, a)
         y = linear_fwd(a, shadow([l3.weight]), D, 64, l3.bias.data)
         ctx.mod = mod
@@ -1851,7 +1851,7 @@ class AdapterFn(torch.autograd.Function):
         l0, ln, l3 = mod.point_mlp[0], mod.point_mlp[1], mod.point_mlp[3]
         D = l3.weight.shape[0]
         M, C = x.shape
-        dy16 = to_bf16(dy).view(M, D)
+        dy16 = to_h16(dy).view(M, D)
         linear_wgrad(dy16, a, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
         da = linear_dgrad(dy16, shadow([l3.weight]), D, 64)
         ws = torch.empty(2048 * 64 * 11, dtype=F32, device=x.device)          # per-block partial parameter gradients
@@ -1871,7 +1871,7 @@ class PosMLPFn(torch.autograd.Function):
         M = x.shape[0]
         l0, l2 = seq[0], seq[2]
         Hd, D = l0.weight.shape[0], l2.weight.shape[0]
-        g = torch.empty(M, Hd, dtype=BF16, device=x.device)
+        g = torch.empty(M, Hd, dtype=H16, device=x.device)
         L.call("vpf_smallk_fwd", x, M, C, l0.weight.data, l0.bias.data, Hd, 1, g)
         y = linear_fwd(g, shadow([l2.weight]), D, Hd, l2.bias.data, out_f32=True)
         ctx.seq = seq
@@ -1885,7 +1885,7 @@ class PosMLPFn(torch.autograd.Function):
         l0, l2 = ctx.seq[0], ctx.seq[2]
         Hd, D = l0.weight.shape[0], l2.weight.shape[0]
         M, C = x.shape
-        dy16 = to_bf16(dy).view(M, D)
+        dy16 = to_h16(dy).view(M, D)
         linear_wgrad(dy16, g, D, Hd, grad_buf(l2.weight), grad_buf(l2.bias))
         dg = linear_dgrad(dy16, shadow([l2.weight]), D, Hd)
         L.call("vpf_smallk_bwd", x, dg, M, C, l0.weight.data, l0.bias.data, Hd, 1, grad_buf(l0.weight), grad_buf(l0.bias))
@@ -1915,11 +1915,11 @@ class CaFrontFn(torch.autograd.Function):
         blocks = [(catt, ca[1].module, False, False)] + [(l[0].module.attention, l[1].module, True, True) for l in layers]
         packed = _pack_blocks(blocks, ca, dev, front=l2)
         tok = tokens.contiguous().float()
-        hpos = torch.empty(M, Hd, dtype=BF16, device=dev)
+        hpos = torch.empty(M, Hd, dtype=H16, device=dev)
         pos = torch.empty(M, D, dtype=F32, device=dev)
         base = torch.empty(M, D, dtype=F32, device=dev)
         mq, rq = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
-        nq, q = torch.empty(M, D, dtype=BF16, device=dev), torch.empty(M, D, dtype=BF16, device=dev)
+        nq, q = torch.empty(M, D, dtype=H16, device=dev), torch.empty(M, D, dtype=H16, device=dev)
         a = L.CaFront()
         a.M, a.D, a.hidden, a.C = M, D, Hd, C
         a.centers, a.W0, a.b0 = x.data_ptr(), l0.weight.data.data_ptr(), l0.bias.data.data_ptr()
@@ -1952,7 +1952,8 @@ def ca_front_supported(seq, tokens, enc) -> bool:
         return False
     # the stash is only ever consumed by EncoderFusedFn: the encoder call that follows must take the fused path
     probe = tokens.new_empty((tokens.shape[0], 1, 2 * tokens.shape[2]))
-    return bool(enc.fused_ok(tokens, probe))
+    fused_ok = getattr(enc, "fused_ok", None)              # (kernel tests hand in a bare stand-in for the encoder)
+    return bool(fused_ok(tokens, probe)) if fused_ok is not None else True
 
 
 class PatchEmbedFn(torch.autograd.Function):
@@ -1967,7 +1968,7 @@ class PatchEmbedFn(torch.autograd.Function):
         T, pd = (Hh // p) * (Ww // p), p * p * C
         if Hh % p or Ww % p:
             raise L.VpfError(f"image {Hh}x{Ww} is not divisible by patch_size {p}")
-        patches = torch.empty(B * T, pd, dtype=BF16, device=imgs.device)
+        patches = torch.empty(B * T, pd, dtype=H16, device=imgs.device)
         sb, sh, sw, sc = imgs.stride()
         L.call("vpf_patchify", imgs, sb, sh, sw, sc, B, Hh, Ww, C, p, patches)
         D = lin.weight.shape[0]
@@ -1982,7 +1983,7 @@ class PatchEmbedFn(torch.autograd.Function):
         (patches,) = ctx.saved_tensors
         lin = ctx.lin
         D, pd = lin.weight.shape
-        dy16 = to_bf16(dy).view(-1, D)
+        dy16 = to_h16(dy).view(-1, D)
         linear_wgrad(dy16, patches, D, pd, grad_buf(lin.weight), grad_buf(lin.bias))
         return (None, None, None) + (None,) * ctx.nparams
 
@@ -2029,7 +2030,7 @@ class HeadFn(torch.autograd.Function):
                 st = _bn_stat(t, C, bn, training)
                 return st, _bn_act(t, C, st, bn, True, True)
             st = torch.empty(2 * C, dtype=F32, device=t.device)
-            y_ = torch.empty(Bn, C, dtype=BF16, device=t.device)
+            y_ = torch.empty(Bn, C, dtype=H16, device=t.device)
             L.call("vpf_bn_small_fwd", t, Bn, C, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), bn.running_mean,
                    bn.running_var, bn.num_batches_tracked, st, y_, 1)
             return st, y_
@@ -2050,17 +2051,17 @@ class HeadFn(torch.autograd.Function):
         bn1, l1, bn2, l2 = seq[0], seq[2], seq[3], seq[5]
         C1 = x.shape[1]
         C2, C3 = l1.weight.shape[0], l2.weight.shape[0]
-        dy16 = to_bf16(dy)
+        dy16 = to_h16(dy)
         if l2.bias is not None:
             colsum(dy16, C3, grad_buf(l2.bias))
         linear_wgrad(dy16, a2, C3, C2, grad_buf(l2.weight))
         da2 = linear_dgrad(dy16, shadow([l2.weight]), C3, C2, out_f32=True)
 
-        def bn_bwd(dt, t, C, st, bn, out_bf16):
+        def bn_bwd(dt, t, C, st, bn, out_h16):
             if not ctx.small:
-                return _bn_bwd(dt, t, C, st, bn, True, training, out_bf16)
-            dx_ = torch.empty(t.shape[0], C, dtype=BF16 if out_bf16 else F32, device=t.device)
-            L.call("vpf_bn_small_bwd", dt, t, st, bn.weight.data, bn.bias.data, t.shape[0], C, 1, dx_, int(out_bf16),
+                return _bn_bwd(dt, t, C, st, bn, True, training, out_h16)
+            dx_ = torch.empty(t.shape[0], C, dtype=H16 if out_h16 else F32, device=t.device)
+            L.call("vpf_bn_small_bwd", dt, t, st, bn.weight.data, bn.bias.data, t.shape[0], C, 1, dx_, int(out_h16),
                    grad_buf(bn.weight), grad_buf(bn.bias))
             return dx_
 
@@ -2086,7 +2087,7 @@ class BnReluLinearFn(torch.autograd.Function):
         small = training and Bn <= 4096 and C1 % 64 == 0
         if small:
             st = torch.empty(2 * C1, dtype=F32, device=x.device)
-            a = torch.empty(Bn, C1, dtype=BF16, device=x.device)
+            a = torch.empty(Bn, C1, dtype=H16, device=x.device)
             L.call("vpf_bn_small_fwd", x, Bn, C1, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), bn.running_mean,
                    bn.running_var, bn.num_batches_tracked, st, a, 1)
         else:
@@ -2103,7 +2104,7 @@ class BnReluLinearFn(torch.autograd.Function):
         x, st, a = ctx.saved_tensors
         bn, lin = ctx.mods
         C1, C2 = x.shape[1], lin.weight.shape[0]
-        dy16 = to_bf16(dy)
+        dy16 = to_h16(dy)
         if lin.bias is not None:
             colsum(dy16, C2, grad_buf(lin.bias))
         linear_wgrad(dy16, a, C2, C1, grad_buf(lin.weight))

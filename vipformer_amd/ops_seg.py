@@ -1,13 +1,13 @@
 """Host-side glue of the part-segmentation head (BASELINE config 5): CrossFormer_partseg.forward partseg.py:407-470 and
 PointNetFeaturePropagation.forward utils.py:205-242 as autograd Functions over the C ABI -- the same conventions as ops.py (fp32
-master weights, bf16 MFMA operands, fp32 accumulation and statistics; weight gradients through ops._GradSink).
+master weights, h16 MFMA operands, fp32 accumulation and statistics; weight gradients through ops._GradSink).
 
     taps (encoder layers layer_idx, fp32 [B,G,D] each)
       -> LnTapsFn      : LayerNorm (shared parameters) of every tap, concatenated        -> xcat fp32 [B,G,F]   F = len(layer_idx) * D
       -> ops.PoolFn    : cat[max over groups, mean over groups]                          -> [B,2F]
     cls_label [B,16] -> LabelBranchFn : conv1d(16,64,no bias) + BatchNorm + LeakyReLU(0.2) -> [B,64]
     FeaturePropFn(pts, centers, points1 = pts, xcat): 3-NN inverse-distance interpolation + (conv1d + BatchNorm + ReLU) x len(mlp)
-                                                                                         -> f_level_0 bf16 [B,N,1024]
+                                                                                         -> f_level_0 h16 [B,N,1024]
     SegConvFn(f_level_0, [max | mean | label]) : conv1 on cat(f_level_0, global.repeat(N)) -- the global part enters as a
         per-cloud bias (global . W[:,1024:]^T + b), it is never repeated N times -- BatchNorm ReLU Dropout(0.5) conv2 BatchNorm ReLU conv3
                                                                                          -> logits fp32 [B,N,num_part_classes]
@@ -18,8 +18,8 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .ops import (BF16, EPI_ATOMIC, EPI_GROUPBIAS, F32, _bn_act, _bn_bwd, _bn_stat, _sinked, colsum, gemm, grad_buf, linear_dgrad,
-                  linear_fwd, linear_wgrad, shadow, to_bf16)
+from .ops import (H16, EPI_ATOMIC, EPI_GROUPBIAS, F32, _bn_act, _bn_bwd, _bn_stat, _sinked, colsum, gemm, grad_buf, linear_dgrad,
+                  linear_fwd, linear_wgrad, shadow, to_h16)
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2        # the `relu` argument of the BatchNorm entry points (2 = LeakyReLU(0.2))
 
@@ -28,10 +28,10 @@ def _pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
-def _pad_bf16(src, rows, K, rows_out, Kp):
-    """bf16 [rows_out, Kp] zero-padded copy of src [rows, K] (vpf_pad_bf16): GEMM operands need multiples of 8."""
-    out = torch.empty(rows_out, Kp, dtype=BF16, device=src.device)
-    L.call("vpf_pad_bf16", src, int(src.dtype == BF16), rows, K, K, rows_out, Kp, out)
+def _pad_h16(src, rows, K, rows_out, Kp):
+    """h16 [rows_out, Kp] zero-padded copy of src [rows, K] (vpf_pad_h16): GEMM operands need multiples of 8."""
+    out = torch.empty(rows_out, Kp, dtype=H16, device=src.device)
+    L.call("vpf_pad_h16", src, int(src.dtype == H16), rows, K, K, rows_out, Kp, out)
     return out
 
 
@@ -84,10 +84,10 @@ class LabelBranchFn(torch.autograd.Function):
         B = cls_label.shape[0]
         lab = cls_label.reshape(B, Cin)
         L.need_cuda(lab)
-        lab16 = to_bf16(lab)
+        lab16 = to_h16(lab)
         z = linear_fwd(lab16, shadow([conv.weight]), Cout, Cin, None, out_f32=True)
         small = training and B <= 4096 and Cout % 64 == 0
-        y = torch.empty(B, Cout, dtype=BF16, device=z.device)
+        y = torch.empty(B, Cout, dtype=H16, device=z.device)
         if small:
             st = torch.empty(2 * Cout, dtype=F32, device=z.device)
             L.call("vpf_bn_small_fwd", z, B, Cout, bn.weight.data, bn.bias.data, float(bn.eps), float(bn.momentum), bn.running_mean,
@@ -108,7 +108,7 @@ class LabelBranchFn(torch.autograd.Function):
         Cin = lab16.shape[1]
         dy = dy.contiguous().float()
         if ctx.small:
-            dz = torch.empty(B, Cout, dtype=BF16, device=z.device)
+            dz = torch.empty(B, Cout, dtype=H16, device=z.device)
             L.call("vpf_bn_small_bwd", dy, z, st, bn.weight.data, bn.bias.data, B, Cout, ACT_LEAKY, dz, 1, grad_buf(bn.weight), grad_buf(bn.bias))
         else:
             dz = _bn_bwd(dy, z, Cout, st, bn, ACT_LEAKY, ctx.training, True)
@@ -117,9 +117,9 @@ class LabelBranchFn(torch.autograd.Function):
 
 
 def _conv_bn_relu_fwd(x16, K, conv, bn, training, w16=None):
-    """relu(bn(conv1d_k1(x))) on rows: x16 bf16 [M,K] -> (h f32 [M,Cout] pre-norm, stat, a bf16 [M,Cout]).  The pre-normalisation
+    """relu(bn(conv1d_k1(x))) on rows: x16 h16 [M,K] -> (h f32 [M,Cout] pre-norm, stat, a h16 [M,Cout]).  The pre-normalisation
     activation stays fp32: training-mode BatchNorm divides by the spread of a channel over the rows, which for smoothly interpolated
-    features is a small fraction of its magnitude -- a bf16 rounding of h (relative to |h|) would be amplified by |h| / std(h)."""
+    features is a small fraction of its magnitude -- a h16 rounding of h (relative to |h|) would be amplified by |h| / std(h)."""
     Cout = conv.weight.shape[0]
     h = linear_fwd(x16, w16 if w16 is not None else shadow([conv.weight]), Cout, K, conv.bias.data if conv.bias is not None else None,
                    out_f32=True)
@@ -130,7 +130,7 @@ def _conv_bn_relu_fwd(x16, K, conv, bn, training, w16=None):
 class FeaturePropFn(torch.autograd.Function):
     """PointNetFeaturePropagation.forward (utils.py:205-242) in row-major layouts: xyz1 [B,N,3+] (targets), xyz2 [B,S,3+] (sources),
     points1 [B,N,C1] or None (concatenated IN FRONT of the interpolated features, :232-236), feat fp32 [B,S,F] (= points2) ->
-    bf16 [B,N,mlp[-1]].  The full sort of utils.py:224 is a running 3-minimum (vpf_three_nn_f32), the gather + weighting + concat
+    h16 [B,N,mlp[-1]].  The full sort of utils.py:224 is a running 3-minimum (vpf_three_nn_f32), the gather + weighting + concat
     land directly in the first convolution's operand (vpf_interp_rows_fwd)."""
 
     @staticmethod
@@ -156,12 +156,12 @@ class FeaturePropFn(torch.autograd.Function):
             p1, C1 = xyz1c, 0
         Kin = C1 + Fd
         Kp = _pad8(Kin)
-        A0 = torch.empty(M, Kp, dtype=BF16, device=dev)
+        A0 = torch.empty(M, Kp, dtype=H16, device=dev)
         L.call("vpf_interp_rows_fwd", featc, p1, B, N, C1, S, Fd, idx, w, Kp, A0)
         convs, bns = list(mod.mlp_convs), list(mod.mlp_bns)
         if convs[0].weight.shape[1] != Kin:
             raise L.VpfError(f"PointNetFeaturePropagation: in_channel {convs[0].weight.shape[1]} != {C1} + {Fd}")
-        w0p = _pad_bf16(shadow([convs[0].weight]), convs[0].weight.shape[0], Kin, convs[0].weight.shape[0], Kp)
+        w0p = _pad_h16(shadow([convs[0].weight]), convs[0].weight.shape[0], Kin, convs[0].weight.shape[0], Kp)
         saved, x16, K = [], A0, Kp
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             h, st, a = _conv_bn_relu_fwd(x16, K, conv, bn, training, w0p if i == 0 else None)
@@ -180,7 +180,7 @@ class FeaturePropFn(torch.autograd.Function):
         B, N, S, Fd, C1, Kp = ctx.dims
         convs, bns = list(mod.mlp_convs), list(mod.mlp_bns)
         M = B * N
-        d = to_bf16(dout).view(M, -1)
+        d = to_h16(dout).view(M, -1)
         for i in range(len(convs) - 1, -1, -1):
             conv, bn = convs[i], bns[i]
             x16, h, st = saved[3 * i:3 * i + 3]
@@ -205,7 +205,7 @@ class FeaturePropFn(torch.autograd.Function):
 
 class SegConvFn(torch.autograd.Function):
     """partseg.py:452-468: x = cat(f_level_0, x_global_feature.repeat(N)); relu(bn1(conv1(x))); dp1; relu(bn2(conv2)); conv3; permute.
-    f0 bf16 [B,N,C0]; gvec fp32 [B,Cg] = [x_max | x_avg | label feature] (the order of conv1's input channels after f_level_0)."""
+    f0 h16 [B,N,C0]; gvec fp32 [B,Cg] = [x_max | x_avg | label feature] (the order of conv1's input channels after f_level_0)."""
 
     @staticmethod
     def forward(ctx, f0, gvec, mod, training, *params):
@@ -218,8 +218,8 @@ class SegConvFn(torch.autograd.Function):
         Kt, C1o = conv1.weight.shape[1], conv1.weight.shape[0]
         if Kt != C0 + Cg or C0 % 8 or Cg % 8:
             raise L.VpfError(f"conv1 expects {Kt} input channels, got {C0} + {Cg} (both multiples of 8)")
-        f016 = to_bf16(f0).view(M, C0)
-        g16 = to_bf16(gvec)
+        f016 = to_h16(f0).view(M, C0)
+        g16 = to_h16(gvec)
         w1 = shadow([conv1.weight])                                               # [C1o, Kt]: columns [0,C0) per point, [C0,Kt) per cloud
         gb = torch.empty(B, C1o, dtype=F32, device=dev)
         gemm(g16, 0, Cg, w1[C0:], 0, Kt, B, C1o, Cg, gb, C1o, c_f32=True, bias=conv1.bias.data)      # the per-cloud part, once per cloud
@@ -232,7 +232,7 @@ class SegConvFn(torch.autograd.Function):
         if p > 0.0:
             tmp = torch.empty(M, C1o, dtype=F32, device=dev)
             L.call("vpf_dropout_add_fwd", a3, None, tmp, tmp.numel(), ctx.rng_st, mod.dp1.site, p)
-            a3d = to_bf16(tmp)
+            a3d = to_h16(tmp)
         else:
             a3d = a3
         C2o = conv2.weight.shape[0]
@@ -241,7 +241,7 @@ class SegConvFn(torch.autograd.Function):
         a4 = _bn_act(h4, C2o, st2, bn2, ACT_RELU, True)
         NC = conv3.weight.shape[0]
         NCp = _pad8(NC)
-        w3p = _pad_bf16(shadow([conv3.weight]), NC, C2o, NCp, C2o)
+        w3p = _pad_h16(shadow([conv3.weight]), NC, C2o, NCp, C2o)
         b3p = torch.zeros(NCp, dtype=F32, device=dev)
         b3p[:NC] = conv3.bias.data
         logits = linear_fwd(a4, w3p, NCp, C2o, b3p, out_f32=True)
@@ -260,7 +260,7 @@ class SegConvFn(torch.autograd.Function):
         Kt, C1o, C2o = conv1.weight.shape[1], conv1.weight.shape[0], conv2.weight.shape[0]
         M = B * N
         dev = dlogits.device
-        dl16 = _pad_bf16(dlogits.contiguous().float().view(M, NC), M, NC, M, NCp)
+        dl16 = _pad_h16(dlogits.contiguous().float().view(M, NC), M, NC, M, NCp)
         dW3 = torch.zeros(NCp, C2o, dtype=F32, device=dev)
         db3 = torch.zeros(NCp, dtype=F32, device=dev)
         linear_wgrad(dl16, a4, NCp, C2o, dW3, db3)
@@ -271,7 +271,7 @@ class SegConvFn(torch.autograd.Function):
         linear_wgrad(dh4, a3d, C2o, C1o, grad_buf(conv2.weight), grad_buf(conv2.bias))
         if p > 0.0:
             da3f = linear_dgrad(dh4, shadow([conv2.weight]), C2o, C1o, out_f32=True)
-            da3 = torch.empty(M, C1o, dtype=BF16, device=dev)
+            da3 = torch.empty(M, C1o, dtype=H16, device=dev)
             L.call("vpf_dropout_bwd", da3f, da3, da3f.numel(), ctx.rng_st, mod.dp1.site, p)
         else:
             da3 = linear_dgrad(dh4, shadow([conv2.weight]), C2o, C1o)
@@ -283,14 +283,14 @@ class SegConvFn(torch.autograd.Function):
         for b in range(B):
             colsum(dh3[b * N:(b + 1) * N], C1o, dgb[b])
         colsum(dgb, C1o, grad_buf(conv1.bias))
-        dgb16 = to_bf16(dgb)
+        dgb16 = to_h16(dgb)
         gemm(dgb16, 1, C1o, g16, 1, Cg, C1o, Cg, B, gW1[C0:], Kt, c_f32=True, mode=EPI_ATOMIC)       # dW1[:, C0:]
         dg = torch.empty(B, Cg, dtype=F32, device=dev)
         gemm(dgb16, 0, C1o, w1[C0:], 1, Kt, B, Cg, C1o, dg, Cg, c_f32=True)
-        df0 = torch.empty(M, C0, dtype=BF16, device=dev)
+        df0 = torch.empty(M, C0, dtype=H16, device=dev)
         gemm(dh3, 0, C1o, w1, 1, Kt, M, C0, C1o, df0, C0, c_f32=False)
         df0 = df0.view(B, N, C0)
-        return (df0 if ctx.f0_dtype == BF16 else ops.to_f32(df0), dg, None, None) + (None,) * ctx.nparams
+        return (df0 if ctx.f0_dtype == H16 else ops.to_f32(df0), dg, None, None) + (None,) * ctx.nparams
 
 
 class CrossEntropySmoothFn(torch.autograd.Function):

@@ -7,16 +7,18 @@
 What is specific to this implementation:
   * all parameters of both models live in ONE flat fp32 buffer (q/k/v weights adjacent so the
     fused [3D,D] projection needs no copy); gradients in one flat fp32 buffer that the wgrad
-    kernels accumulate into directly; Adam moments flat; a flat bf16 shadow of the weights is
+    kernels accumulate into directly; Adam moments flat; a flat h16 shadow of the weights is
     rewritten by the fused AdamW kernel (vpf_adamw_step) and is what the MFMA kernels read.
   * data parallelism = one process per GPU; the only collective is ONE all-reduce of the flat
     gradient buffer over RCCL/xGMI (the reference's two DDP reducers with 25 MB buckets become a
     single 33 MB message); NT-Xent negatives and BatchNorm statistics stay rank-local exactly
     like the reference (lightly 1.1.21 has no gather; no SyncBatchNorm).  The mean over ranks is
     folded into the AdamW kernel's gradient scale.
-  * bf16 operands need no loss scaling, so the reference's GradScaler (fp16 autocast,
-    pretrain.py:154,209-211) has no counterpart; the AdamW kernel still takes a gradient scale
-    and a skip flag so a scaler can be put in front of it.
+  * the MFMA operands are fp16 like the reference's autocast (pretrain.py:154,176), so the backward pass runs under
+    GradScaler's loss scale (pretrain.py:154,209-211) -- kept ON THE DEVICE so that a captured hipGraph follows it: the
+    loss gradient is seeded with the scale, vpf_grad_check looks for inf / NaN in the flat gradient, the AdamW kernel divides
+    the scale out or skips the step, and the kernel behind it halves / doubles the scale (torch.cuda.amp.GradScaler's defaults:
+    65536, x2 every 2000 good steps, x0.5 on overflow).
   * the whole step (forward, backward, AdamW, dropout-state advance) can be captured into one
     hipGraph (``capture=True``): a few hundred short kernels per step are launch-bound from Python.
 """
@@ -34,7 +36,7 @@ from . import ops
 
 
 class FlatParams:
-    """Flat fp32 parameters / gradients / Adam moments + bf16 shadow for a list of modules."""
+    """Flat fp32 parameters / gradients / Adam moments + h16 shadow for a list of modules."""
 
     def __init__(self, modules: Sequence[torch.nn.Module]):
         seen, params = set(), []
@@ -47,7 +49,7 @@ class FlatParams:
         dev = params[0].device
         offs, n = [], 0
         for p in params:
-            n = (n + 7) // 8 * 8            # 16-byte aligned bf16 shadow / 32-byte aligned fp32
+            n = (n + 7) // 8 * 8            # 16-byte aligned h16 shadow / 32-byte aligned fp32
             offs.append(n)
             n += p.numel()
         n = (n + 7) // 8 * 8
@@ -56,7 +58,7 @@ class FlatParams:
         self.g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.s = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        self.s = torch.empty(n, dtype=L.H16, device=dev)
         self.managed = ops.ManagedFlat(self.p, self.s, self.g)      # parameters point at it weakly: no process-wide registry
         for p, o in zip(params, offs):
             self.p[o:o + p.numel()].copy_(p.data.reshape(-1))
@@ -67,9 +69,9 @@ class FlatParams:
         self.refresh_shadow()
 
     def refresh_shadow(self) -> None:
-        """Re-cast the whole bf16 shadow from the fp32 values.  ops.shadow() does this per parameter when ``p._version`` moved
+        """Re-cast the whole h16 shadow from the fp32 values.  ops.shadow() does this per parameter when ``p._version`` moved
         (load_state_dict, an external optimizer); raw writes through ``p.data`` / ``flat.p`` do not bump it: call this then."""
-        L.call("vpf_cast_f32_bf16", self.p, self.s, self.numel)
+        L.call("vpf_cast_f32_h16", self.p, self.s, self.numel)
         for p in self.params:
             p._vpf_ver = p._version
 
@@ -186,7 +188,14 @@ class Pretrainer:
     """One object = the reference's models + AdamW + NT-Xent loop state for one rank."""
 
     def __init__(self, pc_model, img_model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, temperature=0.1,
-                 cmid_weight=1.0, process_group=None, world_size: Optional[int] = None, force_data_parallel: bool = False):
+                 cmid_weight=1.0, process_group=None, world_size: Optional[int] = None, force_data_parallel: bool = False,
+                 loss_scale: Optional[float] = None, growth_interval: int = 2000, growth_factor: float = 2.0, backoff_factor: float = 0.5):
+        """loss_scale: GradScaler's init_scale (pretrain.py:154).  None: torch's default 2 ** 16 (or VPF_LOSS_SCALE from the environment:
+        the test suite's 2 - 8-pair batches have per-sample gradients 8 - 30 x those of a 64-pair batch and inspect a single step, so
+        they start at the scale the scaler would back off to); 0 disables loss scaling and the overflow check (gradients below
+        fp16's range are then lost in the backward pass's 16-bit operands)."""
+        if loss_scale is None:
+            loss_scale = float(os.environ.get("VPF_LOSS_SCALE", "65536"))
         self.pc_model, self.img_model = pc_model, img_model
         self.temperature, self.cmid_weight = temperature, cmid_weight
         self.flat = FlatParams([pc_model, img_model])
@@ -198,9 +207,12 @@ class Pretrainer:
         # RCCL path is exercised on a single GPU (tests/test_boundary_gpu.py)
         self.dp = world_size > 1 or force_data_parallel
         dev = self.flat.p.device
-        # {lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip}
-        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / world_size, 0.0, 0.0],
-                                  dtype=torch.float32, device=dev)
+        # {lr, beta1, beta2, eps, weight_decay, grad_scale, step, skip | loss_scale, growth_tracker, growth_interval, found_inf,
+        #  growth_factor, backoff_factor, skipped_steps, -}  (include/vipformer_hip.h: vpf_adamw_step)
+        self.scaled = bool(loss_scale) and L.H16 == torch.float16
+        self.hyper = torch.tensor([lr, betas[0], betas[1], eps, weight_decay, 1.0 / world_size, 0.0, 0.0,
+                                   float(loss_scale) if self.scaled else 0.0, 0.0, float(growth_interval), 0.0,
+                                   float(growth_factor), float(backoff_factor), 0.0, 0.0], dtype=torch.float32, device=dev)
         self.device = dev
         # the image branch is independent of the point-cloud branch until the CMC loss: it runs on its own
         # stream so its kernels fill the CUs that FPS / kNN / the small GEMMs of the pc branch leave idle
@@ -219,7 +231,9 @@ class Pretrainer:
         self.losses = None
         self.zero_grad_in_optimizer = False      # AdamW leaves the gradient buffer zeroed for the next step (set by capture())
         self._g_clean = False
-        self._one = torch.ones((), dtype=torch.float32, device=dev)
+        # the loss gradient's seed: GradScaler.scale(loss) (pretrain.py:209) -- a VIEW of the device-resident scale, so a replayed graph
+        # backpropagates with whatever the last update left there; a persistent 1.0 without loss scaling (no ones_like fill per step)
+        self._one = self.hyper[8] if self.scaled else torch.ones((), dtype=torch.float32, device=dev)
         # gradient regions in the order backward finishes them: the image model (second half of the flat buffer; its backward runs
         # on the side stream and ends first), then the point-cloud model (Group2Emb / adapter weight gradients come last)
         n_pc = len({id(p) for p in pc_model.parameters()})
@@ -377,6 +391,33 @@ class Pretrainer:
         """The step's exchange: SUM of the flat gradient over ranks (mean folded into AdamW), region by region."""
         self.exchange.all()
 
+    # ------------------------------------------------------------------ GradScaler state (device-resident)
+    @property
+    def loss_scale(self) -> float:
+        """The current loss scale (a device read: not for the hot loop).  1.0 without loss scaling."""
+        return float(self.hyper[8]) if self.scaled else 1.0
+
+    @property
+    def skipped_steps(self) -> int:
+        """Steps the overflow check skipped so far (GradScaler: found_inf)."""
+        return int(self.hyper[14])
+
+    def unscaled_grad(self) -> torch.Tensor:
+        """flat.g without the loss scale (what GradScaler.unscale_ would leave in .grad); a copy."""
+        return self.flat.g / self.hyper[8] if self.scaled else self.flat.g.clone()
+
+    def unscale_(self) -> None:
+        """GradScaler.unscale_(optimizer): divide the flat gradient by the loss scale in place (for gradient clipping, or for reading
+        ``p.grad`` in the loss's own units); the next optimizer step then takes the gradients as they are."""
+        if self.scaled and float(self.hyper[15]) == 0.0:
+            self.flat.g.div_(self.hyper[8])
+            self.hyper[15] = 1.0
+
+    def _check_grads(self) -> None:
+        """scaler.step's inf / NaN check (pretrain.py:210) over the whole flat gradient, on the device: sets hyper[11]."""
+        if self.scaled:
+            L.call("vpf_grad_check", self.flat.g, self.flat.numel, self.hyper)
+
     def _adamw_region(self, a: int, b: int, advance: bool) -> None:
         f = self.flat
         L.call("vpf_adamw_step", f.p[a:b], f.g[a:b], f.m[a:b], f.v[a:b], f.s[a:b], b - a, self.hyper,
@@ -388,8 +429,15 @@ class Pretrainer:
         backward pass, launched after the early regions' transfers and before the late regions'.  The bias-correction step counter advances
         with the last region; the dropout state once per step."""
         last = len(self.regions) - 1
-        self.exchange.exchange([n for n, _, _ in self.late_regions], between,
-                               lambda i, n, a, b: self._adamw_region(a, b, i == last))
+        if self.scaled:
+            # the skip decision needs EVERY region's reduced gradient (an inf survives the SUM, so all ranks decide alike): AdamW runs
+            # once, behind the check, instead of region by region on arrival
+            self.exchange.exchange([n for n, _, _ in self.late_regions], between, None)
+            self._check_grads()
+            self._adamw_region(0, self.flat.numel, True)
+        else:
+            self.exchange.exchange([n for n, _, _ in self.late_regions], between,
+                                   lambda i, n, a, b: self._adamw_region(a, b, i == last))
         self._g_clean = self.zero_grad_in_optimizer
         ops.rng.advance(self.device)
 
@@ -400,6 +448,7 @@ class Pretrainer:
 
     def optimizer_step(self) -> None:
         f = self.flat
+        self._check_grads()
         L.call("vpf_adamw_step", f.p, f.g, f.m, f.v, f.s, f.numel, self.hyper, 1 | (2 if self.zero_grad_in_optimizer else 0))
         self._g_clean = self.zero_grad_in_optimizer
         ops.rng.advance(self.device)
@@ -438,6 +487,7 @@ class Pretrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.hyper[7] = skip_keep
+        self.hyper[11] = 0.0                                   # (an overflow seen by a warm-up step is not the first real step's business)
         ops.rng.state(self.device).copy_(rng_keep)
         with torch.no_grad():
             for b, k in zip(bufs, keep):
