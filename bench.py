@@ -284,7 +284,8 @@ def _pmc():
 PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step budget whose per-launch figures add up to one "launch" of the leg
     "fps_kernel": ["fps_kernel"],
     "knn_group_select_kernel": ["knn_group_select_kernel"],
-    "gemm_wgrad_group_kernel": ["gemm_wgrad_group_kernel"],
+    "gemm_wgrad_group_kernel": ["gemm_wgrad_group_kernel"],                # the stack-sized leg: the launch the step makes
+    "gemm_wgrad_group_kernel (one layer)": [],                             # (no such launch in the step: stand-alone figures only)
     "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel", "sa_rows_fwd_kernel"],
     "sa_bwd_qkv_mlp_rows_kernel": ["sa_bwd_qkv_mlp_rows_kernel"],
     "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel<3, 128>", "attn_fwd_kernel<4, 128>"],

@@ -11,7 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- p
 tail -1 $out/bench.log | cut -c1-200
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $PWD/gpurun_out/${tag}_bench_c2_kernel_stats.csv
 csvs=""
-for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
+for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16"; do
   d=$out/pmc_$(echo $ctr | cut -d' ' -f1)
   mkdir -p $d
   rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $d -o pmc -- python3 tools/microbench.py preproc attn wgroup satail > $d/log.txt 2>&1
