@@ -43,9 +43,11 @@ ARCHS = {"c2": dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=1024, img=224, patch=16
 # the geometry the reference's own training scripts ship (scripts/pretrain/pt-E1CL6SL-H4D256-L96-MR2-0.sh:10-16 + parser.py:112): 2048-pt
 # clouds, 144 x 144 images, patch 12 -> 144 tokens of 432 values; a side line like c3 / c4
 ARCHS["ref144"] = dict(D=256, H=4, G=96, K=32, S=6, MR=2, N=2048, img=144, patch=12)
-PAIRS = {"c2": 64, "c3": 32, "c4": 16, "ref144": 64}
+ARCHS["ref144m4"] = dict(ARCHS["ref144"], MR=4)                      # scripts/pretrain/pt-E1CL6SL-H4D256-L96-MR4-0.sh
+PAIRS = {"c2": 64, "c3": 32, "c4": 16, "ref144": 64, "ref144m4": 64}
 NAMES = {"c2": "E1CL6SL-H4D256-L96-MR2", "c3": "E1CL8SL-H4D256-L128-MR2", "c4": "E1CL8SL-H6D384-L128-MR4",
-         "ref144": "E1CL6SL-H4D256-L96-MR2, the reference scripts' 2048 pts + 144x144 img / patch 12"}
+         "ref144": "E1CL6SL-H4D256-L96-MR2, the reference scripts' 2048 pts + 144x144 img / patch 12",
+         "ref144m4": "E1CL6SL-H4D256-L96-MR4, the reference scripts' 2048 pts + 144x144 img / patch 12"}
 def _gflop_per_pair(a):
     """SURVEY 8d's formula (MAC counts x 2 FLOP, backward = 2 x forward): two clouds + one image."""
     D, G, K, S, MR, N = a["D"], a["G"], a["K"], a["S"], a["MR"], a["N"]
@@ -54,13 +56,14 @@ def _gflop_per_pair(a):
              + 2 * G * D * D + 2 * N * D * D + 2 * G * N * D + 2 * G * MR * D * D + S * (4 * G * D * D + 2 * G * G * D + 2 * G * MR * D * D) + 3 * D * D)
     image = T * 3 * p * p * D + (S + 1) * (4 * T * D * D + 2 * T * T * D + 2 * T * MR * D * D) + 3 * D * D
     return round(3 * 2 * (2 * cloud + image) / 1e9, 1)
-GFLOP_PER_PAIR = {"c2": 17.4, "c3": 24.2, "c4": 64.7, "ref144": _gflop_per_pair(ARCHS["ref144"])}   # fwd+bwd, 2 FLOP/MAC, backward = 2x forward
+GFLOP_PER_PAIR = {"c2": 17.4, "c3": 24.2, "c4": 64.7, "ref144": _gflop_per_pair(ARCHS["ref144"]), "ref144m4": _gflop_per_pair(ARCHS["ref144m4"])}   # fwd+bwd, 2 FLOP/MAC, backward = 2x forward
 PEAK_H16_TFLOPS = 2500.0      # MI355X dense h16 MFMA (guide: MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
 # whole-step budgets (tools/collect_step_bytes.sh: kernel trace + FETCH_SIZE + WRITE_SIZE passes of this very command, folded per
 # kernel over the last whole steps): launches per step, in-step average duration, HBM bytes per launch IN THE STEP
 PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r04_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r04_step_bytes_c3.json"),
-                "c4": os.path.join(ROOT, "profiles", "r04_step_bytes_c4.json"), "ref144": os.path.join(ROOT, "profiles", "r04_step_bytes_ref144.json")}
+                "c4": os.path.join(ROOT, "profiles", "r04_step_bytes_c4.json"), "ref144": os.path.join(ROOT, "profiles", "r04_step_bytes_ref144.json"),
+                "ref144m4": os.path.join(ROOT, "profiles", "r04_step_bytes_ref144m4.json")}
 PROFILE_PMC = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels (tools/collect_profiles.sh)
 
 

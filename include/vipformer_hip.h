@@ -432,6 +432,8 @@ typedef struct VpfPgradJob { const float* partials; int rows; int D; float* dgam
 int vpf_ln_pgrad_reduce(const VpfPgradJob* host_jobs, int njobs, void* stream);
 /* number of partial rows (2 D floats each) the two backward kernels write for M tokens: size pgrad1 / pgrad2 and the reduce job with it */
 int vpf_sa_layer_pgrad_rows(long M, int D);
+/* ... for an MLP hidden width other than the default of D (512 at D = 256, 1536 at D = 384): D = 256 / hidden 1024 (mlp_widen_factor 4) */
+int vpf_sa_layer_pgrad_rows_h(long M, int D, int hidden);
 /* PointCloudInputAdapter.point_mlp (classifier.py:31-36) + the cross-attention kv LayerNorm and K / V projections
  * (partseg.py:48-51,100-116) in one kernel, 64 (D = 256) or 32 (D = 384) points per workgroup.  x f32 [M,C<=8]; W1 f32 [64,C];
  * W2 = vpf_pack_wfrag of the h16 [D,64] weight; Wkv = vpf_pack_wfrag of the h16 [2D,D] k|v weights.

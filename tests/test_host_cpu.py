@@ -49,7 +49,7 @@ def test_ctypes_table_matches_header():
                 t = p.split()[1] if p.startswith("const") else p.split()[0]
                 want.append({"int": "i", "long": "l", "float": "f", "uint32_t": "u"}[t])
         assert [kind[t] for t in sig] == want, name
-    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id", "vpf_operand_dtype", "vpf_debug_set", "vpf_debug_get", "vpf_sa_layer_pgrad_rows", "vpf_adapter_kv_pgrad_rows"}
+    assert set(fns) - set(_lib.SIGS) <= {"vpf_version", "vpf_strerror", "vpf_build_id", "vpf_operand_dtype", "vpf_debug_set", "vpf_debug_get", "vpf_sa_layer_pgrad_rows", "vpf_sa_layer_pgrad_rows_h", "vpf_adapter_kv_pgrad_rows"}
     # the 16-bit operand type the library was built for is the one the Python side allocates (fp16: the reference's autocast dtype)
     import torch as _t
     from tests import helpers as _Hh

@@ -344,9 +344,12 @@ ZERO_GRAD = ("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias")    
 # near-tied max-pool winner that flips re-routes its gradient -- which is also why the bf16-era rule "within 3 x the emulated budget of the
 # same batch" no longer says anything: the emulation of one batch has no flip (budget 2e-5), the kernels have one (5e-4), both are fine).
 FLOORS = {"linear loss": (2e-3, 1e-2), "NT-Xent loss": (4e-3, 2e-2)}           # tag -> (all-parameter deficit, worst per-tensor deficit)
+# ... and at the goldens' 4 - 8 pairs, where the pre-training loss sits behind a BatchNorm over 8 / 4 samples and a temperature-0.1 softmax:
+# the fp16-EMULATING oracle itself is 1.2 - 3.1e-3 from fp32 there (measured, both encoder paths), the kernels 0.7 - 5.2e-3
+FLOORS_SMALL_BATCH = {"linear loss": (2e-3, 1e-2), "NT-Xent loss": (8e-3, 3e-2)}
 
 
-def budget_check(ck, where, tag, pc, im, hip_grad_of, g_emu, g_f32, slack_all=None, slack_min=None):
+def budget_check(ck, where, tag, pc, im, hip_grad_of, g_emu, g_f32, slack_all=None, slack_min=None, floors=None):
     """Gradient parity against the fp32 oracle with CONSTANT floors (FLOORS above; VERDICT r03 item 2: the rounding-budget multiples of
     rounds 2 - 3 are gone with bf16).  The deficit of the fp16-emulating oracle on the same batch -- what the data format costs
     whatever the kernels do -- is reported beside it, not asserted.  g_emu / g_f32: [pc grads, img grads] dicts by parameter name."""
@@ -363,7 +366,7 @@ def budget_check(ck, where, tag, pc, im, hip_grad_of, g_emu, g_f32, slack_all=No
     for x in sorted(per, reverse=True)[:3]:
         report(f"{where} [{tag}] largest deficit vs fp32: hip {x[0]:.5f} emulated {x[1]:.5f} hip-vs-emulated {x[2]:.5f} {x[3]}")
     report(f"{where} [{tag}] all-parameter deficit (1 - cos): hip/fp32 {d_hf:.5f}  emulated/fp32 {d_ef:.5f}  hip/emulated {d_he:.5f}")
-    f_all, f_min = FLOORS[tag]
+    f_all, f_min = (floors or FLOORS)[tag]
     ck.lt(f"[{tag}] all-parameter gradient deficit (1 - cos) vs fp32", d_hf, f_all)
     ck.lt(f"[{tag}] all-parameter gradient deficit (1 - cos) vs the fp16-emulating oracle", d_he, f_all)
     ck.lt(f"[{tag}] worst per-tensor gradient deficit vs fp32", w_hf, f_min)
@@ -455,10 +458,10 @@ def _training_step_with_dropout_vs_oracle(name):
     ntx_emu = grads_of((pcp, imp)); clear((pcp, imp))
     # loss linear in the backbone features: the well-conditioned check of every backward kernel (residual differences: max-pool
     # winners -- token pooling, group pooling -- that flip between near-tied candidates re-route a gradient discontinuously)
-    budget_check(ck, f"dropout-step[{name}]", "linear loss", pc, im, lambda p: lin_grads.get(id(p)), lin_emu, lin_f32, 2e-4, 2e-3)
+    budget_check(ck, f"dropout-step[{name}]", "linear loss", pc, im, lambda p: lin_grads.get(id(p)), lin_emu, lin_f32, floors=FLOORS_SMALL_BATCH)
     # the pre-training loss: BatchNorm over 2B / B samples and the temperature-0.1 softmax amplify every forward difference into a
     # rotation of dL/dfeats that all parameter gradients inherit -- the budget measures exactly that amplification for this batch
-    budget_check(ck, f"dropout-step[{name}]", "NT-Xent loss", pc, im, lambda p: p.grad, ntx_emu, ntx_f32, 1e-3, 5e-3)
+    budget_check(ck, f"dropout-step[{name}]", "NT-Xent loss", pc, im, lambda p: p.grad, ntx_emu, ntx_f32, floors=FLOORS_SMALL_BATCH)
     ck.done()
 
 
@@ -546,11 +549,12 @@ def test_ln_pgrad_reduce_flush_mid_stack_sees_written_partials():
     C.done()
 
 
-@pytest.mark.parametrize("name", ["c1", "c4"])
+@pytest.mark.parametrize("name", ["c1", "c4", "ref144m4"])
 def test_fused_sa_stack_matches_unfused_blocks(name):
     """vpf_sa_layer_fwd / vpf_sa_layer_bwd_* (fused self-attention layers) against the block-by-block kernels they
     replace: same dropout masks (same sites / state), so the loss and the gradients agree up to h16 rounding of
-    intermediates.  c4 (D = 384, 6 heads, hidden 1536: BASELINE config 4) runs the round-3 row-block kernels (sa_rows.hip)."""
+    intermediates.  c4 (D = 384, 6 heads, hidden 1536: BASELINE config 4) and ref144m4 (D = 256 with hidden 1024: the reference's -MR4-
+    scripts) run the D-generic row-block kernels (sa_rows.hip)."""
     from vipformer_amd import ops
     from vipformer_amd.train import Pretrainer, build_models
     a = Hh.ARCHS[name]
@@ -592,19 +596,19 @@ def test_fused_sa_stack_matches_unfused_blocks(name):
     C = Checks(f"fused_sa_stack {name}")
     for (l1, f1, g1), (fused, fused_bwd, split, enc) in zip(results[1:], variants[1:]):
         tag = f"[fwd fused, attention {'split' if split else 'inside'}, bwd {'fused' if fused_bwd else 'blocks'}{(', CA tail + adapter/kv fused' + (' (bwd too)' if enc == 2 else '')) if enc else ''}]"
-        C.lt(tag + " pc backbone feats rel", rel(f1, f0), 2e-2)
-        C.lt(tag + " loss rel", abs(l1 - l0) / abs(l0), 2e-2)
+        C.lt(tag + " pc backbone feats rel", rel(f1, f0), 2e-3)
+        C.lt(tag + " loss rel", abs(l1 - l0) / abs(l0), 2e-3)
         allg1 = torch.cat([g1[k].reshape(-1) for k in g0])
         # (the pre-training loss: BatchNorm over 8 samples and the temperature-0.1 softmax amplify the h16 differences of two
         # equivalent kernel paths, and a near-tie of the token max-pool can re-route a gradient: 0.97-0.995 across operating
         # points; the well-conditioned gradient checks are the linear-loss ones of the golden / oracle tests)
-        C.gt(tag + " all grads cos", cosine(allg1, allg0), 0.95)
+        C.gt(tag + " all grads cos", cosine(allg1, allg0), 0.99)
         worst = min((cosine(g1[k], g0[k]), k) for k in g0 if "sa_layers" in k and g0[k].numel() >= 256)
         report(f"fused_sa_stack {tag} worst sa grad: {worst}")
-        C.gt(tag + " worst sa-layer grad cos", worst[0], 0.9)
+        C.gt(tag + " worst sa-layer grad cos", worst[0], 0.97)
         front = min((cosine(g1[k], g0[k]), k) for k in g0 if ("input_adapter" in k or "kv_norm" in k or "k_proj" in k or "v_proj" in k) and k.startswith("pc."))
         report(f"fused_sa_stack {tag} worst adapter / kv grad: {front}")
-        C.gt(tag + " worst adapter / kv-side grad cos", front[0], 0.9)
+        C.gt(tag + " worst adapter / kv-side grad cos", front[0], 0.97)
     C.done()
 
 
@@ -827,14 +831,16 @@ def test_group2emb_first_conv_backward_fused_matches_two_kernels():
             assert cosine(grads[0][k], grads[1][k]) > 0.9999, k          # (untouched by the switch: fp32 atomic order only)
 
 
-def test_reference_script_geometry_takes_the_fused_paths():
+@pytest.mark.parametrize("name", ["ref144", "ref144m4"])
+def test_reference_script_geometry_takes_the_fused_paths(name):
     """scripts/pretrain/pt-E1CL6SL-H4D256-L96-MR2-0.sh:10-16 + parser.py:112 (2048-point clouds, 144 x 144 images, patch 12 -> 144 tokens
-    of 432 values): every fused path of the c2 architecture applies unchanged -- the fused encoder (no block-by-block fallback), the
-    fused K / V producer, the cross-attention front, the resident self-attention kernels (5 query blocks) -- and one captured training
-    step runs.  (Parity of this geometry: the ref144 cases of the golden / dropout-step / full-batch tests.)"""
+    of 432 values), and the -MR4- scripts' mlp_widen_factor 4 (hidden 1024 at D = 256: the D-generic row-block kernels): every fused
+    path applies -- the fused encoder (no block-by-block fallback), the fused K / V producer, the cross-attention front, the resident
+    self-attention kernels (5 query blocks) -- and one training step runs.  (Parity of these geometries: the ref144 / ref144m4 cases of
+    the golden / dropout-step / full-batch tests.)"""
     from vipformer_amd import ops
     from vipformer_amd.train import Pretrainer
-    pc, im, a = build("ref144", (0.1, 0.5))
+    pc, im, a = build(name, (0.1, 0.5))
     pc.train(); im.train()
     B = 4
     tok = torch.empty(2 * B, a["G"], a["D"], device="cuda")
@@ -859,4 +865,5 @@ def test_reference_script_geometry_takes_the_fused_paths():
     assert all(torch.isfinite(l).item() for l in losses)
     n_fwd = sum(1 for n in launched if n == "vpf_sa_layer_fwd")
     assert n_fwd == 2 * (a["S"] + 1), (n_fwd, sorted(set(launched)))                 # one fused tail per layer and branch: nothing fell back
-    assert "vpf_adapter_kv_fwd" in launched and "vpf_ca_front_fwd" in launched and "vpf_ca_front_bwd" in launched
+    assert "vpf_adapter_kv_fwd" in launched and "vpf_ca_front_fwd" in launched
+    assert ("vpf_ca_front_bwd" in launched) == (name == "ref144")                     # (its partial rows are per 64 tokens: hidden 512 only)

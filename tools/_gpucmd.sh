@@ -1,2 +1,2 @@
-timeout 400 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; tail -c 200 gpurun_out/bench_default.err
-for a in c3 c4; do timeout 300 python bench.py --arch $a --no-cpu-baseline --no-variants > gpurun_out/bench_$a.json 2>/dev/null; done
+timeout 1500 python -m pytest tests/test_modules_gpu.py -q -p no:cacheprovider -k "ref144m4" > gpurun_out/t_mr4.log 2>&1; grep -E '^(FAILED|ERROR)|passed|failed' gpurun_out/t_mr4.log; grep -E "^E  " gpurun_out/t_mr4.log | head -20
+timeout 300 python bench.py --arch ref144 --no-cpu-baseline --no-kernels --no-variants 2>/dev/null | tail -1 | cut -c1-200

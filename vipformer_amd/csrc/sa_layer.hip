@@ -862,7 +862,7 @@ extern "C" int vpf_sa_layer_fwd(const VpfSaLayerFwd* args, void* stream)
     if (a.B <= 0 || a.L <= 0 || a.chunk_rows <= 0) return VPF_ERR_BADSHAPE;
     hipStream_t st = (hipStream_t)stream;
     // round 3: the row-block kernels built for two workgroups per CU (sa_rows.hip); D = 384 / hidden 1536 exists only there
-    if (a.attention_done && sa_rows_supported(a.D, a.hidden) && ((vpf_debug().sa_wg2 & 1) || a.D != SA_D)) {
+    if (a.attention_done && sa_rows_supported(a.D, a.hidden) && ((vpf_debug().sa_wg2 & 1) || a.D != SA_D || a.hidden != SA_HID)) {
         if (a.D != a.H * SA_DH) return VPF_ERR_UNSUPPORTED;
         return sa_rows_fwd_launch(a, st);
     }
@@ -1564,13 +1564,14 @@ extern "C" int vpf_ln_pgrad_reduce(const VpfPgradJob* jobs, int njobs, void* str
 // rows of LayerNorm parameter-gradient partials (2 D floats each) that vpf_sa_layer_bwd_mlp / _qkv write for M tokens: the caller
 // sizes pgrad1 / pgrad2 and the reduce job with it (one row per 64 tokens for the D = 256 kernels of rounds 1 - 2, per 32 tokens for
 // the round-3 kernels)
-extern "C" int vpf_sa_layer_pgrad_rows(long M, int D)
+extern "C" int vpf_sa_layer_pgrad_rows_h(long M, int D, int hidden)
 {
     if (M <= 0) return 0;
-    if (D == SA_D && !(vpf_debug().sa_wg2 & 2)) return vpf_cdiv(M, 64);
+    if (D == SA_D && hidden == SA_HID && !(vpf_debug().sa_wg2 & 2)) return vpf_cdiv(M, 64);
     const int t = sa_rows_bwd_pgrad_tokens(D);
     return D == SA_D ? vpf_cdiv(M, 64) * (64 / t) : vpf_cdiv(M, t);
 }
+extern "C" int vpf_sa_layer_pgrad_rows(long M, int D) { return vpf_sa_layer_pgrad_rows_h(M, D, D == SA_D ? SA_HID : 4 * D); }
 
 static int sa_bwd_nj()
 {
@@ -1578,7 +1579,7 @@ static int sa_bwd_nj()
 }
 static bool sa_bwd_rows3(const VpfSaLayerBwd& a)      // the round-3 kernels (sa_rows.hip): any supported width when asked for, the only ones beyond D = 256
 {
-    return sa_rows_supported(a.D, a.hidden) && ((vpf_debug().sa_wg2 & 2) || a.D != SA_D);
+    return sa_rows_supported(a.D, a.hidden) && ((vpf_debug().sa_wg2 & 2) || a.D != SA_D || a.hidden != SA_HID);
 }
 static int sa_bwd_check(const VpfSaLayerBwd& a)
 {

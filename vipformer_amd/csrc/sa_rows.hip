@@ -1067,7 +1067,8 @@ int bwd_qkv_launch(const VpfSaLayerBwd& a, hipStream_t st)
 
 }   // namespace
 
-bool sa_rows_supported(int D, int hidden) { return (D == 256 && hidden == 512) || (D == 384 && hidden == 1536); }
+// (D = 256, hidden 1024: mlp_widen_factor 4 at the default width -- scripts/pretrain/pt-*-MR4-0.sh of the reference; only these kernels have it)
+bool sa_rows_supported(int D, int hidden) { return (D == 256 && (hidden == 512 || hidden == 1024)) || (D == 384 && hidden == 1536); }
 
 int sa_rows_fwd_launch(const VpfSaLayerFwd& a, hipStream_t st)
 {
@@ -1079,6 +1080,7 @@ int sa_rows_fwd_launch(const VpfSaLayerFwd& a, hipStream_t st)
             default: return fwd_launch<256, 512, 1, 1, 4>(a, st, true);
         }
     }
+    if (a.D == 256 && a.hidden == 1024) return fwd_launch<256, 1024, 1, 1, 4>(a, st, true);
     if (a.D == 384 && a.hidden == 1536) return vpf_debug().sa_rb == 2 ? fwd_launch<384, 1536, 2, 1, 3>(a, st) : fwd_launch<384, 1536, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
 }
@@ -1090,6 +1092,7 @@ int sa_rows_bwd_pgrad_tokens(int D) { return (D == 384 && vpf_debug().sa_rb == 2
 int sa_rows_bwd_mlp_launch(const VpfSaLayerBwd& a, hipStream_t st)
 {
     if (a.D == 256 && a.hidden == 512) return bwd_mlp_launch<256, 512, 1, 2, 4>(a, st);      // 16 waves x 32 tokens each (the 8-wave x 64 shape spills at 128 registers)
+    if (a.D == 256 && a.hidden == 1024) return bwd_mlp_launch<256, 1024, 1, 2, 4>(a, st);
     if (a.D == 384 && a.hidden == 1536) return vpf_debug().sa_rb == 2 ? bwd_mlp_launch<384, 1536, 2, 1, 3>(a, st) : bwd_mlp_launch<384, 1536, 1, 1, 3>(a, st);
     return VPF_ERR_UNSUPPORTED;
 }

@@ -818,19 +818,24 @@ def sa_stack_supported(layers, x) -> bool:
     if not cfg.sa_fused or len(layers) == 0 or x.dim() != 3:
         return False
     B, Lq, D = x.shape
-    if (D, FUSED_WIDTHS.get(D)) not in ((256, (4, 512)), (384, (6, 1536))) or Lq > 224:
+    if D not in FUSED_WIDTHS or Lq > 224:
         return False
+    first = None
     for layer in layers:
         att = layer[0].module.attention
         mlp = layer[1].module
-        if (att.num_heads, mlp[1].weight.shape[0]) != FUSED_WIDTHS[D] or mlp[1].weight.shape[1] != D:
+        hw = (att.num_heads, mlp[1].weight.shape[0])
+        if hw not in FUSED_WIDTHS[D] or mlp[1].weight.shape[1] != D or hw != (first or hw):
             return False
+        first = hw
         if not isinstance(layer[0].drop_path, torch.nn.Identity) or not isinstance(layer[1].drop_path, torch.nn.Identity):
             return False
     return True
 
 
-FUSED_WIDTHS = {256: (4, 512), 384: (6, 1536)}      # model width -> (heads, MLP hidden) the fused encoder kernels are built for
+# model width -> the (heads, MLP hidden) pairs the fused encoder kernels are built for (first = the default of that width; D = 256 with
+# hidden 1024 = mlp_widen_factor 4, scripts/pretrain/pt-*-MR4-0.sh of the reference, runs the D-generic kernels of sa_rows.hip)
+FUSED_WIDTHS = {256: ((4, 512), (4, 1024)), 384: ((6, 1536),)}
 
 
 def _block_dims(att, mlp):
@@ -838,11 +843,13 @@ def _block_dims(att, mlp):
     return mlp[1].weight.shape[1], mlp[1].weight.shape[0], att.num_heads
 
 
-def pgrad_rows(M: int, D: int) -> int:
-    """Partial rows the backward row-block kernels write per LayerNorm (vpf_sa_layer_pgrad_rows)."""
-    fn = L.lib().vpf_sa_layer_pgrad_rows
-    fn.argtypes, fn.restype = [ctypes.c_long, ctypes.c_int], ctypes.c_int
-    return int(fn(M, D))
+def pgrad_rows(M: int, D: int, hidden: Optional[int] = None) -> int:
+    """Partial rows the backward row-block kernels write per LayerNorm (vpf_sa_layer_pgrad_rows[_h])."""
+    if hidden is None:
+        hidden = FUSED_WIDTHS[D][0][1] if D in FUSED_WIDTHS else 2 * D
+    fn = L.lib().vpf_sa_layer_pgrad_rows_h
+    fn.argtypes, fn.restype = [ctypes.c_long, ctypes.c_int, ctypes.c_int], ctypes.c_int
+    return int(fn(M, D, hidden))
 
 
 def _sa_packed(layers, dev):
@@ -940,7 +947,7 @@ class SAStackFn(torch.autograd.Function):
             a.p_res2, a.site_res2 = float(layer[1].dropout.p if training else 0.0), layer[1].site
             a.o, a.lse, a.x1, a.mean2, a.rstd2, a.n2 = o.data_ptr(), lse.data_ptr(), x1.data_ptr(), m2.data_ptr(), r2.data_ptr(), n2.data_ptr()
             a.u, a.h, a.out = u.data_ptr(), h.data_ptr(), out.data_ptr()
-            split = cfg.sa_split_attn if (cfg.sa_split_attn is not None and D == 256) else True      # (attention inside the layer kernel: D = 256 only)
+            split = cfg.sa_split_attn if (cfg.sa_split_attn is not None and D == 256 and Hd == 512) else True      # (attention inside the layer kernel: D = 256 / hidden 512 only)
             if split:
                 L.call("vpf_attention_fwd", qkv, 3 * D, qkv[:, D:], 3 * D, qkv[:, 2 * D:], 3 * D, B, H, Lq, Lq, D // H, float(att.dp_scale),
                        float(a.p_att), st, att.site_attn, o, D, lse)
@@ -1037,7 +1044,7 @@ class SAStackFn(torch.autograd.Function):
         B, Lq, D, Hd, H = ctx.dims
         M = B * Lq
         dev = d.device
-        nwg = pgrad_rows(M, D)
+        nwg = pgrad_rows(M, D, Hd)
         nl = len(layers)
         pg = torch.empty(nl, 2, nwg * 2 * D, dtype=F32, device=dev)       # LayerNorm parameter-gradient partials of every layer
         pjobs = (L.PgradJob * 32)()
@@ -1296,7 +1303,7 @@ class EncoderFusedFn(torch.autograd.Function):
         d = dout.contiguous().float().view(M, D) if dout is not None else None
         want_pos = ctx.pos_shape is not None and ctx.needs_input_grad[1]
         nl = len(layers)
-        nwg = pgrad_rows(M, D)
+        nwg = pgrad_rows(M, D, Hd)
         pg = torch.empty(nl + 1, 2, nwg * 2 * D, dtype=F32, device=dev)
         pjobs = (L.PgradJob * 32)()
         npj = 0
@@ -1580,8 +1587,10 @@ def encoder_fused_supported(ca, layers, x, xkv) -> bool:
         return False
     att, mlp = ca[0].module.attention, ca[1].module
     D = x.shape[-1]
-    if (att.num_heads, mlp[1].weight.shape[0]) != FUSED_WIDTHS[D] or xkv.shape[-1] not in (D, 2 * D):
+    if (att.num_heads, mlp[1].weight.shape[0]) not in FUSED_WIDTHS[D] or xkv.shape[-1] not in (D, 2 * D):
         return False
+    if layers and mlp[1].weight.shape[0] != layers[0][1].module[1].weight.shape[0]:
+        return False                                                   # (one MLP width per stack)
     return isinstance(ca[0].drop_path, torch.nn.Identity) and isinstance(ca[1].drop_path, torch.nn.Identity)
 
 
