@@ -416,3 +416,31 @@ def test_pretrainer_loss_scale_backs_off_on_overflow_inside_the_captured_graph()
     assert float(tr.hyper[6]) == 40 - skipped                                                       # AdamW's step counter counts the good steps only
     assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.5, (losses[0], losses[-1])     # and those steps train
     assert torch.isfinite(tr.flat.p).all().item()
+
+
+def test_reference_loop_with_torch_gradscaler_and_autocast_trains():
+    """pretrain.py:154,173-211 as it stands on the mirrored modules -- torch's own GradScaler (default init_scale 2 ** 16) around autocast,
+    `scaler.scale(loss).backward(); scaler.step(opt); scaler.update()`, one torch.optim.AdamW over both models, no Pretrainer: the
+    kernels take the scaled gradients as fp16 operands and turn what does not fit into inf / NaN, so the scaler skips those steps and
+    backs its scale off exactly as it does for the reference's autocast modules; the good steps train."""
+    from vipformer_amd import ops
+    pc, im, a = build("tiny", (0.1, 0.5))
+    pc.train(); im.train()
+    opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3)          # pretrain.py:106,121-124
+    scaler = torch.amp.GradScaler("cuda")                                                    # pretrain.py:154
+    t1, t2, imgs, start = _batch(a, 8)
+    p0 = [p.detach().clone() for p in pc.parameters()]
+    losses, scales = [], []
+    for it in range(30):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = _loop_body(pc, im, t1, t2, imgs, start)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        losses.append(float(loss)); scales.append(scaler.get_scale())
+    assert all(l == l for l in losses), losses
+    assert scales[-1] <= 65536.0 and scales[-1] == scales[-3], scales                       # backed off (or never had to), then stable
+    assert all(torch.isfinite(p).all().item() for p in pc.parameters())
+    assert any(not torch.equal(a_, b_) for a_, b_ in zip(p0, pc.parameters()))
+    assert losses[-1] < losses[0] - 0.5, (losses[0], losses[-1], scales)
