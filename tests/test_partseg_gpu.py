@@ -247,3 +247,41 @@ def test_ft_partseg_step_trains_from_a_pretraining_checkpoint():
         losses.append(loss.item())
     report(f"ft_partseg losses first {losses[0]:.4f} last {losses[-1]:.4f}")
     assert losses[-1] < 0.75 * losses[0], losses
+
+
+def test_finetune_backward_needs_no_gradscaler():
+    """ft_partseg.py:145-176 has no GradScaler and averages CrossEntropyLoss over B x N points: the logits receive gradients of ~1e-6,
+    far below what fp16 gradient operands resolve (tools/diag_ft_scale.py: all-parameter cosine 0.964 against the scaled step).  The
+    fine-tune models normalise the gradient that enters them (ops.internal_grad_scale / ScaleGradFn: a power of two from max|g|,
+    on the device): the default backward pass must equal the one of an explicitly scaled loss, and ``p.grad`` must come back in the
+    loss's own units."""
+    from vipformer_amd import ops, ops_seg as S
+    from vipformer_amd.model.pointcloud import CrossFormer_partseg, PointCloudInputAdapter
+    a = Hh.ARCHS["c3"]
+    B, N = 8, 1024
+    torch.manual_seed(1)
+    m = CrossFormer_partseg(PointCloudInputAdapter((N, 3), a["D"]), a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.1, 0.5,
+                            [2, 5, 8], 50).cuda().train()
+    pts = Hh.synth_points(31, B, N).cuda()
+    onehot = torch.zeros(B, 16, device="cuda"); onehot[torch.arange(B), torch.arange(B) % 16] = 1.0
+    target = torch.from_numpy((np.random.default_rng(32).random((B, N)) * 50).astype(np.int64)).cuda()
+    start = Hh.synth_start(33, B, N).cuda()
+    grads = {}
+    for tag, internal, k in (("default", True, 0), ("off", False, 0), ("loss x 4096", False, 12)):
+        ops.rng.seed(5)
+        m.internal_grad_scale = internal
+        m.zero_grad(set_to_none=True)
+        with forced_start(start), ops.rng.pinned():
+            pred = m(pts, onehot)
+            loss = S.cross_entropy_smooth(pred.reshape(-1, 50), target.reshape(-1), 0.2)
+            (loss * float(2 ** k)).backward()
+        grads[tag] = torch.cat([p.grad.detach().double().flatten() / 2 ** k for p in m.parameters() if p.grad is not None])
+    m.internal_grad_scale = True
+    ref = grads["loss x 4096"]
+    assert torch.isfinite(ref).all().item() and torch.isfinite(grads["default"]).all().item()
+    c_def, c_off = cosine(grads["default"], ref), cosine(grads["off"], ref)
+    report(f"finetune-scale: cosine against the scaled-loss step: model default {c_def:.6f}, internal scale off {c_off:.6f}; "
+           f"norm ratio default {float(grads['default'].norm() / ref.norm()):.5f}")
+    assert c_def > 0.9998, c_def                                        # (two powers of two apart: fp32 atomic order + a few fp16 roundings)
+    assert abs(float(grads["default"].norm() / ref.norm()) - 1.0) < 2e-3
+    assert c_off < c_def                                                # what the unscaled fp16 backward pass loses (measured ~0.96 - 0.99)

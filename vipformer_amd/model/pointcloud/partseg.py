@@ -420,12 +420,16 @@ class CrossFormer_pc_mp_ft(CrossFormer_pc_mp):
                                            nn.BatchNorm1d(D), nn.ReLU(), nn.Linear(D, D // 2),
                                            nn.BatchNorm1d(D // 2), nn.ReLU(), nn.Linear(D // 2, num_obj_classes))
 
+    # ft_cls.py's loop has no GradScaler: the backward pass of this model normalises the gradient that enters it (ops.internal_grad_scale)
+    internal_grad_scale = True
+
     def forward(self, pts):
-        h = self.backbone(pts)
-        head = self.finetune_head
-        for i in (0, 3, 6):
-            h = ops.BnReluLinearFn.apply(h, head[i], head[i + 2], self.training, *head[i].parameters(), *head[i + 2].parameters())
-        return h
+        with ops.internal_grad_scale(self.internal_grad_scale and self.training and torch.is_grad_enabled()) as sc:
+            h = self.backbone(pts)
+            head = self.finetune_head
+            for i in (0, 3, 6):
+                h = ops.BnReluLinearFn.apply(h, head[i], head[i + 2], self.training, *head[i].parameters(), *head[i + 2].parameters())
+        return ops.ScaleGradFn.apply(h, sc) if sc.on else h
 
 
 class CrossFormer_partseg(_PointBackbone):
@@ -465,7 +469,16 @@ class CrossFormer_partseg(_PointBackbone):
         self.relu = nn.ReLU()
         ops.assign_sites(self, "pcseg")
 
+    # ft_partseg.py:145-176 has no GradScaler and averages its loss over B x N points (gradients of 1e-6 at the logits): the backward
+    # pass of this model normalises the gradient that enters it (ops.internal_grad_scale; tools/diag_ft_scale.py)
+    internal_grad_scale = True
+
     def forward(self, pts, cls_label):
+        with ops.internal_grad_scale(self.internal_grad_scale and self.training and torch.is_grad_enabled()) as sc:
+            y = self._forward(pts, cls_label)
+        return ops.ScaleGradFn.apply(y, sc) if sc.on else y
+
+    def _forward(self, pts, cls_label):
         from ... import ops_seg as S
         if self.num_layer_idx not in (3, 4):
             # partseg.py:430-435 only defines x for 3 or 4 taps (UnboundLocalError otherwise)

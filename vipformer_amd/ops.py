@@ -284,6 +284,7 @@ class _GradSink:
 
 
 _tls = threading.local()
+_tls_scale = threading.local()
 
 
 def _sink_stack():
@@ -293,9 +294,66 @@ def _sink_stack():
     return st
 
 
+# ---- internal gradient scale: fp16 gradient operands for loops that have no GradScaler (ft_cls.py, ft_partseg.py)
+# The pre-training loop scales its loss (pretrain.py:154,209); the reference's fine-tune loops run in fp32 and do not.  With fp16
+# gradient operands their backward pass loses what lies below 6e-5 (a CrossEntropyLoss averaged over 16 x 1024 points hands the head
+# gradients of 1e-6: measured, tools/diag_ft_scale.py: all-parameter cosine 0.964 against the same step with a scaled loss).  The
+# fine-tune MODELS therefore scale inside: their forward runs under ``internal_grad_scale()`` and returns its logits through
+# ScaleGradFn, which -- in the backward pass -- multiplies the incoming gradient by S = 2^k, k = floor(log2(1 / max|g|)) clamped to
+# [0, 24]: the gradient ENTERS the model with its largest element in [0.5, 1], the regime every parity test of the backward kernels
+# runs in, whatever the loss's normalisation.  Every op between the Functions is linear in the gradient, so the whole backward pass of
+# the model works on S x the gradient, and every Function created under the context multiplies its PARAMETER gradients by 1 / S before
+# autograd sees them.  S is a power of two computed ON THE DEVICE (no host synchronisation, capturable): nothing is rounded by it.  It
+# never scales DOWN: under a GradScaler (incoming gradients already large) S = 1 and nothing changes.
+class _ScaleHolder:
+    __slots__ = ("inv", "on")
+
+    def __init__(self, on: bool):
+        self.on, self.inv = on, None        # inv: 0-dim device tensor 1 / S, set by ScaleGradFn.backward (the first node of the model's backward pass)
+
+
+def _current_iscale():
+    return getattr(_tls_scale, "h", None)
+
+
+class internal_grad_scale:
+    """``with internal_grad_scale() as h:`` -- Functions created inside hand back parameter gradients multiplied by ``h.inv`` (see above)."""
+
+    def __init__(self, on: bool = True):
+        self.h = _ScaleHolder(bool(on) and L.H16 == torch.float16)
+
+    def __enter__(self):
+        self.prev = _current_iscale()
+        _tls_scale.h = self.h if self.h.on else None
+        return self.h
+
+    def __exit__(self, *exc):
+        _tls_scale.h = self.prev
+
+
+class ScaleGradFn(torch.autograd.Function):
+    """Identity; the gradient passing back through it is multiplied by a power of two that brings its largest element into [0.5, 1]
+    (never below 1: see internal_grad_scale).  ``holder.inv`` receives the reciprocal for the parameter-gradient sinks."""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        amax = g.detach().abs().amax().float().clamp_min(1e-30)
+        k = torch.floor(torch.log2(1.0 / amax))
+        k = torch.nan_to_num(k, nan=0.0, posinf=24.0, neginf=0.0).clamp_(0.0, 24.0)
+        s = torch.exp2(k)
+        ctx.holder.inv = 1.0 / s
+        return g * s.to(g.dtype), None
+
+
 def _sinked(backward):
     """Decorator of Function.backward: the trailing ``len(ctx.params)`` entries of the returned tuple (the parameters' slots)
-    are replaced by what the weight-gradient kernels wrote for unmanaged parameters (see _GradSink)."""
+    are replaced by what the weight-gradient kernels wrote for unmanaged parameters (see _GradSink), divided by the internal
+    gradient scale the Function's forward ran under (``ctx._vpf_iscale``, set by _scale_aware_forwards)."""
 
     @functools.wraps(backward)
     def wrapped(ctx, *grads):
@@ -307,9 +365,42 @@ def _sinked(backward):
         finally:
             stack.pop()
         n = len(ctx.params)
-        return out if n == 0 else tuple(out[:len(out) - n]) + sk.collect()
+        if n == 0:
+            return out
+        got = sk.collect()
+        h = getattr(ctx, "_vpf_iscale", None)
+        if h is not None and h.inv is not None:
+            seen, ts = set(), []
+            for t in got:
+                if t is not None:
+                    base = t._base if t._base is not None else t              # (packed buffers: several parameters, one allocation)
+                    if id(base) not in seen:
+                        seen.add(id(base)); ts.append(base)
+            if ts:
+                torch._foreach_mul_(ts, h.inv)
+        return tuple(out[:len(out) - n]) + got
 
+    wrapped._vpf_sinked = True
     return wrapped
+
+
+def _scale_aware_forwards(namespace) -> None:
+    """Every Function of ``namespace`` whose backward is @_sinked records the internal gradient scale its forward ran under."""
+    for cls in list(namespace.values()):
+        if isinstance(cls, type) and issubclass(cls, torch.autograd.Function) and getattr(cls.__dict__.get("backward", None), "__func__", None) is not None:
+            bw = cls.__dict__["backward"].__func__
+            if not getattr(bw, "_vpf_sinked", False) or getattr(cls, "_vpf_scale_aware", False):
+                continue
+
+            def make(f):
+                @functools.wraps(f)
+                def fwd(ctx, *a, **k):
+                    ctx._vpf_iscale = _current_iscale()
+                    return f(ctx, *a, **k)
+                return fwd
+
+            cls.forward = staticmethod(make(cls.__dict__["forward"].__func__))
+            cls._vpf_scale_aware = True
 
 
 def packed_grad(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
@@ -1911,6 +2002,7 @@ class CaFrontFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, centers, seq, tokens, enc, *params):
+        ctx._vpf_iscale = _current_iscale()                 # (backward is PosMLPFn.backward: the sink reads the scale from THIS ctx)
         ctx.nparams, ctx.params = len(params), params
         B, G, C = centers.shape
         x = centers.contiguous().float().view(-1, C)
@@ -2243,3 +2335,6 @@ def pretrain_losses(f, g, temperature=0.1, cmid_weight=1.0):
 
 def ntxent_loss(z0, z1, temperature=0.1):
     return NTXentFn.apply(z0, z1, temperature)
+
+
+_scale_aware_forwards(globals())

@@ -320,3 +320,7 @@ class CrossEntropySmoothFn(torch.autograd.Function):
 
 def cross_entropy_smooth(logits, target, label_smoothing=0.2):
     return CrossEntropySmoothFn.apply(logits, target, label_smoothing)
+
+
+from .ops import _scale_aware_forwards as _saf  # noqa: E402
+_saf(globals())
