@@ -1,2 +1,6 @@
-python3 tools/diag_ft_scale.py 16 2>&1 | grep -v "amdgpu.ids\|UserWarning\|Consider\|print(f"
-timeout 1500 python -m pytest tests/test_partseg_gpu.py tests/test_modules_gpu.py -q -p no:cacheprovider -k "partseg or finetune or ft_" > gpurun_out/t_ft.log 2>&1; grep -E '^(FAILED|ERROR)|passed|failed' gpurun_out/t_ft.log; grep -E "^E  " gpurun_out/t_ft.log | head -12
+run() { env $1 python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernels --no-variants 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['median_ms_200']['median'])"; }
+for i in 1 2 3 4; do
+  for cfg in "VPF_X=0" "VPF_LIB=tools/_bin/libvipformer_prio.so"; do
+    echo "$cfg  $(run "$cfg")"
+  done
+done

@@ -30,6 +30,9 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 PER_FILE = {"preproc.hip": ["-ffp-contract=off"]}
 # `python -m vipformer_amd.build --bf16` (or VPF_OPERAND=bf16 in the environment): the A/B build with bf16 MFMA operands (rounds 1-3)
 # instead of fp16 -- csrc/vpf_common.h VPF_OPERAND_FP16; vipformer_amd._lib refuses a library that does not match VPF_OPERAND.
+# VPF_EXTRA_CFLAGS="-DVPF_EXP_SETPRIO=1": experiment builds (part of the build id, so the library is rebuilt when it changes)
+if os.environ.get("VPF_EXTRA_CFLAGS"):
+    COMMON = COMMON[:8] + os.environ["VPF_EXTRA_CFLAGS"].split() + COMMON[8:]
 if os.environ.get("VPF_OPERAND", "f16") == "bf16" or "--bf16" in sys.argv:
     COMMON = COMMON[:8] + ["-DVPF_OPERAND_FP16=0"] + COMMON[8:]
 
