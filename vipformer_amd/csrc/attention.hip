@@ -276,7 +276,12 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st)
 // Lq == Lkv <= 224 (the encoder's self-attention: 96 latents / 196 patches): the head's whole K and V tiles are staged in
 // ONE round of loads (all of them in flight together) and every wave walks them without further barriers.  The tiled
 // kernel above pays one global-load latency plus a barrier per 64 keys, which is all there is at these sizes.
-template <int NW>
+// MODE (round 4): the dropout variant is a TEMPLATE parameter, so the loops over the resident blocks are straight-line code the
+// compiler schedules across blocks -- the run-time tests cost a scalar branch per group of four scores (phase B of the backward: two
+// per score) that cut every block into pieces.  RES_GENERAL keeps every run-time test (64-bit group indices, L % 4 != 0).
+enum { RES_GENERAL = 0, RES_DROP32 = 1, RES_NODROP = 2 };
+static inline int res_mode(const AttnArgs& a) { return a.p > 0.f ? (a.rng_fast ? RES_DROP32 : RES_GENERAL) : RES_NODROP; }
+template <int NW, int MODE>
 __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
 {
     constexpr int NT = NW * 64, LPT = NW * 32;
@@ -314,47 +319,79 @@ __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
     f32x16_t o[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
-    float m = -INFINITY, l = 0.f;
     const float c = a.scale * LOG2E;
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
-    const bool drop = a.p > 0.f;
+    const bool drop = MODE == RES_DROP32 ? true : MODE == RES_NODROP ? false : a.p > 0.f;
     const uint64_t rbase = ((uint64_t)bh * L + (uint64_t)(qok ? q : 0)) * (uint64_t)L;
+    // Round 4: the whole score row of a query is resident (<= 7 blocks of 32 keys = 112 registers per lane), so the softmax is TWO-PASS
+    // instead of online: pass 1 forms every S block and the row maximum; pass 2 exponentiates against that one maximum (the softmax
+    // scale rides in the same fused multiply-add), draws the dropout decisions and runs P V.  Gone per block of 32 keys: the running
+    // maximum's exponential, the rescaling of the 32 output accumulators and of the running sum, the per-score scale multiply and --
+    // in every block but the last -- the key-bound select; the dropout decision compares the hash's 16-bit fields directly instead of
+    // assembling a 4-bit mask and taking it apart again (NOTES.md round 4: 27 -> 17 VALU instructions per score).
+    f32x16_t sc[NW];
+    float tmax = -INFINITY;
 #pragma unroll
-    for (int kv0 = 0; kv0 < LPT; kv0 += 32) {
+    for (int blk = 0; blk < NW; ++blk) {
+        const int kv0 = blk * 32;
         if (kv0 >= L) break;
-        f32x16_t s;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int r = 0; r < 16; ++r) sc[blk][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            s = vpf_mfma32(frag_row(sK, KLD, kv0, ks * 16), qf[ks], s);
-        float tmax = -INFINITY;
+            sc[blk] = vpf_mfma32(frag_row(sK, KLD, kv0, ks * 16), qf[ks], sc[blk]);
+        if (kv0 + 32 > L) {                                   // (only the last block can hold keys beyond L: a uniform branch)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-            s[r] = kv < L ? s[r] * c : -INFINITY;
-            tmax = fmaxf(tmax, s[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                sc[blk][r] = kv < L ? sc[blk][r] : -INFINITY;
+            }
         }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mn = fmaxf(m, tmax);
-        const float alpha = vpf_exp2(m - mn);
-        m = mn;
-        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[blk][r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m = tmax * c;                                  // the row maximum of the scaled scores, in log2 units (c > 0)
+    float l = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NW; ++blk) {
+        const int kv0 = blk * 32;
+        if (kv0 >= L) break;
         float pv[16];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const uint32_t keep = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl))) : 15u;
+            const uint32_t i0 = (uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl);
+            if (MODE == RES_NODROP) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g4 + e;
-                const float pr = vpf_exp2(s[r] - mn);
-                ps += pr;
-                pv[r] = ((keep >> e) & 1u) ? pr * rng.scale : 0.f;        // p = 0: keep = 15, scale = 1
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    pv[r] = vpf_exp2(fmaf(sc[blk][r], c, -m));
+                    l += pv[r];
+                }
+            } else if (MODE == RES_DROP32 || !drop || a.rng_fast) {
+                // aligned groups of four scores: the hash's four 16-bit uniforms against the threshold (p = 0: no hash, everything kept)
+                uint2 w = make_uint2(0xffffffffu, 0xffffffffu);
+                if (drop) w = vpf_rand4x16_32(rng, i0 >> 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const float pr = vpf_exp2(fmaf(sc[blk][r], c, -m));
+                    l += pr;
+                    const uint32_t word = (e & 2) ? w.y : w.x;
+                    const uint32_t fld = (e & 1) ? (word >> 16) : (word & 0xffffu);
+                    pv[r] = pr * (fld >= rng.thresh ? rng.scale : 0.f);
+                }
+            } else {
+                const uint32_t keep = vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g4 + e;
+                    const float pr = vpf_exp2(fmaf(sc[blk][r], c, -m));
+                    l += pr;
+                    pv[r] = ((keep >> e) & 1u) ? pr * rng.scale : 0.f;
+                }
             }
         }
-        l = l * alpha + ps;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             const h16x8_t pf = pack8(pv + 8 * s2);
@@ -399,10 +436,16 @@ static int launch_res_fwd(const AttnArgs& a, hipStream_t st)
     constexpr size_t lds = (size_t)2 * NW * 32 * KLD * sizeof(h16_t);      // K and V (the per-wave output staging rows reuse K)
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_fwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        if (lds > 65536)
+            for (const void* f : {(const void*)attn_res_fwd_kernel<NW, RES_GENERAL>, (const void*)attn_res_fwd_kernel<NW, RES_DROP32>, (const void*)attn_res_fwd_kernel<NW, RES_NODROP>})
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((attn_res_fwd_kernel<NW>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a);
+    switch (res_mode(a)) {
+    case RES_DROP32: hipLaunchKernelGGL((attn_res_fwd_kernel<NW, RES_DROP32>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a); break;
+    case RES_NODROP: hipLaunchKernelGGL((attn_res_fwd_kernel<NW, RES_NODROP>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a); break;
+    default: hipLaunchKernelGGL((attn_res_fwd_kernel<NW, RES_GENERAL>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a);
+    }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -755,7 +798,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_kernel(AttnArgs a, const
 // above (a wave = 32 queries, delta computed on the way), phase B the dk / dv kernel (a wave = 32 keys), both walking
 // the resident tiles without barriers: one launch and one load latency instead of two kernels that each re-stage
 // their operands tile by tile.
-template <int NW>
+template <int NW, int MODE>
 __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float* __restrict__ delta_out)
 {
     constexpr int NT = NW * 64, LPT = NW * 32;
@@ -771,6 +814,12 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H, L = a.Lq;
     const int q = wave * 32 + ql;                                 // phase A: this lane's query; phase B: this lane's key
     const bool qok = q < L;
+#ifdef VPF_EXP_STAMP
+    uint64_t stamp[6]; stamp[0] = __builtin_amdgcn_s_memtime();
+#define VPF_STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VPF_STAMP(i) do {} while (0)
+#endif
     {
         uint4 rr[CPT];
 #pragma unroll
@@ -797,6 +846,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             if (e < NCH) *reinterpret_cast<uint4*>(rlds + (which * LPT + row) * KLD + ch * 8) = rr[it];
         }
         __syncthreads();
+        VPF_STAMP(1);
         // delta[q] = sum_d dO[q,d] * O[q,d]
         float delta = 0.f;
 #pragma unroll
@@ -815,7 +865,10 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
     }
     const float c = a.scale * LOG2E;
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
-    const bool drop = a.p > 0.f;
+    const bool drop = MODE == RES_DROP32 ? true : MODE == RES_NODROP ? false : a.p > 0.f;
+    // Round 4 (NOTES.md): the key / query bound is only tested in the LAST block of 32 (the only one that can be partial; rows of invalid
+    // lanes are never stored, so their own validity is not tested at all), phase A compares the hash's 16-bit fields directly instead
+    // of assembling a 4-bit mask, and carries the softmax scale inside the keep factor and delta.
     // A wave's [32 x 64] result tiles (dQ, dK, dV) leave through ITS OWN 32 rows of the K / V tiles, which only it reads once
     // phase B has its fragments in registers: the accumulator layout would store 8 bytes per lane into 32 different rows,
     // from LDS the same tile goes out as 128-byte rows (16 bytes per lane, 8 rows per wave-instruction).
@@ -840,6 +893,7 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { qf[ks] = frag_row(sQ, KLD, wave * 32, ks * 16); dof[ks] = frag_row(sD, KLD, wave * 32, ks * 16); }
         const float lse2 = sL[q], delta = sDel[q];       // written by this very lane (hl == 0) or its partner: same wave, in order
+        const float delta_s = delta * a.scale, keep_s = rng.scale * a.scale;      // dS = p (dP keep - delta) scale, the scale inside the operands
         const uint64_t rbase = ((uint64_t)bh * L + (uint64_t)(qok ? q : 0)) * (uint64_t)L;
         f32x16_t dq[2];
 #pragma unroll
@@ -857,17 +911,36 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             }
             float ds[16];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const uint32_t kbits = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl))) : 15u;
+            for (int r = 0; r < 16; ++r) ds[r] = vpf_exp2(fmaf(s[r], c, -lse2));      // p (unconditional: no exec-mask branch per score)
+            if (kv0 + 32 > L) {                                                         // keys beyond L: only in the last block
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g4 + e;
-                    const int kv = kv0 + e + 8 * g4 + 4 * hl;
-                    const bool ok = qok && kv < L;
-                    const float ex = vpf_exp2(s[r] * c - lse2);                 // unconditional: a select, not an exec-mask branch per score
-                    const float pr = ok ? ex : 0.f;
-                    const float keep = ((kbits >> e) & 1u) ? rng.scale : 0.f;      // p = 0: kbits = 15, scale = 1
-                    ds[r] = pr * (dp[r] * keep - delta) * a.scale;
+                for (int r = 0; r < 16; ++r) ds[r] = (kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl) < L ? ds[r] : 0.f;
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                if (MODE == RES_NODROP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        ds[r] = ds[r] * fmaf(dp[r], a.scale, -delta_s);
+                    }
+                } else if (MODE == RES_DROP32 || !drop || a.rng_fast) {
+                    uint2 w = make_uint2(0xffffffffu, 0xffffffffu);                     // p = 0: thresh 0, scale 1 -- everything kept
+                    if (drop) w = vpf_rand4x16_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        const uint32_t word = (e & 2) ? w.y : w.x;
+                        const uint32_t fld = (e & 1) ? (word >> 16) : (word & 0xffffu);
+                        ds[r] = ds[r] * fmaf(dp[r], fld >= rng.thresh ? keep_s : 0.f, -delta_s);
+                    }
+                } else {
+                    const uint32_t kbits = vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        ds[r] = ds[r] * fmaf(dp[r], ((kbits >> e) & 1u) ? keep_s : 0.f, -delta_s);
+                    }
                 }
             }
 #pragma unroll
@@ -895,15 +968,18 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = frag_row(sK, KLD, wave * 32, ks * 16); vf[ks] = frag_row(sV, KLD, wave * 32, ks * 16); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers before the rows are reused
+        VPF_STAMP(2);
         tile_out(sK, dqp, a.dQ, a.lddq);
         f32x16_t dk[2], dv[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[0][r] = dk[1][r] = dv[0][r] = dv[1][r] = 0.f; }
-        const bool quad_ok = (L & 3) == 0;
-        const bool slow_keep = drop && !quad_ok;
+        const bool quad_ok = MODE == RES_DROP32 || (L & 3) == 0;
+        const bool slow_keep = MODE == RES_GENERAL && drop && !quad_ok;
+        const bool rfast = MODE == RES_DROP32 || a.rng_fast;
 #pragma unroll
         for (int q0 = 0; q0 < LPT; q0 += 32) {
             if (q0 >= L) break;
+            const bool tailq = q0 + 32 > L;
             f32x16_t s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -914,11 +990,32 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
             }
             float pd[16], ds[16];
 #pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {                                        // p, with the four queries' statistics in one 16-byte read each
+                const float4 l4 = *reinterpret_cast<const float4*>(sL + q0 + 8 * g4 + 4 * hl);
+                const float lq[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pd[4 * g4 + e] = vpf_exp2(fmaf(s[4 * g4 + e], c, -lq[e]));   // unconditional: no exec-mask branch per score
+            }
+            if (tailq) {                                                            // queries beyond L: only in the last block (uniform branch)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pd[r] = (q0 + (r & 3) + 8 * (r >> 2) + 4 * hl) < L ? pd[r] : 0.f;
+            }
+#pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 d4 = *reinterpret_cast<const float4*>(sDel + q0 + 8 * g4 + 4 * hl);
+                const float dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+                if (MODE == RES_NODROP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        ds[r] = pd[r] * (dp[r] - dq4[e]) * a.scale;
+                    }
+                    continue;
+                }
                 uint2 grp = make_uint2(0u, 0u);
                 if (drop && quad_ok) {
                     const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
-                    grp = a.rng_fast ? vpf_rand4x16_32(rng, (((uint32_t)bh * L + (uint32_t)qh) * (uint32_t)L + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * L + (uint64_t)qh) * (uint64_t)L + (uint64_t)kv) >> 2);
+                    grp = rfast ? vpf_rand4x16_32(rng, (((uint32_t)bh * L + (uint32_t)qh) * (uint32_t)L + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * L + (uint64_t)qh) * (uint64_t)L + (uint64_t)kv) >> 2);
                 }
                 uint32_t gw[4];
                 {
@@ -930,16 +1027,13 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g4 + e;
-                    const int qr = e + 8 * g4 + 4 * hl;
-                    const int qq = q0 + qr;
-                    const bool ok = kvok && qq < L;
-                    const float ex = vpf_exp2(s[r] * c - sL[qq]);                 // unconditional: a select, not an exec-mask branch per score
-                    const float pr = ok ? ex : 0.f;
+                    const int qq = q0 + e + 8 * g4 + 4 * hl;
+                    const float pr = pd[r];
                     const uint32_t word = gw[e];                                   // this lane's half of quad lane e's group (p = 0: thresh 0, scale 1)
                     float keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
-                    if (slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * L + (uint64_t)qq) * (uint64_t)L + (uint64_t)kv) ? rng.scale : 0.f;
+                    if (MODE == RES_GENERAL && slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * L + (uint64_t)qq) * (uint64_t)L + (uint64_t)kv) ? rng.scale : 0.f;
                     pd[r] = pr * keep;
-                    ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
+                    ds[r] = pr * (dp[r] * keep - dq4[e]) * a.scale;
                 }
             }
 #pragma unroll
@@ -962,8 +1056,14 @@ __global__ void __launch_bounds__(NW * 64) attn_res_bwd_kernel(AttnArgs a, float
                     tk[dt][gq].x = pack_h16x2(dk[dt][4 * gq + 0], dk[dt][4 * gq + 1]); tk[dt][gq].y = pack_h16x2(dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]);
                     tv[dt][gq].x = pack_h16x2(dv[dt][4 * gq + 0], dv[dt][4 * gq + 1]); tv[dt][gq].y = pack_h16x2(dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]);
                 }
+            VPF_STAMP(3);
             tile_out(sK, tk, a.dK, a.lddk);
             tile_out(sV, tv, a.dV, a.lddv);
+            VPF_STAMP(4);
+#ifdef VPF_EXP_STAMP
+            if (lane == 0) for (int i = 1; i < 5; ++i) delta_out[(size_t)bh * L + wave * 8 + i] = (float)(stamp[i] - stamp[0]);
+            if (lane == 0) delta_out[(size_t)bh * L + wave * 8] = (float)(stamp[0] & 0xffffff);
+#endif
         }
     }
 }
@@ -973,10 +1073,16 @@ static int launch_res_bwd(const AttnArgs& a, float* delta, hipStream_t st)
     constexpr size_t lds = (size_t)4 * NW * 32 * KLD * sizeof(h16_t) + (size_t)2 * NW * 32 * sizeof(float);
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (lds > 65536 && hipFuncSetAttribute((const void*)attn_res_bwd_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        if (lds > 65536)
+            for (const void* f : {(const void*)attn_res_bwd_kernel<NW, RES_GENERAL>, (const void*)attn_res_bwd_kernel<NW, RES_DROP32>, (const void*)attn_res_bwd_kernel<NW, RES_NODROP>})
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((attn_res_bwd_kernel<NW>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a, delta);
+    switch (res_mode(a)) {
+    case RES_DROP32: hipLaunchKernelGGL((attn_res_bwd_kernel<NW, RES_DROP32>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a, delta); break;
+    case RES_NODROP: hipLaunchKernelGGL((attn_res_bwd_kernel<NW, RES_NODROP>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a, delta); break;
+    default: hipLaunchKernelGGL((attn_res_bwd_kernel<NW, RES_GENERAL>), dim3(a.B * a.H), dim3(NW * 64), lds, st, a, delta);
+    }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
