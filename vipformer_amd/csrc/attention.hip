@@ -127,10 +127,16 @@ __device__ __forceinline__ void kv_store(h16_t* __restrict__ S, const uint4 (&re
     }
 }
 
+// MODE (round 4): the dropout variant is a TEMPLATE parameter, so the loops over the resident blocks are straight-line code the
+// compiler schedules across blocks -- the run-time tests cost a scalar branch per group of four scores (phase B of the backward: two
+// per score) that cut every block into pieces.  RES_GENERAL keeps every run-time test (64-bit group indices, L % 4 != 0).
+enum { RES_GENERAL = 0, RES_DROP32 = 1, RES_NODROP = 2 };
+static inline int res_mode(const AttnArgs& a) { return a.p > 0.f ? (a.rng_fast ? RES_DROP32 : RES_GENERAL) : RES_NODROP; }
 // =============================================================================== forward
 #define FWD_MAXC 3  // ceil(64*8 / 192) chunks per thread at the smallest block (3 waves); 1-wave blocks loop 8x below
 // FWD_KT = kv rows per LDS stage (64 = two 32-row sub-tiles; 128 when there are many keys)
-template <int NW, int FWD_KT>
+// MODE: RES_DROP32 (training: dropout on, 32-bit group indices, no padding mask) or RES_GENERAL (every run-time test)
+template <int NW, int FWD_KT, int MODE>
 __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
 {
     constexpr int NT = NW * 64;
@@ -155,9 +161,9 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
     float m = -INFINITY, l = 0.f;
     const float c = a.scale * LOG2E;
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
-    const bool drop = a.p > 0.f;
+    const bool drop = MODE == RES_DROP32 ? true : a.p > 0.f;
     const uint64_t rbase = ((uint64_t)bh * a.Lq + (uint64_t)(qok ? q : 0)) * (uint64_t)a.Lkv;
-    const uint8_t* padrow = a.pad ? a.pad + (size_t)b * a.Lkv : nullptr;
+    const uint8_t* padrow = MODE == RES_GENERAL && a.pad ? a.pad + (size_t)b * a.Lkv : nullptr;
 
     uint4 rk[MAXC], rv[MAXC];
     const int nt = (a.Lkv + FWD_KT - 1) / FWD_KT;
@@ -184,37 +190,69 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
                 s = vpf_mfma32(frag_row(sK, KLD, sub * 32, ks * 16), qf[ks], s);
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                s[r] = kv < a.Lkv ? s[r] * c : -INFINITY;
-                tmax = fmaxf(tmax, s[r]);
-            }
-            if (padrow) {                              // (block-uniform; the unmasked path is untouched)
-                tmax = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                    if (kv < a.Lkv && padrow[kv]) s[r] = PAD_SCORE;
-                    tmax = fmaxf(tmax, s[r]);
-                }
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mn = fmaxf(m, tmax);           // finite: every sub-tile has >= 1 valid key
-            const float alpha = vpf_exp2(m - mn);
-            m = mn;
-            float ps = 0.f;
+            float tmax = -INFINITY, mn, alpha, ps = 0.f;
             float pv[16];
+            if (MODE == RES_DROP32) {
+                // raw scores: the softmax scale rides in the exponent's fused multiply-add; the key bound is tested in the last block only
+                if (kv0 + 32 > a.Lkv) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const uint32_t keep = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl))) : 15u;   // keys kv0 + 8 g4 + 4 hl + 0..3
+                    for (int r = 0; r < 16; ++r) s[r] = (kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl) < a.Lkv ? s[r] : -INFINITY;
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g4 + e;
-                    const float pr = vpf_exp2(s[r] - mn);
-                    ps += pr;
-                    pv[r] = ((keep >> e) & 1u) ? pr * rng.scale : 0.f;        // p = 0: keep = 15, scale = 1
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                mn = fmaxf(m, tmax * c);                   // finite: every sub-tile has >= 1 valid key (c > 0)
+                alpha = vpf_exp2(m - mn);
+                m = mn;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const uint2 w = vpf_rand4x16_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        const float pr = vpf_exp2(fmaf(s[r], c, -mn));
+                        ps += pr;
+                        const uint32_t word = (e & 2) ? w.y : w.x;
+                        const uint32_t fld = (e & 1) ? (word >> 16) : (word & 0xffffu);
+                        pv[r] = pr * (fld >= rng.thresh ? rng.scale : 0.f);
+                    }
+                }
+            } else {
+                // the same arithmetic with every run-time test (equal masks give bit-identical results); a padded key's SCALED score is
+                // PAD_SCORE: it enters the row maximum as that constant and its exponent is PAD_SCORE - max, exactly 0 when every key
+                // so far was padded
+                uint32_t padbits = 0u;
+                if (kv0 + 32 > a.Lkv) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = (kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl) < a.Lkv ? s[r] : -INFINITY;
+                }
+                if (padrow) {                              // (block-uniform; the unmasked path is untouched)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hl;
+                        if (kv < a.Lkv && padrow[kv]) { padbits |= 1u << r; s[r] = -INFINITY; }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+                tmax *= c;                                 // (-inf stays -inf: c > 0)
+                if (padbits) tmax = fmaxf(tmax, PAD_SCORE);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                mn = fmaxf(m, tmax);                       // finite: every sub-tile has >= 1 valid key
+                alpha = vpf_exp2(m - mn);
+                m = mn;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const uint32_t keep = drop ? (a.rng_fast ? vpf_keep4_32(rng, ((uint32_t)rbase + (uint32_t)(kv0 + 8 * g4 + 4 * hl)) >> 2) : vpf_keep4_at(rng, rbase + (uint64_t)(kv0 + 8 * g4 + 4 * hl))) : 15u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        float arg = fmaf(s[r], c, -mn);
+                        if (padrow) arg = ((padbits >> r) & 1u) ? PAD_SCORE - mn : arg;
+                        const float pr = vpf_exp2(arg);
+                        ps += pr;
+                        pv[r] = pr * (((keep >> e) & 1u) ? rng.scale : 0.f);      // p = 0: keep = 15, scale = 1
+                    }
                 }
             }
             l = l * alpha + ps;
@@ -256,17 +294,22 @@ template <int NW>
 static int launch_fwd(const AttnArgs& a, hipStream_t st)
 {
     dim3 grid(a.B * a.H, vpf_cdiv(a.Lq, 32 * NW));
+    const bool d32 = res_mode(a) == RES_DROP32 && !a.pad;
     if (a.Lkv >= 256) {
         constexpr int KT = 128;
         constexpr size_t lds = sizeof(h16_t) * 2 * 2 * KT * KLD;
         static VpfPerDevice attr_dev; bool& attr = attr_dev();
         if (!attr) {
-            if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+            for (const void* f : {(const void*)attn_fwd_kernel<NW, KT, RES_GENERAL>, (const void*)attn_fwd_kernel<NW, KT, RES_DROP32>})
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
             attr = true;
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<NW, KT>), grid, dim3(NW * 64), lds, st, a);
+        if (d32) hipLaunchKernelGGL((attn_fwd_kernel<NW, KT, RES_DROP32>), grid, dim3(NW * 64), lds, st, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<NW, KT, RES_GENERAL>), grid, dim3(NW * 64), lds, st, a);
     } else {
-        hipLaunchKernelGGL((attn_fwd_kernel<NW, 64>), grid, dim3(NW * 64), sizeof(h16_t) * 2 * 2 * 64 * KLD, st, a);
+        constexpr size_t lds = sizeof(h16_t) * 2 * 2 * 64 * KLD;
+        if (d32) hipLaunchKernelGGL((attn_fwd_kernel<NW, 64, RES_DROP32>), grid, dim3(NW * 64), lds, st, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<NW, 64, RES_GENERAL>), grid, dim3(NW * 64), lds, st, a);
     }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
@@ -276,11 +319,6 @@ static int launch_fwd(const AttnArgs& a, hipStream_t st)
 // Lq == Lkv <= 224 (the encoder's self-attention: 96 latents / 196 patches): the head's whole K and V tiles are staged in
 // ONE round of loads (all of them in flight together) and every wave walks them without further barriers.  The tiled
 // kernel above pays one global-load latency plus a barrier per 64 keys, which is all there is at these sizes.
-// MODE (round 4): the dropout variant is a TEMPLATE parameter, so the loops over the resident blocks are straight-line code the
-// compiler schedules across blocks -- the run-time tests cost a scalar branch per group of four scores (phase B of the backward: two
-// per score) that cut every block into pieces.  RES_GENERAL keeps every run-time test (64-bit group indices, L % 4 != 0).
-enum { RES_GENERAL = 0, RES_DROP32 = 1, RES_NODROP = 2 };
-static inline int res_mode(const AttnArgs& a) { return a.p > 0.f ? (a.rng_fast ? RES_DROP32 : RES_GENERAL) : RES_NODROP; }
 template <int NW, int MODE>
 __global__ void __launch_bounds__(NW * 64) attn_res_fwd_kernel(AttnArgs a)
 {
@@ -1218,7 +1256,7 @@ __global__ void __launch_bounds__(NW * 64) attn_bwd_dkv_resq_kernel(AttnArgs a, 
 // owns query block w and adds K^T . dS^T over the tile's 128 keys into its dQ^T accumulators (both operands by transposing LDS reads,
 // in the k order attn_bwd_dq_kernel uses) -- no cross-wave reduction, no atomics; S, dP, the exponentials and the dropout hash are
 // computed once instead of twice and K / V cross HBM once.  Same arithmetic and rounding points as the two kernels it replaces.
-template <int QB>
+template <int QB, int MODE>
 __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
 {
     constexpr int NW = 4, NT = NW * 64, QPT = QB * 32, KT = NW * 32, DLD = QPT + 8;
@@ -1275,9 +1313,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
     }
     const float c = a.scale * LOG2E;
     const VpfRng rng = vpf_rng_init(a.rng, a.site, a.p);
-    const bool drop = a.p > 0.f;
-    const bool quad_ok = (a.Lkv & 3) == 0;
-    const bool slow_keep = drop && !quad_ok;
+    const bool drop = MODE == RES_DROP32 ? true : MODE == RES_NODROP ? false : a.p > 0.f;
+    const bool quad_ok = MODE == RES_DROP32 || (a.Lkv & 3) == 0;
+    const bool slow_keep = MODE == RES_GENERAL && drop && !quad_ok;
+    const bool rfast = MODE == RES_DROP32 || a.rng_fast;
     const int nt = (a.Lkv + KT - 1) / KT;
     const bool bwave = wave < QB && wave * 32 < a.Lq;  // this wave owns a query block in phase B
     f32x16_t dq[2];
@@ -1300,6 +1339,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
     for (int t = 0; t < nt; ++t) {
         const int kv = t * KT + wave * 32 + kl;
         const bool kvok = kv < a.Lkv;
+        const bool tail_t = t * KT + KT > a.Lkv;          // (uniform) only the last tile can hold keys beyond Lkv
         h16_t* myK = sK + (wave * 32 + kl) * KLD + 8 * hl;
         h16_t* myT = sT + (wave * 32 + kl) * DLD + 4 * hl;
 #pragma unroll
@@ -1321,31 +1361,50 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_ca_kernel(AttnArgs a)
             }
             float pd[16], ds[16];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                uint2 grp = make_uint2(0u, 0u);
-                if (drop && quad_ok) {
-                    const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
-                    grp = a.rng_fast ? vpf_rand4x16_32(rng, (((uint32_t)bh * a.Lq + (uint32_t)qh) * (uint32_t)a.Lkv + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
-                }
-                uint32_t gw[4];
-                {
-                    const uint32_t mine = (lane & 2) ? 1u : 0u;
-                    const uint32_t x0 = quad_bcast<0>(grp.x), x1 = quad_bcast<1>(grp.x), x2 = quad_bcast<2>(grp.x), x3 = quad_bcast<3>(grp.x);
-                    const uint32_t y0 = quad_bcast<0>(grp.y), y1 = quad_bcast<1>(grp.y), y2 = quad_bcast<2>(grp.y), y3 = quad_bcast<3>(grp.y);
-                    gw[0] = mine ? y0 : x0; gw[1] = mine ? y1 : x1; gw[2] = mine ? y2 : x2; gw[3] = mine ? y3 : x3;
-                }
+            for (int g4 = 0; g4 < 4; ++g4) {                                        // p, the four queries' statistics in one 16-byte read each
+                const float4 l4 = *reinterpret_cast<const float4*>(sL + q0 + 8 * g4 + 4 * hl);
+                const float lq[4] = {l4.x, l4.y, l4.z, l4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g4 + e;
-                    const int qq = q0 + e + 8 * g4 + 4 * hl;
-                    const bool ok = kvok && qq < a.Lq;
-                    const float ex = vpf_exp2(s[r] * c - sL[qq]);                 // unconditional: a select, not an exec-mask branch per score
-                    const float pr = ok ? ex : 0.f;
-                    const uint32_t word = gw[e];                                   // this lane's half of quad lane e's group (p = 0: thresh 0, scale 1)
-                    float keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
-                    if (slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
-                    pd[r] = pr * keep;
-                    ds[r] = pr * (dp[r] * keep - sDel[qq]) * a.scale;
+                for (int e = 0; e < 4; ++e) pd[4 * g4 + e] = vpf_exp2(fmaf(s[4 * g4 + e], c, -lq[e]));   // unconditional: no exec-mask branch per score
+            }
+            if (tail_t || q0 + 32 > a.Lq) {                                         // keys / queries beyond the bounds: last tile, last block only
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pd[r] = (kvok && (q0 + (r & 3) + 8 * (r >> 2) + 4 * hl) < a.Lq) ? pd[r] : 0.f;
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 d4 = *reinterpret_cast<const float4*>(sDel + q0 + 8 * g4 + 4 * hl);
+                const float dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+                if (MODE == RES_NODROP) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        ds[r] = pd[r] * (dp[r] - dq4[e]) * a.scale;
+                    }
+                } else {
+                    uint2 grp = make_uint2(0u, 0u);
+                    if (drop && quad_ok) {
+                        const int qh = q0 + 8 * g4 + 4 * hl + (lane & 3);
+                        grp = rfast ? vpf_rand4x16_32(rng, (((uint32_t)bh * a.Lq + (uint32_t)qh) * (uint32_t)a.Lkv + (uint32_t)kv) >> 2) : vpf_rand4x16(rng, (((uint64_t)bh * a.Lq + (uint64_t)qh) * (uint64_t)a.Lkv + (uint64_t)kv) >> 2);
+                    }
+                    uint32_t gw[4];
+                    {
+                        const uint32_t mine = (lane & 2) ? 1u : 0u;
+                        const uint32_t x0 = quad_bcast<0>(grp.x), x1 = quad_bcast<1>(grp.x), x2 = quad_bcast<2>(grp.x), x3 = quad_bcast<3>(grp.x);
+                        const uint32_t y0 = quad_bcast<0>(grp.y), y1 = quad_bcast<1>(grp.y), y2 = quad_bcast<2>(grp.y), y3 = quad_bcast<3>(grp.y);
+                        gw[0] = mine ? y0 : x0; gw[1] = mine ? y1 : x1; gw[2] = mine ? y2 : x2; gw[3] = mine ? y3 : x3;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e;
+                        const int qq = q0 + e + 8 * g4 + 4 * hl;
+                        const float pr = pd[r];
+                        const uint32_t word = gw[e];                               // this lane's half of quad lane e's group (p = 0: thresh 0, scale 1)
+                        float keep = (((lane & 1) ? (word >> 16) : (word & 0xffffu)) >= rng.thresh) ? rng.scale : 0.f;
+                        if (MODE == RES_GENERAL && slow_keep) keep = vpf_keep(rng, ((uint64_t)bh * a.Lq + (uint64_t)qq) * (uint64_t)a.Lkv + (uint64_t)kv) ? rng.scale : 0.f;
+                        pd[r] = pr * keep;
+                        ds[r] = pr * (dp[r] * keep - dq4[e]) * a.scale;
+                    }
                 }
                 uint2 w;
                 w.x = pack_h16x2(ds[4 * g4 + 0], ds[4 * g4 + 1]); w.y = pack_h16x2(ds[4 * g4 + 2], ds[4 * g4 + 3]);
@@ -1424,10 +1483,15 @@ static int launch_bwd_ca(const AttnArgs& a, hipStream_t st)
     constexpr size_t lds = sizeof(h16_t) * (2 * QPT * KLD + KT * KLD + KT * (QPT + 8)) + sizeof(float) * 2 * QPT;
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_ca_kernel<QB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        for (const void* f : {(const void*)attn_bwd_ca_kernel<QB, RES_GENERAL>, (const void*)attn_bwd_ca_kernel<QB, RES_DROP32>, (const void*)attn_bwd_ca_kernel<QB, RES_NODROP>})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((attn_bwd_ca_kernel<QB>), dim3(a.B * a.H), dim3(256), lds, st, a);
+    switch (res_mode(a)) {
+    case RES_DROP32: hipLaunchKernelGGL((attn_bwd_ca_kernel<QB, RES_DROP32>), dim3(a.B * a.H), dim3(256), lds, st, a); break;
+    case RES_NODROP: hipLaunchKernelGGL((attn_bwd_ca_kernel<QB, RES_NODROP>), dim3(a.B * a.H), dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((attn_bwd_ca_kernel<QB, RES_GENERAL>), dim3(a.B * a.H), dim3(256), lds, st, a);
+    }
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
