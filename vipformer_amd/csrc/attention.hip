@@ -136,15 +136,21 @@ static inline int res_mode(const AttnArgs& a) { return a.p > 0.f ? (a.rng_fast ?
 #define FWD_MAXC 3  // ceil(64*8 / 192) chunks per thread at the smallest block (3 waves); 1-wave blocks loop 8x below
 // FWD_KT = kv rows per LDS stage (64 = two 32-row sub-tiles; 128 when there are many keys)
 // MODE: RES_DROP32 (training: dropout on, 32-bit group indices, no padding mask) or RES_GENERAL (every run-time test)
-template <int NW, int FWD_KT, int MODE>
-__global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
+// KS (round 4): the keys of a stage are split over KS waves per query block (QB * KS waves in all; wave = ks * QB + qb takes the
+// 32-key sub-tiles ks, ks + KS, .. of every stage) and the KS partial (max, sum, output) triples are merged through LDS at the end.
+// A few-queries-many-keys attention (96 latents against 1024 points) otherwise runs three waves per (cloud, head), each one serial
+// chain S -> softmax -> P V over 32 blocks with nothing to hide its latencies behind.
+template <int QB, int FWD_KT, int MODE, int KS>
+__global__ void __launch_bounds__(QB * KS * 64) attn_fwd_kernel(AttnArgs a)
 {
-    constexpr int NT = NW * 64;
+    constexpr int NW = QB * KS, NT = NW * 64;
     constexpr int MAXC = (FWD_KT * 8 + NT - 1) / NT;
+    static_assert((FWD_KT / 32) % KS == 0 && (KS & (KS - 1)) == 0, "the sub-tiles of a stage divide over the key splits");
     extern __shared__ __attribute__((aligned(16))) h16_t lds[];               // [2 buf][K,V][FWD_KT][KLD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane >> 5;
+    const int qb = KS == 1 ? wave : wave % QB, ks = KS == 1 ? 0 : wave / QB;
     const int bh = blockIdx.x, b = bh / a.H, hd = bh % a.H;
-    const int q = (blockIdx.y * NW + wave) * 32 + (lane & 31);
+    const int q = (blockIdx.y * QB + qb) * 32 + (lane & 31);
     const bool qok = q < a.Lq;
     const h16_t* Kg = a.K + (size_t)b * a.Lkv * a.ldk + hd * DH;
     const h16_t* Vg = a.V + (size_t)b * a.Lkv * a.ldv + hd * DH;
@@ -181,7 +187,8 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
             kv_load<FWD_KT, MAXC>(Vg, a.ldv, a.Lkv, (t + 1) * FWD_KT, rv, NT);
         }
 #pragma unroll
-        for (int sub = 0; sub < FWD_KT / 32; ++sub) {
+        for (int si = 0; si < FWD_KT / 32 / KS; ++si) {
+            const int sub = ks + si * KS;
             const int kv0 = t * FWD_KT + sub * 32;
             if (kv0 >= a.Lkv) break;
             f32x16_t s;
@@ -273,9 +280,38 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
         }
         __syncthreads();
     }
+    if (KS > 1) {
+        // merge tree over the key splits (the loop above ended on a barrier: the stage buffers are free).  Slot layout [34][64]: element-
+        // major, one float per lane -- conflict-free.  A split that saw no key at all (Lkv <= 32 * ks) carries m = -inf, l = 0, o = 0.
+        float* sM = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int step = KS / 2; step >= 1; step >>= 1) {
+            if (ks >= step && ks < 2 * step) {
+                float* slot = sM + (size_t)((ks - step) * QB + qb) * 34 * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { slot[r * 64] = o[0][r]; slot[(16 + r) * 64] = o[1][r]; }
+                slot[32 * 64] = m; slot[33 * 64] = l;
+            }
+            __syncthreads();
+            if (ks < step) {
+                const float* slot = sM + (size_t)(ks * QB + qb) * 34 * 64 + lane;
+                const float m2 = slot[32 * 64], l2 = slot[33 * 64];
+                const float mn = fmaxf(m, m2);
+                const float a1 = m == -INFINITY ? 0.f : vpf_exp2(m - mn), a2 = m2 == -INFINITY ? 0.f : vpf_exp2(m2 - mn);
+                l = l * a1 + l2 * a2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o[0][r] = o[0][r] * a1 + slot[r * 64] * a2;
+                    o[1][r] = o[1][r] * a1 + slot[(16 + r) * 64] * a2;
+                }
+                m = mn;
+            }
+            if (step > 1) __syncthreads();
+        }
+    }
     const float lt = l + __shfl_xor(l, 32, 64);
     const float inv = 1.f / lt;
-    if (qok) {
+    if (qok && ks == 0) {
         h16_t* op = a.O + ((size_t)b * a.Lq + q) * a.ldo + hd * DH;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -290,29 +326,37 @@ __global__ void __launch_bounds__(NW * 64) attn_fwd_kernel(AttnArgs a)
     }
 }
 
+template <int QB, int KT, int KS>
+static int launch_fwd_ks(const AttnArgs& a, hipStream_t st)
+{
+    dim3 grid(a.B * a.H, vpf_cdiv(a.Lq, 32 * QB));
+    const bool d32 = res_mode(a) == RES_DROP32 && !a.pad;
+    constexpr size_t lds = sizeof(h16_t) * 2 * 2 * KT * KLD;
+    static_assert(KS == 1 || sizeof(float) * (KS / 2) * QB * 34 * 64 <= lds, "the merge slots reuse the stage buffers");
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (lds > 65536)
+            for (const void* f : {(const void*)attn_fwd_kernel<QB, KT, RES_GENERAL, KS>, (const void*)attn_fwd_kernel<QB, KT, RES_DROP32, KS>})
+                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    if (d32) hipLaunchKernelGGL((attn_fwd_kernel<QB, KT, RES_DROP32, KS>), grid, dim3(QB * KS * 64), lds, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<QB, KT, RES_GENERAL, KS>), grid, dim3(QB * KS * 64), lds, st, a);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
 template <int NW>
 static int launch_fwd(const AttnArgs& a, hipStream_t st)
 {
-    dim3 grid(a.B * a.H, vpf_cdiv(a.Lq, 32 * NW));
-    const bool d32 = res_mode(a) == RES_DROP32 && !a.pad;
     if (a.Lkv >= 256) {
-        constexpr int KT = 128;
-        constexpr size_t lds = sizeof(h16_t) * 2 * 2 * KT * KLD;
-        static VpfPerDevice attr_dev; bool& attr = attr_dev();
-        if (!attr) {
-            for (const void* f : {(const void*)attn_fwd_kernel<NW, KT, RES_GENERAL>, (const void*)attn_fwd_kernel<NW, KT, RES_DROP32>})
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
-            attr = true;
+        if constexpr (NW <= 4) {          // few queries, many keys: split the keys over the waves too (VPF_ATTN_KSPLIT: 1 / 2 / 4)
+            const int ksplit = a.Lkv >= 512 ? vpf_debug().attn_ksplit : 1;
+            if constexpr (NW <= 3) if (ksplit >= 4) return launch_fwd_ks<NW, 128, 4>(a, st);      // (4 x 4 waves would leave 128 registers a lane: spills)
+            if (ksplit >= 2) return launch_fwd_ks<NW, 128, 2>(a, st);
         }
-        if (d32) hipLaunchKernelGGL((attn_fwd_kernel<NW, KT, RES_DROP32>), grid, dim3(NW * 64), lds, st, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<NW, KT, RES_GENERAL>), grid, dim3(NW * 64), lds, st, a);
-    } else {
-        constexpr size_t lds = sizeof(h16_t) * 2 * 2 * 64 * KLD;
-        if (d32) hipLaunchKernelGGL((attn_fwd_kernel<NW, 64, RES_DROP32>), grid, dim3(NW * 64), lds, st, a);
-        else hipLaunchKernelGGL((attn_fwd_kernel<NW, 64, RES_GENERAL>), grid, dim3(NW * 64), lds, st, a);
+        return launch_fwd_ks<NW, 128, 1>(a, st);
     }
-    VPF_CHECK_LAUNCH();
-    return VPF_OK;
+    return launch_fwd_ks<NW, 64, 1>(a, st);
 }
 
 // =============================================================================== resident self-attention, forward

@@ -43,6 +43,7 @@ struct VpfDebug {
     int sa_bwd_rows;        // VPF_SA_BWD_ROWS       1: row-coalesced backward row-block kernels
     int smallk_rpb;         // VPF_SMALLK_RPB        rows per block of the K = 3 front kernels (0: default)
     int sa_wg2;             // VPF_SA_WG2            bit 0 / bit 1: the round-3 forward / backward row-block kernels (sa_rows.hip) also at D = 256 (measured slower in the step: 0)
+    int attn_ksplit;        // VPF_ATTN_KSPLIT       key splits per query block in the tiled forward when Lq <= 128 and Lkv >= 512 (1, 2 or 4)
     int attn_ca_merged;     // VPF_ATTN_CA_MERGED    N > 0: dQ / dK / dV of a few-queries-many-keys attention in one kernel when B * H >= N (0: two kernels)
     int attn_rng32;         // VPF_ATTN_RNG32        1: 32-bit dropout group indices in the attention kernels when the score tensor allows it (same masks)
     int sa_bwd_fuse;        // VPF_SA_BWD_FUSE       1: qkv backward of a layer + MLP backward of the layer below as one launch (vpf_sa_layer_bwd_qkv_mlp), 0: two
