@@ -70,7 +70,7 @@ struct GemmArgs {
     const uint32_t* rng; uint32_t site; float p;   // dropout
     float* dbias;                                   // EPI_ATOMIC with a k-strided A: dbias[m] += sum_k A(m,k)
     int uneven;                                     // split-K slices of alternating length (4/3, 2/3 of the mean): see vpf_wgrad_group
-    int dbg;                                        // timing experiments only (VPF_WGROUP_DBG): 1 = no flush, 2 = no MFMA, 4 = no LDS fragment reads
+    int dbg;                                        // timing experiments only (VPF_WGROUP_DBG): 1 = no flush; in -DVPF_GEMM_DBG_LOOP builds 2 = no MFMA, 4 = no LDS fragment reads
     float* part; int* cnt; int ntx;                 // EPI_PARTIAL: partial tiles [tile][slice][BM*BN] (accumulator order), arrival counters [tile], tiles per row
     OpXform xa, xb;                                 // operand prologues (kind 0 = none)
 };
@@ -179,6 +179,11 @@ __device__ __forceinline__ void tile_store(h16_t* __restrict__ S, const uint4 (&
     }
 }
 
+#ifdef VPF_GEMM_DBG_LOOP
+#define GEMM_DBG_S(s) ((g.dbg & 4) ? 0 : (s))
+#else
+#define GEMM_DBG_S(s) (s)
+#endif
 // fragment for one 32x32x16 MFMA: rows [row0, row0+32), k-step s (16 wide) of the BK-deep tile
 template <int ROWS, bool TR, int BK>
 __device__ __forceinline__ h16x8_t frag_read(const h16_t* __restrict__ S, int row0, int s)
@@ -297,14 +302,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
                 tile_load<BM, ATR, BK, AX>(A, g.lda, g.M, g.K, m0, kbeg + (kt + PF) * BK, kend, ra[p], g.xa);
                 tile_load<BN, BTR, BK, BX>(B, g.ldb, g.N, g.K, n0, kbeg + (kt + PF) * BK, kend, rb[p], g.xb);
             }
-            if (!(g.dbg & 2)) {
+#ifdef VPF_GEMM_DBG_LOOP
+            if (!(g.dbg & 2))       // (experiment builds only: run-time tests in this loop turn the fragment offsets into VALU arithmetic)
+#endif
+            {
 #pragma unroll
             for (int s = 0; s < BK / 16; ++s) {
                 h16x8_t fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, (g.dbg & 4) ? 0 : s);
+                for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, ATR, BK>(cA, (wm * TM + i) * 32, GEMM_DBG_S(s));
 #pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR, BK>(cB, (wn * TN + j) * 32, (g.dbg & 4) ? 0 : s);
+                for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, BTR, BK>(cB, (wn * TN + j) * 32, GEMM_DBG_S(s));
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
