@@ -1,2 +1,2 @@
-bash tools/collect_step_bytes.sh r04 c2 > gpurun_out/sb_c2.log 2>&1; tail -5 gpurun_out/sb_c2.log | cut -c1-200
-rm -rf gpurun_out/stepbytes_r04_c2
+bash tools/ab.sh "VPF_KV_BWD_ON_SIDE=0" "VPF_KV_BWD_ON_SIDE=1" 4 --steps 60
+python3 tools/step_timeline.py c2 64 30 2>&1 | tail -12
