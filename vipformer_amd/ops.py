@@ -43,7 +43,7 @@ class OpsConfig:
     The library's own launch-time knobs live in its VpfDebug struct (``_lib.debug_get`` / ``debug_set``)."""
     __slots__ = ("wgrad_async", "wgrad_group", "wgrad_group_async", "wgrad_deterministic", "wgrad_defer", "sa_debug", "sa_split_attn",
                  "sa_fused_bwd", "sa_fused", "enc_bwd_hook", "adapter_kv_fused", "adapter_kv_bwd_fused", "enc_fused", "g2e_bn_merged",
-                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack", "ca_front_bwd_fused", "ca_kv_bwd_fused", "pgrad_flush")
+                 "g2e_conv1_bwd_fused", "ca_front_fused", "wgrad_stack", "ca_front_bwd_fused", "ca_kv_bwd_fused", "pgrad_flush", "kv_bwd_defer")
 
     def __init__(self, env=os.environ):
         self.wgrad_async = False          # weight-gradient GEMMs on a side stream: measured slower (cross-stream event cost > overlap gain)
@@ -62,6 +62,7 @@ class OpsConfig:
         self.ca_front_fused = env.get("VPF_CA_FRONT", "1") == "1"     # position MLP + (tokens + pos) + q_norm + q projection of the point-cloud branch as one kernel
         self.ca_front_bwd_fused = env.get("VPF_CA_FRONT_BWD", "1") == "1"      # the cross-attention layer's query-side backward as one row-block kernel (vpf_ca_front_bwd)
         self.ca_kv_bwd_fused = env.get("VPF_CA_KV_BWD", "0") == "1"            # ... and its key / value side where the kv input is an f32 tensor (image branch: vpf_ca_kv_bwd; measured: no gain, 3.93 vs 3.94 ms: off)
+        self.kv_bwd_defer = None          # the open KvBwdDeferral, if any: the K / V producer's backward (weight gradients only) is issued by its drain()
         self.pgrad_flush = 32             # LayerNorm parameter-gradient folds queued per vpf_ln_pgrad_reduce launch (tests lower it: ADVICE r03)
         self.wgrad_stack = env.get("VPF_WGRAD_STACK", "1") == "1"               # the weight gradients of a whole fused encoder stack as ONE grouped launch at the end of its backward
         self.g2e_bn_merged = env.get("VPF_G2E_BN_MERGED", "1") != "0"          # BatchNorm bookkeeping of Group2Emb as single launches
@@ -619,6 +620,41 @@ class WgradDeferral:
         self.queue = []
 
 
+
+
+class KvBwdDeferral:
+    """AdapterKVFn.backward hands its arguments over instead of launching; ``drain`` runs it on ``target`` (the image branch's stream,
+    behind that branch's backward) once ``backward`` has returned, not before ``gate`` (an event on the point-cloud stream, recorded by
+    Group2Emb's backward behind its chip-filling kernels).  See AdapterKVFn.backward."""
+
+    def __init__(self, target: torch.cuda.Stream):
+        self.target = target
+        self.queue = []
+        self.gate = None
+
+    def take(self, args) -> bool:
+        cur = torch.cuda.current_stream()
+        if cur == self.target:
+            return False
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.queue.append((ev, args))
+        return True
+
+    def mark_gate(self) -> None:
+        self.gate = torch.cuda.Event()
+        self.gate.record(torch.cuda.current_stream())
+
+    def drain(self) -> None:
+        with torch.cuda.stream(self.target):
+            for ev, args in self.queue:
+                self.target.wait_event(ev)
+                if self.gate is not None:
+                    self.target.wait_event(self.gate)
+                AdapterKVFn._backward(*args)
+                for t in tuple(args[3]) + (args[4],):
+                    t.record_stream(self.target)          # (allocated on the main stream, read by this stream's kernels)
+        self.queue = []
 
 
 class WgradBatch:
@@ -1615,8 +1651,21 @@ class AdapterKVFn(torch.autograd.Function):
     @staticmethod
     @_sinked
     def backward(ctx, dkv):
-        x, a1, xkv, mk, rk, nk = ctx.saved_tensors
-        adapter, cross = ctx.mods
+        # Nothing downstream waits for this node (its inputs are the raw points; its results are weight gradients the kernels write
+        # themselves), but autograd runs it at the END of the point-cloud branch's backward -- it was created first -- where the other
+        # branch's stream has long run dry.  A two-stream trainer opens a deferral (cfg.kv_bwd_defer, a KvBwdDeferral): the ~285 us chain
+        # is then issued by drain() on that stream, gated behind Group2Emb's two big backward kernels (which own every CU's register
+        # file: nothing runs beside them), so it runs beside the small launches that follow them instead of behind those.
+        saved = ctx.saved_tensors
+        args = (ctx.mods, ctx.packed, ctx.nparams, saved, dkv)
+        if cfg.kv_bwd_defer is not None and dkv.is_cuda and cfg.kv_bwd_defer.take(args):
+            return (None, None, None) + (None,) * ctx.nparams
+        return AdapterKVFn._backward(*args)
+
+    @staticmethod
+    def _backward(mods, packed, nparams, saved, dkv):
+        x, a1, xkv, mk, rk, nk = saved
+        adapter, cross = mods
         l0, ln, l3 = adapter.point_mlp[0], adapter.point_mlp[1], adapter.point_mlp[3]
         catt, lnkv = cross.attention, cross.kv_norm
         D = l3.weight.shape[0]
@@ -1625,7 +1674,7 @@ class AdapterKVFn(torch.autograd.Function):
         w16, gKV = shadow(qkvw), packed_grad(qkvw[1:])
         dkv = to_h16(dkv).view(M, 2 * D)
         if cfg.adapter_kv_bwd_fused:
-            pk = ctx.packed
+            pk = packed
             n2, nkv = D * 64, 2 * D * D
             fn = L.lib().vpf_adapter_kv_pgrad_rows
             fn.argtypes, fn.restype = [ctypes.c_long, ctypes.c_int], ctypes.c_int
@@ -1650,7 +1699,7 @@ class AdapterKVFn(torch.autograd.Function):
             wg.add(dkv, nk, 2 * D, D, gKV)
             wg.add(dy16, a1, D, 64, grad_buf(l3.weight), grad_buf(l3.bias))
             wg.flush()
-            return (None, None, None) + (None,) * ctx.nparams
+            return (None, None, None) + (None,) * nparams
         linear_wgrad(dkv, nk, 2 * D, D, gKV)
         dnk = linear_dgrad(dkv, w16[D * D:], 2 * D, D)
         dy16 = layernorm_bwd(dnk, xkv, mk, rk, lnkv.weight, lnkv.bias, None, out_h16=True).view(M, D)
@@ -1659,7 +1708,7 @@ class AdapterKVFn(torch.autograd.Function):
         ws = torch.empty(2048 * 64 * 11, dtype=F32, device=x.device)
         L.call("vpf_adapter_front_bwd", x, da, M, C, l0.weight.data, l0.bias.data, ln.weight.data, ln.bias.data,
                grad_buf(l0.weight), grad_buf(l0.bias), grad_buf(ln.weight), grad_buf(ln.bias), ws, ws.numel())
-        return (None, None, None) + (None,) * ctx.nparams
+        return (None, None, None) + (None,) * nparams
 
 
 
@@ -1877,6 +1926,8 @@ class Group2EmbFn(torch.autograd.Function):
             dh2 = torch.empty(M, 128, dtype=H16, device=dev)
             L.call("vpf_g2e_bwd", dout, arg4, Dm, NG, h3, stat2, bn2.weight.data, bn2.bias.data, w4t, w3bt, int(training), tmp2, dh3,
                    dgb, dh2, grad_buf(bn2.weight), grad_buf(bn2.bias), G2E_DEBUG.get("dbg"))
+            if cfg.kv_bwd_defer is not None:
+                cfg.kv_bwd_defer.mark_gate()
         else:
             if ctx.fused:
                 # d(conv output) = max-pool gradient: rebuilt on the fly from (dout, arg4) inside both GEMMs' A-operand

@@ -225,6 +225,9 @@ class Pretrainer:
         # Measured +0.11 ms/step on MI355X: the two branches already share the CUs for most of the step, the step is bound by the SUM
         # of kernel time (6.9 ms over 4.55 ms of wall), not by the longer stream
         self.defer_wgrad = os.environ.get("VPF_DEFER_WGRAD", "0") == "1"
+        # the K / V producer's backward (weight gradients only, the LAST node autograd runs) on the image branch's stream, beside the
+        # small launches at the end of Group2Emb's backward instead of behind them (ops.AdapterKVFn.backward, ops.KvBwdDeferral)
+        self.kv_bwd_on_side = os.environ.get("VPF_KV_BWD_ON_SIDE", "1") == "1"
         self._side = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._graph = None
         self._static = None
@@ -369,10 +372,15 @@ class Pretrainer:
             total = loss_imid + self.cmid_weight * loss_cmid
         defer = ops.WgradDeferral(self._side) if (self.overlap and self._side is not None and self.defer_wgrad) else None
         ops.cfg.wgrad_defer = defer
+        kvd = ops.KvBwdDeferral(self._side) if (self.overlap and self._side is not None and self.kv_bwd_on_side) else None
+        ops.cfg.kv_bwd_defer = kvd
         try:
             total.backward(self._one)                       # (a persistent 1.0: no ones_like fill launch per step)
         finally:
             ops.cfg.wgrad_defer = None
+            ops.cfg.kv_bwd_defer = None
+        if kvd is not None:
+            kvd.drain()                                     # the K / V producer's backward, on the image branch's stream
         if defer is not None:
             defer.drain()                                   # the point-cloud branch's grouped weight gradients, behind the image branch's backward
         if tl is not None:
