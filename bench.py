@@ -291,14 +291,14 @@ PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step budget
     "gemm_wgrad_group_kernel (one layer)": [],                             # (no such launch in the step: stand-alone figures only)
     "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel", "sa_rows_fwd_kernel"],
     "sa_bwd_qkv_mlp_rows_kernel": ["sa_bwd_qkv_mlp_rows_kernel"],
-    "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel<3, 128>", "attn_fwd_kernel<4, 128>"],
+    "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel<3, 128,", "attn_fwd_kernel<4, 128,"],
     # (one "launch" of the leg = the merged kernel, or the dq + dk/dv pair of the same shape where the merged one is not used)
     "attn_bwd_dq/dkv_kernel (cross-attention pc)": ["attn_bwd_dq_kernel<3, 128>", "attn_bwd_dq_kernel<4, 128>", "attn_bwd_dkv_resq_kernel<4, 3>",
-                                                    "attn_bwd_dkv_resq_kernel<4, 4>", "attn_bwd_ca_kernel"],
-    "attn_res_fwd_kernel (self-attention pc)": ["attn_res_fwd_kernel<3>", "attn_res_fwd_kernel<4>"],
-    "attn_res_fwd_kernel (self-attention img)": ["attn_res_fwd_kernel<7>"],
-    "attn_res_bwd_kernel (self-attention pc)": ["attn_res_bwd_kernel<3>", "attn_res_bwd_kernel<4>"],
-    "attn_res_bwd_kernel (self-attention img)": ["attn_res_bwd_kernel<7>"],
+                                                    "attn_bwd_dkv_resq_kernel<4, 4>", "attn_bwd_ca_kernel"],        # (substrings: template lists may continue)
+    "attn_res_fwd_kernel (self-attention pc)": ["attn_res_fwd_kernel<3,", "attn_res_fwd_kernel<4,"],
+    "attn_res_fwd_kernel (self-attention img)": ["attn_res_fwd_kernel<7,", "attn_res_fwd_kernel<5,"],
+    "attn_res_bwd_kernel (self-attention pc)": ["attn_res_bwd_kernel<3,", "attn_res_bwd_kernel<4,"],
+    "attn_res_bwd_kernel (self-attention img)": ["attn_res_bwd_kernel<7,", "attn_res_bwd_kernel<5,"],
 }
 
 

@@ -1,24 +1,7 @@
-python3 - <<'PY'
-import torch, bench
-torch.backends.cuda.matmul.allow_fp16_reduced_precision_reduction = False
-M=12288
-for (N,K) in ((768,256),(256,256),(512,256),(256,512),(512,131072//256)):
-    for dt in (torch.float16,):
-        dy=torch.randn(M,N,device="cuda",dtype=dt); x=torch.randn(M,K,device="cuda",dtype=dt)
-        out=torch.empty(N,K,device="cuda",dtype=torch.float32)
-        f=lambda: torch.mm(dy.t(), x)
-        us=bench._events(f, 30, 5)
-        print(f"torch mm dW[{N}x{K}] over M={M}: {us:.1f} us  {2*M*N*K/us/1e6:.0f} TFLOP/s", flush=True)
-# the K/V wgrad: M = 131072, N = 512, K = 256
-M=131072
-dy=torch.randn(M,512,device="cuda",dtype=torch.float16); x=torch.randn(M,256,device="cuda",dtype=torch.float16)
-us=bench._events(lambda: torch.mm(dy.t(), x), 20, 3)
-print(f"torch mm dW[512x256] over M={M}: {us:.1f} us  {2*M*512*256/us/1e6:.0f} TFLOP/s")
-# batched: 6 layers x 4 GEMMs as one bmm-like loop (sum of times)
-M=12288
-tot=0
-for (N,K) in ((768,256),(256,256),(512,256),(256,512)):
-    dy=torch.randn(M,N,device="cuda",dtype=torch.float16); x=torch.randn(M,K,device="cuda",dtype=torch.float16)
-    tot+=bench._events(lambda: torch.mm(dy.t(), x), 30, 5)
-print(f"one layer's four wgrads via torch.mm: {tot:.1f} us (ours grouped: ~41 us/layer, 210 us/7-layer stack)")
-PY
+for a in c2 c3 c4 ref144 ref144m4; do bash tools/collect_step_bytes.sh r04 $a > gpurun_out/sb_$a.log 2>&1; tail -1 gpurun_out/sb_$a.log | cut -c1-150; rm -rf gpurun_out/stepbytes_r04_$a; done
+cp gpurun_out/r04_step_bytes*.json profiles/
+bash tools/collect_step_issue.sh r04 c2 > gpurun_out/si_c2.log 2>&1; tail -2 gpurun_out/si_c2.log | cut -c1-150; rm -rf gpurun_out/stepissue_r04_c2
+bash tools/collect_profiles.sh r04 > gpurun_out/cp.log 2>&1; tail -2 gpurun_out/cp.log | cut -c1-150; rm -rf gpurun_out/prof_r04
+cp gpurun_out/r04_pmc_summary.json profiles/
+python3 bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/bench_default.err; tail -1 gpurun_out/r04_bench_default.json | cut -c1-300
+for a in ref144 c5 c3 c4; do python3 bench.py --arch $a --no-cpu-baseline > gpurun_out/r04_bench_$a.json 2>/dev/null; tail -1 gpurun_out/r04_bench_$a.json | cut -c1-200; done
