@@ -1,4 +1,5 @@
-timeout 3000 python -m pytest tests -q -p no:cacheprovider -m gpu -x > gpurun_out/t_gpu.log 2>&1; grep -E '^(FAILED|ERROR)|passed|failed' gpurun_out/t_gpu.log; grep -E "^E  " gpurun_out/t_gpu.log | head -8
-cp gpurun_out/t_gpu.log gpurun_out/r04_gpu_tests.log
-python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 600 python3 tools/dp2_one_gpu.py > gpurun_out/dp2.log 2>&1; tail -5 gpurun_out/dp2.log
+for i in 1 2 3; do for cfg in "VPF_MAIN_PRIO=0 VPF_SIDE_PRIO=0" "VPF_MAIN_PRIO=-1 VPF_SIDE_PRIO=0" "VPF_MAIN_PRIO=0 VPF_SIDE_PRIO=-1"; do
+ms=$(env $cfg python3 bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-kernels --no-variants 2>/dev/null | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")
+echo "$cfg  $ms ms/step"
+done; done
+python3 -c "import torch; print(torch.cuda.Stream.priority_range())"
