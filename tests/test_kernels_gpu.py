@@ -223,6 +223,7 @@ def test_attention_bwd_one_kernel_equals_two_bitwise(B, H, Lq, Lkv, p):
     L.call("vpf_attention_fwd", q16, D, k16, D, v16, D, B, H, Lq, Lkv, 64, scale, p, st, site, o, D, lse)
 
     def run(flag):
+        prev = L.debug_get("attn_ca_merged")
         L.debug_set("attn_ca_merged", flag)
         try:
             dq = torch.full((B * Lq, D), float("nan"), dtype=H16, device="cuda")
@@ -233,7 +234,7 @@ def test_attention_bwd_one_kernel_equals_two_bitwise(B, H, Lq, Lkv, p):
             torch.cuda.synchronize()
             return dq, dk, dv
         finally:
-            L.debug_set("attn_ca_merged", 512)
+            L.debug_set("attn_ca_merged", prev)
 
     two, one, again = run(0), run(1), run(1)
     for name, a, b, c in zip(("dq", "dk", "dv"), two, one, again):

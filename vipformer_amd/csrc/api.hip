@@ -68,7 +68,7 @@ static const VpfDebugKey kDebugKeys[] = {
     {"smallk_rpb", "VPF_SMALLK_RPB", &VpfDebug::smallk_rpb, 0},
     {"sa_wg2", "VPF_SA_WG2", &VpfDebug::sa_wg2, 0},
     {"attn_ksplit", "VPF_ATTN_KSPLIT", &VpfDebug::attn_ksplit, 4},
-    {"attn_ca_merged", "VPF_ATTN_CA_MERGED", &VpfDebug::attn_ca_merged, 512},
+    {"attn_ca_merged", "VPF_ATTN_CA_MERGED", &VpfDebug::attn_ca_merged, 128},
     {"attn_rng32", "VPF_ATTN_RNG32", &VpfDebug::attn_rng32, 1},
     {"sa_bwd_fuse", "VPF_SA_BWD_FUSE", &VpfDebug::sa_bwd_fuse, 1},
     {"wgroup_xlist", "VPF_WGROUP_XLIST", &VpfDebug::wgroup_xlist, 1},
