@@ -88,6 +88,14 @@ def main(arch="c2", pairs=64, replays=30):
     pc.train(); im.train()
     tr = Pretrainer(pc, im)
     tl = tr.timeline = ops.Timeline(dev)
+    kv_apply = ops.AdapterKVFn.apply
+
+    def kv_marked(*a):                        # the K / V producer: the point-cloud stream's first kernels
+        tl.mark("pc.kv.fwd.begin")
+        out = kv_apply(*a)
+        tl.mark("pc.kv.fwd.end")
+        return out
+    ops.AdapterKVFn.apply = kv_marked
     wrap_forward(pc.group2emb, tl, "pc.g2e.fwd.begin", "pc.g2e.fwd.end", "pc.g2e.bwd.begin")
     wrap_forward(pc.encoder, tl, "pc.enc.fwd.begin", "pc.enc.fwd.end", "pc.enc.bwd.begin")
     wrap_forward(im.encoder, tl, "img.enc.fwd.begin", "img.enc.fwd.end", "img.enc.bwd.begin")
