@@ -121,9 +121,10 @@ def main(arch="c2", pairs=64, replays=30):
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / replays
-    for _ in range(replays):                    # (reading the marks needs a sync per replay: timed separately above)
-        tr.replay()
-        torch.cuda.synchronize()
+    for _ in range(replays):                    # (reading the marks needs a sync: timed separately above)
+        for _ in range(4):                      # the marks of the LAST of four back-to-back replays: a replay launched on an idle GPU runs
+            tr.replay()                         # its first ~0.5 ms at the host's enqueue rate (tools/diag_replay_host.py) and shows the
+        torch.cuda.synchronize()                # second branch starting 50 - 140 us late; in steady state the host is several steps ahead
         rows.append(tl.read())
     names = list(rows[0])
     med = {n: sorted(r[n] for r in rows)[len(rows) // 2] for n in names}

@@ -219,9 +219,9 @@ class Pretrainer:
         self.overlap = True
         self.fused_losses = True
         # FPS + kNN at the head of the image branch's stream (the point-cloud stream then starts with the K / V producer) or where the
-        # model runs them, at the head of the point-cloud stream.  Round 4: the replayed graph starts its second branch 50 - 140 us into
-        # the step whatever is put there (tools/step_timeline.py), so the grouping -- which Group2Emb waits for -- is better off on the
-        # first one: equal on the fastest box seen, -0.05 .. -0.075 ms on two slower ones (NOTES.md).  Off since then.
+        # model runs them, at the head of the point-cloud stream.  Round 4, alternating runs: the second placement is equal on the fastest
+        # box seen and -0.05 .. -0.075 ms on two slower ones (NOTES.md: the forward join is better balanced with the first, the end of
+        # backward with the second).  Off since then.
         self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "0") == "1"
         self.main_first = os.environ.get("VPF_MAIN_FIRST", "0") == "1"       # measured: no gain in the unmarked step (4.31 vs 4.29 ms), off
         self.timeline = None                 # an ops.Timeline: device timestamps at the branch boundaries (tools/step_timeline.py); None = no marks
