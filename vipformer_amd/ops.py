@@ -631,13 +631,24 @@ class KvBwdDeferral:
         self.target = target
         self.queue = []
         self.gate = None
+        self.ready = None
+
+    def mark_ready(self) -> None:
+        """The producer of the node's input gradient (the cross-attention backward) has been launched on the current stream: the
+        deferred chain waits for THIS point, not for the point where autograd gets round to the node (the end of the whole backward
+        pass when the node was created first)."""
+        self.ready = torch.cuda.Event()
+        self.ready.record(torch.cuda.current_stream())
 
     def take(self, args) -> bool:
         cur = torch.cuda.current_stream()
         if cur == self.target:
             return False
-        ev = torch.cuda.Event()
-        ev.record(cur)
+        ev = self.ready
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+        self.ready = None
         self.queue.append((ev, args))
         return True
 
@@ -1534,6 +1545,8 @@ class EncoderFusedFn(torch.autograd.Function):
         L.call("vpf_attention_bwd", q, D, kv, 2 * D, kv[:, D:], 2 * D, o, D, do, D, lse, B, H, Lq, Lkv, D // H, float(catt.dp_scale),
                float(catt.dropout.p if training else 0.0), st, catt.site_attn, dq, D, dkv, 2 * D, dkv[:, D:], 2 * D,
                torch.empty(B * H * Lq, dtype=F32, device=dev))
+        if ctx.kv_ready and cfg.kv_bwd_defer is not None:
+            cfg.kv_bwd_defer.mark_ready()          # dK | dV exist from here on (autograd may reach AdapterKVFn.backward much later)
         qkvw = [catt.q_proj.weight, catt.k_proj.weight, catt.v_proj.weight]
         w16, gW = shadow(qkvw), packed_grad(qkvw[:1] if ctx.kv_ready else qkvw)      # (K / V weights: AdapterKVFn's business then)
         wg = wg_all if wg_all is not None else WgradBatch()

@@ -218,11 +218,12 @@ class Pretrainer:
         # stream so its kernels fill the CUs that FPS / kNN / the small GEMMs of the pc branch leave idle
         self.overlap = True
         self.fused_losses = True
-        # FPS + kNN at the head of the image branch's stream (the point-cloud stream then starts with the K / V producer) or where the
-        # model runs them, at the head of the point-cloud stream.  Round 4, alternating runs: the second placement is equal on the fastest
-        # box seen and -0.05 .. -0.075 ms on two slower ones (NOTES.md: the forward join is better balanced with the first, the end of
-        # backward with the second).  Off since then.
-        self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "0") == "1"
+        # FPS + kNN at the head of the image branch's stream (the point-cloud stream then starts with the K / V producer, which needs only
+        # the raw points, and meets the groups in front of Group2Emb) or where the model runs them, at the head of the point-cloud stream.
+        # Round 4, alternating runs (NOTES.md): with the K / V producer's backward handed to the other stream FROM THE POINT WHERE ITS
+        # INPUT GRADIENT EXISTS (ops.KvBwdDeferral.mark_ready) the first placement wins by 0.07 ms -- the forward join is balanced (both
+        # branches within 25 us) and so is the end of backward.
+        self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "1") == "1"
         self.main_first = os.environ.get("VPF_MAIN_FIRST", "0") == "1"       # measured: no gain in the unmarked step (4.31 vs 4.29 ms), off
         self.timeline = None                 # an ops.Timeline: device timestamps at the branch boundaries (tools/step_timeline.py); None = no marks
         # optional: the point-cloud branch's grouped weight gradients on the image branch's stream behind its backward (ops.WgradDeferral).
