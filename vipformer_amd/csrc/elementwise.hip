@@ -837,13 +837,35 @@ __global__ void pool_bwd_kernel(const float* __restrict__ dout, const int* __res
         dx[i] = v;
     }
 }
+// D % 4 == 0 and fewer than 2^31 elements: a thread writes four channels of one token row (16-byte stores, 32-bit index arithmetic):
+// 10.8 -> 6.2 us at 128 x 96 x 256 (round 4)
+__global__ void __launch_bounds__(256) pool_bwd_vec_kernel(const float* __restrict__ dout, const int* __restrict__ arg, int rows, int L, int D4,
+                                                           float* __restrict__ dx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * D4) return;
+    const int row = i / D4, c4 = i - row * D4, b = row / L, l = row - b * L, D = 4 * D4;
+    const float4 mx = *reinterpret_cast<const float4*>(dout + (size_t)b * 2 * D + 4 * c4);
+    const float4 mn = *reinterpret_cast<const float4*>(dout + (size_t)b * 2 * D + D + 4 * c4);
+    const int4 a = *reinterpret_cast<const int4*>(arg + (size_t)b * D + 4 * c4);
+    const float fl = (float)L;
+    float4 v = make_float4(mn.x / fl, mn.y / fl, mn.z / fl, mn.w / fl);
+    if (a.x == l) v.x += mx.x;
+    if (a.y == l) v.y += mx.y;
+    if (a.z == l) v.z += mx.z;
+    if (a.w == l) v.w += mx.w;
+    *reinterpret_cast<float4*>(dx + (size_t)i * 4) = v;
+}
 extern "C" int vpf_pool_bwd(const float* dout, const int* arg, int B, int L, int D, float* dx, void* stream)
 {
     (void)hipGetLastError();   // drop any stale (non-sticky) error left by an earlier runtime call of this thread
     if (!dout || !arg || !dx) return VPF_ERR_NULL;
     if (B < 0 || L <= 0 || D <= 0) return VPF_ERR_BADSHAPE;
     if (B == 0) return VPF_OK;
-    hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for((long)B * L * D, 256)), dim3(256), 0, (hipStream_t)stream, dout, arg, B, L, D, dx);
+    if (D % 4 == 0 && (long)B * L * D < (1l << 31) && !((uintptr_t)dout & 15) && !((uintptr_t)arg & 15) && !((uintptr_t)dx & 15))
+        hipLaunchKernelGGL(pool_bwd_vec_kernel, dim3((unsigned)(((long)B * L * (D / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, arg, B * L, L, D / 4, dx);
+    else
+        hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_for((long)B * L * D, 256)), dim3(256), 0, (hipStream_t)stream, dout, arg, B, L, D, dx);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
