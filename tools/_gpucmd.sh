@@ -1,2 +1,3 @@
-timeout 1500 python -m pytest tests/test_modules_gpu.py tests/test_boundary_gpu.py -q -p no:cacheprovider -x > gpurun_out/t_mod.log 2>&1; grep -E '^(FAILED|ERROR)|passed|failed' gpurun_out/t_mod.log; grep -E "^E  " gpurun_out/t_mod.log | head -8
-bash tools/ab.sh "VPF_WGRAD_CARRY=0" "VPF_WGRAD_CARRY=1" 4 --steps 60
+timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_modules_gpu.py -q -p no:cacheprovider -x -k "g2e or group2emb or Group2Emb or pool or training_step" > gpurun_out/t_g2e.log 2>&1; grep -E '^(FAILED|ERROR)|passed|failed' gpurun_out/t_g2e.log; grep -E "^E  " gpurun_out/t_g2e.log | head -8
+for lib in tools/_bin/lib_prev.so vipformer_amd/libvipformer_hip.so; do echo $lib; VPF_LIB=$PWD/$lib python3 tools/microbench.py g2e 2>&1 | grep -v amdgpu | tail -2; done
+bash tools/ab.sh "VPF_LIB=$PWD/tools/_bin/lib_prev.so" "VPF_LIB=$PWD/vipformer_amd/libvipformer_hip.so" 3 --steps 60

@@ -568,7 +568,10 @@ struct G2eBwd {
     long long* dbg;               // diagnostic: per-phase cycle sums of wave 0 of every workgroup (nullable)
 };
 
-template <int PASS>
+// KSC (round 4): the number of 16-wide k-steps of the dh4 . W4 product as a template parameter (16 at Dm = 256; 0 = read Dm at run time).
+// With `ks < Dm / 16` tested at run time every k-step was its own basic block -- two LDS reads, a wait for them, two MFMAs, a branch --
+// and nothing of step ks + 1 could be issued under step ks (tools/inst_mix.py: 16 x "LLWMWM s_cbranch").
+template <int PASS, int KSC>
 __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
 {
     extern __shared__ __attribute__((aligned(16))) h16_t smem[];
@@ -587,11 +590,11 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
         }
         // (visible to every wave after the first barrier of the loop)
     }
-    const int KS4 = p.Dm / 16;                  // k-steps of the dh4 . W4 product (<= 16)
+    const int KS4 = KSC ? KSC : p.Dm / 16;      // k-steps of the dh4 . W4 product (<= 16)
     h16x8_t w4f[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks)
-        w4f[ks] = ks < KS4 ? ldfrag(p.w4t + (size_t)(w * 32 + l31) * p.Dm + ks * 16 + 8 * hl) : __builtin_bit_cast(h16x8_t, make_uint4(0, 0, 0, 0));
+        w4f[ks] = (KSC ? ks < KSC : ks < KS4) ? ldfrag(p.w4t + (size_t)(w * 32 + l31) * p.Dm + ks * 16 + 8 * hl) : __builtin_bit_cast(h16x8_t, make_uint4(0, 0, 0, 0));
     const int col = w * 32 + l31;
     const float mean = p.stat2[col], rstd = p.stat2[256 + col], ga = p.gamma2[col], be = p.beta2[col];
     float sg = 0.f, sgx = 0.f;
@@ -674,7 +677,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks)
-            if (ks < KS4) {
+            if (KSC ? ks < KSC : ks < KS4) {
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
                     acc[rt] = vpf_mfma32(ldfrag(sD4 + (rt * 32 + l31) * H3LD + ks * 16 + 8 * hl), w4f[ks], acc[rt]);
@@ -781,14 +784,21 @@ extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long 
     const size_t lds = sizeof(h16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
-        if (hipFuncSetAttribute((const void*)g2e_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return VPF_ERR_HIP;
+        for (const void* f : {(const void*)g2e_bwd_kernel<0, 0>, (const void*)g2e_bwd_kernel<0, 16>})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        for (const void* f : {(const void*)g2e_bwd_kernel<1, 0>, (const void*)g2e_bwd_kernel<1, 16>})
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
     long grid = (NG + 1) / 2; if (grid > g2e_max_grid()) grid = g2e_max_grid();
     hipStream_t st = (hipStream_t)stream;
-    if (training) hipLaunchKernelGGL(g2e_bwd_kernel<0>, dim3((unsigned)grid), dim3(512), lds, st, p);
-    hipLaunchKernelGGL(g2e_bwd_kernel<1>, dim3((unsigned)grid), dim3(512), lds1, st, p);
+    if (Dm == 256) {
+        if (training) hipLaunchKernelGGL((g2e_bwd_kernel<0, 16>), dim3((unsigned)grid), dim3(512), lds, st, p);
+        hipLaunchKernelGGL((g2e_bwd_kernel<1, 16>), dim3((unsigned)grid), dim3(512), lds1, st, p);
+    } else {
+        if (training) hipLaunchKernelGGL((g2e_bwd_kernel<0, 0>), dim3((unsigned)grid), dim3(512), lds, st, p);
+        hipLaunchKernelGGL((g2e_bwd_kernel<1, 0>), dim3((unsigned)grid), dim3(512), lds1, st, p);
+    }
     if (training) hipLaunchKernelGGL(g2e_bn2_param_grad_kernel, dim3(1), dim3(256), 0, st, (const float*)tmp512_zeroed, dgamma2, dbeta2);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
