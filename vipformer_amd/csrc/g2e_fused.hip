@@ -709,7 +709,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
                 g = dead ? 0.f : g;
                 if (PASS == 0) { a0 += g; a1 += g * xh; }
                 else {
-                    const float dv = p.training ? ga * rstd * (g - sg - xh * sgx) : ga * rstd * g;
+                    const float dv = ga * rstd * (g - sg - xh * sgx);        // (eval: sg = sgx = 0 above -- the same value as ga * rstd * g, without a select per element)
                     const h16_t db = f32_to_h16(dv);
                     dres[r] = db;
                     gsum[rt] += h16_to_f32(db);
