@@ -141,15 +141,21 @@ __global__ void __launch_bounds__(512) g2e_fwd_a_kernel(G2eA p)
                 }
             }
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
+            for (int rt = 0; rt < 2; ++rt) {
+                // a pair holds 32 or 64 valid rows (whole groups): the second row tile is valid as a whole or not at all -- one uniform
+                // test per tile instead of a compare + select per element (round 4)
+                h16_t hbv[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl;
-                    const h16_t hb = f32_to_h16(acc[rt][r] + b3v);
-                    sH3[row * H3LD + w * 32 + l31] = hb;
-                    const float hv = row < nrows ? h16_to_f32(hb) : 0.f;          // (a select, not a branch per element)
-                    ssum += hv; ssq += hv * hv;
+                    hbv[r] = f32_to_h16(acc[rt][r] + b3v);
+                    sH3[row * H3LD + w * 32 + l31] = hbv[r];
                 }
+                if (rt == 0 || nrows == 64) {                 // (same additions in the same order as before)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float hv = h16_to_f32(hbv[r]); ssum += hv; ssq += hv * hv; }
+                }
+            }
         }
         __syncthreads();
         for (int c = t; c < 64 * 32; c += 512) {
