@@ -456,7 +456,8 @@ def partseg_line(args, device):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(m.parameters(), 10, norm_type=2)
         opt.step()
-        last[0] = loss
+        last[0] = loss.detach()               # (not the loss itself: a live autograd graph from an eager step keeps its AccumulateGrad nodes,
+                                              #  bound to the stream of that step, for the captured one below)
 
     for _ in range(args.warmup):
         step()
@@ -466,12 +467,31 @@ def partseg_line(args, device):
         step()
     torch.cuda.synchronize()
     el = (time.perf_counter() - t0) / args.steps
+    eager_loss = float(last[0])
+    # the same loop body captured into a hipGraph (train.GraphedStep; torch's AdamW made capturable, nothing else changed)
+    graphed = None
+    try:
+        from vipformer_amd.train import GraphedStep
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, capturable=True)
+        run = GraphedStep(step, warmup=3)
+        for _ in range(args.warmup):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        torch.cuda.synchronize()
+        eg = (time.perf_counter() - t0) / args.steps
+        graphed = {"value": round(B / eg, 2), "ms_per_step": round(eg * 1e3, 3), "last_loss": float(last[0]),
+                   "note": "train.GraphedStep: the same loop body (torch AdamW with capturable=True) replayed as one hipGraph"}
+    except Exception as e:                                    # (a side line of a side line: never fatal)
+        graphed = {"error": f"{type(e).__name__}: {e}"[:200]}
     return {"metric": "part-segmentation fine-tune clouds/sec (ShapeNetPart-shaped, E1CL8SL-H4D256-L128-MR2 backbone)", "value": round(B / el, 2),
             "unit": "clouds/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[4]: CrossFormer_partseg fine-tune step, {B} clouds x {N} points, 16 object / 50 part classes, "
                                    "CE(label_smoothing 0.2) + clip_grad_norm_(10) + torch AdamW, eager (ft_partseg.py:145-176)",
-                       "last_loss": float(last[0]), "hip_graph": False,
+                       "last_loss": eager_loss, "hip_graph": False, "graphed": graphed,
                        "note": "side line: the reference's fine-tune loop body unchanged on the mirrored CrossFormer_partseg; not the pre-training metric"},
             "roofline": None, "cpu_baseline": None}
 

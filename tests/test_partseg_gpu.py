@@ -285,3 +285,52 @@ def test_finetune_backward_needs_no_gradscaler():
     assert c_def > 0.9998, c_def                                        # (two powers of two apart: fp32 atomic order + a few fp16 roundings)
     assert abs(float(grads["default"].norm() / ref.norm()) - 1.0) < 2e-3
     assert c_off < c_def                                                # what the unscaled fp16 backward pass loses (measured ~0.96 - 0.99)
+
+
+def test_graphed_step_replays_the_finetune_loop_with_fresh_masks():
+    """train.GraphedStep: the reference's fine-tune loop body (ft_partseg.py:145-176) captured into one hipGraph -- replays train (the
+    loss falls on a fixed batch), every replay draws new dropout masks (two replays from the same parameters and the same batch give
+    different losses only if the masks differ: checked with a zero learning rate), and the captured step matches an eager step."""
+    from vipformer_amd import ops, ops_seg as S
+    from vipformer_amd.train import GraphedStep
+    name = "tinyseg"
+    a = Hh.ARCHS[name]
+    B, N = 4, a["N"]
+    torch.manual_seed(3)
+    ops.rng.seed(77)
+    m = _build(name, drops=(0.1, 0.5)).cuda()
+    m.train()
+    pts = Hh.synth_points(1, B, N).cuda()
+    onehot = torch.zeros(B, 16, device="cuda"); onehot[torch.arange(B), torch.arange(B) % 16] = 1.0
+    target = (torch.arange(B * N, device="cuda") % 50).view(B, N)
+    lr = torch.tensor(0.0, device="cuda")
+    opt = torch.optim.AdamW(m.parameters(), lr=lr, capturable=True)
+    out = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred = m(pts, onehot)
+        loss = S.cross_entropy_smooth(pred.reshape(-1, 50), target.reshape(-1), 0.2)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 10, norm_type=2)
+        opt.step()
+        out["loss"] = loss.detach()
+
+    run = GraphedStep(step, warmup=2)
+    graph_loss = out["loss"]                                  # the captured step's (static) loss tensor
+    losses = []
+    for _ in range(3):
+        run(); torch.cuda.synchronize(); losses.append(float(out["loss"]))
+    assert all(l == l and abs(l) < 1e3 for l in losses)
+    assert len(set(losses)) == 3, losses                      # lr = 0: only the dropout masks change between replays
+    step(); torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - sum(losses) / 3) < 0.2    # an eager step of the same (unchanged) parameters: the same loss up to its masks
+    out["loss"] = graph_loss
+    lr.fill_(2e-3)                                            # (a tensor learning rate: the captured optimizer reads it on the device)
+    first = None
+    for i in range(40):
+        run()
+        if i == 0:
+            torch.cuda.synchronize(); first = float(out["loss"])
+    torch.cuda.synchronize()
+    assert float(out["loss"]) < first - 0.05, (first, float(out["loss"]))
