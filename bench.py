@@ -556,6 +556,53 @@ def modules_ddp_eager(a, pairs, t1, t2, imgs, device, steps):
             dist.destroy_process_group()
 
 
+def modules_graphed(a, pairs, t1, t2, imgs, device, steps):
+    """The same loop body (pretrain.py:173-211: autocast, GradScaler, ONE torch AdamW over both mirrored models) captured as it stands
+    into one hipGraph by train.GraphedStep and replayed -- single process (DistributedDataParallel does not capture here; N > 1 is the
+    Pretrainer's business), torch's AdamW with fused=True, capturable=True so that GradScaler.step hands it found_inf on the device.  A side
+    line (never `value`): what the drop-in costs a maintainer who changes one constructor call."""
+    from vipformer_amd import ops
+    from vipformer_amd.train import GraphedStep, build_models
+    torch.manual_seed(1)
+    pc, im = build_models(**a, device=device)
+    pc.train(); im.train()
+    opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3, fused=True, capturable=True)
+    scaler = torch.amp.GradScaler("cuda")
+    scaler.scale(torch.zeros(1, device=device))                  # (the device-side scale exists before the capture)
+    b = t1.shape[0]
+    out = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            x = torch.permute(imgs, (0, 2, 3, 1))
+            pcs = torch.cat([t1, t2], dim=0)
+            feats = pc(pcs)[0]
+            f1, f2 = feats[:b, :], feats[b:, :]
+            loss_imid = ops.ntxent_loss(f1, f2, 0.1)
+            img_feats = im(x)[0]
+            loss_cmid = ops.ntxent_loss((f1 + f2) / 2, img_feats, 0.1)
+            total = loss_imid + 1.0 * loss_cmid
+        scaler.scale(total).backward()
+        scaler.step(opt)
+        scaler.update()
+        out["losses"] = torch.stack([loss_imid.detach(), loss_cmid.detach(), total.detach()])
+
+    run = GraphedStep(step, warmup=3)
+    for _ in range(4):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / steps
+    return dict(value=round(pairs / el, 2), ms_per_step=round(el * 1e3, 3), steps=steps, last_losses=[float(v) for v in out["losses"]],
+                grad_scale=float(scaler.get_scale()),
+                note="pretrain.py:173-211 on the mirrored modules through train.GraphedStep: autocast + torch GradScaler + torch AdamW(fused, "
+                     "capturable), one process, the loop body replayed as one hipGraph (losses read after the run, not per step)")
+
+
 # ----------------------------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -802,6 +849,10 @@ def main():
             variants["modules_ddp_eager"] = modules_ddp_eager(a, pairs, t1, t2, imgs, device, max(5, args.steps // 2))
         except Exception as e:                                       # noqa: BLE001 -- a side line must never cost the metric
             variants["modules_ddp_eager"] = dict(error=repr(e))
+        try:
+            variants["modules_graphed"] = modules_graphed(a, pairs, t1, t2, imgs, device, max(5, args.steps // 2))
+        except Exception as e:                                       # noqa: BLE001
+            variants["modules_graphed"] = dict(error=repr(e))
 
     legs, roof = {}, None
     prof = _step_profile(args.arch) if rank == 0 else {}

@@ -444,3 +444,39 @@ def test_reference_loop_with_torch_gradscaler_and_autocast_trains():
     assert all(torch.isfinite(p).all().item() for p in pc.parameters())
     assert any(not torch.equal(a_, b_) for a_, b_ in zip(p0, pc.parameters()))
     assert losses[-1] < losses[0] - 0.5, (losses[0], losses[-1], scales)
+
+
+def test_reference_loop_body_captured_by_graphed_step_trains():
+    """train.GraphedStep on the same loop body: torch's GradScaler + autocast + ONE torch AdamW (fused, capturable: GradScaler.step
+    then hands it found_inf on the device) captured into one hipGraph.  Replays train, the scale backs off inside the graph when the
+    fp16 gradients overflow, and every replay draws new dropout masks."""
+    from vipformer_amd.train import GraphedStep
+    pc, im, a = build("tiny", (0.1, 0.5))
+    pc.train(); im.train()
+    opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3, fused=True, capturable=True)
+    scaler = torch.amp.GradScaler("cuda")
+    scaler.scale(torch.zeros(1, device="cuda"))
+    t1, t2, imgs, start = _batch(a, 8)
+    p0 = [p.detach().clone() for p in pc.parameters()]
+    out = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = _loop_body(pc, im, t1, t2, imgs, start)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        out["loss"] = loss.detach()
+
+    run = GraphedStep(step, warmup=2)
+    losses, scales = [], []
+    for _ in range(30):
+        run()
+        torch.cuda.synchronize()
+        losses.append(float(out["loss"])); scales.append(scaler.get_scale())
+    assert all(l == l for l in losses), losses
+    assert scales[-1] <= 65536.0 and scales[-1] == scales[-3], scales
+    assert all(torch.isfinite(p).all().item() for p in pc.parameters())
+    assert any(not torch.equal(a_, b_) for a_, b_ in zip(p0, pc.parameters()))
+    assert losses[-1] < losses[0] - 0.5, (losses[0], losses[-1], scales)
