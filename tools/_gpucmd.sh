@@ -1,1 +1,4 @@
-timeout 900 python -m pytest tests/test_boundary_gpu.py -q -p no:cacheprovider -x -k "graphed or gradscaler" > gpurun_out/t_gs.log 2>&1; grep -E '^(FAILED|ERROR)|passed|failed' gpurun_out/t_gs.log; grep -E "^E  " gpurun_out/t_gs.log | head -12
+timeout 3000 python -m pytest tests -q -p no:cacheprovider -m gpu -x > gpurun_out/t_gpu.log 2>&1; grep -E '^(FAILED|ERROR)|passed|failed' gpurun_out/t_gpu.log; grep -E "^E  " gpurun_out/t_gpu.log | head -8
+cp gpurun_out/t_gpu.log gpurun_out/r04_gpu_tests.log
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python3 bench.py > gpurun_out/r04_bench_default.json 2> gpurun_out/bench_default.err; tail -1 gpurun_out/r04_bench_default.json | cut -c1-200
