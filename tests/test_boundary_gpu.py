@@ -448,16 +448,17 @@ def test_reference_loop_with_torch_gradscaler_and_autocast_trains():
 
 def test_reference_loop_body_captured_by_graphed_step_trains():
     """train.GraphedStep on the same loop body: torch's GradScaler + autocast + ONE torch AdamW (fused, capturable: GradScaler.step
-    then hands it found_inf on the device) captured into one hipGraph.  Replays train, the scale backs off inside the graph when the
-    fp16 gradients overflow, and every replay draws new dropout masks."""
+    then hands it found_inf on the device) captured into one hipGraph.  Dropout off, so the loss is a function of the weights alone:
+    replays train (the loss falls steadily), the scale backs off inside the graph if the fp16 gradients overflow, and the h16 operands
+    follow the optimizer -- torch's fused optimizers do not bump `p._version`, the kernels' weight copies are keyed on the count of
+    optimizer steps as well (ops._OPT_EPOCH)."""
     from vipformer_amd.train import GraphedStep
-    pc, im, a = build("tiny", (0.1, 0.5))
+    pc, im, a = build("tiny")
     pc.train(); im.train()
     opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3, fused=True, capturable=True)
     scaler = torch.amp.GradScaler("cuda")
     scaler.scale(torch.zeros(1, device="cuda"))
     t1, t2, imgs, start = _batch(a, 8)
-    p0 = [p.detach().clone() for p in pc.parameters()]
     out = {}
 
     def step():
@@ -478,5 +479,37 @@ def test_reference_loop_body_captured_by_graphed_step_trains():
     assert all(l == l for l in losses), losses
     assert scales[-1] <= 65536.0 and scales[-1] == scales[-3], scales
     assert all(torch.isfinite(p).all().item() for p in pc.parameters())
-    assert any(not torch.equal(a_, b_) for a_, b_ in zip(p0, pc.parameters()))
-    assert losses[-1] < losses[0] - 0.5, (losses[0], losses[-1], scales)
+    assert losses[-1] < losses[0] - 0.5 and losses[-1] < losses[10] < losses[0], (losses[0], losses[10], losses[-1], scales)
+    # the replayed steps computed with the weights they updated: an eval forward of the trained model equals a fresh model loaded with them
+    pc.eval()
+    sd = {k: v.clone() for k, v in pc.state_dict().items()}
+    pcf, _, _ = build("tiny")
+    pcf.load_state_dict(sd); pcf.eval()
+    with torch.no_grad(), forced_start(start):
+        x = pc(torch.cat([t1, t2]))[1]
+        y = pcf(torch.cat([t1, t2]))[1]
+    assert torch.equal(x, y)
+
+
+def test_fused_torch_optimizer_reaches_the_mfma_operands():
+    """torch.optim.AdamW(fused=True) updates the parameters without bumping `p._version`; the h16 weight copies must follow it all the
+    same (eager loop, no scaler): the loss falls on a fixed batch without dropout, and the trained model equals a fresh one loaded
+    with its weights."""
+    pc, im, a = build("tiny")
+    pc.train(); im.train()
+    opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3, fused=True)
+    t1, t2, imgs, start = _batch(a, 8)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad(set_to_none=True)
+        loss = _loop_body(pc, im, t1, t2, imgs, start)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0] - 0.3 and losses[-1] < losses[5] < losses[0], losses
+    pc.eval()
+    sd = {k: v.clone() for k, v in pc.state_dict().items()}
+    pcf, _, _ = build("tiny")
+    pcf.load_state_dict(sd); pcf.eval()
+    with torch.no_grad(), forced_start(start):
+        assert torch.equal(pc(torch.cat([t1, t2]))[1], pcf(torch.cat([t1, t2]))[1])

@@ -334,3 +334,13 @@ def test_graphed_step_replays_the_finetune_loop_with_fresh_masks():
             torch.cuda.synchronize(); first = float(out["loss"])
     torch.cuda.synchronize()
     assert float(out["loss"]) < first - 0.05, (first, float(out["loss"]))
+    # the replays computed with the weights they updated (the optimizer is a torch one: ops._OPT_EPOCH keys the h16 copies)
+    m.eval()
+    mf = _build(name, drops=(0.1, 0.5)).cuda()
+    mf.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}); mf.eval()
+    start = Hh.synth_start(11, B, N).cuda()
+    with torch.no_grad(), forced_start(start):
+        y1 = m(pts, onehot)
+    with torch.no_grad(), forced_start(start):
+        y2 = mf(pts, onehot)
+    assert torch.equal(y1, y2)

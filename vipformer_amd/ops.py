@@ -194,12 +194,12 @@ class ManagedFlat:
 
     def adopt(self, param: torch.nn.Parameter, offset: int) -> None:
         param._vpf_managed = (weakref.ref(self), offset)
-        param._vpf_ver = param._version
+        param._vpf_ver = (param._version, _OPT_EPOCH[0])
 
     def recast(self, param: torch.nn.Parameter, offset: int) -> None:
         n = param.numel()
         L.call("vpf_cast_f32_h16", self.p[offset:offset + n], self.s[offset:offset + n], n)
-        param._vpf_ver = param._version
+        param._vpf_ver = (param._version, _OPT_EPOCH[0])
 
 
 def _managed(p):
@@ -436,6 +436,20 @@ def grad_buf(p: torch.nn.Parameter) -> torch.Tensor:
     return p.grad
 
 
+_OPT_EPOCH = [0]
+
+
+def _optimizer_stepped(optimizer, args, kwargs) -> None:
+    _OPT_EPOCH[0] += 1
+
+
+try:                                                        # (torch >= 2.1: a process-wide hook behind every Optimizer.step)
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(_optimizer_stepped)
+except Exception:                                           # noqa: BLE001 -- without the hook the `_version` key is all there is
+    pass
+
+
 def shadow(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
     """h16 copy of the (adjacent) parameters as one flat tensor.  Trainer-owned parameters: a slice of the trainer's shadow
     (rewritten by its fused AdamW), re-cast here if somebody else wrote the parameter since (load_state_dict, an external
@@ -452,13 +466,15 @@ def shadow(params: Sequence[torch.nn.Parameter]) -> torch.Tensor:
             if o2 is not owner or f2 != end:
                 ok = False
                 break
-            if p._version != p._vpf_ver:
+            if (p._version, _OPT_EPOCH[0]) != p._vpf_ver:        # (a torch optimizer stepped, or somebody wrote the parameter in place)
                 owner.recast(p, f2)
             end = f2 + p.numel()
         if ok:
             return owner.s[off:off + n]
-    # cached on the first parameter OBJECT (dies with it; a (pointer, size) key could alias a freed model)
-    ver = tuple((p._version, p.data_ptr()) for p in params)
+    # cached on the first parameter OBJECT (dies with it; a (pointer, size) key could alias a freed model).  The key also carries the
+    # count of optimizer steps taken in this process (_OPT_EPOCH): torch's FUSED optimizers update the parameters without bumping
+    # `_version`, and a model trained with one would otherwise compute with the h16 copy of its initial weights for ever.
+    ver = (_OPT_EPOCH[0],) + tuple((p._version, p.data_ptr()) for p in params)
     hit = getattr(p0, "_vpf_shadow", None)
     if hit is not None and hit[0] == ver and hit[1].numel() == n:
         return hit[1]

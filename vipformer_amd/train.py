@@ -73,7 +73,7 @@ class FlatParams:
         (load_state_dict, an external optimizer); raw writes through ``p.data`` / ``flat.p`` do not bump it: call this then."""
         L.call("vpf_cast_f32_h16", self.p, self.s, self.numel)
         for p in self.params:
-            p._vpf_ver = p._version
+            p._vpf_ver = (p._version, ops._OPT_EPOCH[0])
 
     def attach_grads(self) -> None:
         """(Re-)install the flat views as ``p.grad`` wherever they are missing: after optimizer.zero_grad(set_to_none=True)
