@@ -396,3 +396,17 @@ def test_checkpoint_files_interchange_with_the_reference(tmp_path):
     res = probe.load_pretrained(Wrapper(ft), ref_file)
     assert res.unexpected_keys == [] and all(k.startswith("module.finetune_head.") for k in res.missing_keys)
     assert torch.equal(ft.state_dict()["encoder.sa_layers.1.1.module.3.weight"], ref_sd["encoder.sa_layers.1.1.module.3.weight"])
+
+
+def test_optimizer_step_hook_counts_every_torch_optimizer_step():
+    """ops.shadow keys the h16 weight copies on (p._version, data_ptr) AND on a process-wide count of Optimizer.step calls: torch's fused
+    optimizers do not bump `_version` (GPU side: test_fused_torch_optimizer_reaches_the_mfma_operands).  The hook must be installed by
+    importing the package and fire for any optimizer class."""
+    import torch
+    from vipformer_amd import ops
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    for opt in (torch.optim.SGD([p], lr=0.1), torch.optim.AdamW([p], lr=0.1), torch.optim.Adam([p], lr=0.1, foreach=True)):
+        e = ops._OPT_EPOCH[0]
+        opt.step()
+        assert ops._OPT_EPOCH[0] == e + 1, type(opt).__name__
