@@ -276,6 +276,40 @@ def _step_profile(arch):
     return prof
 
 
+# SURVEY 8c's tolerance contract as the -m gpu tests assert it (fp16 operand column; tests/test_modules_gpu.py FLOORS, tests/test_fullsize_gpu.py)
+TOLERANCES = {
+    "index_work": "bit-exact (FPS indices, kNN sets, neighbours, 3-NN indices and weight bits)",
+    "fwd_rel_l2": 2e-3, "fwd_rel_l2_behind_batchnorm_head": 1e-2, "loss_abs": 5e-3,
+    "grad_cos_all": {"linear_loss": 0.998, "ntxent_loss": 0.996}, "grad_cos_worst_tensor": {"linear_loss": 0.99, "ntxent_loss": 0.98},
+    "note": "against the fp32 oracle at the per-GPU batch; SURVEY 8c asked for grad cosine >= 0.999: not reachable with fp16 operand storage "
+            "(fp16 weights alone cost 0.99922, profiles/r04_rounding_budget_fp16_c1_16.txt) -- the floors above are what the tests assert",
+}
+
+
+def _tolerances():
+    """The contract + the worst values the last committed GPU parity report measured (tools/parity_summary.py -> profiles/rNN_parity_measured.json)."""
+    out = dict(TOLERANCES)
+    try:
+        names = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_parity_measured.json"))
+        with open(os.path.join(ROOT, "profiles", names[-1])) as f:
+            m = json.load(f)
+        c = m["classes"]
+        g = lambda k: (round(c[k]["worst"], 6) if k in c else None)
+        gc = lambda k: (round(1.0 - c[k]["worst"], 5) if k in c else None)
+        out["measured"] = {
+            "source": "profiles/" + names[-1],
+            "fwd_rel_l2_eval": g("fwd_rel_eval_full_batch"), "fwd_rel_l2_train_backbone": g("fwd_rel_train_backbone_full_batch"),
+            "fwd_rel_l2_behind_batchnorm_head": g("fwd_rel_train_feats_behind_batchnorm_full_batch"), "loss_abs": g("loss_abs_full_batch"),
+            "grad_cos_all": {"linear_loss": gc("grad_deficit_all_linear_full_batch"), "ntxent_loss": gc("grad_deficit_all_ntxent_full_batch")},
+            "grad_cos_worst_tensor": {"linear_loss": gc("grad_deficit_worst_tensor_linear_full_batch"),
+                                      "ntxent_loss": gc("grad_deficit_worst_tensor_ntxent_full_batch")},
+            "failing_checks": m.get("failing_checks"),
+        }
+    except (OSError, ValueError, KeyError, IndexError):
+        out["measured"] = None
+    return out
+
+
 def _pmc():
     try:
         with open(PROFILE_PMC) as f:
@@ -364,10 +398,14 @@ def physical_cores():
         return os.cpu_count()
 
 
-def cpu_baseline(a, pairs=8, timed_steps=3):
+def cpu_baseline(a, pairs=8, timed_steps=10, warm_steps=2, timed_steps_all=3):
     """The oracle (fp32 torch-CPU restatement of the reference step, pinned against the reference by the golden fixtures) on this
-    box's host cores: forward + backward + AdamW on config 1 (8 c1-shaped pairs), all physical cores and 8 threads; beside it the
-    DataLoader-worker leg (datasets/data.py:97-112: two trans_1 views + one image transform per pair, single thread x cores)."""
+    box's host cores: forward + backward + AdamW on config 1 (8 c1-shaped pairs).  The reported value is the MEDIAN of `timed_steps`
+    steps behind `warm_steps` warm-up steps at 8 threads (BASELINE.md section 3 plans 5 + 20; 2 + 10 keeps the default bench run inside
+    its few minutes at ~0.8 s per step) -- the thread count the survey measured the reference at and, on every box seen, the faster
+    one; the all-physical-cores run (1 + `timed_steps_all`, median) is reported beside it and becomes the value only if it is faster.
+    Beside both: the DataLoader-worker leg (datasets/data.py:97-112: two trans_1 views + one image transform per pair, single thread
+    x cores)."""
     from oracle import augment as A
     from oracle import torch_oracle as O
     from tests import helpers as Hh
@@ -378,7 +416,7 @@ def cpu_baseline(a, pairs=8, timed_steps=3):
     t1, t2, imgs = synth_batch(pairs, a["N"], a["img"], 0, "cpu")
     imgs = imgs.permute(0, 2, 3, 1)
 
-    def run(threads, steps):
+    def run(threads, steps, warm):
         torch.set_num_threads(threads)
         pcp = {k: v.clone().requires_grad_() for k, v in pc_sd.items() if isparam(k, v)}
         imp = {k: v.clone().requires_grad_() for k, v in im_sd.items() if isparam(k, v)}
@@ -390,7 +428,7 @@ def cpu_baseline(a, pairs=8, timed_steps=3):
                     s[k] = s[k.replace("cross_attn_1.", "cross_attn_n.")]
         params = {**{"pc." + k: v for k, v in pcp.items()}, **{"img." + k: v for k, v in imp.items()}}
         state, times = {}, []
-        for it in range(1 + steps):
+        for it in range(warm + steps):
             t0 = time.perf_counter()
             for v in params.values():
                 v.grad = None
@@ -399,23 +437,28 @@ def cpu_baseline(a, pairs=8, timed_steps=3):
             loss.backward()
             with torch.no_grad():
                 O.adamw_step({k: v for k, v in params.items()}, {k: v.grad for k, v in params.items()}, state, it + 1)
-            if it > 0:
+            if it >= warm:
                 times.append(time.perf_counter() - t0)
-        return sum(times) / len(times)
+        times.sort()
+        n = len(times)
+        return times[n // 2] if n % 2 else 0.5 * (times[n // 2 - 1] + times[n // 2])
 
     default_threads = torch.get_num_threads()
     cores = physical_cores()
-    sec_all = run(cores, timed_steps)
-    sec8 = run(min(8, cores), timed_steps)
+    sec_all = run(cores, timed_steps_all, 1) if cores > 8 else None
+    sec8 = run(min(8, cores), timed_steps, warm_steps)
+    if sec_all is None:
+        sec_all = sec8
     torch.set_num_threads(1)
     t_view, t_img = A.time_sample(a["N"], a["img"], a["img"], repeats=30)
     torch.set_num_threads(default_threads)
     aug_pair = 2 * t_view + t_img
     # the CPU path's best foot forward: 8 pairs are too little work for 128 threads (torch's intra-op parallelism loses to its own
     # synchronisation), so `value` is the faster of the two thread counts and `cores` says which one it was
-    sec, used = (sec_all, cores) if sec_all <= sec8 else (sec8, min(8, cores))
+    sec, used = (sec_all, cores) if sec_all < sec8 else (sec8, min(8, cores))
+    n_t, n_w = (timed_steps_all, 1) if used != min(8, cores) else (timed_steps, warm_steps)
     return dict(value=round(pairs / sec, 3), unit="pairs/s", cores=used, kind="port",
-                sample=f"{timed_steps} timed steps (after 1 warm-up) of {pairs} pairs = BASELINE configs[0] (E1CL6SL-H4D256-L96-MR2, 1024 pts + "
+                sample=f"median of {n_t} timed steps (after {n_w} warm-up) of {pairs} pairs = BASELINE configs[0] (E1CL6SL-H4D256-L96-MR2, 1024 pts + "
                        f"224x224 img), fp32 torch-CPU oracle incl. FPS/kNN (C), fwd+bwd+AdamW; {sec:.2f} s/step on {used} threads",
                 pairs_per_s_all_physical_cores=round(pairs / sec_all, 3), physical_cores=cores, pairs_per_s_8_threads=round(pairs / sec8, 3),
                 augmentation=dict(ms_per_view_trans_1=round(t_view * 1e3, 3), ms_per_image_transform=round(t_img * 1e3, 3),
@@ -754,6 +797,7 @@ def main():
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_med))
         median_ms = dict(median=round(per[n_med // 2], 4), p10=round(per[n_med // 10], 4), p90=round(per[(9 * n_med) // 10], 4), steps=n_med)
     comm_ms = None
+    comm_estimate = None
     if tr.dp:
         # the same steps again with device events around every region's exchange on the communication stream (never inside `value`)
         tr.exchange.timing = True
@@ -761,6 +805,20 @@ def main():
         for _ in range(cs):
             run()
         comm_ms = round(tr.exchange.comm_ms() / cs, 4)
+        # what the exchange moves, so that the first real N > 1 run can be judged at once: per region S bytes of
+        # fp32 gradient; a ring all-reduce puts 2 (n - 1) / n x S on every rank's busiest link, which at xGMI's ~153 GB/s per link
+        # (MI355X_MICROARCH.md / SURVEY section 5) is the floor printed beside the measured time
+        link_gbs = 153.0
+        comm_estimate = {"regions": [], "link_GBps_assumed": link_gbs}
+        tot = 0.0
+        for name, lo, hi in tr.regions:
+            S = (hi - lo) * 4
+            wire = 2.0 * (world - 1) / max(world, 1) * S
+            comm_estimate["regions"].append({"name": name, "bytes": S, "ring_bytes_per_link": int(wire),
+                                             "ring_floor_ms": round(wire / (link_gbs * 1e9) * 1e3, 4)})
+            tot += wire
+        comm_estimate["ring_bytes_per_link_total"] = int(tot)
+        comm_estimate["ring_floor_ms_total"] = round(tot / (link_gbs * 1e9) * 1e3, 4)
         tr.exchange.timing = False
     losses = [float(x) for x in tr.losses]
     finite = all(map(lambda v: v == v and abs(v) != float("inf"), losses))
@@ -901,7 +959,7 @@ def main():
                                    "dropout 0.1/0.5" % (NAMES[args.arch], pairs, a["N"], a["img"], a["img"], a["patch"]),
                        "global_batch": pairs * world, "parallelism": f"dp{world}" + (" (data-parallel code path forced in a one-rank group)" if force_dp else ""), "hip_graph": use_graph, "capture": capture_mode, "two_stream_overlap": tr.overlap,
                        **({"ablation": f"dropout probabilities overridden to {drops} (VPF_BENCH_DROPS): NOT the metric's workload"} if drops else {}),
-                       "ranks_seen": ranks_seen, "comm_ms": comm_ms, "comm_regions": ([n for n, _, _ in tr.regions] if tr.dp else None),
+                       "ranks_seen": ranks_seen, "comm_ms": comm_ms, "comm_regions": ([n for n, _, _ in tr.regions] if tr.dp else None), "comm_estimate": comm_estimate,
                        "last_losses": losses, "losses_finite": finite,
                        "median_ms_200": median_ms,
                        "loss_scale": tr.loss_scale, "overflow_skipped_steps": tr.skipped_steps,      # GradScaler state after the run (device-resident)
@@ -910,6 +968,7 @@ def main():
                        "kernels_per_step": (prof.get("kernels_per_step") if use_graph else None),       # launches per replayed step (committed whole-step budget)
                        "step_hbm_bytes": prof.get("hbm_bytes_per_step"),                                # FETCH_SIZE x 2 + WRITE_SIZE summed over a step's kernels
                        "step_hbm_frac": (round(prof["hbm_bytes_per_step"] / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4) if prof.get("hbm_bytes_per_step") else None),
+                       "tolerances": _tolerances(),
                        "version": __version__},
             "roofline": roof, "kernels": legs, "variants": variants, "cpu_baseline": cpu,
         }

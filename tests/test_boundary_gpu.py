@@ -489,6 +489,54 @@ def test_reference_loop_body_captured_by_graphed_step_trains():
         x = pc(torch.cat([t1, t2]))[1]
         y = pcf(torch.cat([t1, t2]))[1]
     assert torch.equal(x, y)
+    # ... and again after MORE replays (train by replay, evaluate, train, evaluate -- ADVICE r04): the replay steps the optimizer on the
+    # device, Python's optimizer hooks do not run, and the second evaluation used to hit the h16 copies the first one had cached
+    pc.train()
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    pc.eval()
+    pcf.load_state_dict({k: v.clone() for k, v in pc.state_dict().items()})
+    with torch.no_grad(), forced_start(start):
+        x2 = pc(torch.cat([t1, t2]))[1]
+        y2 = pcf(torch.cat([t1, t2]))[1]
+    assert torch.equal(x2, y2) and not torch.equal(x2, x)
+
+
+def test_graphed_step_without_warmup_on_a_model_that_has_run_captures_the_weight_casts():
+    """warmup = 0 on a model whose h16 weight copies are already cached (it ran an eager forward): the capture must still contain
+    the casts, or every replay would compute with the capture-time weights.  Dropout off: the loss of a fixed batch
+    falls replay after replay only if the replays see their own updates."""
+    from vipformer_amd.train import GraphedStep
+    pc, im, a = build("tiny")
+    pc.train(); im.train()
+    opt = torch.optim.AdamW(list(pc.parameters()) + list(im.parameters()), lr=1e-3, fused=True, capturable=True)
+    t1, t2, imgs, start = _batch(a, 8)
+    out = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = _loop_body(pc, im, t1, t2, imgs, start)
+        (loss * 256.0).backward()
+        for p in opt.param_groups[0]["params"]:
+            if p.grad is not None:
+                p.grad.mul_(1.0 / 256.0)
+        opt.step()
+        out["loss"] = loss.detach()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()                                                  # an eager step: the optimizer's state exists, the h16 caches are filled
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    run = GraphedStep(step, warmup=0)
+    losses = []
+    for _ in range(12):
+        run()
+        torch.cuda.synchronize()
+        losses.append(float(out["loss"]))
+    assert losses[-1] < losses[0] - 0.3 and losses[-1] < losses[5] < losses[0], losses
 
 
 def test_fused_torch_optimizer_reaches_the_mfma_operands():

@@ -129,3 +129,69 @@ def test_full_batch_train_step_loss_and_gradients(name):
     budget_check(ck, where, "linear loss", pc, im, lambda p: lin_grads.get(id(p)), lin_emu, lin_f32, 2e-4, 2e-3)
     budget_check(ck, where, "NT-Xent loss", pc, im, lambda p: p.grad, ntx_emu, ntx_f32, 1e-3, 5e-3)
     ck.done()
+
+
+def test_c2_train_step_at_the_benchmarked_batch_64_pairs():
+    """BASELINE configs[1] exactly as bench.py runs it: E1CL6SL-H4D256-L96-MR2 at 64 pairs per GPU, train mode,
+    dropout 0.1 / 0.5 with the kernels' own masks handed to the oracle -- BatchNorm of the projection head over 128 / 64 rows, 128 x 128
+    and 64 x 64 NT-Xent logits.  One fp32 oracle forward + ONE backward (the pre-training loss; the linear-loss and fp16-emulating passes
+    run at 32 pairs in test_full_batch_train_step_loss_and_gradients): loss abs <= 5e-3, backbone rel <= 2e-3, features <= 1e-2,
+    every parameter's gradient against the constant floors (all-parameter cosine >= 0.996, worst tensor >= 0.98)."""
+    from oracle import torch_oracle as O
+    from vipformer_amd import ops
+    from tests.test_modules_gpu import FLOORS, ZERO_GRAD, grads_of
+    name, B = "c1", 64
+    ops.rng.seed(8765)
+    with ops.rng.pinned():
+        pc, im, a = build(name, (0.1, 0.5))
+        ck = Checks(f"fullsize-train[{name}, {B} pairs]")
+        pts = Hh.synth_points(920, 2 * B, a["N"]); start = Hh.synth_start(920, 2 * B, a["N"])
+        imgs = Hh.synth_images(921, B, a["img"], a["img"])
+        pc.train(); im.train(); pc.zero_grad(); im.zero_grad()
+        with forced_start(start.cuda()):
+            f, bb = pc(pts.cuda())
+        fi, bbi = im(imgs.cuda())
+        f1, f2 = f[:B], f[B:]
+        loss = ops.ntxent_loss(f1, f2, 0.1) + ops.ntxent_loss((f1 + f2) / 2, fi, 0.1)
+        loss.backward()
+        arch = O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"],
+                      atten_drop=0.1, mlp_drop=0.5)
+        pm = O.Masks("given", _site_masks(pc, (2 * B, a["G"]), a["N"], a, "cuda"))
+        T = (a["img"] // a["patch"]) ** 2
+        imk = O.Masks("given", _site_masks(im, (B, T), T, a, "cuda"))
+    pc_sd, im_sd = _oracle_sd(name)
+    isparam = lambda k, v: v.dtype == torch.float32 and "running" not in k and "cross_attn_1." not in k
+    pcp = {k: v.clone().requires_grad_() for k, v in pc_sd.items() if isparam(k, v)}
+    imp = {k: v.clone().requires_grad_() for k, v in im_sd.items() if isparam(k, v)}
+    s1 = dict(pc_sd); s1.update(pcp); s2 = dict(im_sd); s2.update(imp)
+    for s in (s1, s2):
+        for k in list(s):
+            if "cross_attn_1." in k:
+                s[k] = s[k.replace("cross_attn_1.", "cross_attn_n.")]
+    fr, bbr = O.pc_forward(s1, pts, start, arch, True, pm, {})
+    fir, bbir = O.img_forward(s2, imgs, arch, True, imk, {})
+    lref = O.ntxent(fr[:B], fr[B:]) + O.ntxent((fr[:B] + fr[B:]) / 2, fir)
+    report(f"fullsize-train[{name}, {B} pairs] loss hip {loss.item():.5f} fp32 oracle {lref.item():.5f}")
+    ck.lt("pc backbone rel (fp32 oracle)", rel(bb, bbr), 2e-3)
+    ck.lt("img backbone rel (fp32 oracle)", rel(bbi, bbir), 2e-3)
+    ck.lt("pc feats rel (fp32 oracle)", rel(f, fr), 1e-2)
+    ck.lt("img feats rel (fp32 oracle)", rel(fi, fir), 1e-2)
+    ck.lt("loss abs diff vs fp32 oracle (SURVEY 8c: 5e-3)", abs(loss.item() - lref.item()), 5e-3)
+    lref.backward()
+    g32 = grads_of((pcp, imp))
+    rows = []
+    for model, gf in ((pc, g32[0]), (im, g32[1])):
+        for k, p in model.named_parameters():
+            if k.endswith(ZERO_GRAD) or k not in gf or p.grad is None:
+                continue
+            rows.append((k, p.grad.cpu(), gf[k]))
+    cat = lambda i: torch.cat([r[i].reshape(-1) for r in rows])
+    d_all = 1 - cosine(cat(1), cat(2))
+    per = sorted(((1 - cosine(r[1], r[2]), r[0]) for r in rows), reverse=True)
+    for x in per[:3]:
+        report(f"fullsize-train[{name}, {B} pairs] [NT-Xent loss] largest deficit vs fp32: hip {x[0]:.5f} {x[1]}")
+    report(f"fullsize-train[{name}, {B} pairs] [NT-Xent loss] all-parameter deficit (1 - cos): hip/fp32 {d_all:.5f}")
+    f_all, f_min = FLOORS["NT-Xent loss"]
+    ck.lt("[NT-Xent loss] all-parameter gradient deficit (1 - cos) vs fp32", d_all, f_all)
+    ck.lt("[NT-Xent loss] worst per-tensor gradient deficit vs fp32", per[0][0], f_min)
+    ck.done()

@@ -679,17 +679,24 @@ def test_sa_rows_fwd_equals_the_one_per_cu_kernel_bitwise(B, Lq, with_next, with
     from vipformer_amd import _lib
     run = _tail_case(B, Lq, with_next, with_pos, 40)
     outs = []
-    for wg2 in (0, 3, 3):
-        _lib.debug_set("sa_wg2", wg2)
+    # (sa_wg2, sa_rb, sa_stagger): the one-per-CU kernel; the round-3 geometry twice; round 5: 16 waves in lockstep, the same 16 waves
+    # as two DECOUPLED 8-wave groups (LDS-counter barriers per group), and those with the second group started 20 x 64 cycles late
+    # 4th field: the cache policy of the row stores (0 plain, 1 sc1 write-through, 2 nt, 3 sc0 sc1) -- the bytes are the same
+    variants = [(0, 0, 0, 0), (3, 0, 0, 0), (3, 0, 0, 0), (1, 12, 0, 0), (1, 13, 0, 0), (1, 13, 20, 0), (1, 13, 20, 1), (1, 13, 0, 2), (1, 13, 0, 3)]
+    for wg2, rb, stg, pol in variants:
+        _lib.debug_set("sa_wg2", wg2); _lib.debug_set("sa_rb", rb); _lib.debug_set("sa_stagger", stg); _lib.debug_set("sa_store", pol)
         try:
             outs.append(run())
         finally:
-            _lib.debug_set("sa_wg2", 0)
+            _lib.debug_set("sa_wg2", 0); _lib.debug_set("sa_rb", 0); _lib.debug_set("sa_stagger", 0); _lib.debug_set("sa_store", 0)
     names = ["x1", "mean2", "rstd2", "n2", "u", "h", "out", "mean1n", "rstd1n", "n1n", "qkv_next"]
     assert len(outs[0]) == len(outs[1])
     for n, p, q, r in zip(names, outs[0], outs[1], outs[2]):
         assert torch.equal(q, r), ("not reproducible", n)
         assert torch.equal(p, q), (n, (p.float() - q.float()).abs().max().item(), (p != q).float().mean().item())
+    for v, o in zip(variants[3:], outs[3:]):
+        for n, p, q in zip(names, outs[0], o):
+            assert torch.equal(p, q), (v, n, (p.float() - q.float()).abs().max().item(), (p != q).float().mean().item())
 
 
 @pytest.mark.parametrize("M,with_dsum,dsum_init", [(12288, True, 1), (150, True, 0), (392, False, 0)])

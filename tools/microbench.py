@@ -134,7 +134,14 @@ def satail():
     c = dbg.tolist()
     print("   phase cycles (wg 0): " + "  ".join(f"{n} {int(v)}" for n, v in zip(names, c)) + f"  total {sum(c[:15])}")
     rec = dbg[32:].view(-1, 4).cpu()
-    rec = rec[rec[:, 1] > 0]
+    last = rec[1024:]
+    rec = rec[:1024]
+    keep = rec[:, 1] > 0
+    if bool((last[:, 1] > 0).any()):
+        lag = (last[:len(rec)][keep][:, 1] - rec[keep][:, 1]).double() / 100.0
+        span = (int(last[:, 1].max()) - int(rec[keep][:, 0].min())) / 100.0
+        print(f"   last group's end minus first group's end: median {lag.median():.1f} us, max {lag.max():.1f} us; first start -> last group's last end {span:.1f} us")
+    rec = rec[keep]
     if len(rec):
         import collections
         t0 = int(rec[:, 0].min())
@@ -152,6 +159,29 @@ def satail():
         alone = [i for i, r in enumerate(rec) if per_cu[(int(r[2]), int(r[3]) & 0xff00)] == 1]
         if shared and alone:
             print(f"   alone on a CU: median {dur[alone].median():.1f} us ({len(alone)}); sharing a CU: median {dur[shared].median():.1f} us ({len(shared)})")
+
+
+def satail3():
+    """the forward tail at 96 / 192 / 256 row blocks of 64 tokens (half a chip, the step's grid, one per CU): is a launch's time set by
+    what ONE CU can do (flat in the grid size) or by chip-level traffic (proportional)?   SATAIL_B=48,96,128 overrides the batch list"""
+    import torch.nn as nn
+    from vipformer_amd import ops
+    from vipformer_amd.model.pointcloud.partseg import SelfAttentionLayer
+    G, D, H = 96, 256, 4
+    for B in [int(v) for v in os.environ.get("SATAIL_B", "64,128,170").split(",")]:
+        M = B * G
+        layers = nn.ModuleList([SelfAttentionLayer(H, D, 2, 0.0, 0.1, 0.5) for _ in range(2)]).cuda()
+        layers.train()
+        blocks = [(l[0].module.attention, l[1].module, True, True) for l in layers]
+        packed = ops._pack_blocks(blocks, layers[0], "cuda")
+        st = ops.rng.state("cuda")
+        base = torch.randn(M, D, device="cuda"); pos = torch.randn(M, D, device="cuda")
+        o = torch.randn(M, D, device="cuda").to(H16)
+        lse = torch.zeros(B * H * G, device="cuda")
+        att, mlp = layers[0][0].module.attention, layers[0][1].module
+        nxt = (layers[1][0].module.norm, packed[1]["Wqkv"])
+        t = timeit(lambda: ops._tail_fwd(att, mlp, layers[0][0], layers[0][1], packed[0], True, st, B, G, o, base, o, lse, nxt, pos, M, "cuda"), 30, 5)
+        print(f"sa_layer_fwd tail, {M} tokens = {M // 64} row blocks: {t:.1f} us")
 
 
 def satail2():
@@ -222,7 +252,12 @@ def satail2():
         return us
 
     for name, wg2, rb in (("round-2 kernels (1 WG/CU)", 0, 0), ("sa_rows <2,1> 64 tok, 76 KB", 1, 2), ("sa_rows <1,1> 32 tok cut to 2/CU", 1, 0),
-                          ("sa_rows <1,1> 32 tok whole", 1, 1), ("sa_rows <1,2> 64 tok 16 waves", 1, 12)):
+                          ("sa_rows <1,1> 32 tok whole", 1, 1), ("sa_rows <1,2> 64 tok 16 waves", 1, 12),
+                          ("sa_rows <1,2> DECOUPLED groups", 1, 13), ("sa_rows <1,2> DECOUPLED, stagger 20", 1, 13 + 20 * 256),
+                          ("sa_rows <1,2> DECOUPLED, stagger 60", 1, 13 + 60 * 256)):
+        L.debug_set("sa_stagger", rb >> 8); rb &= 255
+        if os.environ.get("SATAIL2_ONLY") and str(rb) not in os.environ["SATAIL2_ONLY"].split(","):
+            continue
         L.debug_set("sa_wg2", wg2); L.debug_set("sa_rb", rb)
         print(name)
         a = timed([0], "pc alone (6 launches)")

@@ -73,6 +73,8 @@ static const VpfDebugKey kDebugKeys[] = {
     {"sa_bwd_fuse", "VPF_SA_BWD_FUSE", &VpfDebug::sa_bwd_fuse, 1},
     {"wgroup_xlist", "VPF_WGROUP_XLIST", &VpfDebug::wgroup_xlist, 1},
     {"sa_rb", "VPF_SA_RB", &VpfDebug::sa_rb, 0},
+    {"sa_stagger", "VPF_SA_STAGGER", &VpfDebug::sa_stagger, 0},
+    {"sa_store", "VPF_SA_STORE", &VpfDebug::sa_store, 0},
 };
 VpfDebug& vpf_debug()
 {

@@ -55,6 +55,62 @@ __device__ __forceinline__ void who(int tid_, int& cw, int& tb0)
     tb0 = (wv / (D / 32)) * RB;
 }
 
+// ------------------------------------------------------------------ 16-byte row stores with a cache policy (round 5)
+// ST = 0 plain; 1 `sc1` (write-through: the line does not stay dirty in the XCD's L2, so the end-of-kernel write-back of the
+// launch's last ~30 MB of outputs is spread over the kernel instead -- MI355X_MICROARCH.md, "stores of each flavour"); 2 `nt`;
+// 3 `sc0 sc1`.  The inline-asm stores are invisible to the compiler's vmcnt bookkeeping, which is safe: vmcnt retires in order, so
+// extra operations in the queue only make a counted wait cover more than the compiler asked for.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+template <int ST, class V>
+__device__ __forceinline__ void st16(V* p, const V& v)
+{
+    static_assert(sizeof(V) == 16, "16-byte stores");
+    if constexpr (ST == 0) *p = v;
+    else {
+        const u32x4_t d = __builtin_bit_cast(u32x4_t, v);
+        if constexpr (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
+        else if constexpr (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(d) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+    }
+}
+
+// ------------------------------------------------------------------ wave groups (round 5)
+// The D / 32 waves that share the token blocks [tb0, tb0 + RB) are a GROUP; a workgroup has TH of them.  Nothing but the per-channel
+// parameter vectors is shared between groups: operand-tile rows, LayerNorm exchange entries and slices are per token / per wave.
+//   DEC = false  the groups run in lockstep: workgroup barriers, whole-tile cooperative row passes (rounds 3 - 4).
+//   DEC = true   every group is a pipeline of its own: its barriers are a counter in LDS that only ITS waves arrive at and poll
+//                (gfx950 has one hardware barrier per workgroup and no named barriers), its row passes cover its own rows.  The two
+//                groups of a 16-wave workgroup then drift apart like two workgroups sharing a CU -- one group's MFMA units run under
+//                the other's epilogues and stores -- at the co-residency a 192-workgroup grid never gets from the dispatcher.
+// The counter protocol: a wave drains its LDS operations (s_waitcnt lgkmcnt(0): its tile / exchange writes have landed), lane 0 adds 1,
+// every wave polls until the count reaches NWV x (barriers so far).  LDS operations of a CU execute in issue order, so a wave that
+// has seen the count sees the data written before the adds.  Outstanding global loads (the weight ring) stay in flight.
+template <class C, bool DEC>
+struct Grp {
+    static constexpr int NT = DEC ? 64 * C::NWV : C::NT;               // threads that share a row pass
+    static constexpr int TOK = DEC ? C::TOK / (C::NW / C::NWV) : C::TOK;   // rows of a row pass
+    unsigned* ctr;      // DEC: this group's arrival counter (LDS, zeroed before the workgroup's first barrier)
+    unsigned want;      // arrivals expected once the next barrier is complete
+    int th;             // group index (scalar)
+    __device__ __forceinline__ int tid() const { return DEC ? fresh_tid() - th * NT : fresh_tid(); }
+    __device__ __forceinline__ int row0() const { return DEC ? th * TOK : 0; }
+    __device__ __forceinline__ void sync()
+    {
+        if constexpr (!DEC) { __syncthreads(); }
+        else {
+            want += C::NWV;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if ((fresh_tid() & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (;;) {
+                const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if ((int)(v - want) >= 0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+};
+
 template <int PD> struct WRing { uint4 w[PD]; };
 
 template <int PD>
@@ -161,6 +217,7 @@ __device__ __forceinline__ void rows_to_slice(float* slice, const float4 (&r)[4]
     }
 }
 // slice rows -> HBM
+template <int ST = 0>
 __device__ __forceinline__ void slice_store_rows(const float* slice, float* __restrict__ ubase, const RowOff& ro)
 {
     const int lane = fresh_tid() & 63, tl = lane >> 3, ch = lane & 7;
@@ -168,7 +225,7 @@ __device__ __forceinline__ void slice_store_rows(const float* slice, float* __re
     for (int it = 0; it < 4; ++it) {
         const int tok = 8 * it + tl;
         const float4 v = *reinterpret_cast<const float4*>(slice + tok * 32 + ((ch ^ swz(tok)) << 2));
-        if ((ro.ok >> it) & 1u) *reinterpret_cast<float4*>(ubase + ro.o[it]) = v;
+        if ((ro.ok >> it) & 1u) st16<ST>(reinterpret_cast<float4*>(ubase + ro.o[it]), v);
     }
 }
 // accumulator side: lane (t = lane & 31, hl = lane >> 5) owns channels 8 g + 4 hl + q of token t = registers 4 g + q
@@ -209,7 +266,7 @@ __device__ __forceinline__ void acc_to_slice_h16(h16_t* slice, const f32x16_t (&
         }
 }
 // rows of the slice -> Gu[tok * ld + 8 chunk ..] (Gu = the matrix at the wave's first token and first column) for tok < nv
-template <int RB>
+template <int RB, int ST = 0>
 __device__ __forceinline__ void slice_h16_store_rows(const h16_t* slice, h16_t* __restrict__ Gu, int ld, int nv)
 {
     const int lane = fresh_tid() & 63, tl = lane >> 2, ch = lane & 3;
@@ -217,7 +274,7 @@ __device__ __forceinline__ void slice_h16_store_rows(const h16_t* slice, h16_t* 
     for (int it = 0; it < 2 * RB; ++it) {
         const int tok = 16 * it + tl;
         const uint4 v = *reinterpret_cast<const uint4*>(slice + tok * 32 + ((ch ^ swz2(tok)) << 3));
-        if (tok < nv) *reinterpret_cast<uint4*>(Gu + (unsigned)(tok * ld + ch * 8)) = v;
+        if (tok < nv) st16<ST>(reinterpret_cast<uint4*>(Gu + (unsigned)(tok * ld + ch * 8)), v);
     }
 }
 
@@ -273,6 +330,18 @@ __device__ __forceinline__ void tile_store_rows(const h16_t* sAct, h16_t* __rest
         if (row < nvalid) *reinterpret_cast<uint4*>(Gu + (unsigned)(row * ld + ch * 8)) = v;
     }
 }
+// the rows of one group (Grp: all rows when the groups run in lockstep)
+template <class C, int ST = 0, class G>
+__device__ __forceinline__ void tile_store_rows(const G& gr, const h16_t* sAct, h16_t* __restrict__ Gu, int ld, int nvalid)
+{
+    const int tid_ = gr.tid(), r0 = gr.row0();
+#pragma unroll
+    for (int it = 0; it < G::TOK * C::C8 / G::NT; ++it) {
+        const int e = tid_ + it * G::NT, row = r0 + e / C::C8, ch = e % C::C8;
+        const uint4 v = *reinterpret_cast<const uint4*>(sAct + row * C::ALD + ch * 8);
+        if (row < nvalid) st16<ST>(reinterpret_cast<uint4*>(Gu + (unsigned)(row * ld + ch * 8)), v);
+    }
+}
 template <class C>
 __device__ __forceinline__ void tile_load_rows(h16_t* sAct, const h16_t* __restrict__ Gu, int ld, int nvalid)
 {
@@ -311,6 +380,27 @@ __device__ __forceinline__ void gelu_rows_pass(h16_t* sAct, h16_t* __restrict__ 
         if (row < nvalid) *reinterpret_cast<uint4*>(h_u + go) = hv;
     }
 }
+template <class C, int ST = 0, class G>
+__device__ __forceinline__ void gelu_rows_pass(const G& gr, h16_t* sAct, h16_t* __restrict__ u_u, h16_t* __restrict__ h_u, int ldh, int nvalid)
+{
+    const int tid_ = gr.tid(), r0 = gr.row0();
+#pragma unroll
+    for (int it = 0; it < G::TOK * C::C8 / G::NT; ++it) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int e = tid_ + it * G::NT, row = r0 + e / C::C8, ch = e % C::C8;
+        const uint4 v = *reinterpret_cast<const uint4*>(sAct + row * C::ALD + ch * 8);
+        const unsigned go = row * ldh + ch * 8;
+        if (row < nvalid) st16<ST>(reinterpret_cast<uint4*>(u_u + go), v);
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+        uint32_t hh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            hh[q] = pack_h16x2(vpf_gelu(h16_lo(vv[q])), vpf_gelu(h16_hi(vv[q])));
+        const uint4 hv = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+        *reinterpret_cast<uint4*>(sAct + row * C::ALD + ch * 8) = hv;
+        if (row < nvalid) st16<ST>(reinterpret_cast<uint4*>(h_u + go), hv);
+    }
+}
 // per-channel vectors -> sPar in pieces of 128 floats (128 divides 256, 384, 512 and 1536: a piece never straddles two vectors), one
 // wave per piece with a wave-uniform source (scalar selects, no lane branches); half the lanes carry a float4 each
 template <int D, int HID, int NW>
@@ -332,9 +422,9 @@ __device__ __forceinline__ void stage_params(float* sPar, const float* bo, const
 // Every wave reduces ITS 32 channels of a token to (mean, centred second moment); the pairs of the D / 32 waves that share the token
 // are merged exactly (Chan et al.) through one LDS exchange and one barrier.  Identical arithmetic to sa_layernorm of sa_layer.hip.
 // The statistics go to HBM (gm, gr: the block's first token) from the wave that owns channel block 0.
-template <int D, int RB>
+template <int D, int RB, class SYNC>
 __device__ __forceinline__ void layernorm(f32x16_t (&v)[RB], const float* gamma, const float* beta, float2* sPair, float* __restrict__ gm,
-                                          float* __restrict__ gr, int nvalid)
+                                          float* __restrict__ gr, int nvalid, SYNC&& sync)
 {
     constexpr int NWV = D / 32;
     const int tid_ = fresh_tid();
@@ -355,7 +445,7 @@ __device__ __forceinline__ void layernorm(f32x16_t (&v)[RB], const float* gamma,
         q += __shfl_xor(q, 32, 64);
         if (lane < 32) sPair[((tb0 + i) * 32 + lane) * NWV + cw] = make_float2(mw, q);
     }
-    __syncthreads();
+    sync();
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         float2 pw[NWV];
@@ -381,6 +471,13 @@ __device__ __forceinline__ void layernorm(f32x16_t (&v)[RB], const float* gamma,
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[i][4 * g + q] = (v[i][4 * g + q] - mean[i]) * rstd[i] * gg[q] + bb[q];
     }
+}
+
+template <int D, int RB>
+__device__ __forceinline__ void layernorm(f32x16_t (&v)[RB], const float* gamma, const float* beta, float2* sPair, float* __restrict__ gm,
+                                          float* __restrict__ gr, int nvalid)
+{
+    layernorm<D, RB>(v, gamma, beta, sPair, gm, gr, nvalid, [] { __syncthreads(); });
 }
 
 // v += dropout(acc + bias) for the 32-token block tb: the Residual epilogue (partseg.py:201-213) on the accumulator tile; the mask is
@@ -409,10 +506,11 @@ __device__ __forceinline__ void residual_epilogue(f32x16_t& v, const f32x16_t& a
 }
 
 // ================================================================================================ forward
-template <int D, int HID, int RB, int TH, int MINW, bool FULL, bool DBG = false>
-__global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLayerFwd a, int tpw)
+template <int D, int HID, int RB, int TH, int MINW, bool FULL, bool DBG = false, bool DEC = false, int ST = 0>
+__global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLayerFwd a, int tpw, int stagger)
 {
     using C = Cfg<D, RB, TH>;
+    using G = Grp<C, DEC>;
     constexpr int NWV = C::NWV, TOK = C::TOK, ALD = C::ALD, KS = C::KS, HC = HID / D, PD = C::PD;
     extern __shared__ __attribute__((aligned(16))) h16_t lds[];
     h16_t* actA = lds;                                               // [TOK][ALD]  o -> n2 -> (slices) out, q|k|v staging
@@ -422,6 +520,10 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
     float* xded = sPar + 6 * D + HID;                                 // XDED: the slices' own region
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cw = wave % NWV, tb0 = (wave / NWV) * RB;               // this wave: channels [32 cw, +32) of token blocks tb0 .. tb0 + RB - 1
+    G grp;
+    grp.th = wave / NWV; grp.want = 0;
+    grp.ctr = reinterpret_cast<unsigned*>(xded + (C::XDED ? C::NW * 1024 : 0)) + grp.th;      // DEC: one arrival counter per group behind everything else
+    if (DEC && threadIdx.x < TH) reinterpret_cast<unsigned*>(xded + (C::XDED ? C::NW * 1024 : 0))[threadIdx.x] = 0u;
     // tpw = tokens per workgroup (<= TOK): a grid of ~2 workgroups per CU is cut to fit the machine (sa_rows_tokens_per_wg)
     const long m0 = FULL ? (long)blockIdx.x * TOK : (long)blockIdx.x * tpw;
     const int nvalid = FULL ? TOK : (int)min((long)tpw, (long)a.B * a.L - m0);     // FULL: every block is whole, the bounds checks fold away
@@ -444,6 +546,9 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
             long long* d = a.dbg + 32 + 4 * (long)blockIdx.x;
             d[0] = wg_t0; d[1] = (long long)__builtin_amdgcn_s_memrealtime(); d[2] = xcc & 0xf; d[3] = hw;
         }
+        // the LAST group's end (decoupled groups finish at different times): dbg[32 + 4 (1024 + b) + 1]
+        if (DBG && a.dbg && TH > 1 && (int)threadIdx.x == (TH - 1) * 64 * NWV && blockIdx.x < 1024)
+            a.dbg[32 + 4 * (1024 + (long)blockIdx.x) + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     };
     WRing<PD> ring;
     ring_fill<PD>((const h16_t*)a.Wo, KS, 0, cw, ring);
@@ -453,7 +558,10 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
     for (int i = 0; i < RB; ++i) rows_load(a.base + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid), rb[i]);
     stage_params<D, HID, C::NW>(sPar, a.bo, a.ln2_g, a.ln2_b, a.b2, a.ln1n_g, a.ln1n_b, a.b1);
     tile_load_rows<C>(actA, (const h16_t*)a.o + m0 * D, D, nvalid);
-    __syncthreads();                                                  // o in actA, parameters in sPar
+    __syncthreads();                                                  // o in actA, parameters in sPar (DEC: the workgroup's only common barrier)
+    if (DEC && stagger > 0 && grp.th > 0) {                           // DEC: the later groups start `stagger` x 64 cycles late
+        for (int i = 0; i < stagger * grp.th; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     R_STAMP();      // 0: loads (o, parameters) + barrier
     // ============================================================ x1 = base + dropout(o . Wo^T + bo);  n2 = LN2(x1)
     f32x16_t acc[RB];
@@ -476,16 +584,16 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         acc_to_slice(sliceH, xr[i]);
-        slice_store_rows(sliceH, a.x1 + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid));
+        slice_store_rows<ST>(sliceH, a.x1 + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid));
     }
     R_STAMP();      // 2: base rows in, residual epilogue, x1 rows out
 #pragma unroll
     for (int i = 0; i < RB; ++i) acc[i] = xr[i];
-    layernorm<D, RB>(acc, g2_p, be2_p, sPair, a.mean2 + m0, a.rstd2 + m0, nvalid);
+    layernorm<D, RB>(acc, g2_p, be2_p, sPair, a.mean2 + m0, a.rstd2 + m0, nvalid, [&] { grp.sync(); });
     acc_to_tile<D, RB>(acc, actA, ALD);                                // (the LayerNorm barrier: every wave is done reading o)
-    __syncthreads();                                                  // n2 complete in actA; every wave's x1 slices are drained
+    grp.sync();                                                       // n2 complete in actA; every wave's x1 slices are drained
     R_STAMP();      // 3: LayerNorm 2 + n2 tile + barrier
-    tile_store_rows<C>(actA, (h16_t*)a.n2 + m0 * D, D, nvalid);
+    tile_store_rows<C, ST>(grp, actA, (h16_t*)a.n2 + m0 * D, D, nvalid);
     R_STAMP();      // 4: n2 rows out
 
     // ============================================================ MLP: HC chunks of D hidden channels
@@ -498,12 +606,12 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
         gemm_unit<RB, KS, PD>((const h16_t*)a.W1, KS, 0, hc * NWV + cw, actA, ALD, tb0, acc, ring);
         ring_fill<PD>((const h16_t*)a.W2, HID / 16, hc * KS, cw, ring);   // this chunk's fc2 slice
         if (hc == 0) R_STAMP();      // 5: fc1 MFMA (chunk 0)
-        if (hc) __syncthreads();                                      // every wave is done reading the previous chunk from actH
+        if (hc) grp.sync();                                           // every wave is done reading the previous chunk from actH
         bias_to_tile<D, RB>(acc, b1_p + hc * D, actH, ALD);             // u = h16(acc + b1), accumulator layout
-        __syncthreads();
-        gelu_rows_pass<C>(actH, (h16_t*)a.u + m0 * HID + hc * D, (h16_t*)a.h + m0 * HID + hc * D, HID, nvalid);
+        grp.sync();
+        gelu_rows_pass<C, ST>(grp, actH, (h16_t*)a.u + m0 * HID + hc * D, (h16_t*)a.h + m0 * HID + hc * D, HID, nvalid);
         if (hc == 0) R_STAMP();      // 6: u tile + barrier + gelu row pass (chunk 0)
-        __syncthreads();
+        grp.sync();
         if (hc == 0) R_STAMP();          // 7: barrier
         if (hc + 1 == HC) {
             if constexpr (C::KEEPX) {
@@ -553,16 +661,16 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
             }
             residual_epilogue<D>(xr[i], acc2[i], tb0 + i, cw, b2_p, rng, drop, m0, nvalid);
             acc_to_slice(sliceA, xr[i]);
-            slice_store_rows(sliceA, a.out + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid));
+            slice_store_rows<ST>(sliceA, a.out + m0 * D, row_offsets<D>(tb0 + i, cw, nvalid));
         }
     }
     R_STAMP();      // final residual epilogue + out rows
     if (!nxt) { wg_record(); return; }
-    layernorm<D, RB>(xr, g1n_p, be1n_p, sPair, a.mean1n + m0, a.rstd1n + m0, nvalid);
+    layernorm<D, RB>(xr, g1n_p, be1n_p, sPair, a.mean1n + m0, a.rstd1n + m0, nvalid, [&] { grp.sync(); });
     acc_to_tile<D, RB>(xr, actH, ALD);                                 // (the LayerNorm barrier: every wave is done with the hidden chunk)
-    __syncthreads();                                                  // next n1 complete in actH
+    grp.sync();                                                       // next n1 complete in actH
     R_STAMP();      // next LayerNorm 1 + tile + barrier
-    tile_store_rows<C>(actH, (h16_t*)a.n1n + m0 * D, D, nvalid);
+    tile_store_rows<C, ST>(grp, actH, (h16_t*)a.n1n + m0 * D, D, nvalid);
     R_STAMP();      // n1 rows out
     // q | k | v of the next layer: each wave's [32 RB x 32] result leaves through its slice as 64-byte row pieces
     h16_t* qslice = reinterpret_cast<h16_t*>(sliceA);
@@ -572,7 +680,7 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
         gemm_unit<RB, KS, PD>((const h16_t*)a.Wqkv_next, KS, 0, part * NWV + cw, actH, ALD, tb0, acc, ring);
         if (part + 1 < 3) ring_fill<PD>((const h16_t*)a.Wqkv_next, KS, 0, (part + 1) * NWV + cw, ring);
         acc_to_slice_h16<RB>(qslice, acc);
-        slice_h16_store_rows<RB>(qslice, (h16_t*)a.qkv_next + (m0 + tb0 * 32) * (3 * D) + part * D + 32 * cw, 3 * D, nvalid - tb0 * 32);
+        slice_h16_store_rows<RB, ST>(qslice, (h16_t*)a.qkv_next + (m0 + tb0 * 32) * (3 * D) + part * D + 32 * cw, 3 * D, nvalid - tb0 * 32);
     }
     R_STAMP();      // q | k | v
     wg_record();
@@ -583,7 +691,7 @@ template <int D, int HID, int RB, int TH>
 size_t fwd_lds()
 {
     using C = Cfg<D, RB, TH>;
-    return (size_t)2 * C::TILE * 2 + (size_t)C::TOK * C::NWV * 8 + (size_t)(6 * D + HID) * 4 + (C::XDED ? (size_t)C::NW * 4096 : 0);
+    return (size_t)2 * C::TILE * 2 + (size_t)C::TOK * C::NWV * 8 + (size_t)(6 * D + HID) * 4 + (C::XDED ? (size_t)C::NW * 4096 : 0) + 16;   // + the groups' arrival counters
 }
 
 // Tokens per workgroup of the 8-wave / 32-token geometry: two such workgroups share a CU at 7 % cost each (measured: 26.3 us alone,
@@ -595,7 +703,7 @@ static int tokens_per_wg(long M, int cus = 256)
     return (t >= 20 && t <= 32) ? (int)t : 32;
 }
 
-template <int D, int HID, int RB, int TH, int MINW>
+template <int D, int HID, int RB, int TH, int MINW, bool DEC = false, int ST = 0>
 int fwd_launch(const VpfSaLayerFwd& a, hipStream_t st, bool cut = false)
 {
     using C = Cfg<D, RB, TH>;
@@ -603,17 +711,18 @@ int fwd_launch(const VpfSaLayerFwd& a, hipStream_t st, bool cut = false)
     const size_t lds = fwd_lds<D, HID, RB, TH>();
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
-        if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, true, false, DEC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, false, DEC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
     const int tpw = (cut && C::TOK == 32) ? tokens_per_wg(M) : C::TOK;
+    const int stagger = DEC ? vpf_debug().sa_stagger : 0;
     if (a.dbg) {                                                     // phase stamps of workgroup 0 (tools/microbench.py): a build of its own
-        if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
-        hipLaunchKernelGGL((sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, true>), dim3(vpf_cdiv(M, tpw)), dim3(C::NT), lds, st, a, tpw);
+        if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, true, DEC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
+        hipLaunchKernelGGL((sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, true, DEC, ST>), dim3(vpf_cdiv(M, tpw)), dim3(C::NT), lds, st, a, tpw, stagger);
     }
-    else if (tpw == C::TOK && M % C::TOK == 0) hipLaunchKernelGGL((sa_rows_fwd_kernel<D, HID, RB, TH, MINW, true>), dim3((unsigned)(M / C::TOK)), dim3(C::NT), lds, st, a, tpw);
-    else hipLaunchKernelGGL((sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false>), dim3(vpf_cdiv(M, tpw)), dim3(C::NT), lds, st, a, tpw);
+    else if (tpw == C::TOK && M % C::TOK == 0) hipLaunchKernelGGL((sa_rows_fwd_kernel<D, HID, RB, TH, MINW, true, false, DEC, ST>), dim3((unsigned)(M / C::TOK)), dim3(C::NT), lds, st, a, tpw, stagger);
+    else hipLaunchKernelGGL((sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, false, DEC, ST>), dim3(vpf_cdiv(M, tpw)), dim3(C::NT), lds, st, a, tpw, stagger);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
@@ -1077,6 +1186,13 @@ int sa_rows_fwd_launch(const VpfSaLayerFwd& a, hipStream_t st)
             case 2: return fwd_launch<256, 512, 2, 1, 4>(a, st);
             case 1: return fwd_launch<256, 512, 1, 1, 4>(a, st);
             case 12: return fwd_launch<256, 512, 1, 2, 4>(a, st);
+            case 13:                                                           // round 5: the same 16 waves as two decoupled 8-wave groups
+                switch (vpf_debug().sa_store) {                                // VPF_SA_STORE: cache policy of the row stores (st16)
+                    case 1: return fwd_launch<256, 512, 1, 2, 4, true, 1>(a, st);
+                    case 2: return fwd_launch<256, 512, 1, 2, 4, true, 2>(a, st);
+                    case 3: return fwd_launch<256, 512, 1, 2, 4, true, 3>(a, st);
+                    default: return fwd_launch<256, 512, 1, 2, 4, true, 0>(a, st);
+                }
             default: return fwd_launch<256, 512, 1, 1, 4>(a, st, true);
         }
     }

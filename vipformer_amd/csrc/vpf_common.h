@@ -48,6 +48,8 @@ struct VpfDebug {
     int attn_rng32;         // VPF_ATTN_RNG32        1: 32-bit dropout group indices in the attention kernels when the score tensor allows it (same masks)
     int sa_bwd_fuse;        // VPF_SA_BWD_FUSE       1: qkv backward of a layer + MLP backward of the layer below as one launch (vpf_sa_layer_bwd_qkv_mlp), 0: two
     int wgroup_xlist;       // VPF_WGROUP_XLIST      1: every (problem, K slice) of a grouped weight gradient on ONE XCD when the slices are few (0: plain order)
+    int sa_stagger;         // VPF_SA_STAGGER        decoupled wave groups (sa_rows.hip, Grp<.., DEC>): group g starts g x N x 64 cycles late (0: together)
+    int sa_store;           // VPF_SA_STORE          cache policy of the row-block kernels' 16-byte row stores: 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
     int sa_rb;              // VPF_SA_RB             geometry of those kernels at D = 256: 12 = 16 waves x 32 tokens each (default), 2 = 8 waves x 64, 1 = 8 waves x 32
 };
 VpfDebug& vpf_debug();

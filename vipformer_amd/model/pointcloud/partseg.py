@@ -420,7 +420,8 @@ class CrossFormer_pc_mp_ft(CrossFormer_pc_mp):
                                            nn.BatchNorm1d(D), nn.ReLU(), nn.Linear(D, D // 2),
                                            nn.BatchNorm1d(D // 2), nn.ReLU(), nn.Linear(D // 2, num_obj_classes))
 
-    # ft_cls.py's loop has no GradScaler: the backward pass of this model normalises the gradient that enters it (ops.internal_grad_scale)
+    # ft_cls.py:146,166,179-181 runs under autocast + GradScaler: the incoming gradient is already large there and the internal scale
+    # (ops.internal_grad_scale: never below 1) is the identity; it matters for callers that run this model WITHOUT a scaler (fp32 loops)
     internal_grad_scale = True
 
     def forward(self, pts):

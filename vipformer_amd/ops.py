@@ -295,8 +295,9 @@ def _sink_stack():
     return st
 
 
-# ---- internal gradient scale: fp16 gradient operands for loops that have no GradScaler (ft_cls.py, ft_partseg.py)
-# The pre-training loop scales its loss (pretrain.py:154,209); the reference's fine-tune loops run in fp32 and do not.  With fp16
+# ---- internal gradient scale: fp16 gradient operands for loops that have no GradScaler (ft_partseg.py:145-176)
+# The pre-training loop and ft_cls.py scale their loss (pretrain.py:154,209; ft_cls.py:146,166,179-181: autocast + GradScaler); the
+# part-segmentation fine-tune loop (ft_partseg.py) runs in fp32 without a scaler.  With fp16
 # gradient operands their backward pass loses what lies below 6e-5 (a CrossEntropyLoss averaged over 16 x 1024 points hands the head
 # gradients of 1e-6: measured, tools/diag_ft_scale.py: all-parameter cosine 0.964 against the same step with a scaled loss).  The
 # fine-tune MODELS therefore scale inside: their forward runs under ``internal_grad_scale()`` and returns its logits through
@@ -305,7 +306,15 @@ def _sink_stack():
 # runs in, whatever the loss's normalisation.  Every op between the Functions is linear in the gradient, so the whole backward pass of
 # the model works on S x the gradient, and every Function created under the context multiplies its PARAMETER gradients by 1 / S before
 # autograd sees them.  S is a power of two computed ON THE DEVICE (no host synchronisation, capturable): nothing is rounded by it.  It
-# never scales DOWN: under a GradScaler (incoming gradients already large) S = 1 and nothing changes.
+# never scales DOWN: under a GradScaler (incoming gradients already large: ft_cls.py) S = 1 and nothing changes.
+# What this path does NOT have is a GradScaler's overflow guard: S is chosen from the gradient that ENTERS the model, and a later
+# stage that amplifies it beyond fp16's range (BatchNorm backward multiplies by gamma * rstd, rstd up to 316 on a near-constant
+# channel) produces inf / NaN parameter gradients that nothing skips -- the reference's fp32 loop has no such cliff.  Callers that
+# want the guard run the loop under torch's GradScaler (then S = 1 and the scaler's skip logic applies), as ft_cls.py does.
+# Input gradients (pts.requires_grad) leave the model multiplied by S: ScaleGradFn sits at the OUTPUT, nothing at the input divides it
+# back out (no shipped loop differentiates with respect to the points).
+# Parameters owned by a trainer's flat buffer (ManagedFlat) receive their gradient directly from the kernels, not through the sink:
+# they would accumulate S x the gradient, so _sinked refuses that combination loudly.
 class _ScaleHolder:
     __slots__ = ("inv", "on")
 
@@ -371,6 +380,10 @@ def _sinked(backward):
         got = sk.collect()
         h = getattr(ctx, "_vpf_iscale", None)
         if h is not None and h.inv is not None:
+            if any(_managed(p)[0] is not None for p in ctx.params):
+                raise L.VpfError("internal_grad_scale: a parameter of this Function is owned by a trainer's flat gradient buffer, which "
+                                 "the kernels write directly -- the 1 / S correction cannot reach it.  Train fine-tune models with a torch "
+                                 "optimizer (or under a GradScaler with internal_grad_scale = False)")
             seen, ts = set(), []
             for t in got:
                 if t is not None:

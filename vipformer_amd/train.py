@@ -563,12 +563,21 @@ class GraphedStep:
                 step()
         torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
+        # The kernels' h16 weight copies (ops.shadow) are cached on (p._version, count of optimizer steps Python has seen).  The
+        # captured step must contain the re-casts -- every replay starts from the fp32 weights the previous replay's optimizer wrote --
+        # so every cached copy is made stale before the capture (also with warmup = 0 on a model that has run before) ...
+        ops._OPT_EPOCH[0] += 1
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=self.stream):
             step()
+        ops._OPT_EPOCH[0] += 1
 
     def __call__(self) -> None:
         self.graph.replay()
+        # ... and a replay steps the optimizer on the device without Python's optimizer hooks running: the copies the replay left
+        # behind hold the weights from BEFORE its update, so an eager forward after it (the evaluation between epochs) must re-cast
+        # (without this, every eager forward after the first one computed with weights one step stale).
+        ops._OPT_EPOCH[0] += 1
 
 
 class HostFeeder:
