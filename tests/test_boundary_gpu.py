@@ -205,50 +205,27 @@ def test_two_trainers_in_one_process_do_not_alias():
     assert sorted((a, b) for _, a, b in regs)[0][0] == 0 and sum(b - a for _, a, b in regs) == trainers[0].flat.numel
 
 
-def _report_first_attempt_hang(out, err):
-    """A first-attempt hang is retried once (CI stability) but never silently: the ranks' faulthandler stacks go into a warning
-    (pytest's summary) and into gpurun_out/dp2_first_attempt_hang.txt for whoever picks it up."""
-    import warnings
-    msg = "tools/dp2_one_gpu.py hung on its first attempt (retried once):\n" + out[-1500:] + "\n" + err[-6000:]
-    warnings.warn(msg)
-    try:
-        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(root, "gpurun_out", "dp2_first_attempt_hang.txt"), "a") as f:
-            f.write(msg + "\n" + "=" * 100 + "\n")
-    except OSError:
-        pass
-
-
 def test_data_parallel_two_ranks_on_one_gpu():
     """The N > 1 sequence of bench.py / Pretrainer (hipGraph forward + backward, region-wise asynchronous gradient all-reduce on the
     communication stream, AdamW per region) with two real processes sharing this GPU over gloo (tools/dp2_one_gpu.py; RCCL itself
     needs two GPUs): reduced gradient == sum of the ranks' local gradients, parameters bitwise identical across ranks and equal to
-    AdamW on the mean gradient."""
+    AdamW on the mean gradient.
+    ONE attempt (the retry of rounds 3 - 4 is gone).  The tool rendezvouses on an ephemeral port with a bounded
+    gloo timeout, every rank carries a 150 s faulthandler watchdog that prints its stacks and exits non-zero, and this test kills the
+    process group it started after 300 s: a hang fails here, loudly, with the ranks' stacks in the assertion message."""
     import signal
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "tools", "dp2_one_gpu.py"), "4", "2"]
-    # The ranks carry a 150 s watchdog (faulthandler: a hung rank prints its stacks and exits).  Once in ~100 runs the three processes
-    # sharing this GPU (this one and the two ranks) did not get past the rendezvous-side of the first collective: a second attempt is
-    # allowed for THAT (a timeout), never for a wrong result.
-    for attempt in range(2):
-        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
-        try:
-            out, err = p.communicate(timeout=300)
-        except subprocess.TimeoutExpired:
-            os.killpg(p.pid, signal.SIGKILL)               # the process group this test started: the tool and its two ranks
-            out, err = p.communicate()
-            assert attempt == 0, ("two ranks on one GPU hung twice", out[-2000:], err[-4000:])
-            _report_first_attempt_hang(out, err)
-            continue
-        hung = p.returncode != 0 and "Timeout (" in err    # faulthandler's watchdog fired in a rank
-        if hung and attempt == 0:
-            _report_first_attempt_hang(out, err)
-            continue
-        assert p.returncode == 0 and "dp2 on one GPU: ok" in out, (out[-2000:], err[-4000:])
-        break
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)               # the process group this test started: the tool and its two ranks
+        out, err = p.communicate()
+        raise AssertionError(("two ranks on one GPU hung", out[-2000:], err[-6000:]))
+    assert p.returncode == 0 and "dp2 on one GPU: ok" in out, (out[-2000:], err[-6000:])
 
 
 def test_data_parallel_code_path_over_rccl_in_a_one_rank_group():

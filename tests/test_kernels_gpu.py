@@ -597,6 +597,37 @@ def test_grouped_wgrad_workspace_split_k():
         _lib.debug_set("wgroup_cfg", keep)
 
 
+def test_grouped_wgrad_lds_dma_kernel():
+    """gemm_wgrad_dma_kernel (round 5: 256 x 128 tiles, stages by LDS-DMA, three deep) against fp32 matmuls of the same h16 operands: the
+    four weight gradients of an encoder layer at the point-cloud and image token counts (12 288 = 192 x 64, 12 544 = 196 x 64 tokens:
+    two K slices of 96 and 98 stages) and a whole stack of 28 problems, accumulated INTO non-zero buffers, bias sums on and off, twice
+    in a row; a launch with ONE non-conforming problem must take the register-staged kernel and still be right."""
+    from vipformer_amd import _lib, ops
+    keep = _lib.debug_get("wgroup_dma")
+    layer = [(256, 512), (512, 256), (256, 256), (768, 256)]
+    try:
+        _lib.debug_set("wgroup_dma", 1)
+        for M, shapes in ((12288, layer), (12544, layer), (12288, [(256, 512), (512, 256), (256, 256), (256, 256)] + layer * 6), (320, layer),
+                          (12288, layer + [(64, 128)])):
+            jobs = []
+            for i, (N, K) in enumerate(shapes):
+                dy, x = bf(rnd(100 + i, M, N)), bf(rnd(200 + i, M, K))
+                jobs.append((dy, x, N, K, torch.ones(N, K, device="cuda"), (torch.ones(N, device="cuda") if i % 4 != 3 else None)))
+            for rep in range(2):
+                wg = ops.WgradBatch(cap=ops.WgradBatch.CAP)
+                for dy, x, N, K, dW, db in jobs:
+                    wg.add(dy, x, N, K, dW, db)
+                wg.flush()
+            torch.cuda.synchronize()
+            for dy, x, N, K, dW, db in jobs:
+                ref = dy.float().t() @ x.float()
+                assert rel(dW, 1.0 + 2.0 * ref) < 2e-5, (M, N, K, rel(dW, 1.0 + 2.0 * ref))
+                if db is not None:
+                    assert rel(db, 1.0 + 2.0 * dy.float().sum(0)) < 2e-5, (M, N, K)
+    finally:
+        _lib.debug_set("wgroup_dma", keep)
+
+
 def _grouped_wgrad_cases(ops):
     for M, shapes in ((12288, [(256, 512), (512, 256), (256, 256), (768, 256)]), (1000, [(64, 128), (136, 72)]), (40, [(8, 8)])):
         jobs = []

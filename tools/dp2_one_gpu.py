@@ -117,7 +117,9 @@ def worker(rank, world, pairs, steps, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    # a bounded rendezvous: a rank that cannot reach the store raises after 120 s instead of waiting for the watchdog
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     plain = run_mode(False, rank, world, pairs, steps, dev)
     over = run_mode(True, rank, world, pairs, steps, dev)
     for s, ((p0, g0, l0), (p1, g1, l1)) in enumerate(zip(plain, over)):
@@ -137,7 +139,18 @@ def worker(rank, world, pairs, steps, port):
     faulthandler.cancel_dump_traceback_later()
 
 
-def main(pairs=8, steps=3, port=29577):
+def free_port():
+    """An ephemeral TCP port nobody listens on right now.  (Rounds 2 - 4 used the fixed port 29577: a rendezvous on a fixed port waits
+    for ever -- not "fails" -- when an earlier run's store still holds it, e.g. ranks of a killed attempt, which is the one way this
+    tool was ever seen to stall: once, in round 3, behind its first collective, never again in the suites since.)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def main(pairs=8, steps=3, port=None):
+    port = port or free_port()
     mp.spawn(worker, args=(2, pairs, steps, port), nprocs=2, join=True)
     print("dp2 on one GPU: ok")
 

@@ -254,8 +254,8 @@ def satail2():
     for name, wg2, rb in (("round-2 kernels (1 WG/CU)", 0, 0), ("sa_rows <2,1> 64 tok, 76 KB", 1, 2), ("sa_rows <1,1> 32 tok cut to 2/CU", 1, 0),
                           ("sa_rows <1,1> 32 tok whole", 1, 1), ("sa_rows <1,2> 64 tok 16 waves", 1, 12),
                           ("sa_rows <1,2> DECOUPLED groups", 1, 13), ("sa_rows <1,2> DECOUPLED, stagger 20", 1, 13 + 20 * 256),
-                          ("sa_rows <1,2> DECOUPLED, stagger 60", 1, 13 + 60 * 256)):
-        L.debug_set("sa_stagger", rb >> 8); rb &= 255
+                          ("sa_rows <2,1> cut to 1 per CU (48 / 49 tokens)", 1, 2 + 65536), ("sa_rows <1,1> cut to 3 per CU (16 / 17 tokens)", 1, 1 + 3 * 65536)):
+        L.debug_set("sa_stagger", (rb >> 8) & 255); L.debug_set("sa_tpw", -(rb >> 16)); rb &= 255
         if os.environ.get("SATAIL2_ONLY") and str(rb) not in os.environ["SATAIL2_ONLY"].split(","):
             continue
         L.debug_set("sa_wg2", wg2); L.debug_set("sa_rb", rb)
@@ -264,7 +264,7 @@ def satail2():
         b = timed([1], "img alone (6 launches)")
         c = timed([0, 1], "pc || img (two streams)")
         print(f"   -> side by side / (pc + img alone) = {c / (a + b):.3f}")
-    L.debug_set("sa_wg2", 0); L.debug_set("sa_rb", 0)
+    L.debug_set("sa_wg2", 0); L.debug_set("sa_rb", 0); L.debug_set("sa_tpw", 0); L.debug_set("sa_stagger", 0)
 
 
 def wgroup():
@@ -283,6 +283,25 @@ def wgroup():
     t = timeit(run, 100, 5)
     fl = sum(2.0 * M * N * K for _, _, N, K, _, _ in ts)
     print(f"wgrad group (4 problems, M={M}): {t:.1f} us ({fl/t/1e6:.0f} TF/s)")
+
+
+def wstack():
+    """the grouped weight-gradient launch the STEP makes: the 28 weight gradients of the point-cloud encoder stack (bench.py's leg);
+    read its device-side duration from a kernel trace (tools/kprof.sh): the eager launch is host-bound (28 job descriptors)"""
+    from vipformer_amd import ops
+    M, D, Hd, S = 12288, 256, 512, 6
+    shapes = [(D, Hd), (Hd, D), (D, D), (3 * D, D)]
+    stack = [(D, Hd), (Hd, D), (D, D), (D, D)] + [sh for _ in range(S) for sh in shapes]
+    g = torch.Generator().manual_seed(7)
+    jobs = [(torch.randn(M, N, generator=g).cuda().to(H16), torch.randn(M, K, generator=g).cuda().to(H16), N, K,
+             torch.zeros(N, K, device="cuda"), (torch.zeros(N, device="cuda") if i % 4 != 3 else None)) for i, (N, K) in enumerate(stack)]
+    def run():
+        wg = ops.WgradBatch(cap=ops.WgradBatch.CAP)
+        for dy, x, N, K, dW, db in jobs: wg.add(dy, x, N, K, dW, db)
+        wg.flush()
+    t = timeit(run, 20, 3)
+    fl = sum(2.0 * M * N * K for N, K in stack)
+    print(f"wgrad stack ({len(stack)} problems, M={M}): {t:.1f} us eager ({fl/t/1e6:.0f} TF/s)")
 
 
 def g2e():
@@ -322,6 +341,28 @@ def gemmk():
         print(f"gemmk K={K}: h16-out {t1:.1f} us  f32-out {t2:.1f} us")
     e = torch.empty(8, device="cuda")
     print("empty launch (cast of 8 elems): %.1f us" % timeit(lambda: ops.to_h16(e), 50, 5))
+
+
+def gemmtn():
+    """the single weight-gradient GEMMs of the step (dW[N,K] += dY^T X over M rows, split over M, fp32 atomics) per tile configuration:
+    VPF_WGRAD_CFG 0 = 64x64, 1 = 128x64, 2 = 128x128; and per split (0 = the launcher's own choice)"""
+    from vipformer_amd import _lib as L
+    from vipformer_amd import ops
+    shapes = [("g2e dW3[:,128:] = dh3^T h2", 393216, 256, 128), ("g2e conv2 dW = dh2^T a1", 393216, 128, 64),
+              ("patch embedding dW = dy^T patches", 12544, 256, 768), ("g2e dW3[:,:128] = dgb^T gmax", 12288, 256, 128),
+              ("adapter l3 dW = dy^T a1", 131072, 256, 64), ("kv dW = dkv^T nk", 131072, 512, 256)]
+    for name, M, N, K in shapes:
+        dy = torch.randn(M, N, device="cuda").to(H16); x = torch.randn(M, K, device="cuda").to(H16)
+        dW = torch.zeros(N, K, device="cuda")
+        line = f"{name:38s} M={M:6d} N={N:3d} K={K:3d}:"
+        for cfg in (0, 1, 2):
+            L.debug_set("wgrad_cfg", cfg)
+            for sk in (0,) + ((128, 512) if M > 100000 else (16, 32)):
+                t = timeit(lambda: ops.gemm(dy, 1, N, x, 1, K, N, K, M, dW, K, c_f32=True, mode=ops.EPI_ATOMIC, splitk=sk), 20, 3)
+                line += f"  cfg{cfg}/sk{sk} {t:6.1f}"
+        L.debug_set("wgrad_cfg", 0)
+        gb = M * (N + K) * 2 / 1e9
+        print(line + f"   us   ({gb * 1e3:.0f} MB: {gb / 6.3e3 * 1e6:.1f} us at 6.3 TB/s)")
 
 
 if __name__ == "__main__":

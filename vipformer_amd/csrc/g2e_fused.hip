@@ -572,6 +572,10 @@ struct G2eBwd {
     float invM; int training;
     h16_t* dh3; float* dgb; h16_t* dh2;
     long long* dbg;               // diagnostic: per-phase cycle sums of wave 0 of every workgroup (nullable)
+    // round 5: what three small launches behind this kernel used to produce (colsum of dgb, its h16 cast, BatchNorm-2's parameter
+    // gradients from tmp) leaves from here: a lane owns a column, so the column sums are per-lane registers
+    h16_t* dgb16; float* db3;     // nullable: dgb as h16 [NG,256]; db3[256] += column sums of dgb
+    float* dgamma2; float* dbeta2;
 };
 
 // KSC (round 4): the number of 16-wide k-steps of the dh4 . W4 product as a template parameter (16 at Dm = 256; 0 = read Dm at run time).
@@ -604,7 +608,12 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     const int col = w * 32 + l31;
     const float mean = p.stat2[col], rstd = p.stat2[256 + col], ga = p.gamma2[col], be = p.beta2[col];
     float sg = 0.f, sgx = 0.f;
-    if (PASS == 1 && p.training) { sg = p.tmp[col] * p.invM; sgx = p.tmp[256 + col] * p.invM; }
+    if (PASS == 1 && p.training) {
+        const float t0 = p.tmp[col], t1 = p.tmp[256 + col];
+        sg = t0 * p.invM; sgx = t1 * p.invM;
+        if (blockIdx.x == 0 && hl == 0) { atomicAdd(p.dgamma2 + col, t1); atomicAdd(p.dbeta2 + col, t0); }      // BatchNorm-2's parameter gradients
+    }
+    float colsum3 = 0.f;                                                  // PASS 1: sum over this workgroup's groups of dgb[:, col]
     // dh2 = dh3 . W3b : wave -> row tile rt2 = w >> 2, column tile ct2 = w & 3 of [64 x 128]
     const int rt2 = w >> 2, ct2 = w & 3;
     float a0 = 0.f, a1 = 0.f;
@@ -731,7 +740,11 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             for (int rt = 0; rt < 2; ++rt) {
                 const float s = gsum[rt] + __shfl_xor(gsum[rt], 32, 64);
                 const long g = pr * 2 + rt;
-                if (hl == 0 && g < p.NG) p.dgb[(size_t)g * 256 + col] = s;
+                if (hl == 0 && g < p.NG) {
+                    if (p.dgb) p.dgb[(size_t)g * 256 + col] = s;
+                    if (p.dgb16) p.dgb16[(size_t)g * 256 + col] = f32_to_h16(s);
+                    colsum3 += s;
+                }
             }
             __syncthreads();                                       // dh3 tile complete; dh4 tile no longer needed
             STAMP(2);
@@ -769,27 +782,22 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     if (PASS == 0) {
         a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
         if (hl == 0) { atomicAdd(p.tmp + col, a0); atomicAdd(p.tmp + 256 + col, a1); }
-    }
+    } else if (p.db3 && hl == 0) atomicAdd(p.db3 + col, colsum3);
 }
 
 // Group2Emb backward through conv4 / BatchNorm-2 / conv3's per-point half for group_size 32, Dm <= 256 (see above).
 // tmp512_zeroed: f32 scratch.  Also accumulates dgamma2 / dbeta2.
-__global__ void g2e_bn2_param_grad_kernel(const float* __restrict__ tmp, float* __restrict__ dgamma, float* __restrict__ dbeta)
-{
-    const int c = threadIdx.x;
-    if (c < 256) { atomicAdd(dgamma + c, tmp[256 + c]); atomicAdd(dbeta + c, tmp[c]); }
-}
 extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_h16, const float* stat2,
                            const float* gamma2, const float* beta2, const void* w4t_h16, const void* w3bt_h16, int training,
                            float* tmp512_zeroed, void* dh3_h16, float* dgb, void* dh2_h16, float* dgamma2, float* dbeta2, long long* dbg,
-                           void* stream)
+                           void* dgb_h16, float* db3, void* stream)
 {
     (void)hipGetLastError();
-    if (!dout || !arg4 || !h3_h16 || !stat2 || !gamma2 || !beta2 || !w4t_h16 || !w3bt_h16 || !tmp512_zeroed || !dh3_h16 || !dgb || !dh2_h16 ||
-        !dgamma2 || !dbeta2) return VPF_ERR_NULL;
+    if (!dout || !arg4 || !h3_h16 || !stat2 || !gamma2 || !beta2 || !w4t_h16 || !w3bt_h16 || !tmp512_zeroed || !dh3_h16 || !dh2_h16 ||
+        !dgamma2 || !dbeta2 || (!dgb && !dgb_h16)) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0 || Dm > 256 || (Dm % 16)) return VPF_ERR_BADSHAPE;
     G2eBwd p = {dout, arg4, Dm, NG, (const h16_t*)h3_h16, stat2, gamma2, beta2, (const h16_t*)w4t_h16, (const h16_t*)w3bt_h16, tmp512_zeroed,
-                1.0f / (float)(NG * 32), training, (h16_t*)dh3_h16, dgb, (h16_t*)dh2_h16, dbg};
+                1.0f / (float)(NG * 32), training, (h16_t*)dh3_h16, dgb, (h16_t*)dh2_h16, dbg, (h16_t*)dgb_h16, db3, dgamma2, dbeta2};
     const size_t lds = sizeof(h16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
@@ -808,7 +816,6 @@ extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long 
         if (training) hipLaunchKernelGGL((g2e_bwd_kernel<0, 0>), dim3((unsigned)grid), dim3(512), lds, st, p);
         hipLaunchKernelGGL((g2e_bwd_kernel<1, 0>), dim3((unsigned)grid), dim3(512), lds1, st, p);
     }
-    if (training) hipLaunchKernelGGL(g2e_bn2_param_grad_kernel, dim3(1), dim3(256), 0, st, (const float*)tmp512_zeroed, dgamma2, dbeta2);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

@@ -631,6 +631,178 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(Gemm
     }
     gemm_tile<TM, TN, WM, WN, BK, true, true, 0, 0, PF, PAIR>(g, bx, by, bz);
 }
+// ------------------------------------------------------------------ grouped weight gradient, LDS-DMA staging (round 5)
+// What the anatomy of the STACK launch says (tools/microbench.py wstack under a kernel trace, NOTES.md round 5): 208 us, of which the
+// staging loop alone -- global -> registers -> LDS + one barrier per 64-token stage, no MFMA, no fragment reads, no flush -- is 158 us.
+// It moves 1.4 GB at 18 B/clk per CU where 55 B/clk is available: every stage exposes one L2 / HBM round trip (the registers that carry
+// a stage are refilled one iteration ahead of their store), and a deeper register pipeline costs the occupancy it needs.
+// Here the stages travel by LDS-DMA (global_load_lds_dwordx4: memory -> LDS, no registers, no ds_write): three 48 KB stages per
+// workgroup, two in flight behind the one on the matrix cores.  256 x 128 output tiles on 8 waves (a quarter fewer staged bytes than
+// 128 x 128: every B row block serves 256 output rows), ONE workgroup per CU (144 KB of LDS), <= 256 workgroups per launch.
+//   * The K-strided tile layout of gemm_tile ([BK][ROWS], 32-row column blocks of k row k XOR-permuted by k & 3: conflict-free
+//     transposing reads) is produced on the GLOBAL side: a DMA wave-instruction writes 1 KB of LDS contiguously (lane i -> +16 i), so
+//     lane i fetches the 16-byte chunk whose swizzled position is i -- chunk (pos ^ ((k & 3) << 2)) of its k row; all within the
+//     row's contiguous ROWS x 2 bytes, coalescing is unchanged.
+//   * The DMA is issued from inline asm: through the builtin the compiler (correctly, not knowing better) waits for vmcnt(0) in front
+//     of every LDS read that might alias a pending DMA and in front of every __syncthreads, which is the pipeline.  Protocol per stage:
+//     every wave waits for ITS OWN copies of stage kt (s_waitcnt vmcnt(PER): the next stage's PER copies may stay in flight; vmcnt
+//     retires in order), one s_barrier (all waves' copies have landed, all waves are done with stage kt - 1), the copies of stage
+//     kt + 2 go into stage kt - 1's buffer, then the products of stage kt.
+// Conforming problems only (the launcher checks): M % 256 == 0, N % 128 == 0, K % 64 == 0, 16-byte aligned operands, atomics flush.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"          // (m0 is a reserved register: it is exactly what this instruction takes its LDS address from)
+__device__ __forceinline__ void wg_dma16(const void* gptr, unsigned lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_byte), "v"(gptr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#define WGDMA_BM 256
+#define WGDMA_BN 128
+#define WGDMA_BK 64
+#define WGDMA_NS 3
+__global__ void __launch_bounds__(512) gemm_wgrad_dma_kernel(GemmGroup grp)
+{
+    constexpr int BM = WGDMA_BM, BN = WGDMA_BN, BK = WGDMA_BK, NS = WGDMA_NS, TM = 2, TN = 2;
+    using ACfg = TileCfg<BM, true, BK>;
+    using BCfg = TileCfg<BN, true, BK>;
+    constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;                 // h16 elements per stage (24 576 = 48 KB)
+    constexpr int PER = 6;                                           // DMA instructions per wave and stage: 4 of the A tile, 2 of the B tile
+    extern __shared__ __attribute__((aligned(16))) h16_t lds_dma[];
+    // ---- which problem, tile and K slice (as gemm_wgrad_group_kernel)
+    int p = 0, local = 0, xbz = 0;
+    if (grp.xmode) {
+        const int x = blockIdx.x & 7;
+        int slot = blockIdx.x >> 3, i = grp.xoff[x];
+        const int end = grp.xoff[x + 1];
+        for (; i < end; ++i) {
+            const int nt = grp.nx[grp.xp[i]] * grp.ny[grp.xp[i]];
+            if (slot < nt) break;
+            slot -= nt;
+        }
+        if (i >= end) return;
+        p = grp.xp[i]; xbz = grp.xz[i]; local = slot;
+    } else {
+        while (p + 1 < grp.n && (int)blockIdx.x >= grp.start[p + 1]) ++p;
+        local = blockIdx.x - grp.start[p];
+    }
+    const WgDesc& d = grp.d[p];
+    const int nx = grp.nx[p], ny = grp.ny[p];
+    int bx, by, bz;
+    if (grp.xmode) { bz = xbz; bx = local % nx; by = local / nx; }
+    else { bx = local % nx; by = (local / nx) % ny; bz = local / (nx * ny); }
+    const int m0 = by * BM, n0 = bx * BN;
+    const int per = ((d.K + d.splitk - 1) / d.splitk + BK - 1) / BK * BK;
+    const int kbeg = bz * per, kend = min(d.K, kbeg + per);
+    if (kbeg >= kend) return;
+    const int nk = (kend - kbeg) / BK;
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    // ---- this lane's part of a stage: element offsets inside the stage's 64 k rows (A: 2 k rows per instruction, B: 4)
+    unsigned offA[4], offB[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = wave + 8 * j, kk = 2 * q + (lane >> 5), pos = lane & 31;
+        offA[j] = (unsigned)kk * (unsigned)d.lda + (unsigned)((pos ^ ((kk & 3) << 2)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = wave + 8 * j, kk = 4 * q + (lane >> 4), pos = lane & 15;
+        offB[j] = (unsigned)kk * (unsigned)d.ldb + (unsigned)((pos ^ ((kk & 3) << 2)) * 8);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) h16_t*)lds_dma;
+    const h16_t* Ag = d.A + (size_t)kbeg * d.lda + m0;
+    const h16_t* Bg = d.B + (size_t)kbeg * d.ldb + n0;
+    auto issue = [&](int st) {
+        const unsigned buf = lds0 + (unsigned)(st % NS) * (STAGE * 2);
+        const h16_t* a = Ag + (size_t)st * BK * d.lda;
+        const h16_t* b = Bg + (size_t)st * BK * d.ldb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wg_dma16(a + offA[j], buf + (unsigned)(wave + 8 * j) * 1024u);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wg_dma16(b + offB[j], buf + (unsigned)(ACfg::ELEMS * 2) + (unsigned)(wave + 8 * j) * 1024u);
+    };
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool do_bias = d.dbias != nullptr && bx == 0 && wn == 0;
+    float bsum[TM] = {0.f, 0.f};
+
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // (= PER: the copies of stage kt + 1 may stay in flight)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const h16_t* cA = lds_dma + (size_t)(kt % NS) * STAGE;
+        const h16_t* cB = cA + ACfg::ELEMS;
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            h16x8_t fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, true, BK>(cA, (wm * TM + i) * 32, s);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, true, BK>(cB, (wn * TN + j) * 32, s);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = vpf_mfma32(fa[i], fb[j], acc[i][j]);
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const uint4 w = __builtin_bit_cast(uint4, fa[i]);
+                    bsum[i] = h16_dot2(w.x, VPF_H16_ONES2, bsum[i]);
+                    bsum[i] = h16_dot2(w.y, VPF_H16_ONES2, bsum[i]);
+                    bsum[i] = h16_dot2(w.z, VPF_H16_ONES2, bsum[i]);
+                    bsum[i] = h16_dot2(w.w, VPF_H16_ONES2, bsum[i]);
+                }
+            }
+        }
+        // (the LDS reads of this stage are complete before a wave's MFMAs consume them, i.e. before it reaches the next barrier)
+    }
+    static_assert(PER == 6, "the vmcnt immediate above");
+    // ---- flush: bias sums, then fp32 atomics straight from the accumulators (128-byte row segments), as gemm_tile
+    const int col_l = lane & 31, rsub = 4 * (lane >> 5);
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float tot = bsum[i] + __shfl_xor(bsum[i], 32);
+            const int row = m0 + (wm * TM + i) * 32 + col_l;
+            if (lane < 32 && row < d.M) atomicAdd(d.dbias + row, tot);
+        }
+    }
+    if (grp.dbg & 1) { if (acc[0][0][0] == 12345.678f) d.C[0] = 1.f; return; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + col_l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + rsub;
+                atomicAdd(d.C + (size_t)m * d.ldc + n, acc[i][j][r]);
+            }
+        }
+}
+static int launch_wgrad_dma(const GemmGroup& grp, int nblocks, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(h16_t) * WGDMA_NS * (TileCfg<WGDMA_BM, true, WGDMA_BK>::ELEMS + TileCfg<WGDMA_BN, true, WGDMA_BK>::ELEMS);
+    static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
+    static VpfPerDevice attr_dev; bool& attr = attr_dev();
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)gemm_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_wgrad_dma_kernel, dim3(nblocks), dim3(512), lds, st, grp);
+    VPF_CHECK_LAUNCH();
+    return VPF_OK;
+}
+
 template <int TM, int TN, int WM, int WN, int BK, int PF = 1, bool PAIR = false>
 static int launch_wgrad_group(const GemmGroup& grp, int nblocks, hipStream_t st)
 {
@@ -789,10 +961,18 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
     if (njobs <= 0 || njobs > GEMM_GROUP_MAX) return VPF_ERR_BADSHAPE;
     GemmGroup grp = {};
     grp.n = njobs;
-    const int cfg = vpf_debug().wgroup_cfg, target = vpf_debug().wgroup_wgs > 0 ? vpf_debug().wgroup_wgs : 512;      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     const int partial = ws != nullptr;
-    const int tm = cfg == 0 ? 64 : 128, tn = (cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64);
-    const bool pair = cfg == 8 && !partial;          // two K slices per 8-wave workgroup: half the flush atomics (round 3)
+    // round 5: the LDS-DMA kernel (256 x 128 tiles, one workgroup per CU) when every problem conforms -- multiples of its tile, 64-token
+    // stages, the atomics flush -- and the launch is big enough to stream (VPF_WGROUP_DMA: 0 = never, N > 0 = from N tokens per problem on)
+    bool dma = vpf_debug().wgroup_dma > 0 && !partial;
+    for (int i = 0; i < njobs && dma; ++i) {
+        const VpfWgradJob& j = jobs[i];
+        if (j.M < vpf_debug().wgroup_dma || (j.N % WGDMA_BM) || (j.K % WGDMA_BN) || (j.M % WGDMA_BK) || j.M <= 0) dma = false;
+    }
+    const int cfg = dma ? 2 : vpf_debug().wgroup_cfg;
+    const int target = vpf_debug().wgroup_wgs > 0 ? vpf_debug().wgroup_wgs : (dma ? 256 : 512);      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
+    const int tm = dma ? WGDMA_BM : (cfg == 0 ? 64 : 128), tn = dma ? WGDMA_BN : ((cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64));
+    const bool pair = cfg == 8 && !partial && !dma;          // two K slices per 8-wave workgroup: half the flush atomics (round 3)
     long total_tiles = 0;
     for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
     int at = 0;
@@ -810,7 +990,8 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         long sp = target / (total_tiles > 0 ? total_tiles : 1);
         const long maxs = vpf_cdiv(g.K, 256);
         if (sp > maxs) sp = maxs;
-        if (sp < 2) sp = 2;                       // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
+        if (sp < 2 && !dma) sp = 2;               // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
+        if (sp < 1) sp = 1;
         if (sp > 8 && vpf_debug().wgroup_xlist) sp &= ~7L;      // many slices: a multiple of 8, so that the kernel's XCD ordering applies (a slice's tiles on one XCD)
         if (pair) sp &= ~1L;                      // whole pairs
         g.splitk = (int)sp;
@@ -859,9 +1040,10 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
     // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at
     // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
     // 512 workgroups flushing together at the end (-0.035 ms/step, 15 launches)
-    grp.uneven = vpf_debug().wgroup_uneven;
+    grp.uneven = dma ? 0 : vpf_debug().wgroup_uneven;      // (one workgroup per CU in ONE round: equal slices end together)
     grp.dbg = vpf_debug().wgroup_dbg;
     hipStream_t st = (hipStream_t)stream;
+    if (dma) return launch_wgrad_dma(grp, at, st);
     // workspace split-K (EPI_PARTIAL) when the caller handed over enough scratch: [counters | one tm x tn f32 tile per workgroup]
     if (partial && ws && total_tiles <= WGROUP_CNT_INTS && ws_bytes >= (long)(WGROUP_CNT_INTS * 4 + (size_t)at * tm * tn * 4) && !((uintptr_t)ws & 15)) {
         float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + WGROUP_CNT_INTS * 4);

@@ -59,7 +59,9 @@ __device__ __forceinline__ void who(int tid_, int& cw, int& tb0)
 // ST = 0 plain; 1 `sc1` (write-through: the line does not stay dirty in the XCD's L2, so the end-of-kernel write-back of the
 // launch's last ~30 MB of outputs is spread over the kernel instead -- MI355X_MICROARCH.md, "stores of each flavour"); 2 `nt`;
 // 3 `sc0 sc1`.  The inline-asm stores are invisible to the compiler's vmcnt bookkeeping, which is safe: vmcnt retires in order, so
-// extra operations in the queue only make a counted wait cover more than the compiler asked for.
+// extra operations in the queue only make a counted wait cover more than the compiler asked for.  The trailing s_nop is the wait
+// state the ISA asks for between a store of more than 8 bytes and a write to its data registers (the compiler inserts it for its
+// own stores; it does not see these).
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 template <int ST, class V>
 __device__ __forceinline__ void st16(V* p, const V& v)
@@ -68,9 +70,9 @@ __device__ __forceinline__ void st16(V* p, const V& v)
     if constexpr (ST == 0) *p = v;
     else {
         const u32x4_t d = __builtin_bit_cast(u32x4_t, v);
-        if constexpr (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(d) : "memory");
-        else if constexpr (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(p), "v"(d) : "memory");
-        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(d) : "memory");
+        if constexpr (ST == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" :: "v"(p), "v"(d) : "memory");
+        else if constexpr (ST == 2) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 0" :: "v"(p), "v"(d) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" :: "v"(p), "v"(d) : "memory");
     }
 }
 
@@ -550,6 +552,10 @@ __global__ void __launch_bounds__(2 * D * TH, MINW) sa_rows_fwd_kernel(VpfSaLaye
         if (DBG && a.dbg && TH > 1 && (int)threadIdx.x == (TH - 1) * 64 * NWV && blockIdx.x < 1024)
             a.dbg[32 + 4 * (1024 + (long)blockIdx.x) + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     };
+    if (stagger < 0) {                                                // experiment: workgroup b starts (b mod 4) x |stagger| x 64 cycles late -- de-phases
+        const int n = -stagger * (int)(blockIdx.x & 3);                   // the HBM bursts of a launch whose workgroups all run the same program in step
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     WRing<PD> ring;
     ring_fill<PD>((const h16_t*)a.Wo, KS, 0, cw, ring);
     // ---- residual base rows (consumed behind the first product), o rows -> actA, per-channel vectors -> sPar
@@ -715,8 +721,13 @@ int fwd_launch(const VpfSaLayerFwd& a, hipStream_t st, bool cut = false)
         if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, false, DEC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    const int tpw = (cut && C::TOK == 32) ? tokens_per_wg(M) : C::TOK;
-    const int stagger = DEC ? vpf_debug().sa_stagger : 0;
+    int tpw = (cut && C::TOK == 32) ? tokens_per_wg(M) : C::TOK;
+    // VPF_SA_TPW (experiment): tokens per workgroup, N > 0: min(N, TOK); N < 0: ceil(M / (256 * -N)) -- the grid cut to -N workgroups per CU
+    if (const int t = vpf_debug().sa_tpw) {
+        const long want = t > 0 ? t : (M + 256L * -t - 1) / (256L * -t);
+        tpw = (int)(want < C::TOK ? (want < 1 ? 1 : want) : C::TOK);
+    }
+    const int stagger = (DEC || vpf_debug().sa_stagger < 0) ? vpf_debug().sa_stagger : 0;
     if (a.dbg) {                                                     // phase stamps of workgroup 0 (tools/microbench.py): a build of its own
         if (hipFuncSetAttribute((const void*)sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, true, DEC, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return VPF_ERR_HIP;
         hipLaunchKernelGGL((sa_rows_fwd_kernel<D, HID, RB, TH, MINW, false, true, DEC, ST>), dim3(vpf_cdiv(M, tpw)), dim3(C::NT), lds, st, a, tpw, stagger);

@@ -50,6 +50,8 @@ struct VpfDebug {
     int wgroup_xlist;       // VPF_WGROUP_XLIST      1: every (problem, K slice) of a grouped weight gradient on ONE XCD when the slices are few (0: plain order)
     int sa_stagger;         // VPF_SA_STAGGER        decoupled wave groups (sa_rows.hip, Grp<.., DEC>): group g starts g x N x 64 cycles late (0: together)
     int sa_store;           // VPF_SA_STORE          cache policy of the row-block kernels' 16-byte row stores: 0 plain, 1 sc1 (write-through), 2 nt, 3 sc0 sc1
+    int sa_tpw;             // VPF_SA_TPW            tokens per workgroup of the sa_rows forward kernels (experiment; 0: the geometry's own, < 0: the grid cut to -N workgroups per CU)
+    int wgroup_dma;         // VPF_WGROUP_DMA        N > 0: grouped weight gradients of conforming problems with >= N tokens run the LDS-DMA kernel (0: never)
     int sa_rb;              // VPF_SA_RB             geometry of those kernels at D = 256: 12 = 16 waves x 32 tokens each (default), 2 = 8 waves x 64, 1 = 8 waves x 32
 };
 VpfDebug& vpf_debug();
