@@ -588,13 +588,14 @@ def test_grouped_wgrad_workspace_split_k():
         ops.cfg.wgrad_deterministic = False
     _grouped_wgrad_cases(ops)                                             # the default: fp32 atomics
     from vipformer_amd import _lib
-    keep = _lib.debug_get("wgroup_cfg")
+    keep, keep_dma = _lib.debug_get("wgroup_cfg"), _lib.debug_get("wgroup_dma")
     try:
+        _lib.debug_set("wgroup_dma", 0)                                   # (the register-staged kernels: the LDS-DMA one has its own test)
         for cfg in (2, 8):                                                # 8: two K slices per 8-wave workgroup, LDS exchange, half the atomics
             _lib.debug_set("wgroup_cfg", cfg)
             _grouped_wgrad_cases(ops)
     finally:
-        _lib.debug_set("wgroup_cfg", keep)
+        _lib.debug_set("wgroup_cfg", keep); _lib.debug_set("wgroup_dma", keep_dma)
 
 
 def test_grouped_wgrad_lds_dma_kernel():

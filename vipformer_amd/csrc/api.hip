@@ -76,7 +76,7 @@ static const VpfDebugKey kDebugKeys[] = {
     {"sa_stagger", "VPF_SA_STAGGER", &VpfDebug::sa_stagger, 0},
     {"sa_store", "VPF_SA_STORE", &VpfDebug::sa_store, 0},
     {"sa_tpw", "VPF_SA_TPW", &VpfDebug::sa_tpw, 0},
-    {"wgroup_dma", "VPF_WGROUP_DMA", &VpfDebug::wgroup_dma, 0},
+    {"wgroup_dma", "VPF_WGROUP_DMA", &VpfDebug::wgroup_dma, 2048},
 };
 VpfDebug& vpf_debug()
 {

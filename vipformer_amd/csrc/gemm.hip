@@ -660,7 +660,7 @@ __device__ __forceinline__ void wg_dma16(const void* gptr, unsigned lds_byte)
 #define WGDMA_BN 128
 #define WGDMA_BK 64
 #define WGDMA_NS 3
-__global__ void __launch_bounds__(512) gemm_wgrad_dma_kernel(GemmGroup grp)
+__global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
 {
     constexpr int BM = WGDMA_BM, BN = WGDMA_BN, BK = WGDMA_BK, NS = WGDMA_NS, TM = 2, TN = 2;
     using ACfg = TileCfg<BM, true, BK>;
@@ -713,14 +713,15 @@ __global__ void __launch_bounds__(512) gemm_wgrad_dma_kernel(GemmGroup grp)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) h16_t*)lds_dma;
     const h16_t* Ag = d.A + (size_t)kbeg * d.lda + m0;
     const h16_t* Bg = d.B + (size_t)kbeg * d.ldb + n0;
-    auto issue = [&](int st) {
+    // copy `pc` (0 .. 3: the A tile, 4 .. 5: the B tile) of stage st
+    auto issue_piece = [&](int st, int pc) {
         const unsigned buf = lds0 + (unsigned)(st % NS) * (STAGE * 2);
-        const h16_t* a = Ag + (size_t)st * BK * d.lda;
-        const h16_t* b = Bg + (size_t)st * BK * d.ldb;
+        if (pc < 4) wg_dma16(Ag + (size_t)st * BK * d.lda + offA[pc], buf + (unsigned)(wave + 8 * pc) * 1024u);
+        else wg_dma16(Bg + (size_t)st * BK * d.ldb + offB[pc - 4], buf + (unsigned)(ACfg::ELEMS * 2) + (unsigned)(wave + 8 * (pc - 4)) * 1024u);
+    };
+    auto issue = [&](int st) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wg_dma16(a + offA[j], buf + (unsigned)(wave + 8 * j) * 1024u);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) wg_dma16(b + offB[j], buf + (unsigned)(ACfg::ELEMS * 2) + (unsigned)(wave + 8 * j) * 1024u);
+        for (int pc = 0; pc < 6; ++pc) issue_piece(st, pc);
     };
     f32x16_t acc[TM][TN];
 #pragma unroll
@@ -732,30 +733,66 @@ __global__ void __launch_bounds__(512) gemm_wgrad_dma_kernel(GemmGroup grp)
     const bool do_bias = d.dbias != nullptr && bx == 0 && wn == 0;
     float bsum[TM] = {0.f, 0.f};
 
+    // ---- this lane's fragment addresses inside a stage (frag_read's transposing pattern: per 16-lane group a 4 (k) x 16 (row) block;
+    //      the swizzle depends on k & 3 = q only, so ONE base per fragment serves all four k-steps through immediate offsets)
+    int aoff[TM], boff[TN];
+    {
+        const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, hh = g4 >> 1, ro = 16 * (g4 & 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) aoff[i] = (8 * hh + q) * ACfg::LD + ACfg::tr_swz(q, (wm * TM + i) * 32 + ro + 4 * pp);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) boff[j] = ACfg::ELEMS + (8 * hh + q) * BCfg::LD + BCfg::tr_swz(q, (wn * TN + j) * 32 + ro + 4 * pp);
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"      // (LDS pointers are 32 bits wide)
+    auto frag = [&](unsigned base, int ld, int ks) -> h16x8_t {                 // k-step ks of the fragment whose lane's LDS byte address is `base`
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(base + (unsigned)(ks * 16 * ld * 2)));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(base + (unsigned)((ks * 16 + 4) * ld * 2)));
+        s16x8_t v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(h16x8_t, v);
+    };
+#pragma clang diagnostic pop
     issue(0);
     if (nk > 1) issue(1);
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // (= PER: the copies of stage kt + 1 may stay in flight)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt + 2);
-        const h16_t* cA = lds_dma + (size_t)(kt % NS) * STAGE;
-        const h16_t* cB = cA + ACfg::ELEMS;
+        const bool more = kt + 2 < nk;       // stage kt + 2 goes into stage kt - 1's buffer: its copies are issued BETWEEN the k-steps' products
+        // ONE address register per fragment and stage (opaque to the optimiser: otherwise it keeps 26 per-read lane offsets in registers
+        // and adds the stage base to each with two VALU instructions per read); the k-steps are immediate offsets of the reads
+        const unsigned cS = lds0 + (unsigned)(kt % NS) * (STAGE * 2);
+        unsigned pa[TM] = {cS + (unsigned)aoff[0] * 2u, cS + (unsigned)aoff[1] * 2u};
+        unsigned pb[TN] = {cS + (unsigned)boff[0] * 2u, cS + (unsigned)boff[1] * 2u};
+        asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pb[0]), "+v"(pb[1]));
+        // the fragments of k-step s + 1 are requested in front of the products of k-step s
+        h16x8_t fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = frag(pa[i], ACfg::LD, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = frag(pb[j], BCfg::LD, 0);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
-            h16x8_t fa[TM], fb[TN];
+            if (s + 1 < BK / 16) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = frag_read<BM, true, BK>(cA, (wm * TM + i) * 32, s);
+                for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = frag(pa[i], ACfg::LD, s + 1);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = frag_read<BN, true, BK>(cB, (wn * TN + j) * 32, s);
+                for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = frag(pb[j], BCfg::LD, s + 1);
+            }
+            if (more) {                      // (6 copies over 4 k-steps: 2, 2, 1, 1 -- the matrix cores start right behind the barrier)
+                if (s < 2) { issue_piece(kt + 2, 2 * s); issue_piece(kt + 2, 2 * s + 1); }
+                else issue_piece(kt + 2, s + 2);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = vpf_mfma32(fa[i], fb[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = vpf_mfma32(fa[s & 1][i], fb[s & 1][j], acc[i][j]);
             if (do_bias) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
-                    const uint4 w = __builtin_bit_cast(uint4, fa[i]);
+                    const uint4 w = __builtin_bit_cast(uint4, fa[s & 1][i]);
                     bsum[i] = h16_dot2(w.x, VPF_H16_ONES2, bsum[i]);
                     bsum[i] = h16_dot2(w.y, VPF_H16_ONES2, bsum[i]);
                     bsum[i] = h16_dot2(w.z, VPF_H16_ONES2, bsum[i]);
@@ -855,6 +892,8 @@ static int launch_cfg(const GemmArgs& g, int a_tr, int b_tr, int batch, hipStrea
     return VPF_ERR_UNSUPPORTED;
 }
 
+static bool wgrad_dma_conforms(const VpfWgradJob& j);
+static int wgrad_single_dma(const VpfWgradJob& j, int ldc, hipStream_t st);
 static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t st)
 {
     if (!g.A || !g.B || !g.C) return VPF_ERR_NULL;
@@ -865,6 +904,14 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
     if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15)) return VPF_ERR_BADALIGN;
     if (g.mode == EPI_ATOMIC) {
         if (!g.c_f32) return VPF_ERR_UNSUPPORTED;
+        // round 5: a single weight gradient that fits the LDS-DMA kernel and can fill the chip with slices of >= 1 024 tokens goes there
+        // (Group2Emb's dW3[:, 128:] = dh3^T h2: 393 216 tokens, one 256 x 128 tile, 256 slices)
+        if (a_tr && b_tr && batch == 1 && g.splitk <= 0 && g.xa.kind == 0 && g.xb.kind == 0 && g.ldc <= 0x7fffffff) {
+            VpfWgradJob j = {g.A, g.B, g.K, g.M, g.N, reinterpret_cast<float*>(g.C), g.dbias};
+            const long tiles = (long)(g.M / WGDMA_BM) * (g.N / WGDMA_BN);
+            if (wgrad_dma_conforms(j) && g.lda == g.M && g.ldb == g.N && tiles > 0 && tiles * (256 / tiles < g.K / 1024 ? 256 / tiles : g.K / 1024) >= 128)
+                return wgrad_single_dma(j, (int)g.ldc, st);
+        }
         const int wcfg = vpf_debug().wgrad_cfg, wtarget = vpf_debug().wgrad_wgs > 0 ? vpf_debug().wgrad_wgs : 512;
         const int tm = wcfg == 0 ? 64 : 128, tn = wcfg == 2 ? 128 : 64;
         if (g.splitk <= 0) {
@@ -954,21 +1001,39 @@ extern "C" int vpf_gemm_h16_fused(const void* A, int a_kstrided, long lda, int a
 
 // dW_i[N_i,K_i] += dY_i[M_i,N_i]^T . X_i[M_i,K_i]  (+ dbias_i[N_i] += column sums of dY_i) for up to 32 problems in one launch
 #define WGROUP_CNT_INTS 1024        // arrival counters at the head of the workspace (zeroed ONCE by the caller; the kernel re-zeroes what it used)
+// does job j fit the LDS-DMA kernel?  (multiples of its 256 x 128 tile and of its 64-token stages, enough tokens to stream)
+static bool wgrad_dma_conforms(const VpfWgradJob& j)
+{
+    const int min_tokens = vpf_debug().wgroup_dma;
+    return min_tokens > 0 && j.M >= min_tokens && j.M > 0 && !(j.N % WGDMA_BM) && !(j.K % WGDMA_BN) && !(j.M % WGDMA_BK) && j.N > 0 && j.K > 0;
+}
+static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long ws_bytes, void* stream, bool dma_ok, int ldc_override = 0);
 extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, long ws_bytes, void* stream)
 {
     (void)hipGetLastError();
     if (!jobs) return VPF_ERR_NULL;
     if (njobs <= 0 || njobs > GEMM_GROUP_MAX) return VPF_ERR_BADSHAPE;
+    // round 5: conforming problems go to the LDS-DMA kernel, the others to the register-staged one -- two launches when a group has both
+    if (vpf_debug().wgroup_dma > 0 && ws == nullptr) {
+        VpfWgradJob a[GEMM_GROUP_MAX], b[GEMM_GROUP_MAX];
+        int na = 0, nb = 0;
+        for (int i = 0; i < njobs; ++i) { if (wgrad_dma_conforms(jobs[i])) a[na++] = jobs[i]; else b[nb++] = jobs[i]; }
+        if (na && nb) {
+            const int rc = wgrad_group_launch(a, na, nullptr, 0, stream, true);
+            return rc != VPF_OK ? rc : wgrad_group_launch(b, nb, nullptr, 0, stream, false);
+        }
+        return wgrad_group_launch(jobs, njobs, ws, ws_bytes, stream, na > 0);
+    }
+    return wgrad_group_launch(jobs, njobs, ws, ws_bytes, stream, false);
+}
+static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long ws_bytes, void* stream, bool dma_ok, int ldc_override)
+{
     GemmGroup grp = {};
     grp.n = njobs;
     const int partial = ws != nullptr;
     // round 5: the LDS-DMA kernel (256 x 128 tiles, one workgroup per CU) when every problem conforms -- multiples of its tile, 64-token
     // stages, the atomics flush -- and the launch is big enough to stream (VPF_WGROUP_DMA: 0 = never, N > 0 = from N tokens per problem on)
-    bool dma = vpf_debug().wgroup_dma > 0 && !partial;
-    for (int i = 0; i < njobs && dma; ++i) {
-        const VpfWgradJob& j = jobs[i];
-        if (j.M < vpf_debug().wgroup_dma || (j.N % WGDMA_BM) || (j.K % WGDMA_BN) || (j.M % WGDMA_BK) || j.M <= 0) dma = false;
-    }
+    const bool dma = dma_ok && !partial;
     const int cfg = dma ? 2 : vpf_debug().wgroup_cfg;
     const int target = vpf_debug().wgroup_wgs > 0 ? vpf_debug().wgroup_wgs : (dma ? 256 : 512);      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     const int tm = dma ? WGDMA_BM : (cfg == 0 ? 64 : 128), tn = dma ? WGDMA_BN : ((cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64));
@@ -984,11 +1049,11 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
         WgDesc& g = grp.d[i];
         // C[m = n_out, n = k_in] += sum over tokens: A = dY read k-strided (rows = N), B = X read k-strided (rows = K)
         g.A = (const h16_t*)j.dy; g.B = (const h16_t*)j.x; g.lda = j.N; g.ldb = j.K;
-        g.M = j.N; g.N = j.K; g.K = j.M; g.mode = EPI_ATOMIC; g.C = j.dW; g.ldc = j.K; g.dbias = j.dbias;
+        g.M = j.N; g.N = j.K; g.K = j.M; g.mode = EPI_ATOMIC; g.C = j.dW; g.ldc = ldc_override > 0 ? ldc_override : j.K; g.dbias = j.dbias;
         const int nx = vpf_cdiv(g.N, tn), ny = vpf_cdiv(g.M, tm);
         // ~`target` workgroups over the whole group, every K slice at least 256 tokens deep
         long sp = target / (total_tiles > 0 ? total_tiles : 1);
-        const long maxs = vpf_cdiv(g.K, 256);
+        const long maxs = vpf_cdiv(g.K, dma ? 1024 : 256);      // (DMA kernel: a slice flushes a 128 KB tile -- at least 16 stages of work in front of it)
         if (sp > maxs) sp = maxs;
         if (sp < 2 && !dma) sp = 2;               // gemm_tile reads splitk > 1 as "blockIdx.z is a K slice"
         if (sp < 1) sp = 1;
@@ -1065,4 +1130,10 @@ extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, lon
     if (cfg == 2) return launch_wgrad_group<2, 2, 2, 2, 64>(grp, at, st);
     if (cfg == 1) return launch_wgrad_group<1, 2, 4, 1, 64>(grp, at, st);
     return launch_wgrad_group<1, 1, 2, 2, 128>(grp, at, st);
+}
+
+// one conforming weight gradient whose dW is a column block of a wider matrix (row pitch ldc): the group launcher with one job
+static int wgrad_single_dma(const VpfWgradJob& j, int ldc, hipStream_t st)
+{
+    return wgrad_group_launch(&j, 1, nullptr, 0, st, true, ldc);
 }
