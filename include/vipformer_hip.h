@@ -335,6 +335,9 @@ typedef struct VpfWgradJob { const void* dy; const void* x; int M, N, K; float* 
  * zeroed ONCE by the caller (arrival counters; the kernel leaves them zero), private to the stream: with it the split-K slices
  * exchange their partial tiles through the workspace and the last-arriving slice of a tile writes dW -- no atomics on dW;
  * without it (or if it is too small) fp32 atomics as before. */
+/* Round 5: problems that are multiples of 256 (N_out) x 128 (K_in) x 64 tokens and have at least VPF_WGROUP_DMA (default 2048) tokens
+ * run the LDS-DMA kernel (csrc/gemm.hip: gemm_wgrad_dma_kernel) when no workspace is given; a group that holds both kinds becomes two
+ * launches on `stream`.  Same results up to the order of the fp32 atomics. */
 int vpf_wgrad_group(const VpfWgradJob* host_jobs, int njobs, void* ws, long ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ fused self-attention layer

@@ -604,12 +604,16 @@ def test_grouped_wgrad_lds_dma_kernel():
     two K slices of 96 and 98 stages) and a whole stack of 28 problems, accumulated INTO non-zero buffers, bias sums on and off, twice
     in a row; a launch with ONE non-conforming problem must take the register-staged kernel and still be right."""
     from vipformer_amd import _lib, ops
-    keep = _lib.debug_get("wgroup_dma")
+    keep, keep_tn = _lib.debug_get("wgroup_dma"), _lib.debug_get("wgroup_dma_tn")
     layer = [(256, 512), (512, 256), (256, 256), (768, 256)]
     try:
         _lib.debug_set("wgroup_dma", 1)
-        for M, shapes in ((12288, layer), (12544, layer), (12288, [(256, 512), (512, 256), (256, 256), (256, 256)] + layer * 6), (320, layer),
-                          (12288, layer + [(64, 128)])):
+        # (tile columns, tokens, problems): 256 x 256 tiles (four stages of 32 tokens) where every K_in allows it, 256 x 128 (three stages of
+        # 64) forced and for a group that holds a 128-column problem
+        for tn, M, shapes in ((0, 12288, layer), (128, 12288, layer), (0, 12544, layer), (128, 12544, layer),
+                              (0, 12288, [(256, 512), (512, 256), (256, 256), (256, 256)] + layer * 6), (0, 320, layer), (128, 320, layer),
+                              (0, 4096, layer + [(256, 128)]), (0, 12288, layer + [(64, 128)])):
+            _lib.debug_set("wgroup_dma_tn", tn)
             jobs = []
             for i, (N, K) in enumerate(shapes):
                 dy, x = bf(rnd(100 + i, M, N)), bf(rnd(200 + i, M, K))
@@ -626,7 +630,7 @@ def test_grouped_wgrad_lds_dma_kernel():
                 if db is not None:
                     assert rel(db, 1.0 + 2.0 * dy.float().sum(0)) < 2e-5, (M, N, K)
     finally:
-        _lib.debug_set("wgroup_dma", keep)
+        _lib.debug_set("wgroup_dma", keep); _lib.debug_set("wgroup_dma_tn", keep_tn)
 
 
 def _grouped_wgrad_cases(ops):

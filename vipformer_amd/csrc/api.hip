@@ -77,6 +77,7 @@ static const VpfDebugKey kDebugKeys[] = {
     {"sa_store", "VPF_SA_STORE", &VpfDebug::sa_store, 0},
     {"sa_tpw", "VPF_SA_TPW", &VpfDebug::sa_tpw, 0},
     {"wgroup_dma", "VPF_WGROUP_DMA", &VpfDebug::wgroup_dma, 2048},
+    {"wgroup_dma_tn", "VPF_WGROUP_DMA_TN", &VpfDebug::wgroup_dma_tn, 128},
 };
 VpfDebug& vpf_debug()
 {

@@ -656,17 +656,26 @@ __device__ __forceinline__ void wg_dma16(const void* gptr, unsigned lds_byte)
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_byte), "v"(gptr) : "memory", "m0");
 }
 #pragma clang diagnostic pop
-#define WGDMA_BM 256
+#define WGDMA_BM 256           // tile rows of every configuration; tile columns: 128 (configuration 0) or 256 (configuration 1)
 #define WGDMA_BN 128
-#define WGDMA_BK 64
-#define WGDMA_NS 3
+#define WGDMA_BK 64            // conforming problems have a multiple of 64 tokens (both configurations' stages divide it)
+// Configurations <TN, BK, NS> on 8 waves (4 x 2), wave tile 64 x 32 TN:
+//   <2, 64, 3>  256 x 128 tiles, three 48 KB stages of 64 tokens                 (any conforming problem)
+//   <4, 32, 4>  256 x 256 tiles, four 32 KB stages of 32 tokens: a third fewer staged bytes (every A row block serves 256 output columns
+//               too) and 0.75 instead of 1 fragment read per MFMA, for twice the flushed tile  (problems whose K_in is a multiple of 256).
+//               Measured: 151.8 vs 148.2 us for the stack launch and +0.06 ms per step (3.404 vs 3.344 ms, three alternating pairs) --
+//               200 registers, half the slices' length, twice the barriers per token.  Kept behind VPF_WGROUP_DMA_TN=0.
+template <int TN, int BK, int NS>
 __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
 {
-    constexpr int BM = WGDMA_BM, BN = WGDMA_BN, BK = WGDMA_BK, NS = WGDMA_NS, TM = 2, TN = 2;
+    constexpr int TM = 2, BM = WGDMA_BM, BN = 64 * TN;
     using ACfg = TileCfg<BM, true, BK>;
     using BCfg = TileCfg<BN, true, BK>;
-    constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;                 // h16 elements per stage (24 576 = 48 KB)
-    constexpr int PER = 6;                                           // DMA instructions per wave and stage: 4 of the A tile, 2 of the B tile
+    constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;                 // h16 elements per stage
+    constexpr int RA = 1024 / (BM * 2), RB = 1024 / (BN * 2);        // k rows per 1 KB DMA wave-instruction
+    constexpr int NA = BK / RA / 8, NB = BK / RB / 8, PER = NA + NB;  // DMA instructions per wave and stage
+    constexpr int KS = BK / 16;                                      // k-steps per stage
+    static_assert(NA * RA * 8 == BK && NB * RB * 8 == BK && PER >= KS, "the copies divide over the waves and the k-steps");
     extern __shared__ __attribute__((aligned(16))) h16_t lds_dma[];
     // ---- which problem, tile and K slice (as gemm_wgrad_group_kernel)
     int p = 0, local = 0, xbz = 0;
@@ -691,37 +700,33 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
     if (grp.xmode) { bz = xbz; bx = local % nx; by = local / nx; }
     else { bx = local % nx; by = (local / nx) % ny; bz = local / (nx * ny); }
     const int m0 = by * BM, n0 = bx * BN;
-    const int per = ((d.K + d.splitk - 1) / d.splitk + BK - 1) / BK * BK;
+    const int per = ((d.K + d.splitk - 1) / d.splitk + WGDMA_BK - 1) / WGDMA_BK * WGDMA_BK;
     const int kbeg = bz * per, kend = min(d.K, kbeg + per);
     if (kbeg >= kend) return;
     const int nk = (kend - kbeg) / BK;
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int wm = wave >> 1, wn = wave & 1;
-    // ---- this lane's part of a stage: element offsets inside the stage's 64 k rows (A: 2 k rows per instruction, B: 4)
-    unsigned offA[4], offB[2];
+    // ---- this lane's part of a stage: element offsets inside the stage's BK k rows
+    unsigned offA[NA], offB[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = wave + 8 * j, kk = 2 * q + (lane >> 5), pos = lane & 31;
+    for (int j = 0; j < NA; ++j) {
+        const int q = wave + 8 * j, kk = RA * q + lane / (64 / RA), pos = lane % (64 / RA);
         offA[j] = (unsigned)kk * (unsigned)d.lda + (unsigned)((pos ^ ((kk & 3) << 2)) * 8);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = wave + 8 * j, kk = 4 * q + (lane >> 4), pos = lane & 15;
+    for (int j = 0; j < NB; ++j) {
+        const int q = wave + 8 * j, kk = RB * q + lane / (64 / RB), pos = lane % (64 / RB);
         offB[j] = (unsigned)kk * (unsigned)d.ldb + (unsigned)((pos ^ ((kk & 3) << 2)) * 8);
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) h16_t*)lds_dma;
     const h16_t* Ag = d.A + (size_t)kbeg * d.lda + m0;
     const h16_t* Bg = d.B + (size_t)kbeg * d.ldb + n0;
-    // copy `pc` (0 .. 3: the A tile, 4 .. 5: the B tile) of stage st
+    // copy `pc` (0 .. NA - 1: the A tile, NA .. PER - 1: the B tile) of stage st
     auto issue_piece = [&](int st, int pc) {
         const unsigned buf = lds0 + (unsigned)(st % NS) * (STAGE * 2);
-        if (pc < 4) wg_dma16(Ag + (size_t)st * BK * d.lda + offA[pc], buf + (unsigned)(wave + 8 * pc) * 1024u);
-        else wg_dma16(Bg + (size_t)st * BK * d.ldb + offB[pc - 4], buf + (unsigned)(ACfg::ELEMS * 2) + (unsigned)(wave + 8 * (pc - 4)) * 1024u);
-    };
-    auto issue = [&](int st) {
-#pragma unroll
-        for (int pc = 0; pc < 6; ++pc) issue_piece(st, pc);
+        if (pc < NA) wg_dma16(Ag + (size_t)st * BK * d.lda + offA[pc < NA ? pc : 0], buf + (unsigned)(wave + 8 * pc) * 1024u);
+        else wg_dma16(Bg + (size_t)st * BK * d.ldb + offB[pc >= NA ? pc - NA : 0], buf + (unsigned)(ACfg::ELEMS * 2) + (unsigned)(wave + 8 * (pc - NA)) * 1024u);
     };
     f32x16_t acc[TM][TN];
 #pragma unroll
@@ -734,7 +739,7 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
     float bsum[TM] = {0.f, 0.f};
 
     // ---- this lane's fragment addresses inside a stage (frag_read's transposing pattern: per 16-lane group a 4 (k) x 16 (row) block;
-    //      the swizzle depends on k & 3 = q only, so ONE base per fragment serves all four k-steps through immediate offsets)
+    //      the swizzle depends on k & 3 = q only, so ONE base per fragment serves all k-steps of a stage through immediate offsets)
     int aoff[TM], boff[TN];
     {
         const int g4 = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, hh = g4 >> 1, ro = 16 * (g4 & 1);
@@ -754,19 +759,29 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
         return __builtin_bit_cast(h16x8_t, v);
     };
 #pragma clang diagnostic pop
-    issue(0);
-    if (nk > 1) issue(1);
+    // ---- NS - 1 stages in flight at the start; per stage: wait for OUR copies of stage kt (the stages behind it may stay in flight:
+    //      vmcnt retires in order), barrier, then stage kt + NS - 1 goes into stage kt - 1's buffer between the k-steps' products
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) {
+#pragma unroll
+            for (int pc = 0; pc < PER; ++pc) issue_piece(st, pc);
+        }
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // (= PER: the copies of stage kt + 1 may stay in flight)
+        const int ahead = min(NS - 2, nk - 1 - kt);               // stages behind kt whose copies are in flight
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS > 3 ? 2 * PER : 0) : "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PER) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const bool more = kt + 2 < nk;       // stage kt + 2 goes into stage kt - 1's buffer: its copies are issued BETWEEN the k-steps' products
+        const bool more = kt + NS - 1 < nk;
         // ONE address register per fragment and stage (opaque to the optimiser: otherwise it keeps 26 per-read lane offsets in registers
         // and adds the stage base to each with two VALU instructions per read); the k-steps are immediate offsets of the reads
         const unsigned cS = lds0 + (unsigned)(kt % NS) * (STAGE * 2);
-        unsigned pa[TM] = {cS + (unsigned)aoff[0] * 2u, cS + (unsigned)aoff[1] * 2u};
-        unsigned pb[TN] = {cS + (unsigned)boff[0] * 2u, cS + (unsigned)boff[1] * 2u};
-        asm volatile("" : "+v"(pa[0]), "+v"(pa[1]), "+v"(pb[0]), "+v"(pb[1]));
+        unsigned pa[TM], pb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { pa[i] = cS + (unsigned)aoff[i] * 2u; asm volatile("" : "+v"(pa[i])); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { pb[j] = cS + (unsigned)boff[j] * 2u; asm volatile("" : "+v"(pb[j])); }
         // the fragments of k-step s + 1 are requested in front of the products of k-step s
         h16x8_t fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -774,16 +789,16 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[0][j] = frag(pb[j], BCfg::LD, 0);
 #pragma unroll
-        for (int s = 0; s < BK / 16; ++s) {
-            if (s + 1 < BK / 16) {
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[(s + 1) & 1][i] = frag(pa[i], ACfg::LD, s + 1);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[(s + 1) & 1][j] = frag(pb[j], BCfg::LD, s + 1);
             }
-            if (more) {                      // (6 copies over 4 k-steps: 2, 2, 1, 1 -- the matrix cores start right behind the barrier)
-                if (s < 2) { issue_piece(kt + 2, 2 * s); issue_piece(kt + 2, 2 * s + 1); }
-                else issue_piece(kt + 2, s + 2);
+            if (more) {                      // the PER copies spread over the KS k-steps: the matrix cores start right behind the barrier
+#pragma unroll
+                for (int pc = s * PER / KS; pc < (s + 1) * PER / KS; ++pc) issue_piece(kt + NS - 1, pc);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -802,7 +817,6 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
         }
         // (the LDS reads of this stage are complete before a wave's MFMAs consume them, i.e. before it reaches the next barrier)
     }
-    static_assert(PER == 6, "the vmcnt immediate above");
     // ---- flush: bias sums, then fp32 atomics straight from the accumulators (128-byte row segments), as gemm_tile
     const int col_l = lane & 31, rsub = 4 * (lane >> 5);
     if (do_bias) {
@@ -826,18 +840,24 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
             }
         }
 }
-static int launch_wgrad_dma(const GemmGroup& grp, int nblocks, hipStream_t st)
+template <int TN, int BK, int NS>
+static int launch_wgrad_dma_cfg(const GemmGroup& grp, int nblocks, hipStream_t st)
 {
-    constexpr size_t lds = sizeof(h16_t) * WGDMA_NS * (TileCfg<WGDMA_BM, true, WGDMA_BK>::ELEMS + TileCfg<WGDMA_BN, true, WGDMA_BK>::ELEMS);
-    static_assert(lds <= 160 * 1024, "three stages must fit the CU's LDS");
+    constexpr size_t lds = sizeof(h16_t) * NS * (TileCfg<WGDMA_BM, true, BK>::ELEMS + TileCfg<64 * TN, true, BK>::ELEMS);
+    static_assert(lds <= 160 * 1024, "the stages must fit the CU's LDS");
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)gemm_wgrad_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)gemm_wgrad_dma_kernel<TN, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL(gemm_wgrad_dma_kernel, dim3(nblocks), dim3(512), lds, st, grp);
+    hipLaunchKernelGGL((gemm_wgrad_dma_kernel<TN, BK, NS>), dim3(nblocks), dim3(512), lds, st, grp);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
+}
+static int launch_wgrad_dma(const GemmGroup& grp, int nblocks, int tn, hipStream_t st)
+{
+    if (tn == 256) return launch_wgrad_dma_cfg<4, 32, 4>(grp, nblocks, st);
+    return launch_wgrad_dma_cfg<2, 64, 3>(grp, nblocks, st);
 }
 
 template <int TM, int TN, int WM, int WN, int BK, int PF = 1, bool PAIR = false>
@@ -1036,7 +1056,15 @@ static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long
     const bool dma = dma_ok && !partial;
     const int cfg = dma ? 2 : vpf_debug().wgroup_cfg;
     const int target = vpf_debug().wgroup_wgs > 0 ? vpf_debug().wgroup_wgs : (dma ? 256 : 512);      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
-    const int tm = dma ? WGDMA_BM : (cfg == 0 ? 64 : 128), tn = dma ? WGDMA_BN : ((cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64));
+    // DMA kernel: 256 x 256 tiles when every problem's K_in is a multiple of 256 (VPF_WGROUP_DMA_TN = 128 / 256 forces one), else 256 x 128
+    int dma_tn = WGDMA_BN;
+    if (dma) {
+        bool all256 = true;
+        for (int i = 0; i < njobs; ++i) if (jobs[i].K % 256) all256 = false;
+        const int want = vpf_debug().wgroup_dma_tn;
+        dma_tn = (all256 && want != 128) ? 256 : 128;
+    }
+    const int tm = dma ? WGDMA_BM : (cfg == 0 ? 64 : 128), tn = dma ? dma_tn : ((cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64));
     const bool pair = cfg == 8 && !partial && !dma;          // two K slices per 8-wave workgroup: half the flush atomics (round 3)
     long total_tiles = 0;
     for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
@@ -1108,7 +1136,7 @@ static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long
     grp.uneven = dma ? 0 : vpf_debug().wgroup_uneven;      // (one workgroup per CU in ONE round: equal slices end together)
     grp.dbg = vpf_debug().wgroup_dbg;
     hipStream_t st = (hipStream_t)stream;
-    if (dma) return launch_wgrad_dma(grp, at, st);
+    if (dma) return launch_wgrad_dma(grp, at, tn, st);
     // workspace split-K (EPI_PARTIAL) when the caller handed over enough scratch: [counters | one tm x tn f32 tile per workgroup]
     if (partial && ws && total_tiles <= WGROUP_CNT_INTS && ws_bytes >= (long)(WGROUP_CNT_INTS * 4 + (size_t)at * tm * tn * 4) && !((uintptr_t)ws & 15)) {
         float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + WGROUP_CNT_INTS * 4);
