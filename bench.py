@@ -61,10 +61,10 @@ PEAK_H16_TFLOPS = 2500.0      # MI355X dense h16 MFMA (guide: MI355X_MICROARCH.m
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
 # whole-step budgets (tools/collect_step_bytes.sh: kernel trace + FETCH_SIZE + WRITE_SIZE passes of this very command, folded per
 # kernel over the last whole steps): launches per step, in-step average duration, HBM bytes per launch IN THE STEP
-PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r04_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r04_step_bytes_c3.json"),
-                "c4": os.path.join(ROOT, "profiles", "r04_step_bytes_c4.json"), "ref144": os.path.join(ROOT, "profiles", "r04_step_bytes_ref144.json"),
-                "ref144m4": os.path.join(ROOT, "profiles", "r04_step_bytes_ref144m4.json")}
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels (tools/collect_profiles.sh)
+PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r05_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r05_step_bytes_c3.json"),
+                "c4": os.path.join(ROOT, "profiles", "r05_step_bytes_c4.json"), "ref144": os.path.join(ROOT, "profiles", "r05_step_bytes_ref144.json"),
+                "ref144m4": os.path.join(ROOT, "profiles", "r05_step_bytes_ref144m4.json")}
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels (tools/collect_profiles.sh)
 
 
 def synth_batch(b, N, img, seed, device, dups=False):
@@ -196,9 +196,10 @@ def kernel_legs(device, a, pairs):
 
     us = _events(wstack, 10, 3)
     sbytes = sum(2.0 * M * (Nn + Kk) + 4.0 * Nn * Kk for Nn, Kk in stack_shapes)
-    legs["gemm_wgrad_group_kernel"] = _leg("gemm_wgrad_group_kernel", us, sbytes, sum(2.0 * M * Nn * Kk for Nn, Kk in stack_shapes), "hbm",
+    legs["gemm_wgrad_group_kernel"] = _leg("gemm_wgrad_dma_kernel", us, sbytes, sum(2.0 * M * Nn * Kk for Nn, Kk in stack_shapes), "hbm",
                                            f"{len(stack_shapes)} weight gradients of the point-cloud encoder stack in ONE launch (what the step "
-                                           f"launches), {M} tokens: operands read once + dW written once")
+                                           f"launches), {M} tokens: operands read once + dW written once; LDS-DMA staging (round 5); eager timing, "
+                                           f"host-bound by its 28 job descriptors: the device-side duration is in profiles/r05_wgrad_dma_ab.txt")
     # ---- fused encoder-layer tail (o_proj .. MLP .. next layer's LayerNorm + q/k/v): 9232 B and 2*256*2048 flop per token at D = 256
     layers = nn.ModuleList([SelfAttentionLayer(H, D, a["MR"], 0.0, 0.1, 0.5) for _ in range(2)]).to(device)
     layers.train()
@@ -321,7 +322,8 @@ def _pmc():
 PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step budget whose per-launch figures add up to one "launch" of the leg
     "fps_kernel": ["fps_kernel"],
     "knn_group_select_kernel": ["knn_group_select_kernel"],
-    "gemm_wgrad_group_kernel": ["gemm_wgrad_group_kernel"],                # the stack-sized leg: the launch the step makes
+    "gemm_wgrad_group_kernel": ["gemm_wgrad_dma_kernel"],                  # the stack-sized leg: the launch the step makes (round 5: the LDS-DMA kernel; its in-step
+                                                                           # average also covers the K / V projection's and Group2Emb's dW3 launches of that kernel)
     "gemm_wgrad_group_kernel (one layer)": [],                             # (no such launch in the step: stand-alone figures only)
     "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel", "sa_rows_fwd_kernel"],
     "sa_bwd_qkv_mlp_rows_kernel": ["sa_bwd_qkv_mlp_rows_kernel"],
@@ -936,6 +938,11 @@ def main():
                     hbm_frac=d.get("hbm_frac_in_step", d["hbm_frac"]), mfma_frac=d.get("mfma_frac_in_step", d["mfma_frac"]),
                     bytes_per_launch=d["bytes_per_launch"], flops_per_launch=d["flops_per_launch"],
                     share_of_step_kernel_time=d.get("share_of_step_kernel_time"), profile_build_id=prof.get("build_id"),
+                    binds=("neither roof: `bound` names the NEARER one.  A 64-token row block is a dependent chain of ~8 product units, ~12 barriers "
+                           "and the VALU epilogues between them (27 us for 32 tokens, 35 us for 64), and a CU turns over 64 tokens in ~37 us "
+                           "however the work is cut (8 waves, 16 waves in lockstep, two decoupled 8-wave groups, two workgroups per CU); no unit "
+                           "is saturated -- VALU issue 43 %, LDS 40 %, load return 55 %, MFMA 21 % of a CU's cycles stand-alone (NOTES.md round 5)"
+                           if "sa_layer_fwd" in d["kernel"] or "sa_rows_fwd" in d["kernel"] else None),
                     source=("frac = algorithmic bytes over the kernel's IN-STEP average duration, traffic = its in-step HBM bytes (FETCH_SIZE x 2 + "
                             "WRITE_SIZE), both from " + os.path.relpath(PROFILE_STEP[args.arch], ROOT) + " (rocprofv3 passes of this command with "
                             "this build of the library, tools/collect_step_bytes.sh); *_standalone_live: timed in this run, a hipGraph of "
