@@ -5,7 +5,7 @@
 # guide's HBM recipe -- FETCH_SIZE and WRITE_SIZE cannot share a pass) over the stand-alone kernel harness (tools/microbench.py).
 tag=${1:-r02}
 export TMPDIR=/tmp
-out=$PWD/gpurun_out/prof_$tag
+out=${VPF_SCRATCH:-$PWD/gpurun_out}/prof_$tag
 mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-kernels > $out/bench.log 2>&1
 tail -1 $out/bench.log | cut -c1-200

@@ -6,7 +6,7 @@
 tag=${1:-r03}
 arch=${2:-c2}
 export TMPDIR=/tmp
-out=$PWD/gpurun_out/stepbytes_${tag}_$arch
+out=${VPF_SCRATCH:-$PWD/gpurun_out}/stepbytes_${tag}_$arch
 mkdir -p $out
 python3 bench.py --arch $arch --steps 30 --warmup 5 --no-cpu-baseline --no-kernels --no-variants > $out/plain.log 2>&1
 ms=$(tail -1 $out/plain.log | python3 -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])")

@@ -5,7 +5,7 @@
 tag=${1:-r03}
 arch=${2:-c2}
 export TMPDIR=/tmp
-out=$PWD/gpurun_out/stepissue_${tag}_$arch
+out=${VPF_SCRATCH:-$PWD/gpurun_out}/stepissue_${tag}_$arch
 mkdir -p $out
 i=0
 for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \

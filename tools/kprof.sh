@@ -4,7 +4,7 @@ tag=$1; sub=$2; shift 2
 envs=()
 while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
 export TMPDIR=/tmp
-out=$PWD/gpurun_out/kprof_$tag
+out=${VPF_SCRATCH:-$PWD/gpurun_out}/kprof_$tag
 rm -rf $out; mkdir -p $out
 for e in "${envs[@]}"; do export "$e"; done
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -o k -- python3 tools/microbench.py "$@" > $out/log.txt 2>&1

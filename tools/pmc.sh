@@ -2,7 +2,7 @@
 # usage: tools/pmc.sh <tag> "<counters>" <microbench target>
 tag=$1; ctr=$2; shift 2
 export TMPDIR=/tmp
-out=$PWD/gpurun_out/pmc_$tag
+out=${VPF_SCRATCH:-$PWD/gpurun_out}/pmc_$tag
 mkdir -p $out
 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out -o $tag -- python3 tools/microbench.py "$@" > $out/log.txt 2>&1
 tail -3 $out/log.txt

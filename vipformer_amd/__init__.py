@@ -5,7 +5,7 @@ Hand-written HIP kernels behind the reference's own Python interfaces
 include/vipformer_hip.h.  There is no CPU / eager fallback: every op raises
 ``vipformer_amd._lib.VpfError`` if libvipformer_hip.so is missing or given CPU tensors.
 """
-__version__ = "0.2.0"
+__version__ = "0.3.0"
 
 # names of the reference that this package implements, per reference module
 _OVERLAY = {

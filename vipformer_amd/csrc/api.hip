@@ -78,6 +78,7 @@ static const VpfDebugKey kDebugKeys[] = {
     {"sa_tpw", "VPF_SA_TPW", &VpfDebug::sa_tpw, 0},
     {"wgroup_dma", "VPF_WGROUP_DMA", &VpfDebug::wgroup_dma, 2048},
     {"wgroup_dma_tn", "VPF_WGROUP_DMA_TN", &VpfDebug::wgroup_dma_tn, 128},
+    {"wgroup_dma_ramp", "VPF_WGROUP_DMA_RAMP", &VpfDebug::wgroup_dma_ramp, 50},
 };
 VpfDebug& vpf_debug()
 {

@@ -700,8 +700,24 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
     if (grp.xmode) { bz = xbz; bx = local % nx; by = local / nx; }
     else { bx = local % nx; by = (local / nx) % ny; bz = local / (nx * ny); }
     const int m0 = by * BM, n0 = bx * BN;
-    const int per = ((d.K + d.splitk - 1) / d.splitk + WGDMA_BK - 1) / WGDMA_BK * WGDMA_BK;
-    const int kbeg = bz * per, kend = min(d.K, kbeg + per);
+    int kbeg, kend;
+    if (grp.uneven > 0 && d.splitk >= 16) {
+        // Many slices of ONE or a few tiles (a single weight gradient over 10^5 tokens and more): equal slices end together and their
+        // 128 KB flushes -- 33 MB of fp32 atomics at ~1.3 TB/s, all onto the same tile -- queue up behind the last stage (26 us of a
+        // 70 us launch).  A linear RAMP of slice lengths, (1 - r) .. (1 + r) x the mean with r = uneven / 100, lets the early finishers'
+        // flushes drain under the others' stages.  Boundaries in whole 64-token stages: f(z) = T z ((1 - r) + r (z - 1) / (S - 1)) / S.
+        const long T = d.K / WGDMA_BK, S = d.splitk;
+        auto f = [&](long z) -> long {
+            const double r = 0.01 * grp.uneven;
+            const double v = (double)T * (double)z * ((1.0 - r) + r * (double)(z - 1) / (double)(S - 1)) / (double)S;
+            long q = (long)(v + 0.5);
+            return q < 0 ? 0 : (q > T ? T : q);
+        };
+        kbeg = (int)(f(bz) * WGDMA_BK); kend = bz + 1 == S ? d.K : (int)(f(bz + 1) * WGDMA_BK);
+    } else {
+        const int per = ((d.K + d.splitk - 1) / d.splitk + WGDMA_BK - 1) / WGDMA_BK * WGDMA_BK;
+        kbeg = bz * per; kend = min(d.K, kbeg + per);
+    }
     if (kbeg >= kend) return;
     const int nk = (kend - kbeg) / BK;
 
@@ -1133,7 +1149,7 @@ static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long
     // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at
     // different times, and one's atomic flush (L2 atomic units) overlaps the other's staging (L2 read bandwidth) instead of all
     // 512 workgroups flushing together at the end (-0.035 ms/step, 15 launches)
-    grp.uneven = dma ? 0 : vpf_debug().wgroup_uneven;      // (one workgroup per CU in ONE round: equal slices end together)
+    grp.uneven = dma ? vpf_debug().wgroup_dma_ramp : vpf_debug().wgroup_uneven;      // (DMA kernel: a ramp of slice lengths, in percent, for launches of >= 16 slices)
     grp.dbg = vpf_debug().wgroup_dbg;
     hipStream_t st = (hipStream_t)stream;
     if (dma) return launch_wgrad_dma(grp, at, tn, st);
