@@ -1,18 +1,17 @@
 #!/bin/bash
-# round 5 profile pipeline, part 1: whole-step byte budget + issue counters + stand-alone PMC summary + timeline + the bench line (c2)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export TMPDIR=/tmp VPF_SCRATCH=/tmp/vpf_prof
-mkdir -p $VPF_SCRATCH
+export TMPDIR=/tmp
 {
-bash tools/collect_step_bytes.sh r05 c2
-cp gpurun_out/r05_step_bytes.json profiles/r05_step_bytes.json
-bash tools/collect_step_issue.sh r05 c2
-bash tools/collect_profiles.sh r05
-cp gpurun_out/r05_pmc_summary.json profiles/r05_pmc_summary.json
-python3 tools/step_timeline.py > gpurun_out/r05_step_timeline_c2.txt 2>/dev/null; tail -30 gpurun_out/r05_step_timeline_c2.txt
-python3 bench.py > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err
-tail -1 gpurun_out/r05_bench_default.json | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['median_ms_200'], d['roofline']['frac'], d['roofline']['frac_is'], d['cpu_baseline']['value'])"
-du -sh gpurun_out
-} > gpurun_out/r05_pipeline1.txt 2>&1
-tail -40 gpurun_out/r05_pipeline1.txt
+echo "== tests"; timeout 1500 python3 -m pytest tests/test_modules_gpu.py tests/test_kernels_gpu.py -x -q -k "stages_vs_reference_golden or models_vs_reference_golden or group2emb or g2e or training_step_with_dropout" 2>&1 | tail -5
+bash tools/kprof.sh g2e3 "g2e" X=1 -- g2e > /dev/null 2>&1
+f=$(find gpurun_out/kprof_g2e3 -name "*kernel_stats.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'g2e' in r['Name'] and float(r['AverageNs'])>20000: print(r['Calls'], 'avg us', round(float(r['AverageNs'])/1e3,1), r['Name'][:60])
+PY
+timeout 300 python3 tools/microbench.py g2e 2>&1 | grep "pass "
+echo "== code A/B: base2 vs tree"; bash tools/ab_code.sh base2 3
+} > gpurun_out/r05_p0dma.txt 2>&1
+cat gpurun_out/r05_p0dma.txt | grep -v amdgpu.ids
