@@ -591,13 +591,6 @@ struct G2eBwd {
 // KSC (round 4): the number of 16-wide k-steps of the dh4 . W4 product as a template parameter (16 at Dm = 256; 0 = read Dm at run time).
 // With `ks < Dm / 16` tested at run time every k-step was its own basic block -- two LDS reads, a wait for them, two MFMAs, a branch --
 // and nothing of step ks + 1 could be issued under step ks (tools/inst_mix.py: 16 x "LLWMWM s_cbranch").
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"          // (m0 is a reserved register: it is what the instruction takes its LDS address from)
-__device__ __forceinline__ void g2e_dma16(const void* gptr, unsigned lds_byte)
-{
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_byte), "v"(gptr) : "memory", "m0");
-}
-#pragma clang diagnostic pop
 template <int PASS, int KSC>
 __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
 {
@@ -605,21 +598,6 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     h16_t* sD4 = smem;                         // [64][H3LD]  dh4 tile (Dm <= 256), later dh2 staging
     h16_t* sH3 = smem + 64 * H3LD;             // [64][H3LD]  h3, overwritten by dh3
     h16_t* sW3 = sH3 + 64 * H3LD;              // PASS 1: W3b^T in MFMA fragment order, [4 column tiles][16 k-steps][64 lanes] x 16 B = 64 KB
-    // PASS 0 (round 5): the h3 tile arrives by LDS-DMA into one of TWO unpadded [64][256] tiles behind sD4 (the epilogue's two-byte
-    // reads of it are conflict-free at any pitch).  In-kernel stamps had 49 % of a workgroup's cycles in "stage + barrier": the tile
-    // of the next pair was requested into registers behind the MFMAs -- one BatchNorm epilogue ahead of its store, the kernel has no
-    // registers for more -- and every pair waited for it.  The DMA of pair pr + G is issued right behind pair pr's staging barrier.
-    h16_t* sH3d = smem + 64 * H3LD;            // PASS 0: [2][64][256]
-    const unsigned h3d0 = (unsigned)(size_t)(__attribute__((address_space(3))) h16_t*)sH3d;
-    const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    auto dma_h3 = [&](long pq, int buf) {       // the 32 KB tile of pair pq is contiguous in HBM: wave w copies 1 KB pieces w, w + 8, w + 16, w + 24
-        const long r0 = pq * 64, nr = min((long)64, p.NG * 32 - r0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = wvu + 8 * j;          // rows 2 q, 2 q + 1
-            if (2 * q < nr) g2e_dma16(p.h3 + (size_t)r0 * 256 + (size_t)(q * 64 + (int)(threadIdx.x & 63)) * 8, h3d0 + (unsigned)buf * (64 * 256 * 2) + (unsigned)q * 1024u);
-        }
-    };
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, hl = lane >> 5, l31 = lane & 31;
     if (PASS == 1) {
         // (64 more live registers would spill, and fetched from L2 inside the loop every pair paid that latency in front of
@@ -660,12 +638,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             rh[i] = (pr < npairs && row < nr) ? *reinterpret_cast<const uint4*>(p.h3 + (size_t)(r0 + row) * 256 + ch * 8) : make_uint4(0, 0, 0, 0);
         }
     };
-    if (PASS == 0) {
-        for (int e = threadIdx.x; e < 2 * 64 * 256 / 8; e += 512) reinterpret_cast<uint4*>(sH3d)[e] = make_uint4(0, 0, 0, 0);   // (rows a ragged last pair does not write stay finite)
-        __syncthreads();
-        if ((long)blockIdx.x < npairs) dma_h3(blockIdx.x, 0);
-    } else load_h3(blockIdx.x);
-    int hbuf = 0;
+    load_h3(blockIdx.x);
     uint2 nar = make_uint2(0xffffffffu, 0xffffffffu);
     float4 nd0 = make_float4(0.f, 0.f, 0.f, 0.f), nd1 = nd0;
     auto load_d4 = [&](long pq) {
@@ -716,15 +689,12 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             }
         }
         // ---- stage h3 (requested at the end of the previous iteration, ahead of that iteration's stores)
-        if (PASS == 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = t + i * 512, row = c >> 5, ch = c & 31;
-                *reinterpret_cast<uint4*>(sH3 + row * H3LD + ch * 8) = rh[i];
-            }
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's copies of the pair's tile (issued a whole iteration ago) have landed
+        for (int i = 0; i < 4; ++i) {
+            const int c = t + i * 512, row = c >> 5, ch = c & 31;
+            *reinterpret_cast<uint4*>(sH3 + row * H3LD + ch * 8) = rh[i];
+        }
         __syncthreads();
-        if (PASS == 0 && pr + gridDim.x < npairs) dma_h3(pr + gridDim.x, hbuf ^ 1);      // (the other tile: its pair ended at the last barrier)
         STAMP(0);
         // ---- da3 tile (columns w*32.., both row tiles)
         f32x16_t acc[2];
@@ -739,7 +709,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             }
         STAMP(1);
         load_d4(pr + gridDim.x);
-        // (PASS 0 until round 4: load_h3(pr + gridDim.x) here, into registers)
+        if (PASS == 0) load_h3(pr + gridDim.x);        // (requested in front of the MFMAs instead: 198 k -> 214 k cycles per workgroup, measured again in round 3)
         float gsum[2] = {0.f, 0.f};
         // one row tile at a time: its 16 h3 values of this lane first (independent LDS reads in flight together), then the
         // math, then the stores (both row tiles at once held 64 registers here and the kernel spilled)
@@ -747,9 +717,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
         for (int rt = 0; rt < 2; ++rt) {
             h16_t hraw[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                hraw[r] = PASS == 0 ? sH3d[hbuf * (64 * 256) + (rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * 256 + col]
-                                    : sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col];
+            for (int r = 0; r < 16; ++r) hraw[r] = sH3[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hl) * H3LD + col];
             h16_t dres[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -817,7 +785,6 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             }
         }
         __syncthreads();
-        hbuf ^= 1;
         STAMP(5);
     }
     if (p.dbg && t == 0) { for (int i = 0; i < 6; ++i) p.dbg[(size_t)(blockIdx.x * 2 + PASS) * 6 + i] = ph[i]; }
@@ -841,8 +808,7 @@ extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long 
     if (NG <= 0 || Dm <= 0 || Dm > 256 || (Dm % 16)) return VPF_ERR_BADSHAPE;
     G2eBwd p = {dout, arg4, Dm, NG, (const h16_t*)h3_h16, stat2, gamma2, beta2, (const h16_t*)w4t_h16, (const h16_t*)w3bt_h16, tmp512_zeroed,
                 1.0f / (float)(NG * 32), training, (h16_t*)dh3_h16, dgb, (h16_t*)dh2_h16, dbg, (h16_t*)dgb_h16, db3, dgamma2, dbeta2};
-    const size_t lds1 = sizeof(h16_t) * 2 * 64 * H3LD + 64 * 1024;                 // pass 1: two padded tiles + W3b^T (64 KB)
-    const size_t lds = sizeof(h16_t) * (64 * H3LD + 2 * 64 * 256);                 // pass 0: the dh4 tile + two unpadded h3 tiles filled by LDS-DMA
+    const size_t lds = sizeof(h16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
         for (const void* f : {(const void*)g2e_bwd_kernel<0, 0>, (const void*)g2e_bwd_kernel<0, 16>})
