@@ -244,16 +244,14 @@ int vpf_g2e_fwd_b(const void* h3_h16, long NG, const float* ab2, const void* w4_
 /* Group2Emb backward, group_size == 32:
  *   vpf_g2e_wgrad4: dW4 / db4 from the max-pool gradient (ONE non-zero per (group, column): 32x less work than a dense wgrad)
  *   vpf_g2e_bwd (Dm <= 256): conv4 dgrad on MFMA from the rebuilt gradient tile, BatchNorm-2 backward (two passes), dh3, the
- *                per-group sums dgb and dh2 = dh3 . W3[:,128:]  (w4t = W4^T [256,Dm], w3bt = W3[:,128:]^T [128,256], h16);
- *                dgb leaves as f32 (dgb, nullable) and / or h16 (dgb_h16, nullable; at least one), its column sums -- conv3's bias
- *                gradient, utils.py:153-165 -- are ADDED to db3 when given, BatchNorm-2's parameter gradients to dgamma2 / dbeta2
+ *                per-group sums dgb and dh2 = dh3 . W3[:,128:]  (w4t = W4^T [256,Dm], w3bt = W3[:,128:]^T [128,256], h16)
  *   vpf_transpose_h16: dst[c][r] = src[r][c] */
 int vpf_g2e_wgrad4(const void* h3_h16, long NG, const float* ab2, const float* dout, const uint8_t* arg4, int Dm,
                    float* dW4, float* db4, void* stream);
 int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_h16, const float* stat2,
                 const float* gamma2, const float* beta2, const void* w4t_h16, const void* w3bt_h16, int training,
                 float* tmp512_zeroed, void* dh3_h16, float* dgb, void* dh2_h16, float* dgamma2, float* dbeta2,
-                long long* dbg_cycles /* nullable diagnostic: [256*2*6] per-phase cycle sums */, void* dgb_h16, float* db3, void* stream);
+                long long* dbg_cycles /* nullable diagnostic: [256*2*6] per-phase cycle sums */, void* stream);
 int vpf_transpose_h16(const void* src, long ld, int R, int C, void* dst, void* stream);
 /* torch.max over the K group members (utils.py:180,188): h h16 [NG,K,C] -> out [NG,C], arg uint8 (first max) */
 int vpf_group_max_fwd(const void* h_h16, long NG, int K, int C, void* out, int out_is_h16, uint8_t* arg, void* stream);

@@ -98,7 +98,7 @@ SIGS = {
     "vpf_g2e_fwd_a": [VP, L_, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP],
     "vpf_g2e_fwd_b": [VP, L_, VP, VP, VP, I, VP, VP, VP],
     "vpf_g2e_wgrad4": [VP, L_, VP, VP, VP, I, VP, VP, VP],
-    "vpf_g2e_bwd": [VP, VP, I, L_, VP, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, VP, VP, VP, VP],
+    "vpf_g2e_bwd": [VP, VP, I, L_, VP, VP, VP, VP, VP, VP, I, VP, VP, VP, VP, VP, VP, VP, VP],
     "vpf_grad_check": [VP, L_, VP, VP],
     "vpf_transpose_h16": [VP, L_, I, I, VP, VP],
     "vpf_group_max_fwd": [VP, L_, I, I, VP, I, VP, VP],

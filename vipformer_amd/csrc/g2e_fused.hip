@@ -442,71 +442,61 @@ __global__ void __launch_bounds__(512) g2e_wgrad4_kq_kernel(G2eW4 p)
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc[j] = 0.f;
     float accb = 0.f;
-    // Round 5: W4_PF steps of loads in flight.  A step is ~130 FMAs and 16 LDS reads per thread (~0.4 us) in front of an L2 / HBM round
-    // trip of ~2 us: with ONE step in flight (rounds 1 - 4) every step waited for its loads -- 1.8 us per step, 88 us for 48 steps.  The
-    // register sets cost 12 registers each; the LDS tiles stay double-buffered (a set is committed one step ahead of its use).
-    constexpr int W4_PF = 4;
-    uint4 hv[W4_PF][2];
-    float dn[W4_PF][2];
-    uint8_t rn[W4_PF][2];
-    auto request = [&](int set, long g0) {
+    uint4 hv[2];
+    float dn[2];
+    uint8_t rn[2];
+    auto request = [&](long g0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = t + i * 512, j = c >> 8, row = (c >> 3) & 31, ch = c & 7;
             const long gg = g0 + j;
-            hv[set][i] = gg < p.NG ? *reinterpret_cast<const uint4*>(p.h3 + ((size_t)gg * 32 + row) * 256 + kq * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
+            hv[i] = gg < p.NG ? *reinterpret_cast<const uint4*>(p.h3 + ((size_t)gg * 32 + row) * 256 + kq * 64 + ch * 8) : make_uint4(0, 0, 0, 0);
             const int col = c & 255, nn = nblk * 256 + col;
             const bool ok = nn < p.Dm && gg < p.NG;
-            dn[set][i] = ok ? p.dout[(size_t)gg * p.Dm + nn] : 0.f;
-            rn[set][i] = ok ? p.arg4[(size_t)gg * p.Dm + nn] : 0;
+            dn[i] = ok ? p.dout[(size_t)gg * p.Dm + nn] : 0.f;
+            rn[i] = ok ? p.arg4[(size_t)gg * p.Dm + nn] : 0;
         }
     };
-    auto commit = [&](int set, int buf) {
+    auto commit = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = t + i * 512, j = c >> 8, row = (c >> 3) & 31, ch = c & 7;
-            uint32_t u[4] = {hv[set][i].x, hv[set][i].y, hv[set][i].z, hv[set][i].w};
+            uint32_t u[4] = {hv[i].x, hv[i].y, hv[i].z, hv[i].w};
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 u[q] = pack_h16x2(fmaxf(fmaf(aa[2 * q], h16_lo(u[q]), bb[2 * q]), 0.f),
                                    fmaxf(fmaf(aa[2 * q + 1], h16_hi(u[q]), bb[2 * q + 1]), 0.f));
             *reinterpret_cast<uint4*>(&sA3[buf][(j * 32 + row) * W4_KLD + ch * 8]) = make_uint4(u[0], u[1], u[2], u[3]);
-            sD[buf][j][c & 255] = dn[set][i]; sR[buf][j][c & 255] = rn[set][i];
+            sD[buf][j][c & 255] = dn[i]; sR[buf][j][c & 255] = rn[i];
         }
     };
     long g0 = (long)blockIdx.x * W4_G;
     const long gstep = (long)gridDim.x * W4_G;
     int buf = 0;
-#pragma unroll
-    for (int u = 0; u < W4_PF; ++u) request(u, g0 + u * gstep);          // (groups beyond NG read nothing and stage zeros)
-    commit(0, 0);
+    if (g0 < p.NG) { request(g0); commit(0); }
     __syncthreads();
-    for (; g0 < p.NG; g0 += W4_PF * gstep) {
+    for (; g0 < p.NG; g0 += gstep) {
+        const long gn = g0 + gstep;
+        if (gn < p.NG) request(gn);
 #pragma unroll
-        for (int u = 0; u < W4_PF; ++u) {                                 // step g0 + u gstep: its tile is in LDS buffer `buf`, register set u is free
-            const long g = g0 + u * gstep;
-            if (g >= p.NG) break;
-            request(u, g + W4_PF * gstep);
+        for (int j = 0; j < W4_G; ++j) {
+            const float d = sD[buf][j][nl];
+            const h16_t* row = &sA3[buf][(j * 32 + (int)sR[buf][j][nl]) * W4_KLD + kh * 32];
+            if (kh == 0) accb += d;
 #pragma unroll
-            for (int j = 0; j < W4_G; ++j) {
-                const float d = sD[buf][j][nl];
-                const h16_t* row = &sA3[buf][(j * 32 + (int)sR[buf][j][nl]) * W4_KLD + kh * 32];
-                if (kh == 0) accb += d;
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = *reinterpret_cast<const uint4*>(row + q * 8);
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(row + q * 8);
-                    const uint32_t uu[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc[q * 8 + 2 * e] = fmaf(d, h16_lo(uu[e]), acc[q * 8 + 2 * e]);
-                        acc[q * 8 + 2 * e + 1] = fmaf(d, h16_hi(uu[e]), acc[q * 8 + 2 * e + 1]);
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    acc[q * 8 + 2 * e] = fmaf(d, h16_lo(u[e]), acc[q * 8 + 2 * e]);
+                    acc[q * 8 + 2 * e + 1] = fmaf(d, h16_hi(u[e]), acc[q * 8 + 2 * e + 1]);
                 }
             }
-            if (g + gstep < p.NG) commit((u + 1) % W4_PF, buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
         }
+        if (gn < p.NG) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
     // flush: [256 n] x [64 k] through LDS in two halves of 128 rows, added as 256-byte row segments (64 lanes = 64 consecutive k)
     float* tile = reinterpret_cast<float*>(&sA3[0][0]);            // 128 x 64 f32 = 32 KB <= 2 x 128 x 72 x 2 B
@@ -582,10 +572,6 @@ struct G2eBwd {
     float invM; int training;
     h16_t* dh3; float* dgb; h16_t* dh2;
     long long* dbg;               // diagnostic: per-phase cycle sums of wave 0 of every workgroup (nullable)
-    // round 5: what three small launches behind this kernel used to produce (colsum of dgb, its h16 cast, BatchNorm-2's parameter
-    // gradients from tmp) leaves from here: a lane owns a column, so the column sums are per-lane registers
-    h16_t* dgb16; float* db3;     // nullable: dgb as h16 [NG,256]; db3[256] += column sums of dgb
-    float* dgamma2; float* dbeta2;
 };
 
 // KSC (round 4): the number of 16-wide k-steps of the dh4 . W4 product as a template parameter (16 at Dm = 256; 0 = read Dm at run time).
@@ -618,12 +604,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     const int col = w * 32 + l31;
     const float mean = p.stat2[col], rstd = p.stat2[256 + col], ga = p.gamma2[col], be = p.beta2[col];
     float sg = 0.f, sgx = 0.f;
-    if (PASS == 1 && p.training) {
-        const float t0 = p.tmp[col], t1 = p.tmp[256 + col];
-        sg = t0 * p.invM; sgx = t1 * p.invM;
-        if (blockIdx.x == 0 && hl == 0) { atomicAdd(p.dgamma2 + col, t1); atomicAdd(p.dbeta2 + col, t0); }      // BatchNorm-2's parameter gradients
-    }
-    float colsum3 = 0.f;                                                  // PASS 1: sum over this workgroup's groups of dgb[:, col]
+    if (PASS == 1 && p.training) { sg = p.tmp[col] * p.invM; sgx = p.tmp[256 + col] * p.invM; }
     // dh2 = dh3 . W3b : wave -> row tile rt2 = w >> 2, column tile ct2 = w & 3 of [64 x 128]
     const int rt2 = w >> 2, ct2 = w & 3;
     float a0 = 0.f, a1 = 0.f;
@@ -750,11 +731,7 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
             for (int rt = 0; rt < 2; ++rt) {
                 const float s = gsum[rt] + __shfl_xor(gsum[rt], 32, 64);
                 const long g = pr * 2 + rt;
-                if (hl == 0 && g < p.NG) {
-                    if (p.dgb) p.dgb[(size_t)g * 256 + col] = s;
-                    if (p.dgb16) p.dgb16[(size_t)g * 256 + col] = f32_to_h16(s);
-                    colsum3 += s;
-                }
+                if (hl == 0 && g < p.NG) p.dgb[(size_t)g * 256 + col] = s;
             }
             __syncthreads();                                       // dh3 tile complete; dh4 tile no longer needed
             STAMP(2);
@@ -792,22 +769,27 @@ __global__ void __launch_bounds__(512) g2e_bwd_kernel(G2eBwd p)
     if (PASS == 0) {
         a0 += __shfl_xor(a0, 32, 64); a1 += __shfl_xor(a1, 32, 64);
         if (hl == 0) { atomicAdd(p.tmp + col, a0); atomicAdd(p.tmp + 256 + col, a1); }
-    } else if (p.db3 && hl == 0) atomicAdd(p.db3 + col, colsum3);
+    }
 }
 
 // Group2Emb backward through conv4 / BatchNorm-2 / conv3's per-point half for group_size 32, Dm <= 256 (see above).
 // tmp512_zeroed: f32 scratch.  Also accumulates dgamma2 / dbeta2.
+__global__ void g2e_bn2_param_grad_kernel(const float* __restrict__ tmp, float* __restrict__ dgamma, float* __restrict__ dbeta)
+{
+    const int c = threadIdx.x;
+    if (c < 256) { atomicAdd(dgamma + c, tmp[256 + c]); atomicAdd(dbeta + c, tmp[c]); }
+}
 extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long NG, const void* h3_h16, const float* stat2,
                            const float* gamma2, const float* beta2, const void* w4t_h16, const void* w3bt_h16, int training,
                            float* tmp512_zeroed, void* dh3_h16, float* dgb, void* dh2_h16, float* dgamma2, float* dbeta2, long long* dbg,
-                           void* dgb_h16, float* db3, void* stream)
+                           void* stream)
 {
     (void)hipGetLastError();
-    if (!dout || !arg4 || !h3_h16 || !stat2 || !gamma2 || !beta2 || !w4t_h16 || !w3bt_h16 || !tmp512_zeroed || !dh3_h16 || !dh2_h16 ||
-        !dgamma2 || !dbeta2 || (!dgb && !dgb_h16)) return VPF_ERR_NULL;
+    if (!dout || !arg4 || !h3_h16 || !stat2 || !gamma2 || !beta2 || !w4t_h16 || !w3bt_h16 || !tmp512_zeroed || !dh3_h16 || !dgb || !dh2_h16 ||
+        !dgamma2 || !dbeta2) return VPF_ERR_NULL;
     if (NG <= 0 || Dm <= 0 || Dm > 256 || (Dm % 16)) return VPF_ERR_BADSHAPE;
     G2eBwd p = {dout, arg4, Dm, NG, (const h16_t*)h3_h16, stat2, gamma2, beta2, (const h16_t*)w4t_h16, (const h16_t*)w3bt_h16, tmp512_zeroed,
-                1.0f / (float)(NG * 32), training, (h16_t*)dh3_h16, dgb, (h16_t*)dh2_h16, dbg, (h16_t*)dgb_h16, db3, dgamma2, dbeta2};
+                1.0f / (float)(NG * 32), training, (h16_t*)dh3_h16, dgb, (h16_t*)dh2_h16, dbg};
     const size_t lds = sizeof(h16_t) * 2 * 64 * H3LD, lds1 = lds + 64 * 1024;      // pass 1 also keeps W3b^T (64 KB) in LDS
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
@@ -826,6 +808,7 @@ extern "C" int vpf_g2e_bwd(const float* dout, const uint8_t* arg4, int Dm, long 
         if (training) hipLaunchKernelGGL((g2e_bwd_kernel<0, 0>), dim3((unsigned)grid), dim3(512), lds, st, p);
         hipLaunchKernelGGL((g2e_bwd_kernel<1, 0>), dim3((unsigned)grid), dim3(512), lds1, st, p);
     }
+    if (training) hipLaunchKernelGGL(g2e_bn2_param_grad_kernel, dim3(1), dim3(256), 0, st, (const float*)tmp512_zeroed, dgamma2, dbeta2);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }

@@ -1964,11 +1964,10 @@ class Group2EmbFn(torch.autograd.Function):
             L.call("vpf_g2e_wgrad4", h3, NG, ab2, dout, arg4, Dm, grad_buf(c4.weight), grad_buf(c4.bias))
             tmp2 = torch.zeros(512, dtype=F32, device=dev)
             dh3 = torch.empty(M, 256, dtype=H16, device=dev)
-            dgb = None                                          # (round 5: the kernel hands back dgb as h16 and adds its column sums to db3)
-            dgb16 = torch.empty(NG, 256, dtype=H16, device=dev)
+            dgb = torch.empty(NG, 256, dtype=F32, device=dev)
             dh2 = torch.empty(M, 128, dtype=H16, device=dev)
             L.call("vpf_g2e_bwd", dout, arg4, Dm, NG, h3, stat2, bn2.weight.data, bn2.bias.data, w4t, w3bt, int(training), tmp2, dh3,
-                   None, dh2, grad_buf(bn2.weight), grad_buf(bn2.bias), G2E_DEBUG.get("dbg"), dgb16, grad_buf(c3.bias))
+                   dgb, dh2, grad_buf(bn2.weight), grad_buf(bn2.bias), G2E_DEBUG.get("dbg"))
             if cfg.kv_bwd_defer is not None:
                 cfg.kv_bwd_defer.mark_gate()
         else:
@@ -1997,9 +1996,10 @@ class Group2EmbFn(torch.autograd.Function):
             L.call("vpf_group_sum", dh3, NG, K, 256, dgb)                                        # d(per-group bias)
             dh2 = torch.empty(M, 128, dtype=H16, device=dev)
             gemm(dh3, 0, 256, w3[128:], 1, 256, M, 128, 256, dh2, 128, c_f32=False)                            # dlocal
-        if dgb is not None:
-            colsum(dgb, 256, grad_buf(c3.bias))
-            dgb16 = to_h16(dgb)
+        # (round 5, measured and taken back: colsum / cast / BatchNorm-2's parameter gradients from inside vpf_g2e_bwd -- three launches
+        #  fewer, +0.01 ms per step: NOTES.md)
+        colsum(dgb, 256, grad_buf(c3.bias))
+        dgb16 = to_h16(dgb)
         gemm(dgb16, 1, 256, gmax, 1, 128, 256, 128, NG, gW3, 256, c_f32=True, mode=EPI_ATOMIC)            # dW[:, :128]
         gemm(dh3, 1, 256, h2, 1, 128, 256, 128, M, gW3[:, 128:], 256, c_f32=True, mode=EPI_ATOMIC)        # dW[:, 128:]
         dgmax = torch.empty(NG, 128, dtype=H16, device=dev)
