@@ -612,7 +612,9 @@ def test_grouped_wgrad_lds_dma_kernel():
         # 64) forced and for a group that holds a 128-column problem
         for tn, M, shapes in ((0, 12288, layer), (128, 12288, layer), (0, 12544, layer), (128, 12544, layer),
                               (0, 12288, [(256, 512), (512, 256), (256, 256), (256, 256)] + layer * 6), (0, 320, layer), (128, 320, layer),
-                              (0, 4096, layer + [(256, 128)]), (0, 12288, layer + [(64, 128)])):
+                              (0, 4096, layer + [(256, 128)]), (0, 12288, layer + [(64, 128)]),
+                              # D = 384 / hidden 1536 (config 4): N_out multiples of 128 only -> the 128 x 128 configuration
+                              (0, 4096, [(384, 1536), (1536, 384), (384, 384), (1152, 384)]), (0, 3136, [(384, 1536), (1536, 384), (384, 384), (1152, 384)])):
             _lib.debug_set("wgroup_dma_tn", tn)
             jobs = []
             for i, (N, K) in enumerate(shapes):

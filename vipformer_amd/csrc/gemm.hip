@@ -665,10 +665,11 @@ __device__ __forceinline__ void wg_dma16(const void* gptr, unsigned lds_byte)
 //               too) and 0.75 instead of 1 fragment read per MFMA, for twice the flushed tile  (problems whose K_in is a multiple of 256).
 //               Measured: 151.8 vs 148.2 us for the stack launch and +0.06 ms per step (3.404 vs 3.344 ms, three alternating pairs) --
 //               200 registers, half the slices' length, twice the barriers per token.  Kept behind VPF_WGROUP_DMA_TN=0.
-template <int TN, int BK, int NS>
+//   <TM 1: 2, 64, 3>  128 x 128 tiles (three 32 KB stages) for problems whose N_out is a multiple of 128 only (D = 384: config 4)
+template <int TN, int BK, int NS, int TM = 2>
 __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
 {
-    constexpr int TM = 2, BM = WGDMA_BM, BN = 64 * TN;
+    constexpr int BM = 128 * TM, BN = 64 * TN;
     using ACfg = TileCfg<BM, true, BK>;
     using BCfg = TileCfg<BN, true, BK>;
     constexpr int STAGE = ACfg::ELEMS + BCfg::ELEMS;                 // h16 elements per stage
@@ -752,7 +753,9 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const bool do_bias = d.dbias != nullptr && bx == 0 && wn == 0;
-    float bsum[TM] = {0.f, 0.f};
+    float bsum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bsum[i] = 0.f;
 
     // ---- this lane's fragment addresses inside a stage (frag_read's transposing pattern: per 16-lane group a 4 (k) x 16 (row) block;
     //      the swizzle depends on k & 3 = q only, so ONE base per fragment serves all k-steps of a stage through immediate offsets)
@@ -856,22 +859,23 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
             }
         }
 }
-template <int TN, int BK, int NS>
+template <int TN, int BK, int NS, int TM = 2>
 static int launch_wgrad_dma_cfg(const GemmGroup& grp, int nblocks, hipStream_t st)
 {
-    constexpr size_t lds = sizeof(h16_t) * NS * (TileCfg<WGDMA_BM, true, BK>::ELEMS + TileCfg<64 * TN, true, BK>::ELEMS);
+    constexpr size_t lds = sizeof(h16_t) * NS * (TileCfg<128 * TM, true, BK>::ELEMS + TileCfg<64 * TN, true, BK>::ELEMS);
     static_assert(lds <= 160 * 1024, "the stages must fit the CU's LDS");
     static VpfPerDevice attr_dev; bool& attr = attr_dev();
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)gemm_wgrad_dma_kernel<TN, BK, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
+        if (hipFuncSetAttribute((const void*)gemm_wgrad_dma_kernel<TN, BK, NS, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return VPF_ERR_HIP;
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_wgrad_dma_kernel<TN, BK, NS>), dim3(nblocks), dim3(512), lds, st, grp);
+    hipLaunchKernelGGL((gemm_wgrad_dma_kernel<TN, BK, NS, TM>), dim3(nblocks), dim3(512), lds, st, grp);
     VPF_CHECK_LAUNCH();
     return VPF_OK;
 }
-static int launch_wgrad_dma(const GemmGroup& grp, int nblocks, int tn, hipStream_t st)
+static int launch_wgrad_dma(const GemmGroup& grp, int nblocks, int tm, int tn, hipStream_t st)
 {
+    if (tm == 128) return launch_wgrad_dma_cfg<2, 64, 3, 1>(grp, nblocks, st);
     if (tn == 256) return launch_wgrad_dma_cfg<4, 32, 4>(grp, nblocks, st);
     return launch_wgrad_dma_cfg<2, 64, 3>(grp, nblocks, st);
 }
@@ -945,7 +949,7 @@ static int gemm_dispatch(GemmArgs& g, int a_tr, int b_tr, int batch, hipStream_t
         if (a_tr && b_tr && batch == 1 && g.splitk <= 0 && g.xa.kind == 0 && g.xb.kind == 0 && g.ldc <= 0x7fffffff) {
             VpfWgradJob j = {g.A, g.B, g.K, g.M, g.N, reinterpret_cast<float*>(g.C), g.dbias};
             const long tiles = (long)(g.M / WGDMA_BM) * (g.N / WGDMA_BN);
-            if (wgrad_dma_conforms(j) && g.lda == g.M && g.ldb == g.N && tiles > 0 && tiles * (256 / tiles < g.K / 1024 ? 256 / tiles : g.K / 1024) >= 128)
+            if (wgrad_dma_conforms(j) && !(g.M % WGDMA_BM) && g.lda == g.M && g.ldb == g.N && tiles > 0 && tiles * (256 / tiles < g.K / 1024 ? 256 / tiles : g.K / 1024) >= 128)
                 return wgrad_single_dma(j, (int)g.ldc, st);
         }
         const int wcfg = vpf_debug().wgrad_cfg, wtarget = vpf_debug().wgrad_wgs > 0 ? vpf_debug().wgrad_wgs : 512;
@@ -1041,7 +1045,7 @@ extern "C" int vpf_gemm_h16_fused(const void* A, int a_kstrided, long lda, int a
 static bool wgrad_dma_conforms(const VpfWgradJob& j)
 {
     const int min_tokens = vpf_debug().wgroup_dma;
-    return min_tokens > 0 && j.M >= min_tokens && j.M > 0 && !(j.N % WGDMA_BM) && !(j.K % WGDMA_BN) && !(j.M % WGDMA_BK) && j.N > 0 && j.K > 0;
+    return min_tokens > 0 && j.M >= min_tokens && j.M > 0 && !(j.N % 128) && !(j.K % WGDMA_BN) && !(j.M % WGDMA_BK) && j.N > 0 && j.K > 0;
 }
 static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long ws_bytes, void* stream, bool dma_ok, int ldc_override = 0);
 extern "C" int vpf_wgrad_group(const VpfWgradJob* jobs, int njobs, void* ws, long ws_bytes, void* stream)
@@ -1073,14 +1077,15 @@ static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long
     const int cfg = dma ? 2 : vpf_debug().wgroup_cfg;
     const int target = vpf_debug().wgroup_wgs > 0 ? vpf_debug().wgroup_wgs : (dma ? 256 : 512);      // measured on the c2 step: 128x128 tiles, ~512 workgroups per group
     // DMA kernel: 256 x 256 tiles when every problem's K_in is a multiple of 256 (VPF_WGROUP_DMA_TN = 128 / 256 forces one), else 256 x 128
-    int dma_tn = WGDMA_BN;
+    int dma_tn = WGDMA_BN, dma_tm = WGDMA_BM;
     if (dma) {
-        bool all256 = true;
-        for (int i = 0; i < njobs; ++i) if (jobs[i].K % 256) all256 = false;
+        bool all256 = true, rows256 = true;
+        for (int i = 0; i < njobs; ++i) { if (jobs[i].K % 256) all256 = false; if (jobs[i].N % 256) rows256 = false; }
         const int want = vpf_debug().wgroup_dma_tn;
-        dma_tn = (all256 && want != 128) ? 256 : 128;
+        dma_tm = rows256 ? 256 : 128;                      // 128 x 128 tiles for a group with an N_out that is a multiple of 128 only (D = 384)
+        dma_tn = (all256 && rows256 && want != 128) ? 256 : 128;
     }
-    const int tm = dma ? WGDMA_BM : (cfg == 0 ? 64 : 128), tn = dma ? dma_tn : ((cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64));
+    const int tm = dma ? dma_tm : (cfg == 0 ? 64 : 128), tn = dma ? dma_tn : ((cfg == 3 || cfg == 4) ? 256 : ((cfg == 2 || cfg >= 5) ? 128 : 64));
     const bool pair = cfg == 8 && !partial && !dma;          // two K slices per 8-wave workgroup: half the flush atomics (round 3)
     long total_tiles = 0;
     for (int i = 0; i < njobs; ++i) total_tiles += (long)vpf_cdiv(jobs[i].N, tm) * vpf_cdiv(jobs[i].K, tn);
@@ -1152,7 +1157,7 @@ static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long
     grp.uneven = dma ? vpf_debug().wgroup_dma_ramp : vpf_debug().wgroup_uneven;      // (DMA kernel: a ramp of slice lengths, in percent, for launches of >= 16 slices)
     grp.dbg = vpf_debug().wgroup_dbg;
     hipStream_t st = (hipStream_t)stream;
-    if (dma) return launch_wgrad_dma(grp, at, tn, st);
+    if (dma) return launch_wgrad_dma(grp, at, tm, tn, st);
     // workspace split-K (EPI_PARTIAL) when the caller handed over enough scratch: [counters | one tm x tn f32 tile per workgroup]
     if (partial && ws && total_tiles <= WGROUP_CNT_INTS && ws_bytes >= (long)(WGROUP_CNT_INTS * 4 + (size_t)at * tm * tn * 4) && !((uintptr_t)ws & 15)) {
         float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + WGROUP_CNT_INTS * 4);
