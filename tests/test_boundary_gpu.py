@@ -395,6 +395,30 @@ def test_pretrainer_loss_scale_backs_off_on_overflow_inside_the_captured_graph()
     assert torch.isfinite(tr.flat.p).all().item()
 
 
+def test_pretrainer_at_the_default_loss_scale_backs_off_and_trains():
+    """every other test pins VPF_LOSS_SCALE to 256 (tests/conftest.py).  Here the trainer starts at GradScaler's DEFAULT
+    65 536 on a 4-pair batch, whose per-sample gradients overflow fp16 at that scale: the first replays of the captured graph are skipped
+    (parameters untouched), the scale halves once per skipped step inside the graph, then the steps train -- parameters move, the
+    loss falls, `loss_scale` == 65 536 / 2 ** skipped_steps."""
+    from vipformer_amd.train import Pretrainer
+    pc, im, a = build("tiny", (0.1, 0.5))
+    pc.train(); im.train()
+    tr = Pretrainer(pc, im, loss_scale=65536.0, growth_interval=1000)
+    t1, t2, imgs, start = _batch(a, 4)
+    tr.capture(t1, t2, imgs.permute(0, 3, 1, 2).contiguous(), warmup=2)
+    assert tr.loss_scale == 65536.0 and tr.skipped_steps == 0
+    p0 = tr.flat.p.clone()
+    losses = []
+    for _ in range(40):
+        losses.append(float(tr.replay()[0]))
+    sk = tr.skipped_steps
+    assert 0 <= sk < 20, sk
+    assert tr.loss_scale == 65536.0 * 0.5 ** sk
+    assert float(tr.hyper[6]) == 40 - sk                                   # AdamW counted the good steps only
+    assert not torch.equal(tr.flat.p, p0) and torch.isfinite(tr.flat.p).all().item()
+    assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.5, (losses[0], losses[-1], sk)
+
+
 def test_reference_loop_with_torch_gradscaler_and_autocast_trains():
     """pretrain.py:154,173-211 as it stands on the mirrored modules -- torch's own GradScaler (default init_scale 2 ** 16) around autocast,
     `scaler.scale(loss).backward(); scaler.step(opt); scaler.update()`, one torch.optim.AdamW over both models, no Pretrainer: the
