@@ -604,7 +604,7 @@ def test_grouped_wgrad_lds_dma_kernel():
     two K slices of 96 and 98 stages) and a whole stack of 28 problems, accumulated INTO non-zero buffers, bias sums on and off, twice
     in a row; a launch with ONE non-conforming problem must take the register-staged kernel and still be right."""
     from vipformer_amd import _lib, ops
-    keep, keep_tn, keep_sk, keep_wgs = (_lib.debug_get(k) for k in ("wgroup_dma", "wgroup_dma_tn", "wgroup_dma_sk", "wgroup_wgs"))
+    keep, keep_tn, keep_wgs = (_lib.debug_get(k) for k in ("wgroup_dma", "wgroup_dma_tn", "wgroup_wgs"))
     layer = [(256, 512), (512, 256), (256, 256), (768, 256)]
     stack = [(256, 512), (512, 256), (256, 256), (256, 256)] + layer * 6
     try:
@@ -614,7 +614,7 @@ def test_grouped_wgrad_lds_dma_kernel():
         for tn, M, shapes, wgs in ((0, 12288, layer, 0), (128, 12288, layer, 0), (0, 12544, layer, 0), (128, 12544, layer, 0),
                                    (0, 12288, stack, 0), (128, 12288, stack, 0), (128, 12544, stack, 0), (0, 320, layer, 0), (128, 320, layer, 0),
                                    (0, 4096, layer + [(256, 128)], 0), (0, 12288, layer + [(64, 128)], 0),
-                                   # three slices (86, 86, 84 stages) per tile: XCD lists of ~40 tile-slices -- a stream-K run of ~108 stages spans two or three tiles
+                                   # three slices (86, 86, 84 stages) per tile: XCD lists of ~40 tile-slices, two rounds of workgroups
                                    (128, 16384, stack, 384),
                                    # D = 384 / hidden 1536 (config 4): N_out multiples of 128 only -> the 128 x 128 configuration
                                    (0, 4096, [(384, 1536), (1536, 384), (384, 384), (1152, 384)], 0), (0, 3136, [(384, 1536), (1536, 384), (384, 384), (1152, 384)], 0),
@@ -624,23 +624,20 @@ def test_grouped_wgrad_lds_dma_kernel():
             for i, (N, K) in enumerate(shapes):
                 dy, x = bf(rnd(100 + i, M, N)), bf(rnd(200 + i, M, K))
                 jobs.append((dy, x, N, K, (torch.ones(N, device="cuda") if i % 4 != 3 else None)))
-            # stream-K over the XCD lists (VPF_WGROUP_DMA_SK) off and on: the same sums in another order
-            for sk in (0, 1):
-                _lib.debug_set("wgroup_dma_sk", sk)
-                outs = [(torch.ones(N, K, device="cuda"), (torch.ones(N, device="cuda") if db is not None else None)) for dy, x, N, K, db in jobs]
-                for rep in range(2):
-                    wg = ops.WgradBatch(cap=ops.WgradBatch.CAP)
-                    for (dy, x, N, K, _), (dW, db) in zip(jobs, outs):
-                        wg.add(dy, x, N, K, dW, db)
-                    wg.flush()
-                torch.cuda.synchronize()
+            outs = [(torch.ones(N, K, device="cuda"), (torch.ones(N, device="cuda") if db is not None else None)) for dy, x, N, K, db in jobs]
+            for rep in range(2):
+                wg = ops.WgradBatch(cap=ops.WgradBatch.CAP)
                 for (dy, x, N, K, _), (dW, db) in zip(jobs, outs):
-                    ref = dy.float().t() @ x.float()
-                    assert rel(dW, 1.0 + 2.0 * ref) < 2e-5, (sk, M, N, K, rel(dW, 1.0 + 2.0 * ref))
-                    if db is not None:
-                        assert rel(db, 1.0 + 2.0 * dy.float().sum(0)) < 2e-5, (sk, M, N, K)
+                    wg.add(dy, x, N, K, dW, db)
+                wg.flush()
+            torch.cuda.synchronize()
+            for (dy, x, N, K, _), (dW, db) in zip(jobs, outs):
+                ref = dy.float().t() @ x.float()
+                assert rel(dW, 1.0 + 2.0 * ref) < 2e-5, (M, N, K, rel(dW, 1.0 + 2.0 * ref))
+                if db is not None:
+                    assert rel(db, 1.0 + 2.0 * dy.float().sum(0)) < 2e-5, (M, N, K)
     finally:
-        for k, v in (("wgroup_dma", keep), ("wgroup_dma_tn", keep_tn), ("wgroup_dma_sk", keep_sk), ("wgroup_wgs", keep_wgs)):
+        for k, v in (("wgroup_dma", keep), ("wgroup_dma_tn", keep_tn), ("wgroup_wgs", keep_wgs)):
             _lib.debug_set(k, v)
 
 

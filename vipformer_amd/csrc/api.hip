@@ -79,7 +79,6 @@ static const VpfDebugKey kDebugKeys[] = {
     {"wgroup_dma", "VPF_WGROUP_DMA", &VpfDebug::wgroup_dma, 2048},
     {"wgroup_dma_tn", "VPF_WGROUP_DMA_TN", &VpfDebug::wgroup_dma_tn, 128},
     {"wgroup_dma_ramp", "VPF_WGROUP_DMA_RAMP", &VpfDebug::wgroup_dma_ramp, 50},
-    {"wgroup_dma_sk", "VPF_WGROUP_DMA_SK", &VpfDebug::wgroup_dma_sk, 0},
 };
 VpfDebug& vpf_debug()
 {

@@ -591,11 +591,6 @@ struct GemmGroup {
     // (1 126 -> ~600 MB per stack launch).  Workgroup id -> XCD id % 8 (the dispatcher's round-robin), slot id / 8 -> walk the XCD's list.
     int xmode;                                              // 1: the lists below are in use; grid = 8 x the longest list's tile count
     unsigned char xp[WGROUP_XLIST_MAX], xz[WGROUP_XLIST_MAX], xoff[9];     // slab i: problem xp[i], slice xz[i]; XCD x owns slabs xoff[x] .. xoff[x + 1] - 1
-    // xmode 2 (LDS-DMA kernel, stream-K over the lists): slab i's K slice in 64-token stages, and every list's tiles x stages.  Filled in by
-    // the host: the kernel-side restatement (d[xp[i]].K / .splitk through a run-time index) compiled to s_load_dwordx2 with the 88-byte
-    // stride split over base (+ 2 xp) and offset register (86 xp) -- the low two bits of each are dropped, every odd problem read its
-    // neighbouring fields (tools/diag_streamk.py found the lists' totals short by exactly the odd problems' tiles)
-    unsigned short xns[WGROUP_XLIST_MAX]; int xtotal[8];
 };
 template <int TM, int TN, int WM, int WN, int BK, int PF, bool PAIR = false>
 __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(GemmGroup grp)
@@ -684,35 +679,8 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
     static_assert(NA * RA * 8 == BK && NB * RB * 8 == BK && PER >= KS, "the copies divide over the waves and the k-steps");
     extern __shared__ __attribute__((aligned(16))) h16_t lds_dma[];
     // ---- which problem, tile and K slice (as gemm_wgrad_group_kernel)
-    // xmode 2 (stream-K over an XCD's list): the list's (slab, tile, stage) units, in that order, are cut into gridDim / 8 equal runs, one per
-    // workgroup -- a run ends where it ends, in the middle of a tile if need be, and the workgroup flushes once per tile it touched (at
-    // most two when a run is shorter than a slice).  A stack's 216 tile-slices then keep all 256 CUs busy for 81 stages each instead of
-    // 216 CUs for 96.  The slabs of a list stay on their XCD.
-    const bool streamk = grp.xmode == 2;
-    int sk_unit = 0, sk_end = 0;
-    auto slab_stages = [&](int i) -> int { return (int)grp.xns[i] * (WGDMA_BK / BK); };      // stages of list entry i's K slice
-    if (streamk) {
-        const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-        const int total = grp.xtotal[x] * (WGDMA_BK / BK), run = (total + nslots - 1) / nslots;
-        sk_unit = slot * run; sk_end = min(total, sk_unit + run);
-        if (sk_unit >= sk_end) return;
-    }
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int wm = wave >> 1, wn = wave & 1;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) h16_t*)lds_dma;
-  for (;;) {
-    int p = 0, local = 0, xbz = 0, seg0 = 0, seg1 = 0;
-    if (streamk) {
-        const int x = blockIdx.x & 7;
-        int i = grp.xoff[x], u = sk_unit, ns = 0, nt = 0;
-        for (;; ++i) {
-            ns = slab_stages(i); nt = grp.nx[grp.xp[i]] * grp.ny[grp.xp[i]];
-            if (u < nt * ns) break;
-            u -= nt * ns;
-        }
-        p = grp.xp[i]; xbz = grp.xz[i]; local = u / ns; seg0 = u - local * ns; seg1 = min(ns, seg0 + (sk_end - sk_unit));
-        sk_unit += seg1 - seg0;
-    } else if (grp.xmode) {
+    int p = 0, local = 0, xbz = 0;
+    if (grp.xmode) {
         const int x = blockIdx.x & 7;
         int slot = blockIdx.x >> 3, i = grp.xoff[x];
         const int end = grp.xoff[x + 1];
@@ -734,10 +702,7 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
     else { bx = local % nx; by = (local / nx) % ny; bz = local / (nx * ny); }
     const int m0 = by * BM, n0 = bx * BN;
     int kbeg, kend;
-    if (streamk) {
-        const int per = ((d.K + d.splitk - 1) / d.splitk + WGDMA_BK - 1) / WGDMA_BK * WGDMA_BK;
-        kbeg = bz * per + seg0 * BK; kend = bz * per + seg1 * BK;
-    } else if (grp.uneven > 0 && d.splitk >= 16) {
+    if (grp.uneven > 0 && d.splitk >= 16) {
         // Many slices of ONE or a few tiles (a single weight gradient over 10^5 tokens and more): equal slices end together and their
         // 128 KB flushes -- 33 MB of fp32 atomics at ~1.3 TB/s, all onto the same tile -- queue up behind the last stage (26 us of a
         // 70 us launch).  A linear RAMP of slice lengths, (1 - r) .. (1 + r) x the mean with r = uneven / 100, lets the early finishers'
@@ -757,6 +722,8 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
     if (kbeg >= kend) return;
     const int nk = (kend - kbeg) / BK;
 
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
     // ---- this lane's part of a stage: element offsets inside the stage's BK k rows
     unsigned offA[NA], offB[NB];
 #pragma unroll
@@ -769,6 +736,7 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
         const int q = wave + 8 * j, kk = RB * q + lane / (64 / RB), pos = lane % (64 / RB);
         offB[j] = (unsigned)kk * (unsigned)d.ldb + (unsigned)((pos ^ ((kk & 3) << 2)) * 8);
     }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) h16_t*)lds_dma;
     const h16_t* Ag = d.A + (size_t)kbeg * d.lda + m0;
     const h16_t* Bg = d.B + (size_t)kbeg * d.ldb + n0;
     // copy `pc` (0 .. NA - 1: the A tile, NA .. PER - 1: the B tile) of stage st
@@ -890,9 +858,6 @@ __global__ void __launch_bounds__(512, 2) gemm_wgrad_dma_kernel(GemmGroup grp)
                 atomicAdd(d.C + (size_t)m * d.ldc + n, acc[i][j][r]);
             }
         }
-    if (!streamk || sk_unit >= sk_end) break;
-    __syncthreads();                       // the run goes on in the next tile: every wave is done with this one's last stage buffers
-  }
 }
 template <int TN, int BK, int NS, int TM = 2>
 static int launch_wgrad_dma_cfg(const GemmGroup& grp, int nblocks, hipStream_t st)
@@ -1184,19 +1149,6 @@ static int wgrad_group_launch(const VpfWgradJob* jobs, int njobs, void* ws, long
             grp.xoff[8] = (unsigned char)w;
             grp.xmode = 1;
             at = 8 * longest;
-            // LDS-DMA kernel: stream-K over each XCD's list -- one run of stages per CU (32 per XCD)
-            if (dma && vpf_debug().wgroup_dma_sk > 0) {
-                grp.xmode = 2; at = 256;
-                for (int x = 0; x < 8; ++x) {
-                    grp.xtotal[x] = 0;
-                    for (int k = grp.xoff[x]; k < grp.xoff[x + 1]; ++k) {
-                        const WgDesc& e = grp.d[grp.xp[k]];
-                        const int per = vpf_cdiv(vpf_cdiv(e.K, e.splitk), WGDMA_BK) * WGDMA_BK, kb = grp.xz[k] * per, ke = e.K < kb + per ? e.K : kb + per;
-                        grp.xns[k] = (unsigned short)(ke > kb ? (ke - kb) / WGDMA_BK : 0);
-                        grp.xtotal[x] += (int)grp.nx[grp.xp[k]] * grp.ny[grp.xp[k]] * grp.xns[k];
-                    }
-                }
-            }
         }
     }
     // K slices of alternating length (4/3 and 2/3 of the mean): the two workgroups a CU holds then leave their staging loops at

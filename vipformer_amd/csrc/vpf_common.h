@@ -54,7 +54,6 @@ struct VpfDebug {
     int wgroup_dma;         // VPF_WGROUP_DMA        N > 0: grouped weight gradients of conforming problems with >= N tokens run the LDS-DMA kernel (0: never)
     int wgroup_dma_tn;      // VPF_WGROUP_DMA_TN     tile columns of the LDS-DMA kernel: 128 = always 256 x 128 (default), 0 = 256 x 256 where every problem allows it (measured slower: 151.8 vs 148.2 us, +0.06 ms per step)
     int wgroup_dma_ramp;    // VPF_WGROUP_DMA_RAMP   LDS-DMA kernel, launches of >= 16 K slices per problem: slice lengths ramp over (1 -+ N / 100) x the mean (0: equal)
-    int wgroup_dma_sk;      // VPF_WGROUP_DMA_SK     LDS-DMA kernel, XCD-list launches: 1 = every XCD's list of (tile, stage) units is cut into 32 equal runs (stream-K)
     int sa_rb;              // VPF_SA_RB             geometry of those kernels at D = 256: 12 = 16 waves x 32 tokens each (default), 2 = 8 waves x 64, 1 = 8 waves x 32
 };
 VpfDebug& vpf_debug();
