@@ -6,7 +6,9 @@ the HIP path runs configs 2, 3 and 4 at their per-GPU batch (64 / 32 / 16 pairs)
   * the c2 architecture at 32 pairs, config 3 at 32 and config 4 at 16 pairs, the reference scripts' own geometry (2048 points,
     144 x 144 / patch 12) at 16, train mode with the real dropout probabilities and the kernels' own masks: the NT-Xent loss
     (abs <= 5e-3, the contract's bound), features behind the BatchNorm head <= 1e-2, and the gradients of every parameter for a
-    linear and for the pre-training loss against the fp32 oracle with constant floors (test_modules_gpu.FLOORS).
+    linear and for the pre-training loss against the fp32 oracle with constant floors (test_modules_gpu.FLOORS);
+  * the c2 train step at the BENCHMARKED batch, 64 pairs (round 5): the same checks as the 32-pair case with the
+    oracle's backward passes cut to the pre-training loss (test_c2_train_step_at_the_benchmarked_batch_64_pairs).
 """
 import numpy as np
 import pytest
