@@ -32,7 +32,10 @@ def test_library_exports_every_declared_symbol():
     assert lib.vpf_build_id().decode() == "VPF_BUILD_ID=" + build.source_hash()      # the .so was compiled from THIS tree
     assert _lib.lib().vpf_strerror(-3).decode().startswith("unsupported")
     # no packed-fp32 VALU instruction anywhere in the device code (the co-residency fault's trigger)
+    # ... and no scalar load whose address is split over a base pair and an offset register (NOTES.md round 5: gfx950 truncates each part)
     assert build.check_no_packed_f32(build.LIB) >= 8
+    hit = "\ts_load_dwordx2 s[24:25], s[4:5], s21 offset:0x44\n"
+    assert build.SPLIT_SLOAD.findall(hit) and not build.SPLIT_SLOAD.findall("\ts_load_dwordx2 s[24:25], s[4:5], 0x44\n\ts_load_dword s6, s[0:1], 0xce0\n")
 
 
 def test_ctypes_table_matches_header():

@@ -85,15 +85,23 @@ def device_code_objects(path: str):
         yield data[i:i + e_shoff + e_shentsize * e_shnum]
 
 
+# s_load_dword* with BOTH a base pair and an offset register: the compiler forms it when it splits a run-time index into a by-value
+# kernel-argument array of structs over the two (round 5: an 88-byte stride became base + 2 i, offset 86 i).  gfx950 drops the low two
+# bits of each part, not of the sum -- odd indices read the neighbouring fields, silently.  No kernel of the library has one; the link
+# step keeps it that way.
+import re as _re
+SPLIT_SLOAD = _re.compile(r"^.*\bs_(?:buffer_)?load_dword(?:x\d+)?\s+s\[?[0-9:]+\]?,\s*s\[[0-9:]+\],\s*s\d+.*$", _re.M)
+
+
 def check_no_packed_f32(lib_path: str) -> int:
     """Fail the build if the library's device code contains a packed-fp32 VALU instruction (v_pk_add_f32 / v_pk_mul_f32 /
     v_pk_fma_f32).  With them fps_kernel mis-sampled whenever gemm_kernel workgroups shared its CU: the
     mechanism is not understood, so the instruction class is banned from the whole library -- -fno-slp-vectorize keeps the compiler
     from forming them, this check keeps a hand-written one (inline asm, a builtin, a vector type) from re-opening the fault
-    silently.  Returns the number of code objects scanned."""
+    silently.  The same pass rejects split scalar loads (SPLIT_SLOAD above).  Returns the number of code objects scanned."""
     import re
     import tempfile
-    n, bad = 0, []
+    n, bad, bad_sload = 0, [], []
     for img in device_code_objects(lib_path):
         n += 1
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
@@ -103,10 +111,16 @@ def check_no_packed_f32(lib_path: str) -> int:
         if hits:
             kernels = sorted(set(re.findall(r"^[0-9a-f]+ <([^>]+)>:", d, flags=re.M)))[:4]
             bad.append(f"code object {n}: {len(hits)} ({', '.join(kernels)} ...)")
+        split = SPLIT_SLOAD.findall(d)
+        if split:
+            bad_sload.append(f"code object {n}: {len(split)} (first: {split[0].strip()})")
     if n == 0:
         raise RuntimeError(f"no gfx950 code object found in {lib_path}")
     if bad:
         raise RuntimeError("packed-fp32 instructions in the device code (the co-residency fault's trigger, DESIGN.md section 6): " + "; ".join(bad))
+    if bad_sload:
+        raise RuntimeError("scalar loads with a base AND an offset register in the device code (NOTES.md round 5: each part loses its low two "
+                           "address bits -- index the kernel-argument table another way): " + "; ".join(bad_sload))
     return n
 
 
@@ -150,7 +164,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])
         n = check_no_packed_f32(LIB)
         if verbose:
-            print(f"linked {LIB} ({n} code objects, no packed-fp32 instructions)")
+            print(f"linked {LIB} ({n} code objects, no packed-fp32 instructions, no split scalar loads)")
     return LIB
 
 
