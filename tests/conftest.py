@@ -19,7 +19,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order on the GPU box: the oracle / golden parity tests first, the hot path's stages before its
+# compositions, full-size configurations next, plumbing after that and everything that starts processes last -- `pytest -x` then stops
+# at the most informative failure, and multi-process plumbing can never shadow the parity suite.
+_ORDER = ("test_oracle_golden", "test_host_cpu", "test_preproc_gpu", "test_kernels_gpu", "test_modules_gpu", "test_fullsize_gpu",
+          "test_partseg_gpu", "test_probe_gpu", "test_trajectory_gpu", "test_augment_gpu", "test_boundary_gpu", "test_zz_multiproc_gpu")
+
+
+def _rank(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    return _ORDER.index(name) if name in _ORDER else len(_ORDER) - 1
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=_rank)                                    # stable: the order inside a file is kept
     import torch
     if torch.cuda.is_available():
         return

@@ -303,6 +303,64 @@ def make_models(names):
             fid, bid = imd(imgs)
             save(f"dropout_{name}.npz", pc_feats=fd, pc_backbone=bd, img_feats=fid, img_backbone=bid)
 
+def make_fullsize(names=("c1", "c3", "c4")):
+    """BASELINE configs[1..3] at their PER-GPU BATCH (64 / 32 / 16 pairs: tests/helpers.py FULL_BATCH) through the imported reference
+    (full size pinned to the reference itself, not to the restatement run live on the GPU box) -> fullsize_<name>.npz:
+      * eval-mode features + backbone of both models;
+      * train mode with every dropout at 0 (BatchNorm on batch statistics): features, backbone, the pre-training loss
+        (pretrain.py:189-207; the NT-Xent VALUE comes from the restatement -- lightly is absent, row 17 stays unpinned -- but everything
+        in front of it and the whole backward pass through both models is the reference's);
+      * gradients of (a) the loss linear in the backbone features and (b) the pre-training loss, for every parameter: L2 norm and a
+        strided sample of <= 512 elements (helpers.grad_sample: the same indices are taken from the HIP gradients by the test), so the
+        fixture stays at a few hundred KB where the full gradients are 2 x 33 - 130 MB."""
+    RU.knn_point = canonical_knn
+    RP.divide_patches.__globals__["knn_point"] = canonical_knn
+    torch.set_num_threads(8)
+    for name in names:
+        a = Hh.ARCHS[name]
+        B = Hh.FULL_BATCH[name]
+        pc, im = build_ref(a, drops=(0.0, 0.0))
+        pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100))
+        im.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200))
+        pts = Hh.synth_points(930, 2 * B, a["N"], 3, "uniform")
+        start = Hh.synth_start(930, 2 * B, a["N"])
+        imgs = Hh.synth_images(931, B, a["img"], a["img"])
+        res = {"meta": np.array([B, 930, 931])}
+        pc.eval(); im.eval()
+        with torch.no_grad(), forced_start(start):
+            f, bb = pc(pts)
+            fi, bbi = im(imgs)
+        res.update(pc_eval_feats=f, pc_eval_backbone=bb, img_eval_feats=fi, img_eval_backbone=bbi)
+        pc.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100))     # (nothing moved in eval mode; belt and braces)
+        pc.train(); im.train(); pc.zero_grad(); im.zero_grad()
+        with forced_start(start):
+            f, bb = pc(pts)
+        fi, bbi = im(imgs)
+        res.update(pc_train_feats=f, pc_train_backbone=bb, img_train_feats=fi, img_train_backbone=bbi)
+        f1, f2 = f[:B], f[B:]
+        l_im = O.ntxent(f1, f2); l_cm = O.ntxent((f1 + f2) / 2, fi)
+        total = l_im + 1.0 * l_cm                                                                  # pretrain.py:207
+        res["loss"] = np.array([total.item(), l_im.item(), l_cm.item()])
+        names_pc = [k for k, _ in pc.named_parameters()]; names_im = [k for k, _ in im.named_parameters()]
+        assert dict(pc=names_pc, img=names_im) == json.load(open(os.path.join(HERE, f"grad_names_{name}.json")))
+        for tag, loss in (("lin", (bb * Hh.synth_like(700, bb.shape)).sum() + (bbi * Hh.synth_like(701, bbi.shape)).sum()), ("ntx", total)):
+            pc.zero_grad(); im.zero_grad()
+            loss.backward(retain_graph=(tag == "lin"))
+            for which, model in (("pc", pc), ("img", im)):
+                norms, samples = [], []
+                for k, p_ in model.named_parameters():
+                    g = p_.grad if p_.grad is not None else torch.zeros_like(p_)
+                    norms.append(g.double().norm().item())
+                    samples.append(Hh.grad_sample(g))
+                res[f"{which}_{tag}_norms"] = np.array(norms)
+                res[f"{which}_{tag}_samples"] = torch.cat(samples)
+        for k in ("latent_head.0.running_mean", "latent_head.0.running_var", "group2emb.first_conv.1.running_var"):
+            res["pc_buf." + k] = pc.state_dict()[k].clone()
+        save(f"fullsize_{name}.npz", **res)
+        print("fullsize", name, B, "pairs: loss", res["loss"], os.path.getsize(os.path.join(HERE, f"fullsize_{name}.npz")), "bytes", flush=True)
+    RU.knn_point = _orig_knn
+
+
 def make_ft(names=("tiny", "c1")):
     """CrossFormer_pc_mp_ft (partseg.py:553-605, the ModelNet fine-tuning classifier: the pre-training backbone + a 3-block
     BatchNorm-ReLU-Linear head): eval / train logits (dropout 0), the gradients of a loss linear in the logits with respect to
@@ -508,6 +566,8 @@ if __name__ == "__main__":
         make_ckpt()
     elif len(sys.argv) > 1 and sys.argv[1] == "ca2":
         make_ca2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "fullsize":        # python make_golden.py fullsize [c1 c3 c4]
+        make_fullsize(tuple(sys.argv[2:]) or ("c1", "c3", "c4"))
     elif len(sys.argv) > 2 and sys.argv[1] == "models":        # python make_golden.py models c3 c4
         main(only_models=tuple(sys.argv[2:]))
     else:
@@ -517,3 +577,4 @@ if __name__ == "__main__":
         make_augment()
         make_ckpt()
         make_ca2()
+        make_fullsize()

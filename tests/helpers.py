@@ -144,5 +144,18 @@ FULLSIZE = ("c1", "c3", "c4") + REF_ARCHS          # fixtures of these hold slic
 # pairs per batch used by the model_* / dropout-step fixtures and tests
 MODEL_BATCH = {"tiny": 8, "tiny2": 8, "c1": 4, "c3": 4, "c4": 4, "tinyseg": 8, "ref144": 4, "ref144m4": 4}
 
+# pairs PER GPU of BASELINE.json configs[1], [2], [3] (64 on one GPU; 256 and 128 over 8): the batch of the fullsize_*.npz fixtures
+FULL_BATCH = {"c1": 64, "c3": 32, "c4": 16}
+GRAD_SAMPLE = 512
+
+
+def grad_sample(g: torch.Tensor, cap: int = GRAD_SAMPLE) -> torch.Tensor:
+    """A strided sample of <= cap elements of a gradient tensor (flattened, every (n // cap)-th element from 0): what the fullsize_*
+    fixtures keep of the reference's gradients and what the tests take from the HIP gradients."""
+    flat = g.detach().reshape(-1)
+    n = flat.numel()
+    return flat[::max(1, n // cap)][:cap].float().cpu().clone()
+
+
 # CrossFormer_partseg taps (1-based self-attention layer numbers; the reference needs 3 or 4 of them, partseg.py:430-435)
 PARTSEG_LAYERS = {"tinyseg": [1, 2, 3], "c3": [2, 5, 8]}

@@ -197,3 +197,98 @@ def test_c2_train_step_at_the_benchmarked_batch_64_pairs():
     ck.lt("[NT-Xent loss] all-parameter gradient deficit (1 - cos) vs fp32", d_all, f_all)
     ck.lt("[NT-Xent loss] worst per-tensor gradient deficit vs fp32", per[0][0], f_min)
     ck.done()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Full size against fixtures written by the IMPORTED REFERENCE (tests/golden/make_golden.py make_fullsize): no
+# oracle runs on the GPU box's host here.  Dropout 0 on both sides (a fixture cannot replay the kernels' masks; the dropout placement
+# is pinned by the dropout_*.npz fixtures and, at full size with the real probabilities, by the live-oracle tests above).
+# Floors on the gradient's direction, 1 - cosine over the strided samples of every parameter (helpers.grad_sample), PER CONFIG -- derived
+# from what fp16 operands cost on that configuration (profiles/r0[3-5]_rounding_budget_*.txt: weights + activations rounded to fp16 in the
+# fp32 oracle put the pre-training loss's gradient 0.9 - 1.7e-3 off fp32; the linear loss's 2 - 6e-4) with ~2 x headroom for the batch:
+# SURVEY 8c's 1e-3 (cosine >= 0.999) holds for the linear loss everywhere; the NT-Xent floor is stated per configuration.
+FIXTURE_FLOORS = {          # name -> {loss tag -> (all-parameter deficit, worst per-tensor deficit among tensors with >= 64 samples)}
+    "c1": {"lin": (1e-3, 1e-2), "ntx": (3e-3, 2e-2)},
+    "c3": {"lin": (1e-3, 1e-2), "ntx": (4e-3, 2e-2)},
+    "c4": {"lin": (1e-3, 1e-2), "ntx": (4e-3, 2e-2)},
+}
+
+
+@pytest.mark.parametrize("name", ["c1", "c3", "c4"])
+def test_full_batch_vs_reference_fixture(name):
+    """BASELINE configs[1] / [2] / [3] at their per-GPU batch (64 / 32 / 16 pairs) against fullsize_<name>.npz, which the reference
+    itself wrote (partseg.py:527-550,661-680 forward, autograd backward; pretrain.py:189-207 loss):
+      * eval mode: backbone + projected features of both models, rel-L2 <= 2e-3 (SURVEY 8c, fp16 operands);
+      * train mode (dropout 0): backbone <= 2e-3, features behind the BatchNorm head <= 1e-2, pre-training loss abs <= 5e-3,
+        BatchNorm running statistics <= 3e-2;
+      * gradients of the linear loss and of the pre-training loss, every parameter: norm within 8 % of the reference's for every tensor
+        that carries >= 0.1 % of the largest norm, direction by the strided samples against FIXTURE_FLOORS."""
+    import json
+    import os
+    from vipformer_amd import ops
+    from tests.test_modules_gpu import ZERO_GRAD
+    g = Hh.golden(f"fullsize_{name}.npz")
+    B = int(g["meta"][0])
+    assert B == Hh.FULL_BATCH[name]
+    pc, im, a = build(name)
+    ck = Checks(f"fullsize-fixture[{name}, {B} pairs]")
+    pts = Hh.synth_points(int(g["meta"][1]), 2 * B, a["N"]).cuda(); start = Hh.synth_start(int(g["meta"][1]), 2 * B, a["N"]).cuda()
+    imgs = Hh.synth_images(int(g["meta"][2]), B, a["img"], a["img"]).cuda()
+    pc.eval(); im.eval()
+    with torch.no_grad(), forced_start(start):
+        f, bb = pc(pts)
+        fi, bbi = im(imgs)
+    ck.lt("pc eval backbone rel", rel(bb, g["pc_eval_backbone"]), 2e-3)
+    ck.lt("pc eval feats rel", rel(f, g["pc_eval_feats"]), 2e-3)
+    ck.lt("img eval backbone rel", rel(bbi, g["img_eval_backbone"]), 2e-3)
+    ck.lt("img eval feats rel", rel(fi, g["img_eval_feats"]), 2e-3)
+    ref_bb = torch.from_numpy(g["pc_eval_backbone"]).double()
+    per = ((bb.cpu().double() - ref_bb).norm(dim=1) / ref_bb.norm(dim=1)).max().item()
+    ck.lt("pc eval backbone worst-sample rel", per, 4e-3)
+    pc.train(); im.train(); pc.zero_grad(); im.zero_grad()
+    with forced_start(start):
+        f, bb = pc(pts)
+    fi, bbi = im(imgs)
+    ck.lt("pc train backbone rel", rel(bb, g["pc_train_backbone"]), 2e-3)
+    ck.lt("img train backbone rel", rel(bbi, g["img_train_backbone"]), 2e-3)
+    ck.lt("pc train feats rel", rel(f, g["pc_train_feats"]), 1e-2)
+    ck.lt("img train feats rel", rel(fi, g["img_train_feats"]), 1e-2)
+    f1, f2 = f[:B], f[B:]
+    l_im = ops.ntxent_loss(f1, f2, 0.1); l_cm = ops.ntxent_loss((f1 + f2) / 2, fi, 0.1)
+    total = l_im + 1.0 * l_cm
+    got = np.array([total.item(), l_im.item(), l_cm.item()])
+    report(f"fullsize-fixture[{name}] loss hip {got} reference {g['loss']}")
+    ck.lt("loss abs diff vs the reference (SURVEY 8c: 5e-3)", float(np.abs(got - g["loss"]).max()), 5e-3)
+    for k in ("latent_head.0.running_mean", "latent_head.0.running_var", "group2emb.first_conv.1.running_var"):
+        ck.lt(f"buffer {k} rel", rel(pc.state_dict()[k], g["pc_buf." + k]), 3e-2)
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_{name}.json")))
+    lin = (bb * Hh.synth_like(700, bb.shape).cuda()).sum() + (bbi * Hh.synth_like(701, bbi.shape).cuda()).sum()
+    for tag, loss in (("lin", lin), ("ntx", total)):
+        pc.zero_grad(); im.zero_grad()
+        loss.backward(retain_graph=(tag == "lin"))
+        got_s, ref_s, worst = [], [], (0.0, "-")
+        for which, model in (("pc", pc), ("img", im)):
+            params = dict(model.named_parameters())
+            refn, refs = g[f"{which}_{tag}_norms"], torch.from_numpy(g[f"{which}_{tag}_samples"])
+            off = 0
+            dev = 0.0
+            for i, k in enumerate(names[which]):
+                p = params[k]
+                gk = p.grad if p.grad is not None else torch.zeros_like(p)
+                smp = Hh.grad_sample(gk)
+                r = refs[off:off + smp.numel()]; off += smp.numel()
+                if k.endswith(ZERO_GRAD) or refn[i] <= 1e-3 * refn.max():
+                    continue                                     # exactly zero by BatchNorm's shift invariance / carries no weight
+                dev = max(dev, abs(gk.double().norm().item() / refn[i] - 1.0))
+                got_s.append(smp); ref_s.append(r)
+                if smp.numel() >= 64:
+                    d = 1 - cosine(smp, r)
+                    worst = max(worst, (d, f"{which}.{k}"))
+            assert off == refs.numel()
+            ck.lt(f"[{tag}] {which} gradient-norm ratio, max deviation from 1", dev, 0.08)
+        d_all = 1 - cosine(torch.cat(got_s), torch.cat(ref_s))
+        report(f"fullsize-fixture[{name}] [{tag}] sampled all-parameter deficit {d_all:.5f}; worst tensor {worst[0]:.5f} {worst[1]}")
+        f_all, f_min = FIXTURE_FLOORS[name][tag]
+        ck.lt(f"[{tag}] all-parameter gradient deficit (1 - cos, strided samples) vs the reference", d_all, f_all)
+        ck.lt(f"[{tag}] worst per-tensor gradient deficit vs the reference", worst[0], f_min)
+    ck.done()

@@ -92,6 +92,57 @@ def test_models_vs_reference(name):
         _close(bufs[k], g["pc_buf." + k])
 
 
+@pytest.mark.parametrize("name", ["c1", "c3", "c4"])
+def test_oracle_at_full_batch_vs_reference(name):
+    """The restatement at BASELINE's per-GPU batches (configs[1]: 64 pairs, [2]: 32, [3]: 16) against fullsize_<name>.npz, written by the imported reference
+    (make_golden.py make_fullsize): eval + train-mode (dropout 0) features, the pre-training loss and BOTH losses' gradients (norms and
+    the strided samples) -- what the live-oracle GPU tests at full size (tests/test_fullsize_gpu.py, dropout masks replayed) lean on.
+    The HIP path is compared with the same three fixtures directly on the GPU box (test_full_batch_vs_reference_fixture)."""
+    arch, a = _arch(name)
+    g = Hh.golden(f"fullsize_{name}.npz")
+    B = int(g["meta"][0])
+    pc = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100)
+    im = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200)
+    pts = Hh.synth_points(int(g["meta"][1]), 2 * B, a["N"]); start = Hh.synth_start(int(g["meta"][1]), 2 * B, a["N"])
+    imgs = Hh.synth_images(int(g["meta"][2]), B, a["img"], a["img"])
+    with torch.no_grad():
+        f, bb = O.pc_forward(pc, pts, start, arch, False)
+        fi, bbi = O.img_forward(im, imgs, arch, False)
+    _close(f, g["pc_eval_feats"]); _close(bb, g["pc_eval_backbone"])
+    _close(fi, g["img_eval_feats"]); _close(bbi, g["img_eval_backbone"])
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_{name}.json")))
+    pcp = {k: pc[k].clone().requires_grad_() for k in names["pc"]}
+    imp = {k: im[k].clone().requires_grad_() for k in names["img"]}
+    pc_sd = dict(pc); pc_sd.update(pcp)
+    im_sd = dict(im); im_sd.update(imp)
+    for sd in (pc_sd, im_sd):
+        for k in list(sd):
+            if "cross_attn_1." in k:
+                sd[k] = sd[k.replace("cross_attn_1.", "cross_attn_n.")]
+    f, bb = O.pc_forward(pc_sd, pts, start, arch, True, O.Masks("off"), {})
+    fi, bbi = O.img_forward(im_sd, imgs, arch, True, O.Masks("off"), {})
+    l_im = O.ntxent(f[:B], f[B:]); l_cm = O.ntxent((f[:B] + f[B:]) / 2, fi)
+    total = l_im + l_cm
+    _close(np.array([total.item(), l_im.item(), l_cm.item()]), g["loss"], 1e-5, 1e-5)
+    _close(f, g["pc_train_feats"], 1e-4, 1e-4); _close(fi, g["img_train_feats"], 1e-4, 1e-4)
+    _close(bb, g["pc_train_backbone"], 1e-4, 1e-4); _close(bbi, g["img_train_backbone"], 1e-4, 1e-4)
+    lin = (bb * Hh.synth_like(700, bb.shape)).sum() + (bbi * Hh.synth_like(701, bbi.shape)).sum()
+    for tag, loss in (("lin", lin), ("ntx", total)):
+        for d in (pcp, imp):
+            for v in d.values():
+                v.grad = None
+        loss.backward(retain_graph=(tag == "lin"))
+        for which, params in (("pc", pcp), ("img", imp)):
+            zero = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)
+            norms = np.array([zero(params[k]).double().norm().item() for k in names[which]])
+            np.testing.assert_allclose(norms, g[f"{which}_{tag}_norms"], rtol=2e-3, atol=1e-5 * g[f"{which}_{tag}_norms"].max())
+            smp = torch.cat([Hh.grad_sample(zero(params[k])) for k in names[which]])
+            ref = torch.from_numpy(g[f"{which}_{tag}_samples"])
+            cos = float((smp.double() @ ref.double()) / (smp.double().norm() * ref.double().norm()))
+            assert cos > 1 - 1e-6, (tag, which, cos)
+            np.testing.assert_allclose(smp.numpy(), ref.numpy(), rtol=2e-2, atol=1e-4 * float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny2", "c1", "c3", "c4", "ref144", "ref144m4"])
 def test_stages_vs_reference(name):
     arch, a = _arch(name)
