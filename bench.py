@@ -2,6 +2,7 @@
 """bench.py -- pre-training pairs/s of the MI355X-native ViPFormer hot path.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks: vipformer_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -281,9 +282,17 @@ def _step_profile(arch):
 TOLERANCES = {
     "index_work": "bit-exact (FPS indices, kNN sets, neighbours, 3-NN indices and weight bits)",
     "fwd_rel_l2": 2e-3, "fwd_rel_l2_behind_batchnorm_head": 1e-2, "loss_abs": 5e-3,
-    "grad_cos_all": {"linear_loss": 0.998, "ntxent_loss": 0.996}, "grad_cos_worst_tensor": {"linear_loss": 0.99, "ntxent_loss": 0.98},
-    "note": "against the fp32 oracle at the per-GPU batch; SURVEY 8c asked for grad cosine >= 0.999: not reachable with fp16 operand storage "
-            "(fp16 weights alone cost 0.99922, profiles/r04_rounding_budget_fp16_c1_16.txt) -- the floors above are what the tests assert",
+    "grad_cos_all": {"linear_loss": 0.999, "ntxent_loss": {"c2": 0.9978, "c3": 0.9978, "c4": 0.9983, "ref144": 0.9956}},
+    "grad_cos_worst_tensor": {"linear_loss": 0.99, "ntxent_loss": 0.98},
+    "note": "against the fp32 oracle at the per-GPU batch, real dropout with the kernels' masks replayed; SURVEY 8c asked for grad cosine >= 0.999: "
+            "held for the loss linear in the backbone features on every configuration; for the pre-training loss it is not reachable with fp16 "
+            "operand storage (fp16 weights alone cost 0.99922, profiles/r04_rounding_budget_fp16_c1_16.txt) -- the per-configuration floors "
+            "above (tests/test_fullsize_gpu.py FLOORS_FULL) are what the live-oracle tests assert; against the fixtures the imported reference wrote at 64 / 32 / 16 pairs (tests/golden/fullsize_*.npz, dropout 0) the "
+            "linear loss IS held to 0.999 and the NT-Xent floor is stated per configuration (tests/test_fullsize_gpu.py FIXTURE_FLOORS).  "
+            "NT-Xent itself (lightly==1.1.21, absent from the image and from /root/reference) is restated from the published SimCLR "
+            "formulation: that row is PARITY-UNPINNED -- everything in front of the loss and the whole backward pass is pinned to the reference",
+    "grad_cos_all_vs_reference_fixture": {"linear_loss": 0.999, "ntxent_loss": {"c2@64": 0.987, "c3@32": 0.991, "c4@16": 0.979},
+                                          "derivation": "2 x the fp16 rounding budget of the same inputs, profiles/r06_rounding_budget_fixture_fp16_*.txt"},
 }
 
 
@@ -400,14 +409,15 @@ def physical_cores():
         return os.cpu_count()
 
 
-def cpu_baseline(a, pairs=8, timed_steps=10, warm_steps=2, timed_steps_all=3):
+def cpu_baseline(a, pairs=8, timed_steps=10, warm_steps=2, timed_steps_all=2):
     """The oracle (fp32 torch-CPU restatement of the reference step, pinned against the reference by the golden fixtures) on this
-    box's host cores: forward + backward + AdamW on config 1 (8 c1-shaped pairs).  The reported value is the MEDIAN of `timed_steps`
-    steps behind `warm_steps` warm-up steps at 8 threads (BASELINE.md section 3 plans 5 + 20; 2 + 10 keeps the default bench run inside
-    its few minutes at ~0.8 s per step) -- the thread count the survey measured the reference at and, on every box seen, the faster
-    one; the all-physical-cores run (1 + `timed_steps_all`, median) is reported beside it and becomes the value only if it is faster.
-    Beside both: the DataLoader-worker leg (datasets/data.py:97-112: two trans_1 views + one image transform per pair, single thread
-    x cores)."""
+    box's host cores: forward + backward + AdamW on config 1 (8 c1-shaped pairs).  A SHORT THREAD SWEEP first (8 / 16 / 32 / 64 / all
+    physical cores, 1 warm-up + `timed_steps_all` timed steps each: 8 pairs are too little work for 100+ threads -- torch's intra-op
+    parallelism loses to its own synchronisation, 9 x on the boxes seen), then the reported value: the MEDIAN of `timed_steps` steps
+    behind `warm_steps` warm-up steps at the BEST thread count the sweep found (`cores` says which).  BASELINE.md section 3 plans 5 + 20
+    steps: main() asks for that when the bench itself runs >= 100 timed steps; 2 + 10 keeps the default run inside its few minutes.
+    Beside it: the sweep, and the DataLoader-worker leg (datasets/data.py:97-112: two trans_1 views + one image transform per pair,
+    single thread x cores)."""
     from oracle import augment as A
     from oracle import torch_oracle as O
     from tests import helpers as Hh
@@ -447,21 +457,21 @@ def cpu_baseline(a, pairs=8, timed_steps=10, warm_steps=2, timed_steps_all=3):
 
     default_threads = torch.get_num_threads()
     cores = physical_cores()
-    sec_all = run(cores, timed_steps_all, 1) if cores > 8 else None
-    sec8 = run(min(8, cores), timed_steps, warm_steps)
-    if sec_all is None:
-        sec_all = sec8
+    counts = sorted({min(c, cores) for c in (8, 16, 32, 64, cores)})
+    sweep = {c: run(c, timed_steps_all, 1) for c in counts} if len(counts) > 1 else {}
+    used = min(sweep, key=sweep.get) if sweep else counts[0]
+    sec = run(used, timed_steps, warm_steps)
+    sec_all = sweep.get(cores, sec)
+    sec8 = sec if used == min(8, cores) else sweep.get(min(8, cores), sec)
     torch.set_num_threads(1)
     t_view, t_img = A.time_sample(a["N"], a["img"], a["img"], repeats=30)
     torch.set_num_threads(default_threads)
     aug_pair = 2 * t_view + t_img
-    # the CPU path's best foot forward: 8 pairs are too little work for 128 threads (torch's intra-op parallelism loses to its own
-    # synchronisation), so `value` is the faster of the two thread counts and `cores` says which one it was
-    sec, used = (sec_all, cores) if sec_all < sec8 else (sec8, min(8, cores))
-    n_t, n_w = (timed_steps_all, 1) if used != min(8, cores) else (timed_steps, warm_steps)
     return dict(value=round(pairs / sec, 3), unit="pairs/s", cores=used, kind="port",
-                sample=f"median of {n_t} timed steps (after {n_w} warm-up) of {pairs} pairs = BASELINE configs[0] (E1CL6SL-H4D256-L96-MR2, 1024 pts + "
-                       f"224x224 img), fp32 torch-CPU oracle incl. FPS/kNN (C), fwd+bwd+AdamW; {sec:.2f} s/step on {used} threads",
+                sample=f"median of {timed_steps} timed steps (after {warm_steps} warm-up) of {pairs} pairs = BASELINE configs[0] (E1CL6SL-H4D256-L96-MR2, 1024 pts + "
+                       f"224x224 img), fp32 torch-CPU oracle incl. FPS/kNN (C), fwd+bwd+AdamW; {sec:.2f} s/step on {used} threads = the best of "
+                       f"the thread sweep {counts}",
+                thread_sweep_pairs_per_s={str(c): round(pairs / t, 3) for c, t in sweep.items()},
                 pairs_per_s_all_physical_cores=round(pairs / sec_all, 3), physical_cores=cores, pairs_per_s_8_threads=round(pairs / sec8, 3),
                 augmentation=dict(ms_per_view_trans_1=round(t_view * 1e3, 3), ms_per_image_transform=round(t_img * 1e3, 3),
                                   ms_per_pair_one_thread=round(aug_pair * 1e3, 3), pairs_per_s_all_cores=round(cores / aug_pair, 1),
@@ -664,6 +674,15 @@ def main():
     ap.add_argument("--wgrad-async", action="store_true", help="grouped weight-gradient launches on a side stream")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (default: the configuration's per-GPU batch)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (the reference self-spawns as well,
+        # pretrain.py:332-341) -- BEFORE this process has touched the GPU -- relay their output and hand rank 0's JSON line on as
+        # the last line of stdout (vipformer_amd/launch.py).  Under torch.distributed.run (WORLD_SIZE set) nothing changes.
+        from vipformer_amd.launch import launch_ranks
+        if os.environ.get("VPF_SINGLE_GPU", "0") != "1" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus,
+                              timeout_s=float(os.environ.get("VPF_BENCH_LAUNCH_TIMEOUT_S", "1500"))))
     if args.arch == "c5":
         if int(os.environ.get("WORLD_SIZE", "1")) != 1:
             raise SystemExit("--arch c5 is a one-GPU side line")
@@ -951,7 +970,9 @@ def main():
                             + prof.get("stale", "no whole-step budget committed for this architecture")))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(ARCHS["c2"])
+        # 5 warm-up + 20 timed CPU steps -- taken when the bench itself is run at its full length (>= 100 steps);
+        # the default / driver-length run keeps 2 + 10 so that it finishes within its few minutes
+        cpu = cpu_baseline(ARCHS["c2"], timed_steps=20, warm_steps=5) if args.steps >= 100 else cpu_baseline(ARCHS["c2"])
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -35,6 +35,10 @@ def pytest_collection_modifyitems(config, items):
     items.sort(key=_rank)                                    # stable: the order inside a file is kept
     import torch
     if torch.cuda.is_available():
+        # The checker (oracle/torch_oracle.py) runs on the GPU box's HOST: with torch's default of one thread per core of a 100+-core
+        # box its small fp32 ops are oversubscribed and run ~9 x slower than on 8 threads (bench.py's cpu_baseline measured exactly that:
+        # 1.43 vs 12.7 pairs/s) -- round 5's suite spent 500 of its 535 s there.  8 threads, the container's count.
+        torch.set_num_threads(min(8, os.cpu_count() or 8))
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for it in items:

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Per-stage error budget of the bf16 rounding points -- oracle against oracle, CPU only.
 
-    python -m tests.rounding_budget [arch=c1] [pairs=4] [bf16|fp16|fp16s|fp16s1] [quick] > profiles/r04_rounding_budget_<fwd>_<arch>.txt
+    python -m tests.rounding_budget [arch=c1] [pairs=4] [bf16|fp16|fp16s|fp16s1] [quick] [fixture] > profiles/r04_rounding_budget_<fwd>_<arch>.txt
+
+`fixture` (round 6): the conditions of tests/golden/fullsize_<arch>.npz -- inputs of seeds 930 / 931, every dropout at 0 -- and, beside
+the exact cosines, the cosine over the strided samples of helpers.grad_sample that the fixture keeps: the per-configuration NT-Xent
+floors of tests/test_fullsize_gpu.py FIXTURE_FLOORS come from these tables (profiles/r06_rounding_budget_fixture_*.txt).
 
 The fp32 oracle (pinned against the reference) is the baseline.  Each rounding point of the HIP path (oracle/torch_oracle.py:
 FWD_TAGS -- activations / weights stored as bf16 -- and BWD_TAGS -- gradients stored as bf16 operands of the backward products) is
@@ -27,9 +31,12 @@ def cosine(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
+DROPS = (0.1, 0.5)
+
+
 def run(name, B, tags, backward, pts, start, imgs, masks, Rb, Rbi):
     a = Hh.ARCHS[name]
-    arch = O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"], atten_drop=0.1, mlp_drop=0.5)
+    arch = O.Arch(D=a["D"], H=a["H"], G=a["G"], K=a["K"], S=a["S"], MR=a["MR"], img=a["img"], patch=a["patch"], atten_drop=DROPS[0], mlp_drop=DROPS[1])
     pc_sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_pc_{name}.json"), 100)
     im_sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_img_{name}.json"), 200)
     isparam = lambda k, v: v.dtype == torch.float32 and "running" not in k and "cross_attn_1." not in k
@@ -65,11 +72,16 @@ def main():
     import functools
     EMU = {"bf16": O.emulate_bf16, "fp16": O.emulate_fp16, "fp16s": functools.partial(O.emulate_fp16, grad_scale=65536.0),
            "fp16s1": functools.partial(O.emulate_fp16, grad_scale=1.0)}[fwd]
-    quick = len(sys.argv) > 4 and sys.argv[4] == "quick"        # only the combined rows
+    quick = "quick" in sys.argv[4:]                             # only the combined rows
+    fixture = "fixture" in sys.argv[4:]
+    global DROPS
+    if fixture:
+        DROPS = (0.0, 0.0)
     a = Hh.ARCHS[name]
     torch.manual_seed(0)
-    pts = Hh.synth_points(300, 2 * B, a["N"]); start = Hh.synth_start(300, 2 * B, a["N"])
-    imgs = Hh.synth_images(400, B, a["img"], a["img"])
+    s_pts, s_img = (930, 931) if fixture else (300, 400)
+    pts = Hh.synth_points(s_pts, 2 * B, a["N"]); start = Hh.synth_start(s_pts, 2 * B, a["N"])
+    imgs = Hh.synth_images(s_img, B, a["img"], a["img"])
     T = (a["img"] // a["patch"]) ** 2
 
     class FixedMasks(O.Masks):        # torch Bernoulli masks drawn ONCE per site and replayed for every variant
@@ -90,8 +102,10 @@ def main():
     variants = [] if quick else [(t, (t,), t in O.BWD_TAGS) for t in O.FWD_TAGS + O.BWD_TAGS]
     variants += [("all forward", O.FWD_TAGS, False), ("all backward", O.BWD_TAGS, True), ("all (the HIP data path)", O.FWD_TAGS + O.BWD_TAGS, True)]
     print(f"# forward operands rounded to {fwd[:4]} (gradient operands: " + {"fp16s": "fp16 at loss scale 65536", "fp16s1": "fp16, no loss scale"}.get(fwd, "bf16") + ")")
-    print(f"# rounding budget, arch {name}, {B} pairs, train mode, dropout 0.1 / 0.5 with fixed masks; baseline = fp32 oracle (loss {ref['loss']:.5f})")
-    print(f"{'rounding point(s)':28s} {'pc bb rel':>10s} {'img bb rel':>10s} {'dloss':>9s} | linear loss: {'all cos':>9s} {'lowest':>8s} | NT-Xent: {'all cos':>9s} {'median':>8s} {'lowest':>8s}")
+    print(f"# rounding budget, arch {name}, {B} pairs, train mode, dropout {DROPS[0]} / {DROPS[1]}" + (" (the fullsize fixture's inputs)" if fixture else " with fixed masks")
+          + f"; baseline = fp32 oracle (loss {ref['loss']:.5f})")
+    print(f"{'rounding point(s)':28s} {'pc bb rel':>10s} {'img bb rel':>10s} {'dloss':>9s} | linear loss: {'all cos':>9s} {'lowest':>8s} | NT-Xent: {'all cos':>9s} {'median':>8s} {'lowest':>8s}"
+          + (" | strided samples: lin all cos, NT-Xent all cos" if fixture else ""))
     for label, tags, bwd in variants:
         r = run(name, B, tags, bwd, pts, start, imgs, masks, Rb, Rbi)
         rel = lambda x, y: float((x - y).double().norm() / y.double().norm())
@@ -100,9 +114,11 @@ def main():
             ks = [k for k in ref[key] if k in r[key] and not k.endswith(("first_conv.0.bias", "first_conv.3.bias", "second_conv.0.bias"))]
             allc = cosine(torch.cat([r[key][k].flatten() for k in ks]), torch.cat([ref[key][k].flatten() for k in ks]))
             per = sorted(cosine(r[key][k], ref[key][k]) for k in ks)
-            out.append((allc, float(np.median(per)), per[0]))
+            smp = cosine(torch.cat([Hh.grad_sample(r[key][k]) for k in ks]), torch.cat([Hh.grad_sample(ref[key][k]) for k in ks]))
+            out.append((allc, float(np.median(per)), per[0], smp))
         print(f"{label:28s} {rel(r['bb'], ref['bb']):10.2e} {rel(r['bbi'], ref['bbi']):10.2e} {abs(r['loss'] - ref['loss']):9.2e} | "
-              f"{'':13s}{out[0][0]:9.5f} {out[0][2]:8.5f} | {'':9s}{out[1][0]:9.5f} {out[1][1]:8.5f} {out[1][2]:8.5f}", flush=True)
+              f"{'':13s}{out[0][0]:9.5f} {out[0][2]:8.5f} | {'':9s}{out[1][0]:9.5f} {out[1][1]:8.5f} {out[1][2]:8.5f}"
+              + (f" | {out[0][3]:9.5f} {out[1][3]:9.5f}" if fixture else ""), flush=True)
 
 
 if __name__ == "__main__":

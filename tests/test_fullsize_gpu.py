@@ -56,6 +56,17 @@ def test_full_batch_eval_forward_vs_oracle(name):
 
 
 TRAIN_FULL = {"c1": 32, "c3": 32, "c4": 16, "ref144": 16}      # c1: half of configs[1]'s 64 pairs (the oracle's four backward passes stay in minutes)
+# Gradient-direction floors of the full-batch live-oracle tests (deficit = 1 - cosine against the fp32 oracle, all parameters / worst tensor),
+# PER CONFIGURATION (no blanket 0.996).  Linear loss: SURVEY 8c's cosine >= 0.999 everywhere (measured 7.1 - 9.0e-4 over
+# rounds 4 - 6, identical to five digits run after run: the masks are seeded; the fp16-emulating oracle itself sits at 6.9 - 8.8e-4, so this IS the
+# data format's budget).  Pre-training loss: 1.35 x the larger of (measured, emulated budget) of profiles/r0[4-6]_parity_report.txt --
+# c1 1.52 / 1.66e-3 (32 / 64 pairs), c3 1.62e-3, c4 budget 1.23e-3, ref144 budget 3.27e-3 (eight layers of 128 latents at 16 pairs: NOTES round 5).
+FLOORS_FULL = {
+    "c1": {"linear loss": (1e-3, 1e-2), "NT-Xent loss": (2.2e-3, 2e-2)},
+    "c3": {"linear loss": (1e-3, 1e-2), "NT-Xent loss": (2.2e-3, 2e-2)},
+    "c4": {"linear loss": (1e-3, 1e-2), "NT-Xent loss": (1.7e-3, 2e-2)},
+    "ref144": {"linear loss": (1e-3, 1e-2), "NT-Xent loss": (4.4e-3, 2e-2)},
+}
 
 
 @pytest.mark.parametrize("name", ["c1", "c3", "c4", "ref144"])
@@ -64,9 +75,9 @@ def test_full_batch_train_step_loss_and_gradients(name):
     dropout 0.1 / 0.5 with the kernels' own masks handed to the oracle.
       * NT-Xent loss: abs <= 5e-3 against the fp32 oracle (SURVEY 8c) -- the projection head's BatchNorm sees 64 / 32 samples here;
       * gradients of a loss linear in the backbone features AND of the pre-training loss, every parameter, against the fp32 oracle
-        with constant floors (test_modules_gpu.FLOORS: all-parameter cosine >= 0.998 / 0.996, worst tensor >= 0.99 / 0.98; measured
-        0.9990 - 0.9994 / 0.9983 - 0.9995 with fp16 operands, where bf16 operands gave 0.9855 - 0.9947); the deficit of the
-        fp16-emulating oracle on the same batch is reported beside it."""
+        with constant per-configuration floors (FLOORS_FULL: linear loss cosine >= 0.999 everywhere, the pre-training loss >= 0.9978 /
+        0.9978 / 0.9983 / 0.9956; measured 0.9991 - 0.9993 / 0.9969 - 0.9994 with fp16 operands, where bf16 operands gave 0.9855 -
+        0.9947); the deficit of the fp16-emulating oracle on the same batch is reported beside it."""
     from oracle import torch_oracle as O
     from vipformer_amd import ops
     from tests.test_modules_gpu import budget_check, clear, grads_of
@@ -128,8 +139,8 @@ def test_full_batch_train_step_loss_and_gradients(name):
     le.backward()
     ntx_emu = grads_of((pcp, imp)); clear((pcp, imp))
     where = f"fullsize-train[{name}]"
-    budget_check(ck, where, "linear loss", pc, im, lambda p: lin_grads.get(id(p)), lin_emu, lin_f32, 2e-4, 2e-3)
-    budget_check(ck, where, "NT-Xent loss", pc, im, lambda p: p.grad, ntx_emu, ntx_f32, 1e-3, 5e-3)
+    budget_check(ck, where, "linear loss", pc, im, lambda p: lin_grads.get(id(p)), lin_emu, lin_f32, floors=FLOORS_FULL[name])
+    budget_check(ck, where, "NT-Xent loss", pc, im, lambda p: p.grad, ntx_emu, ntx_f32, floors=FLOORS_FULL[name])
     ck.done()
 
 
@@ -138,10 +149,10 @@ def test_c2_train_step_at_the_benchmarked_batch_64_pairs():
     dropout 0.1 / 0.5 with the kernels' own masks handed to the oracle -- BatchNorm of the projection head over 128 / 64 rows, 128 x 128
     and 64 x 64 NT-Xent logits.  One fp32 oracle forward + ONE backward (the pre-training loss; the linear-loss and fp16-emulating passes
     run at 32 pairs in test_full_batch_train_step_loss_and_gradients): loss abs <= 5e-3, backbone rel <= 2e-3, features <= 1e-2,
-    every parameter's gradient against the constant floors (all-parameter cosine >= 0.996, worst tensor >= 0.98)."""
+    every parameter's gradient against the configuration's constant floors (FLOORS_FULL["c1"]: all-parameter cosine >= 0.9978, worst tensor >= 0.98)."""
     from oracle import torch_oracle as O
     from vipformer_amd import ops
-    from tests.test_modules_gpu import FLOORS, ZERO_GRAD, grads_of
+    from tests.test_modules_gpu import ZERO_GRAD, grads_of
     name, B = "c1", 64
     ops.rng.seed(8765)
     with ops.rng.pinned():
@@ -193,7 +204,7 @@ def test_c2_train_step_at_the_benchmarked_batch_64_pairs():
     for x in per[:3]:
         report(f"fullsize-train[{name}, {B} pairs] [NT-Xent loss] largest deficit vs fp32: hip {x[0]:.5f} {x[1]}")
     report(f"fullsize-train[{name}, {B} pairs] [NT-Xent loss] all-parameter deficit (1 - cos): hip/fp32 {d_all:.5f}")
-    f_all, f_min = FLOORS["NT-Xent loss"]
+    f_all, f_min = FLOORS_FULL[name]["NT-Xent loss"]
     ck.lt("[NT-Xent loss] all-parameter gradient deficit (1 - cos) vs fp32", d_all, f_all)
     ck.lt("[NT-Xent loss] worst per-tensor gradient deficit vs fp32", per[0][0], f_min)
     ck.done()
@@ -203,14 +214,21 @@ def test_c2_train_step_at_the_benchmarked_batch_64_pairs():
 # Full size against fixtures written by the IMPORTED REFERENCE (tests/golden/make_golden.py make_fullsize): no
 # oracle runs on the GPU box's host here.  Dropout 0 on both sides (a fixture cannot replay the kernels' masks; the dropout placement
 # is pinned by the dropout_*.npz fixtures and, at full size with the real probabilities, by the live-oracle tests above).
-# Floors on the gradient's direction, 1 - cosine over the strided samples of every parameter (helpers.grad_sample), PER CONFIG -- derived
-# from what fp16 operands cost on that configuration (profiles/r0[3-5]_rounding_budget_*.txt: weights + activations rounded to fp16 in the
-# fp32 oracle put the pre-training loss's gradient 0.9 - 1.7e-3 off fp32; the linear loss's 2 - 6e-4) with ~2 x headroom for the batch:
-# SURVEY 8c's 1e-3 (cosine >= 0.999) holds for the linear loss everywhere; the NT-Xent floor is stated per configuration.
-FIXTURE_FLOORS = {          # name -> {loss tag -> (all-parameter deficit, worst per-tensor deficit among tensors with >= 64 samples)}
-    "c1": {"lin": (1e-3, 1e-2), "ntx": (3e-3, 2e-2)},
-    "c3": {"lin": (1e-3, 1e-2), "ntx": (4e-3, 2e-2)},
-    "c4": {"lin": (1e-3, 1e-2), "ntx": (4e-3, 2e-2)},
+# Floors on the gradient's direction (deficit = 1 - cosine over the strided samples of every parameter, helpers.grad_sample), PER CONFIG and
+# DERIVED, not fitted: tests/rounding_budget.py in `fixture` mode runs the fp32 oracle against the same oracle with every fp16 rounding
+# point of the HIP data path switched on, on exactly these inputs (profiles/r06_rounding_budget_fixture_fp16_{c1_64,c3_32,c4_16}.txt, last
+# row, last two columns) -- what fp16 operand storage costs on that configuration whatever the kernels do:
+#     linear loss  : 1.9e-4 / 1.7e-4 / 1.7e-4   -> floor 1e-3 everywhere = SURVEY 8c's cosine >= 0.999 (HIP measured 1.5e-4 at c1)
+#     NT-Xent loss : 6.3e-3 / 4.3e-3 / 1.05e-2  -> floor = 2 x the budget (HIP measured 8.2e-3 at c1)
+# Without dropout the synthetic-weight features of a batch are nearly collinear and the temperature-0.1 softmax is sharp (l_cmid ~ 8.9 against
+# ln 63 = 4.1 at chance): dL/dfeats is a small difference of large terms, so the pre-training loss's gradient is far more sensitive to the
+# forward roundings here than in the dropout runs of the live-oracle tests above (3e-3 at c1 / 64 pairs).  Per tensor the budget's LOWEST cosine is
+# meaningless (-0.08 .. 0.14: tensors whose gradient is noise); its MEDIAN is 1.2e-3 / 1.0e-3 / 0.5e-3 -> floor 2 x that, and the worst tensor
+# among those that carry >= 1 % of the largest norm is held to 5e-2 (a logic error shows as a cosine near 0, not as 0.95).
+FIXTURE_FLOORS = {          # name -> {loss tag -> (all-parameter deficit, median per-tensor deficit, worst deficit among heavy tensors)}
+    "c1": {"lin": (1e-3, 1e-3, 1e-2), "ntx": (1.3e-2, 2.4e-3, 5e-2)},
+    "c3": {"lin": (1e-3, 1e-3, 1e-2), "ntx": (9e-3, 2.0e-3, 5e-2)},
+    "c4": {"lin": (1e-3, 1e-3, 1e-2), "ntx": (2.1e-2, 1.1e-3, 5e-2)},
 }
 
 
@@ -222,7 +240,8 @@ def test_full_batch_vs_reference_fixture(name):
       * train mode (dropout 0): backbone <= 2e-3, features behind the BatchNorm head <= 1e-2, pre-training loss abs <= 5e-3,
         BatchNorm running statistics <= 3e-2;
       * gradients of the linear loss and of the pre-training loss, every parameter: norm within 8 % of the reference's for every tensor
-        that carries >= 0.1 % of the largest norm, direction by the strided samples against FIXTURE_FLOORS."""
+        that carries >= 0.1 % of the largest norm, direction by the strided samples against FIXTURE_FLOORS (derived per configuration from
+        the fp16 rounding budget of exactly these inputs)."""
     import json
     import os
     from vipformer_amd import ops
@@ -266,7 +285,7 @@ def test_full_batch_vs_reference_fixture(name):
     for tag, loss in (("lin", lin), ("ntx", total)):
         pc.zero_grad(); im.zero_grad()
         loss.backward(retain_graph=(tag == "lin"))
-        got_s, ref_s, worst = [], [], (0.0, "-")
+        got_s, ref_s, worst, per = [], [], (0.0, "-"), []
         for which, model in (("pc", pc), ("img", im)):
             params = dict(model.named_parameters())
             refn, refs = g[f"{which}_{tag}_norms"], torch.from_numpy(g[f"{which}_{tag}_samples"])
@@ -283,12 +302,16 @@ def test_full_batch_vs_reference_fixture(name):
                 got_s.append(smp); ref_s.append(r)
                 if smp.numel() >= 64:
                     d = 1 - cosine(smp, r)
-                    worst = max(worst, (d, f"{which}.{k}"))
+                    per.append(d)
+                    if refn[i] >= 1e-2 * refn.max():
+                        worst = max(worst, (d, f"{which}.{k}"))
             assert off == refs.numel()
             ck.lt(f"[{tag}] {which} gradient-norm ratio, max deviation from 1", dev, 0.08)
         d_all = 1 - cosine(torch.cat(got_s), torch.cat(ref_s))
-        report(f"fullsize-fixture[{name}] [{tag}] sampled all-parameter deficit {d_all:.5f}; worst tensor {worst[0]:.5f} {worst[1]}")
-        f_all, f_min = FIXTURE_FLOORS[name][tag]
+        med = float(np.median(per))
+        report(f"fullsize-fixture[{name}] [{tag}] sampled all-parameter deficit {d_all:.5f}; per tensor: median {med:.5f}, worst heavy tensor {worst[0]:.5f} {worst[1]}")
+        f_all, f_med, f_min = FIXTURE_FLOORS[name][tag]
         ck.lt(f"[{tag}] all-parameter gradient deficit (1 - cos, strided samples) vs the reference", d_all, f_all)
-        ck.lt(f"[{tag}] worst per-tensor gradient deficit vs the reference", worst[0], f_min)
+        ck.lt(f"[{tag}] median per-tensor gradient deficit vs the reference", med, f_med)
+        ck.lt(f"[{tag}] worst gradient deficit among tensors with >= 1 % of the largest norm vs the reference", worst[0], f_min)
     ck.done()

@@ -36,6 +36,9 @@ def test_library_exports_every_declared_symbol():
     assert build.check_no_packed_f32(build.LIB) >= 8
     hit = "\ts_load_dwordx2 s[24:25], s[4:5], s21 offset:0x44\n"
     assert build.SPLIT_SLOAD.findall(hit) and not build.SPLIT_SLOAD.findall("\ts_load_dwordx2 s[24:25], s[4:5], 0x44\n\ts_load_dword s6, s[0:1], 0xce0\n")
+    for reg in ("s7", "m0", "vcc_lo", "vcc_hi", "ttmp4"):                      # every register an offset can sit in, with and without an immediate
+        assert build.SPLIT_SLOAD.findall(f"\ts_load_dword s6, s[0:1], {reg}\n"), reg
+        assert build.SPLIT_SLOAD.findall(f"\ts_buffer_load_dwordx4 s[8:11], s[0:3], {reg} offset:0x10\n"), reg
 
 
 def test_ctypes_table_matches_header():
@@ -260,6 +263,13 @@ def _dp_worker(rank, world, port, q):
     allp = [torch.zeros(n) for _ in range(world)]
     dist.all_gather(allp, pa["w"])
     ok_same = all(torch.equal(allp[0], t) for t in allp)
+    # DDP's per-forward buffer broadcast (train.sync_module_buffers, called by Pretrainer.eval() / probe.extract_features(trainer=...)):
+    # every rank ends with rank 0's BatchNorm running statistics and step counter
+    from vipformer_amd.train import sync_module_buffers
+    bn = torch.nn.BatchNorm1d(16)
+    bn.running_mean.fill_(float(rank) + 0.5); bn.running_var.fill_(2.0 + rank); bn.num_batches_tracked.fill_(7 + rank)
+    n_b = sync_module_buffers([bn], 0)
+    ok_same = ok_same and n_b == 3 and bool((bn.running_mean == 0.5).all()) and bool((bn.running_var == 2.0).all()) and int(bn.num_batches_tracked) == 7
     q.put((rank, ok_sum, ok_step, ok_same))
     dist.destroy_process_group()
 
@@ -413,3 +423,39 @@ def test_optimizer_step_hook_counts_every_torch_optimizer_step():
         e = ops._OPT_EPOCH[0]
         opt.step()
         assert ops._OPT_EPOCH[0] == e + 1, type(opt).__name__
+
+
+def _run_launcher(mode, nproc=2, timeout_s=None):
+    """vipformer_amd.launch.launch_ranks in a child python (it prints to ITS stdout / stderr: captured here)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from vipformer_amd.launch import launch_ranks; "
+            "sys.exit(launch_ranks(%r, [%r], %d, timeout_s=%r))" % (root, os.path.join(root, "tests", "_launch_stub.py"), mode, nproc, timeout_s))
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+
+
+def test_launch_ranks_relays_the_json_line_as_the_last_stdout_line():
+    """`python bench.py --gpus N` starts its own ranks (the reference: pretrain.py:332-341 mp.spawn).  The launcher with
+    a CPU stand-in for bench.py: two ranks over gloo, rank 0 prints the JSON line, then every rank prints more to stdout -- the launcher's
+    stdout must hold exactly the JSON line (last), everything else goes to stderr, exit code 0."""
+    import json
+    r = _run_launcher("ok")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[-1])
+    assert d == {"metric": "stub", "ranks_seen": 2, "n_gpus": 2}
+    assert "banner of rank 0" in r.stderr and "banner of rank 1" in r.stderr
+
+
+def test_launch_ranks_propagates_a_failed_rank_and_ends_a_hung_launch():
+    """A rank that exits non-zero makes the launch exit non-zero with NO result line on stdout; a rank that never comes back is ended
+    after the timeout by killing the session the launcher started (exit code 124), not waited for."""
+    import time
+    r = _run_launcher("fail")
+    assert r.returncode != 0 and r.stdout.strip() == "", (r.returncode, r.stdout)
+    t0 = time.time()
+    r = _run_launcher("hang", timeout_s=20.0)
+    assert r.returncode == 124 and r.stdout.strip() == "", (r.returncode, r.stdout, r.stderr[-2000:])
+    assert time.time() - t0 < 120

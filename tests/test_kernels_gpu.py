@@ -727,12 +727,15 @@ def test_sa_rows_fwd_equals_the_one_per_cu_kernel_bitwise(B, Lq, with_next, with
     # as two DECOUPLED 8-wave groups (LDS-counter barriers per group), and those with the second group started 20 x 64 cycles late
     # 4th field: the cache policy of the row stores (0 plain, 1 sc1 write-through, 2 nt, 3 sc0 sc1) -- the bytes are the same
     variants = [(0, 0, 0, 0), (3, 0, 0, 0), (3, 0, 0, 0), (1, 12, 0, 0), (1, 13, 0, 0), (1, 13, 20, 0), (1, 13, 20, 1), (1, 13, 0, 2), (1, 13, 0, 3)]
+    keys = ("sa_wg2", "sa_rb", "sa_stagger", "sa_store")
+    before = {k: _lib.debug_get(k) for k in keys}          # (a suite run with VPF_SA_RB / VPF_SA_WG2 set keeps ITS geometry afterwards)
     for wg2, rb, stg, pol in variants:
         _lib.debug_set("sa_wg2", wg2); _lib.debug_set("sa_rb", rb); _lib.debug_set("sa_stagger", stg); _lib.debug_set("sa_store", pol)
         try:
             outs.append(run())
         finally:
-            _lib.debug_set("sa_wg2", 0); _lib.debug_set("sa_rb", 0); _lib.debug_set("sa_stagger", 0); _lib.debug_set("sa_store", 0)
+            for k in keys:
+                _lib.debug_set(k, int(before[k]))
     names = ["x1", "mean2", "rstd2", "n2", "u", "h", "out", "mean1n", "rstd1n", "n1n", "qkv_next"]
     assert len(outs[0]) == len(outs[1])
     for n, p, q, r in zip(names, outs[0], outs[1], outs[2]):

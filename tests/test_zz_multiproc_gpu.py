@@ -149,6 +149,32 @@ def test_bench_json_line_is_the_last_stdout_line_with_rccl_alive():
     assert d["config"]["hip_graph"] is True and d["config"]["capture"] == "split" and d["config"]["losses_finite"]
 
 
+def test_bench_gpus_2_starts_its_own_ranks_and_relays_the_json_line():
+    """`python bench.py --gpus 2` with NO launcher around it (the reference self-spawns, pretrain.py:332-341): bench.py
+    starts two fresh ranks through torch.distributed.run before it touches the GPU (vipformer_amd/launch.py), the ranks run the N > 1
+    flow (broadcast, split capture, region-wise exchange, barrier + MAX timing) -- here sharing cuda:0 and exchanging over gloo, which is
+    what one GPU allows (VPF_DIST_BACKEND=gloo VPF_SINGLE_GPU=1; the driver's runs use RCCL, one GPU per rank) -- and the parent's
+    stdout ends with rank 0's JSON line: n_gpus 2, both ranks seen by the all-reduce, value = both ranks' pairs over the slowest rank's time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VPF_DIST_BACKEND="gloo", VPF_SINGLE_GPU="1", VPF_BENCH_WATCHDOG_S="150", VPF_BENCH_LAUNCH_TIMEOUT_S="210",
+               VPF_BENCH_MEDIAN="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs", "8",
+                        "--no-cpu-baseline", "--no-kernels", "--no-variants"], capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    if r.returncode != 0:
+        pytest.fail("bench.py --gpus 2 (self-launched) failed, rc %d\n---- stdout ----\n%s\n---- stderr (tail) ----\n%s"
+                    % (r.returncode, r.stdout, r.stderr[-8000:]), pytrace=False)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                                       # everything but the result line went to stderr
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["losses_finite"] and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 8 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+
+
 def test_data_parallel_two_ranks_on_one_gpu():
     """The N > 1 sequence of bench.py / Pretrainer (hipGraph forward + backward, region-wise asynchronous gradient all-reduce on the
     communication stream, AdamW per region) with two real processes sharing this GPU over gloo (tools/dp2_one_gpu.py; RCCL itself

@@ -88,9 +88,11 @@ def device_code_objects(path: str):
 # s_load_dword* with BOTH a base pair and an offset register: the compiler forms it when it splits a run-time index into a by-value
 # kernel-argument array of structs over the two (round 5: an 88-byte stride became base + 2 i, offset 86 i).  gfx950 drops the low two
 # bits of each part, not of the sum -- odd indices read the neighbouring fields, silently.  No kernel of the library has one; the link
-# step keeps it that way.
+# step keeps it that way.  The ban is deliberately BROAD: any scalar load whose offset operand is a register -- sN, m0,
+# vcc_lo / vcc_hi, ttmpN -- with or without an immediate is rejected, including the harmless dword-aligned `s_load_dword sX, s[a:b], sN`
+# form; a kernel that trips it on a plain run-time index should take the index through a VGPR / global load instead (the error text says so).
 import re as _re
-SPLIT_SLOAD = _re.compile(r"^.*\bs_(?:buffer_)?load_dword(?:x\d+)?\s+s\[?[0-9:]+\]?,\s*s\[[0-9:]+\],\s*s\d+.*$", _re.M)
+SPLIT_SLOAD = _re.compile(r"^.*\bs_(?:buffer_)?load_dword(?:x\d+)?\s+s\[?[0-9:]+\]?,\s*s\[[0-9:]+\],\s*(?:s\d+|m0|vcc_lo|vcc_hi|ttmp\d+)\b.*$", _re.M)
 
 
 def check_no_packed_f32(lib_path: str) -> int:
@@ -119,8 +121,9 @@ def check_no_packed_f32(lib_path: str) -> int:
     if bad:
         raise RuntimeError("packed-fp32 instructions in the device code (the co-residency fault's trigger, DESIGN.md section 6): " + "; ".join(bad))
     if bad_sload:
-        raise RuntimeError("scalar loads with a base AND an offset register in the device code (NOTES.md round 5: each part loses its low two "
-                           "address bits -- index the kernel-argument table another way): " + "; ".join(bad_sload))
+        raise RuntimeError("scalar loads with a base AND an offset REGISTER in the device code (every such form is banned, also the dword-aligned one; "
+                           "NOTES.md round 5: base + register + immediate loses the low two address bits of each part -- take the run-time index "
+                           "through a VGPR / global load, or index the kernel-argument table another way): " + "; ".join(bad_sload))
     return n
 
 

@@ -653,7 +653,9 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(Gemm
 #pragma clang diagnostic ignored "-Winline-asm"          // (m0 is a reserved register: it is exactly what this instruction takes its LDS address from)
 __device__ __forceinline__ void wg_dma16(const void* gptr, unsigned lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_byte), "v"(gptr) : "memory", "m0");
+    // s_nop 0: a SALU write of M0 followed by an LDS-DMA read of M0 is a GFX9-family hazard that needs one wait state; the compiler's
+    // hazard recogniser does not look inside inline asm, so the wait state is written out (as in sa_rows.hip st16)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_byte), "v"(gptr) : "memory", "m0");
 }
 #pragma clang diagnostic pop
 #define WGDMA_BM 256           // tile rows of every configuration; tile columns: 128 (configuration 0) or 256 (configuration 1)

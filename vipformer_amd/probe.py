@@ -19,8 +19,13 @@ import torch
 
 
 @torch.no_grad()
-def extract_features(pc_model: torch.nn.Module, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], device=None):
-    """pretrain.py:235-249.  batches yield (data [B,N,3], label [B] or [B,1]); returns (feats float64 [n, 2D], labels int64 [n])."""
+def extract_features(pc_model: torch.nn.Module, batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], device=None, trainer=None):
+    """pretrain.py:235-249.  batches yield (data [B,N,3], label [B] or [B,1]); returns (feats float64 [n, 2D], labels int64 [n]).
+    trainer: the train.Pretrainer that owns `pc_model`, if any -- data-parallel, rank 0's BatchNorm running statistics are broadcast
+    first (the reference's eval forwards go through the DDP wrapper, pretrain.py:243,266, which does that in front of every forward
+    pass); EVERY rank must then make this call, as every rank runs the probe loop in the reference."""
+    if trainer is not None:
+        trainer.sync_buffers(0)
     was_training = pc_model.training
     pc_model.eval()
     dev = device if device is not None else next(pc_model.parameters()).device

