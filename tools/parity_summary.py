@@ -17,6 +17,13 @@ CLASSES = [          # (key, regex on the check's label, which contract bound it
     ("grad_deficit_all_ntxent_full_batch", r"^fullsize-train\[.*\] \[NT-Xent loss\] all-parameter gradient deficit \(1 - cos\) vs fp32:"),
     ("grad_deficit_worst_tensor_linear_full_batch", r"^fullsize-train\[.*\] \[linear loss\] worst per-tensor gradient deficit vs fp32:"),
     ("grad_deficit_worst_tensor_ntxent_full_batch", r"^fullsize-train\[.*\] \[NT-Xent loss\] worst per-tensor gradient deficit vs fp32:"),
+    # round 6: against fixtures the imported reference wrote at 64 / 32 / 16 pairs (dropout 0), tests/golden/fullsize_*.npz
+    ("fwd_rel_eval_vs_reference_fixture", r"^fullsize-fixture\[.*\] (pc|img) eval (backbone|feats) rel:"),
+    ("fwd_rel_train_backbone_vs_reference_fixture", r"^fullsize-fixture\[.*\] (pc|img) train backbone rel:"),
+    ("fwd_rel_train_feats_behind_batchnorm_vs_reference_fixture", r"^fullsize-fixture\[.*\] (pc|img) train feats rel:"),
+    ("loss_abs_vs_reference_fixture", r"^fullsize-fixture\[.*\] loss abs diff vs the reference"),
+    ("grad_deficit_all_linear_vs_reference_fixture", r"^fullsize-fixture\[.*\] \[lin\] all-parameter gradient deficit"),
+    ("grad_deficit_all_ntxent_vs_reference_fixture", r"^fullsize-fixture\[.*\] \[ntx\] all-parameter gradient deficit"),
     ("grad_deficit_all_ntxent_golden_batches", r"^dropout-step\[.*\] \[NT-Xent loss\] all-parameter gradient deficit \(1 - cos\) vs fp32:"),
     ("grad_deficit_worst_tensor_ntxent_golden_batches", r"^dropout-step\[.*\] \[NT-Xent loss\] worst per-tensor gradient deficit vs fp32:"),
 ]

@@ -312,8 +312,8 @@ class _PointBackbone(nn.Module):
     """What CrossFormer_pc_mp, CrossFormer_pc_mp_ft and CrossFormer_partseg share (partseg.py:407-425, 527-545): per-point adapter,
     divide_patches, Group2Emb, position MLP, Encoder.  Sub-classes create the members under the reference's names."""
 
-    def backbone(self, pts, _groups=None, _cut=None):
-        return ops.PoolFn.apply(self._encode(pts, (), _groups, _cut)[0])
+    def backbone(self, pts, _groups=None, _cut=None, _after_g2e=None):
+        return ops.PoolFn.apply(self._encode(pts, (), _groups, _cut, _after_g2e)[0])
 
     def _cut_here(self, _cut, *tensors):
         """_cut (a list, trainer extension): the encoder consumes DETACHED copies of its inputs and the (produced, consumed) pairs are
@@ -330,11 +330,12 @@ class _PointBackbone(nn.Module):
             out.append(d)
         return tuple(out)
 
-    def _encode(self, pts, layer_idx=(), _groups=None, _cut=None):
+    def _encode(self, pts, layer_idx=(), _groups=None, _cut=None, _after_g2e=None):
         """Everything up to and including the encoder (partseg.py:527-545 / :407-425) -> (encoder output, group centres).
         _groups (an extension the trainer uses, not part of the reference signature): (neighborhood, center, event) computed by
         divide_patches on ANOTHER stream; the K / V producer -- which needs only the raw points -- is then issued first and this
-        stream waits for the event only in front of Group2Emb, so FPS / kNN (latency-bound, a few workgroups) run beside it."""
+        stream waits for the event only in front of Group2Emb, so FPS / kNN (latency-bound, a few workgroups) run beside it.
+        _after_g2e (trainer extension, experiment VPF_IMG_GATE): called once Group2Emb's forward kernels are queued on this stream."""
         enc = self.encoder
         fuse_kv = (ops.adapter_kv_supported(self.input_adapter, pts) and enc.num_cross_attention_layers == 1 and pts.is_cuda
                    and ops.cfg.sa_fused and ops.cfg.enc_fused and self.training == enc.training)
@@ -355,6 +356,8 @@ class _PointBackbone(nn.Module):
         else:
             neighborhood, center = divide_patches(pts, self.num_groups, self.group_size)
         group_embs = self.group2emb(neighborhood)
+        if _after_g2e is not None:
+            _after_g2e()
         if ops.ca_front_supported(self.position_emb, group_embs, enc) and self.training == enc.training:
             # position MLP + (tokens + pos) + q_norm + q projection of the cross-attention layer in one kernel; the encoder picks up
             # what it needs from a one-shot stash on the layer (and computes it itself if anything about its inputs differs)
@@ -397,8 +400,8 @@ class CrossFormer_pc_mp(_PointBackbone):
         self.latent_head = _latent_head(num_latent_channels)
         ops.assign_sites(self, "pc")          # dropout sites by module name: independent of what else the process built
 
-    def forward(self, pts, _groups=None, _cut=None):
-        backbone_feats = self.backbone(pts, _groups, _cut)
+    def forward(self, pts, _groups=None, _cut=None, _after_g2e=None):
+        backbone_feats = self.backbone(pts, _groups, _cut, _after_g2e)
         feats = ops.HeadFn.apply(backbone_feats, self.latent_head, self.training, *self.latent_head.parameters())
         return feats, backbone_feats
 

@@ -235,8 +235,15 @@ class Pretrainer:
         # Round 4, alternating runs (NOTES.md): with the K / V producer's backward handed to the other stream FROM THE POINT WHERE ITS
         # INPUT GRADIENT EXISTS (ops.KvBwdDeferral.mark_ready) the first placement wins by 0.07 ms -- the forward join is balanced (both
         # branches within 25 us) and so is the end of backward.
-        self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "1") == "1"
+        self.preproc_on_side = os.environ.get("VPF_PREPROC_ON_SIDE", "1") in ("1", "2")
+        # "2" (round 6 experiment): FPS + kNN on a THIRD stream -- the image branch starts at once, the K / V producer runs on the
+        # point-cloud stream, and the sampler's few workgroups run beside both; Group2Emb meets the groups as before
+        self.preproc_own_stream = os.environ.get("VPF_PREPROC_ON_SIDE", "1") == "2"
+        self._pre = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.preproc_own_stream) else None
         self.main_first = os.environ.get("VPF_MAIN_FIRST", "0") == "1"       # measured: no gain in the unmarked step (4.31 vs 4.29 ms), off
+        # experiment: the image branch's encoder held back until Group2Emb's forward is queued on the point-cloud
+        # stream, so that the resident image attention does not run beside adapter_kv_fwd / g2e_fwd_a (NOTES round 6 has the A/B)
+        self.img_gate = os.environ.get("VPF_IMG_GATE", "0") == "1"
         self.timeline = None                 # an ops.Timeline: device timestamps at the branch boundaries (tools/step_timeline.py); None = no marks
         # optional: the point-cloud branch's grouped weight gradients on the image branch's stream behind its backward (ops.WgradDeferral).
         # Measured +0.11 ms/step on MI355X: the two branches already share the CUs for most of the step, the step is bound by the SUM
@@ -354,10 +361,19 @@ class Pretrainer:
             def side_branch():
                 """FPS + kNN grouping and the whole image forward on the side stream.  Returns the groups for the point-cloud branch."""
                 groups = None
+                if self._pre is not None:
+                    from .model.pointcloud.utils import divide_patches
+                    self._pre.wait_stream(main)
+                    with torch.cuda.stream(self._pre):
+                        nb, ct = divide_patches(pc, self.pc_model.num_groups, self.pc_model.group_size)
+                        ev = torch.cuda.Event()
+                        ev.record(self._pre)
+                        nb.record_stream(main); ct.record_stream(main)
+                        groups = (nb, ct, ev)
                 with torch.cuda.stream(self._side):
                     if tl is not None:
                         tl.mark("side.begin")
-                    if self.preproc_on_side:
+                    if self.preproc_on_side and self._pre is None:
                         # FPS + kNN grouping ahead of the image branch on ITS stream (it has ~0.6 ms of slack): the point-cloud
                         # stream starts with the K / V producer, which needs only the raw points, and meets the groups later
                         from .model.pointcloud.utils import divide_patches
@@ -368,8 +384,17 @@ class Pretrainer:
                         groups = (nb, ct, ev)
                         if tl is not None:
                             tl.mark("side.preproc.end")
-                    side_out["img"] = stamp(self.img_model(imgs)[0], "img.fwd.end", "img.bwd.begin")
+                    if not self.img_gate:
+                        side_out["img"] = stamp(self.img_model(imgs)[0], "img.fwd.end", "img.bwd.begin")
                 return groups
+
+            def gated_image_branch():
+                """VPF_IMG_GATE: the image forward, issued from inside the point-cloud model once Group2Emb's kernels are queued."""
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(self._side):
+                    self._side.wait_event(ev)
+                    side_out["img"] = stamp(self.img_model(imgs)[0], "img.fwd.end", "img.bwd.begin")
 
             if tl is not None:
                 tl.mark("pc.fwd.begin")
@@ -379,10 +404,13 @@ class Pretrainer:
                 # other way round the replayed graph started the point-cloud branch only 168 us into the step)
                 feats = stamp(self.pc_model(pc, _groups=side_branch, _cut=cut)[0], "pc.fwd.end", "pc.bwd.begin")
                 if "img" not in side_out:
-                    side_branch()                                   # (a model path that never asked for the groups)
+                    (gated_image_branch if self.img_gate else side_branch)()    # (a model path that never asked for the groups)
             else:
                 groups = side_branch()
-                feats = stamp(self.pc_model(pc, _groups=groups, _cut=cut)[0], "pc.fwd.end", "pc.bwd.begin")
+                feats = stamp(self.pc_model(pc, _groups=groups, _cut=cut, _after_g2e=gated_image_branch if self.img_gate else None)[0],
+                              "pc.fwd.end", "pc.bwd.begin")
+                if "img" not in side_out:
+                    gated_image_branch()                            # (a model path that never reached the hook)
             img_feats = side_out["img"]
             main.wait_stream(self._side)
             img_feats.record_stream(main)
