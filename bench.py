@@ -62,10 +62,10 @@ PEAK_H16_TFLOPS = 2500.0      # MI355X dense h16 MFMA (guide: MI355X_MICROARCH.m
 PEAK_HBM_GBS = 8000.0          # MI355X HBM3E (guide: MI355X_MICROARCH.md)
 # whole-step budgets (tools/collect_step_bytes.sh: kernel trace + FETCH_SIZE + WRITE_SIZE passes of this very command, folded per
 # kernel over the last whole steps): launches per step, in-step average duration, HBM bytes per launch IN THE STEP
-PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r05_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r05_step_bytes_c3.json"),
-                "c4": os.path.join(ROOT, "profiles", "r05_step_bytes_c4.json"), "ref144": os.path.join(ROOT, "profiles", "r05_step_bytes_ref144.json"),
-                "ref144m4": os.path.join(ROOT, "profiles", "r05_step_bytes_ref144m4.json")}
-PROFILE_PMC = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels (tools/collect_profiles.sh)
+PROFILE_STEP = {"c2": os.path.join(ROOT, "profiles", "r06_step_bytes.json"), "c3": os.path.join(ROOT, "profiles", "r06_step_bytes_c3.json"),
+                "c4": os.path.join(ROOT, "profiles", "r06_step_bytes_c4.json"), "ref144": os.path.join(ROOT, "profiles", "r06_step_bytes_ref144.json"),
+                "ref144m4": os.path.join(ROOT, "profiles", "r06_step_bytes_ref144m4.json")}
+PROFILE_PMC = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")      # stand-alone MFMA-busy counters of the attention kernels (tools/collect_profiles.sh)
 
 
 def synth_batch(b, N, img, seed, device, dups=False):
@@ -201,6 +201,19 @@ def kernel_legs(device, a, pairs):
                                            f"{len(stack_shapes)} weight gradients of the point-cloud encoder stack in ONE launch (what the step "
                                            f"launches), {M} tokens: operands read once + dW written once; LDS-DMA staging (round 5); eager timing, "
                                            f"host-bound by its 28 job descriptors: the device-side duration is in profiles/r05_wgrad_dma_ab.txt")
+    # ---- the single split-K weight gradients of Group2Emb's tail: rows = every member of every group
+    #      dW3[:, 128:] = dh3^T h2 goes to the LDS-DMA kernel (one 256 x 128 tile, 256 slices with a ramp of slice lengths);
+    #      conv2's dW = dh2^T a1 (128 x 64: N_out is not a multiple of 128) stays on gemm_kernel<1,1,2,2,128,true,true> -- the largest launch
+    #      left on that symbol (the other seven are 5 - 22 us: head, patch embedding, dW3[:, :128])
+    Mg = B * G * K
+    for key, kern, Nn, Kk, why in (("gemm_wgrad_dma_kernel (Group2Emb dW3[:,128:])", "gemm_wgrad_dma_kernel", 256, 128, "dh3^T h2, one 256 x 128 tile, 256 K slices"),
+                                   ("gemm_kernel TN split-K (Group2Emb conv2 dW)", "gemm_kernel<1, 1, 2, 2, 128, true, true>", 128, 64, "dh2^T a1, 64 x 64 tiles, split over the rows")):
+        dy = torch.randn(Mg, Nn, generator=g).to(device).to(H16); x = torch.randn(Mg, Kk, generator=g).to(device).to(H16)
+        dW = torch.zeros(Nn, Kk, device=device); db = torch.zeros(Nn, device=device)
+        us = _events(lambda: ops.linear_wgrad(dy, x, Nn, Kk, dW, db), 20, 3)
+        legs[key] = _leg(kern, us, 2.0 * Mg * (Nn + Kk) + 4.0 * Nn * Kk, 2.0 * Mg * Nn * Kk, "hbm",
+                         f"{why}: {Mg} rows x {Nn} x {Kk}; operands read once ({2.0 * Mg * (Nn + Kk) / 1e6:.0f} MB) + dW")
+        del dy, x
     # ---- fused encoder-layer tail (o_proj .. MLP .. next layer's LayerNorm + q/k/v): 9232 B and 2*256*2048 flop per token at D = 256
     layers = nn.ModuleList([SelfAttentionLayer(H, D, a["MR"], 0.0, 0.1, 0.5) for _ in range(2)]).to(device)
     layers.train()
@@ -313,6 +326,12 @@ def _tolerances():
             "grad_cos_all": {"linear_loss": gc("grad_deficit_all_linear_full_batch"), "ntxent_loss": gc("grad_deficit_all_ntxent_full_batch")},
             "grad_cos_worst_tensor": {"linear_loss": gc("grad_deficit_worst_tensor_linear_full_batch"),
                                       "ntxent_loss": gc("grad_deficit_worst_tensor_ntxent_full_batch")},
+            "vs_reference_fixture_64_32_16_pairs": {
+                "fwd_rel_l2_eval": g("fwd_rel_eval_vs_reference_fixture"), "fwd_rel_l2_train_backbone": g("fwd_rel_train_backbone_vs_reference_fixture"),
+                "fwd_rel_l2_behind_batchnorm_head": g("fwd_rel_train_feats_behind_batchnorm_vs_reference_fixture"),
+                "loss_abs": g("loss_abs_vs_reference_fixture"),
+                "grad_cos_all": {"linear_loss": gc("grad_deficit_all_linear_vs_reference_fixture"),
+                                 "ntxent_loss": gc("grad_deficit_all_ntxent_vs_reference_fixture")}},
             "failing_checks": m.get("failing_checks"),
         }
     except (OSError, ValueError, KeyError, IndexError):
@@ -334,6 +353,8 @@ PROFILE_NAMES = {   # leg key -> kernel-name substrings of the whole-step budget
     "gemm_wgrad_group_kernel": ["gemm_wgrad_dma_kernel"],                  # the stack-sized leg: the launch the step makes (round 5: the LDS-DMA kernel; its in-step
                                                                            # average also covers the K / V projection's and Group2Emb's dW3 launches of that kernel)
     "gemm_wgrad_group_kernel (one layer)": [],                             # (no such launch in the step: stand-alone figures only)
+    "gemm_wgrad_dma_kernel (Group2Emb dW3[:,128:])": [],                    # (shares its symbol with the stack launch: stand-alone figures only)
+    "gemm_kernel TN split-K (Group2Emb conv2 dW)": ["gemm_kernel<1, 1, 2, 2, 128, true, true"],       # in-step: the average over all 8 launches of the symbol
     "sa_layer_fwd_kernel": ["sa_layer_fwd_kernel", "sa_rows_fwd_kernel"],
     "sa_bwd_qkv_mlp_rows_kernel": ["sa_bwd_qkv_mlp_rows_kernel"],
     "attn_fwd_kernel (cross-attention pc)": ["attn_fwd_kernel<3, 128,", "attn_fwd_kernel<4, 128,"],
