@@ -44,3 +44,20 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _history_independent_random_state(request):
+    """Every GPU test starts from ITS OWN fixed random state -- torch's generators (FPS start indices, torch.randn inputs) and the
+    library's device-resident dropout state -- derived from the test's node id, so that a test's masks and inputs do not depend on which
+    tests ran before it (round 6: re-ordering the suite moved `test_pretrainer_at_the_default_loss_scale_backs_off_and_trains` onto
+    a marginal realisation of its 2-pair dropout masks, and it failed once in three suites).  Tests that seed explicitly are unaffected."""
+    if "gpu" in request.keywords:
+        import zlib
+        import torch
+        if torch.cuda.is_available():
+            from vipformer_amd import ops
+            h = zlib.crc32(request.node.nodeid.encode())
+            torch.manual_seed(h)
+            ops.rng.seed(0x5EED0000 + h)
+    yield

@@ -448,6 +448,43 @@ def make_partseg(names=("tinyseg", "c3")):
         save(f"partseg_{name}.npz", **res)
 
 
+def make_partseg_full(name="c3", B=16):
+    """BASELINE configs[4] at ITS batch: CrossFormer_partseg on the configs[2] backbone, 16 clouds of 1024 points (parser.py's fine-tune
+    defaults; bench.py --arch c5) through the imported reference -> fullsize_partseg_<name>.npz: eval / train logits (slices; the head's
+    Dropout(0.5) patched to 0 as in make_partseg), the label-smoothed cross entropy of ft_partseg.py:128, and the gradient of THAT loss for
+    every parameter (norm + strided sample, helpers.grad_sample) -- what one fine-tune step backpropagates."""
+    NPART = 50
+    a = Hh.ARCHS[name]
+    lidx = Hh.PARTSEG_LAYERS[name]
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ad = PointCloudInputAdapter((a["N"], 3), a["D"])
+    m = RP.CrossFormer_partseg(ad, a["G"], a["D"], a["K"], 1, a["H"], a["S"], a["H"], a["MR"], 0.0, 0.0, 0.0, lidx, NPART)
+    m.load_state_dict(Hh.synth_state_dict(Hh.load_keyshapes(f"keys_partseg_{name}.json"), 100))
+    pts, start, cls, target = Hh.partseg_inputs(name, B, 940)
+    res = {"meta": np.array([B, 940])}
+    RU.knn_point = canonical_knn
+    m.eval()
+    with torch.no_grad(), forced_start(start):
+        res["eval_logits"] = m(pts, cls)[:, :64].clone()
+    m.train(); m.zero_grad()
+    m.dp1.p = 0.0
+    with forced_start(start):
+        y = m(pts, cls)
+    res["train_logits"] = y[:, :64].clone()
+    loss = torch.nn.CrossEntropyLoss(label_smoothing=0.2)(y.reshape(-1, NPART), target.reshape(-1))
+    res["ce_loss"] = np.array([loss.item()])
+    loss.backward()
+    names_ = json.load(open(os.path.join(HERE, f"grad_names_partseg_{name}.json")))
+    params = dict(m.named_parameters())
+    res["grad_norms"] = np.array([params[k].grad.double().norm().item() for k in names_])
+    res["grad_samples"] = torch.cat([Hh.grad_sample(params[k].grad) for k in names_])
+    for k in ("bn1.running_mean", "bn1.running_var", "propagation.mlp_bns.1.running_var", "label_conv.1.running_var"):
+        res["buf." + k] = m.state_dict()[k].clone()
+    RU.knn_point = _orig_knn
+    save(f"fullsize_partseg_{name}.npz", **res)
+
+
 def make_augment():
     """datasets/data.py:16-25 (trans_1) run with the reference's own data_utils.py classes (loaded by file path: the datasets
     package itself imports h5py / torchvision) under np.random.seed / torch.manual_seed -> augment_trans1.npz."""
@@ -568,6 +605,8 @@ if __name__ == "__main__":
         make_ca2()
     elif len(sys.argv) > 1 and sys.argv[1] == "fullsize":        # python make_golden.py fullsize [c1 c3 c4]
         make_fullsize(tuple(sys.argv[2:]) or ("c1", "c3", "c4"))
+    elif len(sys.argv) > 1 and sys.argv[1] == "partseg_full":
+        make_partseg_full()
     elif len(sys.argv) > 2 and sys.argv[1] == "models":        # python make_golden.py models c3 c4
         main(only_models=tuple(sys.argv[2:]))
     else:
@@ -578,3 +617,4 @@ if __name__ == "__main__":
         make_ckpt()
         make_ca2()
         make_fullsize()
+        make_partseg_full()

@@ -157,5 +157,15 @@ def grad_sample(g: torch.Tensor, cap: int = GRAD_SAMPLE) -> torch.Tensor:
     return flat[::max(1, n // cap)][:cap].float().cpu().clone()
 
 
+def partseg_inputs(name: str, B: int, seed: int):
+    """Inputs of a part-segmentation fixture: clouds, FPS start indices, one-hot object labels (16 classes), per-point part targets (50)."""
+    a = ARCHS[name]
+    pts = synth_points(seed, B, a["N"]); start = synth_start(seed, B, a["N"])
+    cls = torch.zeros(B, 16)
+    cls[torch.arange(B), torch.arange(B) % 16] = 1.0
+    target = torch.from_numpy((np.random.default_rng(seed + 1).random((B, a["N"])) * 50).astype(np.int64))
+    return pts, start, cls, target
+
+
 # CrossFormer_partseg taps (1-based self-attention layer numbers; the reference needs 3 or 4 of them, partseg.py:430-435)
 PARTSEG_LAYERS = {"tinyseg": [1, 2, 3], "c3": [2, 5, 8]}

@@ -239,12 +239,16 @@ def test_pretrainer_loss_scale_backs_off_on_overflow_inside_the_captured_graph()
 
 def test_pretrainer_at_the_default_loss_scale_backs_off_and_trains():
     """every other test pins VPF_LOSS_SCALE to 256 (tests/conftest.py).  Here the trainer starts at GradScaler's DEFAULT
-    65 536 on a 2-pair batch, whose per-sample gradients overflow fp16 at that scale (measured: 5 skipped steps, scale 2 048; 4 pairs: 1;
-    8 pairs: none): the first replays of the captured graph are skipped
-    (parameters untouched), the scale halves once per skipped step inside the graph, then the steps train -- parameters move, the
-    loss falls, `loss_scale` == 65 536 / 2 ** skipped_steps."""
+    65 536 on a 2-pair batch, whose per-sample gradients overflow fp16 at that scale (measured: 4 - 7 skipped steps, scale 512 - 4 096;
+    4 pairs: 1; 8 pairs: none): the first replays of the captured graph are skipped (parameters untouched), the scale halves once per
+    skipped step inside the graph, then the steps train -- parameters move, the loss falls, `loss_scale` == 65 536 / 2 ** skipped_steps.
+    "The loss falls" on TWO pairs under dropout 0.5 is a statement about means: single replays of the trained model scatter between
+    0.4 and 5.6 (tools/diag_train_margin.py, 12 dropout seeds: the old `losses[-1] < losses[0] - 0.5` held for 9 of them and failed on
+    the round-6 driver rehearsal once in three suites) -- compared are the mean over the SKIPPED replays (all at the initial weights,
+    different masks: 3.3 - 4.9) and the mean of the last eight (1.8 - 3.3; smallest difference over the 12 seeds 0.67).  The dropout
+    state is seeded per test (tests/conftest.py), so the masks do not depend on which tests ran before."""
     from vipformer_amd.train import Pretrainer
-    pc, im, a = build("tiny", (0.1, 0.5))
+    pc, im, a = build("tiny", (0.1, 0.5))                   # (tests/conftest.py seeds the dropout state per test)
     pc.train(); im.train()
     tr = Pretrainer(pc, im, loss_scale=65536.0, growth_interval=1000)
     t1, t2, imgs, start = _batch(a, 2)
@@ -259,7 +263,8 @@ def test_pretrainer_at_the_default_loss_scale_backs_off_and_trains():
     assert tr.loss_scale == 65536.0 * 0.5 ** sk
     assert float(tr.hyper[6]) == 40 - sk                                   # AdamW counted the good steps only
     assert not torch.equal(tr.flat.p, p0) and torch.isfinite(tr.flat.p).all().item()
-    assert all(l == l for l in losses) and losses[-1] < losses[0] - 0.5, (losses[0], losses[-1], sk)
+    at_start, at_end = sum(losses[:sk]) / sk, sum(losses[-8:]) / 8
+    assert all(l == l for l in losses) and at_end < at_start - 0.3, (at_start, at_end, sk, losses)
 
 
 def test_reference_loop_with_torch_gradscaler_and_autocast_trains():

@@ -241,6 +241,39 @@ def test_finetune_classifier_vs_reference(name):
     np.testing.assert_allclose(norms, g["head_grad_norms"], rtol=2e-3, atol=1e-5)
 
 
+def test_partseg_oracle_at_the_finetune_batch_vs_reference():
+    """BASELINE configs[4] at its batch (16 clouds of 1024 points on the configs[2] backbone; fixture: make_golden.py make_partseg_full,
+    written by the imported reference): eval / train logits, the label-smoothed cross entropy and the gradient of THAT loss for every
+    parameter (norms + strided samples)."""
+    name = "c3"
+    arch, a = _arch(name)
+    g = Hh.golden(f"fullsize_partseg_{name}.npz")
+    B = int(g["meta"][0])
+    pts, start, cls, target = Hh.partseg_inputs(name, B, int(g["meta"][1]))
+    lidx = Hh.PARTSEG_LAYERS[name]
+    sd = Hh.synth_state_dict(Hh.load_keyshapes(f"keys_partseg_{name}.json"), 100)
+    with torch.no_grad():
+        _close(O.partseg_forward(sd, pts, start, cls, arch, lidx, False)[:, :64], g["eval_logits"], 2e-4, 2e-4)
+    names = json.load(open(os.path.join(Hh.GOLDEN_DIR, f"grad_names_partseg_{name}.json")))
+    hp = {k: sd[k].clone().requires_grad_() for k in names}
+    sd2 = dict(sd); sd2.update(hp)
+    for k in list(sd2):
+        if "cross_attn_1." in k:
+            sd2[k] = sd2[k.replace("cross_attn_1.", "cross_attn_n.")]
+    keep_all = torch.full((B * a["N"], 512), 0.5)               # the fixture ran the head's Dropout(0.5) at p = 0: keep * 2 == 1
+    y = O.partseg_forward(sd2, pts, start, cls, arch, lidx, True, O.Masks("off"), {}, head_mask=keep_all)
+    _close(y[:, :64], g["train_logits"], 5e-4, 5e-4)
+    loss = torch.nn.functional.cross_entropy(y.reshape(-1, 50), target.reshape(-1), label_smoothing=0.2)
+    assert abs(loss.item() - float(g["ce_loss"][0])) < 1e-5
+    loss.backward()
+    zero = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)
+    norms = np.array([zero(hp[k]).double().norm().item() for k in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=5e-3, atol=1e-5 * g["grad_norms"].max())
+    smp = torch.cat([Hh.grad_sample(zero(hp[k])) for k in names]).double()
+    ref = torch.from_numpy(g["grad_samples"]).double()
+    assert float(smp @ ref / (smp.norm() * ref.norm())) > 1 - 1e-6
+
+
 def _partseg_inputs(name):
     a = Hh.ARCHS[name]
     B = Hh.MODEL_BATCH[name]
