@@ -397,3 +397,31 @@ def test_pad_mask_vs_reference():
     for k in g.files:
         if k.startswith("enc_g."):
             _close(sd[k[6:]].grad, g[k], 1e-4, 2e-3)
+
+
+def test_ntxent_restatement_vs_the_published_formula_and_closed_forms():
+    """NT-Xent is PARITY-UNPINNED (lightly==1.1.21 is absent from the image and from /root/reference: SURVEY 8a row 17).  What can be
+    checked without it: (1) the oracle's vectorised restatement (mask the diagonal, cross entropy over 2b - 1 logits) against the SimCLR
+    paper's equation written out sample by sample in float64 -- l(i, j) = -log(exp(s_ij / T) / sum_{k != i} exp(s_ik / T)), mean over the
+    2b ordered positive pairs, s = cosine similarity; (2) closed forms: b mutually orthogonal pairs with identical views give
+    -log(e^{1/T} / (e^{1/T} + 2b - 2)); all 2b embeddings identical give log(2b - 1) (every negative ties with the positive)."""
+    import math
+    T = 0.1
+    g = torch.Generator().manual_seed(5)
+    for b, d in ((2, 8), (5, 16), (64, 256)):
+        z0, z1 = torch.randn(b, d, generator=g), torch.randn(b, d, generator=g) * 3.0 + 0.5
+        z = torch.cat([z0, z1]).double()
+        z = z / z.norm(dim=1, keepdim=True)
+        s = (z @ z.t()) / T
+        tot = 0.0
+        for i in range(2 * b):
+            j = (i + b) % (2 * b)
+            den = sum(math.exp(float(s[i, k])) for k in range(2 * b) if k != i)
+            tot += -math.log(math.exp(float(s[i, j])) / den)
+        assert abs(O.ntxent(z0, z1, T).item() - tot / (2 * b)) < 2e-5 * max(1.0, abs(tot / (2 * b)))
+    for b in (2, 7, 32):
+        e = torch.eye(b, 2 * b)                                   # b orthonormal directions, the two views identical
+        want = -math.log(math.exp(1 / T) / (math.exp(1 / T) + 2 * b - 2))
+        assert abs(O.ntxent(e, e.clone(), T).item() - want) < 1e-5 * max(1.0, want)
+        same = torch.ones(b, 4)
+        assert abs(O.ntxent(same, same.clone(), T).item() - math.log(2 * b - 1)) < 1e-5
