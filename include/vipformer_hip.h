@@ -333,9 +333,11 @@ typedef struct VpfWgradJob { const void* dy; const void* x; int M, N, K; float* 
  * zeroed ONCE by the caller (arrival counters; the kernel leaves them zero), private to the stream: with it the split-K slices
  * exchange their partial tiles through the workspace and the last-arriving slice of a tile writes dW -- no atomics on dW;
  * without it (or if it is too small) fp32 atomics as before. */
-/* Round 5: problems that are multiples of 256 (N_out) x 128 (K_in) x 64 tokens and have at least VPF_WGROUP_DMA (default 2048) tokens
- * run the LDS-DMA kernel (csrc/gemm.hip: gemm_wgrad_dma_kernel) when no workspace is given; a group that holds both kinds becomes two
- * launches on `stream`.  Same results up to the order of the fp32 atomics. */
+/* Round 5: problems with N_out % 128 == 0, K_in % 128 == 0, tokens % 64 == 0 and at least VPF_WGROUP_DMA (default 2048) tokens run the
+ * LDS-DMA kernel (csrc/gemm.hip: gemm_wgrad_dma_kernel) when no workspace is given: 256 x 128 tiles when EVERY conforming problem of the
+ * group has N_out % 256 == 0, otherwise the whole DMA group runs on 128 x 128 tiles (one N_out that is a multiple of 128 only -- D = 384
+ * -- moves all of them); a group that holds conforming and non-conforming problems becomes two launches on `stream`.  Same results up
+ * to the order of the fp32 atomics. */
 int vpf_wgrad_group(const VpfWgradJob* host_jobs, int njobs, void* ws, long ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ fused self-attention layer

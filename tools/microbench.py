@@ -345,7 +345,9 @@ def gemmk():
 
 def gemmtn():
     """the single weight-gradient GEMMs of the step (dW[N,K] += dY^T X over M rows, split over M, fp32 atomics) per tile configuration:
-    VPF_WGRAD_CFG 0 = 64x64, 1 = 128x64, 2 = 128x128; and per split (0 = the launcher's own choice)"""
+    VPF_WGRAD_CFG 0 = 64x64, 1 = 128x64, 2 = 128x128; and per split (0 = the launcher's own choice).  The cfg sweep runs with the LDS-DMA
+    kernel OFF (wgroup_dma = 0: at splitk 0 a conforming shape would otherwise take gemm_wgrad_dma_kernel whatever cfg says and the
+    three columns would time the same kernel -- ADVICE r05); the DMA kernel gets a column of its own."""
     from vipformer_amd import _lib as L
     from vipformer_amd import ops
     shapes = [("g2e dW3[:,128:] = dh3^T h2", 393216, 256, 128), ("g2e conv2 dW = dh2^T a1", 393216, 128, 64),
@@ -355,12 +357,17 @@ def gemmtn():
         dy = torch.randn(M, N, device="cuda").to(H16); x = torch.randn(M, K, device="cuda").to(H16)
         dW = torch.zeros(N, K, device="cuda")
         line = f"{name:38s} M={M:6d} N={N:3d} K={K:3d}:"
+        dma_before = L.debug_get("wgroup_dma")
+        t = timeit(lambda: ops.gemm(dy, 1, N, x, 1, K, N, K, M, dW, K, c_f32=True, mode=ops.EPI_ATOMIC, splitk=0), 20, 3)
+        line += f"  shipped (DMA kernel where the shape conforms) {t:6.1f} |"
+        L.debug_set("wgroup_dma", 0)
         for cfg in (0, 1, 2):
             L.debug_set("wgrad_cfg", cfg)
             for sk in (0,) + ((128, 512) if M > 100000 else (16, 32)):
                 t = timeit(lambda: ops.gemm(dy, 1, N, x, 1, K, N, K, M, dW, K, c_f32=True, mode=ops.EPI_ATOMIC, splitk=sk), 20, 3)
                 line += f"  cfg{cfg}/sk{sk} {t:6.1f}"
         L.debug_set("wgrad_cfg", 0)
+        L.debug_set("wgroup_dma", dma_before)
         gb = M * (N + K) * 2 / 1e9
         print(line + f"   us   ({gb * 1e3:.0f} MB: {gb / 6.3e3 * 1e6:.1f} us at 6.3 TB/s)")
 

@@ -648,7 +648,9 @@ __global__ void __launch_bounds__(PAIR ? 512 : 256) gemm_wgrad_group_kernel(Gemm
 //     every wave waits for ITS OWN copies of stage kt (s_waitcnt vmcnt(PER): the next stage's PER copies may stay in flight; vmcnt
 //     retires in order), one s_barrier (all waves' copies have landed, all waves are done with stage kt - 1), the copies of stage
 //     kt + 2 go into stage kt - 1's buffer, then the products of stage kt.
-// Conforming problems only (the launcher checks): M % 256 == 0, N % 128 == 0, K % 64 == 0, 16-byte aligned operands, atomics flush.
+// Conforming problems only (wgrad_dma_conforms; in THIS kernel's names M = N_out rows of dW, N = K_in columns, K = tokens):
+// N_out % 128 == 0, K_in % 128 == 0, tokens % 64 == 0, 16-byte aligned operands, atomics flush.  Tile rows: 256 when every problem of the
+// launch has N_out % 256 == 0, else 128 for the WHOLE launch (TM = 1: one N_out that is a multiple of 128 only moves all of them).
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"          // (m0 is a reserved register: it is exactly what this instruction takes its LDS address from)
 __device__ __forceinline__ void wg_dma16(const void* gptr, unsigned lds_byte)
